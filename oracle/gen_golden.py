@@ -1,0 +1,421 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (Sample Factory at /root/reference) on seeded inputs.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (the reference is not present on the GPU box); the
+produced fixtures are committed.  Usage:  python -m oracle.gen_golden   (from the repo root)
+
+Every fixture stores the exact inputs handed to the reference function and the outputs it returned; the
+reference entry point exercised is named in the `ref` field of each file.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import ref_import  # noqa: F401  (installs stubs, adds /root/reference to sys.path)
+from oracle.weights import seeded_state  # our deterministic weight generator (shared with tests)
+
+import gymnasium as gym  # the stub
+from sample_factory.algo.learning.learner import Learner
+from sample_factory.algo.utils.action_distributions import (
+    CategoricalActionDistribution,
+    ContinuousActionDistribution,
+    get_action_distribution,
+)
+from sample_factory.algo.utils.env_info import EnvInfo
+from sample_factory.algo.utils.model_sharing import ParameterServer
+from sample_factory.algo.utils.rl_utils import gae_advantages
+from sample_factory.algo.utils.running_mean_std import RunningMeanStdInPlace
+from sample_factory.algo.utils.shared_buffers import alloc_trajectory_tensors
+from sample_factory.algo.utils.tensor_dict import clone_tensordict
+from sample_factory.cfg.arguments import parse_full_cfg, parse_sf_args
+from sample_factory.model.model_utils import get_rnn_size
+from sample_factory.utils.attr_dict import AttrDict
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+torch.set_num_threads(1)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def make_cfg(extra):
+    argv = ["--algo=APPO", "--env=synthetic", "--experiment=golden", "--train_dir=/tmp/sf_golden", "--device=cpu",
+            "--serial_mode=True", "--use_rnn=False", "--recurrence=1", "--seed=0"] + list(extra)
+    parser, _ = parse_sf_args(argv)
+    return parse_full_cfg(parser, argv)
+
+
+def make_learner(cfg, obs_space, action_space, num_agents):
+    env_info = EnvInfo(obs_space, action_space, num_agents, True, True, None, None, 1)
+    pv = torch.zeros([1], dtype=torch.int32)
+    ps = ParameterServer(0, pv, True)
+    learner = Learner(cfg, env_info, pv, 0, ps)
+    learner.init()
+    return learner, env_info
+
+
+def load_seeded(actor_critic, seed):
+    """Overwrite trainable parameters with our seeded generator so that tests can regenerate them."""
+    shapes = [(k, tuple(v.shape)) for k, v in actor_critic.named_parameters()]
+    st = seeded_state(shapes, seed)
+    with torch.no_grad():
+        for k, p in actor_critic.named_parameters():
+            p.copy_(torch.from_numpy(st[k]))
+    return shapes
+
+
+def fill_batch(b, g, A, continuous=False, p_done=0.1, p_timeout=0.0, p_other_policy=0.0, versions=None):
+    for k, v in b["obs"].items():
+        if v.dtype == torch.uint8:
+            v.copy_(torch.randint(0, 256, v.shape, generator=g, dtype=torch.uint8))
+        else:
+            v.copy_(torch.randn(v.shape, generator=g))
+    b["rnn_states"].zero_()
+    if continuous:
+        b["actions"].copy_(torch.randn(b["actions"].shape, generator=g))
+    else:
+        b["actions"].copy_(torch.randint(0, A, b["actions"].shape, generator=g).float())
+    b["action_logits"].copy_(torch.randn(b["action_logits"].shape, generator=g) * 0.5)
+    b["log_prob_actions"].copy_(-torch.rand(b["log_prob_actions"].shape, generator=g) * 2.0 - 0.5)
+    b["values"].copy_(torch.randn(b["values"].shape, generator=g))
+    b["rewards"].copy_(torch.randn(b["rewards"].shape, generator=g))
+    b["dones"].copy_(torch.rand(b["dones"].shape, generator=g) < p_done)
+    b["time_outs"].copy_((torch.rand(b["dones"].shape, generator=g) < p_timeout) & b["dones"])
+    b["policy_id"].zero_()
+    if p_other_policy > 0:
+        other = torch.rand(b["policy_id"].shape, generator=g) < p_other_policy
+        b["policy_id"][other] = -1
+    if versions is None:
+        b["policy_version"].zero_()
+    else:
+        b["policy_version"].copy_(torch.randint(versions[0], versions[1], b["policy_version"].shape, generator=g).float())
+    b["valids"].fill_(False)
+
+
+def batch_arrays(b, prefix="in_"):
+    out = {}
+    for k, v in b.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                out[f"{prefix}obs_{kk}"] = vv.numpy().copy()
+        else:
+            out[prefix + k] = v.numpy().copy()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- GAE
+def gen_gae():
+    g = torch.Generator().manual_seed(100)
+    arrays = {"ref": "sample_factory/algo/utils/rl_utils.py:78-94 gae_advantages"}
+    cases = [(5, 7, 0.99, 0.95, 0.15, 0.0), (64, 32, 0.99, 0.95, 0.05, 0.1), (33, 128, 0.997, 0.9, 0.02, 0.3),
+             (1, 1, 0.9, 1.0, 0.5, 0.0), (128, 32, 0.99, 0.95, 0.0, 0.0)]
+    arrays["num_cases"] = len(cases)
+    for i, (E, T, gamma, lam, p_done, p_inv) in enumerate(cases):
+        rewards = torch.randn(E, T, generator=g)
+        dones = torch.rand(E, T, generator=g) < p_done
+        values = torch.randn(E, T + 1, generator=g)
+        valids = torch.rand(E, T + 1, generator=g) >= p_inv
+        valids[:, -1] = valids[:, -2]
+        adv = gae_advantages(rewards.clone(), dones.clone(), values.clone(), valids.clone(), gamma, lam)
+        arrays.update({f"c{i}_rewards": rewards.numpy(), f"c{i}_dones": dones.numpy(), f"c{i}_values": values.numpy(),
+                       f"c{i}_valids": valids.numpy(), f"c{i}_gamma": gamma, f"c{i}_lambda": lam,
+                       f"c{i}_adv": adv.contiguous().numpy()})
+    save("gae", **arrays)
+
+
+# ------------------------------------------------------------------------------------------------- RMS
+def gen_rms():
+    g = torch.Generator().manual_seed(200)
+    rms = RunningMeanStdInPlace((1,))
+    rms.train()
+    arrays = {"ref": "sample_factory/algo/utils/running_mean_std.py:22-110 RunningMeanStdInPlace((1,))"}
+    sizes = [64, 1000, 3, 4096]
+    arrays["num_steps"] = len(sizes)
+    for i, n in enumerate(sizes):
+        x = torch.randn(n, generator=g) * (2.0 + i) + (i - 1.5)
+        if i == 2:
+            x = x * 100.0  # exercise the +-5 clip
+        arrays[f"s{i}_x"] = x.numpy().copy()
+        y = x.clone()
+        rms(y)
+        arrays[f"s{i}_normalized"] = y.numpy().copy()
+        arrays[f"s{i}_stats"] = np.array([rms.running_mean.item(), rms.running_var.item(), rms.count.item()])
+        z = (torch.randn(n, generator=g) * 3.0)
+        arrays[f"s{i}_z"] = z.numpy().copy()
+        zz = z.clone()
+        rms(zz, denormalize=True)
+        arrays[f"s{i}_denormalized"] = zz.numpy().copy()
+    rms.eval()
+    x = torch.randn(50, generator=g)
+    y = x.clone()
+    rms(y)
+    arrays["eval_x"], arrays["eval_normalized"] = x.numpy(), y.numpy()
+    arrays["eval_stats"] = np.array([rms.running_mean.item(), rms.running_var.item(), rms.count.item()])
+    save("rms", **arrays)
+
+
+# ------------------------------------------------------------------------------------------------- distributions
+def gen_action_dist():
+    g = torch.Generator().manual_seed(300)
+    arrays = {"ref": "sample_factory/algo/utils/action_distributions.py:99-194,290-323; "
+                     "known answers tests/algo/test_action_distributions.py:142-162"}
+    # the reference test's known answer: softmax([0,1,2])
+    logits = torch.tensor([[0.0, 1.0, 2.0]])
+    d = CategoricalActionDistribution(logits)
+    arrays["ka_logits"], arrays["ka_probs"] = logits.numpy(), d.probs.numpy()
+    arrays["ka_entropy"] = d.entropy().numpy()
+    for i, (N, A, scale) in enumerate([(31, 6, 1.0), (257, 18, 4.0), (64, 2, 10.0)]):
+        z = torch.randn(N, A, generator=g) * scale
+        zo = torch.randn(N, A, generator=g) * scale
+        act = torch.randint(0, A, (N, 1), generator=g).float()
+        d, do = CategoricalActionDistribution(z), CategoricalActionDistribution(zo)
+        arrays.update({f"cat{i}_logits": z.numpy(), f"cat{i}_old_logits": zo.numpy(), f"cat{i}_actions": act.numpy(),
+                       f"cat{i}_log_probs": d.log_probs.numpy(), f"cat{i}_probs": d.probs.numpy(),
+                       f"cat{i}_entropy": d.entropy().numpy(), f"cat{i}_log_prob_actions": d.log_prob(act).numpy(),
+                       f"cat{i}_kl": d.kl_divergence(do).numpy(),
+                       f"cat{i}_symkl_uniform": d.symmetric_kl_with_uniform_prior().numpy(),
+                       f"cat{i}_argmax": torch.argmax(d.probs, dim=-1).numpy()})
+    arrays["num_cat"] = 3
+    for i, (N, D) in enumerate([(40, 8), (7, 1)]):
+        p = torch.randn(N, 2 * D, generator=g)
+        po = torch.randn(N, 2 * D, generator=g)
+        act = torch.randn(N, D, generator=g)
+        d, do = ContinuousActionDistribution(p), ContinuousActionDistribution(po)
+        arrays.update({f"con{i}_params": p.numpy(), f"con{i}_old_params": po.numpy(), f"con{i}_actions": act.numpy(),
+                       f"con{i}_log_prob_actions": d.log_prob(act).numpy(), f"con{i}_entropy": d.entropy().numpy(),
+                       f"con{i}_kl": d.kl_divergence(do).numpy()})
+    arrays["num_con"] = 2
+    save("action_dist", **arrays)
+
+
+# ------------------------------------------------------------------------------------------------- learner
+MLP_OBS = gym.spaces.Dict({"obs": gym.spaces.Box(-10, 10, (8,), np.float32)})
+MLP_ARGS = ["--encoder_mlp_layers", "32", "32", "--nonlinearity=tanh", "--normalize_input=False"]
+
+
+def capture_heads(learner):
+    """Forward hooks that keep the loss-head inputs (action params, values) and let autograd retain their grads."""
+    cap = {}
+
+    def hook(name):
+        def f(_m, _inp, out):
+            out.retain_grad()
+            cap[name] = out
+        return f
+
+    h1 = learner.actor_critic.action_parameterization.distribution_linear.register_forward_hook(hook("params"))
+    h2 = learner.actor_critic.critic_linear.register_forward_hook(hook("values"))
+    return cap, (h1, h2)
+
+
+def gen_prepare_and_losses():
+    variants = [
+        dict(name="ff_default", args=[], E=16, T=8, A=6, fill={}),
+        dict(name="ff_invalids", args=["--max_policy_lag=5", "--kl_loss_coeff=0.2"], E=16, T=8, A=6,
+             fill=dict(p_other_policy=0.2, versions=(90, 100)), train_step=100),
+        dict(name="ff_bootstrap_nonorm", args=["--normalize_returns=False", "--value_bootstrap=True",
+                                                "--exploration_loss=symmetric_kl", "--exploration_loss_coeff=0.01"],
+             E=12, T=16, A=4, fill=dict(p_timeout=0.5, p_done=0.2)),
+        dict(name="ff_continuous", args=["--kl_loss_coeff=0.1", "--exploration_loss_coeff=0.002"], E=10, T=8, A=None,
+             D=3, fill={}),
+        dict(name="ff_vtrace", args=["--with_vtrace=True", "--normalize_returns=False", "--recurrence=8",
+                                      "--vtrace_rho=0.9", "--vtrace_c=0.8"], E=12, T=8, A=5, fill={}),
+    ]
+    for vi, var in enumerate(variants):
+        E, T = var["E"], var["T"]
+        continuous = var.get("A") is None
+        action_space = gym.spaces.Box(-1, 1, (var["D"],), np.float32) if continuous else gym.spaces.Discrete(var["A"])
+        nb = 2
+        cfg = make_cfg(MLP_ARGS + [f"--rollout={T}", f"--batch_size={E * T // nb}", f"--num_batches_per_epoch={nb}",
+                                   "--num_epochs=1"] + var["args"])
+        learner, env_info = make_learner(cfg, MLP_OBS, action_space, E)
+        shapes = load_seeded(learner.actor_critic, seed=7)
+        learner.train_step = var.get("train_step", 0)
+        # give the returns normaliser a non-trivial state
+        if cfg.normalize_returns:
+            learner.actor_critic.returns_normalizer.running_mean[:] = 0.3
+            learner.actor_critic.returns_normalizer.running_var[:] = 2.5
+            learner.actor_critic.returns_normalizer.count[:] = 100.0
+        g = torch.Generator().manual_seed(1000 + vi)
+        b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
+        fill_batch(b, g, var.get("A"), continuous=continuous, **var["fill"])
+        arrays = {"ref": "sample_factory/algo/learning/learner.py:943-1034 Learner._prepare_batch; "
+                         ":537-669 Learner._calculate_losses", "argv": " ".join(var["args"]),
+                  "param_seed": 7, "train_step": learner.train_step}
+        arrays.update(batch_arrays(b))
+        if cfg.normalize_returns:
+            rn = learner.actor_critic.returns_normalizer
+            arrays["in_rms"] = np.array([rn.running_mean.item(), rn.running_var.item(), rn.count.item()])
+        bb = clone_tensordict(b)
+        buff, size, num_invalids = learner._prepare_batch(bb)
+        arrays["bootstrap_values"] = bb["values"][:, -1].numpy().copy()  # written by the reference at :967
+        arrays["out_rewards"] = bb["rewards"].numpy().copy()  # mutated in place by value bootstrap (:990)
+        arrays["out_valids_full"] = bb["valids"].numpy().copy()
+        for k in ["valids", "actions", "log_prob_actions", "values", "rewards", "dones", "action_logits"]:
+            arrays["pb_" + k] = buff[k].numpy().copy()
+        if not cfg.with_vtrace:
+            arrays["pb_advantages"] = buff["advantages"].numpy().copy()
+            arrays["pb_returns"] = buff["returns"].numpy().copy()
+        arrays["pb_num_invalids"] = num_invalids
+        arrays["pb_size"] = size
+        if cfg.normalize_returns:
+            rn = learner.actor_critic.returns_normalizer
+            arrays["out_rms"] = np.array([rn.running_mean.item(), rn.running_var.item(), rn.count.item()])
+
+        # ---- _calculate_losses on the first minibatch (contiguous slice, learner.py:520-521)
+        mb_size = cfg.batch_size
+        mb = AttrDict(learner._get_minibatch(buff, slice(0, mb_size)))
+        cap, hooks = capture_heads(learner)
+        rec = {}
+        orig_value_loss = learner._value_loss
+
+        def spy_value_loss(new_values, old_values, target, clip_value, valids, num_inv):
+            rec["targets"] = target.detach().clone()
+            return orig_value_loss(new_values, old_values, target, clip_value, valids, num_inv)
+
+        learner._value_loss = spy_value_loss
+        (dist, policy_loss, exploration_loss, kl_old, kl_loss, value_loss, summ) = learner._calculate_losses(
+            mb, num_invalids)
+        loss = policy_loss + exploration_loss + kl_loss + value_loss
+        for p in learner.actor_critic.parameters():
+            p.grad = None
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        learner._value_loss = orig_value_loss
+        arrays["mb_size"] = mb_size
+        arrays["l_params"] = cap["params"].detach().numpy().copy()
+        arrays["l_values"] = cap["values"].detach().squeeze(-1).numpy().copy()
+        if continuous:
+            # the distribution sees params through torch.chunk; grads arrive on distribution_linear's output
+            pass
+        arrays["l_grad_params"] = cap["params"].grad.numpy().copy()
+        arrays["l_grad_values"] = cap["values"].grad.squeeze(-1).numpy().copy()
+        arrays["l_policy_loss"] = float(policy_loss)
+        arrays["l_exploration_loss"] = float(exploration_loss)
+        arrays["l_kl_loss"] = float(kl_loss)
+        arrays["l_value_loss"] = float(value_loss)
+        arrays["l_adv_mean"] = float(summ["adv_mean"])
+        arrays["l_adv_std"] = float(summ["adv_std"])
+        arrays["l_adv_normalized"] = summ["adv"].numpy().copy()
+        arrays["l_ratio"] = summ["ratio"].detach().numpy().copy()
+        arrays["l_targets"] = rec["targets"].numpy().copy()
+        if kl_old is not None:
+            arrays["l_kl_old"] = kl_old.detach().numpy().copy()
+        arrays["num_params"] = sum(int(np.prod(s)) for _, s in shapes)
+        save("learner_" + var["name"], **arrays)
+
+
+def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1):
+    cfg = make_cfg(list(model_args) + [f"--rollout={T}", f"--batch_size={E * T // nb}",
+                                       f"--num_batches_per_epoch={nb}", f"--num_epochs={epochs}"] + list(extra))
+    learner, env_info = make_learner(cfg, obs_space, gym.spaces.Discrete(A), E)
+    shapes = load_seeded(learner.actor_critic, seed=param_seed)
+    g = torch.Generator().manual_seed(4242)
+    b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
+    fill_batch(b, g, A, p_done=0.08, p_other_policy=0.05 if "inv" in name else 0.0)
+    arrays = {"ref": "sample_factory/algo/learning/learner.py:1036-1067 Learner.train (prepare_batch + _train: "
+                     "losses, backward, clip_grad_norm_, torch.optim.Adam)", "argv": " ".join(list(model_args) + list(extra)),
+              "param_seed": param_seed, "E": E, "T": T, "A": A, "num_batches": nb, "num_epochs": epochs,
+              "subsample": subsample}
+    arrays.update(batch_arrays(b))
+    # record per-SGD-step grad norms by wrapping clip_grad_norm_
+    norms = []
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def spy_clip(params, max_norm, *a, **k):
+        n = orig_clip(params, max_norm, *a, **k)
+        norms.append(float(n))
+        return n
+
+    torch.nn.utils.clip_grad_norm_ = spy_clip
+    stats = learner.train(clone_tensordict(b))
+    torch.nn.utils.clip_grad_norm_ = orig_clip
+    arrays["grad_norms"] = np.array(norms)
+    arrays["train_step"] = learner.train_step
+    arrays["env_steps"] = stats["learner_env_steps"]
+    sd = learner.actor_critic.state_dict()
+    opt = learner.optimizer.state_dict()["state"]
+    for i, (k, shape) in enumerate(shapes):
+        arrays["after_" + k] = sd[k].numpy().reshape(-1)[::subsample].copy()
+        arrays["m_" + k] = opt[i]["exp_avg"].numpy().reshape(-1)[::subsample].copy()
+        arrays["v_" + k] = opt[i]["exp_avg_sq"].numpy().reshape(-1)[::subsample].copy()
+        arrays["sum_after_" + k] = float(sd[k].double().sum())
+    arrays["param_names"] = np.array([k for k, _ in shapes])
+    arrays["param_shapes"] = np.array([str(s) for _, s in shapes])
+    rn = learner.actor_critic.returns_normalizer
+    arrays["out_rms"] = np.array([rn.running_mean.item(), rn.running_var.item(), rn.count.item()])
+    save("train_" + name, **arrays)
+
+
+def gen_model_fwd():
+    """Nature-CNN actor-critic forward on u8 frames — model/encoder.py:90-150, model/actor_critic.py:160-195,
+    utils/normalize.py:51-70 (obs_scale=255)."""
+    obs_space = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 84, 84), np.uint8)})
+    cfg = make_cfg(["--encoder_conv_architecture=convnet_atari", "--nonlinearity=relu", "--obs_scale=255.0",
+                    "--normalize_input=False", "--rollout=4", "--batch_size=8", "--num_batches_per_epoch=1"])
+    learner, env_info = make_learner(cfg, obs_space, gym.spaces.Discrete(6), 2)
+    shapes = load_seeded(learner.actor_critic, seed=5)
+    g = torch.Generator().manual_seed(77)
+    obs = torch.randint(0, 256, (6, 4, 84, 84), generator=g, dtype=torch.uint8)
+    ac = learner.actor_critic
+    ac.eval()
+    with torch.no_grad():
+        nobs = ac.normalize_obs({"obs": obs})
+        head = ac.forward_head(nobs)
+        res = ac.forward_tail(head, values_only=False, sample_actions=False)
+        conv1 = ac.encoder.encoders["obs"].enc.conv_head[0](nobs["obs"])
+    save("model_fwd_atari", ref="model/actor_critic.py:160-195 ActorCriticSharedWeights.forward_head/forward_tail",
+         param_seed=5, obs=obs.numpy(), head_sum=float(head.double().sum()), head_sample=head[:, ::37].numpy(),
+         action_logits=res["action_logits"].numpy(), values=res["values"].numpy(),
+         conv1_preact_sample=conv1[:, ::5, ::3, ::3].numpy(),
+         param_names=np.array([k for k, _ in shapes]), param_shapes=np.array([str(s) for _, s in shapes]))
+
+
+def gen_minibatch_indices():
+    """Learner._get_minibatches — learner.py:498-526: contiguous slices by default; shuffled = permutation of
+    recurrence-aligned chunk starts expanded to full index runs, np.split into minibatches."""
+    cfg = make_cfg(MLP_ARGS + ["--rollout=8", "--recurrence=4", "--batch_size=32", "--num_batches_per_epoch=4",
+                               "--shuffle_minibatches=True", "--use_rnn=False"])
+    learner, _ = make_learner(cfg, MLP_OBS, gym.spaces.Discrete(3), 16)
+    np.random.seed(123)
+    mbs = learner._get_minibatches(32, 128)
+    np.random.seed(123)
+    perm = np.random.permutation(np.arange(0, 128, 4))
+    save("minibatch_indices", ref="learner.py:498-526 Learner._get_minibatches", experience_size=128, batch_size=32,
+         recurrence=4, chunk_start_permutation=perm, minibatches=np.stack(mbs))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb"]
+    if "gae" in which:
+        gen_gae()
+    if "rms" in which:
+        gen_rms()
+    if "dist" in which:
+        gen_action_dist()
+    if "learner" in which:
+        gen_prepare_and_losses()
+    if "mb" in which:
+        gen_minibatch_indices()
+    if "train" in which:
+        gen_train("mlp", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2)
+        gen_train("mlp_inv", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=4, epochs=1, extra=["--kl_loss_coeff=0.1"])
+        cnn_obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 36, 36), np.uint8)})
+        gen_train("cnn36", cnn_obs, ["--encoder_conv_architecture=convnet_atari", "--nonlinearity=relu",
+                                     "--obs_scale=255.0", "--normalize_input=False",
+                                     "--encoder_conv_mlp_layers", "128"],
+                  E=8, T=4, A=6, nb=2, epochs=1, subsample=7)
+    if "model" in which:
+        gen_model_fwd()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""The CPU oracle (oracle/sf_oracle.c) against golden vectors produced by the reference itself
+(oracle/gen_golden.py ran Sample Factory's own functions).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+
+
+def test_philox_known_answers():
+    # Random123 philox4x32-10 known-answer vectors
+    assert [hex(x) for x in oracle.philox((0, 0, 0, 0), (0, 0))] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in oracle.philox((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2)] == [
+        "0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in oracle.philox((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0))] == [
+        "0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_gae_matches_reference(golden):
+    g = golden("gae")
+    for i in range(int(g["num_cases"])):
+        adv = oracle.gae(g[f"c{i}_rewards"], g[f"c{i}_dones"], g[f"c{i}_values"], g[f"c{i}_valids"],
+                         float(g[f"c{i}_gamma"]), float(g[f"c{i}_lambda"]))
+        np.testing.assert_allclose(adv, g[f"c{i}_adv"], rtol=0, atol=1e-5)  # north-star bound is 1e-4
+
+
+def test_rms_matches_reference(golden):
+    g = golden("rms")
+    stats = np.array([0.0, 1.0, 1.0])
+    for i in range(int(g["num_steps"])):
+        stats = oracle.rms_update(stats, g[f"s{i}_x"])
+        np.testing.assert_allclose(stats, g[f"s{i}_stats"], rtol=2e-6)
+        np.testing.assert_allclose(oracle.rms_apply(stats, g[f"s{i}_x"]), g[f"s{i}_normalized"], atol=2e-6, rtol=1e-6)
+        np.testing.assert_allclose(oracle.rms_apply(stats, g[f"s{i}_z"], denormalize=True), g[f"s{i}_denormalized"],
+                                   atol=1e-5, rtol=1e-6)
+    np.testing.assert_allclose(oracle.rms_apply(g["eval_stats"], g["eval_x"]), g["eval_normalized"], atol=2e-6)
+
+
+def test_categorical_matches_reference(golden):
+    g = golden("action_dist")
+    lp, _, ent = oracle.categorical(g["ka_logits"], np.zeros(1))
+    np.testing.assert_allclose(np.exp(lp), [[0.09003057, 0.24472847, 0.66524096]], atol=1e-7)  # reference test KA
+    np.testing.assert_allclose(ent, g["ka_entropy"], atol=1e-6)
+    for i in range(int(g["num_cat"])):
+        lp, la, ent = oracle.categorical(g[f"cat{i}_logits"], g[f"cat{i}_actions"].reshape(-1))
+        np.testing.assert_allclose(lp, g[f"cat{i}_log_probs"], atol=2e-6, rtol=1e-6)
+        np.testing.assert_allclose(la, g[f"cat{i}_log_prob_actions"], atol=2e-6, rtol=1e-6)
+        np.testing.assert_allclose(ent, g[f"cat{i}_entropy"], atol=2e-6, rtol=1e-5)
+
+
+LEARNER_CASES = ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous"]
+
+
+def _cfg_from_argv(argv):
+    kv = {}
+    for tok in str(argv).split():
+        if tok.startswith("--") and "=" in tok:
+            k, v = tok[2:].split("=", 1)
+            kv[k] = v
+    return kv
+
+
+@pytest.mark.parametrize("case", LEARNER_CASES)
+def test_prepare_batch_matches_reference(golden, case):
+    g = golden("learner_" + case)
+    kv = _cfg_from_argv(g["argv"])
+    values = g["in_values"].copy()
+    values[:, -1] = g["bootstrap_values"]
+    norm = kv.get("normalize_returns", "True") == "True"
+    out = oracle.prepare_batch(
+        g["in_rewards"], g["in_dones"], g["in_time_outs"], values, g["in_policy_id"], g["in_policy_version"],
+        g["in_actions"], g["in_log_prob_actions"], my_policy_id=0, train_step=int(g["train_step"]),
+        max_policy_lag=int(kv.get("max_policy_lag", 1000)), normalize_returns=norm,
+        value_bootstrap=kv.get("value_bootstrap", "False") == "True", gamma=0.99, lam=0.95,
+        rms=g["in_rms"] if norm else (0, 1, 1))
+    assert out["num_invalids"] == int(g["pb_num_invalids"])                       # integer: exact
+    np.testing.assert_array_equal(out["valids"], g["out_valids_full"])            # mask: exact
+    np.testing.assert_array_equal(out["valids"][:, :-1].reshape(-1), g["pb_valids"])
+    np.testing.assert_allclose(out["rewards"], g["out_rewards"], atol=1e-6)
+    np.testing.assert_allclose(out["advantages"].reshape(-1), g["pb_advantages"], atol=1e-5)
+    np.testing.assert_allclose(out["returns"].reshape(-1), g["pb_returns"], atol=1e-5)
+    np.testing.assert_array_equal(out["actions"].reshape(g["pb_actions"].shape), g["pb_actions"])
+    np.testing.assert_array_equal(out["log_prob_actions"].reshape(-1), g["pb_log_prob_actions"])
+    if norm:
+        np.testing.assert_allclose(out["rms"], g["out_rms"], rtol=1e-6)
+
+
+def _loss_kwargs(kv, continuous):
+    expl = kv.get("exploration_loss", "entropy")
+    coeff = float(kv.get("exploration_loss_coeff", 0.003))
+    kind = 0 if coeff == 0 else (1 if expl == "entropy" else 2)
+    return dict(action_kind=1 if continuous else 0, clip_ratio=0.1, clip_value=1.0, value_loss_coeff=0.5,
+                exploration_coeff=coeff, exploration_kind=kind, kl_coeff=float(kv.get("kl_loss_coeff", 0.0)))
+
+
+@pytest.mark.parametrize("case", LEARNER_CASES + ["ff_vtrace"])
+def test_ppo_loss_matches_reference(golden, case):
+    g = golden("learner_" + case)
+    kv = _cfg_from_argv(g["argv"])
+    n = int(g["mb_size"])
+    continuous = case == "ff_continuous"
+    if case == "ff_vtrace":
+        rec = int(kv["recurrence"])
+        vs, adv = oracle.vtrace(g["l_ratio"], g["l_values"], g["pb_rewards"][:n], g["pb_dones"][:n].astype(np.float32),
+                                rec, 0.99, float(kv["vtrace_rho"]), float(kv["vtrace_c"]))
+        np.testing.assert_allclose(vs, g["l_targets"], atol=1e-5)
+        targets = vs
+    else:
+        adv, targets = g["pb_advantages"][:n], g["pb_returns"][:n]
+        np.testing.assert_array_equal(targets, g["l_targets"])
+    out = oracle.ppo_loss(g["l_params"], g["l_values"], g["pb_actions"][:n], g["pb_log_prob_actions"][:n],
+                          g["pb_action_logits"][:n], g["pb_values"][:n], adv, targets, g["pb_valids"][:n],
+                          **_loss_kwargs(kv, continuous))
+    assert abs(out["adv_mean"] - float(g["l_adv_mean"])) < 1e-6
+    assert abs(out["adv_std"] - float(g["l_adv_std"])) < 2e-6
+    for k in ["policy_loss", "exploration_loss", "kl_loss", "value_loss"]:
+        assert abs(out[k] - float(g["l_" + k])) < 2e-6 + 1e-5 * abs(float(g["l_" + k])), (k, out[k], float(g["l_" + k]))
+    np.testing.assert_allclose(out["grad_params"], g["l_grad_params"], atol=2e-7, rtol=2e-4)
+    np.testing.assert_allclose(out["grad_values"], g["l_grad_values"], atol=2e-7, rtol=2e-4)
+
+
+def test_minibatch_index_expansion(golden):
+    g = golden("minibatch_indices")
+    rec, bs = int(g["recurrence"]), int(g["batch_size"])
+    starts = g["chunk_start_permutation"]
+    full = (starts[:, None] + np.arange(rec)[None, :]).reshape(-1)
+    np.testing.assert_array_equal(full.reshape(-1, bs), g["minibatches"])
