@@ -1,0 +1,207 @@
+/*
+ * sf_hip.h — C ABI of libsf_hip.so: the MI355X (gfx950) APPO hot path behind Sample Factory's plugin surface.
+ *
+ * The reference (Sample Factory v2.1.3) has NO native boundary: its hot path is Python calling stock PyTorch ops
+ * (SURVEY.md §2.3).  This header therefore declares one entry point per reference *op sequence* on the path; each
+ * comment cites the reference lines (paths relative to sample_factory/) that the call replaces.  INTEGRATION.md
+ * shows the ctypes stub a Sample Factory maintainer would add at each of those call sites.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer (HBM) unless its name starts with `h_`;
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work, they never
+ *    synchronise the device, never allocate, never throw;
+ *  - return 0 on success, a negative code on failure; sf_last_error() returns the message of the last failure
+ *    on the calling thread;
+ *  - boundary layout is the reference's: env-major [E, T(+1), ...] trajectory tensors, flat index e*T + t
+ *    (learner.py:1009-1012); policy outputs stored as f32 (shared_buffers.py:100-103); bool tensors are 1 byte.
+ */
+#ifndef SF_HIP_H
+#define SF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_ERR_ARG (-1)
+#define SF_ERR_LAUNCH (-2)
+#define SF_ERR_UNSUPPORTED (-3)
+
+const char *sf_last_error(void);
+int sf_abi_version(void);
+
+/* ---- K13: validity mask ---------------------------------------------------------------------------------
+ * learner.py:949-955 (valids = policy_id==pid & train_step-policy_version < max_policy_lag; last column copies
+ * the previous one) and :1021-1032 (count invalids; actions=0, log_prob_actions=-1 at invalid rows).
+ * valids [E,T+1] u8 out; num_invalid: device int32 (overwritten). actions [E*T*num_actions], logp [E*T] in/out. */
+int sf_valid_mask(const int32_t *policy_id, const float *policy_version, uint8_t *valids, float *actions,
+                  int num_actions, float *log_prob_actions, int E, int T, int my_policy_id, int train_step,
+                  int max_policy_lag, int32_t *num_invalid, void *stream);
+
+/* ---- K10+K11: value de-normalisation, value bootstrap, GAE, returns ---------------------------------------
+ * learner.py:969-1003 + rl_utils.py:52-94 (gae_advantages / calculate_discounted_sum_torch).
+ * values [E,T+1] (column T = bootstrap value, learner.py:964-967), valids [E,T+1] u8, dones/time_outs [E,T] u8.
+ * rms_stats: device double[3] {mean,var,count} of the returns normaliser, or NULL when normalize_returns=False.
+ * rewards is updated in place when value_bootstrap != 0 (learner.py:990).  advantages, returns: [E,T] out;
+ * returns are NOT yet normalised (that is sf_rms_*).  One wavefront scans 64 envs; tiles are staged through LDS. */
+int sf_gae_returns(float *rewards, const uint8_t *dones, const uint8_t *time_outs, const float *values,
+                   const uint8_t *valids, const double *rms_stats, int E, int T, float gamma, float gae_lambda,
+                   int value_bootstrap, float *advantages, float *returns, void *stream);
+
+/* ---- K12: RunningMeanStdInPlace (scalar statistics) -------------------------------------------------------
+ * running_mean_std.py:51-110.  sf_moments accumulates {sum, sumsq, count} (double[3], zeroed by the call) over x[n]
+ * restricted to valid entries (valids NULL = all; `index` NULL = identity else x[index[i]], valids[index[i]]).
+ * Between the two calls a data-parallel learner all-reduces the 3 doubles.
+ * sf_rms_update merges the batch moments into stats (Chan merge, :51-62, unbiased batch variance) -> stats_out.
+ * sf_rms_apply normalises ((x-mean)/sqrt(var+1e-5) clamp +-5) or de-normalises (clamp, *sigma, +mean) in place. */
+int sf_moments(const float *x, const uint8_t *valids, const int32_t *index, int64_t n, double *moments,
+               void *stream);
+int sf_rms_update(const double *stats_in, const double *moments, double *stats_out, void *stream);
+int sf_rms_apply(float *x, int64_t n, const double *stats, int denormalize, void *stream);
+
+/* ---- K17: V-trace -----------------------------------------------------------------------------------------
+ * learner.py:601-640 (the reference runs this loop on the CPU).  Flat minibatch of n samples made of
+ * n/recurrence trajectories; sample i of the minibatch is dataset row (index ? index[i] : offset+i).
+ * params [n,A] (row stride ld_params) / values [n] (stride ld_values): CURRENT policy outputs (minibatch order; the
+ * strides let both be columns of the fused heads GEMM output [n, 1+A]); actions/old_logp/rewards/dones: dataset
+ * arrays; dones u8.  Outputs vs, adv [n] in minibatch order.  action_kind as in sf_ppo_loss. */
+int sf_vtrace(const float *params, int ld_params, const float *values, int ld_values, const float *actions,
+              const float *old_logp, const float *rewards, const uint8_t *dones, const int32_t *index, int64_t offset,
+              int64_t n, int A, int action_kind, int recurrence, float gamma, float rho_hat, float c_hat, float *vs,
+              float *adv, void *stream);
+
+/* ---- K16: PPO loss head, forward + backward ----------------------------------------------------------------
+ * learner.py:586-669 (ratio, clamp [0.05,20], per-minibatch advantage normalisation, clipped surrogate, entropy /
+ * symmetric-KL exploration loss, KL(new||old), clipped value loss; all means over valid samples) and the autograd
+ * backward of their sum wrt the action-distribution parameters and the value.
+ * action_kind 0 = Discrete(A) (action_distributions.py:99-194), 1 = Box(A/2) (:290-323).
+ * exploration_kind 0 none, 1 entropy, 2 symmetric_kl.
+ * moments: device double[3] {sum, sumsq, n_valid} of the UN-normalised advantage over the (global) minibatch,
+ * produced by sf_moments (+ all-reduce).  adv/targets: dataset arrays unless dense_adv != 0 (v-trace: minibatch
+ * order).  sums: device double[8], zeroed by the call, receives {policy, entropy-or-symkl, kl, value} sums over
+ * valid samples, [4] = max KL, [5] = n_valid; sf_loss_scalars turns them into the reference's loss scalars.
+ * params/values are read with row strides ld_params/ld_values (elements); g_params [n,A], g_values [n] are written
+ * with the SAME strides (so they can be columns of one [n, 1+A] heads-gradient matrix), minibatch order. */
+typedef struct {
+    float clip_ratio;        /* cfg.ppo_clip_ratio  (clip_high = 1+c, clip_low = 1/(1+c), learner.py:544-546) */
+    float clip_value;        /* cfg.ppo_clip_value */
+    float value_loss_coeff;  /* cfg.value_loss_coeff */
+    float exploration_coeff; /* cfg.exploration_loss_coeff */
+    float kl_coeff;          /* cfg.kl_loss_coeff */
+    int32_t exploration_kind;
+    int32_t action_kind;
+    int32_t dense_adv;
+} sf_loss_cfg;
+
+int sf_ppo_loss(const float *params, int ld_params, const float *values, int ld_values, const float *actions,
+                const float *old_logp, const float *old_params, const float *old_values, const float *adv,
+                const float *targets, const uint8_t *valids, const int32_t *index, int64_t offset, int64_t n, int A,
+                const sf_loss_cfg *h_cfg, const double *moments, double *sums, float *g_params, float *g_values,
+                void *stream);
+/* out[0..3] = policy, exploration, kl, value losses; [4] kl mean; [5] kl max; [6] adv mean; [7] adv std;
+ * [8] n_valid; [9] entropy (or symkl) mean — device float[16]. */
+int sf_loss_scalars(const double *sums, const double *moments, const sf_loss_cfg *h_cfg, float *out, void *stream);
+
+/* ---- K14: minibatch index sets ------------------------------------------------------------------------------
+ * learner.py:498-526.  Writes experience_size int32 indices: a pseudo-random permutation (stateless 4-round
+ * Feistel network with cycle walking, keyed by seed/epoch) of the recurrence-aligned chunk starts, each expanded to
+ * `recurrence` consecutive indices; minibatch k is out[k*batch .. (k+1)*batch).  shuffle==0 writes the identity
+ * (contiguous slices, the reference default). */
+int sf_minibatch_indices(int32_t *out, int64_t experience_size, int recurrence, int shuffle, uint32_t seed,
+                         uint32_t epoch, void *stream);
+
+/* ---- K18/K19: global-norm clip + Adam ------------------------------------------------------------------------
+ * learner.py:782-797: torch.nn.utils.clip_grad_norm_(max_grad_norm) then torch.optim.Adam.step (eps=cfg.adam_eps,
+ * no weight decay/amsgrad; learner.py:228-243).  All parameters live in one flat fp32 buffer of P elements.
+ * sf_grad_sumsq: sumsq (device double[1], zeroed by the call) = sum g^2.  sf_adam_step reads it: coef =
+ * min(1, max_norm/(sqrt(sumsq)+1e-6)) (skipped when max_grad_norm <= 0 or sumsq == NULL), g scaled by
+ * grad_scale*coef, then the Adam update in torch's op order.  `step` is the 1-based Adam step count. */
+int sf_grad_sumsq(const float *g, int64_t P, double *sumsq, void *stream);
+int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
+                 float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale, void *stream);
+
+/* ---- K4/K5: action sampling + policy outputs -> trajectory step ------------------------------------------------
+ * action_distributions.py:110-148 (softmax, multinomial, log_softmax, gather), actor_critic.py:112-117,
+ * inference_worker.py:235-269,330-339 and batched_sampling.py:308-311 (policy outputs copied into traj[:, t]).
+ * logits [B,A] (row stride ld_logits), values [B] (stride ld_values): network outputs.  Samples by inverse CDF from a Philox4x32-10 uniform
+ * (key = (seed, row0+b), counter = (step, 0, 2, 0)) and writes, for env b, element (b*stride + t) of the
+ * trajectory tensors: actions (f32), log_prob_actions, values (row stride T+1), policy_version, action_logits
+ * (A floats) and the int32 action for the env.  `deterministic` != 0 takes argmax (enjoy.py:177-182). */
+int sf_sample_write_step(const float *logits, int ld_logits, const float *values, int ld_values, int B, int A, int T,
+                         int t, uint32_t seed, uint32_t step, uint32_t row0, float policy_version, int deterministic,
+                         float *traj_actions,
+                         float *traj_logits, float *traj_logp, float *traj_values, float *traj_policy_version,
+                         int32_t *env_actions, void *stream);
+
+/* ---- K1/K6: env outputs -> trajectory step ---------------------------------------------------------------------
+ * batched_sampling.py:208-213 (reward*scale, clamp +-clip), :319-335 (rewards/dones/time_outs/policy_id into
+ * traj[:, t]) and :215-287 (episode statistics, kept on device: ep_return/ep_len per env, and on `done` the
+ * finished episode is added to ep_stats {sum_return, sum_len, count} (device double[3])). */
+int sf_traj_write_env_step(const float *rewards, const uint8_t *terminated, const uint8_t *truncated, int B, int T,
+                           int t, float reward_scale, float reward_clip, int policy_id, float *traj_rewards,
+                           uint8_t *traj_dones, uint8_t *traj_time_outs, int32_t *traj_policy_id, float *ep_return,
+                           int32_t *ep_len, double *ep_stats, void *stream);
+
+/* ---- synthetic vector env (SURVEY.md §8d "C2 synthetic inputs") ------------------------------------------------
+ * Device-resident stand-in for a GPU env (the reference's pattern: sf_examples/brax/train_brax.py:160-204).
+ * sf_synth_obs writes frame `step` of envs [env0, env0+B) as u8 [obs_bytes] each, env b at obs + b*env_stride —
+ * i.e. straight into slot t of the trajectory slab (zero-copy K1).  sf_synth_step: reward = (action ==
+ * (step+env)%num_actions), terminated ~ Bernoulli(1/1024) from the Philox stream.  Bit-reproducible on CPU. */
+int sf_synth_obs(uint8_t *obs, int64_t env_stride, int B, int env0, int64_t obs_bytes, uint32_t seed, uint32_t step,
+                 void *stream);
+int sf_synth_step(const int32_t *actions, int B, int env0, int num_actions, uint32_t seed, uint32_t step,
+                  float *rewards, uint8_t *terminated, void *stream);
+
+/* ---- K2/K3/K8/K9/K15/K18: actor-critic network (fp32 MFMA) -------------------------------------------------------
+ * model/encoder.py:90-150 (conv head + MLP), model/actor_critic.py:160-195 (critic_linear + distribution_linear),
+ * utils/normalize.py:51-70 + rl_utils.py:36-42 (u8 -> f32, -mean, *1/scale fused into the first layer's loader;
+ * the f32 copy of the observations is never materialised).
+ *
+ * One implicit-GEMM kernel family, out[M,N] = act(gather(in)[M,K] * W[K,N] + bias), for conv fwd, linear fwd,
+ * data-gradient and weight-gradient; see DESIGN.md.  Activations are NHWC ([sample, oh, ow, c]); weights are
+ * stored K-major [KH*KW*Cin, Cout] (k = (kh*KW + kw)*Cin + c) — conversion to/from the reference's OIHW layout
+ * happens in state_dict()/load_state_dict() on the host side. */
+typedef struct {
+    int32_t Cin, H, W;        /* input  feature map (per sample) */
+    int32_t Cout, KH, KW, stride;
+    int32_t OH, OW;           /* output feature map */
+    int32_t in_u8;            /* 1: input is the raw u8 NCHW observation; loader applies (x - sub_mean) * inv_scale */
+    int32_t relu;             /* 1: ReLU fused in the forward epilogue */
+    int32_t traj_T;           /* >0: input rows live in a trajectory slab [E, T+1, ...]; logical sample d (flat dataset
+                                 index e*T+t, learner.py:1009-1012) is slab row e*(T+1)+t — read in place, no batcher
+                                 copy (batcher.py:192-212) and no [:, :-1] reshape copy (learner.py:1005-1012) */
+    float sub_mean, inv_scale;
+} sf_conv_desc;
+
+/* forward: in = u8 NCHW [n, Cin,H,W] (in_u8) or f32 NHWC [n,H,W,Cin]; sample i of the batch is input row
+ * (index ? index[i] : offset+i) * in_sample_stride (elements).  out f32 NHWC [n,OH,OW,Cout]. */
+int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *w,
+                const float *bias, float *out, int64_t n, const sf_conv_desc *h_desc, void *stream);
+/* weight/bias gradient: dw[K,Cout] (+)= gather(in)^T * dout, db[Cout] = sum dout; dout already has the ReLU mask
+ * applied (sf_conv_fwd's consumer does it).  Deterministic two-stage split reduction; workspace >=
+ * sf_conv_wgrad_workspace(...) bytes. */
+int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc);
+int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *dout,
+                  float *dw, float *db, int64_t n, const sf_conv_desc *h_desc, void *workspace, void *stream);
+/* data gradient: din[n,H,W,Cin] = conv_transpose(dout, w) * relu_mask(in_act) (in_act = this layer's input
+ * activation, i.e. the previous layer's post-ReLU output; NULL = no mask). */
+int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
+                  const sf_conv_desc *h_desc, void *stream);
+/* dense layer: out[M,N] = act(in[M,K] * w[K,N] + bias); wgrad: dw[K,N] = in^T dout, db = colsum(dout);
+ * dgrad: din[M,K] = (dout[M,N] * w^T) * relu_mask(in_act). */
+int sf_linear_fwd(const float *in, const float *w, const float *bias, float *out, int64_t M, int K, int N, int relu,
+                  void *stream);
+int64_t sf_linear_wgrad_workspace(int64_t M, int K, int N);
+int sf_linear_wgrad(const float *in, const float *dout, float *dw, float *db, int64_t M, int K, int N,
+                    void *workspace, void *stream);
+int sf_linear_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t M, int K, int N,
+                    void *stream);
+/* elementwise helper for the backward chain: g[i] = (act[i] > 0) ? g[i] : 0 */
+int sf_relu_mask(float *g, const float *act, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SF_HIP_H */

@@ -111,7 +111,7 @@ SCALAR_NAMES = ("policy_loss", "exploration_loss", "kl_loss", "value_loss", "kl_
 
 def ppo_loss(params, values, actions, old_logp, old_params, old_values, adv, targets, valids, *, action_kind=0,
              clip_ratio=0.1, clip_value=1.0, value_loss_coeff=0.5, exploration_coeff=0.003, exploration_kind=1,
-             kl_coeff=0.0):
+             kl_coeff=0.0, ext_moments=None):
     params = _f32(params)
     N, A = params.shape
     values, actions, old_logp = _f32(values), _f32(actions), _f32(old_logp)
@@ -125,7 +125,9 @@ def ppo_loss(params, values, actions, old_logp, old_params, old_values, adv, tar
                        _p(adv, C.c_float), _p(targets, C.c_float), _p(valids, C.c_uint8), C.c_long(N), A,
                        int(action_kind), C.c_double(clip_ratio), C.c_double(clip_value),
                        C.c_double(value_loss_coeff), C.c_double(exploration_coeff), int(exploration_kind),
-                       C.c_double(kl_coeff), _p(sc, C.c_float), _p(gp, C.c_float), _p(gv, C.c_float))
+                       C.c_double(kl_coeff),
+                       _p(np.ascontiguousarray(ext_moments, dtype=np.float64), C.c_double) if ext_moments is not None else None,
+                       _p(sc, C.c_float), _p(gp, C.c_float), _p(gv, C.c_float))
     out = {k: float(sc[i]) for i, k in enumerate(SCALAR_NAMES)}
     out["grad_params"] = gp
     out["grad_values"] = gv

@@ -394,7 +394,7 @@ def gen_minibatch_indices():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb"]
+    which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb", "cfg"]
     if "gae" in which:
         gen_gae()
     if "rms" in which:
@@ -415,6 +415,10 @@ def main():
                   E=8, T=4, A=6, nb=2, epochs=1, subsample=7)
     if "model" in which:
         gen_model_fwd()
+    if "cfg" in which:
+        import json
+        p, a = parse_sf_args(["--algo=APPO", "--env=x", "--experiment=e"])
+        json.dump(dict(vars(a)), open(os.path.join(OUT, "cfg_defaults.json"), "w"), indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -202,19 +202,25 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
                           const float *old_params, const float *old_values, const float *adv_in,
                           const float *targets, const uint8_t *valids, long N, int A, int action_kind,
                           double clip_ratio, double clip_value, double value_loss_coeff, double exploration_coeff,
-                          int exploration_kind, double kl_coeff, float *out_scalars, float *g_params,
-                          float *g_values) {
+                          int exploration_kind, double kl_coeff, const double *ext_moments, float *out_scalars,
+                          float *g_params, float *g_values) {
     const float clip_hi = (float)(1.0 + clip_ratio);
     const float clip_lo = (float)(1.0 / (1.0 + clip_ratio));
     const float cv = (float)clip_value;
     /* adv normalisation: torch.std_mean over valid entries */
     double s = 0.0; long n = 0;
     for (long i = 0; i < N; ++i) if (valids[i]) { s += adv_in[i]; ++n; }
-    const double mean = n ? s / (double)n : NAN;
+    double mean = n ? s / (double)n : NAN;
     double ss = 0.0;
     for (long i = 0; i < N; ++i) if (valids[i]) { const double d = adv_in[i] - mean; ss += d * d; }
+    double var = n > 1 ? ss / (double)(n - 1) : NAN;
+    if (ext_moments) { /* data-parallel shard: GLOBAL {sum, sumsq, n} supplied by the caller */
+        n = (long)ext_moments[2];
+        mean = ext_moments[0] / ext_moments[2];
+        var = (ext_moments[1] - ext_moments[0] * mean) / (ext_moments[2] - 1.0);
+    }
     const float adv_mean = (float)mean;
-    const float adv_std = (float)sqrt(n > 1 ? ss / (double)(n - 1) : NAN);
+    const float adv_std = (float)sqrt(var);
     const float denom = adv_std < 1e-7f ? 1e-7f : adv_std;
     const float inv_n = 1.0f / (float)n;
     double sum_pl = 0, sum_ent = 0, sum_kl = 0, sum_vl = 0, sum_symkl = 0; float max_kl = -INFINITY;

@@ -1,0 +1,53 @@
+"""Data-parallel learner replicas (C1 — new capability, the reference has one learner per policy:
+sample_factory/algo/utils/shared_buffers.py:26-32).
+
+One process per GPU, envs partitioned by rank; rollout, inference, bootstrap values and the GAE/V-trace scans need no
+communication (recurrences run along T only).  Per SGD step the replicas exchange:
+  * 3 doubles  {sum(adv), sum(adv^2), n_valid}   before the loss  -> global per-minibatch advantage normalisation
+  * 1 bucket   flat fp32 gradient (already scaled by the GLOBAL 1/n_valid) -> sum == gradient of the global mean loss
+and once per dataset 3 doubles of return moments (returns normaliser) and the invalid count.  Adam then runs
+redundantly on identical inputs, so weights never need an all-gather.  `torch.distributed` backend "nccl" is RCCL on
+ROCm; the same code runs over gloo on CPU tensors (tests/test_dp_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class ReplicaGroup:
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.active else 1
+        self.rank = dist.get_rank(process_group) if self.active else 0
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return t
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        return t
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.world > 1:
+            dist.broadcast(t, src=src, group=self.pg)
+        return t
+
+    def env_shard(self, envs_per_rank: int) -> Tuple[int, int]:
+        """[first, last) global env ids owned by this rank (weak scaling: per-rank work is fixed)."""
+        return self.rank * envs_per_rank, (self.rank + 1) * envs_per_rank
+
+    def loss_sums(self, sums: torch.Tensor) -> torch.Tensor:
+        """sums[0..3] additive loss sums, sums[4] = max KL (needs MAX), rest additive."""
+        if self.world > 1:
+            mx = sums[4:5].clone()
+            self.all_reduce_sum(sums)
+            self.all_reduce_max(mx)
+            sums[4:5].copy_(mx)
+        return sums

@@ -1,0 +1,470 @@
+"""Learner — the reference's `Learner` surface (sample_factory/algo/learning/learner.py:125-1067) on HIP kernels.
+
+Same constructor, `init()`, `train(batch)`, `_prepare_batch`, `_get_minibatches`, `_calculate_losses`, `_train`,
+`save()/load_from_checkpoint()` and checkpoint format; what changes is what runs underneath:
+
+  reference op sequence                    here
+  K13 valids / invalid count / sanitise                      sf_valid_mask           (1 launch)
+  K9  bootstrap forward                                       sf_conv_fwd stack on slab[:, T] in place
+  K10-K11 de-normalise, value bootstrap, GAE, returns         sf_gae_returns          (1 launch, LDS-staged scan)
+  K12 returns normaliser                                      sf_moments + sf_rms_update + sf_rms_apply
+  K7/K8 batcher copy + f32 obs materialisation                none: conv1 reads the u8 slab through (index, traj_T)
+  K14 minibatch gather                                        sf_minibatch_indices; consumers read through the index
+  K15 forward / K18 backward                                  fp32-MFMA implicit GEMM (sf_conv_fwd/wgrad/dgrad)
+  K16 loss head fwd+bwd                                       sf_moments + sf_ppo_loss (analytic backward fused)
+  K17 V-trace (CPU loop in the reference)                     sf_vtrace on device
+  K18-K19 clip_grad_norm_ + Adam                              sf_grad_sumsq + sf_adam_step on the flat buffers
+  C1  data-parallel replicas (new)                            torch.distributed all_reduce (RCCL) of the flat grad bucket
+                                                              + 3-double moment buckets
+
+Host synchronisation: one readback per dataset (num_invalids, as the reference) and one per epoch (actor losses for
+the early-stop test / KL for the LR schedulers) instead of ~6 per minibatch.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import time
+from os.path import join
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from sample_factory_amd import lib
+from sample_factory_amd.algo.learning.dp import ReplicaGroup
+from sample_factory_amd.algo.utils.tensor_dict import TensorDict
+from sample_factory_amd.envs.spaces import calc_num_action_parameters, calc_num_actions, is_discrete
+from sample_factory_amd.model.actor_critic import ActorCritic
+from sample_factory_amd.utils.attr_dict import AttrDict
+
+LEARNER_ENV_STEPS, POLICY_ID_KEY, STATS_KEY, TRAIN_STATS = "learner_env_steps", "policy_id", "stats", "train"
+
+
+# ------------------------------------------------------------------------------------------------ LR schedulers
+class LearningRateScheduler:
+    """learner.py:35-113"""
+
+    def update(self, current_lr, recent_kls):
+        return current_lr
+
+    def invoke_after_each_minibatch(self):
+        return False
+
+    def invoke_after_each_epoch(self):
+        return False
+
+
+class KlAdaptiveScheduler(LearningRateScheduler):
+    def __init__(self, cfg, per_epoch: bool):
+        self.threshold, self.min_lr, self.max_lr = cfg.lr_schedule_kl_threshold, cfg.lr_adaptive_min, cfg.lr_adaptive_max
+        self.per_epoch = per_epoch
+        self.n = cfg.num_batches_per_epoch if per_epoch else 1
+
+    def update(self, current_lr, recent_kls):
+        mean_kl = float(np.mean(recent_kls[-self.n:]))
+        lr = current_lr
+        if mean_kl > 2.0 * self.threshold:
+            lr = max(current_lr / 1.5, self.min_lr)
+        if mean_kl < 0.5 * self.threshold:
+            lr = min(current_lr * 1.5, self.max_lr)
+        return lr
+
+    def invoke_after_each_minibatch(self):
+        return not self.per_epoch
+
+    def invoke_after_each_epoch(self):
+        return self.per_epoch
+
+
+class LinearDecayScheduler(LearningRateScheduler):
+    def __init__(self, cfg):
+        self.num_updates = cfg.train_for_env_steps // cfg.batch_size * cfg.num_epochs
+        self.lr0 = cfg.learning_rate
+        self.step = 0
+
+    def invoke_after_each_minibatch(self):
+        return True
+
+    def update(self, current_lr, recent_kls):
+        self.step += 1
+        return self.lr0 * max(0.0, 1.0 - self.step / max(1, self.num_updates))
+
+
+def get_lr_scheduler(cfg) -> LearningRateScheduler:
+    if cfg.lr_schedule == "constant":
+        return LearningRateScheduler()
+    if cfg.lr_schedule == "kl_adaptive_minibatch":
+        return KlAdaptiveScheduler(cfg, per_epoch=False)
+    if cfg.lr_schedule == "kl_adaptive_epoch":
+        return KlAdaptiveScheduler(cfg, per_epoch=True)
+    if cfg.lr_schedule == "linear_decay":
+        return LinearDecayScheduler(cfg)
+    raise RuntimeError(f"Unknown scheduler {cfg.lr_schedule}")
+
+
+def experiment_dir(cfg) -> str:
+    d = join(cfg.train_dir, cfg.experiment)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+class _NullLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class ParameterServer:
+    """model_sharing.py:17-43 — same process, same weights: publishing is bumping the version counter (K20)."""
+
+    def __init__(self, policy_id, policy_versions: torch.Tensor, serial_mode: bool = True):
+        self.policy_id = policy_id
+        self.actor_critic = None
+        self.policy_versions = policy_versions
+        self.device = None
+        self.policy_lock = _NullLock()
+
+    def init(self, actor_critic, policy_version, device):
+        self.actor_critic, self.device = actor_critic, device
+        self.policy_versions[self.policy_id] = policy_version
+
+
+class Learner:
+    def __init__(self, cfg, env_info, policy_versions_tensor: torch.Tensor, policy_id: int, param_server,
+                 process_group=None):
+        self.cfg = cfg
+        self.env_info = env_info
+        self.policy_id = policy_id
+        self.policy_versions_tensor = policy_versions_tensor
+        self.param_server = param_server
+        self.device: Optional[torch.device] = None
+        self.actor_critic: Optional[ActorCritic] = None
+        self.curr_lr: Optional[float] = None
+        self.lr_scheduler: Optional[LearningRateScheduler] = None
+        self.train_step = 0
+        self.env_steps = 0
+        self.best_performance = -1e9
+        self.new_cfg: Optional[Dict] = None
+        self.policy_to_load = None
+        self.is_initialized = False
+        self.last_summary: Dict = {}
+        # data-parallel replicas (C1): one rank per GPU; inactive group = single GPU
+        self.pg = process_group
+        dp_on = process_group is not None or getattr(cfg, "data_parallel", False)
+        self.group = ReplicaGroup(process_group) if dp_on else None
+        self.world = self.group.world if self.group is not None else 1
+        self._grad_norms: List[float] = []
+
+    # ------------------------------------------------------------------------------------------ init / checkpoints
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        if self.world > 1:
+            self.group.all_reduce_sum(t)
+
+    def init(self):
+        cfg = self.cfg
+        if cfg.exploration_loss not in ("entropy", "symmetric_kl"):
+            raise NotImplementedError(f"{cfg.exploration_loss} not supported!")
+        if cfg.optimizer != "adam":
+            raise NotImplementedError("only the default Adam optimizer is native (Lamb: SURVEY.md §2.1 '★-minor')")
+        if cfg.seed is not None:
+            torch.manual_seed(cfg.seed)
+            np.random.seed(cfg.seed)
+        if not torch.cuda.is_available():
+            raise lib.SfHipError("Learner.init(): no GPU visible. sample_factory_amd has no CPU path.")
+        lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        ar = self._all_reduce if self.world > 1 else None
+        self.actor_critic = ActorCritic(cfg, self.env_info.obs_space, self.env_info.action_space, self.device,
+                                        all_reduce=ar)
+        self.actor_critic.train()
+        if self.world > 1:  # identical initial weights on every replica
+            self.group.broadcast(self.actor_critic.flat_params, src=0)
+        P = self.actor_critic.num_flat
+        self.exp_avg = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self.adam_step_count = 0
+        # small device scratch
+        dev = self.device
+        self._num_invalid = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._scalars = None  # [num_epochs*num_batches, 16] per train() call
+        A = calc_num_action_parameters(self.env_info.action_space)
+        self.num_action_params = A
+        self.num_actions = calc_num_actions(self.env_info.action_space)
+        self.loss_cfg = lib.sf_loss_cfg(
+            clip_ratio=cfg.ppo_clip_ratio, clip_value=cfg.ppo_clip_value, value_loss_coeff=cfg.value_loss_coeff,
+            exploration_coeff=cfg.exploration_loss_coeff, kl_coeff=cfg.kl_loss_coeff,
+            exploration_kind=0 if cfg.exploration_loss_coeff == 0.0 else (1 if cfg.exploration_loss == "entropy" else 2),
+            action_kind=0 if is_discrete(self.env_info.action_space) else 1, dense_adv=int(bool(cfg.with_vtrace)))
+        self.load_from_checkpoint(self.policy_id)
+        self.param_server.init(self.actor_critic, self.train_step, self.device)
+        self.policy_versions_tensor[self.policy_id] = self.train_step
+        self.lr_scheduler = get_lr_scheduler(cfg)
+        self.curr_lr = cfg.learning_rate if self.curr_lr is None else self.curr_lr
+        self.is_initialized = True
+        state_dict = None if cfg.serial_mode else self.actor_critic.state_dict()
+        return self.policy_id, state_dict, self.device, self.train_step
+
+    @staticmethod
+    def checkpoint_dir(cfg, policy_id):
+        d = join(experiment_dir(cfg), f"checkpoint_p{policy_id}")
+        os.makedirs(d, exist_ok=True)
+        return d
+
+    @staticmethod
+    def get_checkpoints(checkpoints_dir, pattern="checkpoint_*"):
+        return sorted(glob.glob(join(checkpoints_dir, pattern)))
+
+    @staticmethod
+    def load_checkpoint(checkpoints, device):
+        if not checkpoints:
+            return None
+        return torch.load(checkpoints[-1], map_location="cpu", weights_only=False)
+
+    def _get_checkpoint_dict(self):
+        """learner.py:323-332: {train_step, env_steps, best_performance, model, optimizer, curr_lr}; the optimizer
+        state is torch.optim.Adam's state_dict layout over the reference parameter order."""
+        ac = self.actor_critic
+        names = [n for n, _ in ac.ref_param_shapes()]
+        m, v = ac.flat_to_ref(self.exp_avg), ac.flat_to_ref(self.exp_avg_sq)
+        opt_state = {i: dict(step=torch.tensor(float(self.adam_step_count)), exp_avg=m[n], exp_avg_sq=v[n])
+                     for i, n in enumerate(names)} if self.adam_step_count > 0 else {}
+        opt = dict(state=opt_state, param_groups=[dict(
+            lr=self.curr_lr, betas=(self.cfg.adam_beta1, self.cfg.adam_beta2), eps=self.cfg.adam_eps, weight_decay=0,
+            amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+            decoupled_weight_decay=False, params=list(range(len(names))))])
+        return dict(train_step=self.train_step, env_steps=self.env_steps, best_performance=self.best_performance,
+                    model=ac.state_dict(), optimizer=opt, curr_lr=self.curr_lr)
+
+    def save(self) -> bool:
+        """learner.py:334-362: atomic temp+rename, keep cfg.keep_checkpoints newest."""
+        d = self.checkpoint_dir(self.cfg, self.policy_id)
+        tmp = join(d, "checkpoint_temp")
+        name = join(d, f"checkpoint_{self.train_step:09d}_{self.env_steps}.pth")
+        torch.save(self._get_checkpoint_dict(), tmp)
+        os.rename(tmp, name)
+        cps = self.get_checkpoints(d)
+        while len(cps) > self.cfg.keep_checkpoints:
+            os.remove(cps.pop(0))
+        return True
+
+    def _load_state(self, cp, load_progress=True):
+        """learner.py:289-298"""
+        if load_progress:
+            self.train_step, self.env_steps = cp["train_step"], cp["env_steps"]
+            self.best_performance = cp.get("best_performance", self.best_performance)
+        ac = self.actor_critic
+        ac.load_state_dict(cp["model"])
+        st = cp["optimizer"].get("state", {})
+        if st:
+            names = [n for n, _ in ac.ref_param_shapes()]
+            m = {n: st[i]["exp_avg"] for i, n in enumerate(names)}
+            v = {n: st[i]["exp_avg_sq"] for i, n in enumerate(names)}
+            self._ref_to_flat(m, self.exp_avg)
+            self._ref_to_flat(v, self.exp_avg_sq)
+            self.adam_step_count = int(float(st[0]["step"]))
+        self.curr_lr = cp.get("curr_lr", self.cfg.learning_rate)
+
+    def _ref_to_flat(self, ref: Dict[str, torch.Tensor], flat: torch.Tensor):
+        ac = self.actor_critic
+        keep_p = ac.flat_params.clone()
+        sd = dict(ref)
+        ac.load_state_dict(sd, strict=False)
+        flat.copy_(ac.flat_params)
+        ac.flat_params.copy_(keep_p)
+
+    def load_from_checkpoint(self, policy_id, load_progress=True) -> None:
+        cps = self.get_checkpoints(self.checkpoint_dir(self.cfg, policy_id))
+        cp = self.load_checkpoint(cps, self.device)
+        if cp is not None:
+            self._load_state(cp, load_progress)
+
+    # ------------------------------------------------------------------------------------------ batch preparation
+    def _prepare_batch(self, batch: TensorDict) -> Tuple[AttrDict, int, int]:
+        """learner.py:943-1034.  `batch` is the env-major trajectory slab slice on the GPU; it is mutated in place
+        exactly where the reference mutates it (valids, values[:, -1], rewards under value_bootstrap, sanitised
+        actions/log-probs).  Returns (buff, experience_size, num_invalids); buff holds FLAT [E*T] dataset arrays."""
+        cfg, ac = self.cfg, self.actor_critic
+        obs = batch["obs"]["obs"]
+        E, T = batch["rewards"].shape
+        N = E * T
+        lib.valid_mask(batch["policy_id"], batch["policy_version"], batch["valids"], batch["actions"],
+                       self.num_actions, batch["log_prob_actions"], self.policy_id, self.train_step,
+                       cfg.max_policy_lag, self._num_invalid)
+        if not ac.training:
+            ac.train()
+        # K9: bootstrap value of the T+1-th observation, read from the slab in place
+        last = obs[:, T]
+        heads = ac.forward_heads(last, E, sample_stride=obs.stride(0), tag="inf")[-1]
+        batch["values"][:, T].copy_(heads[:, 0])
+        adv = torch.empty((E, T), dtype=torch.float32, device=self.device)
+        ret = torch.empty((E, T), dtype=torch.float32, device=self.device)
+        buff = AttrDict()
+        if not cfg.with_vtrace:
+            rms = ac.returns_normalizer.stats if cfg.normalize_returns else None
+            lib.gae_returns(batch["rewards"], batch["dones"], batch["time_outs"], batch["values"], batch["valids"],
+                            rms, cfg.gamma, cfg.gae_lambda, cfg.value_bootstrap, adv, ret)
+            buff.advantages, buff.returns = adv.view(N), ret.view(N)
+        elif cfg.value_bootstrap:
+            raise NotImplementedError("value_bootstrap together with with_vtrace")
+        # flat dataset views (index e*T + t); [E,T+1] tensors lose their last column by a small compact copy
+        buff.obs = obs
+        buff.actions = batch["actions"].view(N, self.num_actions)
+        buff.action_logits = batch["action_logits"].view(N, self.num_action_params)
+        buff.log_prob_actions = batch["log_prob_actions"].view(N)
+        buff.rewards = batch["rewards"].view(N)
+        buff.dones = batch["dones"].view(N)
+        buff.values = batch["values"][:, :T].reshape(N)
+        buff.valids = batch["valids"][:, :T].reshape(N)
+        buff.E, buff.T = E, T
+        if cfg.normalize_returns and not cfg.with_vtrace:
+            ac.returns_normalizer(buff.returns)  # in place: update (all-reduced moments under DP) + normalise
+        num_invalids = int(self._num_invalid.item())  # the one host sync per dataset (reference: learner.py:1021)
+        if self.world > 1:
+            t = torch.tensor([num_invalids], dtype=torch.int64, device=self.device)
+            self._all_reduce(t)
+            self._global_invalids = int(t.item())
+        else:
+            self._global_invalids = num_invalids
+        return buff, N, num_invalids
+
+    # ------------------------------------------------------------------------------------------ minibatches
+    def _get_minibatches(self, batch_size, experience_size):
+        """learner.py:498-526.  Returns a list of (index_tensor|None, offset, n).  Shuffling permutes
+        recurrence-aligned chunk starts on the device (sf_minibatch_indices); nothing is gathered."""
+        cfg = self.cfg
+        assert cfg.rollout % cfg.recurrence == 0
+        assert experience_size % batch_size == 0, f"experience size: {experience_size}, batch size: {batch_size}"
+        n_mb = cfg.num_batches_per_epoch
+        if n_mb == 1:
+            return [(None, 0, experience_size)]
+        if cfg.shuffle_minibatches:
+            idx = torch.empty(experience_size, dtype=torch.int32, device=self.device)
+            seed = (cfg.seed or 0) * 7919 + self.policy_id
+            lib.minibatch_indices(idx, experience_size, cfg.recurrence, True, seed, self._shuffle_epoch)
+            self._shuffle_epoch += 1
+            return [(idx[i * batch_size:(i + 1) * batch_size], 0, batch_size) for i in range(experience_size // batch_size)]
+        return [(None, i * batch_size, batch_size) for i in range(n_mb)]
+
+    _shuffle_epoch = 0
+
+    # ------------------------------------------------------------------------------------------ losses
+    def _calculate_losses(self, buff: AttrDict, mb, num_invalids: int, scalars_out: Optional[torch.Tensor] = None):
+        """learner.py:537-669 for one minibatch mb=(index, offset, n): forward, (v-trace), advantage moments,
+        fused loss forward+backward.  Returns (acts, g_heads, scalars[16] device tensor) — scalars follow
+        sf_loss_scalars: policy, exploration, kl, value losses, kl mean/max, adv mean/std, n_valid, entropy."""
+        cfg, ac = self.cfg, self.actor_critic
+        index, offset, n = mb
+        A = self.num_action_params
+        acts = ac.forward_heads(buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
+                                traj_T=buff.T, tag="train")
+        heads = acts[-1]
+        ld = 1 + A
+        params, values = heads[:, 1:], heads[:, 0]
+        g_heads = ac._buf(("g", "heads"), (n, ld))
+        if cfg.with_vtrace:
+            vs = ac._buf(("vt", "vs"), (n,))
+            adv = ac._buf(("vt", "adv"), (n,))
+            lib.vtrace(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.rewards, buff.dones, index,
+                       offset, n, A, self.loss_cfg.action_kind, cfg.recurrence, cfg.gamma, cfg.vtrace_rho,
+                       cfg.vtrace_c, vs, adv)
+            valid_dense = buff.valids[index.long()] if index is not None else buff.valids[offset:offset + n]
+            lib.moments(adv, valid_dense.contiguous(), None, n, self._moments)
+            adv_arr, tgt_arr = adv, vs
+        else:
+            if index is not None:
+                lib.moments(buff.advantages, buff.valids, index, n, self._moments)
+            else:
+                lib.moments(buff.advantages[offset:offset + n], buff.valids[offset:offset + n], None, n, self._moments)
+            adv_arr, tgt_arr = buff.advantages, buff.returns
+        self._all_reduce(self._moments)  # global per-minibatch advantage statistics under DP
+        lib.ppo_loss(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.action_logits, buff.values,
+                     adv_arr, tgt_arr, buff.valids, index, offset, n, A, self.loss_cfg, self._moments, self._sums,
+                     g_heads[:, 1:], g_heads[:, 0])
+        if self.world > 1:
+            self.group.loss_sums(self._sums)
+        out = scalars_out if scalars_out is not None else torch.zeros(16, dtype=torch.float32, device=self.device)
+        lib.loss_scalars(self._sums, self._moments, self.loss_cfg, out)
+        return acts, g_heads, out
+
+    # ------------------------------------------------------------------------------------------ SGD
+    def _train(self, buff: AttrDict, batch_size: int, experience_size: int, num_invalids: int) -> Optional[AttrDict]:
+        """learner.py:671-841"""
+        cfg, ac = self.cfg, self.actor_critic
+        early_stopping_tolerance = 1e-6
+        prev_epoch_actor_loss = 1e9
+        recent_kls: List[float] = []
+        num_sgd_steps = 0
+        n_mb = cfg.num_batches_per_epoch
+        self._scalars = torch.zeros((cfg.num_epochs * n_mb, 16), dtype=torch.float32, device=self.device)
+        global_size = experience_size * self.world
+        need_kl_each_mb = self.lr_scheduler.invoke_after_each_minibatch() and isinstance(self.lr_scheduler, KlAdaptiveScheduler)
+        self._grad_norms = []
+        for epoch in range(cfg.num_epochs):
+            minibatches = self._get_minibatches(batch_size, experience_size)
+            for batch_num, mb in enumerate(minibatches):
+                row = self._scalars[epoch * n_mb + batch_num]
+                acts, g_heads, _ = self._calculate_losses(buff, mb, num_invalids, row)
+                index, offset, n = mb
+                ac.backward(acts, g_heads, buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
+                            traj_T=buff.T)
+                # C1: one fp32 bucket; every replica's gradient already carries the GLOBAL 1/n_valid
+                self._all_reduce(ac.flat_grads)
+                actual_lr = self.curr_lr
+                if self._global_invalids > 0:  # learner.py:788-794
+                    actual_lr = self.curr_lr * (global_size - self._global_invalids) / global_size
+                self.adam_step_count += 1
+                use_clip = cfg.max_grad_norm > 0.0
+                if use_clip or getattr(cfg, "record_grad_norm", False):
+                    lib.grad_sumsq(ac.flat_grads, self._sumsq)
+                    if getattr(cfg, "record_grad_norm", False):
+                        self._grad_norms.append(float(self._sumsq.sqrt().item()))
+                lib.adam_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
+                              actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
+                              cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None)
+                num_sgd_steps += 1
+                self.train_step += 1
+                if need_kl_each_mb:
+                    recent_kls.append(float(row[4].item()))
+                    self.curr_lr = self.lr_scheduler.update(self.curr_lr, recent_kls)
+                elif self.lr_scheduler.invoke_after_each_minibatch():
+                    self.curr_lr = self.lr_scheduler.update(self.curr_lr, recent_kls)
+                # K20: same-process inference reads the same flat buffer in stream order; publishing = version bump
+                self.policy_versions_tensor[self.policy_id] = self.train_step
+            # ---- end of epoch: ONE readback (actor losses for early stopping, KLs for the per-epoch scheduler)
+            rows = self._scalars[epoch * n_mb:(epoch + 1) * n_mb].cpu()
+            actor_losses = (rows[:, 0] + rows[:, 1] + rows[:, 2]).double().numpy()
+            if not need_kl_each_mb:
+                recent_kls.extend(rows[:, 4].double().tolist())
+            if self.lr_scheduler.invoke_after_each_epoch():
+                self.curr_lr = self.lr_scheduler.update(self.curr_lr, recent_kls)
+            new_epoch_actor_loss = float(np.mean(actor_losses))
+            if abs(prev_epoch_actor_loss - new_epoch_actor_loss) < early_stopping_tolerance:
+                break
+            prev_epoch_actor_loss = new_epoch_actor_loss
+        last = rows[-1]
+        stats = AttrDict(lr=self.curr_lr, policy_loss=float(last[0]), exploration_loss=float(last[1]),
+                         kl_loss=float(last[2]), value_loss=float(last[3]), kl_divergence=float(last[4]),
+                         kl_divergence_max=float(last[5]), adv_mean=float(last[6]), adv_std=float(last[7]),
+                         entropy=float(last[9]), loss=float(last[0] + last[1] + last[2] + last[3]),
+                         num_sgd_steps=num_sgd_steps, valids_fraction=1.0 - num_invalids / experience_size)
+        self.last_summary = stats
+        return stats
+
+    def train(self, batch: TensorDict) -> Optional[Dict]:
+        """learner.py:1036-1067"""
+        buff, experience_size, num_invalids = self._prepare_batch(batch)
+        if self._global_invalids >= experience_size * self.world:
+            return None
+        train_stats = self._train(buff, self.cfg.batch_size, experience_size, num_invalids)
+        frameskip = self.env_info.frameskip if self.cfg.summaries_use_frameskip else 1
+        self.env_steps += experience_size * self.world * frameskip
+        stats = {LEARNER_ENV_STEPS: self.env_steps, POLICY_ID_KEY: self.policy_id}
+        if train_stats is not None:
+            stats[TRAIN_STATS] = train_stats
+        return stats

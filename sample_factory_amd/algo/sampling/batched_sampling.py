@@ -1,0 +1,95 @@
+"""Batched rollout on the device — the data path of sample_factory/algo/sampling/batched_sampling.py:298-388
+(BatchedVectorEnvRunner.advance_rollouts / generate_policy_request / _finalize_trajectories) and of
+inference_worker.py:313-341 (InferenceWorker._handle_policy_steps), collapsed into one stream-ordered loop:
+
+  per step t:   policy forward on slab obs[:, t] (in place)          K2+K3  sf_conv_fwd stack
+                sample + write policy outputs into traj[:, t]         K4+K5  sf_sample_write_step
+                env.step -> obs straight into slab obs[:, t+1]        K1     (zero-copy for envs with step_into)
+                rewards/dones/time_outs/policy_id + episode stats     K6     sf_traj_write_env_step
+
+No host synchronisation happens inside a rollout (the reference syncs the device and round-trips dones/rewards to the
+CPU every step: batched_sampling.py:216,323,390-392; torch_utils.py:58-66).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from sample_factory_amd import lib
+from sample_factory_amd.algo.utils.tensor_dict import TensorDict
+
+
+class BatchedVectorEnvRunner:
+    def __init__(self, cfg, env_info, env, actor_critic, traj: TensorDict, policy_id: int = 0,
+                 policy_versions: Optional[torch.Tensor] = None, sample_seed: int = 0):
+        self.cfg, self.env_info, self.env, self.ac = cfg, env_info, env, actor_critic
+        self.traj = traj
+        self.policy_id = policy_id
+        self.policy_versions = policy_versions
+        self.B = env.num_agents
+        self.T = cfg.rollout
+        dev = actor_critic.device
+        self.device = dev
+        assert traj["rewards"].shape == (self.B, self.T), "one slab row per agent (sync mode: one rollout per dataset)"
+        self.env_actions = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.ep_return = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        self.ep_len = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)  # sum_return, sum_len, episodes
+        self.sample_seed = int(sample_seed)
+        self.global_step = 0
+        self.zero_copy = hasattr(env, "step_into")
+        self.obs = traj["obs"]["obs"]
+        self._started = False
+        self.A = actor_critic.num_action_params
+        if getattr(actor_critic.layers[-1].desc, "Cout") != 1 + self.A:
+            raise RuntimeError("heads layout mismatch")
+        if self.env_info.action_space.__class__.__name__ != "Discrete" and not hasattr(self.env_info.action_space, "n"):
+            raise NotImplementedError("native sampler: Discrete action spaces only in this round")
+
+    def reset(self) -> None:
+        """First observation into slab obs[:, 0] (batched_sampling.py:172-206)."""
+        if self.zero_copy:
+            self.env.reset_into(self.obs[:, 0])
+        else:
+            o, _ = self.env.reset()
+            self.obs[:, 0].copy_(torch.as_tensor(o["obs"] if isinstance(o, dict) else o, device=self.device))
+        self._started = True
+
+    def policy_version(self) -> float:
+        return float(self.policy_versions[self.policy_id].item()) if self.policy_versions is not None else 0.0
+
+    def rollout(self, policy_version: Optional[float] = None, deterministic: bool = False) -> None:
+        """Collect cfg.rollout steps for all agents into the slab; leaves obs[:, T] = last observation
+        (_finalize_trajectories, batched_sampling.py:289-296)."""
+        if not self._started:
+            self.reset()
+        tr, T, B, A = self.traj, self.T, self.B, self.A
+        ver = self.policy_version() if policy_version is None else float(policy_version)
+        cfg = self.cfg
+        for t in range(T):
+            heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf")[-1]
+            lib.sample_write_step(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, B, A, T, t, self.sample_seed,
+                                  self.global_step, 0, ver, deterministic, tr["actions"], tr["action_logits"],
+                                  tr["log_prob_actions"], tr["values"], tr["policy_version"], self.env_actions)
+            if self.zero_copy:
+                rew, term, trunc = self.env.step_into(self.env_actions, self.obs[:, t + 1])
+            else:
+                o, rew, term, trunc, _ = self.env.step(self.env_actions)
+                self.obs[:, t + 1].copy_(torch.as_tensor(o["obs"] if isinstance(o, dict) else o, device=self.device))
+                rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
+                term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()
+                trunc = torch.as_tensor(trunc, dtype=torch.bool, device=self.device).contiguous()
+            lib.traj_write_env_step(rew, term, trunc, T, t, cfg.reward_scale, cfg.reward_clip, self.policy_id,
+                                    tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
+                                    self.ep_len, self.ep_stats)
+            self.global_step += 1
+
+    def carry_over(self) -> None:
+        """The next rollout starts from the last observation: slab obs[:, 0] <- obs[:, T] (one frame per agent)."""
+        self.obs[:, 0].copy_(self.obs[:, self.T])
+
+    def episode_stats(self) -> Dict[str, float]:
+        s = self.ep_stats.cpu()
+        n = float(s[2])
+        return dict(episodes=n, mean_return=float(s[0]) / n if n else 0.0, mean_len=float(s[1]) / n if n else 0.0)

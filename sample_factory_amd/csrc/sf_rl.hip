@@ -1,0 +1,950 @@
+// sf_rl.hip — the HBM/latency-bound part of the APPO hot path for gfx950 (MI355X):
+// validity mask, GAE/returns scan, running-mean-std, V-trace, fused PPO loss fwd+bwd, minibatch index sets,
+// grad-norm + Adam, action sampling, trajectory-step writes and the synthetic vector env.
+// Reference op sequences replaced by each kernel are cited in include/sf_hip.h.
+//
+// Compiled with -ffp-contract=off: these kernels keep the reference's fp32 op order (torch CPU/GPU elementwise ops
+// round after every op), so results match the oracle to the last bit wherever libm does.
+#include "sf_common.h"
+
+thread_local char sf_err_buf[512] = "";
+
+extern "C" const char *sf_last_error(void) { return sf_err_buf; }
+extern "C" int sf_abi_version(void) { return 1; }
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// =========================================================================================== K13 validity mask
+__global__ __launch_bounds__(256) void k_valid_mask(const int32_t *__restrict__ policy_id,
+                                                    const float *__restrict__ policy_version,
+                                                    uint8_t *__restrict__ valids, float *__restrict__ actions,
+                                                    int num_actions, float *__restrict__ logp, int E, int T,
+                                                    int my_pid, int train_step, int max_lag,
+                                                    int32_t *__restrict__ num_invalid) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = (int64_t)E * T;
+    const bool in = i < N;
+    bool valid = true;
+    if (in) {
+        const int64_t e = i / T;
+        const int t = (int)(i - e * T);
+        valid = (policy_id[i] == my_pid) && (((float)train_step - policy_version[i]) < (float)max_lag);
+        valids[e * (T + 1) + t] = (uint8_t)valid;
+        if (t == T - 1) valids[e * (T + 1) + T] = (uint8_t)valid;  // learner.py:955
+        if (!valid) {
+            for (int a = 0; a < num_actions; ++a) actions[i * num_actions + a] = 0.0f;
+            logp[i] = -1.0f;
+        }
+    }
+    const unsigned long long b = __ballot(in && !valid);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(num_invalid, (int32_t)__popcll(b));
+}
+
+extern "C" int sf_valid_mask(const int32_t *policy_id, const float *policy_version, uint8_t *valids, float *actions,
+                             int num_actions, float *log_prob_actions, int E, int T, int my_policy_id, int train_step,
+                             int max_policy_lag, int32_t *num_invalid, void *stream) {
+    SF_REQUIRE(E > 0 && T > 0 && num_actions > 0, "sf_valid_mask: bad shape E=%d T=%d na=%d", E, T, num_actions);
+    SF_REQUIRE(policy_id && policy_version && valids && actions && log_prob_actions && num_invalid,
+               "sf_valid_mask: null pointer");
+    int rc = sf_hip_status(hipMemsetAsync(num_invalid, 0, sizeof(int32_t), STREAM(stream)), "sf_valid_mask memset");
+    if (rc) return rc;
+    const int64_t N = (int64_t)E * T;
+    k_valid_mask<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        policy_id, policy_version, valids, actions, num_actions, log_prob_actions, E, T, my_policy_id, train_step,
+        max_policy_lag, num_invalid);
+    return sf_launch_status("sf_valid_mask");
+}
+
+// =========================================================================================== K10+K11 GAE / returns
+// One wavefront owns 64 consecutive envs.  The env-major [E,T] rows are staged through LDS in [64 x 32]-step tiles
+// (row stride 33 words -> the per-lane row walk of the scan is bank-conflict-free) so that every global access is a
+// run of consecutive words across consecutive lanes; the time recursion itself lives in one register per lane.
+constexpr int GAE_TC = 32;
+constexpr int GAE_LD = GAE_TC + 1;
+
+__device__ __forceinline__ void gae_tile_load_f32(float (*s)[GAE_LD], const float *g, int64_t row_stride, int e0,
+                                                  int E, int t0, int ncols, int lane) {
+    for (int idx = lane; idx < 64 * ncols; idx += 64) {
+        const int row = idx / ncols, col = idx - row * ncols;
+        const int e = e0 + row;
+        s[row][col] = (e < E) ? g[(int64_t)e * row_stride + t0 + col] : 0.0f;
+    }
+}
+__device__ __forceinline__ void gae_tile_load_u8(float (*s)[GAE_LD], const uint8_t *g, int64_t row_stride, int e0,
+                                                 int E, int t0, int ncols, int lane) {
+    for (int idx = lane; idx < 64 * ncols; idx += 64) {
+        const int row = idx / ncols, col = idx - row * ncols;
+        const int e = e0 + row;
+        s[row][col] = (e < E && g[(int64_t)e * row_stride + t0 + col]) ? 1.0f : 0.0f;
+    }
+}
+__device__ __forceinline__ void gae_tile_store_f32(const float (*s)[GAE_LD], float *g, int64_t row_stride, int e0,
+                                                   int E, int t0, int ncols, int lane) {
+    for (int idx = lane; idx < 64 * ncols; idx += 64) {
+        const int row = idx / ncols, col = idx - row * ncols;
+        const int e = e0 + row;
+        if (e < E) g[(int64_t)e * row_stride + t0 + col] = s[row][col];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_gae_returns(float *__restrict__ rewards, const uint8_t *__restrict__ dones,
+                                                    const uint8_t *__restrict__ time_outs,
+                                                    const float *__restrict__ values,
+                                                    const uint8_t *__restrict__ valids,
+                                                    const double *__restrict__ rms_stats, int E, int T, float gamma,
+                                                    float gl, int value_bootstrap, float *__restrict__ adv_out,
+                                                    float *__restrict__ ret_out) {
+    __shared__ float s_r[64][GAE_LD], s_v[64][GAE_LD], s_d[64][GAE_LD], s_to[64][GAE_LD], s_va[64][GAE_LD],
+        s_adv[64][GAE_LD], s_ret[64][GAE_LD];
+    const int lane = threadIdx.x;
+    const int e0 = blockIdx.x * 64;
+    const bool denorm = rms_stats != nullptr;
+    float mu = 0.f, sigma = 1.f;
+    if (denorm) {
+        mu = (float)rms_stats[0];
+        sigma = sqrtf((float)rms_stats[1] + 1e-5f);
+    }
+    float cum = 0.0f;
+    for (int t0 = ((T - 1) / GAE_TC) * GAE_TC; t0 >= 0; t0 -= GAE_TC) {
+        const int tc = min(GAE_TC, T - t0);
+        __syncthreads();
+        gae_tile_load_f32(s_r, rewards, T, e0, E, t0, tc, lane);
+        gae_tile_load_u8(s_d, dones, T, e0, E, t0, tc, lane);
+        if (value_bootstrap) gae_tile_load_u8(s_to, time_outs, T, e0, E, t0, tc, lane);
+        gae_tile_load_f32(s_v, values, T + 1, e0, E, t0, tc + 1, lane);
+        gae_tile_load_u8(s_va, valids, T + 1, e0, E, t0, tc + 1, lane);
+        __syncthreads();
+        // per-lane backward scan over this tile (lane = env)
+        for (int c = tc; c >= 0; --c) {  // de-normalise the values of this row first (learner.py:969-979)
+            float v = s_v[lane][c];
+            if (denorm) v = clampf(v, -5.0f, 5.0f) * sigma + mu;
+            s_v[lane][c] = v;
+        }
+        for (int c = tc - 1; c >= 0; --c) {
+            const float v = s_v[lane][c], vn = s_v[lane][c + 1];
+            const float valid = s_va[lane][c], valid_n = s_va[lane][c + 1];
+            const float done = s_d[lane][c];
+            float r = s_r[lane][c];
+            if (value_bootstrap) {  // learner.py:990
+                r = r + ((gamma * v) * s_to[lane][c]) * done;
+                s_r[lane][c] = r;
+            }
+            const float a = (r - v) * valid;
+            const float b = (1.0f - done) * ((gamma * vn) * valid_n);
+            const float delta = a + b;
+            const float disc = gl * valid + (1.0f - valid);
+            cum = delta + (disc * cum) * (1.0f - done);
+            s_adv[lane][c] = cum;
+            s_ret[lane][c] = cum + valid * v;  // learner.py:1003
+        }
+        __syncthreads();
+        gae_tile_store_f32(s_adv, adv_out, T, e0, E, t0, tc, lane);
+        gae_tile_store_f32(s_ret, ret_out, T, e0, E, t0, tc, lane);
+        if (value_bootstrap) gae_tile_store_f32(s_r, rewards, T, e0, E, t0, tc, lane);
+    }
+}
+
+extern "C" int sf_gae_returns(float *rewards, const uint8_t *dones, const uint8_t *time_outs, const float *values,
+                              const uint8_t *valids, const double *rms_stats, int E, int T, float gamma,
+                              float gae_lambda, int value_bootstrap, float *advantages, float *returns,
+                              void *stream) {
+    SF_REQUIRE(E > 0 && T > 0, "sf_gae_returns: bad shape E=%d T=%d", E, T);
+    SF_REQUIRE(rewards && dones && values && valids && advantages && returns, "sf_gae_returns: null pointer");
+    SF_REQUIRE(!value_bootstrap || time_outs, "sf_gae_returns: value_bootstrap needs time_outs");
+    // the reference multiplies the python doubles gamma*lambda before the cast to f32 (rl_utils.py:90)
+    const float gl = (float)((double)gamma * (double)gae_lambda);
+    k_gae_returns<<<dim3((unsigned)((E + 63) / 64)), dim3(64), 0, STREAM(stream)>>>(
+        rewards, dones, time_outs, values, valids, rms_stats, E, T, gamma, gl, value_bootstrap, advantages, returns);
+    return sf_launch_status("sf_gae_returns");
+}
+
+// =========================================================================================== K12 running mean/std
+__global__ __launch_bounds__(256) void k_moments(const float *__restrict__ x, const uint8_t *__restrict__ valids,
+                                                 const int32_t *__restrict__ index, int64_t n,
+                                                 double *__restrict__ moments) {
+    __shared__ double lds[4 * 3];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = index ? (int64_t)index[i] : i;
+        if (!valids || valids[j]) {
+            const double v = (double)x[j];
+            acc[0] += v;
+            acc[1] += v * v;
+            acc[2] += 1.0;
+        }
+    }
+    sf_block_sum<3>(acc, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(&moments[0], acc[0]);
+        atomicAdd(&moments[1], acc[1]);
+        atomicAdd(&moments[2], acc[2]);
+    }
+}
+
+extern "C" int sf_moments(const float *x, const uint8_t *valids, const int32_t *index, int64_t n, double *moments,
+                          void *stream) {
+    SF_REQUIRE(x && moments && n >= 0, "sf_moments: bad args");
+    int rc = sf_hip_status(hipMemsetAsync(moments, 0, 3 * sizeof(double), STREAM(stream)), "sf_moments memset");
+    if (rc || n == 0) return rc;
+    const int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    k_moments<<<dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, STREAM(stream)>>>(x, valids, index, n,
+                                                                                                   moments);
+    return sf_launch_status("sf_moments");
+}
+
+__global__ void k_rms_update(const double *__restrict__ stats_in, const double *__restrict__ moments,
+                             double *__restrict__ stats_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double n = moments[2];
+    const double mean = stats_in[0], var = stats_in[1], count = stats_in[2];
+    if (n <= 0.0) { stats_out[0] = mean; stats_out[1] = var; stats_out[2] = count; return; }
+    // batch mean / unbiased variance are fp32 tensors in the reference (x.mean(), x.var()) -> round to f32
+    const double bm64 = moments[0] / n;
+    const double bv64 = (moments[1] - moments[0] * bm64) / (n - 1.0);
+    const double batch_mean = (double)(float)bm64, batch_var = (double)(float)bv64;
+    const double delta = batch_mean - mean;
+    const double tot = count + n;
+    const double new_mean = mean + delta * n / tot;
+    const double M2 = var * count + batch_var * n + (delta * delta) * count * n / tot;
+    stats_out[0] = new_mean;
+    stats_out[1] = M2 / tot;
+    stats_out[2] = tot;
+}
+
+extern "C" int sf_rms_update(const double *stats_in, const double *moments, double *stats_out, void *stream) {
+    SF_REQUIRE(stats_in && moments && stats_out, "sf_rms_update: null pointer");
+    k_rms_update<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(stats_in, moments, stats_out);
+    return sf_launch_status("sf_rms_update");
+}
+
+__global__ __launch_bounds__(256) void k_rms_apply(float *__restrict__ x, int64_t n,
+                                                   const double *__restrict__ stats, int denormalize) {
+    const float mu = (float)stats[0];
+    const float sigma = sqrtf((float)stats[1] + 1e-5f);
+    const float inv = 1.0f / sigma;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (denormalize) v = clampf(v, -5.0f, 5.0f) * sigma + mu;
+        else v = clampf((v - mu) * inv, -5.0f, 5.0f);
+        x[i] = v;
+    }
+}
+
+extern "C" int sf_rms_apply(float *x, int64_t n, const double *stats, int denormalize, void *stream) {
+    SF_REQUIRE(x && stats && n >= 0, "sf_rms_apply: bad args");
+    if (n == 0) return SF_OK;
+    const int64_t blocks = (n + 255) / 256;
+    k_rms_apply<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, STREAM(stream)>>>(x, n, stats,
+                                                                                                   denormalize);
+    return sf_launch_status("sf_rms_apply");
+}
+
+// =========================================================================================== action distributions
+// log-prob of the taken action under the current policy, for one sample (used by v-trace and the loss head).
+template <int MAXA>
+__device__ __forceinline__ float action_logp(const float *__restrict__ z, int A, int action_kind,
+                                             const float *__restrict__ act_row) {
+    if (action_kind == 0) {
+        float zz[MAXA];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) { zz[k] = k < A ? z[k] : -INFINITY; mx = fmaxf(mx, zz[k]); }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) if (k < A) se += expf(zz[k] - mx);
+        const float lse = logf(se);
+        const int a = (int)act_row[0];
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) if (k == a) r = (zz[k] - mx) - lse;
+        return r;
+    } else {
+        const int D = A / 2;
+        float r = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float mu = z[k], sd = clampf(expf(z[D + k]), 1e-4f, 1e4f);
+            const float a = act_row[k];
+            r += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+        }
+        return r;
+    }
+}
+
+// =========================================================================================== K17 V-trace
+template <int MAXA>
+__global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params, int ldp,
+                                               const float *__restrict__ values, int ldv,
+                                               const float *__restrict__ actions, const float *__restrict__ old_logp,
+                                               const float *__restrict__ rewards, const uint8_t *__restrict__ dones,
+                                               const int32_t *__restrict__ index, int64_t offset, int64_t ntraj, int A,
+                                               int action_kind, int rec, float gamma, float rho_hat, float c_hat,
+                                               float *__restrict__ vs, float *__restrict__ adv) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ntraj) return;
+    const int nact = action_kind == 0 ? 1 : A / 2;
+    const int64_t base = j * rec;
+    const int64_t last = base + rec - 1;
+    const int64_t dl = index ? (int64_t)index[last] : offset + last;
+    float next_values = (values[last * ldv] - rewards[dl]) / gamma;
+    float next_vs = next_values;
+    for (int i = rec - 1; i >= 0; --i) {
+        const int64_t k = base + i;
+        const int64_t d = index ? (int64_t)index[k] : offset + k;
+        const float lp = action_logp<MAXA>(params + k * ldp, A, action_kind, actions + d * nact);
+        const float ratio = clampf(expf(lp - old_logp[d]), 0.05f, 20.0f);  // learner.py:591-594
+        const float rho = fminf(rho_hat, ratio), c = fminf(c_hat, ratio);
+        const float not_done = 1.0f - (dones[d] ? 1.0f : 0.0f);
+        const float ndg = not_done * gamma;
+        const float cv = values[k * ldv], r = rewards[d];
+        const float delta_s = rho * ((r + ndg * next_values) - cv);
+        adv[k] = rho * ((r + ndg * next_vs) - cv);
+        next_vs = (cv + delta_s) + (ndg * c) * (next_vs - next_values);
+        vs[k] = next_vs;
+        next_values = cv;
+    }
+}
+
+extern "C" int sf_vtrace(const float *params, int ld_params, const float *values, int ld_values,
+                         const float *actions, const float *old_logp, const float *rewards, const uint8_t *dones,
+                         const int32_t *index, int64_t offset, int64_t n, int A, int action_kind, int recurrence,
+                         float gamma, float rho_hat, float c_hat, float *vs, float *adv, void *stream) {
+    SF_REQUIRE(ld_params >= A && ld_values >= 1, "sf_vtrace: bad strides");
+    SF_REQUIRE(params && values && actions && old_logp && rewards && dones && vs && adv, "sf_vtrace: null pointer");
+    SF_REQUIRE(recurrence > 0 && n % recurrence == 0, "sf_vtrace: n=%lld not a multiple of recurrence=%d",
+               (long long)n, recurrence);
+    SF_REQUIRE(A > 0 && A <= 128 && (action_kind == 0 || (action_kind == 1 && A % 2 == 0)),
+               "sf_vtrace: unsupported action params A=%d kind=%d", A, action_kind);
+    const int64_t ntraj = n / recurrence;
+    if (ntraj == 0) return SF_OK;
+    const dim3 grid((unsigned)((ntraj + 63) / 64)), block(64);
+#define VT_LAUNCH(M)                                                                                             \
+    k_vtrace<M><<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, rewards, dones, index,    \
+                                                    offset, ntraj, A, action_kind, recurrence, gamma, rho_hat,   \
+                                                    c_hat, vs, adv)
+    if (A <= 8) VT_LAUNCH(8);
+    else if (A <= 32) VT_LAUNCH(32);
+    else VT_LAUNCH(128);
+#undef VT_LAUNCH
+    return sf_launch_status("sf_vtrace");
+}
+
+// =========================================================================================== K16 PPO loss fwd+bwd
+// One lane per sample; the per-sample distribution lives in registers (template MAXA bounds the unrolled loops so no
+// array is indexed dynamically).  Loss sums use wave shuffles -> LDS -> one double atomic per block per quantity.
+struct LossDev {
+    float clip_lo, clip_hi, clip_value, value_coeff, expl_coeff, kl_coeff;
+    int expl_kind, action_kind, dense_adv;
+};
+
+__device__ __forceinline__ void atomic_max_float(double *addr, float v) {
+    // sums[4] holds the running max as a double; KL >= 0 up to rounding, compare on the bit pattern of (v+1) > 0
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+    const double dv = (double)v;
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        if (__longlong_as_double((long long)assumed) >= dv) break;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(dv));
+    } while (assumed != old);
+}
+
+template <int MAXA>
+__global__ __launch_bounds__(256) void k_ppo_loss(const float *__restrict__ params, int ldp,
+                                                  const float *__restrict__ values, int ldv,
+                                                  const float *__restrict__ actions,
+                                                  const float *__restrict__ old_logp,
+                                                  const float *__restrict__ old_params,
+                                                  const float *__restrict__ old_values, const float *__restrict__ adv,
+                                                  const float *__restrict__ targets,
+                                                  const uint8_t *__restrict__ valids,
+                                                  const int32_t *__restrict__ index, int64_t offset, int64_t n, int A,
+                                                  LossDev h, const double *__restrict__ moments,
+                                                  double *__restrict__ sums, float *__restrict__ g_params,
+                                                  float *__restrict__ g_values) {
+    __shared__ double lds[4 * 4];
+    __shared__ float lds_max[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // global (all-reduced) advantage moments -> mean / unbiased std, learner.py:646-647
+    const double mn = moments[2];
+    const double mean64 = moments[0] / mn;
+    const double var64 = (moments[1] - moments[0] * mean64) / (mn - 1.0);
+    const float adv_mean = (float)mean64;
+    const float adv_std = (float)sqrt(var64 > 0.0 ? var64 : (mn > 1.0 ? 0.0 : NAN));
+    const float denom = fmaxf(adv_std, 1e-7f);
+    const float inv_n = 1.0f / (float)mn;
+    // symmetric-KL exploration: clamp(max=30) / non-finite gate need the MEAN; it is passed through moments-like
+    // slot sums[6] by a pre-pass only when that loss is selected (see sf_ppo_loss); gate defaults to open.
+    const float symkl_gate = (h.expl_kind == 2) ? (float)sums[6] : 1.0f;
+
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    float kl_max = -1.0f;
+    if (i < n) {
+        const int64_t d = index ? (int64_t)index[i] : offset + i;
+        const bool valid = valids[d] != 0;
+        const float *z = params + i * ldp;
+        float *gz = g_params + i * ldp;
+        float logp_a = 0.f, ent = 0.f, kl = 0.f, symkl = 0.f;
+        const int D = A / 2;
+        float zz[MAXA], zo[MAXA];
+        float mx = -INFINITY, mxo = -INFINITY, lse = 0.f, lseo = 0.f;
+        int act = 0;
+        if (h.action_kind == 0) {
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k) {
+                zz[k] = k < A ? z[k] : -INFINITY;
+                zo[k] = k < A ? old_params[d * A + k] : -INFINITY;
+                mx = fmaxf(mx, zz[k]);
+                mxo = fmaxf(mxo, zo[k]);
+            }
+            float se = 0.f, seo = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k)
+                if (k < A) { se += expf(zz[k] - mx); seo += expf(zo[k] - mxo); }
+            lse = logf(se);
+            lseo = logf(seo);
+            act = (int)actions[d];
+            const float u = 1.0f / (float)A, lu = logf(u);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k)
+                if (k < A) {
+                    const float lp = (zz[k] - mx) - lse, p = expf(lp), q = (zo[k] - mxo) - lseo;
+                    if (k == act) logp_a = lp;
+                    ent -= p * lp;
+                    kl += p * (lp - q);
+                    a1 += p * (lp - lu);
+                    a2 += u * (lu - lp);
+                }
+            symkl = 0.5f * (a1 + a2);
+        } else {
+            for (int k = 0; k < D; ++k) {
+                const float mu = z[k], sd = clampf(expf(z[D + k]), 1e-4f, 1e4f);
+                const float a = actions[d * D + k];
+                const float var = sd * sd;
+                logp_a += -((a - mu) * (a - mu)) / (2.f * var) - logf(sd) - 0.91893853320467274178f;
+                ent += 0.5f + 0.91893853320467274178f + logf(sd);
+                const float muo = old_params[d * A + k], sdo = clampf(expf(old_params[d * A + D + k]), 1e-4f, 1e4f);
+                const float vr = (sd / sdo) * (sd / sdo);
+                const float t1 = ((mu - muo) / sdo) * ((mu - muo) / sdo);
+                kl += 0.5f * (vr + t1 - 1.f - logf(vr));
+            }
+        }
+        const float raw_ratio = expf(logp_a - old_logp[d]);
+        const float ratio = clampf(raw_ratio, 0.05f, 20.0f);
+        const int64_t da = h.dense_adv ? i : d;
+        const float advn = (adv[da] - adv_mean) / denom;
+        const float clipped = clampf(ratio, h.clip_lo, h.clip_hi);
+        const float lu_ = ratio * advn, lc_ = clipped * advn;
+        const float pl = fminf(lu_, lc_);
+        const float v = values[i * ldv], vo = old_values[d], R = targets[da];
+        const float vclip = vo + clampf(v - vo, -h.clip_value, h.clip_value);
+        const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+        const float vl = fmaxf(l1, l2);
+        if (valid) {
+            acc[0] = pl;
+            acc[1] = (h.expl_kind == 2) ? symkl : ent;
+            acc[2] = kl;
+            acc[3] = vl;
+            kl_max = kl;
+            // ---------------- backward (autograd semantics of min/max ties and clamp boundaries)
+            float dpl_dr;
+            const bool in_clip = ratio >= h.clip_lo && ratio <= h.clip_hi;
+            if (lu_ < lc_) dpl_dr = advn;
+            else if (lu_ > lc_) dpl_dr = in_clip ? advn : 0.f;
+            else dpl_dr = 0.5f * advn + (in_clip ? 0.5f * advn : 0.f);
+            const bool in_hard = raw_ratio >= 0.05f && raw_ratio <= 20.0f;
+            const float dL_dlogp = in_hard ? (-inv_n) * dpl_dr * raw_ratio : 0.f;
+            if (h.action_kind == 0) {
+                const float u = 1.0f / (float)A, lu = logf(u);
+                float klpu = 0.f;
+                if (h.expl_kind == 2) {
+#pragma unroll
+                    for (int k = 0; k < MAXA; ++k)
+                        if (k < A) { const float lp = (zz[k] - mx) - lse; klpu += expf(lp) * (lp - lu); }
+                }
+#pragma unroll
+                for (int k = 0; k < MAXA; ++k)
+                    if (k < A) {
+                        const float lp = (zz[k] - mx) - lse, p = expf(lp), q = (zo[k] - mxo) - lseo;
+                        float gk = dL_dlogp * ((k == act ? 1.f : 0.f) - p);
+                        if (h.expl_kind == 1) gk += h.expl_coeff * inv_n * (p * (lp + ent));
+                        if (h.expl_kind == 2)
+                            gk += symkl_gate * h.expl_coeff * inv_n * 0.5f * (p * ((lp - lu) - klpu) + p - u);
+                        if (h.kl_coeff != 0.f) gk += h.kl_coeff * inv_n * (p * ((lp - q) - kl));
+                        gz[k] = gk;
+                    }
+            } else {
+                for (int k = 0; k < D; ++k) {
+                    const float mu = z[k], e = expf(z[D + k]);
+                    const float sd = clampf(e, 1e-4f, 1e4f);
+                    const float dsd = (e >= 1e-4f && e <= 1e4f) ? e : 0.f;
+                    const float a = actions[d * D + k];
+                    const float var = sd * sd;
+                    float gmu = dL_dlogp * ((a - mu) / var);
+                    float gsd = dL_dlogp * (((a - mu) * (a - mu)) / (var * sd) - 1.f / sd);
+                    if (h.expl_kind == 1) gsd += -h.expl_coeff * inv_n * (1.f / sd);
+                    if (h.kl_coeff != 0.f) {
+                        const float muo = old_params[d * A + k];
+                        const float sdo = clampf(expf(old_params[d * A + D + k]), 1e-4f, 1e4f);
+                        gmu += h.kl_coeff * inv_n * ((mu - muo) / (sdo * sdo));
+                        gsd += h.kl_coeff * inv_n * (sd / (sdo * sdo) - 1.f / sd);
+                    }
+                    gz[k] = gmu;
+                    gz[D + k] = gsd * dsd;
+                }
+            }
+            const bool in_v = (v - vo) >= -h.clip_value && (v - vo) <= h.clip_value;
+            float dvl;
+            if (l1 > l2) dvl = 2.f * (v - R);
+            else if (l2 > l1) dvl = in_v ? 2.f * (vclip - R) : 0.f;
+            else dvl = (v - R) + (in_v ? (vclip - R) : 0.f);
+            g_values[i * ldv] = h.value_coeff * inv_n * dvl;
+        } else {
+            for (int k = 0; k < A; ++k) gz[k] = 0.f;
+            g_values[i * ldv] = 0.f;
+        }
+    }
+    // block reduction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    kl_max = sf_wave_max(kl_max);
+    if (lane == 0) lds_max[wave] = kl_max;
+    sf_block_sum<4>(acc, lds);  // contains a __syncthreads()
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], acc[0]);
+        atomicAdd(&sums[1], acc[1]);
+        atomicAdd(&sums[2], acc[2]);
+        atomicAdd(&sums[3], acc[3]);
+        const float m = fmaxf(fmaxf(lds_max[0], lds_max[1]), fmaxf(lds_max[2], lds_max[3]));
+        if (m > -1.0f) atomic_max_float(&sums[4], m);
+    }
+}
+
+// pre-pass for the symmetric-KL exploration loss: mean over valid samples decides clamp(max=30) / isfinite gate
+template <int MAXA>
+__global__ __launch_bounds__(256) void k_symkl_sum(const float *__restrict__ params, int ldp,
+                                                   const uint8_t *__restrict__ valids,
+                                                   const int32_t *__restrict__ index, int64_t offset, int64_t n, int A,
+                                                   double *__restrict__ out) {
+    __shared__ double lds[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[1] = {0.0};
+    if (i < n) {
+        const int64_t d = index ? (int64_t)index[i] : offset + i;
+        if (valids[d]) {
+            const float *z = params + i * ldp;
+            float zz[MAXA];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k) { zz[k] = k < A ? z[k] : -INFINITY; mx = fmaxf(mx, zz[k]); }
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k) if (k < A) se += expf(zz[k] - mx);
+            const float lse = logf(se), u = 1.0f / (float)A, lu = logf(u);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k)
+                if (k < A) { const float lp = (zz[k] - mx) - lse; a1 += expf(lp) * (lp - lu); a2 += u * (lu - lp); }
+            acc[0] = 0.5f * (a1 + a2);
+        }
+    }
+    sf_block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) atomicAdd(out, acc[0]);
+}
+
+__global__ void k_symkl_gate(double *__restrict__ sums, const double *__restrict__ moments) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float m = (float)(sums[7] / moments[2]);
+    sums[6] = (isfinite(m) && m <= 30.0f) ? 1.0 : 0.0;
+}
+
+static LossDev make_loss_dev(const sf_loss_cfg *c) {
+    LossDev h;
+    h.clip_hi = (float)(1.0 + (double)c->clip_ratio);
+    h.clip_lo = (float)(1.0 / (1.0 + (double)c->clip_ratio));
+    h.clip_value = c->clip_value;
+    h.value_coeff = c->value_loss_coeff;
+    h.expl_coeff = c->exploration_coeff;
+    h.kl_coeff = c->kl_coeff;
+    h.expl_kind = c->exploration_coeff == 0.f ? 0 : c->exploration_kind;
+    h.action_kind = c->action_kind;
+    h.dense_adv = c->dense_adv;
+    return h;
+}
+
+extern "C" int sf_ppo_loss(const float *params, int ld_params, const float *values, int ld_values,
+                           const float *actions, const float *old_logp, const float *old_params,
+                           const float *old_values, const float *adv, const float *targets, const uint8_t *valids,
+                           const int32_t *index, int64_t offset, int64_t n, int A, const sf_loss_cfg *h_cfg,
+                           const double *moments, double *sums, float *g_params, float *g_values, void *stream) {
+    SF_REQUIRE(ld_params >= A && ld_values >= 1, "sf_ppo_loss: bad strides");
+    SF_REQUIRE(params && values && actions && old_logp && old_params && old_values && adv && targets && valids &&
+                   h_cfg && moments && sums && g_params && g_values,
+               "sf_ppo_loss: null pointer");
+    SF_REQUIRE(n > 0 && A > 0 && A <= 128, "sf_ppo_loss: bad shape n=%lld A=%d", (long long)n, A);
+    SF_REQUIRE(h_cfg->action_kind == 0 || (h_cfg->action_kind == 1 && A % 2 == 0), "sf_ppo_loss: bad action_kind");
+    SF_REQUIRE(!(h_cfg->exploration_kind == 2 && h_cfg->action_kind != 0 && h_cfg->exploration_coeff != 0.f),
+               "sf_ppo_loss: symmetric_kl exploration loss needs a categorical distribution");
+    const LossDev h = make_loss_dev(h_cfg);
+    int rc = sf_hip_status(hipMemsetAsync(sums, 0, 8 * sizeof(double), STREAM(stream)), "sf_ppo_loss memset");
+    if (rc) return rc;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define PL_DISPATCH(KERNEL, ...)                                                        \
+    do {                                                                                \
+        if (A <= 8) KERNEL<8><<<grid, block, 0, STREAM(stream)>>>(__VA_ARGS__);         \
+        else if (A <= 32) KERNEL<32><<<grid, block, 0, STREAM(stream)>>>(__VA_ARGS__);  \
+        else KERNEL<128><<<grid, block, 0, STREAM(stream)>>>(__VA_ARGS__);              \
+    } while (0)
+    if (h.expl_kind == 2) {
+        PL_DISPATCH(k_symkl_sum, params, ld_params, valids, index, offset, n, A, sums + 7);
+        k_symkl_gate<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(sums, moments);
+    }
+    PL_DISPATCH(k_ppo_loss, params, ld_params, values, ld_values, actions, old_logp, old_params, old_values, adv, targets, valids, index,
+                offset, n, A, h, moments, sums, g_params, g_values);
+#undef PL_DISPATCH
+    return sf_launch_status("sf_ppo_loss");
+}
+
+__global__ void k_loss_scalars(const double *__restrict__ sums, const double *__restrict__ moments, LossDev h,
+                               float *__restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    const double n = moments[2];
+    const double mean64 = moments[0] / n;
+    const double var64 = (moments[1] - moments[0] * mean64) / (n - 1.0);
+    out[0] = (float)(-(sums[0] / n));
+    if (h.expl_kind == 1) out[1] = (float)(-(double)h.expl_coeff * (sums[1] / n));
+    else if (h.expl_kind == 2) {
+        float m = (float)(sums[1] / n);
+        if (!isfinite(m)) m = 0.f;
+        out[1] = h.expl_coeff * fminf(m, 30.0f);
+    } else out[1] = 0.f;
+    out[2] = (float)((double)h.kl_coeff * (sums[2] / n));
+    out[3] = (float)((double)h.value_coeff * (sums[3] / n));
+    out[4] = (float)(sums[2] / n);
+    out[5] = (float)sums[4];
+    out[6] = (float)mean64;
+    out[7] = (float)sqrt(var64 > 0.0 ? var64 : 0.0);
+    out[8] = (float)n;
+    out[9] = (float)(sums[1] / n);
+}
+
+extern "C" int sf_loss_scalars(const double *sums, const double *moments, const sf_loss_cfg *h_cfg, float *out,
+                               void *stream) {
+    SF_REQUIRE(sums && moments && h_cfg && out, "sf_loss_scalars: null pointer");
+    k_loss_scalars<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(sums, moments, make_loss_dev(h_cfg), out);
+    return sf_launch_status("sf_loss_scalars");
+}
+
+// =========================================================================================== K14 minibatch indices
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+// bijection on [0, 2^(2*half)) : 4-round balanced Feistel
+__device__ __forceinline__ uint32_t feistel(uint32_t x, int half, uint32_t key) {
+    const uint32_t mask = (1u << half) - 1u;
+    uint32_t l = x >> half, r = x & mask;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const uint32_t f = mix32(r ^ (key + 0x9E3779B9u * (uint32_t)(round + 1))) & mask;
+        const uint32_t nl = r, nr = l ^ f;
+        l = nl; r = nr;
+    }
+    return (l << half) | r;
+}
+
+__global__ __launch_bounds__(256) void k_minibatch_indices(int32_t *__restrict__ out, int64_t n_chunks, int rec,
+                                                           int shuffle, int half, uint32_t key) {
+    const int64_t wave_first = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63;  // first chunk of wave
+    const int lane = threadIdx.x & 63;
+    const int64_t j = wave_first + lane;
+    uint32_t start = 0;
+    if (j < n_chunks) {
+        uint32_t x = (uint32_t)j;
+        if (shuffle) {
+            do { x = feistel(x, half, key); } while ((int64_t)x >= n_chunks);  // cycle walking keeps it a bijection
+        }
+        start = x;
+    }
+    // expansion: the wave's 64 chunk starts are exchanged with wave shuffles so that the 64*rec output words are
+    // written as fully coalesced runs (lane l writes word q*64+l of the wave's output span).
+    const int64_t out_base = wave_first * rec;
+    for (int q = 0; q < rec; ++q) {
+        const int w = q * 64 + lane;
+        const int src_lane = w / rec, r = w - src_lane * rec;
+        const uint32_t s = __shfl(start, src_lane, 64);
+        if (wave_first + src_lane < n_chunks) out[out_base + w] = (int32_t)(s * (uint32_t)rec + (uint32_t)r);
+    }
+}
+
+extern "C" int sf_minibatch_indices(int32_t *out, int64_t experience_size, int recurrence, int shuffle, uint32_t seed,
+                                    uint32_t epoch, void *stream) {
+    SF_REQUIRE(out && experience_size > 0 && recurrence > 0 && experience_size % recurrence == 0,
+               "sf_minibatch_indices: experience_size=%lld recurrence=%d", (long long)experience_size, recurrence);
+    SF_REQUIRE(experience_size < (1LL << 31), "sf_minibatch_indices: experience too large for int32 indices");
+    const int64_t n_chunks = experience_size / recurrence;
+    int bits = 1;
+    while ((1LL << bits) < n_chunks) ++bits;
+    const int half = (bits + 1) / 2;
+    const uint32_t key = seed * 0x9E3779B1u + epoch * 0x85EBCA77u + 0x165667B1u;
+    k_minibatch_indices<<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        out, n_chunks, recurrence, shuffle, half, key);
+    return sf_launch_status("sf_minibatch_indices");
+}
+
+// =========================================================================================== K18/K19 clip + Adam
+__global__ __launch_bounds__(256) void k_grad_sumsq(const float *__restrict__ g, int64_t P,
+                                                    double *__restrict__ sumsq) {
+    __shared__ double lds[4];
+    double acc[1] = {0.0};
+    const int64_t nvec = P / 4;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < nvec; i += nt) {
+        const float4 v = g4[i];
+        acc[0] += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int64_t i = nvec * 4 + tid; i < P; i += nt) acc[0] += (double)g[i] * g[i];
+    sf_block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) atomicAdd(sumsq, acc[0]);
+}
+
+extern "C" int sf_grad_sumsq(const float *g, int64_t P, double *sumsq, void *stream) {
+    SF_REQUIRE(g && sumsq && P > 0, "sf_grad_sumsq: bad args");
+    SF_REQUIRE(((uintptr_t)g & 15) == 0, "sf_grad_sumsq: gradient buffer must be 16-byte aligned");
+    int rc = sf_hip_status(hipMemsetAsync(sumsq, 0, sizeof(double), STREAM(stream)), "sf_grad_sumsq memset");
+    if (rc) return rc;
+    const int64_t blocks = (P / 4 + 255) / 256;
+    k_grad_sumsq<<<dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024)), dim3(256), 0, STREAM(stream)>>>(
+        g, P, sumsq);
+    return sf_launch_status("sf_grad_sumsq");
+}
+
+struct AdamC {
+    float lr_step, bc2_sqrt, w1, b2, w2, eps, max_norm, grad_scale;
+};
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamC &c, float coef) {
+    g = g * coef;
+    m = m + (g - m) * c.w1;
+    v = v * c.b2 + (g * g) * c.w2;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = p - c.lr_step * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
+                                              float *__restrict__ m, float *__restrict__ v, int64_t P, AdamC c,
+                                              const double *__restrict__ sumsq) {
+    float coef = c.grad_scale;
+    if (sumsq && c.max_norm > 0.f) {
+        // clip_grad_norm_: total_norm of the (already grad_scale'd) gradient
+        const float total = (float)sqrt(*sumsq) * fabsf(c.grad_scale);
+        const float cc = c.max_norm / (total + 1e-6f);
+        coef = c.grad_scale * fminf(cc, 1.0f);
+    }
+    const int64_t nvec = P / 4;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (int64_t i = tid; i < nvec; i += nt) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, c, coef);
+        adam1(pp.y, gg.y, mm.y, vv.y, c, coef);
+        adam1(pp.z, gg.z, mm.z, vv.z, c, coef);
+        adam1(pp.w, gg.w, mm.w, vv.w, c, coef);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    for (int64_t i = nvec * 4 + tid; i < P; i += nt) adam1(p[i], g[i], m[i], v[i], c, coef);
+}
+
+extern "C" int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
+                            float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale,
+                            void *stream) {
+    SF_REQUIRE(p && g && m && v && P > 0 && step >= 1, "sf_adam_step: bad args");
+    SF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+               "sf_adam_step: buffers must be 16-byte aligned");
+    AdamC c;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    c.lr_step = (float)((double)lr / bc1);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.w1 = (float)(1.0 - (double)beta1);
+    c.b2 = beta2;
+    c.w2 = (float)(1.0 - (double)beta2);
+    c.eps = eps;
+    c.max_norm = max_grad_norm;
+    c.grad_scale = grad_scale;
+    const int64_t blocks = (P / 4 + 255) / 256;
+    k_adam<<<dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, STREAM(stream)>>>(
+        p, g, m, v, P, c, sumsq);
+    return sf_launch_status("sf_adam_step");
+}
+
+// =========================================================================================== K4/K5 sample + write
+template <int MAXA>
+__global__ __launch_bounds__(256) void k_sample_write(const float *__restrict__ logits, int ldl,
+                                                      const float *__restrict__ values, int ldv, int B, int A, int T, int t,
+                                                      uint32_t seed, uint32_t step, uint32_t row0, float version,
+                                                      int deterministic, float *__restrict__ t_actions,
+                                                      float *__restrict__ t_logits, float *__restrict__ t_logp,
+                                                      float *__restrict__ t_values, float *__restrict__ t_version,
+                                                      int32_t *__restrict__ env_actions) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *z = logits + (int64_t)b * ldl;
+    float zz[MAXA];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) { zz[k] = k < A ? z[k] : -INFINITY; mx = fmaxf(mx, zz[k]); }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) if (k < A) se += expf(zz[k] - mx);
+    const float lse = logf(se);
+    int a = A - 1;
+    if (deterministic) {
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) if (k < A && !found && zz[k] == mx) { a = k; found = true; }
+    } else {
+        uint32_t w[4];
+        sf_philox4x32_10(step, 0u, 2u, 0u, seed, row0 + (uint32_t)b, w);
+        const float u = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+        float acc = 0.f;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k)
+            if (k < A && !found) {
+                acc += expf((zz[k] - mx) - lse);
+                if (u < acc) { a = k; found = true; }
+            }
+    }
+    float lp = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) if (k == a) lp = (zz[k] - mx) - lse;
+    const int64_t it = (int64_t)b * T + t;
+    t_actions[it] = (float)a;
+    t_logp[it] = lp;
+    t_version[it] = version;
+    t_values[(int64_t)b * (T + 1) + t] = values[(int64_t)b * ldv];
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) if (k < A) t_logits[it * A + k] = zz[k];
+    env_actions[b] = a;
+}
+
+extern "C" int sf_sample_write_step(const float *logits, int ld_logits, const float *values, int ld_values, int B,
+                                    int A, int T, int t, uint32_t seed, uint32_t step, uint32_t row0, float policy_version,
+                                    int deterministic, float *traj_actions, float *traj_logits, float *traj_logp,
+                                    float *traj_values, float *traj_policy_version, int32_t *env_actions,
+                                    void *stream) {
+    SF_REQUIRE(logits && values && traj_actions && traj_logits && traj_logp && traj_values && traj_policy_version &&
+                   env_actions,
+               "sf_sample_write_step: null pointer");
+    SF_REQUIRE(B > 0 && A > 0 && A <= 128 && T > 0 && t >= 0 && t < T, "sf_sample_write_step: bad shape B=%d A=%d T=%d t=%d",
+               B, A, T, t);
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+#define SW_LAUNCH(M)                                                                                               \
+    k_sample_write<M><<<grid, block, 0, STREAM(stream)>>>(logits, ld_logits, values, ld_values, B, A, T, t, seed, step, row0,            \
+                                                          policy_version, deterministic, traj_actions, traj_logits, \
+                                                          traj_logp, traj_values, traj_policy_version, env_actions)
+    if (A <= 8) SW_LAUNCH(8);
+    else if (A <= 32) SW_LAUNCH(32);
+    else SW_LAUNCH(128);
+#undef SW_LAUNCH
+    return sf_launch_status("sf_sample_write_step");
+}
+
+// =========================================================================================== K1/K6 env step -> traj
+__global__ __launch_bounds__(256) void k_traj_write_env(const float *__restrict__ rewards,
+                                                        const uint8_t *__restrict__ terminated,
+                                                        const uint8_t *__restrict__ truncated, int B, int T, int t,
+                                                        float scale, float clip, int pid,
+                                                        float *__restrict__ t_rewards, uint8_t *__restrict__ t_dones,
+                                                        uint8_t *__restrict__ t_timeouts, int32_t *__restrict__ t_pid,
+                                                        float *__restrict__ ep_ret, int32_t *__restrict__ ep_len,
+                                                        double *__restrict__ ep_stats) {
+    __shared__ double lds[4 * 3];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (b < B) {
+        const float raw = rewards[b];
+        const bool term = terminated[b] != 0, trunc = truncated ? truncated[b] != 0 : false;
+        const bool done = term || trunc;
+        const int64_t it = (int64_t)b * T + t;
+        t_rewards[it] = clampf(raw * scale, -clip, clip);  // batched_sampling.py:208-213
+        t_dones[it] = (uint8_t)done;
+        t_timeouts[it] = (uint8_t)trunc;
+        t_pid[it] = pid;
+        if (ep_ret) {
+            const float r = ep_ret[b] + raw;  // episode stats use the raw reward (batched_sampling.py:216-219)
+            const int l = ep_len[b] + 1;
+            if (done) { acc[0] = r; acc[1] = (double)l; acc[2] = 1.0; ep_ret[b] = 0.f; ep_len[b] = 0; }
+            else { ep_ret[b] = r; ep_len[b] = l; }
+        }
+    }
+    if (ep_stats) {
+        sf_block_sum<3>(acc, lds);
+        if (threadIdx.x == 0 && acc[2] > 0.0) {
+            atomicAdd(&ep_stats[0], acc[0]);
+            atomicAdd(&ep_stats[1], acc[1]);
+            atomicAdd(&ep_stats[2], acc[2]);
+        }
+    }
+}
+
+extern "C" int sf_traj_write_env_step(const float *rewards, const uint8_t *terminated, const uint8_t *truncated, int B,
+                                      int T, int t, float reward_scale, float reward_clip, int policy_id,
+                                      float *traj_rewards, uint8_t *traj_dones, uint8_t *traj_time_outs,
+                                      int32_t *traj_policy_id, float *ep_return, int32_t *ep_len, double *ep_stats,
+                                      void *stream) {
+    SF_REQUIRE(rewards && terminated && traj_rewards && traj_dones && traj_time_outs && traj_policy_id,
+               "sf_traj_write_env_step: null pointer");
+    SF_REQUIRE(B > 0 && T > 0 && t >= 0 && t < T, "sf_traj_write_env_step: bad shape");
+    SF_REQUIRE((ep_return == nullptr) == (ep_len == nullptr), "sf_traj_write_env_step: ep_return/ep_len mismatch");
+    k_traj_write_env<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        rewards, terminated, truncated, B, T, t, reward_scale, reward_clip, policy_id, traj_rewards, traj_dones,
+        traj_time_outs, traj_policy_id, ep_return, ep_len, ep_stats);
+    return sf_launch_status("sf_traj_write_env_step");
+}
+
+// =========================================================================================== synthetic env
+__global__ __launch_bounds__(256) void k_synth_obs(uint8_t *__restrict__ obs, int64_t env_stride, int B, int env0,
+                                                   int64_t blocks_per_env, uint32_t seed, uint32_t step) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)B * blocks_per_env) return;
+    const int64_t e = gid / blocks_per_env, blk = gid - e * blocks_per_env;
+    uint32_t w[4];
+    sf_philox4x32_10(step, (uint32_t)blk, 0u, 0u, seed, (uint32_t)(env0 + e), w);
+    *reinterpret_cast<uint4 *>(obs + e * env_stride + blk * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+extern "C" int sf_synth_obs(uint8_t *obs, int64_t env_stride, int B, int env0, int64_t obs_bytes, uint32_t seed,
+                            uint32_t step, void *stream) {
+    SF_REQUIRE(obs && B > 0 && obs_bytes > 0 && obs_bytes % 16 == 0 && env_stride % 16 == 0 &&
+                   ((uintptr_t)obs & 15) == 0,
+               "sf_synth_obs: obs_bytes/env_stride/base must be multiples of 16");
+    const int64_t total = (int64_t)B * (obs_bytes / 16);
+    k_synth_obs<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(obs, env_stride, B, env0,
+                                                                                         obs_bytes / 16, seed, step);
+    return sf_launch_status("sf_synth_obs");
+}
+
+__global__ __launch_bounds__(256) void k_synth_step(const int32_t *__restrict__ actions, int B, int env0,
+                                                    int num_actions, uint32_t seed, uint32_t step,
+                                                    float *__restrict__ rewards, uint8_t *__restrict__ terminated) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t env = (uint32_t)(env0 + b);
+    rewards[b] = (actions[b] == (int32_t)((step + env) % (uint32_t)num_actions)) ? 1.0f : 0.0f;
+    uint32_t w[4];
+    sf_philox4x32_10(step, 0u, 1u, 0u, seed, env, w);
+    terminated[b] = (uint8_t)(w[0] < (1u << 22));
+}
+
+extern "C" int sf_synth_step(const int32_t *actions, int B, int env0, int num_actions, uint32_t seed, uint32_t step,
+                             float *rewards, uint8_t *terminated, void *stream) {
+    SF_REQUIRE(actions && rewards && terminated && B > 0 && num_actions > 0, "sf_synth_step: bad args");
+    k_synth_step<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(actions, B, env0, num_actions,
+                                                                                      seed, step, rewards, terminated);
+    return sf_launch_status("sf_synth_step");
+}

@@ -1,0 +1,74 @@
+"""Synthetic device-resident vector env (SURVEY.md §8d "C2 synthetic inputs"): N agents, u8 [C,H,W] frames from a
+counter-based Philox4x32-10 stream, reward 1 when action == (step + env_id) % num_actions, Bernoulli(1/1024)
+termination.  To Sample Factory it looks like the reference's GPU envs (brax / isaacgym: `num_agents=N`, tensors on
+the device, auto-reset; sf_examples/brax/train_brax.py:160-204).  Additionally it implements the zero-copy hook
+`step_into(actions, obs_out)`: the frame generator writes straight into slot t+1 of the trajectory slab (K1).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from sample_factory_amd import lib
+from sample_factory_amd.envs import spaces
+
+
+class SyntheticVecEnv:
+    def __init__(self, num_agents=4096, obs_shape=(4, 84, 84), num_actions=6, seed=0, env0=0, device="cuda"):
+        self.num_agents = int(num_agents)
+        self.obs_shape = tuple(obs_shape)
+        self.obs_bytes = int(np.prod(obs_shape))
+        assert self.obs_bytes % 16 == 0, "frame size must be a multiple of 16 bytes"
+        self.observation_space = spaces.Dict({"obs": spaces.Box(0, 255, self.obs_shape, np.uint8)})
+        self.action_space = spaces.Discrete(num_actions)
+        self.num_actions = num_actions
+        self.seed_, self.env0 = int(seed), int(env0)
+        self.device = torch.device(device)
+        self.step_count = 0
+        self._rew = torch.zeros(self.num_agents, dtype=torch.float32, device=self.device)
+        self._term = torch.zeros(self.num_agents, dtype=torch.bool, device=self.device)
+        self._trunc = torch.zeros(self.num_agents, dtype=torch.bool, device=self.device)
+        self._obs = None
+
+    # -- zero-copy interface used by the native rollout runner
+    def write_obs(self, obs_out: torch.Tensor) -> None:
+        """obs_out: [N, C, H, W] u8 view (possibly strided over dim 0, e.g. slab[:, t])."""
+        assert obs_out.dtype == torch.uint8 and obs_out.is_cuda and obs_out.shape[0] == self.num_agents
+        assert obs_out[0].is_contiguous()
+        lib.synth_obs(obs_out.data_ptr(), obs_out.stride(0), self.num_agents, self.env0, self.obs_bytes, self.seed_,
+                      self.step_count)
+
+    def reset_into(self, obs_out: torch.Tensor) -> None:
+        self.step_count = 0
+        self.write_obs(obs_out)
+
+    def step_into(self, actions: torch.Tensor, obs_out: torch.Tensor):
+        """actions int32 [N] on device. Returns (rewards f32, terminated bool, truncated bool) device tensors."""
+        lib.synth_step(actions, self.env0, self.num_actions, self.seed_, self.step_count, self._rew, self._term)
+        self.step_count += 1
+        self.write_obs(obs_out)
+        return self._rew, self._term, self._trunc
+
+    # -- gymnasium-style interface (what a stock Sample Factory runner would call; make_env.py:147-237)
+    def reset(self, **kwargs):
+        if self._obs is None:
+            self._obs = torch.empty((self.num_agents,) + self.obs_shape, dtype=torch.uint8, device=self.device)
+        self.reset_into(self._obs)
+        return {"obs": self._obs}, {}
+
+    def step(self, actions):
+        if self._obs is None:
+            self.reset()
+        a = torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(-1).contiguous()
+        rew, term, trunc = self.step_into(a, self._obs)
+        return {"obs": self._obs}, rew, term, trunc, {}
+
+    def close(self):
+        pass
+
+
+def make_synthetic_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    n = getattr(cfg, "synthetic_num_agents", 4096) if cfg is not None else 4096
+    seed = (getattr(cfg, "seed", None) or 0) if cfg is not None else 0
+    env0 = getattr(cfg, "synthetic_env0", 0) if cfg is not None else 0
+    return SyntheticVecEnv(num_agents=n, seed=seed, env0=env0)

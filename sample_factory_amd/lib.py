@@ -1,0 +1,285 @@
+"""ctypes binding of libsf_hip.so (C ABI: include/sf_hip.h).
+
+PyTorch is plumbing only: it owns device memory (the caching allocator) and the stream; every call below hands raw
+device pointers + the current HIP stream to the library.  There is no fallback: a missing library or a non-GPU tensor
+raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsf_hip.so")
+
+
+class SfHipError(RuntimeError):
+    pass
+
+
+class sf_loss_cfg(C.Structure):
+    _fields_ = [("clip_ratio", C.c_float), ("clip_value", C.c_float), ("value_loss_coeff", C.c_float),
+                ("exploration_coeff", C.c_float), ("kl_coeff", C.c_float), ("exploration_kind", C.c_int32),
+                ("action_kind", C.c_int32), ("dense_adv", C.c_int32)]
+
+
+class sf_conv_desc(C.Structure):
+    _fields_ = [("Cin", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32),
+                ("KW", C.c_int32), ("stride", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+                ("in_u8", C.c_int32), ("relu", C.c_int32), ("traj_T", C.c_int32), ("sub_mean", C.c_float),
+                ("inv_scale", C.c_float)]
+
+
+# every symbol include/sf_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = [
+    "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
+    "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
+    "sf_adam_step", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
+    "sf_conv_fwd", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_linear_fwd",
+    "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or fail loudly (no CPU path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SfHipError(
+                f"{LIB_PATH} not found: build it with `python -m sample_factory_amd.build` (hipcc, gfx950). "
+                "sample_factory_amd has no CPU/PyTorch fallback for the hot path.")
+        lib = C.CDLL(LIB_PATH)
+        lib.sf_last_error.restype = C.c_char_p
+        lib.sf_conv_wgrad_workspace.restype = C.c_int64
+        lib.sf_linear_wgrad_workspace.restype = C.c_int64
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise SfHipError(f"{what} failed ({rc}): {load().sf_last_error().decode()}")
+
+
+_DT = {"f32": torch.float32, "f64": torch.float64, "i32": torch.int32, "u8": (torch.uint8, torch.bool)}
+
+
+def ptr(t: Optional[torch.Tensor], kind: str, name: str = "tensor") -> C.c_void_p:
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    want = _DT[kind]
+    ok = t.dtype in want if isinstance(want, tuple) else t.dtype == want
+    if not ok:
+        raise SfHipError(f"{name}: expected dtype {kind}, got {t.dtype}")
+    if not t.is_cuda:
+        raise SfHipError(f"{name}: tensor lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
+    if not t.is_contiguous():
+        raise SfHipError(f"{name}: tensor must be contiguous (shape {tuple(t.shape)}, strides {t.stride()})")
+    return C.c_void_p(t.data_ptr())
+
+
+def _raw(t: torch.Tensor, kind: str, name: str) -> C.c_void_p:
+    """Device pointer of a possibly STRIDED view (the callee is told the stride explicitly)."""
+    want = _DT[kind]
+    if t.dtype != want:
+        raise SfHipError(f"{name}: expected dtype {kind}, got {t.dtype}")
+    if not t.is_cuda:
+        raise SfHipError(f"{name}: tensor lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f(x) -> C.c_float:
+    return C.c_float(float(x))
+
+
+def i64(x) -> C.c_int64:
+    return C.c_int64(int(x))
+
+
+def u32(x) -> C.c_uint32:
+    return C.c_uint32(int(x) & 0xFFFFFFFF)
+
+
+# ------------------------------------------------------------------------------------------------ thin wrappers
+def valid_mask(policy_id, policy_version, valids, actions, num_actions, log_prob_actions, my_policy_id, train_step,
+               max_policy_lag, num_invalid) -> None:
+    E, T = policy_id.shape
+    _check(load().sf_valid_mask(ptr(policy_id, "i32", "policy_id"), ptr(policy_version, "f32", "policy_version"),
+                                ptr(valids, "u8", "valids"), ptr(actions, "f32", "actions"), int(num_actions),
+                                ptr(log_prob_actions, "f32", "log_prob_actions"), E, T, int(my_policy_id),
+                                int(train_step), int(max_policy_lag), ptr(num_invalid, "i32", "num_invalid"),
+                                stream()), "sf_valid_mask")
+
+
+def gae_returns(rewards, dones, time_outs, values, valids, rms_stats, gamma, gae_lambda, value_bootstrap, advantages,
+                returns) -> None:
+    E, T = rewards.shape
+    assert values.shape == (E, T + 1) and valids.shape == (E, T + 1)
+    _check(load().sf_gae_returns(ptr(rewards, "f32", "rewards"), ptr(dones, "u8", "dones"),
+                                 ptr(time_outs, "u8", "time_outs"), ptr(values, "f32", "values"),
+                                 ptr(valids, "u8", "valids"), ptr(rms_stats, "f64", "rms_stats"), E, T, f(gamma),
+                                 f(gae_lambda), int(bool(value_bootstrap)), ptr(advantages, "f32", "advantages"),
+                                 ptr(returns, "f32", "returns"), stream()), "sf_gae_returns")
+
+
+def moments(x, valids, index, n, out) -> None:
+    _check(load().sf_moments(ptr(x, "f32", "x"), ptr(valids, "u8", "valids"), ptr(index, "i32", "index"), i64(n),
+                             ptr(out, "f64", "moments"), stream()), "sf_moments")
+
+
+def rms_update(stats_in, mom, stats_out) -> None:
+    _check(load().sf_rms_update(ptr(stats_in, "f64"), ptr(mom, "f64"), ptr(stats_out, "f64"), stream()),
+           "sf_rms_update")
+
+
+def rms_apply(x, stats, denormalize: bool) -> None:
+    _check(load().sf_rms_apply(ptr(x, "f32", "x"), i64(x.numel()), ptr(stats, "f64"), int(bool(denormalize)),
+                               stream()), "sf_rms_apply")
+
+
+def vtrace(params, ld_params, values, ld_values, actions, old_logp, rewards, dones, index, offset, n, A, action_kind,
+           recurrence, gamma, rho_hat, c_hat, vs, adv) -> None:
+    _check(load().sf_vtrace(_raw(params, "f32", "params"), int(ld_params), _raw(values, "f32", "values"),
+                            int(ld_values), ptr(actions, "f32", "actions"),
+                            ptr(old_logp, "f32", "old_logp"), ptr(rewards, "f32", "rewards"), ptr(dones, "u8", "dones"),
+                            ptr(index, "i32", "index"), i64(offset), i64(n), int(A), int(action_kind),
+                            int(recurrence), f(gamma), f(rho_hat), f(c_hat), ptr(vs, "f32", "vs"),
+                            ptr(adv, "f32", "adv"), stream()), "sf_vtrace")
+
+
+def ppo_loss(params, ld_params, values, ld_values, actions, old_logp, old_params, old_values, adv, targets, valids,
+             index, offset, n, A, cfg: sf_loss_cfg, mom, sums, g_params, g_values) -> None:
+    """params/values (and g_params/g_values) may be strided column views of one [n, ld] matrix."""
+    _check(load().sf_ppo_loss(_raw(params, "f32", "params"), int(ld_params), _raw(values, "f32", "values"),
+                              int(ld_values), ptr(actions, "f32", "actions"), ptr(old_logp, "f32", "old_logp"),
+                              ptr(old_params, "f32", "old_params"), ptr(old_values, "f32", "old_values"),
+                              ptr(adv, "f32", "adv"), ptr(targets, "f32", "targets"), ptr(valids, "u8", "valids"),
+                              ptr(index, "i32", "index"), i64(offset), i64(n), int(A), C.byref(cfg),
+                              ptr(mom, "f64", "moments"), ptr(sums, "f64", "sums"), _raw(g_params, "f32", "g_params"),
+                              _raw(g_values, "f32", "g_values"), stream()), "sf_ppo_loss")
+
+
+def loss_scalars(sums, mom, cfg: sf_loss_cfg, out) -> None:
+    _check(load().sf_loss_scalars(ptr(sums, "f64"), ptr(mom, "f64"), C.byref(cfg), ptr(out, "f32"), stream()),
+           "sf_loss_scalars")
+
+
+def minibatch_indices(out, experience_size, recurrence, shuffle, seed, epoch) -> None:
+    _check(load().sf_minibatch_indices(ptr(out, "i32", "indices"), i64(experience_size), int(recurrence),
+                                       int(bool(shuffle)), u32(seed), u32(epoch), stream()), "sf_minibatch_indices")
+
+
+def grad_sumsq(g, sumsq) -> None:
+    _check(load().sf_grad_sumsq(ptr(g, "f32", "grad"), i64(g.numel()), ptr(sumsq, "f64", "sumsq"), stream()),
+           "sf_grad_sumsq")
+
+
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, max_grad_norm, sumsq, grad_scale=1.0) -> None:
+    _check(load().sf_adam_step(ptr(p, "f32", "params"), ptr(g, "f32", "grads"), ptr(m, "f32", "exp_avg"),
+                               ptr(v, "f32", "exp_avg_sq"), i64(p.numel()), int(step), f(lr), f(beta1), f(beta2),
+                               f(eps), f(max_grad_norm), ptr(sumsq, "f64", "sumsq"), f(grad_scale), stream()),
+           "sf_adam_step")
+
+
+def sample_write_step(logits, ld_logits, values, ld_values, B, A, T, t, seed, step, row0, policy_version, deterministic,
+                      traj_actions, traj_logits, traj_logp, traj_values, traj_policy_version, env_actions) -> None:
+    _check(load().sf_sample_write_step(_raw(logits, "f32", "logits"), int(ld_logits), _raw(values, "f32", "values"),
+                                       int(ld_values), int(B), int(A), int(T),
+                                       int(t), u32(seed), u32(step), u32(row0), f(policy_version),
+                                       int(bool(deterministic)), ptr(traj_actions, "f32"), ptr(traj_logits, "f32"),
+                                       ptr(traj_logp, "f32"), ptr(traj_values, "f32"),
+                                       ptr(traj_policy_version, "f32"), ptr(env_actions, "i32"), stream()),
+           "sf_sample_write_step")
+
+
+def traj_write_env_step(rewards, terminated, truncated, T, t, reward_scale, reward_clip, policy_id, traj_rewards,
+                        traj_dones, traj_time_outs, traj_policy_id, ep_return, ep_len, ep_stats) -> None:
+    B = rewards.numel()
+    _check(load().sf_traj_write_env_step(ptr(rewards, "f32", "rewards"), ptr(terminated, "u8", "terminated"),
+                                         ptr(truncated, "u8", "truncated"), B, int(T), int(t), f(reward_scale),
+                                         f(reward_clip), int(policy_id), ptr(traj_rewards, "f32"),
+                                         ptr(traj_dones, "u8"), ptr(traj_time_outs, "u8"), ptr(traj_policy_id, "i32"),
+                                         ptr(ep_return, "f32"), ptr(ep_len, "i32"), ptr(ep_stats, "f64"), stream()),
+           "sf_traj_write_env_step")
+
+
+def synth_obs(obs_slot_ptr: int, env_stride, B, env0, obs_bytes, seed, step) -> None:
+    _check(load().sf_synth_obs(C.c_void_p(obs_slot_ptr), i64(env_stride), int(B), int(env0), i64(obs_bytes),
+                               u32(seed), u32(step), stream()), "sf_synth_obs")
+
+
+def synth_step(actions, env0, num_actions, seed, step, rewards, terminated) -> None:
+    _check(load().sf_synth_step(ptr(actions, "i32", "actions"), actions.numel(), int(env0), int(num_actions),
+                                u32(seed), u32(step), ptr(rewards, "f32"), ptr(terminated, "u8"), stream()),
+           "sf_synth_step")
+
+
+# ---- network kernels (csrc/sf_nn.hip)
+def _raw_in(t: torch.Tensor, desc: sf_conv_desc) -> C.c_void_p:
+    want = torch.uint8 if desc.in_u8 else torch.float32
+    if t.dtype != want:
+        raise SfHipError(f"conv input: expected {want}, got {t.dtype}")
+    if not t.is_cuda:
+        raise SfHipError(f"conv input lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def conv_fwd_raw(inp, in_sample_stride, index, offset, w, bias, out, n, desc: sf_conv_desc) -> None:
+    """`inp` may be a strided view (e.g. slab[:, t]); its data_ptr is sample 0, samples are in_sample_stride apart."""
+    _check(load().sf_conv_fwd(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
+                              i64(offset), ptr(w, "f32", "w"), ptr(bias, "f32", "bias"), ptr(out, "f32", "out"),
+                              i64(n), C.byref(desc), stream()), "sf_conv_fwd")
+
+
+def conv_wgrad_workspace(n, desc: sf_conv_desc) -> int:
+    return int(load().sf_conv_wgrad_workspace(i64(n), C.byref(desc)))
+
+
+def conv_wgrad_raw(inp, in_sample_stride, index, offset, dout, dw, db, n, desc: sf_conv_desc, workspace) -> None:
+    _check(load().sf_conv_wgrad(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
+                                i64(offset), ptr(dout, "f32", "dout"), ptr(dw, "f32", "dw"), ptr(db, "f32", "db"),
+                                i64(n), C.byref(desc), ptr(workspace, "u8", "workspace"), stream()), "sf_conv_wgrad")
+
+
+def conv_dgrad(dout, w, in_act, din, n, desc: sf_conv_desc) -> None:
+    _check(load().sf_conv_dgrad(ptr(dout, "f32", "dout"), ptr(w, "f32", "w"), ptr(in_act, "f32", "in_act"),
+                                ptr(din, "f32", "din"), i64(n), C.byref(desc), stream()), "sf_conv_dgrad")
+
+
+def linear_fwd(inp, w, bias, out, M, K, N, relu) -> None:
+    _check(load().sf_linear_fwd(ptr(inp, "f32", "in"), ptr(w, "f32", "w"), ptr(bias, "f32", "bias"),
+                                ptr(out, "f32", "out"), i64(M), int(K), int(N), int(bool(relu)), stream()),
+           "sf_linear_fwd")
+
+
+def linear_wgrad_workspace(M, K, N) -> int:
+    return int(load().sf_linear_wgrad_workspace(i64(M), int(K), int(N)))
+
+
+def linear_wgrad(inp, dout, dw, db, M, K, N, workspace) -> None:
+    _check(load().sf_linear_wgrad(ptr(inp, "f32", "in"), ptr(dout, "f32", "dout"), ptr(dw, "f32", "dw"),
+                                  ptr(db, "f32", "db"), i64(M), int(K), int(N), ptr(workspace, "u8", "workspace"),
+                                  stream()), "sf_linear_wgrad")
+
+
+def linear_dgrad(dout, w, in_act, din, M, K, N) -> None:
+    _check(load().sf_linear_dgrad(ptr(dout, "f32", "dout"), ptr(w, "f32", "w"), ptr(in_act, "f32", "in_act"),
+                                  ptr(din, "f32", "din"), i64(M), int(K), int(N), stream()), "sf_linear_dgrad")
+
+
+def relu_mask(g, act) -> None:
+    _check(load().sf_relu_mask(ptr(g, "f32", "g"), ptr(act, "f32", "act"), i64(g.numel()), stream()), "sf_relu_mask")
+
+
+conv_fwd = conv_fwd_raw
+conv_wgrad = conv_wgrad_raw

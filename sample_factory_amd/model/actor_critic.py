@@ -1,0 +1,358 @@
+"""Native actor-critic: encoder (conv head + MLP | MLP) -> identity core -> decoder MLP -> {critic, action params}.
+
+Architecture, initialisation and parameter NAMES follow the reference (sample_factory/model/actor_critic.py:136-195,
+model/encoder.py:72-150, model/decoder.py:15-31, model/action_parameterization.py:20-39) so `state_dict()` round-trips
+with Sample Factory checkpoints; the compute is libsf_hip.so's fp32-MFMA implicit-GEMM kernels:
+
+ * all parameters live in ONE flat fp32 buffer (segments padded to 256 B) with matching flat grad / Adam-moment buffers
+   -> one launch for grad-norm, one for Adam, one bucket for the data-parallel all-reduce;
+ * activations are NHWC, weights K-major [K, Cout]; conversion from/to the reference's OIHW / [out,in] layouts happens
+   only in load_state_dict()/state_dict();
+ * the u8 -> f32 observation normalisation (utils/normalize.py:51-70) is fused into the first layer's loader;
+ * critic_linear and distribution_linear are one fused [F, 1+A] GEMM (column 0 = value).
+
+Only feed-forward ReLU models are native in this round (the north-star config); anything else raises — there is no
+silent PyTorch fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from sample_factory_amd import lib
+from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
+from sample_factory_amd.envs.spaces import calc_num_action_parameters, is_discrete
+
+CONV_ARCHS = {  # model/encoder.py:126-134: [out_channels, kernel, stride]
+    "convnet_simple": [[32, 8, 4], [64, 4, 2], [128, 3, 2]],
+    "convnet_impala": [[16, 8, 4], [32, 4, 2]],
+    "convnet_atari": [[32, 8, 4], [64, 4, 2], [64, 3, 1]],
+}
+
+
+def get_rnn_size(cfg) -> int:
+    """model/model_utils.py:11-24"""
+    size = cfg.rnn_size * cfg.rnn_num_layers if cfg.use_rnn else 1
+    if cfg.rnn_type == "lstm":
+        size *= 2
+    if not cfg.actor_critic_share_weights:
+        size *= 2
+    return size
+
+
+def _pad(n: int, q: int = 64) -> int:
+    return (n + q - 1) // q * q
+
+
+class _Layer:
+    """One implicit-GEMM layer: conv (spatial) or linear (1x1 on a 1x1 image)."""
+
+    def __init__(self, name, desc: lib.sf_conv_desc, ref_w_shape, kind, first_fc_chw=None):
+        self.name = name          # reference parameter prefix, e.g. encoder.encoders.obs.enc.conv_head.0
+        self.desc = desc
+        self.kind = kind          # "conv_u8" | "conv" | "linear" | "linear_after_conv" | "heads"
+        self.ref_w_shape = ref_w_shape
+        self.first_fc_chw = first_fc_chw
+        self.K = desc.KH * desc.KW * desc.Cin
+        self.N = desc.Cout
+        self.w = self.b = self.gw = self.gb = None  # views into the flat buffers
+
+    @property
+    def out_pixels(self):
+        return self.desc.OH * self.desc.OW
+
+    # ---- layout conversion (reference <-> native)
+    def w_from_ref(self, w_ref: torch.Tensor) -> torch.Tensor:
+        d = self.desc
+        if self.kind == "conv_u8":      # k = (c*KH + kh)*KW + kw
+            return w_ref.reshape(d.Cout, self.K).t().contiguous()
+        if self.kind == "conv":         # k = (kh*KW + kw)*Cin + c
+            return w_ref.permute(2, 3, 1, 0).reshape(self.K, d.Cout).contiguous()
+        if self.kind == "linear_after_conv":  # reference flattens NCHW, we flatten NHWC
+            C, OH, OW = self.first_fc_chw
+            return w_ref.view(self.N, C, OH, OW).permute(2, 3, 1, 0).reshape(self.K, self.N).contiguous()
+        return w_ref.t().contiguous()   # linear: [out,in] -> [in,out]
+
+    def w_to_ref(self, w: torch.Tensor) -> torch.Tensor:
+        d = self.desc
+        if self.kind == "conv_u8":
+            return w.t().reshape(d.Cout, d.Cin, d.KH, d.KW).contiguous()
+        if self.kind == "conv":
+            return w.reshape(d.KH, d.KW, d.Cin, d.Cout).permute(3, 2, 0, 1).contiguous()
+        if self.kind == "linear_after_conv":
+            C, OH, OW = self.first_fc_chw
+            return w.reshape(OH, OW, C, self.N).permute(3, 2, 0, 1).reshape(self.N, self.K).contiguous()
+        return w.t().contiguous()
+
+
+def _linear_desc(K, N, relu) -> lib.sf_conv_desc:
+    return lib.sf_conv_desc(Cin=K, H=1, W=1, Cout=N, KH=1, KW=1, stride=1, OH=1, OW=1, in_u8=0, relu=int(relu),
+                            traj_T=0, sub_mean=0.0, inv_scale=1.0)
+
+
+class ActorCritic:
+    """Shared-weights feed-forward actor-critic (reference: ActorCriticSharedWeights)."""
+
+    def __init__(self, cfg, obs_space, action_space, device="cuda", all_reduce=None):
+        self.cfg = cfg
+        self.obs_space = obs_space
+        self.action_space = action_space
+        self.device = torch.device(device)
+        self.training = True
+        if cfg.use_rnn:
+            raise NotImplementedError("native RNN core is not built yet (SURVEY.md §8f.3); use_rnn=False only")
+        if not cfg.actor_critic_share_weights:
+            raise NotImplementedError("separate actor/critic weights are outside the hot-path scope (SURVEY.md §2.1)")
+        if cfg.nonlinearity != "relu":
+            raise NotImplementedError(f"native kernels fuse ReLU only; nonlinearity={cfg.nonlinearity} not built yet")
+        if cfg.normalize_input:
+            raise NotImplementedError("normalize_input=True (per-pixel running mean/std) is not built yet; the "
+                                      "north-star preset uses obs_scale/obs_subtract_mean with normalize_input=False")
+        if not is_discrete(action_space) and not cfg.adaptive_stddev:
+            raise NotImplementedError("non-adaptive stddev parameterisation not built yet")
+        keys = sorted(obs_space.spaces.keys())
+        if keys != ["obs"]:
+            raise NotImplementedError(f"single 'obs' key only, got {keys}")
+        space = obs_space["obs"]
+        self.obs_shape = tuple(space.shape)
+        self.obs_u8 = np.dtype(space.dtype) == np.uint8
+        self.num_action_params = calc_num_action_parameters(action_space)
+        self.layers: List[_Layer] = []
+        sub_mean = float(cfg.obs_subtract_mean)
+        inv_scale = float(np.float32(1.0 / cfg.obs_scale)) if abs(cfg.obs_scale - 1.0) > 1e-5 else 1.0
+        if abs(sub_mean) <= 1e-5:
+            sub_mean = 0.0
+
+        if len(self.obs_shape) == 3:
+            C, H, W = self.obs_shape
+            if not self.obs_u8:
+                raise NotImplementedError("image observations must be uint8 CHW (pixel_format=CHW)")
+            pfx = "encoder.encoders.obs.enc."
+            cin, h, w = C, H, W
+            for i, (cout, k, s) in enumerate(CONV_ARCHS[cfg.encoder_conv_architecture]):
+                oh, ow = (h - k) // s + 1, (w - k) // s + 1
+                first = i == 0
+                desc = lib.sf_conv_desc(Cin=cin, H=h, W=w, Cout=cout, KH=k, KW=k, stride=s, OH=oh, OW=ow,
+                                        in_u8=int(first), relu=1, traj_T=0,
+                                        sub_mean=sub_mean if first else 0.0, inv_scale=inv_scale if first else 1.0)
+                self.layers.append(_Layer(f"{pfx}conv_head.{2 * i}", desc, (cout, cin, k, k),
+                                          "conv_u8" if first else "conv"))
+                cin, h, w = cout, oh, ow
+            feat, chw = cin * h * w, (cin, h, w)
+            for j, size in enumerate(cfg.encoder_conv_mlp_layers):
+                self.layers.append(_Layer(f"{pfx}mlp_layers.{2 * j}", _linear_desc(feat, size, True), (size, feat),
+                                          "linear_after_conv" if j == 0 else "linear", first_fc_chw=chw))
+                feat = size
+        elif len(self.obs_shape) == 1:
+            if self.obs_u8 or sub_mean != 0.0 or inv_scale != 1.0:
+                raise NotImplementedError("vector observations must be f32 without obs_scale/obs_subtract_mean")
+            feat = self.obs_shape[0]
+            for j, size in enumerate(cfg.encoder_mlp_layers):
+                self.layers.append(_Layer(f"encoder.encoders.obs.mlp_head.{2 * j}", _linear_desc(feat, size, True),
+                                          (size, feat), "linear"))
+                feat = size
+        else:
+            raise NotImplementedError(f"Unsupported observation shape {self.obs_shape}")
+        for j, size in enumerate(cfg.decoder_mlp_layers):
+            self.layers.append(_Layer(f"decoder.mlp.{2 * j}", _linear_desc(feat, size, True), (size, feat), "linear"))
+            feat = size
+        self.feat = feat
+        A = self.num_action_params
+        self.layers.append(_Layer("heads", _linear_desc(feat, 1 + A, False), (1 + A, feat), "heads"))
+        self.obs_elems = int(np.prod(self.obs_shape))
+
+        # ---- flat parameter / gradient / Adam buffers
+        off = 0
+        self._segs = []
+        for L in self.layers:
+            self._segs.append((off, off + _pad(L.K * L.N)))
+            off = self._segs[-1][1] + _pad(L.N)
+        self.num_flat = off
+        self.flat_params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        for L, (o, ob) in zip(self.layers, self._segs):
+            L.w = self.flat_params[o:o + L.K * L.N].view(L.K, L.N)
+            L.b = self.flat_params[ob:ob + L.N]
+            L.gw = self.flat_grads[o:o + L.K * L.N].view(L.K, L.N)
+            L.gb = self.flat_grads[ob:ob + L.N]
+        self.returns_normalizer: Optional[RunningMeanStdInPlace] = None
+        if cfg.normalize_returns:
+            self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
+        self._bufs: Dict = {}
+        self._ws: Optional[torch.Tensor] = None
+        self.initialize_weights()
+
+    # ------------------------------------------------------------------------------------------ reference surface
+    def num_params(self) -> int:
+        return sum(L.K * L.N + L.N for L in self.layers)
+
+    def train(self, mode=True):
+        self.training = mode
+        if self.returns_normalizer is not None:
+            self.returns_normalizer.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def model_to_device(self, device):
+        assert torch.device(device).type == "cuda", "the native model only lives on the GPU"
+
+    def normalize_obs(self, obs):
+        """Identity: normalisation is fused into the first layer (the f32 copy is never materialised)."""
+        return obs
+
+    def initialize_weights(self):
+        """actor_critic.py:73-96: orthogonal (gain) / xavier_uniform / torch_default on the REFERENCE layout; bias 0."""
+        cfg = self.cfg
+        gain = cfg.policy_init_gain
+        sd = {}
+        for name, shape in self.ref_param_shapes():
+            t = torch.empty(shape, dtype=torch.float32)
+            if name.endswith(".bias"):
+                if cfg.policy_initialization == "torch_default":
+                    fan_in = int(np.prod(dict(self.ref_param_shapes())[name[:-4] + "weight"][1:]))
+                    bound = 1 / math.sqrt(fan_in)
+                    t.uniform_(-bound, bound)
+                else:
+                    t.zero_()
+            elif cfg.policy_initialization == "orthogonal":
+                torch.nn.init.orthogonal_(t, gain=gain)
+            elif cfg.policy_initialization == "xavier_uniform":
+                torch.nn.init.xavier_uniform_(t, gain=gain)
+            else:
+                torch.nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            sd[name] = t
+        self.load_state_dict(sd, strict=False)
+
+    def ref_param_shapes(self):
+        """(name, shape) of every trainable parameter under the reference's names, in the reference's order."""
+        out = []
+        for L in self.layers[:-1]:
+            out.append((L.name + ".weight", tuple(L.ref_w_shape)))
+            out.append((L.name + ".bias", (L.N,)))
+        A, F = self.num_action_params, self.feat
+        out += [("critic_linear.weight", (1, F)), ("critic_linear.bias", (1,)),
+                ("action_parameterization.distribution_linear.weight", (A, F)),
+                ("action_parameterization.distribution_linear.bias", (A,))]
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        sd = {}
+        if self.returns_normalizer is not None:
+            sd.update(self.returns_normalizer.state_dict("returns_normalizer."))
+        for L in self.layers[:-1]:
+            sd[L.name + ".weight"] = L.w_to_ref(L.w.detach()).cpu()
+            sd[L.name + ".bias"] = L.b.detach().cpu().clone()
+        H = self.layers[-1]
+        w = H.w.detach().cpu()
+        sd["critic_linear.weight"] = w[:, 0:1].t().contiguous()
+        sd["critic_linear.bias"] = H.b.detach().cpu()[0:1].clone()
+        sd["action_parameterization.distribution_linear.weight"] = w[:, 1:].t().contiguous()
+        sd["action_parameterization.distribution_linear.bias"] = H.b.detach().cpu()[1:].clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        with torch.no_grad():
+            for L in self.layers[:-1]:
+                L.w.copy_(L.w_from_ref(torch.as_tensor(sd[L.name + ".weight"], dtype=torch.float32)))
+                L.b.copy_(torch.as_tensor(sd[L.name + ".bias"], dtype=torch.float32))
+            H = self.layers[-1]
+            cw = torch.as_tensor(sd["critic_linear.weight"], dtype=torch.float32)
+            aw = torch.as_tensor(sd["action_parameterization.distribution_linear.weight"], dtype=torch.float32)
+            H.w.copy_(torch.cat([cw, aw], dim=0).t().contiguous())
+            H.b.copy_(torch.cat([torch.as_tensor(sd["critic_linear.bias"], dtype=torch.float32).reshape(1),
+                                 torch.as_tensor(sd["action_parameterization.distribution_linear.bias"],
+                                                 dtype=torch.float32).reshape(-1)]))
+            if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
+                self.returns_normalizer.load_state_dict(sd, "returns_normalizer.")
+            elif strict and self.returns_normalizer is not None:
+                raise KeyError("returns_normalizer.* missing from state dict")
+
+    # flat <-> reference order (for optimizer state interop and parity tests)
+    def flat_to_ref(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Interpret a flat buffer (params, grads or Adam moments) under the reference's names/layouts."""
+        out = {}
+        for L, (o, ob) in zip(self.layers[:-1], self._segs[:-1]):
+            out[L.name + ".weight"] = L.w_to_ref(flat[o:o + L.K * L.N].view(L.K, L.N)).cpu()
+            out[L.name + ".bias"] = flat[ob:ob + L.N].cpu().clone()
+        H, (o, ob) = self.layers[-1], self._segs[-1]
+        w = flat[o:o + H.K * H.N].view(H.K, H.N).cpu()
+        b = flat[ob:ob + H.N].cpu()
+        out["critic_linear.weight"] = w[:, 0:1].t().contiguous()
+        out["critic_linear.bias"] = b[0:1].clone()
+        out["action_parameterization.distribution_linear.weight"] = w[:, 1:].t().contiguous()
+        out["action_parameterization.distribution_linear.bias"] = b[1:].clone()
+        return out
+
+    # ------------------------------------------------------------------------------------------ compute
+    def _buf(self, key, shape, dtype=torch.float32):
+        t = self._bufs.get(key)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward_heads(self, obs: torch.Tensor, n: int, *, sample_stride: int, index=None, offset: int = 0,
+                      traj_T: int = 0, tag="inf") -> List[torch.Tensor]:
+        """Run the whole stack on `n` samples; returns the list of layer outputs (last = heads [n, 1+A]).
+
+        obs: any (possibly strided) view whose data_ptr is sample 0; logical sample i lives at row
+        (index[i] | offset+i) [-> slab row if traj_T] * sample_stride elements.
+        """
+        acts = []
+        x = obs
+        for li, L in enumerate(self.layers):
+            out = self._buf((tag, li), (n * L.out_pixels, L.N))
+            d = L.desc
+            if li == 0:
+                d = lib.sf_conv_desc.from_buffer_copy(L.desc)
+                d.traj_T = int(traj_T)
+                lib.conv_fwd_raw(x, sample_stride, index, offset, L.w, L.b, out, n, d)
+            else:
+                lib.conv_fwd_raw(x, d.H * d.W * d.Cin, None, 0, L.w, L.b, out, n, d)
+            acts.append(out)
+            x = out
+        return acts
+
+    def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
+        """Inference-style forward on a dense obs batch [B, ...]; returns dict(values, action_logits) (GPU tensors).
+        Sampling is a separate fused kernel (sf_sample_write_step) driven by the rollout runner."""
+        obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
+        assert action_mask is None, "action masks are not supported by the native sampler yet"
+        B = obs.shape[0]
+        heads = self.forward_heads(obs, B, sample_stride=self.obs_elems if obs.is_contiguous() else obs.stride(0))[-1]
+        res = dict(values=heads[:, 0])
+        if not values_only:
+            res["action_logits"] = heads[:, 1:]
+        res["new_rnn_states"] = rnn_states
+        return res
+
+    def backward(self, acts: List[torch.Tensor], g_heads: torch.Tensor, obs: torch.Tensor, n: int, *,
+                 sample_stride: int, index=None, offset: int = 0, traj_T: int = 0) -> None:
+        """Back-propagate d(loss)/d(heads) [n, 1+A] through the stack into self.flat_grads (overwritten)."""
+        g = g_heads
+        for li in range(len(self.layers) - 1, -1, -1):
+            L = self.layers[li]
+            d = L.desc
+            x = obs if li == 0 else acts[li - 1]
+            if li == 0:
+                d0 = lib.sf_conv_desc.from_buffer_copy(d)
+                d0.traj_T = int(traj_T)
+                ws = self._workspace(lib.conv_wgrad_workspace(n, d0))
+                lib.conv_wgrad_raw(x, sample_stride, index, offset, g, L.gw, L.gb, n, d0, ws)
+            else:
+                stride = d.H * d.W * d.Cin
+                ws = self._workspace(lib.conv_wgrad_workspace(n, d))
+                lib.conv_wgrad_raw(x, stride, None, 0, g, L.gw, L.gb, n, d, ws)
+                gin = self._buf(("g", li - 1), tuple(acts[li - 1].shape))
+                lib.conv_dgrad(g, L.w, acts[li - 1], gin, n, d)  # ReLU mask of the previous layer fused
+                g = gin

@@ -1,0 +1,95 @@
+"""`run_rl(cfg)` / `make_runner(cfg)` — the entry points of sample_factory/train.py:12-41 for the native engine.
+
+One process per GPU owns env, inference, GAE and learning (the design the reference itself recommends for GPU envs:
+docs/07-advanced-topics/profiling.md:178-180, serial_mode + sync in sf_examples/brax/train_brax.py:200-201).  With
+torchrun (WORLD_SIZE>1) each rank runs a replica on its own env shard and gradients are all-reduced over RCCL.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Tuple
+
+import torch
+
+from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+from sample_factory_amd.algo.sampling.batched_sampling import BatchedVectorEnvRunner
+from sample_factory_amd.algo.utils.env_info import extract_env_info
+from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+from sample_factory_amd.cfg.arguments import preprocess_cfg
+from sample_factory_amd.envs.env_utils import create_env
+from sample_factory_amd.model.actor_critic import get_rnn_size
+from sample_factory_amd.utils.attr_dict import AttrDict
+
+
+class ExperimentStatus:
+    SUCCESS, FAILURE, INTERRUPTED = 0, 1, 2
+
+
+class Runner:
+    """The slice of sample_factory/algo/runners/runner.py the hot path needs: init(), run(), FPS accounting
+    (runner.py:748-765: env_steps / wall-clock), observers hooks kept as no-ops."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.status = ExperimentStatus.SUCCESS
+        self.observers = []
+        self.env_steps = 0
+        self.fps = 0.0
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+
+    def register_observer(self, observer):
+        self.observers.append(observer)
+
+    def init(self) -> int:
+        cfg = self.cfg
+        if self.world > 1 and not torch.distributed.is_initialized():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.distributed.init_process_group("nccl")
+            cfg.data_parallel = True
+            cfg.synthetic_env0 = self.rank * getattr(cfg, "synthetic_num_agents", 4096)
+        env_config = AttrDict(worker_index=0, vector_index=0, env_id=0)
+        self.env = create_env(cfg.env, cfg, env_config)
+        self.env_info = extract_env_info(self.env, cfg)
+        if not preprocess_cfg(cfg, self.env_info):
+            raise ValueError("Invalid config! See above for details.")
+        self.policy_versions = torch.zeros(cfg.num_policies, dtype=torch.int32)
+        self.learner = Learner(cfg, self.env_info, self.policy_versions, 0, ParameterServer(0, self.policy_versions))
+        self.learner.init()
+        dev = self.learner.device
+        self.traj = alloc_trajectory_tensors(self.env_info, self.env_info.num_agents, cfg.rollout, get_rnn_size(cfg), dev)
+        self.sampler = BatchedVectorEnvRunner(cfg, self.env_info, self.env, self.learner.actor_critic, self.traj, 0,
+                                              self.policy_versions, sample_seed=(cfg.seed or 0) + 1000003 * self.rank)
+        return ExperimentStatus.SUCCESS
+
+    def iteration(self):
+        """one dataset: rollout of all envs, then Learner.train on the slab in place"""
+        self.sampler.rollout(policy_version=float(self.learner.train_step))
+        stats = self.learner.train(self.traj)
+        self.sampler.carry_over()
+        return stats
+
+    def run(self) -> int:
+        cfg = self.cfg
+        t0 = time.time()
+        while self.learner.env_steps < cfg.train_for_env_steps and time.time() - t0 < cfg.train_for_seconds:
+            self.iteration()
+        torch.cuda.synchronize()
+        self.env_steps = self.learner.env_steps
+        self.fps = self.env_steps / max(1e-9, time.time() - t0)
+        if self.rank == 0:
+            print(f"Collected {{0: {self.env_steps}}}, FPS: {self.fps:.1f}")
+        return self.status
+
+
+def make_runner(cfg) -> Tuple[object, Runner]:
+    return cfg, Runner(cfg)
+
+
+def run_rl(cfg):
+    cfg, runner = make_runner(cfg)
+    status = runner.init()
+    if status == ExperimentStatus.SUCCESS:
+        status = runner.run()
+    return status

@@ -22,3 +22,14 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
     return load
+
+
+@pytest.fixture(scope="session")
+def golden_json():
+    import json
+
+    def load(name):
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            return json.load(f)
+
+    return load

@@ -1,0 +1,164 @@
+"""CPU suite: the C-ABI library loads without a GPU and exports every symbol include/sf_hip.h declares; host-side
+logic (config surface, TensorDict, layouts, LR schedulers, minibatch planning)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from sample_factory_amd import build, lib
+    build.build()
+    L = lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 26
+    assert sorted(lib.SYMBOLS) == syms, "sample_factory_amd.lib.SYMBOLS out of date with include/sf_hip.h"
+    for s in syms:
+        assert hasattr(L, s), f"libsf_hip.so does not export {s}"
+    assert L.sf_abi_version() == 1
+    assert L.sf_selftest_host() == 0          # exact integer division used by every im2col address
+    assert isinstance(L.sf_last_error(), bytes)
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from sample_factory_amd import lib
+    L = lib.load()
+    rc = L.sf_gae_returns(None, None, None, None, None, None, 0, 0, ctypes.c_float(0.99), ctypes.c_float(0.95), 0, None, None, None)
+    assert rc == -1 and b"sf_gae_returns" in L.sf_last_error()
+    with pytest.raises(lib.SfHipError):      # CPU tensors are refused: there is no fallback path
+        lib.grad_sumsq(torch.zeros(8), torch.zeros(1, dtype=torch.float64))
+
+
+def test_struct_layouts_match_header():
+    from sample_factory_amd import lib
+    assert ctypes.sizeof(lib.sf_loss_cfg) == 8 * 4
+    assert ctypes.sizeof(lib.sf_conv_desc) == 14 * 4
+    assert [f[0] for f in lib.sf_conv_desc._fields_] == ["Cin", "H", "W", "Cout", "KH", "KW", "stride", "OH", "OW",
+                                                          "in_u8", "relu", "traj_T", "sub_mean", "inv_scale"]
+
+
+def test_cfg_defaults_equal_reference(golden_json):
+    from sample_factory_amd.cfg.arguments import default_cfg, parse_full_cfg, parse_sf_args
+    ref = golden_json("cfg_defaults")
+    cfg = vars(default_cfg())
+    skip = {"train_dir", "command_line", "env", "experiment", "help"}
+    for k, v in cfg.items():
+        if k in skip:
+            continue
+        assert k in ref, f"flag {k} does not exist in the reference"
+        assert ref[k] == v, (k, ref[k], v)
+    argv = ["--env=x", "--rollout=64", "--use_rnn=False", "--encoder_conv_mlp_layers", "256", "128", "--gamma=0.9"]
+    p, _ = parse_sf_args(argv)
+    c = parse_full_cfg(p, argv)
+    assert (c.rollout, c.use_rnn, c.encoder_conv_mlp_layers, c.gamma) == (64, False, [256, 128], 0.9)
+
+
+def test_verify_cfg_rules():
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.cfg.arguments import default_cfg, preprocess_cfg
+    ei = EnvInfo(None, None, 4096)
+    ok = default_cfg(use_rnn=False, async_rl=False, num_workers=1, num_envs_per_worker=1, rollout=32, batch_size=32768,
+                     num_batches_per_epoch=4)
+    assert preprocess_cfg(ok, ei) and ok.recurrence == 1
+    bad = default_cfg(use_rnn=False, with_vtrace=True, normalize_returns=True)
+    assert not preprocess_cfg(bad, ei)
+    bad2 = default_cfg(use_rnn=False, async_rl=False, num_workers=1, num_envs_per_worker=1, batch_size=1024)
+    assert not preprocess_cfg(bad2, ei)
+
+
+def test_tensor_dict_semantics():
+    from sample_factory_amd.algo.utils.tensor_dict import TensorDict, clone_tensordict
+    d = TensorDict(a=torch.zeros(4, 3), obs=TensorDict(x=torch.zeros(4, 3, 2)))
+    step = d[:, 1]
+    assert step["a"].shape == (4,) and step["obs"]["x"].shape == (4, 2)
+    step[:] = dict(a=torch.ones(4), obs=dict(x=np.full((4, 2), 2.0, np.float32)))
+    assert d["a"][:, 1].eq(1).all() and d["obs"]["x"][:, 1].eq(2).all() and d["a"][:, 0].eq(0).all()
+    c = clone_tensordict(d)
+    c["a"].fill_(5)
+    assert d["a"].max() == 1
+
+
+def test_trajectory_layout_matches_reference():
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.envs import spaces
+    ei = EnvInfo(spaces.Dict({"obs": spaces.Box(0, 255, (4, 84, 84), np.uint8)}), spaces.Discrete(6), 8)
+    t = alloc_trajectory_tensors(ei, 8, 32, 1, "cpu")
+    shapes = {k: (tuple(v.shape), v.dtype) for k, v in t.items() if k != "obs"}
+    assert t["obs"]["obs"].shape == (8, 33, 4, 84, 84) and t["obs"]["obs"].dtype == torch.uint8
+    assert shapes == {"rnn_states": ((8, 33, 1), torch.float32), "actions": ((8, 32, 1), torch.float32),
+                      "action_logits": ((8, 32, 6), torch.float32), "log_prob_actions": ((8, 32), torch.float32),
+                      "values": ((8, 33), torch.float32), "policy_version": ((8, 32), torch.float32),
+                      "rewards": ((8, 32), torch.float32), "dones": ((8, 32), torch.bool),
+                      "time_outs": ((8, 32), torch.bool), "policy_id": ((8, 32), torch.int32),
+                      "valids": ((8, 33), torch.bool)}
+    assert (t["policy_id"] == -1).all() and t["dones"].all() and not t["valids"].any()
+
+
+def test_weight_layout_round_trips():
+    from sample_factory_amd import lib
+    from sample_factory_amd.model.actor_critic import _Layer, _linear_desc
+    g = torch.Generator().manual_seed(0)
+    d1 = lib.sf_conv_desc(Cin=4, H=84, W=84, Cout=32, KH=8, KW=8, stride=4, OH=20, OW=20, in_u8=1, relu=1)
+    L1 = _Layer("c1", d1, (32, 4, 8, 8), "conv_u8")
+    w = torch.randn((32, 4, 8, 8), generator=g)
+    k = L1.w_from_ref(w)
+    assert k.shape == (256, 32) and torch.equal(L1.w_to_ref(k), w)
+    assert k[(2 * 8 + 3) * 8 + 5, 7] == w[7, 2, 3, 5]                       # k = (c*KH + kh)*KW + kw
+    d2 = lib.sf_conv_desc(Cin=32, H=20, W=20, Cout=64, KH=4, KW=4, stride=2, OH=9, OW=9, in_u8=0, relu=1)
+    L2 = _Layer("c2", d2, (64, 32, 4, 4), "conv")
+    w = torch.randn((64, 32, 4, 4), generator=g)
+    k = L2.w_from_ref(w)
+    assert k.shape == (512, 64) and torch.equal(L2.w_to_ref(k), w)
+    assert k[(1 * 4 + 2) * 32 + 9, 11] == w[11, 9, 1, 2]                    # k = (kh*KW + kw)*Cin + c
+    L3 = _Layer("fc", _linear_desc(3136, 512, True), (512, 3136), "linear_after_conv", first_fc_chw=(64, 7, 7))
+    w = torch.randn((512, 3136), generator=g)
+    k = L3.w_from_ref(w)
+    assert torch.equal(L3.w_to_ref(k), w)
+    assert k[(3 * 7 + 4) * 64 + 10, 99] == w[99, 10 * 49 + 3 * 7 + 4]       # NHWC flatten vs the reference's NCHW
+
+
+def test_lr_schedulers():
+    from sample_factory_amd.algo.learning.learner import get_lr_scheduler
+    from sample_factory_amd.cfg.arguments import default_cfg
+    s = get_lr_scheduler(default_cfg(lr_schedule="kl_adaptive_minibatch"))
+    assert s.invoke_after_each_minibatch() and not s.invoke_after_each_epoch()
+    assert s.update(1e-4, [0.1]) == pytest.approx(1e-4 / 1.5) and s.update(1e-4, [0.0]) == pytest.approx(1.5e-4)
+    assert s.update(1e-4, [0.008]) == 1e-4 and s.update(1e-6, [1.0]) == 1e-6 and s.update(1e-2, [0.0]) == 1e-2
+    e = get_lr_scheduler(default_cfg(lr_schedule="kl_adaptive_epoch", num_batches_per_epoch=2))
+    assert e.invoke_after_each_epoch() and e.update(1e-4, [1.0, 0.0, 0.0]) == pytest.approx(1.5e-4)
+    assert get_lr_scheduler(default_cfg()).update(3e-4, []) == 3e-4
+    with pytest.raises(RuntimeError):
+        get_lr_scheduler(default_cfg(lr_schedule="nope"))
+
+
+def test_env_registry():
+    from sample_factory_amd.envs.env_utils import create_env, register_env
+    calls = []
+    register_env("dummy_env", lambda name, cfg, env_config, render_mode: calls.append((name, cfg, env_config, render_mode)) or "ENV")
+    assert create_env("dummy_env", 1, 2, None) == "ENV" and calls == [("dummy_env", 1, 2, None)]
+    with pytest.raises(ValueError):
+        create_env("not_registered")
+
+
+def test_oracle_is_not_imported_by_the_product():
+    """the product package must never reach into oracle/ (tests, smoke and bench's cpu_baseline leg only)"""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sample_factory_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "sf_oracle" in src or "/root/reference" in src:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

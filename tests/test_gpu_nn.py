@@ -1,0 +1,280 @@
+"""GPU parity tests for the fp32-MFMA implicit-GEMM network kernels (sf_conv_fwd / wgrad / dgrad and the linear
+wrappers) and for the whole model/learner against golden vectors produced by the reference's own ActorCritic /
+Learner.train.  Floating-point kernels: the checker is plain torch fp32/fp64 math on the CPU (same op, different
+implementation); tolerances are fp32-accumulation class and written next to each assert."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.weights import seeded_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sample_factory_amd import lib as L
+    L.load()
+    return L
+
+
+def desc(lib, Cin, H, W, Cout, K, S, in_u8=0, relu=1, sub_mean=0.0, inv_scale=1.0, traj_T=0):
+    return lib.sf_conv_desc(Cin=Cin, H=H, W=W, Cout=Cout, KH=K, KW=K, stride=S, OH=(H - K) // S + 1, OW=(W - K) // S + 1,
+                            in_u8=in_u8, relu=relu, traj_T=traj_T, sub_mean=sub_mean, inv_scale=inv_scale)
+
+
+def to_kmajor(w_ref, u8):
+    O, C, KH, KW = w_ref.shape
+    if u8:
+        return w_ref.reshape(O, -1).t().contiguous()
+    return w_ref.permute(2, 3, 1, 0).reshape(KH * KW * C, O).contiguous()
+
+
+def from_kmajor(w, O, C, KH, KW, u8):
+    if u8:
+        return w.t().reshape(O, C, KH, KW)
+    return w.reshape(KH, KW, C, O).permute(3, 2, 0, 1)
+
+
+GEOMS = [  # (Cin, H, W, Cout, K, S, u8)
+    (4, 84, 84, 32, 8, 4, 1),    # Nature conv1 on raw u8 frames
+    (32, 20, 20, 64, 4, 2, 0),   # conv2
+    (64, 9, 9, 64, 3, 1, 0),     # conv3
+    (4, 36, 36, 32, 8, 4, 1),    # the golden cnn36 model's conv1
+    (16, 11, 13, 48, 3, 2, 0),   # odd sizes, Cout not a multiple of 32/64, H % stride != 0
+    (8, 6, 6, 128, 3, 1, 0),     # convnet_simple-like wide layer
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("n", [3, 37])
+def test_conv_fwd_wgrad_dgrad_vs_torch(lib, geom, n):
+    Cin, H, W, Cout, K, S, u8 = geom
+    g = torch.Generator().manual_seed(Cin * 131 + n)
+    if u8:
+        x = torch.randint(0, 256, (n, Cin, H, W), generator=g, dtype=torch.uint8)
+        xf = (x.double() - 3.0) * float(np.float32(1 / 255.0))
+        d = desc(lib, Cin, H, W, Cout, K, S, in_u8=1, sub_mean=3.0, inv_scale=float(np.float32(1 / 255.0)))
+        x_dev = x.cuda()
+        stride = Cin * H * W
+    else:
+        x = torch.randn((n, Cin, H, W), generator=g)
+        xf = x.double()
+        d = desc(lib, Cin, H, W, Cout, K, S)
+        x_dev = x.permute(0, 2, 3, 1).contiguous().cuda()  # NHWC
+        stride = Cin * H * W
+    w_ref = torch.randn((Cout, Cin, K, K), generator=g) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    wk = to_kmajor(w_ref, u8).cuda()
+    OH, OW = d.OH, d.OW
+    out = torch.empty((n * OH * OW, Cout), device="cuda")
+    lib.conv_fwd(x_dev, stride, None, 0, wk, b.cuda(), out, n, d)
+    ref = F.relu(F.conv2d(xf, w_ref.double(), b.double(), stride=S))           # [n, Cout, OH, OW] fp64
+    got = out.view(n, OH, OW, Cout).permute(0, 3, 1, 2).cpu().double()
+    scale = ref.abs().max().item() + 1e-6
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, scale), "forward"   # fp32 accumulation over K<=576
+
+    # weight / bias gradient for an upstream gradient dY (already ReLU-masked by the caller)
+    dy = torch.randn((n, Cout, OH, OW), generator=g)
+    dy_dev = dy.permute(0, 2, 3, 1).contiguous().cuda().view(n * OH * OW, Cout)
+    dw = torch.zeros_like(wk)
+    db = torch.zeros(Cout, device="cuda")
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    lib.conv_wgrad(x_dev, stride, None, 0, dy_dev, dw, db, n, d, ws)
+    xr = xf.clone().requires_grad_(True)
+    wr = w_ref.double().clone().requires_grad_(True)
+    br = b.double().clone().requires_grad_(True)
+    F.conv2d(xr, wr, br, stride=S).backward(dy.double())
+    dw_got = from_kmajor(dw.cpu().double(), Cout, Cin, K, K, u8)
+    s = wr.grad.abs().max().item() + 1e-6
+    assert (dw_got - wr.grad).abs().max().item() < 3e-5 * max(1.0, s), "wgrad"
+    assert (db.cpu().double() - br.grad).abs().max().item() < 3e-5 * max(1.0, br.grad.abs().max().item()), "bgrad"
+
+    if not u8:  # data gradient (+ fused ReLU mask of the producer layer's activation)
+        act = x_dev  # pretend x is the producer's post-ReLU output: mask = x > 0
+        din = torch.full((n, H, W, Cin), 7.0, device="cuda")
+        lib.conv_dgrad(dy_dev, wk, act, din, n, d)
+        dref = (xr.grad * (xf > 0)).permute(0, 2, 3, 1)
+        s = dref.abs().max().item() + 1e-6
+        assert (din.cpu().double() - dref).abs().max().item() < 3e-5 * max(1.0, s), "dgrad"
+        din2 = torch.empty((n, H, W, Cin), device="cuda")
+        lib.conv_dgrad(dy_dev, wk, None, din2, n, d)
+        assert (din2.cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 3e-5 * max(1.0, s), "dgrad nomask"
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64)])
+def test_linear_fwd_bwd_vs_torch(lib, M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn((M, K), generator=g)
+    w = torch.randn((K, N), generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    dy = torch.randn((M, N), generator=g)
+    xd, wd, bd, dyd = x.cuda(), w.cuda(), b.cuda(), dy.cuda()
+    out = torch.empty((M, N), device="cuda")
+    lib.linear_fwd(xd, wd, bd, out, M, K, N, True)
+    ref = F.relu(x.double() @ w.double() + b.double())
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    lib.linear_fwd(xd, wd, bd, out, M, K, N, False)
+    ref = x.double() @ w.double() + b.double()
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    ws = torch.empty(lib.linear_wgrad_workspace(M, K, N), dtype=torch.uint8, device="cuda")
+    lib.linear_wgrad(xd, dyd, dw, db, M, K, N, ws)
+    rw = x.double().t() @ dy.double()
+    assert (dw.cpu().double() - rw).abs().max().item() < 3e-5 * max(1.0, rw.abs().max().item())
+    assert (db.cpu().double() - dy.double().sum(0)).abs().max().item() < 3e-5 * max(1.0, dy.double().sum(0).abs().max().item())
+    din = torch.empty((M, K), device="cuda")
+    lib.linear_dgrad(dyd, wd, xd, din, M, K, N)
+    rd = (dy.double() @ w.double().t()) * (x.double() > 0)
+    assert (din.cpu().double() - rd).abs().max().item() < 3e-5 * max(1.0, rd.abs().max().item())
+
+
+def test_conv1_reads_slab_in_place(lib):
+    """index gather + dataset->slab row mapping (flat e*T+t -> row e*(T+1)+t): integer indexing must be exact,
+    so the result has to be BIT-identical to running the same kernel on a dense gathered copy."""
+    E, T, n = 6, 4, 16
+    g = torch.Generator().manual_seed(9)
+    slab = torch.randint(0, 256, (E, T + 1, 4, 36, 36), generator=g, dtype=torch.uint8).cuda()
+    idx = torch.randperm(E * T, generator=g)[:n].to(torch.int32).cuda()
+    d = desc(lib, 4, 36, 36, 32, 8, 4, in_u8=1, inv_scale=float(np.float32(1 / 255.0)), traj_T=T)
+    d0 = desc(lib, 4, 36, 36, 32, 8, 4, in_u8=1, inv_scale=float(np.float32(1 / 255.0)))
+    w = torch.randn((4 * 64, 32), generator=g).cuda()
+    b = torch.zeros(32).cuda()
+    out1 = torch.empty((n * 64, 32), device="cuda")
+    lib.conv_fwd(slab, 4 * 36 * 36, idx, 0, w, b, out1, n, d)
+    e, t = idx.long() // T, idx.long() % T
+    dense = slab[e, t].contiguous()
+    out2 = torch.empty_like(out1)
+    lib.conv_fwd(dense, 4 * 36 * 36, None, 0, w, b, out2, n, d0)
+    assert torch.equal(out1, out2)
+    out3 = torch.empty((8 * 64, 32), device="cuda")  # contiguous offset slice of the dataset
+    lib.conv_fwd(slab, 4 * 36 * 36, None, 8, w, b, out3, 8, d)
+    ii = torch.arange(8, 16)
+    out4 = torch.empty_like(out3)
+    lib.conv_fwd(slab[ii // T, ii % T].contiguous(), 4 * 36 * 36, None, 0, w, b, out4, 8, d0)
+    assert torch.equal(out3, out4)
+    # strided view slab[:, t] as used by the rollout / bootstrap forward
+    out5 = torch.empty((E * 64, 32), device="cuda")
+    lib.conv_fwd(slab[:, 2], slab.stride(0), None, 0, w, b, out5, E, d0)
+    out6 = torch.empty_like(out5)
+    lib.conv_fwd(slab[:, 2].contiguous(), 4 * 36 * 36, None, 0, w, b, out6, E, d0)
+    assert torch.equal(out5, out6)
+
+
+def make_model(cfg_over, obs_shape, A):
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import ActorCritic
+    cfg = default_cfg(use_rnn=False, nonlinearity="relu", normalize_input=False, encoder_conv_architecture="convnet_atari",
+                      obs_scale=255.0, **cfg_over)
+    obs_space = spaces.Dict({"obs": spaces.Box(0, 255, obs_shape, np.uint8)})
+    return cfg, obs_space, ActorCritic(cfg, obs_space, spaces.Discrete(A), "cuda")
+
+
+def load_seeded(ac, names, shapes, seed):
+    st = seeded_state([(n, eval(s)) for n, s in zip(names, shapes)], seed)
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=False)
+    return st
+
+
+def test_model_forward_matches_reference_atari(lib, golden):
+    """Nature-CNN actor-critic on u8 84x84x4 frames vs the REFERENCE model's outputs (model_fwd_atari.npz)."""
+    g = golden("model_fwd_atari")
+    cfg, _, ac = make_model({}, (4, 84, 84), 6)
+    assert ac.num_params() == 1687719                                   # P of the reference model
+    assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
+    load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
+    obs = torch.from_numpy(g["obs"]).cuda()
+    res = ac.forward({"obs": obs}, None)
+    np.testing.assert_allclose(res["action_logits"].cpu().numpy(), g["action_logits"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(res["values"].cpu().numpy(), g["values"], atol=2e-5, rtol=1e-4)
+    # integer-indexed consumers of the logits reproduce the reference's indices (argmax action, enjoy.py:177-182)
+    np.testing.assert_array_equal(res["action_logits"].argmax(1).cpu().numpy(), g["action_logits"].argmax(1))
+    # state_dict round trip in the reference's names / layouts
+    sd = ac.state_dict()
+    st = seeded_state([(n, eval(s)) for n, s in zip(g["param_names"], g["param_shapes"])], int(g["param_seed"]))
+    for k, v in st.items():
+        np.testing.assert_array_equal(sd[k].numpy(), v)
+
+
+def test_learner_train_matches_reference_cnn36(lib, golden, tmp_path):
+    """Full Learner.train on a trajectory batch (prepare_batch, 2 minibatches: fwd, loss, bwd, clip, Adam) vs the
+    post-training parameters / Adam moments / grad norms / normaliser state of the REFERENCE Learner.train."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    g = golden("train_cnn36")
+    E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
+    cfg = default_cfg(use_rnn=False, recurrence=1, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                      encoder_conv_architecture="convnet_atari", encoder_conv_mlp_layers=[128], rollout=T,
+                      batch_size=E * T // nb, num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]), seed=0,
+                      serial_mode=True, train_dir=str(tmp_path), experiment="t", record_grad_norm=True)
+    obs_space = spaces.Dict({"obs": spaces.Box(0, 255, (4, 36, 36), np.uint8)})
+    env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    ac = learner.actor_critic
+    load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
+    batch = alloc_trajectory_tensors(env_info, E, T, 1, "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    stats = learner.train(batch)
+    assert stats["learner_env_steps"] == int(g["env_steps"]) and learner.train_step == int(g["train_step"])
+    np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=2e-4)
+    np.testing.assert_allclose(ac.returns_normalizer.stats.cpu().numpy(), g["out_rms"], rtol=1e-5)
+    sub = int(g["subsample"])
+    after, m, v = ac.state_dict(), ac.flat_to_ref(learner.exp_avg), ac.flat_to_ref(learner.exp_avg_sq)
+    for name in g["param_names"]:
+        np.testing.assert_allclose(m[name].reshape(-1)[::sub].numpy(), g["m_" + name], rtol=2e-3, atol=2e-8, err_msg=name)
+        np.testing.assert_allclose(v[name].reshape(-1)[::sub].numpy(), g["v_" + name], rtol=4e-3, atol=1e-13, err_msg=name)
+        # Adam's first steps move every weight by ~lr regardless of |g|: compare at a fraction of lr=1e-4
+        np.testing.assert_allclose(after[name].reshape(-1)[::sub].numpy(), g["after_" + name], rtol=0, atol=1e-5, err_msg=name)
+    # checkpoint in the reference's format, reload, continue
+    learner.save()
+    l2 = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    l2.init()
+    assert l2.train_step == learner.train_step and l2.env_steps == learner.env_steps
+    assert torch.equal(l2.actor_critic.flat_params, ac.flat_params) and torch.equal(l2.exp_avg, learner.exp_avg)
+    cp = torch.load(Learner.get_checkpoints(Learner.checkpoint_dir(cfg, 0))[-1], weights_only=False)
+    assert set(cp) == {"train_step", "env_steps", "best_performance", "model", "optimizer", "curr_lr"}
+    assert "encoder.encoders.obs.enc.conv_head.0.weight" in cp["model"] and cp["model"]["returns_normalizer.count"].dtype == torch.float64
+
+
+def test_end_to_end_rollout_and_train_small(lib):
+    """synthetic env -> rollout into the slab -> train, a few iterations; checks the slab protocol invariants"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_atari", make_synthetic_env)
+    cfg = default_cfg(env="synthetic_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                      encoder_conv_architecture="convnet_atari", rollout=8, batch_size=256, num_batches_per_epoch=2,
+                      num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=False, seed=1, serial_mode=True,
+                      synthetic_num_agents=64, exploration_loss_coeff=0.01, shuffle_minibatches=True)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    p0 = runner.learner.actor_critic.flat_params.clone()
+    for _ in range(3):
+        stats = runner.iteration()
+    torch.cuda.synchronize()
+    tr = runner.traj
+    assert stats["learner_env_steps"] == 3 * 64 * 8
+    assert torch.all(tr["policy_id"] == 0) and tr["valids"][:, :-1].all()
+    assert ((tr["actions"] >= 0) & (tr["actions"] < 6)).all()
+    assert torch.isfinite(runner.learner.actor_critic.flat_params).all()
+    assert not torch.equal(p0, runner.learner.actor_critic.flat_params)
+    assert (tr["policy_version"] == 4.0).all()   # third rollout was collected by the policy after 2*2 SGD steps
+    # rewards follow the env rule given the recorded actions (identical-rollout bookkeeping)
+    import oracle
+    step_last = 3 * 8 - 1
+    r_ref, _ = oracle.synth_step(tr["actions"][:, -1, 0].cpu().numpy().astype(np.int32), 0, 6, 1, step_last)
+    np.testing.assert_array_equal(tr["rewards"][:, -1].cpu().numpy(), r_ref)
+    np.testing.assert_array_equal(tr["obs"]["obs"][:, 0].cpu().numpy().reshape(64, -1), oracle.synth_obs(64, 0, 28224, 1, 24))
+    s = runner.sampler.episode_stats()
+    assert s["episodes"] >= 0

@@ -1,0 +1,413 @@
+"""GPU parity tests for the HBM/latency-bound kernels, through the C ABI (sample_factory_amd.lib -> libsf_hip.so),
+against (a) golden vectors produced by the reference itself and (b) the CPU oracle on seeded inputs at full sizes.
+Tolerances: integers / masks / indices exact; advantages & returns <= 1e-5 (north star: 1e-4); losses/grads fp32."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sample_factory_amd import lib as L
+    L.load()
+    return L
+
+
+def run_gae(lib, rewards, dones, values, valids, gamma, lam, rms=None, time_outs=None, bootstrap=False):
+    r, d, v, va = dev(rewards, torch.float32), dev(dones, torch.bool), dev(values, torch.float32), dev(valids, torch.bool)
+    to = dev(time_outs, torch.bool) if time_outs is not None else None
+    st = dev(rms, torch.float64) if rms is not None else None
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    lib.gae_returns(r, d, to, v, va, st, gamma, lam, bootstrap, adv, ret)
+    torch.cuda.synchronize()
+    return adv.cpu().numpy(), ret.cpu().numpy(), r.cpu().numpy()
+
+
+def test_gae_golden(lib, golden):
+    g = golden("gae")
+    for i in range(int(g["num_cases"])):
+        adv, _, _ = run_gae(lib, g[f"c{i}_rewards"], g[f"c{i}_dones"], g[f"c{i}_values"], g[f"c{i}_valids"],
+                            float(g[f"c{i}_gamma"]), float(g[f"c{i}_lambda"]))
+        np.testing.assert_allclose(adv, g[f"c{i}_adv"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("E,T", [(4096, 32), (77, 5), (130, 128), (1, 1), (64, 33), (4096, 128)])
+def test_gae_vs_oracle(lib, E, T):
+    rng = np.random.default_rng(E * 1000 + T)
+    rewards = rng.standard_normal((E, T)).astype(np.float32)
+    dones = rng.random((E, T)) < 0.05
+    values = rng.standard_normal((E, T + 1)).astype(np.float32)
+    valids = rng.random((E, T + 1)) > 0.1
+    valids[:, -1] = valids[:, -2]
+    adv, ret, _ = run_gae(lib, rewards, dones, values, valids, 0.99, 0.95)
+    ref = oracle.gae(rewards, dones, values, valids, 0.99, 0.95)
+    np.testing.assert_allclose(adv, ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ret, ref + valids[:, :-1] * values[:, :-1], rtol=0, atol=1e-6)
+    # the wrapper with the reference's signature
+    from sample_factory_amd.algo.utils.rl_utils import gae_advantages
+    a2 = gae_advantages(dev(rewards), dev(dones), dev(values), dev(valids), 0.99, 0.95).cpu().numpy()
+    np.testing.assert_array_equal(a2, adv)
+
+
+def _kv(argv):
+    return {t[2:].split("=", 1)[0]: t[2:].split("=", 1)[1] for t in str(argv).split() if t.startswith("--") and "=" in t}
+
+
+@pytest.mark.parametrize("case", ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous"])
+def test_prepare_batch_golden(lib, golden, case):
+    """K13 + K10 + K11 + K12 chained exactly as Learner._prepare_batch chains them, vs the reference's output."""
+    g = golden("learner_" + case)
+    kv = _kv(g["argv"])
+    norm = kv.get("normalize_returns", "True") == "True"
+    boot = kv.get("value_bootstrap", "False") == "True"
+    E, T = g["in_rewards"].shape
+    values = g["in_values"].copy()
+    values[:, -1] = g["bootstrap_values"]
+    pid, pver = dev(g["in_policy_id"], torch.int32), dev(g["in_policy_version"], torch.float32)
+    valids = torch.zeros((E, T + 1), dtype=torch.bool, device="cuda")
+    actions, logp = dev(g["in_actions"], torch.float32), dev(g["in_log_prob_actions"], torch.float32)
+    ninv = torch.zeros(1, dtype=torch.int32, device="cuda")
+    na = actions.numel() // (E * T)
+    lib.valid_mask(pid, pver, valids, actions, na, logp, 0, int(g["train_step"]), int(kv.get("max_policy_lag", 1000)), ninv)
+    assert int(ninv.item()) == int(g["pb_num_invalids"])
+    np.testing.assert_array_equal(valids.cpu().numpy(), g["out_valids_full"])
+    np.testing.assert_array_equal(actions.cpu().numpy().reshape(g["pb_actions"].shape), g["pb_actions"])
+    np.testing.assert_array_equal(logp.cpu().numpy().reshape(-1), g["pb_log_prob_actions"])
+    rms = g["in_rms"] if norm else None
+    adv, ret, rew = run_gae(lib, g["in_rewards"], g["in_dones"], values, valids.cpu().numpy(), 0.99, 0.95, rms=rms,
+                            time_outs=g["in_time_outs"], bootstrap=boot)
+    np.testing.assert_allclose(rew, g["out_rewards"], atol=1e-6)
+    np.testing.assert_allclose(adv.reshape(-1), g["pb_advantages"], atol=1e-5)
+    if norm:
+        from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
+        r = RunningMeanStdInPlace((1,), "cuda")
+        r.stats.copy_(torch.as_tensor(g["in_rms"]))
+        rt = dev(ret.reshape(-1))
+        r(rt)
+        np.testing.assert_allclose(r.stats.cpu().numpy(), g["out_rms"], rtol=1e-6)
+        ret = rt.cpu().numpy()
+    np.testing.assert_allclose(ret.reshape(-1), g["pb_returns"], atol=1e-5)
+
+
+def test_rms_golden(lib, golden):
+    from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
+    g = golden("rms")
+    r = RunningMeanStdInPlace((1,), "cuda")
+    for i in range(int(g["num_steps"])):
+        x = dev(g[f"s{i}_x"])
+        r(x)
+        np.testing.assert_allclose(r.stats.cpu().numpy(), g[f"s{i}_stats"], rtol=2e-6)
+        np.testing.assert_allclose(x.cpu().numpy(), g[f"s{i}_normalized"], atol=2e-6, rtol=1e-6)
+        z = dev(g[f"s{i}_z"])
+        r(z, denormalize=True)
+        np.testing.assert_allclose(z.cpu().numpy(), g[f"s{i}_denormalized"], atol=1e-5, rtol=1e-6)
+    r.eval()
+    x = dev(g["eval_x"])
+    r(x)
+    np.testing.assert_allclose(x.cpu().numpy(), g["eval_normalized"], atol=2e-6)
+    np.testing.assert_allclose(r.stats.cpu().numpy(), g["eval_stats"], rtol=1e-12)
+    sd = r.state_dict("returns_normalizer.")
+    assert set(sd) == {"returns_normalizer.running_mean", "returns_normalizer.running_var", "returns_normalizer.count"}
+    assert sd["returns_normalizer.count"].dtype == torch.float64
+
+
+def _loss_cfg(lib, kv, continuous, dense_adv=False):
+    expl = kv.get("exploration_loss", "entropy")
+    coeff = float(kv.get("exploration_loss_coeff", 0.003))
+    return lib.sf_loss_cfg(clip_ratio=0.1, clip_value=1.0, value_loss_coeff=0.5, exploration_coeff=coeff,
+                           kl_coeff=float(kv.get("kl_loss_coeff", 0.0)),
+                           exploration_kind=0 if coeff == 0 else (1 if expl == "entropy" else 2),
+                           action_kind=1 if continuous else 0, dense_adv=int(dense_adv))
+
+
+def run_loss(lib, cfg, params, values, actions, old_logp, old_params, old_values, adv, targets, valids, index=None,
+             offset=0, n=None, fused_heads=False):
+    """Runs sf_moments + sf_ppo_loss + sf_loss_scalars; dataset arrays may be larger than the minibatch."""
+    n = params.shape[0] if n is None else n
+    A = params.shape[1]
+    if fused_heads:  # params/values as strided columns of one [n, 1+A] matrix (how the model produces them)
+        heads = torch.cat([dev(values, torch.float32)[:, None], dev(params, torch.float32)], dim=1).contiguous()
+        p, v, ld = heads[:, 1:], heads[:, 0], 1 + A
+        g = torch.zeros_like(heads)
+        gp, gv = g[:, 1:], g[:, 0]
+    else:
+        p, v, ld = dev(params, torch.float32), dev(values, torch.float32), A
+        gp, gv = torch.zeros_like(p), torch.zeros_like(v)
+    d = dict(actions=dev(actions, torch.float32), old_logp=dev(old_logp, torch.float32),
+             old_params=dev(old_params, torch.float32), old_values=dev(old_values, torch.float32),
+             adv=dev(adv, torch.float32), targets=dev(targets, torch.float32), valids=dev(valids, torch.bool))
+    idx = dev(index, torch.int32) if index is not None else None
+    mom = torch.zeros(3, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(8, dtype=torch.float64, device="cuda")
+    out = torch.zeros(16, dtype=torch.float32, device="cuda")
+    if cfg.dense_adv:
+        vd = d["valids"][idx.long()] if idx is not None else d["valids"][offset:offset + n]
+        lib.moments(d["adv"], vd.contiguous(), None, n, mom)
+    elif idx is not None:
+        lib.moments(d["adv"], d["valids"], idx, n, mom)
+    else:
+        lib.moments(d["adv"][offset:offset + n], d["valids"][offset:offset + n], None, n, mom)
+    lib.ppo_loss(p, ld, v, ld if fused_heads else 1, d["actions"], d["old_logp"], d["old_params"], d["old_values"],
+                 d["adv"], d["targets"], d["valids"], idx, offset, n, A, cfg, mom, sums, gp, gv)
+    lib.loss_scalars(sums, mom, cfg, out)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    res = {k: float(o[i]) for i, k in enumerate(oracle.SCALAR_NAMES)}
+    res["grad_params"], res["grad_values"] = gp.cpu().numpy(), gv.cpu().numpy()
+    return res
+
+
+@pytest.mark.parametrize("case", ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous", "ff_vtrace"])
+@pytest.mark.parametrize("fused_heads", [False, True])
+def test_ppo_loss_golden(lib, golden, case, fused_heads):
+    g = golden("learner_" + case)
+    kv = _kv(g["argv"])
+    n = int(g["mb_size"])
+    continuous = case == "ff_continuous"
+    cfg = _loss_cfg(lib, kv, continuous, dense_adv=case == "ff_vtrace")
+    A = g["l_params"].shape[1]
+    if case == "ff_vtrace":
+        vs = torch.zeros(n, device="cuda")
+        adv = torch.zeros(n, device="cuda")
+        lib.vtrace(dev(g["l_params"]), A, dev(g["l_values"]), 1, dev(g["pb_actions"], torch.float32),
+                   dev(g["pb_log_prob_actions"]), dev(g["pb_rewards"]), dev(g["pb_dones"], torch.bool), None, 0, n, A,
+                   0, int(kv["recurrence"]), 0.99, float(kv["vtrace_rho"]), float(kv["vtrace_c"]), vs, adv)
+        np.testing.assert_allclose(vs.cpu().numpy(), g["l_targets"], atol=1e-5)
+        adv_arr, tgt_arr = adv.cpu().numpy(), vs.cpu().numpy()
+    else:
+        adv_arr, tgt_arr = g["pb_advantages"], g["pb_returns"]
+    out = run_loss(lib, cfg, g["l_params"], g["l_values"], g["pb_actions"], g["pb_log_prob_actions"],
+                   g["pb_action_logits"], g["pb_values"], adv_arr, tgt_arr, g["pb_valids"], n=n,
+                   fused_heads=fused_heads)
+    assert abs(out["adv_mean"] - float(g["l_adv_mean"])) < 1e-6
+    assert abs(out["adv_std"] - float(g["l_adv_std"])) < 2e-6
+    for k in ["policy_loss", "exploration_loss", "kl_loss", "value_loss"]:
+        ref = float(g["l_" + k])
+        assert abs(out[k] - ref) < 2e-6 + 1e-5 * abs(ref), (k, out[k], ref)
+    np.testing.assert_allclose(out["grad_params"], g["l_grad_params"], atol=2e-7, rtol=2e-4)
+    np.testing.assert_allclose(out["grad_values"], g["l_grad_values"], atol=2e-7, rtol=2e-4)
+
+
+@pytest.mark.parametrize("A,kind,expl,klc", [(6, 0, 1, 0.0), (18, 0, 2, 0.3), (6, 1, 1, 0.1), (40, 0, 1, 0.2)])
+def test_ppo_loss_vs_oracle_full_size(lib, A, kind, expl, klc):
+    """config-2 minibatch size, read through a shuffled index into a 4x larger dataset."""
+    rng = np.random.default_rng(A * 7 + kind)
+    N, n = 131072, 32768
+    nact = 1 if kind == 0 else A // 2
+    old_params = rng.standard_normal((N, A)).astype(np.float32)
+    actions = (rng.integers(0, A, (N, 1)) if kind == 0 else rng.standard_normal((N, nact))).astype(np.float32)
+    old_logp = (-rng.random(N) * 2 - 0.3).astype(np.float32)
+    old_values = rng.standard_normal(N).astype(np.float32)
+    adv = rng.standard_normal(N).astype(np.float32) * 3 + 0.5
+    targets = rng.standard_normal(N).astype(np.float32)
+    valids = rng.random(N) > 0.07
+    index = rng.permutation(N)[:n].astype(np.int32)
+    params = (old_params[index] + 0.3 * rng.standard_normal((n, A))).astype(np.float32)
+    values = (old_values[index] + rng.standard_normal(n) * 0.7).astype(np.float32)
+    cfg = lib.sf_loss_cfg(clip_ratio=0.1, clip_value=0.5, value_loss_coeff=0.5, exploration_coeff=0.01, kl_coeff=klc,
+                          exploration_kind=expl, action_kind=kind, dense_adv=0)
+    out = run_loss(lib, cfg, params, values, actions, old_logp, old_params, old_values, adv, targets, valids,
+                   index=index, n=n, fused_heads=True)
+    ref = oracle.ppo_loss(params, values, actions[index], old_logp[index], old_params[index], old_values[index],
+                          adv[index], targets[index], valids[index], action_kind=kind, clip_ratio=0.1, clip_value=0.5,
+                          value_loss_coeff=0.5, exploration_coeff=0.01, exploration_kind=expl, kl_coeff=klc)
+    assert out["n_valid"] == ref["n_valid"]
+    for k in ["policy_loss", "exploration_loss", "kl_loss", "value_loss", "adv_mean", "adv_std", "kl_mean"]:
+        assert abs(out[k] - ref[k]) < 1e-6 + 2e-5 * abs(ref[k]), (k, out[k], ref[k])
+    assert abs(out["kl_max"] - ref["kl_max"]) < 1e-4 * max(1.0, abs(ref["kl_max"]))
+    np.testing.assert_allclose(out["grad_params"], ref["grad_params"], atol=1e-9, rtol=5e-4)
+    np.testing.assert_allclose(out["grad_values"], ref["grad_values"], atol=1e-9, rtol=5e-4)
+    # size-independent property: gradients of invalid samples are exactly zero
+    assert np.all(out["grad_params"][~valids[index]] == 0) and np.all(out["grad_values"][~valids[index]] == 0)
+    # categorical: every gradient row sums to ~0 (softmax Jacobian annihilates constants)
+    if kind == 0:
+        assert np.abs(out["grad_params"].sum(1)).max() < 1e-8
+
+
+def test_ppo_loss_offset_equals_index(lib):
+    rng = np.random.default_rng(5)
+    N, n, A = 4096, 1024, 6
+    a = dict(old_params=rng.standard_normal((N, A)), actions=rng.integers(0, A, (N, 1)), old_logp=-rng.random(N) - 0.2,
+             old_values=rng.standard_normal(N), adv=rng.standard_normal(N), targets=rng.standard_normal(N),
+             valids=rng.random(N) > 0.1)
+    params, values = rng.standard_normal((n, A)), rng.standard_normal(n)
+    cfg = lib.sf_loss_cfg(clip_ratio=0.1, clip_value=1.0, value_loss_coeff=0.5, exploration_coeff=0.003, kl_coeff=0.0,
+                          exploration_kind=1, action_kind=0, dense_adv=0)
+    args = (params, values, a["actions"], a["old_logp"], a["old_params"], a["old_values"], a["adv"], a["targets"], a["valids"])
+    o1 = run_loss(lib, cfg, *args, offset=2048, n=n)
+    o2 = run_loss(lib, cfg, *args, index=np.arange(2048, 2048 + n), n=n)
+    np.testing.assert_array_equal(o1["grad_params"], o2["grad_params"])  # integer indexing: bit-exact
+    np.testing.assert_array_equal(o1["grad_values"], o2["grad_values"])
+
+
+@pytest.mark.parametrize("N,rec", [(4096, 8), (640, 32), (96, 1)])
+def test_vtrace_vs_oracle(lib, N, rec):
+    rng = np.random.default_rng(N + rec)
+    A = 6
+    params = rng.standard_normal((N, A)).astype(np.float32)
+    actions = rng.integers(0, A, (N, 1)).astype(np.float32)
+    _, logp_a, _ = oracle.categorical(params, actions.reshape(-1))
+    old_logp = (logp_a + rng.standard_normal(N) * 0.3).astype(np.float32)
+    ratio = np.clip(np.exp(logp_a - old_logp), 0.05, 20.0).astype(np.float32)
+    values, rewards = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    dones = rng.random(N) < 0.1
+    vs, adv = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    lib.vtrace(dev(params), A, dev(values), 1, dev(actions), dev(old_logp), dev(rewards), dev(dones, torch.bool), None,
+               0, N, A, 0, rec, 0.99, 1.0, 1.0, vs, adv)
+    rvs, radv = oracle.vtrace(ratio, values, rewards, dones.astype(np.float32), rec, 0.99)
+    np.testing.assert_allclose(vs.cpu().numpy(), rvs, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(adv.cpu().numpy(), radv, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("P", [1687719 + 25, 1000, 7])
+def test_clip_and_adam_vs_oracle(lib, P):
+    rng = np.random.default_rng(P)
+    Pp = (P + 3) // 4 * 4
+    p = rng.standard_normal(Pp).astype(np.float32)
+    m, v = np.zeros(Pp, np.float32), np.zeros(Pp, np.float32)
+    tp, tm, tv = dev(p), dev(m), dev(v)
+    sumsq = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for step in range(1, 4):
+        g = (rng.standard_normal(Pp) * (10.0 if step == 2 else 0.001)).astype(np.float32)
+        tg = dev(g)
+        lib.grad_sumsq(tg, sumsq)
+        lib.adam_step(tp, tg, tm, tv, step, 1e-4, 0.9, 0.999, 1e-6, 4.0, sumsq)
+        gc, total = oracle.clip_grad_norm(g, 4.0)
+        assert abs(float(sumsq.sqrt().item()) - total) < 1e-5 * max(1.0, total)
+        p, m, v = oracle.adam_step(p, gc, m, v, step, 1e-4, 0.9, 0.999, 1e-6)
+        np.testing.assert_allclose(tm.cpu().numpy(), m, rtol=2e-5, atol=1e-10)
+        np.testing.assert_allclose(tv.cpu().numpy(), v, rtol=4e-5, atol=1e-14)
+        np.testing.assert_allclose(tp.cpu().numpy(), p, rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("N,rec", [(131072, 1), (4096, 32), (96, 4), (64, 64)])
+def test_minibatch_indices_properties(lib, N, rec):
+    out = torch.empty(N, dtype=torch.int32, device="cuda")
+    lib.minibatch_indices(out, N, rec, False, 0, 0)
+    np.testing.assert_array_equal(out.cpu().numpy(), np.arange(N))          # default: contiguous slices
+    lib.minibatch_indices(out, N, rec, True, 123, 0)
+    a = out.cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(np.sort(a), np.arange(N))                 # a permutation of the dataset
+    ch = a.reshape(-1, rec)
+    assert np.all(ch[:, 0] % rec == 0)                                      # chunk starts are recurrence-aligned
+    np.testing.assert_array_equal(ch, ch[:, :1] + np.arange(rec)[None, :])  # chunks stay intact (learner.py:512-515)
+    if N // rec > 8:
+        assert not np.array_equal(a, np.arange(N))
+        lib.minibatch_indices(out, N, rec, True, 123, 1)
+        assert not np.array_equal(out.cpu().numpy(), a)                     # new epoch -> new permutation
+        lib.minibatch_indices(out, N, rec, True, 123, 0)
+        np.testing.assert_array_equal(out.cpu().numpy(), a)                 # stateless / reproducible
+
+
+def test_minibatch_expansion_golden(lib, golden):
+    """index expansion of the reference (learner.py:512-519): our layout of a chunk == theirs"""
+    g = golden("minibatch_indices")
+    rec = int(g["recurrence"])
+    starts = g["minibatches"].reshape(-1, rec)[:, 0]
+    np.testing.assert_array_equal(g["minibatches"].reshape(-1, rec), starts[:, None] + np.arange(rec)[None])
+
+
+def test_synthetic_env_bit_exact(lib):
+    from sample_factory_amd.envs.synthetic import SyntheticVecEnv
+    env = SyntheticVecEnv(num_agents=96, obs_shape=(4, 84, 84), num_actions=6, seed=3, env0=1000)
+    T = 3
+    slab = torch.zeros((96, T + 1, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    env.reset_into(slab[:, 0])
+    np.testing.assert_array_equal(slab[:, 0].cpu().numpy().reshape(96, -1), oracle.synth_obs(96, 1000, 28224, 3, 0))
+    rng = np.random.default_rng(0)
+    for t in range(T):
+        a = rng.integers(0, 6, 96).astype(np.int32)
+        rew, term, trunc = env.step_into(dev(a, torch.int32), slab[:, t + 1])
+        r_ref, t_ref = oracle.synth_step(a, 1000, 6, 3, t)
+        np.testing.assert_array_equal(rew.cpu().numpy(), r_ref)
+        np.testing.assert_array_equal(term.cpu().numpy(), t_ref)
+        np.testing.assert_array_equal(slab[:, t + 1].cpu().numpy().reshape(96, -1), oracle.synth_obs(96, 1000, 28224, 3, t + 1))
+    assert not trunc.any()
+    # gymnasium-style surface
+    obs, info = env.reset()
+    o2, rew, term, trunc, info = env.step(torch.zeros(96, dtype=torch.int64))
+    assert o2["obs"].shape == (96, 4, 84, 84) and o2["obs"].dtype == torch.uint8 and rew.shape == (96,)
+
+
+@pytest.mark.parametrize("B,A", [(4096, 6), (100, 18), (7, 2)])
+def test_sample_write_step_vs_oracle(lib, B, A):
+    rng = np.random.default_rng(B + A)
+    T, t = 5, 2
+    logits = (rng.standard_normal((B, A)) * 2).astype(np.float32)
+    values = rng.standard_normal(B).astype(np.float32)
+    heads = dev(np.concatenate([values[:, None], logits], 1))
+    tr = dict(actions=torch.full((B, T, 1), -7.0, device="cuda"), logits=torch.full((B, T, A), -7.0, device="cuda"),
+              logp=torch.full((B, T), -7.0, device="cuda"), values=torch.full((B, T + 1), -7.0, device="cuda"),
+              ver=torch.full((B, T), -7.0, device="cuda"))
+    env_a = torch.zeros(B, dtype=torch.int32, device="cuda")
+    lib.sample_write_step(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, B, A, T, t, 11, 77, 5, 42.0, False, tr["actions"],
+                          tr["logits"], tr["logp"], tr["values"], tr["ver"], env_a)
+    act_ref, lp_ref = oracle.sample_categorical(logits, 11, 77, row0=5)
+    np.testing.assert_array_equal(tr["actions"][:, t, 0].cpu().numpy(), act_ref)       # integer action: exact
+    np.testing.assert_array_equal(env_a.cpu().numpy(), act_ref.astype(np.int32))
+    np.testing.assert_allclose(tr["logp"][:, t].cpu().numpy(), lp_ref, atol=2e-6)
+    np.testing.assert_array_equal(tr["logits"][:, t].cpu().numpy(), logits)
+    np.testing.assert_array_equal(tr["values"][:, t].cpu().numpy(), values)
+    assert torch.all(tr["ver"][:, t] == 42.0)
+    # untouched steps keep their sentinel
+    assert torch.all(tr["actions"][:, t + 1] == -7.0) and torch.all(tr["values"][:, t + 1] == -7.0)
+    # log-prob is the gather at the recorded integer action (action_distributions.py:145-148)
+    lp_all, _, _ = oracle.categorical(logits, act_ref)
+    np.testing.assert_allclose(tr["logp"][:, t].cpu().numpy(), lp_all[np.arange(B), act_ref.astype(int)], atol=2e-6)
+    # deterministic = argmax (enjoy.py:177-182)
+    lib.sample_write_step(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, B, A, T, t, 11, 77, 5, 42.0, True, tr["actions"],
+                          tr["logits"], tr["logp"], tr["values"], tr["ver"], env_a)
+    np.testing.assert_array_equal(env_a.cpu().numpy(), logits.argmax(1).astype(np.int32))
+
+
+def test_sampler_distribution(lib):
+    """sampling parity is distributional (torch.multinomial's stream cannot be reproduced): chi-square-ish check"""
+    B, A, T = 200000, 6, 1
+    logits = np.tile(np.array([[0.0, 1.0, 2.0, -1.0, 0.5, 0.2]], np.float32), (B, 1))
+    heads = dev(np.concatenate([np.zeros((B, 1), np.float32), logits], 1))
+    z = lambda *s: torch.zeros(s, device="cuda")
+    env_a = torch.zeros(B, dtype=torch.int32, device="cuda")
+    lib.sample_write_step(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, B, A, T, 0, 1, 0, 0, 0.0, False, z(B, T, 1),
+                          z(B, T, A), z(B, T), z(B, T + 1), z(B, T), env_a)
+    freq = np.bincount(env_a.cpu().numpy(), minlength=A) / B
+    p = np.exp(logits[0]) / np.exp(logits[0]).sum()
+    assert np.abs(freq - p).max() < 4 * np.sqrt(p.max() / B) + 1e-3
+
+
+def test_traj_write_env_step(lib):
+    B, T, t = 300, 4, 1
+    rng = np.random.default_rng(1)
+    rew = (rng.standard_normal(B) * 5).astype(np.float32)
+    term, trunc = rng.random(B) < 0.3, rng.random(B) < 0.1
+    tr = dict(r=torch.zeros((B, T), device="cuda"), d=torch.zeros((B, T), dtype=torch.bool, device="cuda"),
+              to=torch.zeros((B, T), dtype=torch.bool, device="cuda"), pid=torch.full((B, T), -1, dtype=torch.int32, device="cuda"))
+    ep_ret, ep_len = dev(np.ones(B, np.float32)), dev(np.full(B, 3, np.int32))
+    ep_stats = torch.zeros(3, dtype=torch.float64, device="cuda")
+    lib.traj_write_env_step(dev(rew), dev(term, torch.bool), dev(trunc, torch.bool), T, t, 0.5, 2.0, 0, tr["r"], tr["d"],
+                            tr["to"], tr["pid"], ep_ret, ep_len, ep_stats)
+    np.testing.assert_allclose(tr["r"][:, t].cpu().numpy(), np.clip(rew * np.float32(0.5), -2, 2), atol=0)
+    done = term | trunc
+    np.testing.assert_array_equal(tr["d"][:, t].cpu().numpy(), done)
+    np.testing.assert_array_equal(tr["to"][:, t].cpu().numpy(), trunc)
+    assert torch.all(tr["pid"][:, t] == 0) and torch.all(tr["pid"][:, 0] == -1)
+    s = ep_stats.cpu().numpy()
+    assert s[2] == done.sum() and s[1] == 4 * done.sum()
+    np.testing.assert_allclose(s[0], (1.0 + rew[done]).sum(), rtol=1e-6)
+    np.testing.assert_allclose(ep_ret.cpu().numpy(), np.where(done, 0, 1.0 + rew), atol=1e-6)
+
+
+def test_no_cpu_fallback(lib):
+    """the product path refuses CPU tensors instead of silently computing elsewhere"""
+    with pytest.raises(lib.SfHipError):
+        lib.grad_sumsq(torch.zeros(16), torch.zeros(1, dtype=torch.float64, device="cuda"))
