@@ -1,0 +1,147 @@
+"""bench.py — env-steps/sec of the APPO hot path on the BASELINE.json workload.
+
+A "step" is one full pass of the hot path over one batch of synthetic input: a rollout of `rollout` env steps for all
+`envs` device-resident synthetic envs (policy inference + sampling + env + trajectory writes) followed by Learner.train
+on that dataset (bootstrap values, GAE, returns normaliser, `num_batches` minibatches of forward / PPO loss / backward
+/ clip / Adam).  Workload = BASELINE.json configs[1] ("synthetic vector env 4096 envs, 84x84x4 uint8 obs, discrete(6),
+Nature-CNN actor-critic, 1xMI355X") with the NS-2 learner preset of SURVEY.md §8d.  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) every rank runs the same per-GPU workload on its own env shard and gradients /
+advantage moments are all-reduced over RCCL: weak scaling, value = whole-job env-steps/s.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_GBS = 8000.0
+
+
+def kernel_flops(key):
+    """algorithmic FLOPs of one launch of a network kernel (2*M*N*K of the implicit GEMM)"""
+    op, n, Cin, H, W, Cout, K, S, OH, OW = key
+    return 2.0 * n * OH * OW * Cout * (K * K * Cin)  # fwd, wgrad and (gather-form, no zero taps) dgrad are equal
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--rollout", type=int, default=32)
+    ap.add_argument("--num_batches", type=int, default=4)
+    ap.add_argument("--num_epochs", type=int, default=1)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_baseline_envs", type=int, default=256)
+    args = ap.parse_args()
+
+    import torch
+
+    from sample_factory_amd import lib
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} must be launched as `python -m torch.distributed.run --nproc-per-node "
+                         f"{args.gpus} bench.py --gpus {args.gpus} ...` (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.distributed.init_process_group("nccl")  # RCCL on ROCm
+
+    register_env("synthetic_atari", make_synthetic_env)
+    B, T = args.envs, args.rollout
+    cfg = default_cfg(
+        env="synthetic_atari", use_rnn=False, recurrence=1, encoder_conv_architecture="convnet_atari",
+        nonlinearity="relu", encoder_conv_mlp_layers=[512], obs_scale=255.0, normalize_input=False,
+        normalize_returns=True, rollout=T, batch_size=B * T // args.num_batches, num_batches_per_epoch=args.num_batches,
+        num_epochs=args.num_epochs, gamma=0.99, gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0,
+        value_loss_coeff=0.5, exploration_loss_coeff=0.01, max_grad_norm=4.0, learning_rate=1e-4, adam_eps=1e-6,
+        async_rl=False, serial_mode=True, batched_sampling=True, num_workers=1, num_envs_per_worker=1,
+        worker_num_splits=1, env_gpu_observations=True, env_gpu_actions=True, actor_worker_gpus=[0], seed=0,
+        synthetic_num_agents=B, synthetic_env0=rank * B, data_parallel=world > 1)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.iteration()
+    lib.PROFILE = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.iteration()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, lib.PROFILE = lib.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    env_steps = args.steps * B * T * world
+    value = env_steps / dt
+
+    # ---- roofline of the dominant kernel (largest total time among the network kernels, HIP events, timed region)
+    kern = []
+    for key, evs in prof.items():
+        ms = [s.elapsed_time(e) for s, e in evs]
+        kern.append((sum(ms), key, len(ms), sum(ms) / len(ms)))
+    kern.sort(reverse=True)
+    total_ms, key, launches, avg_ms = kern[0]
+    achieved = kernel_flops(key) / (avg_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": f"sf_conv_{key[0]} n={key[1]} Cin={key[2]} HxW={key[3]}x{key[4]} Cout={key[5]} "
+                                           f"k={key[6]} s={key[7]}",
+                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "launches": launches, "share_of_step_time": round(total_ms / (dt * 1e3), 4)}
+    net_ms = sum(k[0] for k in kern)
+    net_flops = sum(kernel_flops(k[1]) * k[2] for k in kern)
+    breakdown = [{"kernel": f"{k[1][0]}:{k[1][2]}x{k[1][3]}->{k[1][5]} n={k[1][1]}", "ms_total": round(k[0], 2),
+                  "launches": k[2], "tflops": round(kernel_flops(k[1]) / (k[3] * 1e-3) / 1e12, 1)} for k in kern[:12]]
+
+    out = {
+        "metric": "env-steps/sec (whole node), 4096 envs, 84x84x4 obs", "value": round(value, 1), "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: synthetic vector env {B} envs/GPU, 84x84x4 u8 obs, "
+                               f"Discrete(6), Nature-CNN actor-critic (1,687,719 params), APPO sync, rollout={T}, "
+                               f"batch_size={cfg.batch_size} x {args.num_batches} minibatches x {args.num_epochs} epoch(s)",
+                   "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
+                   "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},
+        "roofline": roofline,
+        "network_kernels": {"ms_per_step": round(net_ms / args.steps, 2), "tflops_avg": round(net_flops / (net_ms * 1e-3) / 1e12, 2),
+                            "share_of_step_time": round(net_ms / (dt * 1e3), 4), "top": breakdown},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_baseline  # checker/baseline leg only; never on the measured path
+        out["cpu_baseline"] = cpu_baseline.run(num_envs=args.cpu_baseline_envs, rollout=T, num_minibatches=args.num_batches)
+        out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

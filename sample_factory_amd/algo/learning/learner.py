@@ -319,7 +319,7 @@ class Learner:
         buff.log_prob_actions = batch["log_prob_actions"].view(N)
         buff.rewards = batch["rewards"].view(N)
         buff.dones = batch["dones"].view(N)
-        buff.values = batch["values"][:, :T].reshape(N)
+        buff["values"] = batch["values"][:, :T].reshape(N)  # NB: item access, AttrDict.values is dict.values
         buff.valids = batch["valids"][:, :T].reshape(N)
         buff.E, buff.T = E, T
         if cfg.normalize_returns and not cfg.with_vtrace:
@@ -383,7 +383,7 @@ class Learner:
                 lib.moments(buff.advantages[offset:offset + n], buff.valids[offset:offset + n], None, n, self._moments)
             adv_arr, tgt_arr = buff.advantages, buff.returns
         self._all_reduce(self._moments)  # global per-minibatch advantage statistics under DP
-        lib.ppo_loss(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.action_logits, buff.values,
+        lib.ppo_loss(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.action_logits, buff["values"],
                      adv_arr, tgt_arr, buff.valids, index, offset, n, A, self.loss_cfg, self._moments, self._sums,
                      g_heads[:, 1:], g_heads[:, 0])
         if self.world > 1:

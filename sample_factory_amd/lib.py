@@ -44,6 +44,32 @@ SYMBOLS = [
 
 _lib: Optional[C.CDLL] = None
 
+# Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).  Events are recorded on
+# torch's CURRENT stream, which is the stream every call below launches on.  PROFILE maps key -> [(start, end), ...].
+PROFILE: Optional[dict] = None
+
+
+class _timed:
+    def __init__(self, key):
+        self.key = key if PROFILE is not None else None
+
+    def __enter__(self):
+        if self.key is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.key is not None:
+            self.e.record()
+            PROFILE.setdefault(self.key, []).append((self.s, self.e))
+        return False
+
+
+def _dkey(op, n, d):
+    return (op, int(n), d.Cin, d.H, d.W, d.Cout, d.KH, d.stride, d.OH, d.OW)
+
 
 def load() -> C.CDLL:
     """Load the HIP library or fail loudly (no CPU path exists)."""
@@ -236,7 +262,8 @@ def _raw_in(t: torch.Tensor, desc: sf_conv_desc) -> C.c_void_p:
 
 def conv_fwd_raw(inp, in_sample_stride, index, offset, w, bias, out, n, desc: sf_conv_desc) -> None:
     """`inp` may be a strided view (e.g. slab[:, t]); its data_ptr is sample 0, samples are in_sample_stride apart."""
-    _check(load().sf_conv_fwd(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
+    with _timed(_dkey("fwd", n, desc)):
+      _check(load().sf_conv_fwd(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
                               i64(offset), ptr(w, "f32", "w"), ptr(bias, "f32", "bias"), ptr(out, "f32", "out"),
                               i64(n), C.byref(desc), stream()), "sf_conv_fwd")
 
@@ -246,13 +273,15 @@ def conv_wgrad_workspace(n, desc: sf_conv_desc) -> int:
 
 
 def conv_wgrad_raw(inp, in_sample_stride, index, offset, dout, dw, db, n, desc: sf_conv_desc, workspace) -> None:
-    _check(load().sf_conv_wgrad(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
+    with _timed(_dkey("wgrad", n, desc)):
+      _check(load().sf_conv_wgrad(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
                                 i64(offset), ptr(dout, "f32", "dout"), ptr(dw, "f32", "dw"), ptr(db, "f32", "db"),
                                 i64(n), C.byref(desc), ptr(workspace, "u8", "workspace"), stream()), "sf_conv_wgrad")
 
 
 def conv_dgrad(dout, w, in_act, din, n, desc: sf_conv_desc) -> None:
-    _check(load().sf_conv_dgrad(ptr(dout, "f32", "dout"), ptr(w, "f32", "w"), ptr(in_act, "f32", "in_act"),
+    with _timed(_dkey("dgrad", n, desc)):
+      _check(load().sf_conv_dgrad(ptr(dout, "f32", "dout"), ptr(w, "f32", "w"), ptr(in_act, "f32", "in_act"),
                                 ptr(din, "f32", "din"), i64(n), C.byref(desc), stream()), "sf_conv_dgrad")
 
 
