@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--num_batches", type=int, default=4)
     ap.add_argument("--num_epochs", type=int, default=1)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_kernel_events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
     args = ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
 
     for _ in range(args.warmup):
         runner.iteration()
-    lib.PROFILE = {}
+    lib.PROFILE = None if args.no_kernel_events else {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -102,6 +103,10 @@ def main():
     env_steps = args.steps * B * T * world
     value = env_steps / dt
 
+    if not prof:
+        if rank == 0:
+            print(json.dumps({"value": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": world}))
+        return
     # ---- roofline of the dominant kernel (largest total time among the network kernels, HIP events, timed region)
     kern = []
     for key, evs in prof.items():

@@ -176,9 +176,14 @@ typedef struct {
 } sf_conv_desc;
 
 /* forward: in = u8 NCHW [n, Cin,H,W] (in_u8) or f32 NHWC [n,H,W,Cin]; sample i of the batch is input row
- * (index ? index[i] : offset+i) * in_sample_stride (elements).  out f32 NHWC [n,OH,OW,Cout]. */
+ * (index ? index[i] : offset+i) * in_sample_stride (elements).  out f32 NHWC [n,OH,OW,Cout].
+ * workspace (optional, >= sf_conv_fwd_workspace bytes, 16-byte aligned): lets small launches (e.g. the 3136->512
+ * layer at inference batch 4096: 256 tiles for 256 CUs) split the reduction over gridDim.z and finish with a
+ * deterministic ordered sum (+bias, ReLU); NULL = never split. */
+int64_t sf_conv_fwd_workspace(int64_t n, const sf_conv_desc *h_desc);
 int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *w,
-                const float *bias, float *out, int64_t n, const sf_conv_desc *h_desc, void *stream);
+                const float *bias, float *out, int64_t n, const sf_conv_desc *h_desc, void *workspace,
+                int64_t workspace_bytes, void *stream);
 /* weight/bias gradient: dw[K,Cout] (+)= gather(in)^T * dout, db[Cout] = sum dout; dout already has the ReLU mask
  * applied (sf_conv_fwd's consumer does it).  Deterministic two-stage split reduction; workspace >=
  * sf_conv_wgrad_workspace(...) bytes. */

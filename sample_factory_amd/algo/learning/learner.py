@@ -364,9 +364,9 @@ class Learner:
         acts = ac.forward_heads(buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
                                 traj_T=buff.T, tag="train")
         heads = acts[-1]
-        ld = 1 + A
+        ld = ac.heads_ld  # 1 + A padded to a multiple of 4; padding columns of g_heads stay zero
         params, values = heads[:, 1:], heads[:, 0]
-        g_heads = ac._buf(("g", "heads"), (n, ld))
+        g_heads = ac._zbuf(("g", "heads"), (n, ld))
         if cfg.with_vtrace:
             vs = ac._buf(("vt", "vs"), (n,))
             adv = ac._buf(("vt", "adv"), (n,))

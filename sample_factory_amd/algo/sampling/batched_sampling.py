@@ -42,8 +42,7 @@ class BatchedVectorEnvRunner:
         self.obs = traj["obs"]["obs"]
         self._started = False
         self.A = actor_critic.num_action_params
-        if getattr(actor_critic.layers[-1].desc, "Cout") != 1 + self.A:
-            raise RuntimeError("heads layout mismatch")
+        self.ld = actor_critic.heads_ld
         if self.env_info.action_space.__class__.__name__ != "Discrete" and not hasattr(self.env_info.action_space, "n"):
             raise NotImplementedError("native sampler: Discrete action spaces only in this round")
 
@@ -69,7 +68,7 @@ class BatchedVectorEnvRunner:
         cfg = self.cfg
         for t in range(T):
             heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf")[-1]
-            lib.sample_write_step(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, B, A, T, t, self.sample_seed,
+            lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
                                   self.global_step, 0, ver, deterministic, tr["actions"], tr["action_logits"],
                                   tr["log_prob_actions"], tr["values"], tr["policy_version"], self.env_actions)
             if self.zero_copy:

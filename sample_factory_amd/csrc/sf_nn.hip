@@ -15,6 +15,10 @@
 // Tile: 256 threads = 4 wavefronts (one per SIMD), block tile BM x BN x 32, LDS image As[32][BM+pad], Bs[32][BN+pad]
 // (reduction-major => both MFMA fragment reads are 32 consecutive words, conflict-free), register prefetch of the next
 // K-chunk while the current one is in the matrix pipe.
+//
+// Loaders are compile-time specialised (MODE) and BRANCH-FREE: out-of-range rows / columns / reduction indices load
+// from a clamped, always-valid address and are zeroed with a select, so the compiler issues every global load of a
+// chunk back-to-back and waits once (the first version branched per load and hipcc serialised them with vmcnt(0)).
 #include "sf_common.h"
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -36,8 +40,8 @@ static inline FastDiv make_fastdiv(uint32_t d) {
     return f;
 }
 __host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
-    if (f.d <= 1) return n;
-    return (uint32_t)(((uint64_t)n * f.mul) >> 32) >> f.shr;
+    const uint32_t q = (uint32_t)(((uint64_t)n * f.mul) >> 32) >> f.shr;
+    return f.d <= 1 ? n : q;  // select, not a branch: keeps the loaders straight-line
 }
 
 extern "C" int sf_selftest_host(void) {  // exercised by the CPU test-suite: the index math everything rests on
@@ -58,7 +62,7 @@ struct ConvG {
     int in_u8, relu, traj_T;
     float sub_mean, inv_scale;
     int K;          // KH*KW*Cin
-    int vecA, vecB; // vector (16-byte / 4-byte-of-u8) loads legal for the activation / weight operand
+    int vecA, vecB; // vector (16-byte / 4-byte-of-u8) loads legal for the activation / [*,Cout] operands
     FastDiv dOHOW, dOW, dCin, dKW, dKHKW, dT, dCout;
 };
 
@@ -89,22 +93,25 @@ static int check_desc(const sf_conv_desc *d, const char *who) {
     return SF_OK;
 }
 
+// loader specialisations
+constexpr int MODE_F32 = 0;      // f32 NHWC activations, Cin % 4 == 0, Cout % 4 == 0: 16-byte loads everywhere
+constexpr int MODE_U8 = 1;       // raw u8 NCHW observation, KW/stride/W % 4 == 0: 4-byte loads of 4 pixels
+constexpr int MODE_GENERIC = 2;  // any geometry: scalar, bounds-checked (slow; odd shapes only)
+
 // input-sample base offset (elements) of logical sample `smp`: optional index gather, optional dataset->trajectory
 // slab row mapping (flat index e*T+t  ->  slab row e*(T+1)+t, learner.py:1005-1012 drops column T by *copy*; we
 // read the slab in place instead).
 __device__ __forceinline__ int64_t sample_base(const ConvG &g, const int32_t *__restrict__ index, int64_t offset,
                                                int64_t stride, uint32_t smp) {
     int64_t d = index ? (int64_t)index[smp] : offset + (int64_t)smp;
-    if (g.traj_T > 0) {
-        const uint32_t e = fdiv((uint32_t)d, g.dT);
-        d = d + (int64_t)e;  // e*(T+1) + (d - e*T)
-    }
+    if (g.traj_T > 0) d += (int64_t)fdiv((uint32_t)d, g.dT);  // e*(T+1) + (d - e*T)
     return d * stride;
 }
 
 // offset (elements) of im2col column k inside one input sample, relative to the patch origin
+template <bool U8>
 __device__ __forceinline__ int tap_offset(const ConvG &g, uint32_t k) {
-    if (g.in_u8) {  // k = (c*KH + kh)*KW + kw over NCHW bytes
+    if (U8) {  // k = (c*KH + kh)*KW + kw over NCHW bytes
         const uint32_t c = fdiv(k, g.dKHKW), r = k - c * (uint32_t)(g.KH * g.KW);
         const uint32_t kh = fdiv(r, g.dKW), kw = r - kh * (uint32_t)g.KW;
         return (int)((c * (uint32_t)g.H + kh) * (uint32_t)g.W + kw);
@@ -114,48 +121,81 @@ __device__ __forceinline__ int tap_offset(const ConvG &g, uint32_t k) {
     return (int)((kh * (uint32_t)g.W + kw) * (uint32_t)g.Cin + c);
 }
 // offset (elements) of output pixel `pix` patch origin inside one input sample
+template <bool U8>
 __device__ __forceinline__ int patch_origin(const ConvG &g, uint32_t pix) {
     const uint32_t oh = fdiv(pix, g.dOW), ow = pix - oh * (uint32_t)g.OW;
-    if (g.in_u8) return (int)(oh * (uint32_t)g.S * (uint32_t)g.W + ow * (uint32_t)g.S);
-    return (int)((oh * (uint32_t)g.S * (uint32_t)g.W + ow * (uint32_t)g.S) * (uint32_t)g.Cin);
+    const uint32_t o = oh * (uint32_t)g.S * (uint32_t)g.W + ow * (uint32_t)g.S;
+    return (int)(U8 ? o : o * (uint32_t)g.Cin);
 }
 
-__device__ __forceinline__ void load_act4(const ConvG &g, const void *__restrict__ in, int64_t base, uint32_t k,
-                                          float (&v)[4]) {
-    // four consecutive im2col columns k..k+3 (k % 4 == 0) of the patch whose origin is `base`
-    if (g.in_u8) {
-        const uint8_t *p = reinterpret_cast<const uint8_t *>(in);
-        if (g.vecA) {
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(p + base + tap_offset(g, k));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((float)((w >> (8 * j)) & 0xFFu) - g.sub_mean) * g.inv_scale;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v[j] = (k + j < (uint32_t)g.K) ? ((float)p[base + tap_offset(g, k + j)] - g.sub_mean) * g.inv_scale : 0.f;
-        }
+// Raw (unconverted, unmasked) operand quads.  The value is NOT touched between the global load and the LDS store of
+// the next iteration, so the loads stay in flight across the whole MFMA phase (a select right after the load made
+// hipcc wait for the data before the first MFMA — no overlap at all).
+template <int MODE>
+struct ARaw {
+    float4 v;
+};
+template <>
+struct ARaw<MODE_U8> {
+    uint32_t v;
+};
+
+// four consecutive im2col columns k..k+3 (k % 4 == 0, k < K) of the patch whose origin is `base`
+template <int MODE>
+__device__ __forceinline__ ARaw<MODE> load_act_raw(const ConvG &g, const void *__restrict__ in, int64_t base,
+                                                   uint32_t k, bool ok) {
+    ARaw<MODE> r;
+    if constexpr (MODE == MODE_U8) {
+        r.v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(in) + base + tap_offset<true>(g, k));
+    } else if constexpr (MODE == MODE_F32) {
+        r.v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(in) + base + tap_offset<false>(g, k));
     } else {
-        const float *p = reinterpret_cast<const float *>(in);
-        if (g.vecA) {
-            const float4 w = *reinterpret_cast<const float4 *>(p + base + tap_offset(g, k));
-            v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
-        } else {
+        float x[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (k + j < (uint32_t)g.K) ? p[base + tap_offset(g, k + j)] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const bool okj = ok && (k + j < (uint32_t)g.K);
+            const uint32_t kj = okj ? k + j : 0u;
+            if (g.in_u8)
+                x[j] = ((float)reinterpret_cast<const uint8_t *>(in)[base + tap_offset<true>(g, kj)] - g.sub_mean) * g.inv_scale;
+            else
+                x[j] = reinterpret_cast<const float *>(in)[base + tap_offset<false>(g, kj)];
+            x[j] = okj ? x[j] : 0.f;
         }
+        r.v = make_float4(x[0], x[1], x[2], x[3]);
+    }
+    return r;
+}
+template <int MODE>
+__device__ __forceinline__ float4 act_finish(const ConvG &g, const ARaw<MODE> &r, bool ok) {
+    if constexpr (MODE == MODE_U8) {
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = ((float)((r.v >> (8 * j)) & 0xFFu) - g.sub_mean) * g.inv_scale;
+            x[j] = ok ? t : 0.f;
+        }
+        return make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+        return make_float4(ok ? r.v.x : 0.f, ok ? r.v.y : 0.f, ok ? r.v.z : 0.f, ok ? r.v.w : 0.f);
     }
 }
 
-// four consecutive columns n..n+3 of row `row` of a row-major [*, N] f32 matrix (weights [K,N], or dY [M,N])
-__device__ __forceinline__ void load_row4(const float *__restrict__ p, int64_t row, int n, int N, bool vec,
-                                          float (&v)[4]) {
-    if (vec && n + 3 < N) {
-        const float4 w = *reinterpret_cast<const float4 *>(p + row * N + n);
-        v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+// four consecutive columns n..n+3 of row `row` of a row-major [*, N] f32 matrix (row must be a valid row index even
+// when the result is going to be masked).  VEC: N % 4 == 0 and n % 4 == 0 -> one 16-byte load; n >= N reads column 0.
+template <bool VEC>
+__device__ __forceinline__ float4 load_row_raw(const float *__restrict__ p, int64_t row, int n, int N) {
+    if constexpr (VEC) {
+        return *reinterpret_cast<const float4 *>(p + row * N + (n < N ? n : 0));
     } else {
+        float x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (n + j < N) ? p[row * N + n + j] : 0.f;
+        for (int j = 0; j < 4; ++j) x[j] = p[row * N + (n + j < N ? n + j : 0)];
+        return make_float4(x[0], x[1], x[2], x[3]);
     }
+}
+__device__ __forceinline__ float4 row_finish(const float4 &r, bool ok, int n, int N) {
+    return make_float4((ok && n < N) ? r.x : 0.f, (ok && n + 1 < N) ? r.y : 0.f, (ok && n + 2 < N) ? r.z : 0.f,
+                       (ok && n + 3 < N) ? r.w : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------- MFMA tile compute
@@ -163,19 +203,36 @@ __device__ __forceinline__ void load_row4(const float *__restrict__ p, int64_t r
 template <int TM, int TN, int LDA, int LDB>
 __device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const float *__restrict__ Bs, int arow0,
                                           int bcol0, int lane, f32x16 (&acc)[TM][TN]) {
+    // Fragments are double-buffered in registers, two k-steps ahead: the ds_reads of step kk+2 are issued before the
+    // MFMAs of step kk, so the LDS latency hides under 2*TM*TN*64 cycles of matrix-pipe time instead of stalling
+    // every MFMA pair behind an lgkmcnt(0) (what hipcc emitted for the naive loop).
     const int i = lane & 31, kh = lane >> 5;
+    const float *ap = As + kh * LDA + arow0 + i;
+    const float *bp = Bs + kh * LDB + bcol0 + i;
+    float a[3][TM], b[3][TN];
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
-        float a[TM], b[TN];
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) a[tm] = As[(kk + kh) * LDA + arow0 + tm * 32 + i];
+        for (int tm = 0; tm < TM; ++tm) a[p][tm] = ap[(2 * p) * LDA + tm * 32];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(kk + kh) * LDB + bcol0 + tn * 32 + i];
+        for (int tn = 0; tn < TN; ++tn) b[p][tn] = bp[(2 * p) * LDB + tn * 32];
+    }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+        const int cur = st % 3, nxt = (st + 2) % 3;
+        if (st + 2 < 16) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[nxt][tm] = ap[(2 * (st + 2)) * LDA + tm * 32];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[nxt][tn] = bp[(2 * (st + 2)) * LDB + tn * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this step's MFMAs
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -189,14 +246,21 @@ struct Tile {
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per block");
 };
 
+#define ZERO_ACC(acc)                                                                                         \
+    _Pragma("unroll") for (int a_ = 0; a_ < T::TM; ++a_) _Pragma("unroll") for (int b_ = 0; b_ < T::TN; ++b_) \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f
+
 // ============================================================================================== FORWARD
 // rows m = (sample, oh, ow); A reduction-major loads (4 consecutive k per slot), B = weights free-axis-major.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restrict__ in, int64_t in_stride,
                                                   const int32_t *__restrict__ index, int64_t offset,
                                                   const float *__restrict__ w, const float *__restrict__ bias,
-                                                  float *__restrict__ out, int64_t Mtot) {
+                                                  float *__restrict__ out, int64_t Mtot, int k_per_split,
+                                                  float *__restrict__ partial) {
     using T = Tile<BM, BN, WM, WN>;
+    constexpr bool U8 = MODE == MODE_U8;
+    constexpr bool VECB = MODE != MODE_GENERIC;
     constexpr int LDA = BM + 1, LDB = BN + 4;
     __shared__ __attribute__((aligned(16))) float As[32 * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[32 * LDB];
@@ -205,90 +269,115 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int N = g.Cout, K = g.K;
+    // split-K (small grids only): this block reduces k in [kbeg, kend) and writes a raw partial tile
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
 
-    // A slots: row = tid/8 + 32*s, k-quad = tid%8
-    const int kq = (tid & 7) * 4;
+    // A slots.  f32 NHWC input: k-quad fastest across lanes (row = tid/8 + 32*s, k-quad = tid%8): 8 lanes read one
+    // 128-byte run of channels.  Raw u8 NCHW input: row fastest (row = tid%32 + 32*s, k-quad = tid/32): consecutive
+    // output pixels are `stride` bytes apart, so 32 lanes x 4 bytes cover one contiguous 128-byte span of the frame.
+    const int arow = U8 ? (tid & 31) : (tid >> 3);
+    const int kq = (U8 ? (tid >> 5) : (tid & 7)) * 4;
     int64_t abase[T::SA];
     bool aval[T::SA];
 #pragma unroll
     for (int s = 0; s < T::SA; ++s) {
-        const int64_t m = m0 + (tid >> 3) + 32 * s;
+        const int64_t m = m0 + arow + 32 * s;
         aval[s] = m < Mtot;
-        abase[s] = 0;
-        if (aval[s]) {
-            const uint32_t smp = fdiv((uint32_t)m, g.dOHOW), pix = (uint32_t)m - smp * (uint32_t)(g.OH * g.OW);
-            abase[s] = sample_base(g, index, offset, in_stride, smp) + patch_origin(g, pix);
-        }
+        const uint32_t mm = aval[s] ? (uint32_t)m : 0u;
+        const uint32_t smp = fdiv(mm, g.dOHOW), pix = mm - smp * (uint32_t)(g.OH * g.OW);
+        const bool u8 = MODE == MODE_GENERIC ? g.in_u8 != 0 : U8;
+        abase[s] = sample_base(g, index, offset, in_stride, smp) +
+                   (u8 ? patch_origin<true>(g, pix) : patch_origin<false>(g, pix));
     }
     // B slots: F-major: column quad cg, reduction row kk0 + s*(1024/BN)
     constexpr int BG = BN / 4, BROWS = 256 / BG;
     const int bcg = (tid % BG) * 4, bkk0 = tid / BG;
 
     f32x16 acc[T::TM][T::TN];
-#pragma unroll
-    for (int a = 0; a < T::TM; ++a)
-#pragma unroll
-        for (int b = 0; b < T::TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    ZERO_ACC(acc);
 
-    float ra[T::SA][4], rb[T::SB][4];
+    ARaw<MODE> ra[T::SA];
+    float4 rb[T::SB];
+    bool aok = false, bok[T::SB];
     auto gload = [&](int k0) {
+        const int ka = k0 + kq;
+        aok = ka < kend;
+        const uint32_t kc = aok ? (uint32_t)ka : (uint32_t)kbeg;
 #pragma unroll
-        for (int s = 0; s < T::SA; ++s) {
-            if (aval[s] && k0 + kq < K) load_act4(g, in, abase[s], (uint32_t)(k0 + kq), ra[s]);
-            else { ra[s][0] = ra[s][1] = ra[s][2] = ra[s][3] = 0.f; }
-        }
+        for (int s = 0; s < T::SA; ++s) ra[s] = load_act_raw<MODE>(g, in, abase[s], kc, aok && aval[s]);
 #pragma unroll
         for (int s = 0; s < T::SB; ++s) {
             const int k = k0 + bkk0 + s * BROWS;
-            if (k < K) load_row4(w, k, n0 + bcg, N, g.vecB, rb[s]);
-            else { rb[s][0] = rb[s][1] = rb[s][2] = rb[s][3] = 0.f; }
+            bok[s] = k < kend;
+            rb[s] = load_row_raw<VECB>(w, bok[s] ? k : kbeg, n0 + bcg, N);
         }
     };
-    gload(0);
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < T::SA; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) As[(kq + j) * LDA + (tid >> 3) + 32 * s] = ra[s][j];
+        for (int s = 0; s < T::SA; ++s) {
+            const float4 v = act_finish<MODE>(g, ra[s], aok && aval[s]);
+            As[(kq + 0) * LDA + arow + 32 * s] = v.x;
+            As[(kq + 1) * LDA + arow + 32 * s] = v.y;
+            As[(kq + 2) * LDA + arow + 32 * s] = v.z;
+            As[(kq + 3) * LDA + arow + 32 * s] = v.w;
+        }
 #pragma unroll
         for (int s = 0; s < T::SB; ++s)
-            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) =
-                make_float4(rb[s][0], rb[s][1], rb[s][2], rb[s][3]);
+            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) = row_finish(rb[s], bok[s], n0 + bcg, N);
         __syncthreads();
-        if (k0 + 32 < K) gload(k0 + 32);
+        if (k0 + 32 < kend) gload(k0 + 32);
         mma_chunk<T::TM, T::TN, LDA, LDB>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, lane, acc);
     }
-    // epilogue: bias + ReLU, NHWC store
+    // epilogue: bias + ReLU, NHWC store (split-K: raw partial, finished by k_splitk_finish)
+    float *dst = partial ? partial + (int64_t)blockIdx.z * Mtot * N : out;
+    const bool fin = partial == nullptr;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < T::TN; ++tn) {
             const int n = n0 + wn * T::TN * 32 + tn * 32 + (lane & 31);
-            const float bv = (n < N && bias) ? bias[n] : 0.f;
+            const float bv = (fin && n < N && bias) ? bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + wm * T::TM * 32 + tm * 32 + FRAG_ROW(r, lane);
                 if (m < Mtot && n < N) {
                     float v = acc[tm][tn][r] + bv;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    out[m * N + n] = v;
+                    if (fin && g.relu) v = fmaxf(v, 0.f);
+                    dst[m * N + n] = v;
                 }
             }
         }
 }
 
+// out[m][n] = act(sum_z partial[z][m][n] + bias[n]), z ascending (deterministic)
+__global__ __launch_bounds__(256) void k_splitk_finish(const float *__restrict__ partial,
+                                                       const float *__restrict__ bias, float *__restrict__ out,
+                                                       int64_t MN, int N, int Z, int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < Z; ++z) s += partial[(int64_t)z * MN + i];
+        if (bias) s += bias[(int)(i % N)];
+        out[i] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+
 // ============================================================================================== WEIGHT GRADIENT
 // dW[k][n] = sum_m col(in)[m][k] * dY[m][n].  GEMM rows = k (BM), cols = n (BN), reduction = m, split over
 // gridDim.z contiguous m-ranges; partial tiles go to workspace[z][K][N], k_reduce_partials sums them in fixed order.
-template <int BM, int BN, int WM, int WN>
+// The bias gradient (column sums of dY) is accumulated from the staged dY tile by the blockIdx.x == 0 blocks.
+template <int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void k_conv_wgrad(ConvG g, const void *__restrict__ in, int64_t in_stride,
                                                     const int32_t *__restrict__ index, int64_t offset,
                                                     const float *__restrict__ dy, float *__restrict__ partial,
-                                                    int64_t Mtot, int64_t m_per_split) {
+                                                    float *__restrict__ partial_b, int64_t Mtot,
+                                                    int64_t m_per_split) {
+    constexpr int BM = 128;
     using T = Tile<BM, BN, WM, WN>;
+    constexpr bool U8 = MODE == MODE_U8;
+    constexpr bool VECB = MODE != MODE_GENERIC;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     __shared__ __attribute__((aligned(16))) float As[32 * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[32 * LDB];
@@ -300,71 +389,89 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvG g, const void *__restr
     const int64_t mbeg = (int64_t)blockIdx.z * m_per_split;
     const int64_t mend = (mbeg + m_per_split < Mtot) ? mbeg + m_per_split : Mtot;
 
-    // A' slots (free-axis-major): 4 consecutive weight rows k for one reduction index m
-    constexpr int AG = BM / 4, AROWS = 256 / AG;
-    const int acg = (tid % AG) * 4, akk0 = tid / AG;
-    const uint32_t ak = (uint32_t)(k0row + acg);
-    const bool akval = (int)ak < K;
-    const int atap = (akval && g.vecA) ? tap_offset(g, ak) : 0;
+    // A' slots (free-axis-major): 4 consecutive weight rows k for one reduction index m.
+    // f32 NHWC input: k-group fastest across lanes (32 lanes read 512 contiguous bytes of channels); slot s holds
+    //   k-group tid%32 of reduction row tid/32 + 8*s.
+    // raw u8 NCHW input: m fastest (32 consecutive output pixels = one contiguous 128-byte span); slot s holds k-group
+    //   tid/32 + 8*s of reduction row tid%32, so the m -> (sample, pixel) decomposition is done once per chunk.
+    int kg[T::SA], tapo[T::SA];
+    bool kval[T::SA];
+#pragma unroll
+    for (int s = 0; s < T::SA; ++s) {
+        kg[s] = (U8 ? (tid >> 5) + 8 * s : (tid & 31)) * 4;
+        const int k = k0row + kg[s];
+        kval[s] = k < K;
+        const uint32_t kc = kval[s] ? (uint32_t)k : 0u;
+        tapo[s] = MODE == MODE_GENERIC ? 0 : (U8 ? tap_offset<true>(g, kc) : tap_offset<false>(g, kc));
+    }
     constexpr int BG = BN / 4, BROWS = 256 / BG;
     const int bcg = (tid % BG) * 4, bkk0 = tid / BG;
 
     f32x16 acc[T::TM][T::TN];
-#pragma unroll
-    for (int a = 0; a < T::TM; ++a)
-#pragma unroll
-        for (int b = 0; b < T::TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    ZERO_ACC(acc);
 
-    float ra[T::SA][4], rb[T::SB][4];
+    ARaw<MODE> ra[T::SA];
+    float4 rb[T::SB];
+    bool aok[T::SA], bok[T::SB];
+    auto patch_base = [&](int64_t m, bool ok) -> int64_t {
+        const uint32_t mm = ok ? (uint32_t)m : (uint32_t)mbeg;
+        const uint32_t smp = fdiv(mm, g.dOHOW), pix = mm - smp * (uint32_t)(g.OH * g.OW);
+        const bool u8 = MODE == MODE_GENERIC ? g.in_u8 != 0 : U8;
+        return sample_base(g, index, offset, in_stride, smp) +
+               (u8 ? patch_origin<true>(g, pix) : patch_origin<false>(g, pix));
+    };
     auto gload = [&](int64_t mc) {
+        if constexpr (U8) {
+            const int64_t m = mc + (tid & 31);
+            const bool mok = m < mend;
+            const int64_t base = patch_base(m, mok);
 #pragma unroll
-        for (int s = 0; s < T::SA; ++s) {
-            const int64_t m = mc + akk0 + s * AROWS;
-            ra[s][0] = ra[s][1] = ra[s][2] = ra[s][3] = 0.f;
-            if (akval && m < mend) {
-                const uint32_t smp = fdiv((uint32_t)m, g.dOHOW), pix = (uint32_t)m - smp * (uint32_t)(g.OH * g.OW);
-                const int64_t base = sample_base(g, index, offset, in_stride, smp) + patch_origin(g, pix);
-                if (g.vecA) {
-                    if (g.in_u8) {
-                        const uint32_t wv = *reinterpret_cast<const uint32_t *>(
-                            reinterpret_cast<const uint8_t *>(in) + base + atap);
+            for (int s = 0; s < T::SA; ++s) {
+                ra[s].v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(in) + base + tapo[s]);
+                aok[s] = mok && kval[s];
+            }
+        } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            ra[s][j] = ((float)((wv >> (8 * j)) & 0xFFu) - g.sub_mean) * g.inv_scale;
-                    } else {
-                        const float4 wv = *reinterpret_cast<const float4 *>(
-                            reinterpret_cast<const float *>(in) + base + atap);
-                        ra[s][0] = wv.x; ra[s][1] = wv.y; ra[s][2] = wv.z; ra[s][3] = wv.w;
-                    }
-                } else {
-                    load_act4(g, in, base, ak, ra[s]);
-                }
+            for (int s = 0; s < T::SA; ++s) {
+                const int64_t m = mc + (tid >> 5) + 8 * s;
+                const bool mok = m < mend;
+                aok[s] = mok && kval[s];
+                const int64_t base = patch_base(m, mok);
+                if constexpr (MODE == MODE_F32)
+                    ra[s].v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(in) + base + tapo[s]);
+                else
+                    ra[s] = load_act_raw<MODE_GENERIC>(g, in, base, (uint32_t)(k0row + kg[s]), aok[s]);
             }
         }
 #pragma unroll
         for (int s = 0; s < T::SB; ++s) {
             const int64_t m = mc + bkk0 + s * BROWS;
-            if (m < mend) load_row4(dy, m, n0 + bcg, N, g.vecB, rb[s]);
-            else { rb[s][0] = rb[s][1] = rb[s][2] = rb[s][3] = 0.f; }
+            bok[s] = m < mend;
+            rb[s] = load_row_raw<VECB>(dy, bok[s] ? m : mbeg, n0 + bcg, N);
         }
     };
+    const bool do_colsum = partial_b != nullptr && blockIdx.x == 0 && tid < BN;  // bias gradient: column sums of dY
+    float colacc = 0.f;
     if (mbeg < mend) gload(mbeg);
     for (int64_t mc = mbeg; mc < mend; mc += 32) {
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < T::SA; ++s)
-            *reinterpret_cast<float4 *>(&As[(akk0 + s * AROWS) * LDA + acg]) =
-                make_float4(ra[s][0], ra[s][1], ra[s][2], ra[s][3]);
+        for (int s = 0; s < T::SA; ++s) {
+            const int lrow = U8 ? (tid & 31) : (tid >> 5) + 8 * s;  // reduction index (m) inside the chunk
+            *reinterpret_cast<float4 *>(&As[lrow * LDA + kg[s]]) = act_finish<MODE>(g, ra[s], aok[s]);
+        }
 #pragma unroll
         for (int s = 0; s < T::SB; ++s)
-            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) =
-                make_float4(rb[s][0], rb[s][1], rb[s][2], rb[s][3]);
+            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) = row_finish(rb[s], bok[s], n0 + bcg, N);
         __syncthreads();
         if (mc + 32 < mend) gload(mc + 32);
+        if (do_colsum) {
+#pragma unroll 8
+            for (int kk = 0; kk < 32; ++kk) colacc += Bs[kk * LDB + tid];
+        }
         mma_chunk<T::TM, T::TN, LDA, LDB>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, lane, acc);
     }
+    if (do_colsum && n0 + tid < N) partial_b[(int64_t)blockIdx.z * N + n0 + tid] = colacc;
     float *dst = partial + (int64_t)blockIdx.z * K * N;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
@@ -377,22 +484,6 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvG g, const void *__restr
                 if (k < K && n < N) dst[(int64_t)k * N + n] = acc[tm][tn][r];
             }
         }
-}
-
-// column sums of dY [Mtot, N] over the same m-splits -> partial_b[z][N]   (bias gradient)
-__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ dy, float *__restrict__ partial_b,
-                                                        int64_t Mtot, int N, int64_t m_per_split) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.y * 64 + lane;
-    const int64_t mbeg = (int64_t)blockIdx.x * m_per_split;
-    const int64_t mend = (mbeg + m_per_split < Mtot) ? mbeg + m_per_split : Mtot;
-    float acc = 0.f;
-    if (n < N)
-        for (int64_t m = mbeg + wave; m < mend; m += 4) acc += dy[m * N + n];
-    red[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && n < N) partial_b[(int64_t)blockIdx.x * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // out[i] = sum_z partial[z][i], z ascending (deterministic)
@@ -409,7 +500,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
 // din[sample, ih, iw, c] = mask * sum_{kh,kw,n} dY[sample, (ih-kh)/S, (iw-kw)/S, n] * W[(kh,kw,c), n], only taps with
 // kh = ih mod S (+ a*S), kw = iw mod S (+ b*S) contribute -> one GEMM per parity class (ph, pw) = blockIdx.z:
 // rows m' = (sample, ihh, iww) with ih = ihh*S+ph, cols = c, reduction k' = ((a*KWs + b)*Cout + n).
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void k_conv_dgrad(ConvG g, const float *__restrict__ dy,
                                                     const float *__restrict__ w, const float *__restrict__ in_act,
                                                     float *__restrict__ din, int64_t nsamples) {
@@ -428,7 +519,6 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvG g, const float *__rest
     const int n0 = blockIdx.y * BN;  // input-channel tile
     const int Cin = g.Cin, Cout = g.Cout;
     const int Kp = KHs * KWs * Cout;  // reduction length of this class (0 if the class has no taps)
-    const bool vec = (Cout % 4) == 0;
 
     const int kq = (tid & 7) * 4;
     int64_t arow[T::SA];  // first dY row (sample * OH*OW) of the slot's sample
@@ -439,61 +529,59 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvG g, const float *__rest
     for (int s = 0; s < T::SA; ++s) {
         const int64_t m = m0 + (tid >> 3) + 32 * s;
         aval[s] = m < Mc;
-        arow[s] = 0; aih[s] = 0; aiw[s] = 0;
-        if (aval[s]) {
-            const uint32_t smp = (uint32_t)m / HcWc;  // m < 2^31 (checked by the launcher)
-            const uint32_t pix = (uint32_t)m - smp * HcWc;
-            aih[s] = (int)(pix / (uint32_t)Wc);
-            aiw[s] = (int)pix - aih[s] * Wc;
-            arow[s] = (int64_t)smp * g.OH * g.OW;
-        }
+        const uint32_t mm = aval[s] ? (uint32_t)m : 0u;  // m < 2^31 (checked by the launcher)
+        const uint32_t smp = mm / HcWc, pix = mm - smp * HcWc;
+        aih[s] = (int)(pix / (uint32_t)Wc);
+        aiw[s] = (int)pix - aih[s] * Wc;
+        arow[s] = (int64_t)smp * g.OH * g.OW;
     }
-    // B' slots (reduction-major): column c = tid/8 + 32*s, 4 consecutive n
     f32x16 acc[T::TM][T::TN];
-#pragma unroll
-    for (int a = 0; a < T::TM; ++a)
-#pragma unroll
-        for (int b = 0; b < T::TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    ZERO_ACC(acc);
 
-    float ra[T::SA][4], rb[T::SB][4];
+    float4 ra[T::SA], rb[T::SB];
+    bool aok[T::SA], bok[T::SB];
+    int ncol = 0;
     auto gload = [&](int k0) {
         const int k = k0 + kq;
-        int a = 0, b = 0, n = 0;
         const bool kval = k < Kp;
-        if (kval) {
-            const int tap = (int)fdiv((uint32_t)k, g.dCout);
-            n = k - tap * Cout;
-            a = tap / KWs;
-            b = tap - a * KWs;
-        }
+        const int kc = kval ? k : 0;
+        const int tap = (int)fdiv((uint32_t)kc, g.dCout);
+        const int n = kc - tap * Cout;
+        ncol = n;
+        const int a = tap / KWs, b = tap - a * KWs;
 #pragma unroll
         for (int s = 0; s < T::SA; ++s) {
-            ra[s][0] = ra[s][1] = ra[s][2] = ra[s][3] = 0.f;
             const int oh = aih[s] - a, ow = aiw[s] - b;
-            if (kval && aval[s] && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW)
-                load_row4(dy, arow[s] + (int64_t)oh * g.OW + ow, n, Cout, vec, ra[s]);
+            aok[s] = kval && aval[s] && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+            ra[s] = load_row_raw<VEC>(dy, arow[s] + (aok[s] ? (int64_t)oh * g.OW + ow : 0), n, Cout);
         }
         const int kh = ph + a * g.S, kw = pw + b * g.S;
 #pragma unroll
         for (int s = 0; s < T::SB; ++s) {
             const int c = n0 + (tid >> 3) + 32 * s;
-            if (kval && c < Cin) load_row4(w, (int64_t)(kh * g.KW + kw) * Cin + c, n, Cout, vec, rb[s]);
-            else { rb[s][0] = rb[s][1] = rb[s][2] = rb[s][3] = 0.f; }
+            bok[s] = kval && c < Cin;
+            rb[s] = load_row_raw<VEC>(w, (int64_t)(kh * g.KW + kw) * Cin + (bok[s] ? c : 0), n, Cout);
         }
     };
     if (Kp > 0) gload(0);
     for (int k0 = 0; k0 < Kp; k0 += 32) {
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < T::SA; ++s)
+        for (int s = 0; s < T::SA; ++s) {
+            const float4 v = row_finish(ra[s], aok[s], ncol, Cout);
+            As[(kq + 0) * LDA + (tid >> 3) + 32 * s] = v.x;
+            As[(kq + 1) * LDA + (tid >> 3) + 32 * s] = v.y;
+            As[(kq + 2) * LDA + (tid >> 3) + 32 * s] = v.z;
+            As[(kq + 3) * LDA + (tid >> 3) + 32 * s] = v.w;
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) As[(kq + j) * LDA + (tid >> 3) + 32 * s] = ra[s][j];
-#pragma unroll
-        for (int s = 0; s < T::SB; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Bs[(kq + j) * LDB + (tid >> 3) + 32 * s] = rb[s][j];
+        for (int s = 0; s < T::SB; ++s) {
+            const float4 v = row_finish(rb[s], bok[s], ncol, Cout);
+            Bs[(kq + 0) * LDB + (tid >> 3) + 32 * s] = v.x;
+            Bs[(kq + 1) * LDB + (tid >> 3) + 32 * s] = v.y;
+            Bs[(kq + 2) * LDB + (tid >> 3) + 32 * s] = v.z;
+            Bs[(kq + 3) * LDB + (tid >> 3) + 32 * s] = v.w;
+        }
         __syncthreads();
         if (k0 + 32 < Kp) gload(k0 + 32);
         mma_chunk<T::TM, T::TN, LDA, LDB>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, lane, acc);
@@ -526,27 +614,84 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-template <int BM, int BN, int WM, int WN>
-static void launch_fwd(const ConvG &g, const void *in, int64_t stride, const int32_t *index, int64_t offset,
-                       const float *w, const float *bias, float *out, int64_t Mtot, hipStream_t st) {
-    dim3 grid(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), 1);
-    k_conv_fwd<BM, BN, WM, WN><<<grid, dim3(256), 0, st>>>(g, in, stride, index, offset, w, bias, out, Mtot);
+static int pick_mode(const ConvG &g) {
+    if (!g.vecA || !g.vecB) return MODE_GENERIC;
+    return g.in_u8 ? MODE_U8 : MODE_F32;
 }
+
+// forward launch plan: tile config + optional split-K when the natural grid cannot fill 256 CUs several times over
+struct FwdPlan {
+    int cfg;  // 0: 128x32 (4x1 waves), 1: 128x64 (2x2), 2: 64x64 (2x2)
+    int splits, k_per_split;
+};
+static FwdPlan plan_fwd(int64_t Mtot, int N, int K, int64_t ws_floats) {
+    FwdPlan p;
+    p.splits = 1;
+    p.k_per_split = (K + 31) / 32 * 32;
+    p.cfg = N <= 32 ? 0 : 1;
+    const int BM = 128, BN = p.cfg == 0 ? 32 : 64;
+    int64_t blocks = ((Mtot + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (blocks < 768 && Mtot <= 64) { p.cfg = 2; blocks = ((Mtot + 63) / 64) * ((N + 63) / 64); }
+    if (blocks < 768 && K >= 512) {
+        int s = (int)((1024 + blocks - 1) / blocks);
+        const int smax = K / 256;  // keep >= 8 chunks per split
+        if (s > smax) s = smax;
+        if (s > 16) s = 16;
+        if (s > 1 && (int64_t)s * Mtot * N <= ws_floats) {
+            const int chunks = (K + 31) / 32;
+            p.k_per_split = ((chunks + s - 1) / s) * 32;
+            p.splits = (K + p.k_per_split - 1) / p.k_per_split;
+        }
+    }
+    return p;
+}
+
+extern "C" int64_t sf_conv_fwd_workspace(int64_t n, const sf_conv_desc *h_desc) {
+    if (!h_desc || n <= 0) return 0;
+    const int K = h_desc->KH * h_desc->KW * h_desc->Cin, N = h_desc->Cout;
+    const int64_t Mtot = n * h_desc->OH * h_desc->OW;
+    const FwdPlan p = plan_fwd(Mtot, N, K, (int64_t)1 << 60);
+    return p.splits > 1 ? (int64_t)sizeof(float) * p.splits * Mtot * N + 256 : 0;
+}
+
+#define FWD_LAUNCH(BM, BN, WM, WN, MODE)                                                                   \
+    k_conv_fwd<BM, BN, WM, WN, MODE><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
+        g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial)
+#define FWD_BY_MODE(BM, BN, WM, WN)                                    \
+    do {                                                               \
+        if (mode == MODE_F32) FWD_LAUNCH(BM, BN, WM, WN, MODE_F32);    \
+        else if (mode == MODE_U8) FWD_LAUNCH(BM, BN, WM, WN, MODE_U8); \
+        else FWD_LAUNCH(BM, BN, WM, WN, MODE_GENERIC);                 \
+    } while (0)
 
 extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
                            const float *w, const float *bias, float *out, int64_t n, const sf_conv_desc *h_desc,
-                           void *stream) {
+                           void *workspace, int64_t workspace_bytes, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_fwd");
     if (rc) return rc;
     SF_REQUIRE(in && w && out && n > 0, "sf_conv_fwd: bad args");
+    SF_REQUIRE(((uintptr_t)workspace & 15) == 0, "sf_conv_fwd: workspace must be 16-byte aligned");
     const ConvG g = make_geom(h_desc);
     const int64_t Mtot = n * g.OH * g.OW;
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
+    int mode = pick_mode(g);
+    if (mode != MODE_GENERIC) {  // vector loads also need aligned bases
+        const bool al = h_desc->in_u8 ? (((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0)
+                                      : (((uintptr_t)in & 15) == 0 && in_sample_stride % 4 == 0);
+        if (!al || ((uintptr_t)w & 15) != 0) mode = MODE_GENERIC;
+    }
     hipStream_t st = STREAM(stream);
-    if (g.Cout <= 32) launch_fwd<128, 32, 4, 1>(g, in, in_sample_stride, index, offset, w, bias, out, Mtot, st);
-    else if (Mtot * ((g.Cout + 63) / 64) < 128LL * 1024)
-        launch_fwd<64, 64, 2, 2>(g, in, in_sample_stride, index, offset, w, bias, out, Mtot, st);
-    else launch_fwd<128, 64, 2, 2>(g, in, in_sample_stride, index, offset, w, bias, out, Mtot, st);
+    const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, workspace ? workspace_bytes / (int64_t)sizeof(float) : 0);
+    float *partial = p.splits > 1 ? reinterpret_cast<float *>(workspace) : nullptr;
+    const unsigned Z = (unsigned)p.splits;
+    if (p.cfg == 0) FWD_BY_MODE(128, 32, 4, 1);
+    else if (p.cfg == 1) FWD_BY_MODE(128, 64, 2, 2);
+    else FWD_BY_MODE(64, 64, 2, 2);
+    if (partial) {
+        const int64_t MN = Mtot * g.Cout;
+        k_splitk_finish<<<dim3(cdiv64(MN, 256) < 4096 ? cdiv64(MN, 256) : 4096), dim3(256), 0, st>>>(
+            partial, bias, out, MN, g.Cout, p.splits, g.relu);
+    }
     return sf_launch_status("sf_conv_fwd");
 }
 
@@ -558,7 +703,7 @@ struct SplitPlan {
 static SplitPlan plan_splits(int64_t Mtot, int K, int N, int BM, int BN) {
     const int64_t tiles = (int64_t)((K + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int64_t chunks = (Mtot + 31) / 32;
-    int64_t Z = (2048 + tiles - 1) / tiles;  // aim for ~2k blocks
+    int64_t Z = (1536 + tiles - 1) / tiles;  // aim for ~1.5k blocks (6 per CU)
     const int64_t zmax = (chunks + 7) / 8;   // at least 8 chunks (256 reduction rows) per split
     if (Z > zmax) Z = zmax;
     if (Z < 1) Z = 1;
@@ -578,6 +723,17 @@ extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc
     return (int64_t)sizeof(float) * p.Z * ((int64_t)K * N + N) + 256;
 }
 
+#define WGRAD_LAUNCH(BN, WM, WN, MODE)                                                                        \
+    k_conv_wgrad<BN, WM, WN, MODE><<<grid, dim3(256), 0, st>>>(g, in, in_sample_stride, index, offset, dout,  \
+                                                              partial_w, db ? partial_b : nullptr, Mtot,     \
+                                                              p.m_per_split)
+#define WGRAD_BY_MODE(BN, WM, WN)                                    \
+    do {                                                             \
+        if (mode == MODE_F32) WGRAD_LAUNCH(BN, WM, WN, MODE_F32);    \
+        else if (mode == MODE_U8) WGRAD_LAUNCH(BN, WM, WN, MODE_U8); \
+        else WGRAD_LAUNCH(BN, WM, WN, MODE_GENERIC);                 \
+    } while (0)
+
 extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
                              const float *dout, float *dw, float *db, int64_t n, const sf_conv_desc *h_desc,
                              void *workspace, void *stream) {
@@ -593,24 +749,29 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
     const SplitPlan p = plan_splits(Mtot, K, N, 128, BN);
     float *partial_w = reinterpret_cast<float *>(workspace);
     float *partial_b = partial_w + (int64_t)p.Z * K * N;
+    int mode = pick_mode(g);
+    if (mode != MODE_GENERIC) {
+        const bool al = h_desc->in_u8 ? (((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0)
+                                      : (((uintptr_t)in & 15) == 0 && in_sample_stride % 4 == 0);
+        if (!al || ((uintptr_t)dout & 15) != 0) mode = MODE_GENERIC;
+    }
     hipStream_t st = STREAM(stream);
     dim3 grid(cdiv64(K, 128), cdiv64(N, BN), (unsigned)p.Z);
-    if (BN == 32)
-        k_conv_wgrad<128, 32, 4, 1><<<grid, dim3(256), 0, st>>>(g, in, in_sample_stride, index, offset, dout, partial_w,
-                                                               Mtot, p.m_per_split);
-    else
-        k_conv_wgrad<128, 64, 2, 2><<<grid, dim3(256), 0, st>>>(g, in, in_sample_stride, index, offset, dout, partial_w,
-                                                               Mtot, p.m_per_split);
+    if (BN == 32) WGRAD_BY_MODE(32, 4, 1);
+    else WGRAD_BY_MODE(64, 2, 2);
     const int64_t KN = (int64_t)K * N;
     k_reduce_partials<<<dim3(cdiv64(KN, 256) < 2048 ? cdiv64(KN, 256) : 2048), dim3(256), 0, st>>>(partial_w, dw, KN,
                                                                                                     p.Z);
-    if (db) {
-        k_colsum_partial<<<dim3((unsigned)p.Z, cdiv64(N, 64)), dim3(256), 0, st>>>(dout, partial_b, Mtot, N,
-                                                                                   p.m_per_split);
-        k_reduce_partials<<<dim3(cdiv64(N, 256)), dim3(256), 0, st>>>(partial_b, db, N, p.Z);
-    }
+    if (db) k_reduce_partials<<<dim3(cdiv64(N, 256)), dim3(256), 0, st>>>(partial_b, db, N, p.Z);
     return sf_launch_status("sf_conv_wgrad");
 }
+
+#define DGRAD_LAUNCH(BM, BN, WM, WN)                                                                          \
+    do {                                                                                                      \
+        dim3 grid(cdiv64(Mc, BM), cdiv64(g.Cin, BN), classes);                                                \
+        if (vec) k_conv_dgrad<BM, BN, WM, WN, true><<<grid, dim3(256), 0, st>>>(g, dout, w, in_act, din, n);  \
+        else k_conv_dgrad<BM, BN, WM, WN, false><<<grid, dim3(256), 0, st>>>(g, dout, w, in_act, din, n);     \
+    } while (0)
 
 extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                              const sf_conv_desc *h_desc, void *stream) {
@@ -626,16 +787,10 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     SF_REQUIRE(n * g.H * g.W < (1LL << 31), "sf_conv_dgrad: too many rows; split the batch");
     hipStream_t st = STREAM(stream);
     const unsigned classes = (unsigned)(g.S * g.S);
-    if (g.Cin <= 32) {
-        dim3 grid(cdiv64(Mc, 128), cdiv64(g.Cin, 32), classes);
-        k_conv_dgrad<128, 32, 4, 1><<<grid, dim3(256), 0, st>>>(g, dout, w, in_act, din, n);
-    } else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) {
-        dim3 grid(cdiv64(Mc, 64), cdiv64(g.Cin, 64), classes);
-        k_conv_dgrad<64, 64, 2, 2><<<grid, dim3(256), 0, st>>>(g, dout, w, in_act, din, n);
-    } else {
-        dim3 grid(cdiv64(Mc, 128), cdiv64(g.Cin, 64), classes);
-        k_conv_dgrad<128, 64, 2, 2><<<grid, dim3(256), 0, st>>>(g, dout, w, in_act, din, n);
-    }
+    const bool vec = g.vecB && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0;
+    if (g.Cin <= 32) DGRAD_LAUNCH(128, 32, 4, 1);
+    else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) DGRAD_LAUNCH(64, 64, 2, 2);
+    else DGRAD_LAUNCH(128, 64, 2, 2);
     return sf_launch_status("sf_conv_dgrad");
 }
 
@@ -651,7 +806,7 @@ extern "C" int sf_linear_fwd(const float *in, const float *w, const float *bias,
                              int relu, void *stream) {
     SF_REQUIRE(M > 0 && K > 0 && N > 0, "sf_linear_fwd: bad shape");
     const sf_conv_desc d = linear_desc(K, N, relu);
-    return sf_conv_fwd(in, K, nullptr, 0, w, bias, out, M, &d, stream);
+    return sf_conv_fwd(in, K, nullptr, 0, w, bias, out, M, &d, nullptr, 0, stream);
 }
 extern "C" int64_t sf_linear_wgrad_workspace(int64_t M, int K, int N) {
     const sf_conv_desc d = linear_desc(K, N, 0);

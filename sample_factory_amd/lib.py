@@ -38,7 +38,7 @@ SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
     "sf_adam_step", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
-    "sf_conv_fwd", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_linear_fwd",
+    "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_linear_fwd",
     "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
 
@@ -82,6 +82,7 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
         lib.sf_last_error.restype = C.c_char_p
         lib.sf_conv_wgrad_workspace.restype = C.c_int64
+        lib.sf_conv_fwd_workspace.restype = C.c_int64
         lib.sf_linear_wgrad_workspace.restype = C.c_int64
         _lib = lib
     return _lib
@@ -260,12 +261,17 @@ def _raw_in(t: torch.Tensor, desc: sf_conv_desc) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
-def conv_fwd_raw(inp, in_sample_stride, index, offset, w, bias, out, n, desc: sf_conv_desc) -> None:
+def conv_fwd_workspace(n, desc: sf_conv_desc) -> int:
+    return int(load().sf_conv_fwd_workspace(i64(n), C.byref(desc)))
+
+
+def conv_fwd_raw(inp, in_sample_stride, index, offset, w, bias, out, n, desc: sf_conv_desc, workspace=None) -> None:
     """`inp` may be a strided view (e.g. slab[:, t]); its data_ptr is sample 0, samples are in_sample_stride apart."""
     with _timed(_dkey("fwd", n, desc)):
       _check(load().sf_conv_fwd(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
                               i64(offset), ptr(w, "f32", "w"), ptr(bias, "f32", "bias"), ptr(out, "f32", "out"),
-                              i64(n), C.byref(desc), stream()), "sf_conv_fwd")
+                              i64(n), C.byref(desc), ptr(workspace, "u8", "workspace"),
+                              i64(workspace.numel() if workspace is not None else 0), stream()), "sf_conv_fwd")
 
 
 def conv_wgrad_workspace(n, desc: sf_conv_desc) -> int:

@@ -161,7 +161,10 @@ class ActorCritic:
             feat = size
         self.feat = feat
         A = self.num_action_params
-        self.layers.append(_Layer("heads", _linear_desc(feat, 1 + A, False), (1 + A, feat), "heads"))
+        # fused heads [F, 1+A] padded to a multiple of 4 columns (zero weights, zero gradients) so that every operand
+        # of every layer takes the 16-byte vector loaders; column 0 = value, columns 1..A = action parameters
+        self.heads_ld = (1 + A + 3) // 4 * 4
+        self.layers.append(_Layer("heads", _linear_desc(feat, self.heads_ld, False), (self.heads_ld, feat), "heads"))
         self.obs_elems = int(np.prod(self.obs_shape))
 
         # ---- flat parameter / gradient / Adam buffers
@@ -187,7 +190,8 @@ class ActorCritic:
 
     # ------------------------------------------------------------------------------------------ reference surface
     def num_params(self) -> int:
-        return sum(L.K * L.N + L.N for L in self.layers)
+        n = sum(L.K * L.N + L.N for L in self.layers[:-1])
+        return n + (self.feat + 1) * (1 + self.num_action_params)
 
     def train(self, mode=True):
         self.training = mode
@@ -247,12 +251,12 @@ class ActorCritic:
         for L in self.layers[:-1]:
             sd[L.name + ".weight"] = L.w_to_ref(L.w.detach()).cpu()
             sd[L.name + ".bias"] = L.b.detach().cpu().clone()
-        H = self.layers[-1]
+        H, A = self.layers[-1], self.num_action_params
         w = H.w.detach().cpu()
         sd["critic_linear.weight"] = w[:, 0:1].t().contiguous()
         sd["critic_linear.bias"] = H.b.detach().cpu()[0:1].clone()
-        sd["action_parameterization.distribution_linear.weight"] = w[:, 1:].t().contiguous()
-        sd["action_parameterization.distribution_linear.bias"] = H.b.detach().cpu()[1:].clone()
+        sd["action_parameterization.distribution_linear.weight"] = w[:, 1:1 + A].t().contiguous()
+        sd["action_parameterization.distribution_linear.bias"] = H.b.detach().cpu()[1:1 + A].clone()
         return sd
 
     def load_state_dict(self, sd, strict=True):
@@ -260,13 +264,14 @@ class ActorCritic:
             for L in self.layers[:-1]:
                 L.w.copy_(L.w_from_ref(torch.as_tensor(sd[L.name + ".weight"], dtype=torch.float32)))
                 L.b.copy_(torch.as_tensor(sd[L.name + ".bias"], dtype=torch.float32))
-            H = self.layers[-1]
+            H, A = self.layers[-1], self.num_action_params
             cw = torch.as_tensor(sd["critic_linear.weight"], dtype=torch.float32)
             aw = torch.as_tensor(sd["action_parameterization.distribution_linear.weight"], dtype=torch.float32)
-            H.w.copy_(torch.cat([cw, aw], dim=0).t().contiguous())
+            pad = self.heads_ld - 1 - A
+            H.w.copy_(torch.cat([cw, aw, torch.zeros((pad, self.feat))], dim=0).t().contiguous())
             H.b.copy_(torch.cat([torch.as_tensor(sd["critic_linear.bias"], dtype=torch.float32).reshape(1),
                                  torch.as_tensor(sd["action_parameterization.distribution_linear.bias"],
-                                                 dtype=torch.float32).reshape(-1)]))
+                                                 dtype=torch.float32).reshape(-1), torch.zeros(pad)]))
             if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
                 self.returns_normalizer.load_state_dict(sd, "returns_normalizer.")
             elif strict and self.returns_normalizer is not None:
@@ -279,13 +284,13 @@ class ActorCritic:
         for L, (o, ob) in zip(self.layers[:-1], self._segs[:-1]):
             out[L.name + ".weight"] = L.w_to_ref(flat[o:o + L.K * L.N].view(L.K, L.N)).cpu()
             out[L.name + ".bias"] = flat[ob:ob + L.N].cpu().clone()
-        H, (o, ob) = self.layers[-1], self._segs[-1]
+        H, (o, ob), A = self.layers[-1], self._segs[-1], self.num_action_params
         w = flat[o:o + H.K * H.N].view(H.K, H.N).cpu()
         b = flat[ob:ob + H.N].cpu()
         out["critic_linear.weight"] = w[:, 0:1].t().contiguous()
         out["critic_linear.bias"] = b[0:1].clone()
-        out["action_parameterization.distribution_linear.weight"] = w[:, 1:].t().contiguous()
-        out["action_parameterization.distribution_linear.bias"] = b[1:].clone()
+        out["action_parameterization.distribution_linear.weight"] = w[:, 1:1 + A].t().contiguous()
+        out["action_parameterization.distribution_linear.bias"] = b[1:1 + A].clone()
         return out
 
     # ------------------------------------------------------------------------------------------ compute
@@ -293,6 +298,14 @@ class ActorCritic:
         t = self._bufs.get(key)
         if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
             t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def _zbuf(self, key, shape):
+        """like _buf but zero-filled on creation (buffers with never-written padding columns)"""
+        t = self._bufs.get(key)
+        if t is None or t.shape != torch.Size(shape):
+            t = torch.zeros(shape, dtype=torch.float32, device=self.device)
             self._bufs[key] = t
         return t
 
@@ -318,7 +331,9 @@ class ActorCritic:
                 d.traj_T = int(traj_T)
                 lib.conv_fwd_raw(x, sample_stride, index, offset, L.w, L.b, out, n, d)
             else:
-                lib.conv_fwd_raw(x, d.H * d.W * d.Cin, None, 0, L.w, L.b, out, n, d)
+                wsb = lib.conv_fwd_workspace(n, d)  # >0 only for launches too small to fill the chip (split-K)
+                lib.conv_fwd_raw(x, d.H * d.W * d.Cin, None, 0, L.w, L.b, out, n, d,
+                                 self._workspace(wsb) if wsb else None)
             acts.append(out)
             x = out
         return acts
@@ -332,7 +347,7 @@ class ActorCritic:
         heads = self.forward_heads(obs, B, sample_stride=self.obs_elems if obs.is_contiguous() else obs.stride(0))[-1]
         res = dict(values=heads[:, 0])
         if not values_only:
-            res["action_logits"] = heads[:, 1:]
+            res["action_logits"] = heads[:, 1:1 + self.num_action_params]
         res["new_rnn_states"] = rnn_states
         return res
 
