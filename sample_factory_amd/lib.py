@@ -47,11 +47,12 @@ _lib: Optional[C.CDLL] = None
 # Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).  Events are recorded on
 # torch's CURRENT stream, which is the stream every call below launches on.  PROFILE maps key -> [(start, end), ...].
 PROFILE: Optional[dict] = None
+PROFILE_ONLY: Optional[set] = None  # when set, only these keys are timed (bench: the dominant kernel only)
 
 
 class _timed:
     def __init__(self, key):
-        self.key = key if PROFILE is not None else None
+        self.key = key if PROFILE is not None and (PROFILE_ONLY is None or key in PROFILE_ONLY) else None
 
     def __enter__(self):
         if self.key is not None:
