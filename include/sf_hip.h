@@ -168,7 +168,9 @@ typedef struct {
     int32_t Cout, KH, KW, stride;
     int32_t OH, OW;           /* output feature map */
     int32_t in_u8;            /* 1: input is the raw u8 NCHW observation; loader applies (x - sub_mean) * inv_scale */
-    int32_t relu;             /* 1: ReLU fused in the forward epilogue */
+    int32_t relu;             /* activation kind: 0 none, 1 ReLU, 2 tanh, 3 ELU(alpha=1) (model/model_utils.py:27-35).
+                                 forward: fused in the epilogue; sf_conv_dgrad: the kind that PRODUCED in_act, whose
+                                 derivative (through the stored output) is fused into the dgrad epilogue */
     int32_t traj_T;           /* >0: input rows live in a trajectory slab [E, T+1, ...]; logical sample d (flat dataset
                                  index e*T+t, learner.py:1009-1012) is slab row e*(T+1)+t — read in place, no batcher
                                  copy (batcher.py:192-212) and no [:, :-1] reshape copy (learner.py:1005-1012) */
@@ -190,8 +192,8 @@ int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32_t *index, 
 int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc);
 int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *dout,
                   float *dw, float *db, int64_t n, const sf_conv_desc *h_desc, void *workspace, void *stream);
-/* data gradient: din[n,H,W,Cin] = conv_transpose(dout, w) * relu_mask(in_act) (in_act = this layer's input
- * activation, i.e. the previous layer's post-ReLU output; NULL = no mask). */
+/* data gradient: din[n,H,W,Cin] = conv_transpose(dout, w) * act'(in_act) (in_act = this layer's input activation,
+ * i.e. the previous layer's post-activation output, kind = h_desc->relu; NULL = no activation derivative). */
 int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                   const sf_conv_desc *h_desc, void *stream);
 /* dense layer: out[M,N] = act(in[M,K] * w[K,N] + bias); wgrad: dw[K,N] = in^T dout, db = colsum(dout);

@@ -21,6 +21,8 @@
 // chunk back-to-back and waits once (the first version branched per load and hipcc serialised them with vmcnt(0)).
 #include "sf_common.h"
 
+#include <stdlib.h>
+
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -64,6 +66,7 @@ struct ConvG {
     int K;          // KH*KW*Cin
     int vecA, vecB; // vector (16-byte / 4-byte-of-u8) loads legal for the activation / [*,Cout] operands
     FastDiv dOHOW, dOW, dCin, dKW, dKHKW, dT, dCout;
+    FastDiv dHcWc[16], dWc[16], dKWs[16];  // data-gradient stride-parity classes (S*S <= 16)
 };
 
 static ConvG make_geom(const sf_conv_desc *d) {
@@ -81,6 +84,14 @@ static ConvG make_geom(const sf_conv_desc *d) {
     g.dKHKW = make_fastdiv((uint32_t)(d->KH * d->KW));
     g.dT = make_fastdiv((uint32_t)(d->traj_T > 0 ? d->traj_T : 1));
     g.dCout = make_fastdiv((uint32_t)d->Cout);
+    for (int z = 0; z < 16; ++z) {
+        const int S = d->stride, ph = z / S, pw = z % S;
+        const int Hc = (d->H - ph + S - 1) / S, Wc = (d->W - pw + S - 1) / S, KWs = (d->KW - pw + S - 1) / S;
+        const bool ok = z < S * S && Hc > 0 && Wc > 0;
+        g.dHcWc[z] = make_fastdiv(ok ? (uint32_t)(Hc * Wc) : 1u);
+        g.dWc[z] = make_fastdiv(ok ? (uint32_t)Wc : 1u);
+        g.dKWs[z] = make_fastdiv(ok && KWs > 0 ? (uint32_t)KWs : 1u);
+    }
     return g;
 }
 
@@ -126,6 +137,21 @@ __device__ __forceinline__ int patch_origin(const ConvG &g, uint32_t pix) {
     const uint32_t oh = fdiv(pix, g.dOW), ow = pix - oh * (uint32_t)g.OW;
     const uint32_t o = oh * (uint32_t)g.S * (uint32_t)g.W + ow * (uint32_t)g.S;
     return (int)(U8 ? o : o * (uint32_t)g.Cin);
+}
+
+// activations (desc.relu carries the kind): 0 none, 1 ReLU, 2 tanh, 3 ELU(alpha=1) — model/model_utils.py:27-35
+__device__ __forceinline__ float act_fwd(float x, int kind) {
+    if (kind == 1) return fmaxf(x, 0.f);
+    if (kind == 2) return tanhf(x);
+    if (kind == 3) return x > 0.f ? x : expm1f(x);
+    return x;
+}
+// derivative expressed through the activation OUTPUT y (what the backward chain has at hand)
+__device__ __forceinline__ float act_bwd(float y, int kind) {
+    if (kind == 1) return y > 0.f ? 1.f : 0.f;
+    if (kind == 2) return 1.f - y * y;
+    if (kind == 3) return y > 0.f ? 1.f : y + 1.f;
+    return 1.f;
 }
 
 // Raw (unconverted, unmasked) operand quads.  The value is NOT touched between the global load and the LDS store of
@@ -252,7 +278,7 @@ struct Tile {
 
 // ============================================================================================== FORWARD
 // rows m = (sample, oh, ow); A reduction-major loads (4 consecutive k per slot), B = weights free-axis-major.
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool DB>
 __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restrict__ in, int64_t in_stride,
                                                   const int32_t *__restrict__ index, int64_t offset,
                                                   const float *__restrict__ w, const float *__restrict__ bias,
@@ -262,8 +288,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
     constexpr bool U8 = MODE == MODE_U8;
     constexpr bool VECB = MODE != MODE_GENERIC;
     constexpr int LDA = BM + 1, LDB = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[32 * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[32 * LDB];
+    constexpr int NBUF = DB ? 2 : 1;  // DB: two LDS images, ONE barrier per K-chunk (store of chunk i+1 overlaps compute i)
+    __shared__ __attribute__((aligned(16))) float As_[NBUF][32 * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs_[NBUF][32 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -313,12 +340,13 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
             rb[s] = load_row_raw<VECB>(w, bok[s] ? k : kbeg, n0 + bcg, N);
         }
     };
-    gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        __syncthreads();
+    // Rows >= Mtot and columns >= N only feed accumulator entries that are never stored, and the clamped addresses
+    // read finite data, so with full K-chunks (every layer of the Nature CNN: K % 32 == 0) nothing needs masking.
+    const bool kfull = ((kend - kbeg) & 31) == 0 && MODE != MODE_GENERIC;
+    auto lstore = [&](float *As, float *Bs) {
 #pragma unroll
         for (int s = 0; s < T::SA; ++s) {
-            const float4 v = act_finish<MODE>(g, ra[s], aok && aval[s]);
+            const float4 v = act_finish<MODE>(g, ra[s], kfull || (aok && aval[s]));
             As[(kq + 0) * LDA + arow + 32 * s] = v.x;
             As[(kq + 1) * LDA + arow + 32 * s] = v.y;
             As[(kq + 2) * LDA + arow + 32 * s] = v.z;
@@ -326,10 +354,29 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
         }
 #pragma unroll
         for (int s = 0; s < T::SB; ++s)
-            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) = row_finish(rb[s], bok[s], n0 + bcg, N);
+            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) =
+                kfull ? rb[s] : row_finish(rb[s], bok[s], n0 + bcg, N);
+    };
+    gload(kbeg);
+    if constexpr (DB) {
+        lstore(As_[0], Bs_[0]);
         __syncthreads();
-        if (k0 + 32 < kend) gload(k0 + 32);
-        mma_chunk<T::TM, T::TN, LDA, LDB>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, lane, acc);
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += 32, buf ^= 1) {
+            const bool more = k0 + 32 < kend;
+            if (more) gload(k0 + 32);
+            mma_chunk<T::TM, T::TN, LDA, LDB>(As_[buf], Bs_[buf], wm * T::TM * 32, wn * T::TN * 32, lane, acc);
+            if (more) lstore(As_[buf ^ 1], Bs_[buf ^ 1]);
+            __syncthreads();
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            __syncthreads();
+            lstore(As_[0], Bs_[0]);
+            __syncthreads();
+            if (k0 + 32 < kend) gload(k0 + 32);
+            mma_chunk<T::TM, T::TN, LDA, LDB>(As_[0], Bs_[0], wm * T::TM * 32, wn * T::TN * 32, lane, acc);
+        }
     }
     // epilogue: bias + ReLU, NHWC store (split-K: raw partial, finished by k_splitk_finish)
     float *dst = partial ? partial + (int64_t)blockIdx.z * Mtot * N : out;
@@ -345,7 +392,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
                 const int64_t m = m0 + wm * T::TM * 32 + tm * 32 + FRAG_ROW(r, lane);
                 if (m < Mtot && n < N) {
                     float v = acc[tm][tn][r] + bv;
-                    if (fin && g.relu) v = fmaxf(v, 0.f);
+                    if (fin) v = act_fwd(v, g.relu);
                     dst[m * N + n] = v;
                 }
             }
@@ -360,7 +407,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float *__restrict__
         float s = 0.f;
         for (int z = 0; z < Z; ++z) s += partial[(int64_t)z * MN + i];
         if (bias) s += bias[(int)(i % N)];
-        out[i] = relu ? fmaxf(s, 0.f) : s;
+        out[i] = act_fwd(s, relu);
     }
 }
 
@@ -458,11 +505,16 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvG g, const void *__restr
 #pragma unroll
         for (int s = 0; s < T::SA; ++s) {
             const int lrow = U8 ? (tid & 31) : (tid >> 5) + 8 * s;  // reduction index (m) inside the chunk
-            *reinterpret_cast<float4 *>(&As[lrow * LDA + kg[s]]) = act_finish<MODE>(g, ra[s], aok[s]);
+            // rows k >= K are never stored and reduction rows >= mend are annihilated by the zeroed dY rows below,
+            // so the activation operand is stored unmasked on the vector paths (clamped loads read finite data)
+            *reinterpret_cast<float4 *>(&As[lrow * LDA + kg[s]]) =
+                act_finish<MODE>(g, ra[s], MODE != MODE_GENERIC || aok[s]);
         }
+        const bool tail = mc + 32 > mend;
 #pragma unroll
         for (int s = 0; s < T::SB; ++s)
-            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) = row_finish(rb[s], bok[s], n0 + bcg, N);
+            *reinterpret_cast<float4 *>(&Bs[(bkk0 + s * BROWS) * LDB + bcg]) =
+                (VECB && !tail) ? rb[s] : row_finish(rb[s], bok[s], n0 + bcg, N);
         __syncthreads();
         if (mc + 32 < mend) gload(mc + 32);
         if (do_colsum) {
@@ -521,25 +573,27 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvG g, const float *__rest
     const int Kp = KHs * KWs * Cout;  // reduction length of this class (0 if the class has no taps)
 
     const int kq = (tid & 7) * 4;
-    int64_t arow[T::SA];  // first dY row (sample * OH*OW) of the slot's sample
-    int aih[T::SA], aiw[T::SA];
+    const FastDiv fHW = g.dHcWc[blockIdx.z], fW = g.dWc[blockIdx.z], fKWs = g.dKWs[blockIdx.z];
+    // per-slot dY row of tap (0,0) as a 32-bit index (launcher guarantees rows*Cout < 2^31), plus (ihh, iww)
+    int arow[T::SA], aih[T::SA], aiw[T::SA];
     bool aval[T::SA];
     const uint32_t HcWc = (uint32_t)(Hc * Wc);
 #pragma unroll
     for (int s = 0; s < T::SA; ++s) {
         const int64_t m = m0 + (tid >> 3) + 32 * s;
         aval[s] = m < Mc;
-        const uint32_t mm = aval[s] ? (uint32_t)m : 0u;  // m < 2^31 (checked by the launcher)
-        const uint32_t smp = mm / HcWc, pix = mm - smp * HcWc;
-        aih[s] = (int)(pix / (uint32_t)Wc);
+        const uint32_t mm = aval[s] ? (uint32_t)m : 0u;
+        const uint32_t smp = fdiv(mm, fHW), pix = mm - smp * HcWc;
+        aih[s] = (int)fdiv(pix, fW);
         aiw[s] = (int)pix - aih[s] * Wc;
-        arow[s] = (int64_t)smp * g.OH * g.OW;
+        arow[s] = (int)(smp * (uint32_t)(g.OH * g.OW)) + aih[s] * g.OW + aiw[s];
     }
+    const bool kfull = (Kp & 31) == 0;  // every chunk full: the weight operand needs no masking
     f32x16 acc[T::TM][T::TN];
     ZERO_ACC(acc);
 
     float4 ra[T::SA], rb[T::SB];
-    bool aok[T::SA], bok[T::SB];
+    bool aok[T::SA], bok = true;
     int ncol = 0;
     auto gload = [&](int k0) {
         const int k = k0 + kq;
@@ -548,19 +602,21 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvG g, const float *__rest
         const int tap = (int)fdiv((uint32_t)kc, g.dCout);
         const int n = kc - tap * Cout;
         ncol = n;
-        const int a = tap / KWs, b = tap - a * KWs;
+        const int a = (int)fdiv((uint32_t)tap, fKWs), b = tap - a * KWs;
+        const int drow = a * g.OW + b;  // tap (a,b) reads dY pixel (ihh - a, iww - b)
 #pragma unroll
         for (int s = 0; s < T::SA; ++s) {
             const int oh = aih[s] - a, ow = aiw[s] - b;
             aok[s] = kval && aval[s] && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
-            ra[s] = load_row_raw<VEC>(dy, arow[s] + (aok[s] ? (int64_t)oh * g.OW + ow : 0), n, Cout);
+            const int row = aok[s] ? arow[s] - drow : 0;
+            ra[s] = load_row_raw<VEC>(dy, row, n, Cout);
         }
-        const int kh = ph + a * g.S, kw = pw + b * g.S;
+        const int wrow = ((ph + a * g.S) * g.KW + (pw + b * g.S)) * Cin;
+        bok = kval;
 #pragma unroll
         for (int s = 0; s < T::SB; ++s) {
             const int c = n0 + (tid >> 3) + 32 * s;
-            bok[s] = kval && c < Cin;
-            rb[s] = load_row_raw<VEC>(w, (int64_t)(kh * g.KW + kw) * Cin + (bok[s] ? c : 0), n, Cout);
+            rb[s] = load_row_raw<VEC>(w, wrow + (c < Cin ? c : 0), n, Cout);  // columns >= Cin are never stored
         }
     };
     if (Kp > 0) gload(0);
@@ -576,7 +632,7 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvG g, const float *__rest
         }
 #pragma unroll
         for (int s = 0; s < T::SB; ++s) {
-            const float4 v = row_finish(rb[s], bok[s], ncol, Cout);
+            const float4 v = (VEC && kfull) ? rb[s] : row_finish(rb[s], bok, ncol, Cout);
             Bs[(kq + 0) * LDB + (tid >> 3) + 32 * s] = v.x;
             Bs[(kq + 1) * LDB + (tid >> 3) + 32 * s] = v.y;
             Bs[(kq + 2) * LDB + (tid >> 3) + 32 * s] = v.z;
@@ -586,21 +642,24 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvG g, const float *__rest
         if (k0 + 32 < Kp) gload(k0 + 32);
         mma_chunk<T::TM, T::TN, LDA, LDB>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, lane, acc);
     }
+    const int akind = g.relu;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < T::TN; ++tn) {
-            const int c = n0 + wn * T::TN * 32 + tn * 32 + (lane & 31);
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * T::TM * 32 + tm * 32 + FRAG_ROW(r, lane);
+            const bool mok = m < Mc;
+            const uint32_t mm = mok ? (uint32_t)m : 0u;
+            const uint32_t smp = fdiv(mm, fHW), pix = mm - smp * HcWc;
+            const int ihh = (int)fdiv(pix, fW), iww = (int)pix - ihh * Wc;
+            const int64_t obase = (((int64_t)smp * g.H + (ihh * g.S + ph)) * g.W + (iww * g.S + pw)) * Cin;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * T::TM * 32 + tm * 32 + FRAG_ROW(r, lane);
-                if (m < Mc && c < Cin) {
-                    const uint32_t smp = (uint32_t)m / HcWc, pix = (uint32_t)m - smp * HcWc;
-                    const int ihh = (int)(pix / (uint32_t)Wc), iww = (int)pix - ihh * Wc;
-                    const int64_t o = (((int64_t)smp * g.H + (ihh * g.S + ph)) * g.W + (iww * g.S + pw)) * Cin + c;
+            for (int tn = 0; tn < T::TN; ++tn) {
+                const int c = n0 + wn * T::TN * 32 + tn * 32 + (lane & 31);
+                if (mok && c < Cin) {
                     float v = acc[tm][tn][r];
-                    if (in_act && !(in_act[o] > 0.f)) v = 0.f;
-                    din[o] = v;
+                    if (in_act) v *= act_bwd(in_act[obase + c], akind);  // kind of the activation that produced in_act
+                    din[obase + c] = v;
                 }
             }
         }
@@ -613,6 +672,19 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// tuning switch for A/B experiments (read once): SF_NN_DB=1 -> double-buffered LDS forward (one barrier per chunk).
+// Measured on MI355X (tools/kbench.py, round 1): 2-7 % SLOWER than single-buffer + register prefetch (fewer resident
+// blocks per CU outweigh the saved barrier), so it is off by default.
+static bool sf_tune_db() {
+    static const bool v = [] { const char *e = getenv("SF_NN_DB"); return e ? atoi(e) != 0 : false; }();
+    return v;
+}
+
+static int sf_tune_bm() {  // SF_NN_BM=256 -> 256-row tiles for the large-M forward / dgrad launches (A/B experiment)
+    static const int v = [] { const char *e = getenv("SF_NN_BM"); return e ? atoi(e) : 128; }();
+    return v;
+}
 
 static int pick_mode(const ConvG &g) {
     if (!g.vecA || !g.vecB) return MODE_GENERIC;
@@ -654,9 +726,15 @@ extern "C" int64_t sf_conv_fwd_workspace(int64_t n, const sf_conv_desc *h_desc) 
     return p.splits > 1 ? (int64_t)sizeof(float) * p.splits * Mtot * N + 256 : 0;
 }
 
-#define FWD_LAUNCH(BM, BN, WM, WN, MODE)                                                                   \
-    k_conv_fwd<BM, BN, WM, WN, MODE><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
-        g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial)
+#define FWD_LAUNCH(BM, BN, WM, WN, MODE)                                                                           \
+    do {                                                                                                           \
+        if (sf_tune_db())                                                                                          \
+            k_conv_fwd<BM, BN, WM, WN, MODE, true><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
+                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial);               \
+        else                                                                                                       \
+            k_conv_fwd<BM, BN, WM, WN, MODE, false><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
+                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial);               \
+    } while (0)
 #define FWD_BY_MODE(BM, BN, WM, WN)                                    \
     do {                                                               \
         if (mode == MODE_F32) FWD_LAUNCH(BM, BN, WM, WN, MODE_F32);    \
@@ -684,8 +762,10 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
     const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, workspace ? workspace_bytes / (int64_t)sizeof(float) : 0);
     float *partial = p.splits > 1 ? reinterpret_cast<float *>(workspace) : nullptr;
     const unsigned Z = (unsigned)p.splits;
-    if (p.cfg == 0) FWD_BY_MODE(128, 32, 4, 1);
-    else if (p.cfg == 1) FWD_BY_MODE(128, 64, 2, 2);
+    const bool big = sf_tune_bm() == 256 && p.splits == 1 && Mtot >= 256 * 2048;
+    const bool big32 = p.splits == 1 && Mtot >= 256 * 2048;  // measured +5 % on conv1 (N=32): more MFMAs per barrier
+    if (p.cfg == 0) { if (big32) FWD_BY_MODE(256, 32, 4, 1); else FWD_BY_MODE(128, 32, 4, 1); }
+    else if (p.cfg == 1) { if (big) FWD_BY_MODE(256, 64, 2, 2); else FWD_BY_MODE(128, 64, 2, 2); }
     else FWD_BY_MODE(64, 64, 2, 2);
     if (partial) {
         const int64_t MN = Mtot * g.Cout;
@@ -784,13 +864,16 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     const ConvG g = make_geom(h_desc);
     const int Hc = (g.H + g.S - 1) / g.S, Wc = (g.W + g.S - 1) / g.S;  // largest parity class
     const int64_t Mc = n * Hc * Wc;
-    SF_REQUIRE(n * g.H * g.W < (1LL << 31), "sf_conv_dgrad: too many rows; split the batch");
+    SF_REQUIRE(n * g.H * g.W < (1LL << 31) && n * g.OH * g.OW * (int64_t)g.Cout < (1LL << 31) &&
+                   (int64_t)g.K * g.Cout < (1LL << 31),
+               "sf_conv_dgrad: operand too large for 32-bit element offsets; split the batch");
     hipStream_t st = STREAM(stream);
     const unsigned classes = (unsigned)(g.S * g.S);
     const bool vec = g.vecB && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0;
-    if (g.Cin <= 32) DGRAD_LAUNCH(128, 32, 4, 1);
+    const bool big = sf_tune_bm() == 256 && Mc >= 256 * 2048;
+    if (g.Cin <= 32) { if (big) DGRAD_LAUNCH(256, 32, 4, 1); else DGRAD_LAUNCH(128, 32, 4, 1); }
     else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) DGRAD_LAUNCH(64, 64, 2, 2);
-    else DGRAD_LAUNCH(128, 64, 2, 2);
+    else { if (big) DGRAD_LAUNCH(256, 64, 2, 2); else DGRAD_LAUNCH(128, 64, 2, 2); }
     return sf_launch_status("sf_conv_dgrad");
 }
 
@@ -821,7 +904,7 @@ extern "C" int sf_linear_wgrad(const float *in, const float *dout, float *dw, fl
 extern "C" int sf_linear_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t M, int K,
                                int N, void *stream) {
     SF_REQUIRE(M > 0 && K > 0 && N > 0, "sf_linear_dgrad: bad shape");
-    const sf_conv_desc d = linear_desc(K, N, 0);
+    const sf_conv_desc d = linear_desc(K, N, in_act ? 1 : 0);  // this wrapper's contract: ReLU mask of in_act
     return sf_conv_dgrad(dout, w, in_act, din, M, &d, stream);
 }
 

@@ -11,8 +11,8 @@ with Sample Factory checkpoints; the compute is libsf_hip.so'
  * the u8 -> f32 observation normalisation (utils/normalize.py:51-70) is fused into the first layer's loader;
  * critic_linear and distribution_linear are one fused [F, 1+A] GEMM (column 0 = value).
 
-Only feed-forward ReLU models are native in this round (the north-star config); anything else raises — there is no
-silent PyTorch fallback.
+Feed-forward models (conv or MLP encoder, relu/tanh/elu) are native; RNN cores, input running-mean-std and separate
+actor/critic weights raise — there is no silent PyTorch fallback.
 """
 from __future__ import annotations
 
@@ -25,6 +25,8 @@ import torch
 from sample_factory_amd import lib
 from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
 from sample_factory_amd.envs.spaces import calc_num_action_parameters, is_discrete
+
+ACT_KIND = {"relu": 1, "tanh": 2, "elu": 3}  # model/model_utils.py:27-35; fused into the GEMM epilogues
 
 CONV_ARCHS = {  # model/encoder.py:126-134: [out_channels, kernel, stride]
     "convnet_simple": [[32, 8, 4], [64, 4, 2], [128, 3, 2]],
@@ -106,8 +108,9 @@ class ActorCritic:
             raise NotImplementedError("native RNN core is not built yet (SURVEY.md §8f.3); use_rnn=False only")
         if not cfg.actor_critic_share_weights:
             raise NotImplementedError("separate actor/critic weights are outside the hot-path scope (SURVEY.md §2.1)")
-        if cfg.nonlinearity != "relu":
-            raise NotImplementedError(f"native kernels fuse ReLU only; nonlinearity={cfg.nonlinearity} not built yet")
+        if cfg.nonlinearity not in ACT_KIND:
+            raise NotImplementedError(f"Unknown nonlinearity {cfg.nonlinearity}")
+        act = ACT_KIND[cfg.nonlinearity]
         if cfg.normalize_input:
             raise NotImplementedError("normalize_input=True (per-pixel running mean/std) is not built yet; the "
                                       "north-star preset uses obs_scale/obs_subtract_mean with normalize_input=False")
@@ -136,14 +139,14 @@ class ActorCritic:
                 oh, ow = (h - k) // s + 1, (w - k) // s + 1
                 first = i == 0
                 desc = lib.sf_conv_desc(Cin=cin, H=h, W=w, Cout=cout, KH=k, KW=k, stride=s, OH=oh, OW=ow,
-                                        in_u8=int(first), relu=1, traj_T=0,
+                                        in_u8=int(first), relu=act, traj_T=0,
                                         sub_mean=sub_mean if first else 0.0, inv_scale=inv_scale if first else 1.0)
                 self.layers.append(_Layer(f"{pfx}conv_head.{2 * i}", desc, (cout, cin, k, k),
                                           "conv_u8" if first else "conv"))
                 cin, h, w = cout, oh, ow
             feat, chw = cin * h * w, (cin, h, w)
             for j, size in enumerate(cfg.encoder_conv_mlp_layers):
-                self.layers.append(_Layer(f"{pfx}mlp_layers.{2 * j}", _linear_desc(feat, size, True), (size, feat),
+                self.layers.append(_Layer(f"{pfx}mlp_layers.{2 * j}", _linear_desc(feat, size, act), (size, feat),
                                           "linear_after_conv" if j == 0 else "linear", first_fc_chw=chw))
                 feat = size
         elif len(self.obs_shape) == 1:
@@ -151,20 +154,21 @@ class ActorCritic:
                 raise NotImplementedError("vector observations must be f32 without obs_scale/obs_subtract_mean")
             feat = self.obs_shape[0]
             for j, size in enumerate(cfg.encoder_mlp_layers):
-                self.layers.append(_Layer(f"encoder.encoders.obs.mlp_head.{2 * j}", _linear_desc(feat, size, True),
+                self.layers.append(_Layer(f"encoder.encoders.obs.mlp_head.{2 * j}", _linear_desc(feat, size, act),
                                           (size, feat), "linear"))
                 feat = size
         else:
             raise NotImplementedError(f"Unsupported observation shape {self.obs_shape}")
         for j, size in enumerate(cfg.decoder_mlp_layers):
-            self.layers.append(_Layer(f"decoder.mlp.{2 * j}", _linear_desc(feat, size, True), (size, feat), "linear"))
+            self.layers.append(_Layer(f"decoder.mlp.{2 * j}", _linear_desc(feat, size, act), (size, feat), "linear"))
             feat = size
         self.feat = feat
         A = self.num_action_params
         # fused heads [F, 1+A] padded to a multiple of 4 columns (zero weights, zero gradients) so that every operand
         # of every layer takes the 16-byte vector loaders; column 0 = value, columns 1..A = action parameters
         self.heads_ld = (1 + A + 3) // 4 * 4
-        self.layers.append(_Layer("heads", _linear_desc(feat, self.heads_ld, False), (self.heads_ld, feat), "heads"))
+        self.layers.append(_Layer("heads", _linear_desc(feat, self.heads_ld, 0), (self.heads_ld, feat), "heads"))
+        self.act_kind = act
         self.obs_elems = int(np.prod(self.obs_shape))
 
         # ---- flat parameter / gradient / Adam buffers
@@ -369,5 +373,7 @@ class ActorCritic:
                 ws = self._workspace(lib.conv_wgrad_workspace(n, d))
                 lib.conv_wgrad_raw(x, stride, None, 0, g, L.gw, L.gb, n, d, ws)
                 gin = self._buf(("g", li - 1), tuple(acts[li - 1].shape))
-                lib.conv_dgrad(g, L.w, acts[li - 1], gin, n, d)  # ReLU mask of the previous layer fused
+                dd = lib.sf_conv_desc.from_buffer_copy(d)
+                dd.relu = self.act_kind  # kind of the activation that produced acts[li-1]; derivative fused
+                lib.conv_dgrad(g, L.w, acts[li - 1], gin, n, dd)
                 g = gin

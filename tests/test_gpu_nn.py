@@ -267,6 +267,69 @@ def test_learner_train_matches_reference_cnn36(lib, golden, tmp_path):
     assert "encoder.encoders.obs.enc.conv_head.0.weight" in cp["model"] and cp["model"]["returns_normalizer.count"].dtype == torch.float64
 
 
+@pytest.mark.parametrize("name", ["mlp", "mlp_inv"])
+def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
+    """vector-observation MLP encoder with tanh (the reference's Mujoco-style model), 2 epochs / KL loss / invalid rows:
+    full Learner.train vs the reference's post-training state (train_mlp*.npz)."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    g = golden("train_" + name)
+    E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
+    kl = 0.1 if "kl_loss_coeff=0.1" in str(g["argv"]) else 0.0
+    cfg = default_cfg(use_rnn=False, recurrence=1, nonlinearity="tanh", normalize_input=False, encoder_mlp_layers=[32, 32],
+                      rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]),
+                      kl_loss_coeff=kl, seed=0, serial_mode=True, train_dir=str(tmp_path), experiment="t",
+                      record_grad_norm=True)
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    ac = learner.actor_critic
+    assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
+    load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
+    batch = alloc_trajectory_tensors(env_info, E, T, 1, "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    stats = learner.train(batch)
+    assert stats["learner_env_steps"] == int(g["env_steps"]) and learner.train_step == int(g["train_step"])
+    np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=3e-4)
+    np.testing.assert_allclose(ac.returns_normalizer.stats.cpu().numpy(), g["out_rms"], rtol=1e-5)
+    after, m = ac.state_dict(), ac.flat_to_ref(learner.exp_avg)
+    for pname in g["param_names"]:
+        np.testing.assert_allclose(m[pname].reshape(-1).numpy(), g["m_" + pname], rtol=3e-3, atol=3e-8, err_msg=pname)
+        np.testing.assert_allclose(after[pname].reshape(-1).numpy(), g["after_" + pname], rtol=0, atol=2e-5, err_msg=pname)
+
+
+@pytest.mark.parametrize("act,kind", [("tanh", 2), ("elu", 3)])
+def test_activation_kinds_fwd_bwd(lib, act, kind):
+    M, K, N = 300, 64, 96
+    g = torch.Generator().manual_seed(kind)
+    x, w, b = torch.randn((M, K), generator=g), torch.randn((K, N), generator=g) / 8, torch.randn(N, generator=g)
+    dy = torch.randn((M, 32), generator=g)
+    w2 = torch.randn((N, 32), generator=g) / 8
+    d = lib.sf_conv_desc(Cin=K, H=1, W=1, Cout=N, KH=1, KW=1, stride=1, OH=1, OW=1, in_u8=0, relu=kind, traj_T=0, sub_mean=0.0, inv_scale=1.0)
+    out = torch.empty((M, N), device="cuda")
+    lib.conv_fwd(x.cuda(), K, None, 0, w.cuda(), b.cuda(), out, M, d)
+    xr = x.double().requires_grad_(True)
+    pre = xr @ w.double() + b.double()
+    y = torch.tanh(pre) if act == "tanh" else F.elu(pre)
+    assert (out.cpu().double() - y.detach()).abs().max().item() < 2e-5
+    # next layer's dgrad fuses this activation's derivative: d(pre) = (dy @ w2^T) * act'(y)
+    d2 = lib.sf_conv_desc(Cin=N, H=1, W=1, Cout=32, KH=1, KW=1, stride=1, OH=1, OW=1, in_u8=0, relu=kind, traj_T=0, sub_mean=0.0, inv_scale=1.0)
+    din = torch.empty((M, N), device="cuda")
+    lib.conv_dgrad(dy.cuda(), w2.cuda(), out, din, M, d2)
+    (y @ w2.double()).backward(dy.double())
+    gpre = torch.autograd.grad((torch.tanh(pre) if act == "tanh" else F.elu(pre)), pre, (dy.double() @ w2.double().t()), retain_graph=False)[0] if False else None
+    ref = (dy.double() @ w2.double().t()) * ((1 - y.detach() ** 2) if act == "tanh" else torch.where(y.detach() > 0, torch.ones_like(y), y.detach() + 1))
+    assert (din.cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_end_to_end_rollout_and_train_small(lib):
     """synthetic env -> rollout into the slab -> train, a few iterations; checks the slab protocol invariants"""
     from sample_factory_amd.cfg.arguments import default_cfg

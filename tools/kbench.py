@@ -1,0 +1,50 @@
+"""Per-kernel timing of the network kernels at the bench shapes (HIP events, many reps).  python tools/kbench.py"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sample_factory_amd import lib
+
+def desc(Cin, H, W, Cout, K, S, u8=0):
+    return lib.sf_conv_desc(Cin=Cin, H=H, W=W, Cout=Cout, KH=K, KW=K, stride=S, OH=(H-K)//S+1, OW=(W-K)//S+1, in_u8=u8,
+                            relu=1, traj_T=0, sub_mean=0.0, inv_scale=1/255.0 if u8 else 1.0)
+
+LAYERS = [("conv1", desc(4,84,84,32,8,4,1)), ("conv2", desc(32,20,20,64,4,2)), ("conv3", desc(64,9,9,64,3,1)),
+          ("fc", desc(3136,1,1,512,1,1)), ("heads", desc(512,1,1,8,1,1))]
+
+def timeit(fn, reps):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+def main():
+    which = sys.argv[1:] or ["fwd", "wgrad", "dgrad"]
+    for n in (4096, 32768):
+        for name, d in LAYERS:
+            K = d.KH*d.KW*d.Cin
+            M = n*d.OH*d.OW
+            flops = 2.0*M*d.Cout*K
+            if d.in_u8: x = torch.randint(0,256,(n,d.Cin,d.H,d.W),dtype=torch.uint8,device="cuda")
+            else: x = torch.randn((n,d.H,d.W,d.Cin),device="cuda")
+            w = torch.randn((K,d.Cout),device="cuda")/np.sqrt(K); b = torch.zeros(d.Cout,device="cuda")
+            out = torch.empty((M,d.Cout),device="cuda"); dy = torch.randn((M,d.Cout),device="cuda")
+            reps = 20 if n == 4096 else 5
+            stride = d.Cin*d.H*d.W
+            res = []
+            if "fwd" in which:
+                wsb = lib.conv_fwd_workspace(n, d); ws = torch.empty(max(wsb,16),dtype=torch.uint8,device="cuda") if wsb else None
+                t = timeit(lambda: lib.conv_fwd(x, stride, None, 0, w, b, out, n, d, ws), reps); res.append(f"fwd {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+            if "wgrad" in which and n == 32768:
+                dw = torch.empty_like(w); db = torch.empty_like(b)
+                ws = torch.empty(lib.conv_wgrad_workspace(n, d),dtype=torch.uint8,device="cuda")
+                t = timeit(lambda: lib.conv_wgrad(x, stride, None, 0, dy, dw, db, n, d, ws), reps); res.append(f"wgrad {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+            if "dgrad" in which and n == 32768 and not d.in_u8:
+                din = torch.empty((n,d.H,d.W,d.Cin),device="cuda")
+                t = timeit(lambda: lib.conv_dgrad(dy, w, x, din, n, d), reps); res.append(f"dgrad {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+            print(f"n={n:6d} {name:6s} " + " | ".join(res), flush=True)
+
+if __name__ == "__main__":
+    main()
