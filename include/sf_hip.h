@@ -128,10 +128,13 @@ int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int st
  * logits [B,A] (row stride ld_logits), values [B] (stride ld_values): network outputs.  Samples by inverse CDF from a Philox4x32-10 uniform
  * (key = (seed, row0+b), counter = (step, 0, 2, 0)) and writes, for env b, element (b*stride + t) of the
  * trajectory tensors: actions (f32), log_prob_actions, values (row stride T+1), policy_version, action_logits
- * (A floats) and the int32 action for the env.  `deterministic` != 0 takes argmax (enjoy.py:177-182). */
+ * (A floats) and the int32 action for the env.  `deterministic` != 0 takes argmax (enjoy.py:177-182).
+ * action_kind 1 = Box(A/2): params are [means | log_std] (action_distributions.py:290-310); the action
+ * mu + clamp(exp(log_std),1e-4,1e4)*eps (eps: Box-Muller on Philox stream 3) is written as A/2 floats into
+ * traj_actions[b*T+t] (the env reads it from there; env_actions may be NULL); deterministic takes the mean. */
 int sf_sample_write_step(const float *logits, int ld_logits, const float *values, int ld_values, int B, int A, int T,
                          int t, uint32_t seed, uint32_t step, uint32_t row0, float policy_version, int deterministic,
-                         float *traj_actions,
+                         int action_kind, float *traj_actions,
                          float *traj_logits, float *traj_logp, float *traj_values, float *traj_policy_version,
                          int32_t *env_actions, void *stream);
 

@@ -191,3 +191,14 @@ def sample_categorical(logits, seed, step, row0=0):
     lib().sfo_sample_categorical(_p(logits, C.c_float), C.c_long(N), A, C.c_uint32(seed), C.c_uint32(step),
                                  C.c_uint32(row0), _p(act, C.c_float), _p(lp, C.c_float))
     return act, lp
+
+
+def sample_normal(params, seed, step, row0=0):
+    params = _f32(params)
+    N, A = params.shape
+    D = A // 2
+    act = np.empty((N, D), np.float32)
+    lp = np.empty(N, np.float32)
+    lib().sfo_sample_normal(_p(params, C.c_float), C.c_long(N), D, C.c_uint32(seed), C.c_uint32(step),
+                            C.c_uint32(row0), _p(act, C.c_float), _p(lp, C.c_float))
+    return act, lp

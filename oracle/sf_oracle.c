@@ -495,3 +495,30 @@ SFO_API void sfo_sample_categorical(const float *logits, long N, int A, uint32_t
         logp[i] = (z[a] - mx) - lse;
     }
 }
+
+/* Continuous (Box) action sampling as done by sf_sample_write_step for action_kind 1: a = mu + sd * eps with
+ * sd = clamp(exp(log_std), 1e-4, 1e4) (action_distributions.py:290-310) and eps ~ N(0,1) from Box-Muller on two
+ * 24-bit Philox uniforms (stream 3, one Philox call yields the normals of dims 2j, 2j+1); log-prob = sum over dims
+ * of Normal.log_prob (torch.distributions.Independent).  The reference samples with torch's RNG (distributional
+ * parity only); this pins the HIP sampler bit-for-bit up to libm. */
+SFO_API void sfo_sample_normal(const float *params, long N, int D, uint32_t seed, uint32_t step, uint32_t row0,
+                               float *actions, float *logp) {
+    for (long i = 0; i < N; ++i) {
+        const float *z = params + i * 2 * D;
+        float lp = 0.f;
+        for (int k = 0; k < D; ++k) {
+            uint32_t w[4];
+            philox4x32_10(step, (uint32_t)(k / 2), 3u, 0u, seed, row0 + (uint32_t)i, w);
+            const float u1 = ((float)(w[(k & 1) * 2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float u2 = (float)(w[(k & 1) * 2 + 1] >> 8) * (1.0f / 16777216.0f);
+            const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+            const float mu = z[k];
+            float sd = expf(z[D + k]);
+            sd = sd < 1e-4f ? 1e-4f : (sd > 1e4f ? 1e4f : sd);
+            const float a = mu + sd * eps;
+            actions[i * D + k] = a;
+            lp += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+        }
+        logp[i] = lp;
+    }
+}

@@ -43,8 +43,7 @@ class BatchedVectorEnvRunner:
         self._started = False
         self.A = actor_critic.num_action_params
         self.ld = actor_critic.heads_ld
-        if self.env_info.action_space.__class__.__name__ != "Discrete" and not hasattr(self.env_info.action_space, "n"):
-            raise NotImplementedError("native sampler: Discrete action spaces only in this round")
+        self.continuous = not hasattr(self.env_info.action_space, "n")  # Box(D): params = [means | log_std]
 
     def reset(self) -> None:
         """First observation into slab obs[:, 0] (batched_sampling.py:172-206)."""
@@ -70,11 +69,13 @@ class BatchedVectorEnvRunner:
             heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf")[-1]
             lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
                                   self.global_step, 0, ver, deterministic, tr["actions"], tr["action_logits"],
-                                  tr["log_prob_actions"], tr["values"], tr["policy_version"], self.env_actions)
+                                  tr["log_prob_actions"], tr["values"], tr["policy_version"],
+                                  None if self.continuous else self.env_actions, action_kind=int(self.continuous))
+            env_actions = tr["actions"][:, t] if self.continuous else self.env_actions  # Box: f32 [B, D] view
             if self.zero_copy:
-                rew, term, trunc = self.env.step_into(self.env_actions, self.obs[:, t + 1])
+                rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])
             else:
-                o, rew, term, trunc, _ = self.env.step(self.env_actions)
+                o, rew, term, trunc, _ = self.env.step(env_actions)
                 self.obs[:, t + 1].copy_(torch.as_tensor(o["obs"] if isinstance(o, dict) else o, device=self.device))
                 rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
                 term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()

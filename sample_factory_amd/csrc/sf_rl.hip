@@ -786,13 +786,37 @@ template <int MAXA>
 __global__ __launch_bounds__(256) void k_sample_write(const float *__restrict__ logits, int ldl,
                                                       const float *__restrict__ values, int ldv, int B, int A, int T, int t,
                                                       uint32_t seed, uint32_t step, uint32_t row0, float version,
-                                                      int deterministic, float *__restrict__ t_actions,
+                                                      int deterministic, int action_kind,
+                                                      float *__restrict__ t_actions,
                                                       float *__restrict__ t_logits, float *__restrict__ t_logp,
                                                       float *__restrict__ t_values, float *__restrict__ t_version,
                                                       int32_t *__restrict__ env_actions) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float *z = logits + (int64_t)b * ldl;
+    if (action_kind == 1) {  // Box(D): params = [means | log_std]; a = mu + sd*eps, eps from Box-Muller on Philox
+        const int D = A / 2;
+        const int64_t it = (int64_t)b * T + t;
+        float lp = 0.f;
+        for (int k = 0; k < D; ++k) {
+            uint32_t w[4];
+            sf_philox4x32_10(step, (uint32_t)(k >> 1), 3u, 0u, seed, row0 + (uint32_t)b, w);
+            const uint32_t w1 = (k & 1) ? w[2] : w[0], w2 = (k & 1) ? w[3] : w[1];
+            const float u1 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float u2 = (float)(w2 >> 8) * (1.0f / 16777216.0f);
+            const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+            const float mu = z[k];
+            const float sd = clampf(expf(z[D + k]), 1e-4f, 1e4f);
+            const float a = deterministic ? mu : mu + sd * eps;  // argmax_actions: the mean (action_distributions.py:78-79)
+            t_actions[it * D + k] = a;
+            lp += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+        }
+        for (int k = 0; k < A; ++k) t_logits[it * A + k] = z[k];
+        t_logp[it] = lp;
+        t_version[it] = version;
+        t_values[(int64_t)b * (T + 1) + t] = values[(int64_t)b * ldv];
+        return;
+    }
     float zz[MAXA];
     float mx = -INFINITY;
 #pragma unroll
@@ -829,23 +853,24 @@ __global__ __launch_bounds__(256) void k_sample_write(const float *__restrict__ 
     t_values[(int64_t)b * (T + 1) + t] = values[(int64_t)b * ldv];
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) if (k < A) t_logits[it * A + k] = zz[k];
-    env_actions[b] = a;
+    if (env_actions) env_actions[b] = a;
 }
 
 extern "C" int sf_sample_write_step(const float *logits, int ld_logits, const float *values, int ld_values, int B,
                                     int A, int T, int t, uint32_t seed, uint32_t step, uint32_t row0, float policy_version,
-                                    int deterministic, float *traj_actions, float *traj_logits, float *traj_logp,
+                                    int deterministic, int action_kind, float *traj_actions, float *traj_logits, float *traj_logp,
                                     float *traj_values, float *traj_policy_version, int32_t *env_actions,
                                     void *stream) {
-    SF_REQUIRE(logits && values && traj_actions && traj_logits && traj_logp && traj_values && traj_policy_version &&
-                   env_actions,
+    SF_REQUIRE(logits && values && traj_actions && traj_logits && traj_logp && traj_values && traj_policy_version,
                "sf_sample_write_step: null pointer");
+    SF_REQUIRE(action_kind == 1 || env_actions, "sf_sample_write_step: discrete actions need the int32 env_actions");
+    SF_REQUIRE(action_kind == 0 || (action_kind == 1 && A % 2 == 0), "sf_sample_write_step: bad action_kind");
     SF_REQUIRE(B > 0 && A > 0 && A <= 128 && T > 0 && t >= 0 && t < T, "sf_sample_write_step: bad shape B=%d A=%d T=%d t=%d",
                B, A, T, t);
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
 #define SW_LAUNCH(M)                                                                                               \
     k_sample_write<M><<<grid, block, 0, STREAM(stream)>>>(logits, ld_logits, values, ld_values, B, A, T, t, seed, step, row0,            \
-                                                          policy_version, deterministic, traj_actions, traj_logits, \
+                                                          policy_version, deterministic, action_kind, traj_actions, traj_logits, \
                                                           traj_logp, traj_values, traj_policy_version, env_actions)
     if (A <= 8) SW_LAUNCH(8);
     else if (A <= 32) SW_LAUNCH(32);

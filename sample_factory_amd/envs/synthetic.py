@@ -67,6 +67,41 @@ class SyntheticVecEnv:
         pass
 
 
+class SyntheticContinuousEnv:
+    """Ant-shaped device-resident env (SURVEY.md §8d C5 stand-in): f32 vector observations, Box actions.  Plain
+    gymnasium-style interface only (no zero-copy hook) — exercises the runner's generic GPU-env path.  Dynamics:
+    obs' = 0.9*obs + 0.1*noise, reward = -mean(action^2) + 0.1*obs[:,0], termination ~ Bernoulli(1/256)."""
+
+    def __init__(self, num_agents=2048, obs_dim=27, act_dim=8, seed=0, device="cuda"):
+        self.num_agents, self.obs_dim, self.act_dim = int(num_agents), int(obs_dim), int(act_dim)
+        self.observation_space = spaces.Dict({"obs": spaces.Box(-np.inf, np.inf, (obs_dim,), np.float32)})
+        self.action_space = spaces.Box(-1.0, 1.0, (act_dim,), np.float32)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self.obs = torch.zeros((self.num_agents, obs_dim), dtype=torch.float32, device=self.device)
+
+    def reset(self, **kwargs):
+        self.obs = torch.randn(self.obs.shape, generator=self.gen, device=self.device)
+        return {"obs": self.obs}, {}
+
+    def step(self, actions):
+        a = torch.as_tensor(actions, device=self.device, dtype=torch.float32).reshape(self.num_agents, self.act_dim)
+        noise = torch.randn(self.obs.shape, generator=self.gen, device=self.device)
+        rew = -(a * a).mean(dim=1) + 0.1 * self.obs[:, 0]
+        term = torch.rand(self.num_agents, generator=self.gen, device=self.device) < (1.0 / 256.0)
+        self.obs = torch.where(term[:, None], noise, 0.9 * self.obs + 0.1 * noise)  # auto-reset is the env's job
+        return {"obs": self.obs}, rew, term, torch.zeros_like(term), {}
+
+    def close(self):
+        pass
+
+
+def make_synthetic_continuous_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    n = getattr(cfg, "synthetic_num_agents", 2048) if cfg is not None else 2048
+    return SyntheticContinuousEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0)
+
+
 def make_synthetic_env(full_env_name, cfg=None, env_config=None, render_mode=None):
     n = getattr(cfg, "synthetic_num_agents", 4096) if cfg is not None else 4096
     seed = (getattr(cfg, "seed", None) or 0) if cfg is not None else 0

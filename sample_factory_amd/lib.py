@@ -220,11 +220,13 @@ def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, max_grad_norm, sumsq, gra
 
 
 def sample_write_step(logits, ld_logits, values, ld_values, B, A, T, t, seed, step, row0, policy_version, deterministic,
-                      traj_actions, traj_logits, traj_logp, traj_values, traj_policy_version, env_actions) -> None:
+                      traj_actions, traj_logits, traj_logp, traj_values, traj_policy_version, env_actions,
+                      action_kind=0) -> None:
     _check(load().sf_sample_write_step(_raw(logits, "f32", "logits"), int(ld_logits), _raw(values, "f32", "values"),
                                        int(ld_values), int(B), int(A), int(T),
                                        int(t), u32(seed), u32(step), u32(row0), f(policy_version),
-                                       int(bool(deterministic)), ptr(traj_actions, "f32"), ptr(traj_logits, "f32"),
+                                       int(bool(deterministic)), int(action_kind), ptr(traj_actions, "f32"),
+                                       ptr(traj_logits, "f32"),
                                        ptr(traj_logp, "f32"), ptr(traj_values, "f32"),
                                        ptr(traj_policy_version, "f32"), ptr(env_actions, "i32"), stream()),
            "sf_sample_write_step")

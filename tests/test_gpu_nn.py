@@ -306,6 +306,106 @@ def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
         np.testing.assert_allclose(after[pname].reshape(-1).numpy(), g["after_" + pname], rtol=0, atol=2e-5, err_msg=pname)
 
 
+def _kv(argv):
+    return {t[2:].split("=", 1)[0]: t[2:].split("=", 1)[1] for t in str(argv).split() if t.startswith("--") and "=" in t}
+
+
+@pytest.mark.parametrize("case", ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous", "ff_vtrace"])
+def test_learner_prepare_batch_and_losses_match_reference(lib, golden, tmp_path, case):
+    """The native Learner's _prepare_batch + _calculate_losses (network forward included) replayed on the reference's
+    golden batches: discrete / invalid+stale samples + KL loss / value bootstrap + symmetric-KL / Box actions / V-trace."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    g = golden("learner_" + case)
+    kv = _kv(g["argv"])
+    E, T = g["in_rewards"].shape
+    continuous = case == "ff_continuous"
+    A = g["in_action_logits"].shape[-1]
+    action_space = spaces.Box(-1, 1, (A // 2,), np.float32) if continuous else spaces.Discrete(A)
+    over = dict(exploration_loss=kv.get("exploration_loss", "entropy"),
+                exploration_loss_coeff=float(kv.get("exploration_loss_coeff", 0.003)),
+                kl_loss_coeff=float(kv.get("kl_loss_coeff", 0.0)), max_policy_lag=int(kv.get("max_policy_lag", 1000)),
+                normalize_returns=kv.get("normalize_returns", "True") == "True",
+                value_bootstrap=kv.get("value_bootstrap", "False") == "True",
+                with_vtrace=kv.get("with_vtrace", "False") == "True", recurrence=int(kv.get("recurrence", 1)),
+                vtrace_rho=float(kv.get("vtrace_rho", 1.0)), vtrace_c=float(kv.get("vtrace_c", 1.0)))
+    cfg = default_cfg(use_rnn=False, nonlinearity="tanh", normalize_input=False, encoder_mlp_layers=[32, 32], rollout=T,
+                      batch_size=E * T // 2, num_batches_per_epoch=2, num_epochs=1, seed=0, serial_mode=True,
+                      train_dir=str(tmp_path), experiment="t", **over)
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    env_info = EnvInfo(obs_space, action_space, E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    ac = learner.actor_critic
+    names = [n for n, _ in ac.ref_param_shapes()]
+    st = seeded_state(ac.ref_param_shapes(), int(g["param_seed"]))
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=False)
+    assert sum(int(np.prod(s)) for _, s in ac.ref_param_shapes()) == int(g["num_params"])
+    learner.train_step = int(g["train_step"])
+    if cfg.normalize_returns:
+        ac.returns_normalizer.stats.copy_(torch.as_tensor(g["in_rms"]))
+    batch = alloc_trajectory_tensors(env_info, E, T, 1, "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    buff, size, num_invalids = learner._prepare_batch(batch)
+    assert size == int(g["pb_size"]) and num_invalids == int(g["pb_num_invalids"])
+    np.testing.assert_allclose(batch["values"][:, -1].cpu().numpy(), g["bootstrap_values"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_array_equal(buff.valids.cpu().numpy(), g["pb_valids"])
+    np.testing.assert_allclose(batch["rewards"].cpu().numpy(), g["out_rewards"], atol=2e-6)
+    if not cfg.with_vtrace:
+        np.testing.assert_allclose(buff.advantages.cpu().numpy(), g["pb_advantages"], atol=1e-5)   # north star: 1e-4
+        np.testing.assert_allclose(buff.returns.cpu().numpy(), g["pb_returns"], atol=1e-5)
+    if cfg.normalize_returns:
+        np.testing.assert_allclose(ac.returns_normalizer.stats.cpu().numpy(), g["out_rms"], rtol=1e-6)
+    mb = int(g["mb_size"])
+    acts, g_heads, sc = learner._calculate_losses(buff, (None, 0, mb), num_invalids)
+    sc = sc.cpu().numpy()
+    heads = acts[-1].cpu().numpy()
+    np.testing.assert_allclose(heads[:, 1:1 + A], g["l_params"], atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(heads[:, 0], g["l_values"], atol=3e-6, rtol=1e-5)
+    for i, k in enumerate(["policy_loss", "exploration_loss", "kl_loss", "value_loss"]):
+        ref = float(g["l_" + k])
+        assert abs(sc[i] - ref) < 3e-6 + 2e-5 * abs(ref), (k, sc[i], ref)
+    assert abs(sc[6] - float(g["l_adv_mean"])) < 2e-6 and abs(sc[7] - float(g["l_adv_std"])) < 3e-6
+    gh = g_heads.cpu().numpy()
+    np.testing.assert_allclose(gh[:, 1:1 + A], g["l_grad_params"], atol=3e-7, rtol=3e-4)
+    np.testing.assert_allclose(gh[:, 0], g["l_grad_values"], atol=3e-7, rtol=3e-4)
+    assert np.all(gh[:, 1 + A:] == 0)
+
+
+def test_continuous_env_rollout_and_vtrace_training(lib):
+    """Box actions end to end: generic (non zero-copy) GPU env -> Normal sampler -> slab -> V-trace learner."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+    for vtrace in (False, True):
+        cfg = default_cfg(env="synthetic_ant", use_rnn=False, nonlinearity="tanh", normalize_input=False,
+                          encoder_mlp_layers=[64, 64], rollout=8, recurrence=8 if vtrace else 1, batch_size=512,
+                          num_batches_per_epoch=2, num_epochs=2, num_workers=1, num_envs_per_worker=1, async_rl=False,
+                          seed=2, serial_mode=True, synthetic_num_agents=128, kl_loss_coeff=0.1, with_vtrace=vtrace,
+                          normalize_returns=not vtrace, shuffle_minibatches=not vtrace)
+        cfg, runner = make_runner(cfg)
+        runner.init()
+        p0 = runner.learner.actor_critic.flat_params.clone()
+        for _ in range(2):
+            stats = runner.iteration()
+        torch.cuda.synchronize()
+        tr = runner.traj
+        assert stats["learner_env_steps"] == 2 * 128 * 8 and tr["actions"].shape == (128, 8, 8)
+        assert torch.isfinite(tr["actions"]).all() and torch.isfinite(tr["log_prob_actions"]).all()
+        assert torch.isfinite(runner.learner.actor_critic.flat_params).all()
+        assert not torch.equal(p0, runner.learner.actor_critic.flat_params)
+        assert np.isfinite(stats["train"]["loss"]) and stats["train"]["kl_divergence"] >= -1e-6
+
+
 @pytest.mark.parametrize("act,kind", [("tanh", 2), ("elu", 3)])
 def test_activation_kinds_fwd_bwd(lib, act, kind):
     M, K, N = 300, 64, 96

@@ -371,6 +371,28 @@ def test_sample_write_step_vs_oracle(lib, B, A):
     np.testing.assert_array_equal(env_a.cpu().numpy(), logits.argmax(1).astype(np.int32))
 
 
+def test_sample_continuous_vs_oracle(lib):
+    rng = np.random.default_rng(3)
+    B, D, T, t = 1000, 8, 4, 1
+    A = 2 * D
+    params = (rng.standard_normal((B, A)) * 0.7).astype(np.float32)
+    values = rng.standard_normal(B).astype(np.float32)
+    heads = dev(np.concatenate([values[:, None], params, np.zeros((B, 3), np.float32)], 1))   # ld = 20
+    ld = heads.shape[1]
+    z = lambda *s: torch.zeros(s, device="cuda")
+    ta, tl, tp, tv, tver = z(B, T, D), z(B, T, A), z(B, T), z(B, T + 1), z(B, T)
+    lib.sample_write_step(heads[:, 1:], ld, heads[:, 0], ld, B, A, T, t, 5, 9, 100, 3.0, False, ta, tl, tp, tv, tver,
+                          None, action_kind=1)
+    a_ref, lp_ref = oracle.sample_normal(params, 5, 9, row0=100)
+    np.testing.assert_allclose(ta[:, t].cpu().numpy(), a_ref, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(tp[:, t].cpu().numpy(), lp_ref, atol=2e-4, rtol=1e-5)
+    np.testing.assert_array_equal(tl[:, t].cpu().numpy(), params)
+    np.testing.assert_array_equal(tv[:, t].cpu().numpy(), values)
+    lib.sample_write_step(heads[:, 1:], ld, heads[:, 0], ld, B, A, T, t, 5, 9, 100, 3.0, True, ta, tl, tp, tv, tver,
+                          None, action_kind=1)
+    np.testing.assert_array_equal(ta[:, t].cpu().numpy(), params[:, :D])      # deterministic: the mean
+
+
 def test_sampler_distribution(lib):
     """sampling parity is distributional (torch.multinomial's stream cannot be reproduced): chi-square-ish check"""
     B, A, T = 200000, 6, 1
