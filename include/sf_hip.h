@@ -61,6 +61,24 @@ int sf_moments(const float *x, const uint8_t *valids, const int32_t *index, int6
 int sf_rms_update(const double *stats_in, const double *moments, double *stats_out, void *stream);
 int sf_rms_apply(float *x, int64_t n, const double *stats, int denormalize, void *stream);
 
+/* ---- K2/K8 (normalize_input=True): observation running mean/std ------------------------------------------------
+ * utils/normalize.py:24-70 (ObservationNormalizer), running_mean_std.py:22-136 (RunningMeanStdDictInPlace, full-shape
+ * statistics).  x' = (float(x) - obs_subtract_mean) * (1/obs_scale).  Sample addressing as in the network kernels
+ * (index | offset, traj_T slab mapping, `stride` elements between rows).  D = elements per observation.
+ * sf_obsnorm_moments: per-element {sum, sumsq}[D] of x' over n samples (f64, zeroed by the call).
+ * sf_obsnorm_update:  Chan merge into mean/var[D] (in place) and count (count_in -> count_out), refreshes the f32
+ *                     tables mu[D], rstd[D] = 1/sqrt(var+1e-5) (n == 0: tables only, e.g. after loading a checkpoint).
+ * sf_obsnorm_apply:   out f32 [n, D] = clamp((x' - mu) * rstd, +-5); for images (C > 0) written channels-last
+ *                     ([n, H*W, C]) for the NHWC conv kernels.  The north-star preset (normalize_input=False) never
+ *                     runs these: there the u8 frames are consumed in place by sf_conv_fwd. */
+int sf_obsnorm_moments(const void *in, int in_u8, int64_t stride, const int32_t *index, int64_t offset, int traj_T,
+                       int64_t n, int D, float sub_mean, float inv_scale, double *sum, double *sumsq, void *stream);
+int sf_obsnorm_update(double *mean, double *var, const double *count_in, double *count_out, const double *sum,
+                      const double *sumsq, int64_t n, int D, float *mu_tab, float *rstd_tab, void *stream);
+int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const int32_t *index, int64_t offset, int traj_T,
+                     int64_t n, int D, int C, int HW, float sub_mean, float inv_scale, const float *mu,
+                     const float *rstd, float *out, void *stream);
+
 /* ---- K17: V-trace -----------------------------------------------------------------------------------------
  * learner.py:601-640 (the reference runs this loop on the CPU).  Flat minibatch of n samples made of
  * n/recurrence trajectories; sample i of the minibatch is dataset row (index ? index[i] : offset+i).

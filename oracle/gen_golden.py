@@ -351,6 +351,19 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
     arrays["param_shapes"] = np.array([str(s) for _, s in shapes])
     rn = learner.actor_critic.returns_normalizer
     arrays["out_rms"] = np.array([rn.running_mean.item(), rn.running_var.item(), rn.count.item()])
+    if cfg.normalize_input:  # obs normaliser state + an eval-mode forward with the post-training weights and statistics
+        on = learner.actor_critic.obs_normalizer.running_mean_std.running_mean_std["obs"]
+        arrays["obsn_mean"] = on.running_mean.numpy().reshape(-1)[::subsample].copy()
+        arrays["obsn_var"] = on.running_var.numpy().reshape(-1)[::subsample].copy()
+        arrays["obsn_count"] = float(on.count.item())
+        ac = learner.actor_critic
+        ac.eval()
+        with torch.no_grad():
+            o = {k: v[:, 0].clone() for k, v in b["obs"].items()}
+            nobs = ac.normalize_obs(o)
+            res = ac.forward_tail(ac.forward_head(nobs), values_only=False, sample_actions=False)
+        arrays["eval_logits"] = res["action_logits"].numpy().copy()
+        arrays["eval_values"] = res["values"].numpy().copy()
     save("train_" + name, **arrays)
 
 
@@ -413,6 +426,12 @@ def main():
                                      "--obs_scale=255.0", "--normalize_input=False",
                                      "--encoder_conv_mlp_layers", "128"],
                   E=8, T=4, A=6, nb=2, epochs=1, subsample=7)
+        gen_train("cnn36_norm", cnn_obs, ["--encoder_conv_architecture=convnet_atari", "--nonlinearity=relu",
+                                          "--obs_scale=255.0", "--normalize_input=True",
+                                          "--encoder_conv_mlp_layers", "128"],
+                  E=8, T=4, A=6, nb=2, epochs=1, subsample=7)
+        gen_train("mlp_norm", MLP_OBS, ["--encoder_mlp_layers", "32", "32", "--nonlinearity=elu",
+                                        "--normalize_input=True"], E=16, T=8, A=6, nb=2, epochs=1)
     if "model" in which:
         gen_model_fwd()
     if "cfg" in which:

@@ -177,6 +177,7 @@ class Learner:
         lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device())
         ar = self._all_reduce if self.world > 1 else None
+        cfg.dp_world = self.world
         self.actor_critic = ActorCritic(cfg, self.env_info.obs_space, self.env_info.action_space, self.device,
                                         all_reduce=ar)
         self.actor_critic.train()
@@ -298,6 +299,8 @@ class Learner:
                        cfg.max_policy_lag, self._num_invalid)
         if not ac.training:
             ac.train()
+        if ac.obs_normalizer is not None:  # learner.py:957-961: statistics updated once per dataset, over all T+1 columns
+            ac.obs_normalizer.update(obs, ac.obs_elems, E * (T + 1))
         # K9: bootstrap value of the T+1-th observation, read from the slab in place
         last = obs[:, T]
         heads = ac.forward_heads(last, E, sample_stride=obs.stride(0), tag="inf")[-1]

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
                                                   const int32_t *__restrict__ index, int64_t offset,
                                                   const float *__restrict__ w, const float *__restrict__ bias,
                                                   float *__restrict__ out, int64_t Mtot, int k_per_split,
-                                                  float *__restrict__ partial) {
+                                                  float *__restrict__ partial, int dbg) {
     using T = Tile<BM, BN, WM, WN>;
     constexpr bool U8 = MODE == MODE_U8;
     constexpr bool VECB = MODE != MODE_GENERIC;
@@ -371,10 +371,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
         }
     } else {
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            __syncthreads();
-            lstore(As_[0], Bs_[0]);
-            __syncthreads();
-            if (k0 + 32 < kend) gload(k0 + 32);
+            // dbg: ablation switches for tools/kbench.py (SF_NN_DBG; results are WRONG when set) — 1: no global
+            // prefetch after the first chunk, 2: no LDS store after the first chunk, 4: no barriers
+            if (!(dbg & 4)) __syncthreads();
+            if (!(dbg & 2) || k0 == kbeg) lstore(As_[0], Bs_[0]);
+            if (!(dbg & 4)) __syncthreads();
+            if (k0 + 32 < kend && !(dbg & 1)) gload(k0 + 32);
             mma_chunk<T::TM, T::TN, LDA, LDB>(As_[0], Bs_[0], wm * T::TM * 32, wn * T::TN * 32, lane, acc);
         }
     }
@@ -681,6 +683,10 @@ static bool sf_tune_db() {
     return v;
 }
 
+static int sf_tune_dbg() {  // SF_NN_DBG: ablation bits for the forward kernel (tools/kbench.py only; wrong results)
+    static const int v = [] { const char *e = getenv("SF_NN_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
 static int sf_tune_bm() {  // SF_NN_BM=256 -> 256-row tiles for the large-M forward / dgrad launches (A/B experiment)
     static const int v = [] { const char *e = getenv("SF_NN_BM"); return e ? atoi(e) : 128; }();
     return v;
@@ -730,10 +736,10 @@ extern "C" int64_t sf_conv_fwd_workspace(int64_t n, const sf_conv_desc *h_desc) 
     do {                                                                                                           \
         if (sf_tune_db())                                                                                          \
             k_conv_fwd<BM, BN, WM, WN, MODE, true><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
-                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial);               \
+                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial, sf_tune_dbg()); \
         else                                                                                                       \
             k_conv_fwd<BM, BN, WM, WN, MODE, false><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
-                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial);               \
+                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial, sf_tune_dbg()); \
     } while (0)
 #define FWD_BY_MODE(BM, BN, WM, WN)                                    \
     do {                                                               \

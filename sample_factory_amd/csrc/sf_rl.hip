@@ -973,3 +973,126 @@ extern "C" int sf_synth_step(const int32_t *actions, int B, int env0, int num_ac
                                                                                       seed, step, rewards, terminated);
     return sf_launch_status("sf_synth_step");
 }
+
+// =========================================================================================== observation normaliser
+// utils/normalize.py:24-70 (ObservationNormalizer) + running_mean_std.py:22-136 (RunningMeanStd(Dict)InPlace with
+// full-shape statistics): x' = (float(x) - obs_subtract_mean) * (1/obs_scale); per-element running mean/var/count
+// (f64, Chan merge); normalised = clamp((x' - mu) * (1/sqrt(var + 1e-5)), +-5).
+// Sample addressing is the same as the network kernels': logical sample i -> row (index ? index[i] : offset + i),
+// optionally mapped dataset->slab (e*T+t -> e*(T+1)+t), times `stride` elements.
+__device__ __forceinline__ int64_t on_row(const int32_t *__restrict__ index, int64_t offset, int traj_T, int64_t i) {
+    int64_t d = index ? (int64_t)index[i] : offset + i;
+    if (traj_T > 0) d += d / traj_T;
+    return d;
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void k_obsnorm_moments(const void *__restrict__ in, int64_t stride,
+                                                         const int32_t *__restrict__ index, int64_t offset, int traj_T,
+                                                         int64_t n, int D, float sub_mean, float inv_scale,
+                                                         double *__restrict__ sum, double *__restrict__ sumsq) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const int64_t per = (n + gridDim.y - 1) / gridDim.y;
+    const int64_t beg = (int64_t)blockIdx.y * per, end = (beg + per < n) ? beg + per : n;
+    double s = 0.0, ss = 0.0;
+    for (int64_t i = beg; i < end; ++i) {
+        const int64_t row = on_row(index, offset, traj_T, i);
+        const float raw = U8 ? (float)reinterpret_cast<const uint8_t *>(in)[row * stride + d]
+                             : reinterpret_cast<const float *>(in)[row * stride + d];
+        const double x = (double)((raw - sub_mean) * inv_scale);
+        s += x;
+        ss += x * x;
+    }
+    atomicAdd(&sum[d], s);
+    atomicAdd(&sumsq[d], ss);
+}
+
+extern "C" int sf_obsnorm_moments(const void *in, int in_u8, int64_t stride, const int32_t *index, int64_t offset,
+                                  int traj_T, int64_t n, int D, float sub_mean, float inv_scale, double *sum,
+                                  double *sumsq, void *stream) {
+    SF_REQUIRE(in && sum && sumsq && n > 0 && D > 0, "sf_obsnorm_moments: bad args");
+    int rc = sf_hip_status(hipMemsetAsync(sum, 0, sizeof(double) * D, STREAM(stream)), "sf_obsnorm_moments memset");
+    if (!rc) rc = sf_hip_status(hipMemsetAsync(sumsq, 0, sizeof(double) * D, STREAM(stream)), "sf_obsnorm_moments memset");
+    if (rc) return rc;
+    const unsigned bx = (unsigned)((D + 255) / 256);
+    unsigned by = (unsigned)(4096 / bx);
+    if (by < 1) by = 1;
+    if ((int64_t)by > n) by = (unsigned)n;
+    if (in_u8) k_obsnorm_moments<true><<<dim3(bx, by), dim3(256), 0, STREAM(stream)>>>(in, stride, index, offset, traj_T, n, D, sub_mean, inv_scale, sum, sumsq);
+    else k_obsnorm_moments<false><<<dim3(bx, by), dim3(256), 0, STREAM(stream)>>>(in, stride, index, offset, traj_T, n, D, sub_mean, inv_scale, sum, sumsq);
+    return sf_launch_status("sf_obsnorm_moments");
+}
+
+// stats: mean[D], var[D] (f64), count[1] (f64); batch moments {sum, sumsq}[D] over n samples -> merged stats (in
+// place; count advanced by the launch with blockIdx 0) and the derived f32 tables mu[D], rstd[D] the apply kernel uses.
+__global__ __launch_bounds__(256) void k_obsnorm_update(double *__restrict__ mean, double *__restrict__ var,
+                                                        const double *__restrict__ count_in,
+                                                        double *__restrict__ count_out, const double *__restrict__ sum,
+                                                        const double *__restrict__ sumsq, double n, int D,
+                                                        float *__restrict__ mu_tab, float *__restrict__ rstd_tab) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const double count = count_in[0];
+    if (d < D) {
+        double m = mean[d], v = var[d];
+        if (n > 0.0) {
+            const double bm64 = sum[d] / n;
+            const double bv64 = (sumsq[d] - sum[d] * bm64) / (n - 1.0);
+            const double bm = (double)(float)bm64, bv = (double)(float)bv64;  // x.mean(0), x.var(0) are f32 tensors
+            const double delta = bm - m, tot = count + n;
+            const double M2 = v * count + bv * n + (delta * delta) * count * n / tot;
+            m = m + delta * n / tot;
+            v = M2 / tot;
+            mean[d] = m;
+            var[d] = v;
+        }
+        mu_tab[d] = (float)m;
+        rstd_tab[d] = 1.0f / sqrtf((float)v + 1e-5f);
+    }
+    if (d == 0) count_out[0] = count + n;
+}
+
+extern "C" int sf_obsnorm_update(double *mean, double *var, const double *count_in, double *count_out,
+                                 const double *sum, const double *sumsq, int64_t n, int D, float *mu_tab,
+                                 float *rstd_tab, void *stream) {
+    SF_REQUIRE(mean && var && count_in && count_out && mu_tab && rstd_tab && D > 0 && n >= 0 && (n == 0 || (sum && sumsq)),
+               "sf_obsnorm_update: bad args");
+    SF_REQUIRE(count_in != count_out, "sf_obsnorm_update: count_in and count_out must be different buffers");
+    k_obsnorm_update<<<dim3((unsigned)((D + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        mean, var, count_in, count_out, sum, sumsq, (double)n, D, mu_tab, rstd_tab);
+    return sf_launch_status("sf_obsnorm_update");
+}
+
+// out[i][pos] = clamp(((x - sub_mean)*inv_scale - mu[d]) * rstd[d], +-5); images (C,H,W given, C>0): d = c*HW + p is
+// written channels-last at pos = p*C + c (the layout the conv kernels read); vectors (C == 0): pos = d.
+template <bool U8>
+__global__ __launch_bounds__(256) void k_obsnorm_apply(const void *__restrict__ in, int64_t stride,
+                                                       const int32_t *__restrict__ index, int64_t offset, int traj_T,
+                                                       int64_t n, int D, int C, int HW, float sub_mean,
+                                                       float inv_scale, const float *__restrict__ mu,
+                                                       const float *__restrict__ rstd, float *__restrict__ out) {
+    const int64_t total = n * D;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = g / D;
+        const int pos = (int)(g - i * D);
+        int d = pos;
+        if (C > 0) { const int p = pos / C, c = pos - p * C; d = c * HW + p; }
+        const int64_t row = on_row(index, offset, traj_T, i);
+        const float raw = U8 ? (float)reinterpret_cast<const uint8_t *>(in)[row * stride + d]
+                             : reinterpret_cast<const float *>(in)[row * stride + d];
+        const float x = (raw - sub_mean) * inv_scale;
+        out[g] = clampf((x - mu[d]) * rstd[d], -5.0f, 5.0f);
+    }
+}
+
+extern "C" int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const int32_t *index, int64_t offset,
+                                int traj_T, int64_t n, int D, int C, int HW, float sub_mean, float inv_scale,
+                                const float *mu, const float *rstd, float *out, void *stream) {
+    SF_REQUIRE(in && mu && rstd && out && n > 0 && D > 0, "sf_obsnorm_apply: bad args");
+    SF_REQUIRE(C == 0 || C * HW == D, "sf_obsnorm_apply: C*HW != D");
+    const int64_t blocks = (n * D + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    if (in_u8) k_obsnorm_apply<true><<<dim3(grid), dim3(256), 0, STREAM(stream)>>>(in, stride, index, offset, traj_T, n, D, C, HW, sub_mean, inv_scale, mu, rstd, out);
+    else k_obsnorm_apply<false><<<dim3(grid), dim3(256), 0, STREAM(stream)>>>(in, stride, index, offset, traj_T, n, D, C, HW, sub_mean, inv_scale, mu, rstd, out);
+    return sf_launch_status("sf_obsnorm_apply");
+}

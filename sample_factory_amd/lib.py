@@ -37,7 +37,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
-    "sf_adam_step", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
+    "sf_adam_step", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
     "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_linear_fwd",
     "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
@@ -173,6 +173,34 @@ def rms_update(stats_in, mom, stats_out) -> None:
 def rms_apply(x, stats, denormalize: bool) -> None:
     _check(load().sf_rms_apply(ptr(x, "f32", "x"), i64(x.numel()), ptr(stats, "f64"), int(bool(denormalize)),
                                stream()), "sf_rms_apply")
+
+
+def _raw_any(t: torch.Tensor, u8: bool, name: str) -> C.c_void_p:
+    want = torch.uint8 if u8 else torch.float32
+    if t.dtype != want:
+        raise SfHipError(f"{name}: expected {want}, got {t.dtype}")
+    if not t.is_cuda:
+        raise SfHipError(f"{name} lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def obsnorm_moments(inp, u8, stride, index, offset, traj_T, n, D, sub_mean, inv_scale, s, ss) -> None:
+    _check(load().sf_obsnorm_moments(_raw_any(inp, u8, "obs"), int(u8), i64(stride), ptr(index, "i32", "index"),
+                                     i64(offset), int(traj_T), i64(n), int(D), f(sub_mean), f(inv_scale),
+                                     ptr(s, "f64", "sum"), ptr(ss, "f64", "sumsq"), stream()), "sf_obsnorm_moments")
+
+
+def obsnorm_update(mean, var, count_in, count_out, s, ss, n, D, mu_tab, rstd_tab) -> None:
+    _check(load().sf_obsnorm_update(ptr(mean, "f64"), ptr(var, "f64"), ptr(count_in, "f64"), ptr(count_out, "f64"),
+                                    ptr(s, "f64"), ptr(ss, "f64"), i64(n), int(D), ptr(mu_tab, "f32"),
+                                    ptr(rstd_tab, "f32"), stream()), "sf_obsnorm_update")
+
+
+def obsnorm_apply(inp, u8, stride, index, offset, traj_T, n, D, C_, HW, sub_mean, inv_scale, mu, rstd, out) -> None:
+    _check(load().sf_obsnorm_apply(_raw_any(inp, u8, "obs"), int(u8), i64(stride), ptr(index, "i32", "index"),
+                                   i64(offset), int(traj_T), i64(n), int(D), int(C_), int(HW), f(sub_mean),
+                                   f(inv_scale), ptr(mu, "f32"), ptr(rstd, "f32"), ptr(out, "f32", "out"), stream()),
+           "sf_obsnorm_apply")
 
 
 def vtrace(params, ld_params, values, ld_values, actions, old_logp, rewards, dones, index, offset, n, A, action_kind,

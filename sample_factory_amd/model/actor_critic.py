@@ -111,9 +111,8 @@ class ActorCritic:
         if cfg.nonlinearity not in ACT_KIND:
             raise NotImplementedError(f"Unknown nonlinearity {cfg.nonlinearity}")
         act = ACT_KIND[cfg.nonlinearity]
-        if cfg.normalize_input:
-            raise NotImplementedError("normalize_input=True (per-pixel running mean/std) is not built yet; the "
-                                      "north-star preset uses obs_scale/obs_subtract_mean with normalize_input=False")
+        if cfg.normalize_input and cfg.normalize_input_keys not in (None, [], ["obs"]):
+            raise NotImplementedError("normalize_input_keys other than the 'obs' key")
         if not is_discrete(action_space) and not cfg.adaptive_stddev:
             raise NotImplementedError("non-adaptive stddev parameterisation not built yet")
         keys = sorted(obs_space.spaces.keys())
@@ -137,7 +136,7 @@ class ActorCritic:
             cin, h, w = C, H, W
             for i, (cout, k, s) in enumerate(CONV_ARCHS[cfg.encoder_conv_architecture]):
                 oh, ow = (h - k) // s + 1, (w - k) // s + 1
-                first = i == 0
+                first = i == 0 and not cfg.normalize_input  # normalised frames arrive as f32 NHWC (utils/normalize.py)
                 desc = lib.sf_conv_desc(Cin=cin, H=h, W=w, Cout=cout, KH=k, KW=k, stride=s, OH=oh, OW=ow,
                                         in_u8=int(first), relu=act, traj_T=0,
                                         sub_mean=sub_mean if first else 0.0, inv_scale=inv_scale if first else 1.0)
@@ -150,8 +149,9 @@ class ActorCritic:
                                           "linear_after_conv" if j == 0 else "linear", first_fc_chw=chw))
                 feat = size
         elif len(self.obs_shape) == 1:
-            if self.obs_u8 or sub_mean != 0.0 or inv_scale != 1.0:
-                raise NotImplementedError("vector observations must be f32 without obs_scale/obs_subtract_mean")
+            if self.obs_u8 or ((sub_mean != 0.0 or inv_scale != 1.0) and not cfg.normalize_input):
+                raise NotImplementedError("vector observations must be f32; obs_scale/obs_subtract_mean on vectors "
+                                          "need normalize_input=True")
             feat = self.obs_shape[0]
             for j, size in enumerate(cfg.encoder_mlp_layers):
                 self.layers.append(_Layer(f"encoder.encoders.obs.mlp_head.{2 * j}", _linear_desc(feat, size, act),
@@ -185,6 +185,12 @@ class ActorCritic:
             L.b = self.flat_params[ob:ob + L.N]
             L.gw = self.flat_grads[o:o + L.K * L.N].view(L.K, L.N)
             L.gb = self.flat_grads[ob:ob + L.N]
+        self.obs_normalizer = None
+        if cfg.normalize_input:
+            from sample_factory_amd.utils.normalize import ObservationNormalizer
+            self.obs_normalizer = ObservationNormalizer(cfg, self.obs_shape, self.obs_u8, self.device,
+                                                        all_reduce=all_reduce, world=getattr(cfg, "dp_world", 1))
+        self._xn: Dict = {}
         self.returns_normalizer: Optional[RunningMeanStdInPlace] = None
         if cfg.normalize_returns:
             self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
@@ -250,6 +256,8 @@ class ActorCritic:
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         sd = {}
+        if self.obs_normalizer is not None:
+            sd.update(self.obs_normalizer.state_dict())
         if self.returns_normalizer is not None:
             sd.update(self.returns_normalizer.state_dict("returns_normalizer."))
         for L in self.layers[:-1]:
@@ -276,6 +284,8 @@ class ActorCritic:
             H.b.copy_(torch.cat([torch.as_tensor(sd["critic_linear.bias"], dtype=torch.float32).reshape(1),
                                  torch.as_tensor(sd["action_parameterization.distribution_linear.bias"],
                                                  dtype=torch.float32).reshape(-1), torch.zeros(pad)]))
+            if self.obs_normalizer is not None and "obs_normalizer.running_mean_std.running_mean_std.obs.count" in sd:
+                self.obs_normalizer.load_state_dict(sd)
             if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
                 self.returns_normalizer.load_state_dict(sd, "returns_normalizer.")
             elif strict and self.returns_normalizer is not None:
@@ -327,6 +337,11 @@ class ActorCritic:
         """
         acts = []
         x = obs
+        if self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
+            xn = self._buf((tag, "obsn"), (n, self.obs_elems))
+            self.obs_normalizer.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T)
+            self._xn[tag] = xn
+            x, sample_stride, index, offset, traj_T = xn, self.obs_elems, None, 0, 0
         for li, L in enumerate(self.layers):
             out = self._buf((tag, li), (n * L.out_pixels, L.N))
             d = L.desc
@@ -359,6 +374,8 @@ class ActorCritic:
                  sample_stride: int, index=None, offset: int = 0, traj_T: int = 0) -> None:
         """Back-propagate d(loss)/d(heads) [n, 1+A] through the stack into self.flat_grads (overwritten)."""
         g = g_heads
+        if self.obs_normalizer is not None:  # the first layer's input is the normalised batch of the last forward
+            obs, sample_stride, index, offset, traj_T = self._xn["train"], self.obs_elems, None, 0, 0
         for li in range(len(self.layers) - 1, -1, -1):
             L = self.layers[li]
             d = L.desc

@@ -306,6 +306,62 @@ def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
         np.testing.assert_allclose(after[pname].reshape(-1).numpy(), g["after_" + pname], rtol=0, atol=2e-5, err_msg=pname)
 
 
+@pytest.mark.parametrize("name", ["cnn36_norm", "mlp_norm"])
+def test_learner_train_matches_reference_normalize_input(lib, golden, tmp_path, name):
+    """normalize_input=True (the reference's default): per-element running mean/std of the observations, updated once
+    per dataset in the learner and applied in both inference and training — vs the reference's Learner.train."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    g = golden("train_" + name)
+    E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
+    if name.startswith("cnn"):
+        over = dict(nonlinearity="relu", obs_scale=255.0, encoder_conv_architecture="convnet_atari", encoder_conv_mlp_layers=[128])
+        obs_space = spaces.Dict({"obs": spaces.Box(0, 255, (4, 36, 36), np.uint8)})
+    else:
+        over = dict(nonlinearity="elu", encoder_mlp_layers=[32, 32])
+        obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    cfg = default_cfg(use_rnn=False, recurrence=1, normalize_input=True, rollout=T, batch_size=E * T // nb,
+                      num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]), seed=0, serial_mode=True,
+                      train_dir=str(tmp_path), experiment="t", record_grad_norm=True, **over)
+    env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    ac = learner.actor_critic
+    load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
+    batch = alloc_trajectory_tensors(env_info, E, T, 1, "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    learner.train(batch)
+    sub = int(g["subsample"])
+    sd = ac.state_dict()
+    pfx = "obs_normalizer.running_mean_std.running_mean_std.obs."
+    assert sd[pfx + "running_mean"].shape == tuple(obs_space["obs"].shape) and sd[pfx + "running_mean"].dtype == torch.float64
+    np.testing.assert_allclose(sd[pfx + "running_mean"].reshape(-1)[::sub].numpy(), g["obsn_mean"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(sd[pfx + "running_var"].reshape(-1)[::sub].numpy(), g["obsn_var"], rtol=1e-5, atol=1e-7)
+    assert float(sd[pfx + "count"]) == float(g["obsn_count"])
+    np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=5e-4)
+    after, m = sd, ac.flat_to_ref(learner.exp_avg)
+    for pname in g["param_names"]:
+        np.testing.assert_allclose(m[pname].reshape(-1)[::sub].numpy(), g["m_" + pname], rtol=5e-3, atol=5e-8, err_msg=pname)
+        np.testing.assert_allclose(after[pname].reshape(-1)[::sub].numpy(), g["after_" + pname], rtol=0, atol=2e-5, err_msg=pname)
+    ac.eval()
+    res = ac.forward({"obs": batch["obs"]["obs"][:, 0].contiguous()}, None)
+    np.testing.assert_allclose(res["action_logits"].cpu().numpy(), g["eval_logits"], atol=2e-4, rtol=2e-3)
+    np.testing.assert_allclose(res["values"].cpu().numpy(), g["eval_values"], atol=2e-4, rtol=2e-3)
+    # checkpoint round trip carries the statistics
+    learner.save()
+    l2 = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    l2.init()
+    assert torch.equal(l2.actor_critic.obs_normalizer.mean, ac.obs_normalizer.mean)
+    assert torch.equal(l2.actor_critic.obs_normalizer.mu_tab, ac.obs_normalizer.mu_tab)
+
+
 def _kv(argv):
     return {t[2:].split("=", 1)[0]: t[2:].split("=", 1)[1] for t in str(argv).split() if t.startswith("--") and "=" in t}
 
