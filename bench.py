@@ -125,6 +125,13 @@ def main():
     ms = [s.elapsed_time(e) for s, e in evs]
     total_ms, launches, avg_ms = sum(ms), len(ms), sum(ms) / len(ms)
     achieved = kernel_flops(key) / (avg_ms * 1e-3) / 1e12
+    label = f"{key[0]}:{key[2]}x{key[3]}->{key[5]} n={key[1]}"
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "r01_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench
+    if os.path.exists(tj):
+        ent = json.load(open(tj)).get(label)
+        if ent:
+            traffic, traffic_src = ent["hbm_bytes"], "profiles/r01_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
     kern = []  # ranking of all network kernels from the instrumented warm-up step (NOT the timed region)
     for k2, evs2 in warm_prof.items():
         m2 = [s.elapsed_time(e) for s, e in evs2]
@@ -133,7 +140,8 @@ def main():
     roofline = {"bound": "mfma", "kernel": f"sf_conv_{key[0]} n={key[1]} Cin={key[2]} HxW={key[3]}x{key[4]} Cout={key[5]} "
                                            f"k={key[6]} s={key[7]}",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(avg_ms, 4),
                 "launches": launches, "share_of_step_time": round(total_ms / (dt * 1e3), 4)}
     net_ms = sum(k[0] for k in kern)
     net_flops = sum(kernel_flops(k[1]) * k[2] for k in kern)

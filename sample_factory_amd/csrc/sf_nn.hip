@@ -21,8 +21,6 @@
 // chunk back-to-back and waits once (the first version branched per load and hipcc serialised them with vmcnt(0)).
 #include "sf_common.h"
 
-#include <stdlib.h>
-
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -278,19 +276,18 @@ struct Tile {
 
 // ============================================================================================== FORWARD
 // rows m = (sample, oh, ow); A reduction-major loads (4 consecutive k per slot), B = weights free-axis-major.
-template <int BM, int BN, int WM, int WN, int MODE, bool DB>
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restrict__ in, int64_t in_stride,
                                                   const int32_t *__restrict__ index, int64_t offset,
                                                   const float *__restrict__ w, const float *__restrict__ bias,
                                                   float *__restrict__ out, int64_t Mtot, int k_per_split,
-                                                  float *__restrict__ partial, int dbg) {
+                                                  float *__restrict__ partial) {
     using T = Tile<BM, BN, WM, WN>;
     constexpr bool U8 = MODE == MODE_U8;
     constexpr bool VECB = MODE != MODE_GENERIC;
     constexpr int LDA = BM + 1, LDB = BN + 4;
-    constexpr int NBUF = DB ? 2 : 1;  // DB: two LDS images, ONE barrier per K-chunk (store of chunk i+1 overlaps compute i)
-    __shared__ __attribute__((aligned(16))) float As_[NBUF][32 * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs_[NBUF][32 * LDB];
+    __shared__ __attribute__((aligned(16))) float As[32 * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -343,7 +340,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
     // Rows >= Mtot and columns >= N only feed accumulator entries that are never stored, and the clamped addresses
     // read finite data, so with full K-chunks (every layer of the Nature CNN: K % 32 == 0) nothing needs masking.
     const bool kfull = ((kend - kbeg) & 31) == 0 && MODE != MODE_GENERIC;
-    auto lstore = [&](float *As, float *Bs) {
+    auto lstore = [&]() {
 #pragma unroll
         for (int s = 0; s < T::SA; ++s) {
             const float4 v = act_finish<MODE>(g, ra[s], kfull || (aok && aval[s]));
@@ -358,27 +355,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
                 kfull ? rb[s] : row_finish(rb[s], bok[s], n0 + bcg, N);
     };
     gload(kbeg);
-    if constexpr (DB) {
-        lstore(As_[0], Bs_[0]);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();  // every wave is done reading the previous chunk's LDS image
+        lstore();         // first use of the prefetched registers: the loads had the whole MFMA phase to land
         __syncthreads();
-        int buf = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += 32, buf ^= 1) {
-            const bool more = k0 + 32 < kend;
-            if (more) gload(k0 + 32);
-            mma_chunk<T::TM, T::TN, LDA, LDB>(As_[buf], Bs_[buf], wm * T::TM * 32, wn * T::TN * 32, lane, acc);
-            if (more) lstore(As_[buf ^ 1], Bs_[buf ^ 1]);
-            __syncthreads();
-        }
-    } else {
-        for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            // dbg: ablation switches for tools/kbench.py (SF_NN_DBG; results are WRONG when set) — 1: no global
-            // prefetch after the first chunk, 2: no LDS store after the first chunk, 4: no barriers
-            if (!(dbg & 4)) __syncthreads();
-            if (!(dbg & 2) || k0 == kbeg) lstore(As_[0], Bs_[0]);
-            if (!(dbg & 4)) __syncthreads();
-            if (k0 + 32 < kend && !(dbg & 1)) gload(k0 + 32);
-            mma_chunk<T::TM, T::TN, LDA, LDB>(As_[0], Bs_[0], wm * T::TM * 32, wn * T::TN * 32, lane, acc);
-        }
+        if (k0 + 32 < kend) gload(k0 + 32);
+        mma_chunk<T::TM, T::TN, LDA, LDB>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, lane, acc);
     }
     // epilogue: bias + ReLU, NHWC store (split-K: raw partial, finished by k_splitk_finish)
     float *dst = partial ? partial + (int64_t)blockIdx.z * Mtot * N : out;
@@ -675,23 +657,6 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-// tuning switch for A/B experiments (read once): SF_NN_DB=1 -> double-buffered LDS forward (one barrier per chunk).
-// Measured on MI355X (tools/kbench.py, round 1): 2-7 % SLOWER than single-buffer + register prefetch (fewer resident
-// blocks per CU outweigh the saved barrier), so it is off by default.
-static bool sf_tune_db() {
-    static const bool v = [] { const char *e = getenv("SF_NN_DB"); return e ? atoi(e) != 0 : false; }();
-    return v;
-}
-
-static int sf_tune_dbg() {  // SF_NN_DBG: ablation bits for the forward kernel (tools/kbench.py only; wrong results)
-    static const int v = [] { const char *e = getenv("SF_NN_DBG"); return e ? atoi(e) : 0; }();
-    return v;
-}
-static int sf_tune_bm() {  // SF_NN_BM=256 -> 256-row tiles for the large-M forward / dgrad launches (A/B experiment)
-    static const int v = [] { const char *e = getenv("SF_NN_BM"); return e ? atoi(e) : 128; }();
-    return v;
-}
-
 static int pick_mode(const ConvG &g) {
     if (!g.vecA || !g.vecB) return MODE_GENERIC;
     return g.in_u8 ? MODE_U8 : MODE_F32;
@@ -732,15 +697,9 @@ extern "C" int64_t sf_conv_fwd_workspace(int64_t n, const sf_conv_desc *h_desc) 
     return p.splits > 1 ? (int64_t)sizeof(float) * p.splits * Mtot * N + 256 : 0;
 }
 
-#define FWD_LAUNCH(BM, BN, WM, WN, MODE)                                                                           \
-    do {                                                                                                           \
-        if (sf_tune_db())                                                                                          \
-            k_conv_fwd<BM, BN, WM, WN, MODE, true><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
-                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial, sf_tune_dbg()); \
-        else                                                                                                       \
-            k_conv_fwd<BM, BN, WM, WN, MODE, false><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
-                g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial, sf_tune_dbg()); \
-    } while (0)
+#define FWD_LAUNCH(BM, BN, WM, WN, MODE)                                                                   \
+    k_conv_fwd<BM, BN, WM, WN, MODE><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), Z), dim3(256), 0, st>>>( \
+        g, in, in_sample_stride, index, offset, w, bias, out, Mtot, p.k_per_split, partial)
 #define FWD_BY_MODE(BM, BN, WM, WN)                                    \
     do {                                                               \
         if (mode == MODE_F32) FWD_LAUNCH(BM, BN, WM, WN, MODE_F32);    \
@@ -768,10 +727,10 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
     const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, workspace ? workspace_bytes / (int64_t)sizeof(float) : 0);
     float *partial = p.splits > 1 ? reinterpret_cast<float *>(workspace) : nullptr;
     const unsigned Z = (unsigned)p.splits;
-    const bool big = sf_tune_bm() == 256 && p.splits == 1 && Mtot >= 256 * 2048;
-    const bool big32 = p.splits == 1 && Mtot >= 256 * 2048;  // measured +5 % on conv1 (N=32): more MFMAs per barrier
+    // 256-row tiles: measured +5 % for N = 32 (conv1: twice the MFMAs per barrier), -3..-15 % for N = 64 (occupancy)
+    const bool big32 = p.splits == 1 && Mtot >= 256 * 2048;
     if (p.cfg == 0) { if (big32) FWD_BY_MODE(256, 32, 4, 1); else FWD_BY_MODE(128, 32, 4, 1); }
-    else if (p.cfg == 1) { if (big) FWD_BY_MODE(256, 64, 2, 2); else FWD_BY_MODE(128, 64, 2, 2); }
+    else if (p.cfg == 1) FWD_BY_MODE(128, 64, 2, 2);
     else FWD_BY_MODE(64, 64, 2, 2);
     if (partial) {
         const int64_t MN = Mtot * g.Cout;
@@ -876,10 +835,9 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     hipStream_t st = STREAM(stream);
     const unsigned classes = (unsigned)(g.S * g.S);
     const bool vec = g.vecB && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0;
-    const bool big = sf_tune_bm() == 256 && Mc >= 256 * 2048;
-    if (g.Cin <= 32) { if (big) DGRAD_LAUNCH(256, 32, 4, 1); else DGRAD_LAUNCH(128, 32, 4, 1); }
+    if (g.Cin <= 32) DGRAD_LAUNCH(128, 32, 4, 1);
     else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) DGRAD_LAUNCH(64, 64, 2, 2);
-    else { if (big) DGRAD_LAUNCH(256, 64, 2, 2); else DGRAD_LAUNCH(128, 64, 2, 2); }
+    else DGRAD_LAUNCH(128, 64, 2, 2);
     return sf_launch_status("sf_conv_dgrad");
 }
 
