@@ -79,6 +79,25 @@ int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const int32_t *i
                      int64_t n, int D, int C, int HW, float sub_mean, float inv_scale, const float *mu,
                      const float *rstd, float *out, void *stream);
 
+/* ---- K3/K15 recurrent core: GRU / LSTM cells -------------------------------------------------------------------
+ * model/core.py:19-64 (ModelCoreRNN over torch.nn.GRU / nn.LSTM, one layer); learner.py:557-581 +
+ * rnn_utils.py:114-158 (BPTT over recurrence-length chunks; PackedSequence there, a masked time loop here — the
+ * equivalence is the reference's own tests/algo/test_rnn.py).  kind 0 = GRU (gate order r,z,n), 1 = LSTM (i,f,g,o),
+ * torch's parameter layout.  gx = x W_ih^T + b_ih, gh = h W_hh^T + b_hh come from sf_conv_fwd (1x1) launches.
+ * fwd: gates_out [C,4H] (GRU {r,z,n,W_hn h + b_hn}; LSTM {i,f,g,o}; NULL at inference), h_out/c_out = new state,
+ *      h_next/c_next = new state * keep[c] (keep = 1 - done_or_invalid, learner.py:561; NULL = keep everything).
+ * bwd: dh = dL/dh_out of this step (output gradient + masked carry), dc_in = carry into c_out (LSTM); writes dgx, dgh
+ *      [C,G*H] (LSTM: dgh may be NULL/alias dgx), dh_direct (GRU: the path of dL/dh_prev that bypasses W_hh),
+ *      dc_prev (LSTM).  The W_hh path of dL/dh_prev is sf_conv_dgrad(dgh, W_hh). */
+int sf_rnn_cell_fwd(int kind, const float *gx, const float *gh, const float *h_prev, int64_t ld_h, const float *c_prev,
+                    int64_t ld_c, const float *keep, int C, int H, float *gates_out, float *h_out, float *c_out,
+                    float *h_next, float *c_next, void *stream);
+int sf_rnn_cell_bwd(int kind, const float *dh, const float *dc_in, const float *gates, const float *h_prev,
+                    int64_t ld_h, const float *c_prev, int64_t ld_c, const float *c_out, int C, int H, float *dgx,
+                    float *dgh, float *dh_direct, float *dc_prev, void *stream);
+/* y[c,:] = (a[c,:] + b[c,:]) * keep[c] — gradient carry across a step boundary (b, keep optional). */
+int sf_rows_add_scale(const float *a, const float *b, const float *keep, int64_t C, int H, float *y, void *stream);
+
 /* ---- K17: V-trace -----------------------------------------------------------------------------------------
  * learner.py:601-640 (the reference runs this loop on the CPU).  Flat minibatch of n samples made of
  * n/recurrence trajectories; sample i of the minibatch is dataset row (index ? index[i] : offset+i).

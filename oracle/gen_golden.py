@@ -44,9 +44,10 @@ def save(name, **arrays):
     print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
-def make_cfg(extra):
+def make_cfg(extra, use_rnn=False):
+    base = [] if use_rnn else ["--use_rnn=False", "--recurrence=1"]
     argv = ["--algo=APPO", "--env=synthetic", "--experiment=golden", "--train_dir=/tmp/sf_golden", "--device=cpu",
-            "--serial_mode=True", "--use_rnn=False", "--recurrence=1", "--seed=0"] + list(extra)
+            "--serial_mode=True", "--seed=0"] + base + list(extra)
     parser, _ = parse_sf_args(argv)
     return parse_full_cfg(parser, argv)
 
@@ -77,6 +78,8 @@ def fill_batch(b, g, A, continuous=False, p_done=0.1, p_timeout=0.0, p_other_pol
         else:
             v.copy_(torch.randn(v.shape, generator=g))
     b["rnn_states"].zero_()
+    if b["rnn_states"].shape[-1] > 1:  # recurrent models: non-trivial stored states, zero after a done step
+        b["rnn_states"].copy_(torch.randn(b["rnn_states"].shape, generator=g) * 0.5)
     if continuous:
         b["actions"].copy_(torch.randn(b["actions"].shape, generator=g))
     else:
@@ -312,9 +315,10 @@ def gen_prepare_and_losses():
         save("learner_" + var["name"], **arrays)
 
 
-def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1):
+def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1, use_rnn=False):
     cfg = make_cfg(list(model_args) + [f"--rollout={T}", f"--batch_size={E * T // nb}",
-                                       f"--num_batches_per_epoch={nb}", f"--num_epochs={epochs}"] + list(extra))
+                                       f"--num_batches_per_epoch={nb}", f"--num_epochs={epochs}"] + list(extra),
+                   use_rnn=use_rnn)
     learner, env_info = make_learner(cfg, obs_space, gym.spaces.Discrete(A), E)
     shapes = load_seeded(learner.actor_critic, seed=param_seed)
     g = torch.Generator().manual_seed(4242)
@@ -430,6 +434,11 @@ def main():
                                           "--obs_scale=255.0", "--normalize_input=True",
                                           "--encoder_conv_mlp_layers", "128"],
                   E=8, T=4, A=6, nb=2, epochs=1, subsample=7)
+        rnn_common = ["--encoder_mlp_layers", "32", "--nonlinearity=relu", "--normalize_input=False", "--use_rnn=True",
+                      "--rnn_size=32", "--recurrence=8"]
+        gen_train("gru", MLP_OBS, rnn_common + ["--rnn_type=gru"], E=16, T=8, A=6, nb=2, epochs=1, use_rnn=True)
+        gen_train("lstm_inv", MLP_OBS, rnn_common + ["--rnn_type=lstm", "--kl_loss_coeff=0.1"], E=16, T=16, A=6, nb=2,
+                  epochs=2, use_rnn=True, extra=["--recurrence=8"])
         gen_train("mlp_norm", MLP_OBS, ["--encoder_mlp_layers", "32", "32", "--nonlinearity=elu",
                                         "--normalize_input=True"], E=16, T=8, A=6, nb=2, epochs=1)
     if "model" in which:

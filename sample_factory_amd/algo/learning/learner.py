@@ -303,7 +303,8 @@ class Learner:
             ac.obs_normalizer.update(obs, ac.obs_elems, E * (T + 1))
         # K9: bootstrap value of the T+1-th observation, read from the slab in place
         last = obs[:, T]
-        heads = ac.forward_heads(last, E, sample_stride=obs.stride(0), tag="inf")[-1]
+        rnn = dict(states=batch["rnn_states"][:, T]) if cfg.use_rnn else None
+        heads = ac.forward_heads(last, E, sample_stride=obs.stride(0), tag="inf", rnn=rnn)[-1]
         batch["values"][:, T].copy_(heads[:, 0])
         adv = torch.empty((E, T), dtype=torch.float32, device=self.device)
         ret = torch.empty((E, T), dtype=torch.float32, device=self.device)
@@ -322,6 +323,8 @@ class Learner:
         buff.log_prob_actions = batch["log_prob_actions"].view(N)
         buff.rewards = batch["rewards"].view(N)
         buff.dones = batch["dones"].view(N)
+        if cfg.use_rnn:
+            buff.rnn_states = batch["rnn_states"][:, :T].reshape(N, -1)
         buff["values"] = batch["values"][:, :T].reshape(N)  # NB: item access, AttrDict.values is dict.values
         buff.valids = batch["valids"][:, :T].reshape(N)
         buff.E, buff.T = E, T
@@ -364,8 +367,15 @@ class Learner:
         cfg, ac = self.cfg, self.actor_critic
         index, offset, n = mb
         A = self.num_action_params
+        rnn = None
+        if cfg.use_rnn:  # learner.py:557-569: chunk-start states, done-or-invalid boundaries (masked-loop BPTT)
+            R, Cn = cfg.recurrence, n // cfg.recurrence
+            rows = index.long() if index is not None else torch.arange(offset, offset + n, device=self.device)
+            doi = (buff.dones[rows] | ~buff.valids[rows]).view(Cn, R)
+            rnn = dict(R=R, h0=buff.rnn_states.index_select(0, rows.view(Cn, R)[:, 0]),
+                       keep_tm=(~doi).t().contiguous().float())
         acts = ac.forward_heads(buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
-                                traj_T=buff.T, tag="train")
+                                traj_T=buff.T, tag="train", rnn=rnn)
         heads = acts[-1]
         ld = ac.heads_ld  # 1 + A padded to a multiple of 4; padding columns of g_heads stay zero
         params, values = heads[:, 1:], heads[:, 0]

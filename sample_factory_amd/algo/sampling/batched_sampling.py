@@ -40,6 +40,8 @@ class BatchedVectorEnvRunner:
         self.global_step = 0
         self.zero_copy = hasattr(env, "step_into")
         self.obs = traj["obs"]["obs"]
+        self.rnn = actor_critic.rnn_kind is not None
+        traj["rnn_states"].zero_()
         self._started = False
         self.A = actor_critic.num_action_params
         self.ld = actor_critic.heads_ld
@@ -66,7 +68,8 @@ class BatchedVectorEnvRunner:
         ver = self.policy_version() if policy_version is None else float(policy_version)
         cfg = self.cfg
         for t in range(T):
-            heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf")[-1]
+            rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
+            heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf", rnn=rnn)[-1]
             lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
                                   self.global_step, 0, ver, deterministic, tr["actions"], tr["action_logits"],
                                   tr["log_prob_actions"], tr["values"], tr["policy_version"],
@@ -83,11 +86,16 @@ class BatchedVectorEnvRunner:
             lib.traj_write_env_step(rew, term, trunc, T, t, cfg.reward_scale, cfg.reward_clip, self.policy_id,
                                     tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
                                     self.ep_len, self.ep_stats)
+            if self.rnn:  # batched_sampling.py:332-335: next-step state = new_rnn_states * (1 - done)
+                keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
+                torch.mul(self.ac.new_rnn_states, keep, out=tr["rnn_states"][:, t + 1])
             self.global_step += 1
 
     def carry_over(self) -> None:
         """The next rollout starts from the last observation: slab obs[:, 0] <- obs[:, T] (one frame per agent)."""
         self.obs[:, 0].copy_(self.obs[:, self.T])
+        if self.rnn:
+            self.traj["rnn_states"][:, 0].copy_(self.traj["rnn_states"][:, self.T])
 
     def episode_stats(self) -> Dict[str, float]:
         s = self.ep_stats.cpu()

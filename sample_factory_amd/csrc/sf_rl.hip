@@ -1096,3 +1096,142 @@ extern "C" int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const
     else k_obsnorm_apply<false><<<dim3(grid), dim3(256), 0, STREAM(stream)>>>(in, stride, index, offset, traj_T, n, D, C, HW, sub_mean, inv_scale, mu, rstd, out);
     return sf_launch_status("sf_obsnorm_apply");
 }
+
+// =========================================================================================== recurrent core cells
+// model/core.py:19-64 (ModelCoreRNN = torch.nn.GRU / nn.LSTM, one layer) as explicit cell kernels; the projections
+// (x W_ih^T + b_ih, h W_hh^T + b_hh) are the MFMA linear kernels, these are the elementwise halves.  BPTT runs as a
+// time loop over recurrence-length chunks with the state zeroed after a done/invalid step — the loop form that the
+// reference's own test (tests/algo/test_rnn.py) proves equal to its PackedSequence path (rnn_utils.py:114-158).
+// kind 0 = GRU (gates r,z,n), 1 = LSTM (gates i,f,g,o).  All matrices row-major; h_prev/c_prev may be strided rows.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// gates_out [C, 4H]: GRU stores {r, z, n, hn = (W_hn h + b_hn)}; LSTM stores {i, f, g, o}.
+// h_out/c_out: the new state (core output); h_next/c_next = state * keep[c] (keep = 1 - done_or_invalid; NULL = 1).
+__global__ __launch_bounds__(256) void k_rnn_cell_fwd(int kind, const float *__restrict__ gx,
+                                                      const float *__restrict__ gh, const float *__restrict__ h_prev,
+                                                      int64_t ld_h, const float *__restrict__ c_prev, int64_t ld_c,
+                                                      const float *__restrict__ keep, int C, int H,
+                                                      float *__restrict__ gates_out, float *__restrict__ h_out,
+                                                      float *__restrict__ c_out, float *__restrict__ h_next,
+                                                      float *__restrict__ c_next) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)C * H) return;
+    const int64_t c = i / H;
+    const int j = (int)(i - c * H);
+    const float k = keep ? keep[c] : 1.0f;
+    if (kind == 0) {
+        const float *x = gx + c * 3 * H, *g = gh + c * 3 * H;
+        const float hp = h_prev[c * ld_h + j];
+        const float r = sigmoidf_(x[j] + g[j]);
+        const float z = sigmoidf_(x[H + j] + g[H + j]);
+        const float hn = g[2 * H + j];
+        const float n = tanhf(x[2 * H + j] + r * hn);
+        const float h = (1.0f - z) * n + z * hp;
+        if (gates_out) {
+            float *go = gates_out + c * 4 * H;
+            go[j] = r; go[H + j] = z; go[2 * H + j] = n; go[3 * H + j] = hn;
+        }
+        h_out[i] = h;
+        if (h_next) h_next[i] = h * k;
+    } else {
+        const float *x = gx + c * 4 * H, *g = gh + c * 4 * H;
+        const float cp = c_prev[c * ld_c + j];
+        const float ig = sigmoidf_(x[j] + g[j]);
+        const float fg = sigmoidf_(x[H + j] + g[H + j]);
+        const float gg = tanhf(x[2 * H + j] + g[2 * H + j]);
+        const float og = sigmoidf_(x[3 * H + j] + g[3 * H + j]);
+        const float cn = fg * cp + ig * gg;
+        const float h = og * tanhf(cn);
+        if (gates_out) {
+            float *go = gates_out + c * 4 * H;
+            go[j] = ig; go[H + j] = fg; go[2 * H + j] = gg; go[3 * H + j] = og;
+        }
+        h_out[i] = h;
+        c_out[i] = cn;
+        if (h_next) h_next[i] = h * k;
+        if (c_next) c_next[i] = cn * k;
+    }
+}
+
+extern "C" int sf_rnn_cell_fwd(int kind, const float *gx, const float *gh, const float *h_prev, int64_t ld_h,
+                               const float *c_prev, int64_t ld_c, const float *keep, int C, int H, float *gates_out,
+                               float *h_out, float *c_out, float *h_next, float *c_next, void *stream) {
+    SF_REQUIRE((kind == 0 || kind == 1) && gx && gh && h_prev && h_out && C > 0 && H > 0, "sf_rnn_cell_fwd: bad args");
+    SF_REQUIRE(kind == 0 || (c_prev && c_out), "sf_rnn_cell_fwd: LSTM needs c_prev and c_out");
+    const int64_t n = (int64_t)C * H;
+    k_rnn_cell_fwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        kind, gx, gh, h_prev, ld_h, c_prev, ld_c, keep, C, H, gates_out, h_out, c_out, h_next, c_next);
+    return sf_launch_status("sf_rnn_cell_fwd");
+}
+
+// backward of one step.  dh [C,H] = gradient wrt this step's h_out (output gradient + carry from t+1, already
+// masked); dc_in = carry into c_out (LSTM; NULL = 0).  Outputs: dgx [C,G*H] (gradient wrt x W_ih^T + b_ih),
+// dgh [C,G*H] (wrt h W_hh^T + b_hh; LSTM: may alias dgx or be NULL since both are equal), dh_direct [C,H] (the part
+// of dL/dh_prev that does not go through W_hh; GRU: dh*z, LSTM: 0 -> not written), dc_prev [C,H] (LSTM: dc*f).
+__global__ __launch_bounds__(256) void k_rnn_cell_bwd(int kind, const float *__restrict__ dh,
+                                                      const float *__restrict__ dc_in,
+                                                      const float *__restrict__ gates, const float *__restrict__ h_prev,
+                                                      int64_t ld_h, const float *__restrict__ c_prev, int64_t ld_c,
+                                                      const float *__restrict__ c_out, int C, int H,
+                                                      float *__restrict__ dgx, float *__restrict__ dgh,
+                                                      float *__restrict__ dh_direct, float *__restrict__ dc_prev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)C * H) return;
+    const int64_t c = i / H;
+    const int j = (int)(i - c * H);
+    const float *go = gates + c * 4 * H;
+    const float d = dh[i];
+    if (kind == 0) {
+        const float r = go[j], z = go[H + j], n = go[2 * H + j], hn = go[3 * H + j];
+        const float hp = h_prev[c * ld_h + j];
+        const float dn_pre = (d * (1.0f - z)) * (1.0f - n * n);
+        const float dz_pre = (d * (hp - n)) * (z * (1.0f - z));
+        const float dr_pre = (dn_pre * hn) * (r * (1.0f - r));
+        float *x = dgx + c * 3 * H, *g = dgh + c * 3 * H;
+        x[j] = dr_pre; x[H + j] = dz_pre; x[2 * H + j] = dn_pre;
+        g[j] = dr_pre; g[H + j] = dz_pre; g[2 * H + j] = dn_pre * r;
+        dh_direct[i] = d * z;
+    } else {
+        const float ig = go[j], fg = go[H + j], gg = go[2 * H + j], og = go[3 * H + j];
+        const float tc = tanhf(c_out[i]);
+        const float dc = d * og * (1.0f - tc * tc) + (dc_in ? dc_in[i] : 0.0f);
+        float *x = dgx + c * 4 * H;
+        const float di = (dc * gg) * (ig * (1.0f - ig)), df = (dc * c_prev[c * ld_c + j]) * (fg * (1.0f - fg));
+        const float dg = (dc * ig) * (1.0f - gg * gg), dob = (d * tc) * (og * (1.0f - og));
+        x[j] = di; x[H + j] = df; x[2 * H + j] = dg; x[3 * H + j] = dob;
+        if (dgh && dgh != dgx) {
+            float *g = dgh + c * 4 * H;
+            g[j] = di; g[H + j] = df; g[2 * H + j] = dg; g[3 * H + j] = dob;
+        }
+        dc_prev[i] = dc * fg;
+    }
+}
+
+extern "C" int sf_rnn_cell_bwd(int kind, const float *dh, const float *dc_in, const float *gates, const float *h_prev,
+                               int64_t ld_h, const float *c_prev, int64_t ld_c, const float *c_out, int C, int H,
+                               float *dgx, float *dgh, float *dh_direct, float *dc_prev, void *stream) {
+    SF_REQUIRE((kind == 0 || kind == 1) && dh && gates && dgx && C > 0 && H > 0, "sf_rnn_cell_bwd: bad args");
+    SF_REQUIRE(kind == 1 || (h_prev && dgh && dh_direct), "sf_rnn_cell_bwd: GRU needs h_prev, dgh, dh_direct");
+    SF_REQUIRE(kind == 0 || (c_prev && c_out && dc_prev), "sf_rnn_cell_bwd: LSTM needs c_prev, c_out, dc_prev");
+    const int64_t n = (int64_t)C * H;
+    k_rnn_cell_bwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        kind, dh, dc_in, gates, h_prev, ld_h, c_prev, ld_c, c_out, C, H, dgx, dgh, dh_direct, dc_prev);
+    return sf_launch_status("sf_rnn_cell_bwd");
+}
+
+// y[c, :] = (a[c, :] + b[c, :]) * keep[c]    (carry of dL/dh across a step boundary; b or keep may be NULL)
+__global__ __launch_bounds__(256) void k_rows_add_scale(const float *__restrict__ a, const float *__restrict__ b,
+                                                        const float *__restrict__ keep, int64_t C, int H,
+                                                        float *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * H) return;
+    const float v = a[i] + (b ? b[i] : 0.0f);
+    y[i] = keep ? v * keep[i / H] : v;
+}
+
+extern "C" int sf_rows_add_scale(const float *a, const float *b, const float *keep, int64_t C, int H, float *y,
+                                 void *stream) {
+    SF_REQUIRE(a && y && C > 0 && H > 0, "sf_rows_add_scale: bad args");
+    k_rows_add_scale<<<dim3((unsigned)((C * H + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(a, b, keep, C, H, y);
+    return sf_launch_status("sf_rows_add_scale");
+}

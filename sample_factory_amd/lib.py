@@ -37,7 +37,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
-    "sf_adam_step", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
+    "sf_adam_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
     "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_linear_fwd",
     "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
@@ -201,6 +201,30 @@ def obsnorm_apply(inp, u8, stride, index, offset, traj_T, n, D, C_, HW, sub_mean
                                    i64(offset), int(traj_T), i64(n), int(D), int(C_), int(HW), f(sub_mean),
                                    f(inv_scale), ptr(mu, "f32"), ptr(rstd, "f32"), ptr(out, "f32", "out"), stream()),
            "sf_obsnorm_apply")
+
+
+def _rp(t, name="tensor"):
+    """raw f32 device pointer of a possibly strided view (None -> NULL)"""
+    return C.c_void_p(0) if t is None else _raw(t, "f32", name)
+
+
+def rnn_cell_fwd(kind, gx, gh, h_prev, ld_h, c_prev, ld_c, keep, Cn, H, gates_out, h_out, c_out, h_next, c_next) -> None:
+    _check(load().sf_rnn_cell_fwd(int(kind), ptr(gx, "f32", "gx"), ptr(gh, "f32", "gh"), _rp(h_prev, "h_prev"),
+                                  i64(ld_h), _rp(c_prev, "c_prev"), i64(ld_c), ptr(keep, "f32", "keep"), int(Cn),
+                                  int(H), ptr(gates_out, "f32"), ptr(h_out, "f32"), ptr(c_out, "f32"),
+                                  ptr(h_next, "f32"), ptr(c_next, "f32"), stream()), "sf_rnn_cell_fwd")
+
+
+def rnn_cell_bwd(kind, dh, dc_in, gates, h_prev, ld_h, c_prev, ld_c, c_out, Cn, H, dgx, dgh, dh_direct, dc_prev) -> None:
+    _check(load().sf_rnn_cell_bwd(int(kind), ptr(dh, "f32", "dh"), ptr(dc_in, "f32"), ptr(gates, "f32", "gates"),
+                                  _rp(h_prev, "h_prev"), i64(ld_h), _rp(c_prev, "c_prev"), i64(ld_c),
+                                  ptr(c_out, "f32"), int(Cn), int(H), ptr(dgx, "f32", "dgx"), ptr(dgh, "f32"),
+                                  ptr(dh_direct, "f32"), ptr(dc_prev, "f32"), stream()), "sf_rnn_cell_bwd")
+
+
+def rows_add_scale(a, b, keep, Cn, H, y) -> None:
+    _check(load().sf_rows_add_scale(ptr(a, "f32", "a"), ptr(b, "f32"), ptr(keep, "f32"), i64(Cn), int(H),
+                                    ptr(y, "f32", "y"), stream()), "sf_rows_add_scale")
 
 
 def vtrace(params, ld_params, values, ld_values, actions, old_logp, rewards, dones, index, offset, n, A, action_kind,

@@ -52,8 +52,13 @@ def _pad(n: int, q: int = 64) -> int:
 class _Layer:
     """One implicit-GEMM layer: conv (spatial) or linear (1x1 on a 1x1 image)."""
 
-    def __init__(self, name, desc: lib.sf_conv_desc, ref_w_shape, kind, first_fc_chw=None):
+    def __init__(self, name, desc: lib.sf_conv_desc, ref_w_shape, kind, first_fc_chw=None, wname=None, bname=None,
+                 role="chain"):
         self.name = name          # reference parameter prefix, e.g. encoder.encoders.obs.enc.conv_head.0
+        self.wname = wname or name + ".weight"
+        self.bname = bname or name + ".bias"
+        self.role = role          # "chain" | "rnn_ih" (x projection, followed by the cell) | "rnn_hh" (side branch)
+        self.in_act_kind = 0      # activation kind of the tensor feeding this layer (fused into its dgrad epilogue)
         self.desc = desc
         self.kind = kind          # "conv_u8" | "conv" | "linear" | "linear_after_conv" | "heads"
         self.ref_w_shape = ref_w_shape
@@ -104,8 +109,8 @@ class ActorCritic:
         self.action_space = action_space
         self.device = torch.device(device)
         self.training = True
-        if cfg.use_rnn:
-            raise NotImplementedError("native RNN core is not built yet (SURVEY.md §8f.3); use_rnn=False only")
+        if cfg.use_rnn and (cfg.rnn_num_layers != 1 or cfg.rnn_type not in ("gru", "lstm")):
+            raise NotImplementedError("native recurrent core: one-layer GRU or LSTM only")
         if not cfg.actor_critic_share_weights:
             raise NotImplementedError("separate actor/critic weights are outside the hot-path scope (SURVEY.md §2.1)")
         if cfg.nonlinearity not in ACT_KIND:
@@ -159,6 +164,18 @@ class ActorCritic:
                 feat = size
         else:
             raise NotImplementedError(f"Unsupported observation shape {self.obs_shape}")
+        self.rnn_kind, self.rnn_H, self.rnn_S = None, 0, get_rnn_size(cfg)
+        if cfg.use_rnn and not self.layers:
+            raise NotImplementedError("a recurrent core needs at least one encoder layer in front of it")
+        if cfg.use_rnn:  # model/core.py:19-64: nn.GRU / nn.LSTM(input=feat, hidden=rnn_size), torch gate order
+            Hs = cfg.rnn_size
+            G = 3 if cfg.rnn_type == "gru" else 4
+            self.rnn_kind, self.rnn_H = (0 if cfg.rnn_type == "gru" else 1), Hs
+            self.layers.append(_Layer("core.core.ih", _linear_desc(feat, G * Hs, 0), (G * Hs, feat), "linear",
+                                      wname="core.core.weight_ih_l0", bname="core.core.bias_ih_l0", role="rnn_ih"))
+            self.layers.append(_Layer("core.core.hh", _linear_desc(Hs, G * Hs, 0), (G * Hs, Hs), "linear",
+                                      wname="core.core.weight_hh_l0", bname="core.core.bias_hh_l0", role="rnn_hh"))
+            feat = Hs
         for j, size in enumerate(cfg.decoder_mlp_layers):
             self.layers.append(_Layer(f"decoder.mlp.{2 * j}", _linear_desc(feat, size, act), (size, feat), "linear"))
             feat = size
@@ -169,6 +186,12 @@ class ActorCritic:
         self.heads_ld = (1 + A + 3) // 4 * 4
         self.layers.append(_Layer("heads", _linear_desc(feat, self.heads_ld, 0), (self.heads_ld, feat), "heads"))
         self.act_kind = act
+        prev_kind = 0  # what produced the input of each chain layer: obs (0), an activated layer (act), the RNN cell (0)
+        for L in self.layers:
+            if L.role == "rnn_hh":
+                continue
+            L.in_act_kind = prev_kind
+            prev_kind = 0 if L.role == "rnn_ih" else L.desc.relu
         self.obs_elems = int(np.prod(self.obs_shape))
 
         # ---- flat parameter / gradient / Adam buffers
@@ -226,7 +249,10 @@ class ActorCritic:
         sd = {}
         for name, shape in self.ref_param_shapes():
             t = torch.empty(shape, dtype=torch.float32)
-            if name.endswith(".bias"):
+            if name.startswith("core.core."):  # nn.GRU/nn.LSTM keep torch's default init (initialize_weights skips them)
+                bound = 1.0 / math.sqrt(self.rnn_H)
+                t.uniform_(-bound, bound)
+            elif name.endswith(".bias"):
                 if cfg.policy_initialization == "torch_default":
                     fan_in = int(np.prod(dict(self.ref_param_shapes())[name[:-4] + "weight"][1:]))
                     bound = 1 / math.sqrt(fan_in)
@@ -246,8 +272,15 @@ class ActorCritic:
         """(name, shape) of every trainable parameter under the reference's names, in the reference's order."""
         out = []
         for L in self.layers[:-1]:
-            out.append((L.name + ".weight", tuple(L.ref_w_shape)))
-            out.append((L.name + ".bias", (L.N,)))
+            if L.role == "rnn_hh":
+                continue
+            if L.role == "rnn_ih":  # torch order: weight_ih, weight_hh, bias_ih, bias_hh
+                Lh = self.layers[self.layers.index(L) + 1]
+                out += [(L.wname, tuple(L.ref_w_shape)), (Lh.wname, tuple(Lh.ref_w_shape)), (L.bname, (L.N,)),
+                        (Lh.bname, (Lh.N,))]
+                continue
+            out.append((L.wname, tuple(L.ref_w_shape)))
+            out.append((L.bname, (L.N,)))
         A, F = self.num_action_params, self.feat
         out += [("critic_linear.weight", (1, F)), ("critic_linear.bias", (1,)),
                 ("action_parameterization.distribution_linear.weight", (A, F)),
@@ -261,8 +294,8 @@ class ActorCritic:
         if self.returns_normalizer is not None:
             sd.update(self.returns_normalizer.state_dict("returns_normalizer."))
         for L in self.layers[:-1]:
-            sd[L.name + ".weight"] = L.w_to_ref(L.w.detach()).cpu()
-            sd[L.name + ".bias"] = L.b.detach().cpu().clone()
+            sd[L.wname] = L.w_to_ref(L.w.detach()).cpu()
+            sd[L.bname] = L.b.detach().cpu().clone()
         H, A = self.layers[-1], self.num_action_params
         w = H.w.detach().cpu()
         sd["critic_linear.weight"] = w[:, 0:1].t().contiguous()
@@ -274,8 +307,8 @@ class ActorCritic:
     def load_state_dict(self, sd, strict=True):
         with torch.no_grad():
             for L in self.layers[:-1]:
-                L.w.copy_(L.w_from_ref(torch.as_tensor(sd[L.name + ".weight"], dtype=torch.float32)))
-                L.b.copy_(torch.as_tensor(sd[L.name + ".bias"], dtype=torch.float32))
+                L.w.copy_(L.w_from_ref(torch.as_tensor(sd[L.wname], dtype=torch.float32)))
+                L.b.copy_(torch.as_tensor(sd[L.bname], dtype=torch.float32))
             H, A = self.layers[-1], self.num_action_params
             cw = torch.as_tensor(sd["critic_linear.weight"], dtype=torch.float32)
             aw = torch.as_tensor(sd["action_parameterization.distribution_linear.weight"], dtype=torch.float32)
@@ -296,8 +329,8 @@ class ActorCritic:
         """Interpret a flat buffer (params, grads or Adam moments) under the reference's names/layouts."""
         out = {}
         for L, (o, ob) in zip(self.layers[:-1], self._segs[:-1]):
-            out[L.name + ".weight"] = L.w_to_ref(flat[o:o + L.K * L.N].view(L.K, L.N)).cpu()
-            out[L.name + ".bias"] = flat[ob:ob + L.N].cpu().clone()
+            out[L.wname] = L.w_to_ref(flat[o:o + L.K * L.N].view(L.K, L.N)).cpu()
+            out[L.bname] = flat[ob:ob + L.N].cpu().clone()
         H, (o, ob), A = self.layers[-1], self._segs[-1], self.num_action_params
         w = flat[o:o + H.K * H.N].view(H.K, H.N).cpu()
         b = flat[ob:ob + H.N].cpu()
@@ -328,69 +361,171 @@ class ActorCritic:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _gemm(self, L, x, stride, index, offset, traj_T, out, n):
+        d = L.desc
+        if traj_T:
+            d = lib.sf_conv_desc.from_buffer_copy(L.desc)
+            d.traj_T = int(traj_T)
+        wsb = lib.conv_fwd_workspace(n, d) if index is None and not traj_T else 0  # split-K for chip-starving launches
+        lib.conv_fwd_raw(x, stride, index, offset, L.w, L.b, out, n, d, self._workspace(wsb) if wsb else None)
+
     def forward_heads(self, obs: torch.Tensor, n: int, *, sample_stride: int, index=None, offset: int = 0,
-                      traj_T: int = 0, tag="inf") -> List[torch.Tensor]:
-        """Run the whole stack on `n` samples; returns the list of layer outputs (last = heads [n, 1+A]).
+                      traj_T: int = 0, tag="inf", rnn=None) -> List[torch.Tensor]:
+        """Run the whole stack on `n` samples; returns the list of layer outputs (last = heads [n, heads_ld]).
 
         obs: any (possibly strided) view whose data_ptr is sample 0; logical sample i lives at row
         (index[i] | offset+i) [-> slab row if traj_T] * sample_stride elements.
+        rnn (recurrent models): {"states": [n, S] view} for one inference step (new state -> self.new_rnn_states) or
+        {"R": recurrence, "h0": [n/R, S], "keep_tm": [R, n/R]} for a training pass over recurrence-length chunks.
         """
-        acts = []
-        x = obs
+        acts: List[Optional[torch.Tensor]] = [None] * len(self.layers)
+        inputs: List[Optional[torch.Tensor]] = [None] * len(self.layers)
+        x, stride, idx, off, tT = obs, sample_stride, index, offset, traj_T
         if self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
             xn = self._buf((tag, "obsn"), (n, self.obs_elems))
             self.obs_normalizer.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T)
-            self._xn[tag] = xn
-            x, sample_stride, index, offset, traj_T = xn, self.obs_elems, None, 0, 0
+            x, stride, idx, off, tT = xn, self.obs_elems, None, 0, 0
+        first_in = (x, stride, idx, off, tT)
+        seq = rnn is not None and "R" in rnn
         for li, L in enumerate(self.layers):
+            if L.role == "rnn_hh":
+                continue
+            if L.role == "rnn_ih" and seq:  # BPTT pass: the recurrent block works time-major ([R, C, .])
+                R, Cn = rnn["R"], n // rnn["R"]
+                xt = self._buf((tag, "x_tm"), (n, L.K))
+                xt.view(R, Cn, L.K).copy_(x.view(Cn, R, L.K).transpose(0, 1))
+                x = xt
+            inputs[li] = x
             out = self._buf((tag, li), (n * L.out_pixels, L.N))
-            d = L.desc
-            if li == 0:
-                d = lib.sf_conv_desc.from_buffer_copy(L.desc)
-                d.traj_T = int(traj_T)
-                lib.conv_fwd_raw(x, sample_stride, index, offset, L.w, L.b, out, n, d)
-            else:
-                wsb = lib.conv_fwd_workspace(n, d)  # >0 only for launches too small to fill the chip (split-K)
-                lib.conv_fwd_raw(x, d.H * d.W * d.Cin, None, 0, L.w, L.b, out, n, d,
-                                 self._workspace(wsb) if wsb else None)
-            acts.append(out)
+            self._gemm(L, x, stride, idx, off, tT, out, n)
+            acts[li] = out
             x = out
+            if L.role == "rnn_ih":
+                x = self._rnn_sequence_fwd(li, out, n, rnn, tag) if seq else self._rnn_step(li, out, n, rnn, tag)
+            stride, idx, off, tT = x.numel() // n, None, 0, 0  # elements per sample of the activation just produced
+        self._ctx = getattr(self, "_ctx", {})
+        self._ctx[tag] = dict(acts=acts, inputs=inputs, first_in=first_in, rnn=rnn)
         return acts
 
+    # ------------------------------------------------------------------------------------------ recurrent core
+    def _rnn_step(self, li, gx, n, rnn, tag):
+        """one inference step: (gx, h W_hh^T + b_hh) -> cell -> new state (model/core.py:37-64)"""
+        Lh, H, S, kind = self.layers[li + 1], self.rnn_H, self.rnn_S, self.rnn_kind
+        st = rnn["states"]
+        assert st.shape == (n, S) and st.stride(1) == 1
+        gh = self._buf((tag, "gh"), (n, Lh.N))
+        lib.conv_fwd_raw(st, st.stride(0), None, 0, Lh.w, Lh.b, gh, n, Lh.desc)
+        h_out = self._buf((tag, "h_out"), (n, H))
+        c_out = self._buf((tag, "c_out"), (n, H)) if kind == 1 else None
+        lib.rnn_cell_fwd(kind, gx, gh, st, st.stride(0), st[:, H:] if kind == 1 else None, st.stride(0), None, n, H,
+                         None, h_out, c_out, None, None)
+        self.new_rnn_states = h_out if kind == 0 else torch.cat([h_out, c_out], dim=1)
+        return h_out
+
+    def _rnn_sequence_fwd(self, li, GX, n, rnn, tag):
+        """training pass: masked time loop over recurrence-length chunks (state zeroed after done/invalid steps —
+        the loop form of rnn_utils.py:114-158, see tests/algo/test_rnn.py in the reference)"""
+        Lh, H, kind = self.layers[li + 1], self.rnn_H, self.rnn_kind
+        R, Cn = rnn["R"], n // rnn["R"]
+        h0, keep = rnn["h0"], rnn["keep_tm"]
+        GH = Lh.N
+        gates = self._buf((tag, "gates"), (R, Cn, 4 * H))
+        Hprev = self._buf((tag, "Hprev"), (R + 1, Cn, H))
+        Hout = self._buf((tag, "Hout"), (R, Cn, H))
+        Cprev = self._buf((tag, "Cprev"), (R + 1, Cn, H)) if kind == 1 else None
+        Cout = self._buf((tag, "Cout"), (R, Cn, H)) if kind == 1 else None
+        Hprev[0].copy_(h0[:, :H])
+        if kind == 1:
+            Cprev[0].copy_(h0[:, H:])
+        gh = self._buf((tag, "gh_seq"), (Cn, GH))
+        GXv = GX.view(R, Cn, GH)
+        for t in range(R):
+            lib.conv_fwd_raw(Hprev[t], H, None, 0, Lh.w, Lh.b, gh, Cn, Lh.desc)
+            lib.rnn_cell_fwd(kind, GXv[t], gh, Hprev[t], H, Cprev[t] if kind == 1 else None, H, keep[t], Cn, H,
+                             gates[t], Hout[t], Cout[t] if kind == 1 else None, Hprev[t + 1],
+                             Cprev[t + 1] if kind == 1 else None)
+        out = self._buf((tag, "core_out"), (n, H))
+        out.view(Cn, R, H).copy_(Hout.transpose(0, 1))
+        self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn)
+        return out
+
+    def _rnn_sequence_bwd(self, li, d_core, n):
+        """BPTT: returns dL/d(gx) time-major [R*C, G*H]; accumulates the W_hh / b_hh gradients"""
+        Lh, H, kind = self.layers[li + 1], self.rnn_H, self.rnn_kind
+        sv = self._rnn_saved
+        R, Cn, keep = sv["R"], sv["Cn"], sv["keep"]
+        GH = Lh.N
+        dOut = self._buf(("g", "dOut_tm"), (R, Cn, H))
+        dOut.copy_(d_core.view(Cn, R, H).transpose(0, 1))
+        dGX = self._buf(("g", "dGX"), (R, Cn, GH))
+        dGH = self._buf(("g", "dGH"), (R, Cn, GH)) if kind == 0 else dGX
+        dh = self._buf(("g", "dh"), (Cn, H))
+        dh_direct = self._buf(("g", "dh_direct"), (Cn, H)) if kind == 0 else None
+        dhW = self._buf(("g", "dhW"), (Cn, H))
+        carry_h = self._buf(("g", "carry_h"), (Cn, H))
+        carry_c = self._buf(("g", "carry_c"), (Cn, H)) if kind == 1 else None
+        dc_prev = self._buf(("g", "dc_prev"), (Cn, H)) if kind == 1 else None
+        for t in range(R - 1, -1, -1):
+            last = t == R - 1
+            lib.rows_add_scale(dOut[t], None if last else carry_h, None, Cn, H, dh)
+            lib.rnn_cell_bwd(kind, dh, None if (last or kind == 0) else carry_c, sv["gates"][t], sv["Hprev"][t], H,
+                             sv["Cprev"][t] if kind == 1 else None, H, sv["Cout"][t] if kind == 1 else None, Cn, H,
+                             dGX[t], dGH[t] if kind == 0 else None, dh_direct, dc_prev)
+            if t > 0:  # gradient wrt the state entering step t, masked by keep[t-1] (state was zeroed after a done)
+                lib.conv_dgrad(dGH[t], Lh.w, None, dhW, Cn, Lh.desc)
+                lib.rows_add_scale(dhW, dh_direct, keep[t - 1], Cn, H, carry_h)
+                if kind == 1:
+                    lib.rows_add_scale(dc_prev, None, keep[t - 1], Cn, H, carry_c)
+        ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
+        lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
+        return dGX.view(n, GH)
+
     def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
-        """Inference-style forward on a dense obs batch [B, ...]; returns dict(values, action_logits) (GPU tensors).
-        Sampling is a separate fused kernel (sf_sample_write_step) driven by the rollout runner."""
+        """Inference-style forward on a dense obs batch [B, ...]; returns dict(values, action_logits, new_rnn_states)
+        (GPU tensors).  Sampling is a separate fused kernel (sf_sample_write_step) driven by the rollout runner."""
         obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
         assert action_mask is None, "action masks are not supported by the native sampler yet"
         B = obs.shape[0]
-        heads = self.forward_heads(obs, B, sample_stride=self.obs_elems if obs.is_contiguous() else obs.stride(0))[-1]
+        rnn = dict(states=rnn_states) if self.rnn_kind is not None else None
+        heads = self.forward_heads(obs, B, sample_stride=self.obs_elems if obs.is_contiguous() else obs.stride(0),
+                                   rnn=rnn)[-1]
         res = dict(values=heads[:, 0])
         if not values_only:
             res["action_logits"] = heads[:, 1:1 + self.num_action_params]
-        res["new_rnn_states"] = rnn_states
+        res["new_rnn_states"] = self.new_rnn_states if self.rnn_kind is not None else rnn_states
         return res
 
     def backward(self, acts: List[torch.Tensor], g_heads: torch.Tensor, obs: torch.Tensor, n: int, *,
                  sample_stride: int, index=None, offset: int = 0, traj_T: int = 0) -> None:
-        """Back-propagate d(loss)/d(heads) [n, 1+A] through the stack into self.flat_grads (overwritten)."""
+        """Back-propagate d(loss)/d(heads) [n, heads_ld] through the stack of the last "train" forward into
+        self.flat_grads (overwritten)."""
+        ctx = self._ctx["train"]
+        inputs = ctx["inputs"]
+        x0, stride0, idx0, off0, tT0 = ctx["first_in"]
         g = g_heads
-        if self.obs_normalizer is not None:  # the first layer's input is the normalised batch of the last forward
-            obs, sample_stride, index, offset, traj_T = self._xn["train"], self.obs_elems, None, 0, 0
-        for li in range(len(self.layers) - 1, -1, -1):
+        chain = [li for li, L in enumerate(self.layers) if L.role != "rnn_hh"]
+        for pos in range(len(chain) - 1, -1, -1):
+            li = chain[pos]
             L = self.layers[li]
             d = L.desc
-            x = obs if li == 0 else acts[li - 1]
-            if li == 0:
+            if L.role == "rnn_ih":
+                g = self._rnn_sequence_bwd(li, g, n)  # dL/d(core_out) [n,H] -> dL/d(gx) time-major
+            if pos == 0:
                 d0 = lib.sf_conv_desc.from_buffer_copy(d)
-                d0.traj_T = int(traj_T)
+                d0.traj_T = int(tT0)
                 ws = self._workspace(lib.conv_wgrad_workspace(n, d0))
-                lib.conv_wgrad_raw(x, sample_stride, index, offset, g, L.gw, L.gb, n, d0, ws)
+                lib.conv_wgrad_raw(x0, stride0, idx0, off0, g, L.gw, L.gb, n, d0, ws)
             else:
-                stride = d.H * d.W * d.Cin
+                x = inputs[li]
                 ws = self._workspace(lib.conv_wgrad_workspace(n, d))
-                lib.conv_wgrad_raw(x, stride, None, 0, g, L.gw, L.gb, n, d, ws)
-                gin = self._buf(("g", li - 1), tuple(acts[li - 1].shape))
+                lib.conv_wgrad_raw(x, d.H * d.W * d.Cin, None, 0, g, L.gw, L.gb, n, d, ws)
+                gin = self._buf(("g", li - 1), tuple(x.shape))
                 dd = lib.sf_conv_desc.from_buffer_copy(d)
-                dd.relu = self.act_kind  # kind of the activation that produced acts[li-1]; derivative fused
-                lib.conv_dgrad(g, L.w, acts[li - 1], gin, n, dd)
+                dd.relu = L.in_act_kind  # derivative of the activation that produced x, fused into the epilogue
+                lib.conv_dgrad(g, L.w, x if L.in_act_kind else None, gin, n, dd)
                 g = gin
+                if L.role == "rnn_ih":  # back to sample-major for the encoder
+                    R, Cn = self._rnn_saved["R"], self._rnn_saved["Cn"]
+                    gs = self._buf(("g", "x_sm"), (n, L.K))
+                    gs.view(Cn, R, L.K).copy_(g.view(R, Cn, L.K).transpose(0, 1))
+                    g = gs

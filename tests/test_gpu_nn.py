@@ -362,6 +362,115 @@ def test_learner_train_matches_reference_normalize_input(lib, golden, tmp_path, 
     assert torch.equal(l2.actor_critic.obs_normalizer.mu_tab, ac.obs_normalizer.mu_tab)
 
 
+@pytest.mark.parametrize("rnn_type", ["gru", "lstm"])
+def test_rnn_cells_match_torch(lib, rnn_type):
+    """GRU / LSTM cell forward + one-step backward vs torch.nn (CPU, fp64)"""
+    Cn, F_, H = 37, 24, 16
+    kind = 0 if rnn_type == "gru" else 1
+    G = 3 if kind == 0 else 4
+    g = torch.Generator().manual_seed(kind + 5)
+    ref = (torch.nn.GRU if kind == 0 else torch.nn.LSTM)(F_, H).double()
+    x, h0, c0 = torch.randn((Cn, F_), generator=g).double(), torch.randn((Cn, H), generator=g).double(), torch.randn((Cn, H), generator=g).double()
+    h0r, c0r, xr = h0.clone().requires_grad_(True), c0.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    if kind == 0:
+        out, hn = ref(xr[None], h0r[None]); cn = None
+    else:
+        out, (hn, cn) = ref(xr[None], (h0r[None], c0r[None]))
+    dh = torch.randn((Cn, H), generator=g).double()
+    dc = torch.randn((Cn, H), generator=g).double()
+    ((out[0] * dh).sum() + ((cn[0] * dc).sum() if kind == 1 else 0)).backward()
+    f32 = lambda t: t.detach().float().cuda().contiguous()
+    w_ih, w_hh = f32(ref.weight_ih_l0.t()), f32(ref.weight_hh_l0.t())      # K-major [in, G*H]
+    gx, gh = torch.empty((Cn, G * H), device="cuda"), torch.empty((Cn, G * H), device="cuda")
+    lib.linear_fwd(f32(x), w_ih, f32(ref.bias_ih_l0), gx, Cn, F_, G * H, False)
+    lib.linear_fwd(f32(h0), w_hh, f32(ref.bias_hh_l0), gh, Cn, H, G * H, False)
+    gates = torch.empty((Cn, 4 * H), device="cuda")
+    h_out, c_out = torch.empty((Cn, H), device="cuda"), torch.empty((Cn, H), device="cuda")
+    h_next, c_next = torch.empty((Cn, H), device="cuda"), torch.empty((Cn, H), device="cuda")
+    keep = (torch.rand(Cn, generator=g) > 0.3).float().cuda()
+    lib.rnn_cell_fwd(kind, gx, gh, f32(h0), H, f32(c0), H, keep, Cn, H, gates, h_out, c_out, h_next, c_next)
+    np.testing.assert_allclose(h_out.cpu().numpy(), hn[0].detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(h_next.cpu().numpy(), (hn[0].detach() * keep.cpu()[:, None].double()).numpy(), atol=2e-6)
+    if kind == 1:
+        np.testing.assert_allclose(c_out.cpu().numpy(), cn[0].detach().numpy(), atol=2e-6)
+    dgx, dgh = torch.empty_like(gx), torch.empty_like(gx)
+    dh_direct, dc_prev = torch.zeros((Cn, H), device="cuda"), torch.zeros((Cn, H), device="cuda")
+    lib.rnn_cell_bwd(kind, f32(dh), f32(dc) if kind == 1 else None, gates, f32(h0), H, f32(c0), H, c_out, Cn, H, dgx,
+                     dgh if kind == 0 else None, dh_direct, dc_prev)
+    dgh_eff = dgh if kind == 0 else dgx
+    dx = dgx.cpu().double() @ ref.weight_ih_l0.detach()
+    dhp = dgh_eff.cpu().double() @ ref.weight_hh_l0.detach() + (dh_direct.cpu().double() if kind == 0 else 0)
+    np.testing.assert_allclose(dx.numpy(), xr.grad.numpy(), atol=3e-6)
+    np.testing.assert_allclose(dhp.numpy(), h0r.grad.numpy(), atol=3e-6)
+    if kind == 1:
+        np.testing.assert_allclose(dc_prev.cpu().numpy(), c0r.grad.numpy(), atol=3e-6)
+
+
+@pytest.mark.parametrize("name", ["gru", "lstm_inv"])
+def test_learner_train_matches_reference_rnn(lib, golden, tmp_path, name):
+    """Recurrent policies: the reference's PackedSequence BPTT (rnn_utils.py) vs the native masked time loop —
+    full Learner.train (stored chunk-start states, resets on dones / invalid rows, 2 minibatches [x 2 epochs])."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import get_rnn_size
+    g = golden("train_" + name)
+    E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
+    rnn_type = "gru" if name == "gru" else "lstm"
+    cfg = default_cfg(use_rnn=True, rnn_type=rnn_type, rnn_size=32, recurrence=8, nonlinearity="relu", normalize_input=False,
+                      encoder_mlp_layers=[32], rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb,
+                      num_epochs=int(g["num_epochs"]), kl_loss_coeff=0.1 if name == "lstm_inv" else 0.0, seed=0,
+                      serial_mode=True, train_dir=str(tmp_path), experiment="t", record_grad_norm=True)
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    ac = learner.actor_critic
+    assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
+    load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
+    batch = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    stats = learner.train(batch)
+    assert stats["learner_env_steps"] == int(g["env_steps"]) and learner.train_step == int(g["train_step"])
+    np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=5e-4)
+    np.testing.assert_allclose(ac.returns_normalizer.stats.cpu().numpy(), g["out_rms"], rtol=1e-5)
+    after, m = ac.state_dict(), ac.flat_to_ref(learner.exp_avg)
+    assert "core.core.weight_hh_l0" in after and after["core.core.weight_ih_l0"].shape == ((3 if rnn_type == "gru" else 4) * 32, 32)
+    for pname in g["param_names"]:
+        np.testing.assert_allclose(m[pname].reshape(-1).numpy(), g["m_" + pname], rtol=5e-3, atol=5e-8, err_msg=pname)
+        np.testing.assert_allclose(after[pname].reshape(-1).numpy(), g["after_" + pname], rtol=0, atol=2e-5, err_msg=pname)
+
+
+def test_recurrent_policy_rollout_and_training(lib):
+    """GRU policy on image observations end to end: state carried through the slab, reset on dones, BPTT"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_atari", make_synthetic_env)
+    cfg = default_cfg(env="synthetic_atari", use_rnn=True, rnn_type="gru", rnn_size=64, nonlinearity="relu",
+                      normalize_input=False, obs_scale=255.0, encoder_conv_architecture="convnet_atari", rollout=8,
+                      batch_size=256, num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1,
+                      async_rl=False, seed=1, serial_mode=True, synthetic_num_agents=64)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    assert cfg.recurrence == 8
+    for _ in range(2):
+        stats = runner.iteration()
+    torch.cuda.synchronize()
+    tr = runner.traj
+    assert tr["rnn_states"].shape == (64, 9, 64) and torch.isfinite(tr["rnn_states"]).all()
+    done_prev = tr["dones"][:, :-1]
+    assert (tr["rnn_states"][:, 1:-1][done_prev].abs().sum() == 0)      # state zeroed after a done step
+    assert tr["rnn_states"][:, 1:].abs().sum() > 0 and np.isfinite(stats["train"]["loss"])
+
+
 def _kv(argv):
     return {t[2:].split("=", 1)[0]: t[2:].split("=", 1)[1] for t in str(argv).split() if t.startswith("--") and "=" in t}
 
