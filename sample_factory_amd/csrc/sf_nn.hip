@@ -522,13 +522,19 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvG g, const void *__restr
         }
 }
 
-// out[i] = sum_z partial[z][i], z ascending (deterministic)
+// out[i] = sum_z partial[z][i] in a FIXED order (deterministic): eight interleaved accumulators (z mod 8) keep eight
+// loads in flight per lane — the single-accumulator loop was latency-bound (Z up to 1024 dependent loads per lane).
 __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict__ partial, float *__restrict__ out,
                                                          int64_t n, int Z) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < Z; ++z) s += partial[(int64_t)z * n + i];
-        out[i] = s;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= Z; z += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += partial[(int64_t)(z + j) * n + i];
+        }
+        for (int j = 0; z < Z; ++z, ++j) s[j] += partial[(int64_t)z * n + i];
+        out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
 }
 

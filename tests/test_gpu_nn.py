@@ -551,9 +551,11 @@ def test_continuous_env_rollout_and_vtrace_training(lib):
     from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
     from sample_factory_amd.train import make_runner
     register_env("synthetic_ant", make_synthetic_continuous_env)
-    for vtrace in (False, True):
-        cfg = default_cfg(env="synthetic_ant", use_rnn=False, nonlinearity="tanh", normalize_input=False,
-                          encoder_mlp_layers=[64, 64], rollout=8, recurrence=8 if vtrace else 1, batch_size=512,
+    # third variant = BASELINE.json configs[4] in miniature: LSTM core + V-trace + Box actions (mujoco_params.py preset)
+    for vtrace, lstm in ((False, False), (True, False), (True, True)):
+        cfg = default_cfg(env="synthetic_ant", use_rnn=lstm, rnn_type="lstm", rnn_size=64, nonlinearity="tanh",
+                          normalize_input=lstm, encoder_mlp_layers=[64, 64], rollout=8,
+                          recurrence=8 if (vtrace or lstm) else 1, batch_size=512,
                           num_batches_per_epoch=2, num_epochs=2, num_workers=1, num_envs_per_worker=1, async_rl=False,
                           seed=2, serial_mode=True, synthetic_num_agents=128, kl_loss_coeff=0.1, with_vtrace=vtrace,
                           normalize_returns=not vtrace, shuffle_minibatches=not vtrace)
@@ -625,3 +627,31 @@ def test_end_to_end_rollout_and_train_small(lib):
     np.testing.assert_array_equal(tr["obs"]["obs"][:, 0].cpu().numpy().reshape(64, -1), oracle.synth_obs(64, 0, 28224, 1, 24))
     s = runner.sampler.episode_stats()
     assert s["episodes"] >= 0
+
+
+def test_cartpole_learns(lib):
+    """BASELINE.json configs[0] as a learning test (the reference's own end-to-end check is a learning test too,
+    tests/examples/test_example.py:159-174): host CartPole env, MLP policy, sync APPO on the GPU; the mean episode length
+    must rise well above the ~22 steps of a random policy."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.cartpole import make_cartpole_env
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.train import make_runner
+    register_env("CartPole-v1", make_cartpole_env)
+    cfg = default_cfg(env="CartPole-v1", use_rnn=False, nonlinearity="tanh", normalize_input=True, encoder_mlp_layers=[64, 64],
+                      rollout=32, batch_size=1024, num_batches_per_epoch=2, num_epochs=4, num_workers=1,
+                      num_envs_per_worker=1, async_rl=False, seed=3, serial_mode=True, cartpole_num_agents=64,
+                      learning_rate=1e-3, exploration_loss_coeff=0.001, gamma=0.99, value_bootstrap=True,
+                      reward_scale=0.1, shuffle_minibatches=True)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    lens = []
+    for it in range(60):
+        runner.sampler.ep_stats.zero_()
+        runner.iteration()
+        s = runner.sampler.episode_stats()
+        if s["episodes"] > 0:
+            lens.append(s["mean_len"])
+    first, last = np.mean(lens[:5]), np.mean(lens[-5:])
+    assert first < 60, first
+    assert last > 150 and last > 3 * first, (first, last)
