@@ -24,20 +24,28 @@ class ReplicaGroup:
         self.world = dist.get_world_size(process_group) if self.active else 1
         self.rank = dist.get_rank(process_group) if self.active else 0
 
-    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        # gloo (CPU collectives) with device tensors: stage through the host.  Only used to exercise the replica
+        # protocol on boxes with fewer GPUs than ranks (tests); production runs use nccl (= RCCL over xGMI).
+        self._stage = self.active and dist.get_backend(process_group) == "gloo"
+
+    def _collective(self, fn, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            if self._stage and t.is_cuda:
+                h = t.detach().cpu()
+                fn(h)
+                t.copy_(h)
+            else:
+                fn(t)
         return t
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        return self._collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.pg), t)
 
     def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-        return t
+        return self._collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.pg), t)
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        if self.world > 1:
-            dist.broadcast(t, src=src, group=self.pg)
-        return t
+        return self._collective(lambda x: dist.broadcast(x, src=src, group=self.pg), t)
 
     def env_shard(self, envs_per_rank: int) -> Tuple[int, int]:
         """[first, last) global env ids owned by this rank (weak scaling: per-rank work is fixed)."""

@@ -153,7 +153,7 @@ class Learner:
         self.last_summary: Dict = {}
         # data-parallel replicas (C1): one rank per GPU; inactive group = single GPU
         self.pg = process_group
-        dp_on = process_group is not None or getattr(cfg, "data_parallel", False)
+        dp_on = process_group is not None or (getattr(cfg, "data_parallel", False) and torch.distributed.is_initialized())
         self.group = ReplicaGroup(process_group) if dp_on else None
         self.world = self.group.world if self.group is not None else 1
         self._grad_norms: List[float] = []

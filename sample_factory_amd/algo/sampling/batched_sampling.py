@@ -22,7 +22,7 @@ from sample_factory_amd.algo.utils.tensor_dict import TensorDict
 
 class BatchedVectorEnvRunner:
     def __init__(self, cfg, env_info, env, actor_critic, traj: TensorDict, policy_id: int = 0,
-                 policy_versions: Optional[torch.Tensor] = None, sample_seed: int = 0):
+                 policy_versions: Optional[torch.Tensor] = None, sample_seed: int = 0, row0: int = 0):
         self.cfg, self.env_info, self.env, self.ac = cfg, env_info, env, actor_critic
         self.traj = traj
         self.policy_id = policy_id
@@ -37,6 +37,7 @@ class BatchedVectorEnvRunner:
         self.ep_len = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)  # sum_return, sum_len, episodes
         self.sample_seed = int(sample_seed)
+        self.row0 = int(row0)  # global index of this replica's first env (Philox key of the action sampler)
         self.global_step = 0
         self.zero_copy = hasattr(env, "step_into")
         self.obs = traj["obs"]["obs"]
@@ -71,7 +72,7 @@ class BatchedVectorEnvRunner:
             rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
             heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf", rnn=rnn)[-1]
             lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
-                                  self.global_step, 0, ver, deterministic, tr["actions"], tr["action_logits"],
+                                  self.global_step, self.row0, ver, deterministic, tr["actions"], tr["action_logits"],
                                   tr["log_prob_actions"], tr["values"], tr["policy_version"],
                                   None if self.continuous else self.env_actions, action_kind=int(self.continuous))
             env_actions = tr["actions"][:, t] if self.continuous else self.env_actions  # Box: f32 [B, D] view

@@ -44,11 +44,13 @@ class Runner:
 
     def init(self) -> int:
         cfg = self.cfg
-        if self.world > 1 and not torch.distributed.is_initialized():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-            torch.distributed.init_process_group("nccl")
+        if self.world > 1:
+            if not torch.distributed.is_initialized():
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+                torch.distributed.init_process_group(os.environ.get("SF_DP_BACKEND", "nccl"))  # nccl = RCCL on ROCm
             cfg.data_parallel = True
-            cfg.synthetic_env0 = self.rank * getattr(cfg, "synthetic_num_agents", 4096)
+            if getattr(cfg, "synthetic_env0", None) in (None, 0):  # env shard of this replica (weak scaling)
+                cfg.synthetic_env0 = self.rank * getattr(cfg, "synthetic_num_agents", 4096)
         env_config = AttrDict(worker_index=0, vector_index=0, env_id=0)
         self.env = create_env(cfg.env, cfg, env_config)
         self.env_info = extract_env_info(self.env, cfg)
@@ -59,8 +61,11 @@ class Runner:
         self.learner.init()
         dev = self.learner.device
         self.traj = alloc_trajectory_tensors(self.env_info, self.env_info.num_agents, cfg.rollout, get_rnn_size(cfg), dev)
+        # one sampling stream for the whole job: key = (seed, global env row) -> a G-replica rollout is bit-identical to
+        # the single-replica rollout of the concatenated env set
         self.sampler = BatchedVectorEnvRunner(cfg, self.env_info, self.env, self.learner.actor_critic, self.traj, 0,
-                                              self.policy_versions, sample_seed=(cfg.seed or 0) + 1000003 * self.rank)
+                                              self.policy_versions, sample_seed=(cfg.seed or 0),
+                                              row0=self.rank * self.env_info.num_agents)
         return ExperimentStatus.SUCCESS
 
     def iteration(self):
