@@ -11,7 +11,7 @@ ROCm; the same code runs over gloo on CPU tensors (tests/test_dp_gloo.py).
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.distributed as dist

@@ -24,7 +24,6 @@ from __future__ import annotations
 
 import glob
 import os
-import time
 from os.path import join
 from typing import Dict, List, Optional, Tuple
 
@@ -197,11 +196,7 @@ class Learner:
         A = calc_num_action_parameters(self.env_info.action_space)
         self.num_action_params = A
         self.num_actions = calc_num_actions(self.env_info.action_space)
-        self.loss_cfg = lib.sf_loss_cfg(
-            clip_ratio=cfg.ppo_clip_ratio, clip_value=cfg.ppo_clip_value, value_loss_coeff=cfg.value_loss_coeff,
-            exploration_coeff=cfg.exploration_loss_coeff, kl_coeff=cfg.kl_loss_coeff,
-            exploration_kind=0 if cfg.exploration_loss_coeff == 0.0 else (1 if cfg.exploration_loss == "entropy" else 2),
-            action_kind=0 if is_discrete(self.env_info.action_space) else 1, dense_adv=int(bool(cfg.with_vtrace)))
+        self._refresh_loss_cfg()
         self.load_from_checkpoint(self.policy_id)
         self.param_server.init(self.actor_critic, self.train_step, self.device)
         self.policy_versions_tensor[self.policy_id] = self.train_step
@@ -284,6 +279,45 @@ class Learner:
         cp = self.load_checkpoint(cps, self.device)
         if cp is not None:
             self._load_state(cp, load_progress)
+
+    # ------------------------------------------------------------------------------------------ PBT hooks
+    def set_new_cfg(self, new_cfg: Dict) -> None:
+        """learner.py:388-389 — population-based training hands over mutated hyper-parameters"""
+        self.new_cfg = new_cfg
+
+    def set_policy_to_load(self, policy_to_load) -> None:
+        """learner.py:391-392"""
+        self.policy_to_load = policy_to_load
+
+    def _refresh_loss_cfg(self) -> None:
+        cfg = self.cfg
+        self.loss_cfg = lib.sf_loss_cfg(
+            clip_ratio=cfg.ppo_clip_ratio, clip_value=cfg.ppo_clip_value, value_loss_coeff=cfg.value_loss_coeff,
+            exploration_coeff=cfg.exploration_loss_coeff, kl_coeff=cfg.kl_loss_coeff,
+            exploration_kind=0 if cfg.exploration_loss_coeff == 0.0 else (1 if cfg.exploration_loss == "entropy" else 2),
+            action_kind=0 if is_discrete(self.env_info.action_space) else 1, dense_adv=int(bool(cfg.with_vtrace)))
+
+    def _maybe_update_cfg(self) -> None:
+        """learner.py:394-413: apply the new values; a PBT-optimised learning rate only with the constant schedule.
+        Loss coefficients and Adam betas are read from cfg at every SGD step, so only the packed loss struct and
+        curr_lr need refreshing."""
+        if self.new_cfg is None:
+            return
+        for key, value in self.new_cfg.items():
+            setattr(self.cfg, key, value)
+        if self.cfg.lr_schedule == "constant" and self.curr_lr != self.cfg.learning_rate:
+            self.curr_lr = self.cfg.learning_rate
+        self._refresh_loss_cfg()
+        self.new_cfg = None
+
+    def _maybe_load_policy(self) -> None:
+        """learner.py:415-428: take another policy's weights (not its progress) and invalidate in-flight experience"""
+        if self.policy_to_load is None:
+            return
+        self.load_from_checkpoint(self.policy_to_load, load_progress=False)
+        self.train_step += self.cfg.max_policy_lag + 1
+        self.policy_versions_tensor[self.policy_id] = self.train_step
+        self.policy_to_load = None
 
     # ------------------------------------------------------------------------------------------ batch preparation
     def _prepare_batch(self, batch: TensorDict) -> Tuple[AttrDict, int, int]:
@@ -471,6 +505,8 @@ class Learner:
 
     def train(self, batch: TensorDict) -> Optional[Dict]:
         """learner.py:1036-1067"""
+        self._maybe_update_cfg()
+        self._maybe_load_policy()
         buff, experience_size, num_invalids = self._prepare_batch(batch)
         if self._global_invalids >= experience_size * self.world:
             return None

@@ -627,6 +627,11 @@ def test_end_to_end_rollout_and_train_small(lib):
     np.testing.assert_array_equal(tr["obs"]["obs"][:, 0].cpu().numpy().reshape(64, -1), oracle.synth_obs(64, 0, 28224, 1, 24))
     s = runner.sampler.episode_stats()
     assert s["episodes"] >= 0
+    # PBT hooks (learner.py:388-428): new hyper-parameters are picked up at the next train() call
+    runner.learner.set_new_cfg(dict(learning_rate=3e-4, exploration_loss_coeff=0.02, ppo_clip_ratio=0.2))
+    runner.iteration()
+    assert runner.learner.curr_lr == 3e-4 and abs(runner.learner.loss_cfg.exploration_coeff - 0.02) < 1e-9
+    assert abs(runner.learner.loss_cfg.clip_ratio - 0.2) < 1e-7 and runner.learner.new_cfg is None
 
 
 def test_cartpole_learns(lib):
