@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
+    ap.add_argument("--async_rl", action="store_true", help="overlap rollout k+1 with train(k) (policy lag of one dataset)")
     args = ap.parse_args()
 
     import torch
@@ -74,7 +75,7 @@ def main():
         normalize_returns=True, rollout=T, batch_size=B * T // args.num_batches, num_batches_per_epoch=args.num_batches,
         num_epochs=args.num_epochs, gamma=0.99, gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0,
         value_loss_coeff=0.5, exploration_loss_coeff=0.01, max_grad_norm=4.0, learning_rate=1e-4, adam_eps=1e-6,
-        async_rl=False, serial_mode=True, batched_sampling=True, num_workers=1, num_envs_per_worker=1,
+        async_rl=args.async_rl, serial_mode=not args.async_rl, batched_sampling=True, num_workers=1, num_envs_per_worker=1,
         worker_num_splits=1, env_gpu_observations=True, env_gpu_actions=True, actor_worker_gpus=[0], seed=0,
         synthetic_num_agents=B, synthetic_env0=rank * B, data_parallel=world > 1)
     cfg, runner = make_runner(cfg)
@@ -153,7 +154,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[1]: synthetic vector env {B} envs/GPU, 84x84x4 u8 obs, "
-                               f"Discrete(6), Nature-CNN actor-critic (1,687,719 params), APPO sync, rollout={T}, "
+                               f"Discrete(6), Nature-CNN actor-critic (1,687,719 params), APPO "
+                               f"{'async (rollout k+1 || train k)' if args.async_rl else 'sync'}, rollout={T}, "
                                f"batch_size={cfg.batch_size} x {args.num_batches} minibatches x {args.num_epochs} epoch(s)",
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
                    "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},

@@ -338,7 +338,7 @@ class Learner:
         # K9: bootstrap value of the T+1-th observation, read from the slab in place
         last = obs[:, T]
         rnn = dict(states=batch["rnn_states"][:, T]) if cfg.use_rnn else None
-        heads = ac.forward_heads(last, E, sample_stride=obs.stride(0), tag="inf", rnn=rnn)[-1]
+        heads = ac.forward_heads(last, E, sample_stride=obs.stride(0), tag="boot", rnn=rnn)[-1]  # learner weights
         batch["values"][:, T].copy_(heads[:, 0])
         adv = torch.empty((E, T), dtype=torch.float32, device=self.device)
         ret = torch.empty((E, T), dtype=torch.float32, device=self.device)

@@ -92,6 +92,17 @@ class BatchedVectorEnvRunner:
                 torch.mul(self.ac.new_rnn_states, keep, out=tr["rnn_states"][:, t + 1])
             self.global_step += 1
 
+    def set_slab(self, traj: TensorDict, carry_from: Optional[TensorDict] = None) -> None:
+        """async mode: switch to another slab; its step 0 continues from the last step of `carry_from`"""
+        self.traj = traj
+        self.obs = traj["obs"]["obs"]
+        if carry_from is not None:
+            self.obs[:, 0].copy_(carry_from["obs"]["obs"][:, self.T])
+            if self.rnn:
+                traj["rnn_states"][:, 0].copy_(carry_from["rnn_states"][:, self.T])
+        elif self.rnn:
+            traj["rnn_states"][:, 0].zero_()
+
     def carry_over(self) -> None:
         """The next rollout starts from the last observation: slab obs[:, 0] <- obs[:, T] (one frame per agent)."""
         self.obs[:, 0].copy_(self.obs[:, self.T])

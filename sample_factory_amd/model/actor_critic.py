@@ -218,7 +218,9 @@ class ActorCritic:
         if cfg.normalize_returns:
             self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
         self._bufs: Dict = {}
-        self._ws: Optional[torch.Tensor] = None
+        self._wss: Dict = {}
+        self._role = "learner"
+        self._snap = None
         self.initialize_weights()
 
     # ------------------------------------------------------------------------------------------ reference surface
@@ -357,17 +359,48 @@ class ActorCritic:
         return t
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-        return self._ws
+        """split-K / wgrad scratch; one per stream role so that the rollout and learner streams never share it"""
+        key = self._role
+        ws = self._wss.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._wss[key] = ws
+        return ws
 
-    def _gemm(self, L, x, stride, index, offset, traj_T, out, n):
+    # ---- async mode (cfg.async_rl): inference reads a published SNAPSHOT of the weights (K20).  The reference copies
+    # the state_dict into every inference worker under policy_lock (model_sharing.py:128-143); here the learner
+    # ping-pongs two device copies so a rollout never sees a half-updated buffer and nothing blocks.
+    def enable_weight_snapshots(self) -> None:
+        self._snap = [self.flat_params.clone(), self.flat_params.clone()]
+        self._snap_views = []
+        for buf in self._snap:
+            self._snap_views.append([(buf[o:o + L.K * L.N].view(L.K, L.N), buf[ob:ob + L.N])
+                                     for L, (o, ob) in zip(self.layers, self._segs)])
+        self.snap_read = 0
+        on = self.obs_normalizer
+        self._snap_tabs = [(on.mu_tab.clone(), on.rstd_tab.clone()) for _ in range(2)] if on is not None else None
+
+    def publish_weights(self, slot: int) -> None:
+        self._snap[slot].copy_(self.flat_params)
+        if self._snap_tabs is not None:
+            self._snap_tabs[slot][0].copy_(self.obs_normalizer.mu_tab)
+            self._snap_tabs[slot][1].copy_(self.obs_normalizer.rstd_tab)
+
+    def _wb(self, li, tag):
+        if tag == "inf" and self._snap is not None:
+            return self._snap_views[self.snap_read][li]
+        L = self.layers[li]
+        return L.w, L.b
+
+    def _gemm(self, li, x, stride, index, offset, traj_T, out, n, tag):
+        L = self.layers[li]
         d = L.desc
         if traj_T:
             d = lib.sf_conv_desc.from_buffer_copy(L.desc)
             d.traj_T = int(traj_T)
+        w, b = self._wb(li, tag)
         wsb = lib.conv_fwd_workspace(n, d) if index is None and not traj_T else 0  # split-K for chip-starving launches
-        lib.conv_fwd_raw(x, stride, index, offset, L.w, L.b, out, n, d, self._workspace(wsb) if wsb else None)
+        lib.conv_fwd_raw(x, stride, index, offset, w, b, out, n, d, self._workspace(wsb) if wsb else None)
 
     def forward_heads(self, obs: torch.Tensor, n: int, *, sample_stride: int, index=None, offset: int = 0,
                       traj_T: int = 0, tag="inf", rnn=None) -> List[torch.Tensor]:
@@ -380,10 +413,12 @@ class ActorCritic:
         """
         acts: List[Optional[torch.Tensor]] = [None] * len(self.layers)
         inputs: List[Optional[torch.Tensor]] = [None] * len(self.layers)
+        self._role = "rollout" if tag == "inf" else "learner"
         x, stride, idx, off, tT = obs, sample_stride, index, offset, traj_T
         if self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
             xn = self._buf((tag, "obsn"), (n, self.obs_elems))
-            self.obs_normalizer.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T)
+            tabs = self._snap_tabs[self.snap_read] if (tag == "inf" and self._snap is not None) else None
+            self.obs_normalizer.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T, tabs=tabs)
             x, stride, idx, off, tT = xn, self.obs_elems, None, 0, 0
         first_in = (x, stride, idx, off, tT)
         seq = rnn is not None and "R" in rnn
@@ -397,7 +432,7 @@ class ActorCritic:
                 x = xt
             inputs[li] = x
             out = self._buf((tag, li), (n * L.out_pixels, L.N))
-            self._gemm(L, x, stride, idx, off, tT, out, n)
+            self._gemm(li, x, stride, idx, off, tT, out, n, tag)
             acts[li] = out
             x = out
             if L.role == "rnn_ih":
@@ -414,7 +449,8 @@ class ActorCritic:
         st = rnn["states"]
         assert st.shape == (n, S) and st.stride(1) == 1
         gh = self._buf((tag, "gh"), (n, Lh.N))
-        lib.conv_fwd_raw(st, st.stride(0), None, 0, Lh.w, Lh.b, gh, n, Lh.desc)
+        w_hh, b_hh = self._wb(li + 1, tag)
+        lib.conv_fwd_raw(st, st.stride(0), None, 0, w_hh, b_hh, gh, n, Lh.desc)
         h_out = self._buf((tag, "h_out"), (n, H))
         c_out = self._buf((tag, "c_out"), (n, H)) if kind == 1 else None
         lib.rnn_cell_fwd(kind, gx, gh, st, st.stride(0), st[:, H:] if kind == 1 else None, st.stride(0), None, n, H,
@@ -500,6 +536,7 @@ class ActorCritic:
         """Back-propagate d(loss)/d(heads) [n, heads_ld] through the stack of the last "train" forward into
         self.flat_grads (overwritten)."""
         ctx = self._ctx["train"]
+        self._role = "learner"
         inputs = ctx["inputs"]
         x0, stride0, idx0, off0, tT0 = ctx["first_in"]
         g = g_heads

@@ -66,13 +66,55 @@ class Runner:
         self.sampler = BatchedVectorEnvRunner(cfg, self.env_info, self.env, self.learner.actor_critic, self.traj, 0,
                                               self.policy_versions, sample_seed=(cfg.seed or 0),
                                               row0=self.rank * self.env_info.num_agents)
+        if cfg.async_rl:  # rollout k+1 overlaps Learner.train(k): two slabs, two streams, published weight snapshots
+            self.traj2 = alloc_trajectory_tensors(self.env_info, self.env_info.num_agents, cfg.rollout,
+                                                  get_rnn_size(cfg), dev)
+            self.slabs = [self.traj, self.traj2]
+            self.rollout_stream = torch.cuda.Stream()
+            self.ev_rollout = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_train = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_publish = torch.cuda.Event()
+            self.learner.actor_critic.enable_weight_snapshots()
+            self.k = 0
+            self.published_version = float(self.learner.train_step)
         return ExperimentStatus.SUCCESS
 
     def iteration(self):
         """one dataset: rollout of all envs, then Learner.train on the slab in place"""
+        if self.cfg.async_rl:
+            return self.iteration_async()
         self.sampler.rollout(policy_version=float(self.learner.train_step))
         stats = self.learner.train(self.traj)
         self.sampler.carry_over()
+        return stats
+
+    def iteration_async(self):
+        """Asynchronous APPO as stream-level overlap (the reference's async mode is process-level: batcher.py:214-218,
+        inference_worker.py:175-181).  Iteration k enqueues rollout k on the rollout stream (reading weight snapshot
+        k % 2, i.e. the weights after train(k-2): policy lag of one dataset, recorded in policy_version as the
+        reference does) and then trains on the slab of rollout k-1 on the main stream.  Slab / snapshot hand-offs are
+        HIP events; the only host syncs are the learner's own (one per dataset, one per epoch)."""
+        k, ac = self.k, self.learner.actor_critic
+        cur, prev = self.slabs[k % 2], self.slabs[(k + 1) % 2]
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.rollout_stream):
+            if k >= 2:
+                self.rollout_stream.wait_event(self.ev_train[k % 2])   # the learner is done with this slab ...
+            if k >= 1:
+                self.rollout_stream.wait_event(self.ev_publish)        # ... and snapshot k % 2 is complete
+            ac.snap_read = k % 2
+            self.sampler.set_slab(cur, carry_from=prev if k >= 1 else None)
+            self.sampler.rollout(policy_version=self.published_version)
+            self.ev_rollout[k % 2].record(self.rollout_stream)
+        stats = None
+        if k >= 1:
+            main.wait_event(self.ev_rollout[(k + 1) % 2])
+            stats = self.learner.train(prev)
+            ac.publish_weights((k + 1) % 2)                            # read by rollout k+1
+            self.ev_publish.record(main)
+            self.ev_train[(k + 1) % 2].record(main)
+            self.published_version = float(self.learner.train_step)
+        self.k += 1
         return stats
 
     def run(self) -> int:

@@ -52,9 +52,10 @@ class ObservationNormalizer:
         self.count, self._count2 = self._count2, self.count
 
     def apply(self, obs: torch.Tensor, stride: int, n: int, out: torch.Tensor, index=None, offset: int = 0,
-              traj_T: int = 0) -> None:
+              traj_T: int = 0, tabs=None) -> None:
+        mu, rstd = tabs if tabs is not None else (self.mu_tab, self.rstd_tab)  # tabs: published snapshot (async mode)
         lib.obsnorm_apply(obs, self.obs_u8, stride, index, offset, traj_T, n, self.D, self.C, self.HW, self.sub_mean,
-                          self.inv_scale, self.mu_tab, self.rstd_tab, out)
+                          self.inv_scale, mu, rstd, out)
 
     def state_dict(self, prefix="obs_normalizer.running_mean_std.running_mean_std.obs."):
         return {prefix + "running_mean": self.mean.detach().cpu().view(self.obs_shape).clone(),

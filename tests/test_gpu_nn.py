@@ -634,6 +634,47 @@ def test_end_to_end_rollout_and_train_small(lib):
     assert abs(runner.learner.loss_cfg.clip_ratio - 0.2) < 1e-7 and runner.learner.new_cfg is None
 
 
+@pytest.mark.parametrize("variant", ["ff", "gru_norm"])
+def test_async_rl_two_streams_equal_same_schedule_on_one_stream(lib, variant):
+    """cfg.async_rl: rollout k+1 on its own stream overlaps Learner.train(k) (two slabs, published weight snapshots).
+    The overlapped run must be bit-identical to the same schedule issued on ONE stream (any missing event / shared
+    scratch buffer / torn snapshot would show up as a difference), and the recorded policy lag is one dataset."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_atari", make_synthetic_env)
+    extra = dict(use_rnn=True, rnn_type="gru", rnn_size=64, normalize_input=True) if variant == "gru_norm" else \
+        dict(use_rnn=False, normalize_input=False)
+
+    def run(one_stream):
+        cfg = default_cfg(env="synthetic_atari", nonlinearity="relu", obs_scale=255.0,
+                          encoder_conv_architecture="convnet_atari", rollout=8, batch_size=1024, num_batches_per_epoch=2,
+                          num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=True, seed=3, serial_mode=False,
+                          synthetic_num_agents=256, shuffle_minibatches=True, **extra)
+        cfg, runner = make_runner(cfg)
+        runner.init()
+        if one_stream:
+            runner.rollout_stream = torch.cuda.current_stream()
+        stats = None
+        for _ in range(6):
+            stats = runner.iteration() or stats
+        torch.cuda.synchronize()
+        return runner, stats
+
+    ra, sa = run(False)
+    rb, sb = run(True)
+    assert ra.rollout_stream != torch.cuda.current_stream()
+    assert torch.equal(ra.learner.actor_critic.flat_params, rb.learner.actor_critic.flat_params)
+    for k in ("actions", "rewards", "values", "policy_version", "rnn_states"):
+        assert torch.equal(ra.slabs[1][k], rb.slabs[1][k]), k
+    assert sa["train"]["loss"] == sb["train"]["loss"] and np.isfinite(sa["train"]["loss"])
+    assert sa["learner_env_steps"] == 5 * 256 * 8            # 6 iterations = 6 rollouts, 5 trained datasets
+    # rollout 5 (slab 1) ran on the weights published after train(3): 4 datasets * 2 SGD steps; the learner was one
+    # dataset ahead when it trained on it -> lag of 2 SGD steps, as async APPO records (inference_worker.py:313-330)
+    assert (ra.slabs[1]["policy_version"] == 8.0).all() and ra.learner.train_step == 10
+
+
 def test_cartpole_learns(lib):
     """BASELINE.json configs[0] as a learning test (the reference's own end-to-end check is a learning test too,
     tests/examples/test_example.py:159-174): host CartPole env, MLP policy, sync APPO on the GPU; the mean episode length
