@@ -28,7 +28,7 @@ PEAK_HBM_GBS = 8000.0
 
 def kernel_flops(key):
     """algorithmic FLOPs of one launch of a network kernel (2*M*N*K of the implicit GEMM)"""
-    op, n, Cin, H, W, Cout, K, S, OH, OW = key
+    op, n, Cin, H, W, Cout, K, S, OH, OW = key[:10]
     return 2.0 * n * OH * OW * Cout * (K * K * Cin)  # fwd, wgrad and (gather-form, no zero taps) dgrad are equal
 
 
@@ -101,8 +101,12 @@ def main():
     if not args.no_kernel_events:
         if not warm_prof:
             raise SystemExit("need --warmup >= 1 to rank kernels (or pass --no_kernel_events)")
-        ranked = sorted(((sum(s.elapsed_time(e) for s, e in evs), key) for key, evs in warm_prof.items()), reverse=True)
-        lib.PROFILE, lib.PROFILE_ONLY = {}, {ranked[0][1]}
+        # "kernel" = one instantiation (key[-1], the name rocprofv3 prints), summed over the shapes it is launched at
+        by_name = {}
+        for key, evs in warm_prof.items():
+            by_name[key[-1]] = by_name.get(key[-1], 0.0) + sum(s_.elapsed_time(e_) for s_, e_ in evs)
+        dominant = max(by_name, key=by_name.get)
+        lib.PROFILE, lib.PROFILE_ONLY = {}, {key for key in warm_prof if key[-1] == dominant}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -121,33 +125,42 @@ def main():
         if rank == 0:
             print(json.dumps({"value": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": world}))
         return
-    # ---- roofline of the dominant kernel (largest total time among the network kernels, HIP events, timed region)
-    (key, evs), = prof.items()
-    ms = [s.elapsed_time(e) for s, e in evs]
-    total_ms, launches, avg_ms = sum(ms), len(ms), sum(ms) / len(ms)
-    achieved = kernel_flops(key) / (avg_ms * 1e-3) / 1e12
-    label = f"{key[0]}:{key[2]}x{key[3]}->{key[5]} n={key[1]}"
+    # ---- roofline of the dominant kernel instantiation (largest total time; HIP events over the timed region).
+    # achieved = mean algorithmic FLOPs per launch / mean launch duration = sum(flops) / sum(duration) over its launches;
+    # avg_launch_ms is directly comparable with AverageNs of the same name in profiles/r01_*_kernel_stats.csv
+    total_ms, launches, flops, shapes = 0.0, 0, 0.0, []
+    for key, evs in prof.items():
+        ms = [s_.elapsed_time(e_) for s_, e_ in evs]
+        total_ms += sum(ms)
+        launches += len(ms)
+        flops += kernel_flops(key) * len(ms)
+        shapes.append({"shape": f"{key[0]}:{key[2]}x{key[3]}->{key[5]} n={key[1]}", "launches": len(ms),
+                       "avg_ms": round(sum(ms) / len(ms), 4),
+                       "tflops": round(kernel_flops(key) / (sum(ms) / len(ms) * 1e-3) / 1e12, 1)})
+    shapes.sort(key=lambda d: -d["avg_ms"] * d["launches"])
+    avg_ms = total_ms / launches
+    achieved = flops / (total_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     tj = os.path.join(ROOT, "profiles", "r01_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench
     if os.path.exists(tj):
-        ent = json.load(open(tj)).get(label)
+        ent = json.load(open(tj)).get(dominant)
         if ent:
             traffic, traffic_src = ent["hbm_bytes"], "profiles/r01_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
     kern = []  # ranking of all network kernels from the instrumented warm-up step (NOT the timed region)
     for k2, evs2 in warm_prof.items():
-        m2 = [s.elapsed_time(e) for s, e in evs2]
+        m2 = [s_.elapsed_time(e_) for s_, e_ in evs2]
         kern.append((sum(m2), k2, len(m2), sum(m2) / len(m2)))
-    kern.sort(reverse=True)
-    roofline = {"bound": "mfma", "kernel": f"sf_conv_{key[0]} n={key[1]} Cin={key[2]} HxW={key[3]}x{key[4]} Cout={key[5]} "
-                                           f"k={key[6]} s={key[7]}",
-                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(avg_ms, 4),
-                "launches": launches, "share_of_step_time": round(total_ms / (dt * 1e3), 4)}
+    kern.sort(reverse=True, key=lambda k: k[0])
+    roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                "gflop_per_launch": round(flops / launches / 1e9, 3),
+                "share_of_step_time": round(total_ms / (dt * 1e3), 4), "shapes": shapes}
     net_ms = sum(k[0] for k in kern)
     net_flops = sum(kernel_flops(k[1]) * k[2] for k in kern)
-    breakdown = [{"kernel": f"{k[1][0]}:{k[1][2]}x{k[1][3]}->{k[1][5]} n={k[1][1]}", "ms_total": round(k[0], 2),
-                  "launches": k[2], "tflops": round(kernel_flops(k[1]) / (k[3] * 1e-3) / 1e12, 1)} for k in kern[:12]]
+    breakdown = [{"kernel": f"{k[1][0]}:{k[1][2]}x{k[1][3]}->{k[1][5]} n={k[1][1]}", "name": k[1][-1],
+                  "ms_total": round(k[0], 2), "launches": k[2],
+                  "tflops": round(kernel_flops(k[1]) / (k[3] * 1e-3) / 1e12, 1)} for k in kern[:12]]
 
     out = {
         "metric": "env-steps/sec (whole node), 4096 envs, 84x84x4 obs", "value": round(value, 1), "unit": "env-steps/s",

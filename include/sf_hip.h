@@ -236,6 +236,10 @@ int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index
  * i.e. the previous layer's post-activation output, kind = h_desc->relu; NULL = no activation derivative). */
 int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                   const sf_conv_desc *h_desc, void *stream);
+
+/* Profiling aid (no reference counterpart): the kernel instantiation a conv/linear launch resolves to, spelled as
+ * rocprofv3 prints it ("k_conv_fwd<128, 64, 2, 2, 0>").  op: 0 forward, 1 wgrad, 2 dgrad. */
+int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *desc, int split_k_allowed, char *out, int cap);
 /* dense layer: out[M,N] = act(in[M,K] * w[K,N] + bias); wgrad: dw[K,N] = in^T dout, db = colsum(dout);
  * dgrad: din[M,K] = (dout[M,N] * w^T) * relu_mask(in_act). */
 int sf_linear_fwd(const float *in, const float *w, const float *bias, float *out, int64_t M, int K, int N, int relu,

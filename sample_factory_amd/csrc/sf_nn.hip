@@ -847,6 +847,35 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     return sf_launch_status("sf_conv_dgrad");
 }
 
+// Name of the kernel instantiation a launch with these arguments resolves to (aligned operands assumed), spelled the
+// way rocprofv3 prints it, so that bench.py can group its HIP-event timings exactly like the rocprof kernel stats.
+extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc, int split_k_allowed, char *out,
+                                   int cap) {
+    int rc = check_desc(h_desc, "sf_conv_kernel_name");
+    if (rc) return rc;
+    SF_REQUIRE(out && cap >= 48 && n > 0 && op >= 0 && op <= 2, "sf_conv_kernel_name: bad args");
+    const ConvG g = make_geom(h_desc);
+    const int64_t Mtot = n * g.OH * g.OW;
+    const int mode = pick_mode(g);
+    if (op == 0) {
+        const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, split_k_allowed ? (int64_t)1 << 60 : 0);
+        const bool big32 = p.splits == 1 && Mtot >= 256 * 2048;
+        if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
+        else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
+    } else if (op == 1) {
+        if (wgrad_bn(g.Cout) == 32) snprintf(out, cap, "k_conv_wgrad<32, 4, 1, %d>", mode);
+        else snprintf(out, cap, "k_conv_wgrad<64, 2, 2, %d>", mode);
+    } else {
+        const int Hc = (g.H + g.S - 1) / g.S, Wc = (g.W + g.S - 1) / g.S;
+        const int64_t Mc = n * Hc * Wc;
+        const char *v = g.vecB ? "true" : "false";
+        if (g.Cin <= 32) snprintf(out, cap, "k_conv_dgrad<128, 32, 4, 1, %s>", v);
+        else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) snprintf(out, cap, "k_conv_dgrad<64, 64, 2, 2, %s>", v);
+        else snprintf(out, cap, "k_conv_dgrad<128, 64, 2, 2, %s>", v);
+    }
+    return SF_OK;
+}
+
 // ---- dense layers = 1x1 conv on a 1x1 image
 static sf_conv_desc linear_desc(int K, int N, int relu) {
     sf_conv_desc d;

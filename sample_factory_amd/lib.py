@@ -38,7 +38,8 @@ SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
     "sf_adam_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
-    "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_linear_fwd",
+    "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_conv_kernel_name",
+    "sf_linear_fwd",
     "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
 
@@ -52,7 +53,8 @@ PROFILE_ONLY: Optional[set] = None  # when set, only these keys are timed (bench
 
 class _timed:
     def __init__(self, key):
-        self.key = key if PROFILE is not None and (PROFILE_ONLY is None or key in PROFILE_ONLY) else None
+        self.key = key if PROFILE is not None and key is not None and \
+            (PROFILE_ONLY is None or key in PROFILE_ONLY) else None
 
     def __enter__(self):
         if self.key is not None:
@@ -68,8 +70,25 @@ class _timed:
         return False
 
 
+_OPS = {"fwd": 0, "wgrad": 1, "dgrad": 2}
+_names: dict = {}
+
+
 def _dkey(op, n, d):
-    return (op, int(n), d.Cin, d.H, d.W, d.Cout, d.KH, d.stride, d.OH, d.OW)
+    """profiling key of a network launch: (op, n, geometry..., kernel instantiation name as rocprofv3 prints it)"""
+    if PROFILE is None:
+        return None
+    k = (op, int(n), d.Cin, d.H, d.W, d.Cout, d.KH, d.stride, d.OH, d.OW, d.in_u8)
+    name = _names.get(k)
+    if name is None:
+        name = _names[k] = conv_kernel_name(_OPS[op], n, d)
+    return k[:-1] + (name,)
+
+
+def conv_kernel_name(op: int, n: int, desc) -> str:
+    buf = C.create_string_buffer(96)
+    _check(load().sf_conv_kernel_name(int(op), i64(n), C.byref(desc), 1, buf, 96), "sf_conv_kernel_name")
+    return buf.value.decode()
 
 
 def load() -> C.CDLL:

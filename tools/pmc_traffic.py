@@ -43,6 +43,21 @@ def main():
                     out[f"{op}:{stem} n={n}"] = dict(fetch_kib=round(fetch[k], 1), write_kib=round(write[k], 1),
                                                      hbm_bytes=int((2 * fetch[k] + write[k]) * 1024), launches=cnt[k],
                                                      kernel=k[0][:60], grid=k[1])
+    # per kernel INSTANTIATION (bench.py's roofline object): mean HBM bytes per launch over every launch of that name
+    f_all, w_all, n_all = collections.defaultdict(float), collections.defaultdict(float), collections.defaultdict(int)
+    for r in csv.DictReader(open(sys.argv[1])):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            f_all[r["Kernel_Name"]] += float(r["Counter_Value"])
+            n_all[r["Kernel_Name"]] += 1
+    for r in csv.DictReader(open(sys.argv[2])):
+        if r["Counter_Name"] == "WRITE_SIZE":
+            w_all[r["Kernel_Name"]] += float(r["Counter_Value"])
+    for name, nl in n_all.items():
+        if "k_conv_" not in name:
+            continue
+        short = name.replace("void ", "").split("(")[0]
+        out[short] = dict(fetch_kib_per_launch=round(f_all[name] / nl, 1), write_kib_per_launch=round(w_all[name] / nl, 1),
+                          hbm_bytes=int((2 * f_all[name] + w_all[name]) / nl * 1024), launches=nl)
     # wgrad: one launch per layer per minibatch, identified by the layer's K*N partial size pattern (largest fetch first)
     wg = sorted(((fetch.get(k, 0), k) for k in write if "k_conv_wgrad<" in k[0]), reverse=True)
     out["_wgrad_unmatched"] = [dict(kernel=k[0][:60], grid=k[1], fetch_kib=round(f, 1), write_kib=round(write[k], 1)) for f, k in wg]
