@@ -237,6 +237,15 @@ int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index
 int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                   const sf_conv_desc *h_desc, void *stream);
 
+/* Forward for the dense hot layers through the gfx950 LDS-DMA path: same result contract as sf_conv_fwd, but the
+ * weights are given Cout-major, wt[Cout, K] (sf_transpose of the canonical [K, Cout] array), the input must be f32
+ * NHWC with Cin % 32 == 0, dense samples (no index gather), 16-byte aligned.  sf_conv_fwd_t_supported says whether a
+ * launch qualifies (and is large enough to be worth it); everything else goes through sf_conv_fwd. */
+int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *desc);
+int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
+                  int64_t n, const sf_conv_desc *desc, void *stream);
+int sf_transpose(const float *w, float *wt, int K, int N, void *stream); /* wt[N,K] = w[K,N]^T */
+
 /* Profiling aid (no reference counterpart): the kernel instantiation a conv/linear launch resolves to, spelled as
  * rocprofv3 prints it ("k_conv_fwd<128, 64, 2, 2, 0>").  op: 0 forward, 1 wgrad, 2 dgrad. */
 int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *desc, int split_k_allowed, char *out, int cap);

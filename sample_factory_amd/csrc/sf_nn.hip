@@ -20,6 +20,7 @@
 // from a clamped, always-valid address and are zeroed with a select, so the compiler issues every global load of a
 // chunk back-to-back and waits once (the first version branched per load and hipcc serialised them with vmcnt(0)).
 #include "sf_common.h"
+#include <stdlib.h>
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -660,6 +661,8 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
         if (!(act[i] > 0.f)) gsrc[i] = 0.f;
 }
 
+#include "sf_nn_glds.h"
+
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
@@ -744,6 +747,43 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
             partial, bias, out, MN, g.Cout, p.splits, g.relu);
     }
     return sf_launch_status("sf_conv_fwd");
+}
+
+// ---- glds forward (pre-transposed weights)
+static bool glds_fwd_ok(const sf_conv_desc *d) {
+    return !d->in_u8 && d->Cin % 32 == 0 && d->traj_T == 0;
+}
+extern "C" int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *h_desc) {
+    if (!h_desc || n <= 0 || !glds_fwd_ok(h_desc)) return 0;
+    // small grids keep the split-K register-staged kernel (a 128-row tile grid must fill 256 CUs a few times over)
+    const int64_t Mtot = n * h_desc->OH * h_desc->OW;
+    return ((Mtot + 127) / 128) * ((h_desc->Cout + 63) / 64) >= 768;
+}
+#define GLDS_FWD(BM, BN, WM, WN)                                                                              \
+    k_fwd_glds<BM, BN, WM, WN><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN)), dim3(256), 0, STREAM(stream)>>>( \
+        g, in, in_sample_stride, wt, bias, out, Mtot)
+extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
+                             int64_t n, const sf_conv_desc *h_desc, void *stream) {
+    int rc = check_desc(h_desc, "sf_conv_fwd_t");
+    if (rc) return rc;
+    SF_REQUIRE(in && wt && out && n > 0, "sf_conv_fwd_t: bad args");
+    SF_REQUIRE(glds_fwd_ok(h_desc), "sf_conv_fwd_t: needs f32 NHWC input with Cin %% 32 == 0 (use sf_conv_fwd)");
+    SF_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)wt & 15) == 0 && in_sample_stride % 4 == 0,
+               "sf_conv_fwd_t: operands must be 16-byte aligned");
+    const ConvG g = make_geom(h_desc);
+    const int64_t Mtot = n * g.OH * g.OW;
+    SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd_t: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
+    static const int cfg = getenv("SF_GLDS_CFG") ? atoi(getenv("SF_GLDS_CFG")) : 0;
+    if (cfg == 1) GLDS_FWD(256, 64, 4, 1);
+    else if (cfg == 2) GLDS_FWD(128, 128, 2, 2);
+    else if (cfg == 3) GLDS_FWD(64, 64, 2, 2);
+    else GLDS_FWD(128, 64, 2, 2);
+    return sf_launch_status("sf_conv_fwd_t");
+}
+extern "C" int sf_transpose(const float *w, float *wt, int K, int N, void *stream) {
+    SF_REQUIRE(w && wt && K > 0 && N > 0, "sf_transpose: bad args");
+    k_transpose<<<dim3(cdiv64(K, 32), cdiv64(N, 32)), dim3(256), 0, STREAM(stream)>>>(w, wt, K, N);
+    return sf_launch_status("sf_transpose");
 }
 
 // split plan shared by the workspace query and the launcher
@@ -841,6 +881,31 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     hipStream_t st = STREAM(stream);
     const unsigned classes = (unsigned)(g.S * g.S);
     const bool vec = g.vecB && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0;
+    // pixel-major LDS-DMA kernel: needs enough samples to fill BM-sample row tiles and Cout % 32 == 0
+    static const int pix_cfg = getenv("SF_DGRAD_PIX") ? atoi(getenv("SF_DGRAD_PIX")) : 1;
+    static const int ablate = getenv("SF_ABLATE") ? atoi(getenv("SF_ABLATE")) : 0;
+    if (pix_cfg && vec && g.Cout % 32 == 0 && n >= 1024) {
+#define DGRAD_PIX(BM, BN, WM, WN)                                                                          \
+    do {                                                                                                   \
+        const int ntiles = (int)((n + BM - 1) / BM), tiles8 = (ntiles + 7) / 8, ctiles = (g.Cin + BN - 1) / BN; \
+        k_dgrad_pix<BM, BN, WM, WN><<<dim3((unsigned)(tiles8 * 8 * g.H * ctiles)), dim3(256), 0, st>>>(    \
+            g, dout, w, in_act, din, (int)n, ntiles, tiles8, ablate);                                      \
+    } while (0)
+        if (g.Cin <= 32) { if (pix_cfg == 2) DGRAD_PIX(128, 32, 4, 1); else DGRAD_PIX(256, 32, 4, 1); }
+        else DGRAD_PIX(128, 64, 2, 2);
+        return sf_launch_status("sf_conv_dgrad");
+    }
+    // gfx950 LDS-DMA path: reduction chunks must not straddle a tap (Cout % 32 == 0) and the grid must be large
+    static const int glds_cfg = getenv("SF_GLDS_DGRAD") ? atoi(getenv("SF_GLDS_DGRAD")) : 0;
+    if (glds_cfg && vec && g.Cout % 32 == 0 && Mc * ((g.Cin + 63) / 64) >= 128LL * 1024) {
+#define DGRAD_GLDS(BM, BN, WM, WN)                                                                          \
+    k_dgrad_glds<BM, BN, WM, WN><<<dim3(cdiv64(Mc, BM), cdiv64(g.Cin, BN), classes), dim3(256), 0, st>>>(   \
+        g, dout, w, in_act, din, n)
+        if (g.Cin <= 32) { if (glds_cfg == 2) DGRAD_GLDS(256, 32, 4, 1); else DGRAD_GLDS(128, 32, 4, 1); }
+        else if (glds_cfg == 2) DGRAD_GLDS(128, 128, 2, 2);
+        else DGRAD_GLDS(128, 64, 2, 2);
+        return sf_launch_status("sf_conv_dgrad");
+    }
     if (g.Cin <= 32) DGRAD_LAUNCH(128, 32, 4, 1);
     else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) DGRAD_LAUNCH(64, 64, 2, 2);
     else DGRAD_LAUNCH(128, 64, 2, 2);
@@ -853,7 +918,7 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
                                    int cap) {
     int rc = check_desc(h_desc, "sf_conv_kernel_name");
     if (rc) return rc;
-    SF_REQUIRE(out && cap >= 48 && n > 0 && op >= 0 && op <= 2, "sf_conv_kernel_name: bad args");
+    SF_REQUIRE(out && cap >= 48 && n > 0 && op >= 0 && op <= 3, "sf_conv_kernel_name: bad args");
     const ConvG g = make_geom(h_desc);
     const int64_t Mtot = n * g.OH * g.OW;
     const int mode = pick_mode(g);
@@ -862,6 +927,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         const bool big32 = p.splits == 1 && Mtot >= 256 * 2048;
         if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
+    } else if (op == 3) {
+        snprintf(out, cap, "k_fwd_glds<128, 64, 2, 2>");
     } else if (op == 1) {
         if (wgrad_bn(g.Cout) == 32) snprintf(out, cap, "k_conv_wgrad<32, 4, 1, %d>", mode);
         else snprintf(out, cap, "k_conv_wgrad<64, 2, 2, %d>", mode);
@@ -869,7 +936,9 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         const int Hc = (g.H + g.S - 1) / g.S, Wc = (g.W + g.S - 1) / g.S;
         const int64_t Mc = n * Hc * Wc;
         const char *v = g.vecB ? "true" : "false";
-        if (g.Cin <= 32) snprintf(out, cap, "k_conv_dgrad<128, 32, 4, 1, %s>", v);
+        if (g.vecB && g.Cout % 32 == 0 && n >= 1024)
+            snprintf(out, cap, g.Cin <= 32 ? "k_dgrad_pix<256, 32, 4, 1>" : "k_dgrad_pix<128, 64, 2, 2>");
+        else if (g.Cin <= 32) snprintf(out, cap, "k_conv_dgrad<128, 32, 4, 1, %s>", v);
         else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) snprintf(out, cap, "k_conv_dgrad<64, 64, 2, 2, %s>", v);
         else snprintf(out, cap, "k_conv_dgrad<128, 64, 2, 2, %s>", v);
     }

@@ -1,0 +1,434 @@
+// sf_nn_glds.h — LDS-DMA ("glds") variants of the implicit-GEMM family for the dense hot layers (included by sf_nn.hip).
+//
+// The register-staged kernels in sf_nn.hip spend their non-MFMA time on the vector-memory path: global_load -> VGPR
+// -> (convert/select) -> ds_write_b32 x4 -> ds_read_b32 per fragment word.  For operands that are already f32 and whose
+// reduction axis is contiguous in memory gfx950 can do better:
+//   * global_load_lds_dwordx4: the 16 bytes of every lane go straight into LDS (no staging VGPRs, no ds_write pass);
+//     the destination is lane-linear (wave-uniform base + lane*16), the SOURCE address is per lane.
+//   * both operands are laid out "row = free index, 32 reduction words contiguous" (128-byte LDS rows), so one
+//     ds_read_b128 fetches the operand words of FOUR MFMAs.  The MFMA only needs A and B to agree on which reduction
+//     index sits in which half-wave slot, so the reduction order inside a 32-chunk is permuted: for group c = 0..3 the
+//     lanes of half h = lane>>5 hold words k = 8c + 4h + j, j = 0..3, and MFMA j consumes word j of both quads.
+//   * bank conflicts: 16 lanes x 16 B are served per cycle, rows are 128 B, so a plain row-major image would put all
+//     rows of equal parity on the same 16-byte slots (8-way).  Chunk position p of row r stores reduction chunk
+//     p ^ ((r >> 1) & 7); since the DMA destination cannot be permuted the permutation is applied to the per-lane
+//     SOURCE address and (the same involution) to the ds_read address (cdna_hip_programming.md rule 21).
+//   * LDS is double buffered: the DMA of chunk t+1 is issued right after the barrier that publishes chunk t and has
+//     the whole MFMA phase (32+ MFMAs = 2k+ cycles per wave) to land; one barrier per chunk.
+//
+// Preconditions (checked by the launchers, everything else stays on the register-staged kernels): f32 NHWC input,
+// Cin % 32 == 0 (a 32-chunk never straddles a filter tap), dense samples (no index gather), 16-byte aligned bases.
+#pragma once
+
+#define GLDS16(gsrc, ldst)                                                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),    \
+                                     (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
+
+// One 32-deep chunk of MFMAs out of the swizzled row-major LDS images.  As: BM rows x 32 words, Bs: BN rows x 32 words.
+template <int TM, int TN>
+__device__ __forceinline__ void mma_chunk_rows(const float *__restrict__ As, const float *__restrict__ Bs, int arow0,
+                                               int brow0, int lane, f32x16 (&acc)[TM][TN]) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+    const float *ap = As + (arow0 + r) * 32, *bp = Bs + (brow0 + r) * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int pos = (((2 * c + h) ^ sw) << 2);
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(ap + i * 32 * 32 + pos);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const float4 *>(bp + i * 32 * 32 + pos);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        j == 0 ? a[tm].x : j == 1 ? a[tm].y : j == 2 ? a[tm].z : a[tm].w,
+                        j == 0 ? b[tn].x : j == 1 ? b[tn].y : j == 2 ? b[tn].z : b[tn].w, acc[tm][tn], 0, 0, 0);
+    }
+}
+
+// ============================================================================================== FORWARD (glds)
+// out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ),  A = im2col view of the NHWC input, Wt = weights [Cout, K].
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                  const float *__restrict__ wt, const float *__restrict__ bias,
+                                                  float *__restrict__ out, int64_t Mtot) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
+    constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per block");
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int N = g.Cout, K = g.K;
+
+    // per-lane DMA sources: lane = (row-in-group lrow, chunk position lpos); position p holds chunk p ^ swz(row)
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const float *asrc[AI], *bsrc[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int64_t m = m0 + row;
+        m = m < Mtot ? m : Mtot - 1;  // rows past the end re-read the last row; their results are never stored
+        const uint32_t smp = fdiv((uint32_t)m, g.dOHOW), pix = (uint32_t)m - smp * (uint32_t)(g.OH * g.OW);
+        asrc[i] = in + (int64_t)smp * in_stride + patch_origin<false>(g, pix) + ((lpos ^ ((row >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int n = n0 + row;
+        n = n < N ? n : N - 1;
+        bsrc[i] = wt + (int64_t)n * K + ((lpos ^ ((row >> 1) & 7)) << 2);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < TN; ++b_)
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+
+    auto issue = [&](int k0, int stage) {
+        // chunk k0..k0+31 = channels c0.. of filter tap (kh, kw): one wave-uniform offset inside the input patch
+        const uint32_t tap = fdiv((uint32_t)k0, g.dCin), c0 = (uint32_t)k0 - tap * (uint32_t)g.Cin;
+        const uint32_t kh = fdiv(tap, g.dKW), kw = tap - kh * (uint32_t)g.KW;
+        const int aoff = (int)((kh * (uint32_t)g.W + kw) * (uint32_t)g.Cin + c0);
+        float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) GLDS16(asrc[i] + aoff, sa + (i * 4 + wave) * 256);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + k0, sb + (i * 4 + wave) * 256);
+    };
+    issue(0, 0);
+    int stage = 0;
+    for (int k0 = 0; k0 < K; k0 += 32, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of chunk k0 is in LDS
+        __syncthreads();                                   // ... everybody's is; stage^1 is no longer being read
+        if (k0 + 32 < K) issue(k0 + 32, stage ^ 1);
+        const float *sa = lds + stage * STAGE;
+        mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+            const float bv = (n < N && bias) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * TM * 32 + tm * 32 + FRAG_ROW(r, lane);
+                if (m < Mtot && n < N) out[m * N + n] = act_fwd(acc[tm][tn][r] + bv, g.relu);
+            }
+        }
+}
+
+// wt[n][k] = w[k][n]  (weights are kept K-major for the data-gradient; the glds forward wants them Cout-major)
+__global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ w, float *__restrict__ wt, int K, int N) {
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int k = k0 + ty + i, n = n0 + tx;
+        t[ty + i][tx] = (k < K && n < N) ? w[(int64_t)k * N + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int n = n0 + ty + i, k = k0 + tx;
+        if (n < N && k < K) wt[(int64_t)n * K + k] = t[tx][ty + i];
+    }
+}
+
+// ============================================================================================== DATA GRADIENT (glds)
+// din[m'][c] = act'(in_act) * sum_{(a,b),co} dY[smp, ihh-a, iww-b, co] * W[((ph+a*S)*KW + pw+b*S)*Cin + c][co]
+// per stride-parity class (ph, pw) = blockIdx.z, rows m' = (smp, ihh, iww) over the class's input pixels — the same
+// decomposition as k_conv_dgrad.  Both operands have the reduction index co contiguous (dY rows; the canonical
+// K-major weights ARE Cin-row-major for this product), so no transposed copy is needed.  A tap that falls outside dY
+// for a given row must contribute zero: its DMA source is redirected to a page of zeros.
+__device__ __attribute__((aligned(128))) const float sf_zero_page[32] = {};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_dgrad_glds(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
+                                                    const float *__restrict__ in_act, float *__restrict__ din,
+                                                    int64_t nsamples) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BI >= 1, "4 waves per block");
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ph = blockIdx.z / g.S, pw = blockIdx.z % g.S;
+    const int Hc = (g.H - ph + g.S - 1) / g.S, Wc = (g.W - pw + g.S - 1) / g.S;
+    const int KHs = (g.KH - ph + g.S - 1) / g.S, KWs = (g.KW - pw + g.S - 1) / g.S;
+    const int64_t Mc = nsamples * Hc * Wc;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    if (m0 >= Mc || Hc <= 0 || Wc <= 0) return;
+    const int n0 = blockIdx.y * BN;
+    const int Cin = g.Cin, Cout = g.Cout;
+    const int Kp = KHs * KWs * Cout;
+    const FastDiv fHW = g.dHcWc[blockIdx.z], fW = g.dWc[blockIdx.z], fKWs = g.dKWs[blockIdx.z];
+    const uint32_t HcWc = (uint32_t)(Hc * Wc);
+
+    const int lrow = lane >> 3, lpos = lane & 7;
+    int arow[AI], aih[AI], aiw[AI], apos[AI];
+    const float *bsrc[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int64_t m = m0 + row;
+        m = m < Mc ? m : Mc - 1;
+        const uint32_t smp = fdiv((uint32_t)m, fHW), pix = (uint32_t)m - smp * HcWc;
+        aih[i] = (int)fdiv(pix, fW);
+        aiw[i] = (int)pix - aih[i] * Wc;
+        arow[i] = (int)(smp * (uint32_t)(g.OH * g.OW)) + aih[i] * g.OW + aiw[i];
+        apos[i] = (lpos ^ ((row >> 1) & 7)) << 2;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int c = n0 + row;
+        c = c < Cin ? c : Cin - 1;
+        bsrc[i] = w + (int64_t)c * Cout + ((lpos ^ ((row >> 1) & 7)) << 2);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < TN; ++b_)
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+
+    auto issue = [&](int k0, int stage) {
+        const int tap = (int)fdiv((uint32_t)k0, g.dCout), co0 = k0 - tap * Cout;  // wave-uniform
+        const int a = (int)fdiv((uint32_t)tap, fKWs), b = tap - a * KWs;
+        const int drow = a * g.OW + b;
+        const int64_t wrow = (int64_t)(((ph + a * g.S) * g.KW + (pw + b * g.S)) * Cin) * Cout + co0;
+        float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int oh = aih[i] - a, ow = aiw[i] - b;
+            const bool ok = oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+            const float *src = ok ? dy + (int64_t)(arow[i] - drow) * Cout + co0 + apos[i] : sf_zero_page + apos[i];
+            GLDS16(src, sa + (i * 4 + wave) * 256);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + wrow, sb + (i * 4 + wave) * 256);
+    };
+    if (Kp > 0) issue(0, 0);
+    int stage = 0;
+    for (int k0 = 0; k0 < Kp; k0 += 32, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k0 + 32 < Kp) issue(k0 + 32, stage ^ 1);
+        const float *sa = lds + stage * STAGE;
+        mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+    }
+    const int akind = g.relu;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * TM * 32 + tm * 32 + FRAG_ROW(r, lane);
+            const bool mok = m < Mc;
+            const uint32_t mm = mok ? (uint32_t)m : 0u;
+            const uint32_t smp = fdiv(mm, fHW), pix = mm - smp * HcWc;
+            const int ihh = (int)fdiv(pix, fW), iww = (int)pix - ihh * Wc;
+            const int64_t obase = (((int64_t)smp * g.H + (ihh * g.S + ph)) * g.W + (iww * g.S + pw)) * Cin;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int c = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+                if (mok && c < Cin) {
+                    float v = acc[tm][tn][r];
+                    if (in_act) v *= act_bwd(in_act[obase + c], akind);
+                    din[obase + c] = v;
+                }
+            }
+        }
+}
+
+// ============================================================================================== DATA GRADIENT, pixel-major
+// The class-decomposed gather form above still multiplies by structural zeros at the image border: a row tile mixes
+// pixels for which a tap is inside dY with pixels for which it is not (conv3: 81 input pixels x 9 taps, only 49 x 9
+// pairs exist: 40 % of the MFMA work is 0 * w).  Here a row tile is BM SAMPLES at ONE input pixel, so whether a tap
+// exists is uniform over the tile and non-existent taps are skipped: the MFMA work equals the algorithmic
+// 2 * n*OH*OW * Cout * KH*KW*Cin exactly.  A block walks one input row (ih fixed, iw = 0..W-1) with the DMA pipeline
+// running across pixel boundaries; rows of both operands are contiguous 128-byte runs of output channels:
+//   A[s][co] = dY[s, oh, ow, co]   (per-lane base = sample, wave-uniform offset = (oh, ow, co-chunk))
+//   B[c][co] = W[(kh*KW + kw)*Cin + c][co]
+// Work-group ids are dealt round-robin to the 8 XCDs; the ids are re-mapped so that all pixel rows of one sample tile
+// run on the same XCD and share its L2 copy of that tile's dY.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
+                                                   const float *__restrict__ in_act, float *__restrict__ din,
+                                                   int nsamples, int ntiles, int tiles8, int ablate) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BI >= 1, "4 waves per block");
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int Cin = g.Cin, Cout = g.Cout, S = g.S, OH = g.OH, OW = g.OW;
+    // (sample tile, input row, Cin tile) from the XCD-swizzled linear id
+    const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+    const int ih = (int)(local % (uint32_t)g.H);
+    const uint32_t t = local / (uint32_t)g.H;
+    const int st = (int)((t % (uint32_t)tiles8) * 8u + xcd), ct = (int)(t / (uint32_t)tiles8);
+    if (st >= ntiles) return;
+    const int s0 = st * BM, n0 = ct * BN;
+    const int CC = Cout >> 5;  // 32-chunks per tap
+
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const float *asrc[AI], *bsrc[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int s = s0 + row;
+        s = s < nsamples ? s : nsamples - 1;
+        asrc[i] = dy + (int64_t)s * (OH * OW) * Cout + ((lpos ^ ((row >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int c = n0 + row;
+        c = c < Cin ? c : Cin - 1;
+        bsrc[i] = w + (int64_t)c * Cout + ((lpos ^ ((row >> 1) & 7)) << 2);
+    }
+    // taps of input row ih: kh = ph + S*a, oh = ihc - a in [0, OH)  ->  a in [a_lo, a_hi]
+    const int ph = ih % S, ihc = ih / S, KHs = (g.KH - ph + S - 1) / S;
+    const int a_lo = ihc - OH + 1 > 0 ? ihc - OH + 1 : 0, a_hi = ihc < KHs - 1 ? ihc : KHs - 1;
+
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < TN; ++b_)
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+    };
+    // epilogue addressing: 32-bit element offsets (launcher guarantees n*H*W*Cin < 2^31); everything that depends on
+    // the accumulator register index is wave-uniform, so one VGPR offset per lane suffices
+    const uint32_t sstride = (uint32_t)(g.H * g.W * Cin);
+    const int srow = s0 + wm * TM * 32 + 4 * (lane >> 5), ccol = n0 + wn * TN * 32 + (lane & 31);
+    const uint32_t obase = (uint32_t)srow * sstride + (uint32_t)(ih * g.W) * (uint32_t)Cin + (uint32_t)ccol;
+    const int slim = nsamples - srow;  // rows r with rowconst(r) < slim exist
+    // Epilogue, software-pipelined against the MFMA phases (a plain "load in_act, multiply, store" tail at the end of
+    // every pixel cost 40 % of the kernel: scattered 128-byte rows, nothing to overlap with).  The activation values of
+    // pixel p are prefetched into registers during p's first chunk; at the end of p the masked result is parked in
+    // registers and written out during the first chunk of the NEXT pixel, so neither the load latency nor the store
+    // drain sits in front of a vmcnt(0).
+    float pend[TM][TN][16], actv[TM][TN][16];
+    auto prefetch_act = [&](int iw) {
+        if (!in_act || (ablate & 2)) return;
+        const uint32_t pix = (uint32_t)iw * (uint32_t)Cin;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rc = tm * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const bool ok = rc < slim && ccol + tn * 32 < Cin;
+                    const uint32_t o = obase + pix + (uint32_t)rc * sstride + (uint32_t)(tn * 32);
+                    actv[tm][tn][r] = in_act[ok ? o : obase];
+                }
+            }
+    };
+    auto park_pixel = [&]() {
+        const int akind = g.relu;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[tm][tn][r];
+                    if (in_act && !(ablate & 2)) v *= act_bwd(actv[tm][tn][r], akind);
+                    pend[tm][tn][r] = v;
+                }
+    };
+    auto store_pixel = [&](int iw) {
+        const uint32_t pix = (uint32_t)iw * (uint32_t)Cin;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rc = tm * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    if (rc < slim && ccol + tn * 32 < Cin) {
+                        const uint32_t o = obase + pix + (uint32_t)rc * sstride + (uint32_t)(tn * 32);
+                        if ((ablate & 1) && pend[tm][tn][r] != 12345.678f) continue;
+                        din[o] = pend[tm][tn][r];
+                    }
+                }
+            }
+    };
+    auto zero_pixel = [&](int iw) {  // an input pixel no filter tap reaches: gradient 0
+        const uint32_t pix = (uint32_t)iw * (uint32_t)Cin;
+        for (int rc = 0; rc < TM * 32; rc += 1) {
+            const int rr = (rc & 3) + 8 * ((rc & 15) >> 2) + 32 * (rc >> 4);  // same row set as the fragments
+            for (int tn = 0; tn < TN; ++tn)
+                if (rr < slim && ccol + tn * 32 < Cin) din[obase + pix + (uint32_t)rr * sstride + (uint32_t)(tn * 32)] = 0.f;
+        }
+    };
+    // wave-uniform walk over the pixels of this input row; per pixel the reduction runs over q = (a, b, cc)
+    struct Px { int iw, pw, iwc, b_lo, nb, total; };
+    auto pixel = [&](int iw) {  // first pixel >= iw that some tap reaches (iw = W: none left)
+        Px p;
+        for (p.iw = iw; p.iw < g.W; ++p.iw) {
+            p.pw = p.iw % S; p.iwc = p.iw / S;
+            const int KWs = (g.KW - p.pw + S - 1) / S;
+            p.b_lo = p.iwc - OW + 1 > 0 ? p.iwc - OW + 1 : 0;
+            const int b_hi = p.iwc < KWs - 1 ? p.iwc : KWs - 1;
+            p.nb = b_hi - p.b_lo + 1;
+            p.total = (a_hi - a_lo + 1) * p.nb * CC;
+            if (p.nb > 0 && a_hi >= a_lo) return p;
+        }
+        p.total = 0;
+        return p;
+    };
+    auto issue = [&](const Px &p, int q, int stage) {
+        const int tap = q / CC, cc = q - tap * CC;  // CC, nb: small wave-uniform divisors (scalar unit)
+        const int a = a_lo + tap / p.nb, b = p.b_lo + tap % p.nb;
+        const int oh = ihc - a, ow = p.iwc - b, kh = ph + a * S, kw = p.pw + b * S;
+        const int64_t aoff = (int64_t)(oh * OW + ow) * Cout + cc * 32;
+        const int64_t boff = (int64_t)((kh * g.KW + kw) * Cin) * Cout + cc * 32;
+        float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
+        if (ablate & 4) return;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) GLDS16(asrc[i] + ((ablate & 8) ? 0 : aoff), sa + (i * 4 + wave) * 256);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + boff, sb + (i * 4 + wave) * 256);
+    };
+    Px cur = pixel(0);
+    for (int z = 0; z < cur.iw; ++z) zero_pixel(z);
+    if (cur.iw < g.W) issue(cur, 0, 0);
+    int stage = 0, parked = -1;  // parked: pixel whose result waits in pend[]
+    while (cur.iw < g.W) {
+        const Px nx = pixel(cur.iw + 1);
+        zero_acc();
+        for (int q = 0; q < cur.total; ++q, stage ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (q == 0 && parked >= 0) store_pixel(parked);
+            if (q + 1 < cur.total) issue(cur, q + 1, stage ^ 1);
+            else if (nx.iw < g.W) issue(nx, 0, stage ^ 1);  // the DMA pipeline runs across the pixel boundary
+            if (q == 0) prefetch_act(cur.iw);
+            const float *sa = lds + stage * STAGE;
+            mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+        }
+        park_pixel();
+        parked = cur.iw;
+        for (int z = cur.iw + 1; z < nx.iw; ++z) zero_pixel(z);  // pixels no tap reaches
+        cur = nx;
+    }
+    if (parked >= 0) store_pixel(parked);
+}

@@ -39,6 +39,7 @@ SYMBOLS = [
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
     "sf_adam_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
     "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_conv_kernel_name",
+    "sf_conv_fwd_t_supported", "sf_conv_fwd_t", "sf_transpose",
     "sf_linear_fwd",
     "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
@@ -70,7 +71,7 @@ class _timed:
         return False
 
 
-_OPS = {"fwd": 0, "wgrad": 1, "dgrad": 2}
+_OPS = {"fwd": 0, "wgrad": 1, "dgrad": 2, "fwd_t": 3}
 _names: dict = {}
 
 
@@ -363,6 +364,22 @@ def conv_dgrad(dout, w, in_act, din, n, desc: sf_conv_desc) -> None:
     with _timed(_dkey("dgrad", n, desc)):
       _check(load().sf_conv_dgrad(ptr(dout, "f32", "dout"), ptr(w, "f32", "w"), ptr(in_act, "f32", "in_act"),
                                 ptr(din, "f32", "din"), i64(n), C.byref(desc), stream()), "sf_conv_dgrad")
+
+
+def conv_fwd_t_supported(n, desc: sf_conv_desc) -> bool:
+    return bool(load().sf_conv_fwd_t_supported(i64(n), C.byref(desc)))
+
+
+def conv_fwd_t(inp, in_sample_stride, wt, bias, out, n, desc: sf_conv_desc) -> None:
+    """glds forward: wt is the [Cout, K] transpose of the canonical weights"""
+    with _timed(_dkey("fwd_t", n, desc)):
+        _check(load().sf_conv_fwd_t(ptr(inp, "f32", "in"), i64(in_sample_stride), ptr(wt, "f32", "wt"),
+                                    ptr(bias, "f32", "bias"), ptr(out, "f32", "out"), i64(n), C.byref(desc), stream()),
+               "sf_conv_fwd_t")
+
+
+def transpose(w, wt, K, N) -> None:
+    _check(load().sf_transpose(ptr(w, "f32", "w"), ptr(wt, "f32", "wt"), int(K), int(N), stream()), "sf_transpose")
 
 
 def linear_fwd(inp, w, bias, out, M, K, N, relu) -> None:

@@ -103,6 +103,49 @@ def test_conv_fwd_wgrad_dgrad_vs_torch(lib, geom, n):
         assert (din2.cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 3e-5 * max(1.0, s), "dgrad nomask"
 
 
+@pytest.mark.parametrize("geom,n", [((32, 20, 20, 64, 4, 2), 2500), ((64, 9, 9, 64, 3, 1), 2500),
+                                    ((32, 11, 13, 96, 3, 2), 4100), ((96, 1, 1, 160, 1, 1), 70001),
+                                    ((32, 12, 14, 64, 3, 2), 4300)])  # last: input row/col no filter tap reaches
+def test_glds_fwd_dgrad_large_grids_vs_torch(lib, geom, n):
+    """the gfx950 LDS-DMA kernels (sf_nn_glds.h) only take launches that fill the chip: forward through
+    sf_conv_fwd_t (transposed weights), data gradient through sf_conv_dgrad's internal dispatch.  Odd sizes, boundary
+    taps (zero page), Cout not a multiple of the column tile, ragged last row tile."""
+    Cin, H, W, Cout, K, S = geom
+    g = torch.Generator().manual_seed(Cin * 7 + n)
+    x = torch.randn((n, Cin, H, W), generator=g)
+    d = desc(lib, Cin, H, W, Cout, K, S)
+    x_dev = x.permute(0, 2, 3, 1).contiguous().cuda()
+    w_ref = torch.randn((Cout, Cin, K, K), generator=g) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    wk = to_kmajor(w_ref, 0).cuda()
+    OH, OW = d.OH, d.OW
+    assert lib.conv_fwd_t_supported(n, d)
+    wt = torch.empty((Cout, K * K * Cin), device="cuda")
+    lib.transpose(wk, wt, K * K * Cin, Cout)
+    assert torch.equal(wt, wk.t().contiguous())
+    out = torch.empty((n * OH * OW, Cout), device="cuda")
+    lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d)
+    xr = x.clone().requires_grad_(True)
+    pre = F.conv2d(xr, w_ref, b, stride=S)
+    ref = F.relu(pre)
+    got = out.view(n, OH, OW, Cout).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), "forward"
+    out_old = torch.empty_like(out)
+    lib.conv_fwd(x_dev, Cin * H * W, None, 0, wk, b.cuda(), out_old, n, d)
+    assert (out - out_old).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+    dy = torch.randn((n, Cout, OH, OW), generator=g)
+    dy_dev = dy.permute(0, 2, 3, 1).contiguous().cuda().view(n * OH * OW, Cout)
+    pre.backward(dy)
+    din = torch.full((n, H, W, Cin), 7.0, device="cuda")
+    lib.conv_dgrad(dy_dev, wk, x_dev, din, n, d)
+    dref = (xr.grad * (x > 0)).permute(0, 2, 3, 1)
+    s_ = dref.abs().max().item() + 1e-6
+    assert (din.cpu() - dref).abs().max().item() < 3e-5 * max(1.0, s_), "dgrad"
+    lib.conv_dgrad(dy_dev, wk, None, din, n, d)
+    assert (din.cpu() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 3e-5 * max(1.0, s_), "dgrad nomask"
+
+
 @pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64)])
 def test_linear_fwd_bwd_vs_torch(lib, M, K, N):
     g = torch.Generator().manual_seed(M + K + N)

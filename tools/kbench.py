@@ -37,6 +37,14 @@ def main():
             if "fwd" in which:
                 wsb = lib.conv_fwd_workspace(n, d); ws = torch.empty(max(wsb,16),dtype=torch.uint8,device="cuda") if wsb else None
                 t = timeit(lambda: lib.conv_fwd(x, stride, None, 0, w, b, out, n, d, ws), reps); res.append(f"fwd {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+            if "fwd" in which and lib.conv_fwd_t_supported(n, d):
+                wt = torch.empty((d.Cout, K), device="cuda"); lib.transpose(w, wt, K, d.Cout)
+                assert torch.equal(wt, w.t().contiguous())
+                ref = out.clone(); out.zero_()
+                for cfg in os.environ.get("GLDS_CFGS", "0").split(","):
+                    t = timeit(lambda: lib.conv_fwd_t(x, stride, wt, b, out, n, d), reps)
+                    err = (out - ref).abs().max().item() / ref.abs().max().item()
+                    res.append(f"fwd_t {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF relerr {err:.1e}")
             if "wgrad" in which and n == 32768:
                 dw = torch.empty_like(w); db = torch.empty_like(b)
                 ws = torch.empty(lib.conv_wgrad_workspace(n, d),dtype=torch.uint8,device="cuda")
