@@ -671,6 +671,12 @@ static int pick_mode(const ConvG &g) {
     return g.in_u8 ? MODE_U8 : MODE_F32;
 }
 
+// geometry contract of k_conv_u8_img<2, 4, 5, 16, *>
+static bool conv1_img_ok(const ConvG &g, int mode, int64_t n) {
+    return mode == MODE_U8 && n >= 256 && g.Cin == 4 && g.H == 84 && g.W == 84 && g.KH == 8 && g.KW == 8 && g.S == 4 &&
+           g.Cout <= 32;
+}
+
 // forward launch plan: tile config + optional split-K when the natural grid cannot fill 256 CUs several times over
 struct FwdPlan {
     int cfg;  // 0: 128x32 (4x1 waves), 1: 128x64 (2x2), 2: 64x64 (2x2)
@@ -733,6 +739,19 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
         if (!al || ((uintptr_t)w & 15) != 0) mode = MODE_GENERIC;
     }
     hipStream_t st = STREAM(stream);
+    // Nature-CNN conv1 on raw frames: strip-image kernel (bytes converted once into an f32 LDS image, im2col read
+    // out of LDS).  Geometry contract of the <2,4,5,16> instantiation: K = 256, 2*4*OW rows = 10 fragments.
+    static const int img_on = getenv("SF_CONV1_IMG") ? atoi(getenv("SF_CONV1_IMG")) : 1;
+    if (img_on && conv1_img_ok(g, mode, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0) {
+        const unsigned lds_bytes = (unsigned)(2 * 4 * 20 * 84 * sizeof(float));  // [SMP][Cin][RS][W] f32
+        if (g.sub_mean != 0.f)
+            k_conv_u8_img<2, 4, 5, 16, true><<<dim3(cdiv64(n, 2)), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
+        else
+            k_conv_u8_img<2, 4, 5, 16, false><<<dim3(cdiv64(n, 2)), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
+        return sf_launch_status("sf_conv_fwd");
+    }
     const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, workspace ? workspace_bytes / (int64_t)sizeof(float) : 0);
     float *partial = p.splits > 1 ? reinterpret_cast<float *>(workspace) : nullptr;
     const unsigned Z = (unsigned)p.splits;
@@ -759,9 +778,9 @@ extern "C" int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *h_desc) {
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
     return ((Mtot + 127) / 128) * ((h_desc->Cout + 63) / 64) >= 768;
 }
-#define GLDS_FWD(BM, BN, WM, WN)                                                                              \
-    k_fwd_glds<BM, BN, WM, WN><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN)), dim3(256), 0, STREAM(stream)>>>( \
-        g, in, in_sample_stride, wt, bias, out, Mtot)
+#define GLDS_FWD(BM, BN, WM, WN, NS)                                                                              \
+    k_fwd_glds<BM, BN, WM, WN, NS><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN)), dim3(256), 0, STREAM(stream)>>>( \
+        g, in, in_sample_stride, wt, bias, out, Mtot, ablate_f)
 extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
                              int64_t n, const sf_conv_desc *h_desc, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_fwd_t");
@@ -774,10 +793,11 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     const int64_t Mtot = n * g.OH * g.OW;
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd_t: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
     static const int cfg = getenv("SF_GLDS_CFG") ? atoi(getenv("SF_GLDS_CFG")) : 0;
-    if (cfg == 1) GLDS_FWD(256, 64, 4, 1);
-    else if (cfg == 2) GLDS_FWD(128, 128, 2, 2);
-    else if (cfg == 3) GLDS_FWD(64, 64, 2, 2);
-    else GLDS_FWD(128, 64, 2, 2);
+    static const int ablate_f = getenv("SF_ABLATE") ? atoi(getenv("SF_ABLATE")) : 0;
+    if (cfg == 1) GLDS_FWD(128, 64, 2, 2, 3);
+    else if (cfg == 2) GLDS_FWD(128, 128, 2, 2, 2);
+    else if (cfg == 3) GLDS_FWD(128, 128, 2, 2, 3);
+    else GLDS_FWD(128, 64, 2, 2, 2);
     return sf_launch_status("sf_conv_fwd_t");
 }
 extern "C" int sf_transpose(const float *w, float *wt, int K, int N, void *stream) {
@@ -805,13 +825,35 @@ static SplitPlan plan_splits(int64_t Mtot, int K, int N, int BM, int BN) {
     return p;
 }
 static inline int wgrad_bn(int N) { return N <= 32 ? 32 : 64; }
+struct WgradGlds {
+    int cfg;  // 0: 256x64 (waves 4x1), 1: 128x128 (2x2), 2: 128x64 (2x2)
+    int BK, BN, Z;
+    int64_t m_per_split;
+};
+static WgradGlds plan_wgrad_glds(int64_t Mtot, int K, int N) {
+    static const int force = getenv("SF_WGRAD_GLDS") ? atoi(getenv("SF_WGRAD_GLDS")) : 1;
+    WgradGlds q;
+    q.cfg = N >= 128 ? 1 : (K >= 256 ? 0 : 2);
+    if (force >= 2) q.cfg = force - 2;
+    q.BK = q.cfg == 0 ? 256 : 128;
+    q.BN = q.cfg == 1 ? 128 : 64;
+    const SplitPlan p = plan_splits(Mtot, K, N, q.BK, q.BN);
+    q.Z = p.Z;
+    q.m_per_split = p.m_per_split;
+    return q;
+}
 
 extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc) {
     if (!h_desc || n <= 0) return 0;
     const int K = h_desc->KH * h_desc->KW * h_desc->Cin, N = h_desc->Cout;
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
     const SplitPlan p = plan_splits(Mtot, K, N, 128, wgrad_bn(N));
-    return (int64_t)sizeof(float) * p.Z * ((int64_t)K * N + N) + 256;
+    int Z = p.Z;
+    if (!h_desc->in_u8) {  // the LDS-DMA kernel may pick other tiles (hence another split count)
+        const WgradGlds q = plan_wgrad_glds(Mtot, K, N);
+        if (q.Z > Z) Z = q.Z;
+    }
+    return (int64_t)sizeof(float) * Z * ((int64_t)K * N + N) + 256;
 }
 
 #define WGRAD_LAUNCH(BN, WM, WN, MODE)                                                                        \
@@ -847,13 +889,30 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
         if (!al || ((uintptr_t)dout & 15) != 0) mode = MODE_GENERIC;
     }
     hipStream_t st = STREAM(stream);
-    dim3 grid(cdiv64(K, 128), cdiv64(N, BN), (unsigned)p.Z);
-    if (BN == 32) WGRAD_BY_MODE(32, 4, 1);
-    else WGRAD_BY_MODE(64, 2, 2);
+    static const int glds_on = getenv("SF_WGRAD_GLDS") ? atoi(getenv("SF_WGRAD_GLDS")) : 1;
+    int Zused = p.Z;
+    if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && Mtot >= 65536) {
+        // gfx950 LDS-DMA kernel (dense f32 NHWC input): different tiles, so its own split plan and partial layout
+        const WgradGlds q = plan_wgrad_glds(Mtot, K, N);
+        partial_b = partial_w + (int64_t)q.Z * K * N;
+        Zused = q.Z;
+        dim3 gq(cdiv64(K, q.BK), cdiv64(N, q.BN), (unsigned)q.Z);
+        const float *inf = reinterpret_cast<const float *>(in);
+#define WGRAD_GLDS(BK_, BN_, WM_, WN_)                                                                      \
+    k_wgrad_glds<BK_, BN_, WM_, WN_><<<gq, dim3(256), 0, st>>>(g, inf, in_sample_stride, dout, partial_w,   \
+                                                              db ? partial_b : nullptr, Mtot, q.m_per_split)
+        if (q.cfg == 0) WGRAD_GLDS(256, 64, 4, 1);
+        else if (q.cfg == 1) WGRAD_GLDS(128, 128, 2, 2);
+        else WGRAD_GLDS(128, 64, 2, 2);
+    } else {
+        dim3 grid(cdiv64(K, 128), cdiv64(N, BN), (unsigned)p.Z);
+        if (BN == 32) WGRAD_BY_MODE(32, 4, 1);
+        else WGRAD_BY_MODE(64, 2, 2);
+    }
     const int64_t KN = (int64_t)K * N;
     k_reduce_partials<<<dim3(cdiv64(KN, 256) < 2048 ? cdiv64(KN, 256) : 2048), dim3(256), 0, st>>>(partial_w, dw, KN,
-                                                                                                    p.Z);
-    if (db) k_reduce_partials<<<dim3(cdiv64(N, 256)), dim3(256), 0, st>>>(partial_b, db, N, p.Z);
+                                                                                                    Zused);
+    if (db) k_reduce_partials<<<dim3(cdiv64(N, 256)), dim3(256), 0, st>>>(partial_b, db, N, Zused);
     return sf_launch_status("sf_conv_wgrad");
 }
 
@@ -922,13 +981,19 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
     const ConvG g = make_geom(h_desc);
     const int64_t Mtot = n * g.OH * g.OW;
     const int mode = pick_mode(g);
-    if (op == 0) {
+    if (op == 0 && conv1_img_ok(g, mode, n)) {
+        snprintf(out, cap, g.sub_mean != 0.f ? "k_conv_u8_img<2, 4, 5, 16, true>" : "k_conv_u8_img<2, 4, 5, 16, false>");
+    } else if (op == 0) {
         const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, split_k_allowed ? (int64_t)1 << 60 : 0);
         const bool big32 = p.splits == 1 && Mtot >= 256 * 2048;
         if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
     } else if (op == 3) {
         snprintf(out, cap, "k_fwd_glds<128, 64, 2, 2>");
+    } else if (op == 1 && mode == MODE_F32 && Mtot >= 65536) {
+        const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
+        snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"
+                                                                                  : "k_wgrad_glds<128, 64, 2, 2>");
     } else if (op == 1) {
         if (wgrad_bn(g.Cout) == 32) snprintf(out, cap, "k_conv_wgrad<32, 4, 1, %d>", mode);
         else snprintf(out, cap, "k_conv_wgrad<64, 2, 2, %d>", mode);

@@ -24,6 +24,17 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),    \
                                      (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
 
+// Work-group barrier WITHOUT the memory fence of __syncthreads(): the fence makes hipcc drain every outstanding DMA
+// (s_waitcnt vmcnt(0)) in front of the barrier, which is exactly what a multi-stage pipeline must not do.  Ordering is
+// provided by the explicit counted s_waitcnt in front of it (DMA data) and by the fact that every ds_read result has
+// been consumed by an MFMA before the wave gets here.
+#define BARRIER_NOFENCE()                  \
+    do {                                   \
+        asm volatile("" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();      \
+        asm volatile("" ::: "memory");     \
+    } while (0)
+
 // One 32-deep chunk of MFMAs out of the swizzled row-major LDS images.  As: BM rows x 32 words, Bs: BN rows x 32 words.
 template <int TM, int TN>
 __device__ __forceinline__ void mma_chunk_rows(const float *__restrict__ As, const float *__restrict__ Bs, int arow0,
@@ -52,15 +63,15 @@ __device__ __forceinline__ void mma_chunk_rows(const float *__restrict__ As, con
 
 // ============================================================================================== FORWARD (glds)
 // out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ),  A = im2col view of the NHWC input, Wt = weights [Cout, K].
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                                   const float *__restrict__ wt, const float *__restrict__ bias,
-                                                  float *__restrict__ out, int64_t Mtot) {
+                                                  float *__restrict__ out, int64_t Mtot, int ablate) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per block");
-    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && (NS == 2 || NS == 3), "4 waves per block");
+    __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -104,14 +115,23 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + k0, sb + (i * 4 + wave) * 256);
     };
+    // NS-stage DMA pipeline: chunk t+NS-1 is issued while chunk t is in the matrix pipe.  Loads retire in order, so
+    // "at most (NS-2) chunks' worth of DMA instructions outstanding" == "chunk t has landed" — never a vmcnt(0)
+    // inside the loop for NS = 3.
     issue(0, 0);
+    if (NS == 3 && 32 < K) issue(32, 1);
     int stage = 0;
-    for (int k0 = 0; k0 < K; k0 += 32, stage ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of chunk k0 is in LDS
-        __syncthreads();                                   // ... everybody's is; stage^1 is no longer being read
-        if (k0 + 32 < K) issue(k0 + 32, stage ^ 1);
-        const float *sa = lds + stage * STAGE;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        if (NS == 3 && k0 + 32 < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(ablate & 4)) BARRIER_NOFENCE();  // chunk k0 is visible to all waves, and the stage about to be refilled is no longer read
+        const int kn = k0 + (NS - 1) * 32;
+        int sn = stage + NS - 1;
+        sn = sn >= NS ? sn - NS : sn;
+        if (kn < K && !(ablate & 1)) issue(kn, sn);
+        const float *sa = lds + ((ablate & 2) ? 0 : stage * STAGE);
         mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+        stage = stage + 1 == NS ? 0 : stage + 1;
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -431,4 +451,271 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
         cur = nx;
     }
     if (parked >= 0) store_pixel(parked);
+}
+
+// ============================================================================================== WEIGHT GRADIENT (glds)
+// partial[z][k][n] = sum_{m in split z} A[m][k] * dY[m][n]   (A = im2col view of the f32 NHWC input)
+// Both operands are reduction-major in memory already (a row = one reduction index m, free index contiguous), so the
+// DMA image is As[32 m][BK k], Bs[32 m][BN n].  A lane of the MFMA A operand owns an output row; output rows are
+// relabelled so that lane i owns the TM CONSECUTIVE k's TM*i .. TM*i+TM-1 (one per fragment): one ds_read_b32/b64/
+// b128 feeds TM MFMAs (same for the TN fragments of dY).  Odd reduction rows are stored with their two 128-byte
+// halves swapped (chunk ^ 8) so the two half-waves of a 4-byte read hit different banks.
+template <int W> struct VecW;
+template <> struct VecW<1> { typedef float T; };
+template <> struct VecW<2> { typedef float2 T; };
+template <> struct VecW<4> { typedef float4 T; };
+template <int W>
+__device__ __forceinline__ float vec_elem(const typename VecW<W>::T &v, int i) {
+    if constexpr (W == 1) return v;
+    else if constexpr (W == 2) return i == 0 ? v.x : v.y;
+    else return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+template <int BK, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                    const float *__restrict__ dy, float *__restrict__ partial,
+                                                    float *__restrict__ partial_b, int64_t Mtot, int64_t m_per_split) {
+    constexpr int TM = BK / WM / 32, TN = BN / WN / 32;
+    static_assert(WM * WN == 4 && (TM == 1 || TM == 2 || TM == 4) && (TN == 1 || TN == 2 || TN == 4), "tile");
+    constexpr int A_RPI = 256 / BK, B_RPI = 256 / BN;  // reduction rows per 1-KiB DMA instruction
+    constexpr int AI = 32 / A_RPI / 4, BI = 32 / B_RPI / 4;  // DMA instructions per wave and chunk
+    constexpr int STAGE = (BK + BN) * 32;
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int k0row = blockIdx.x * BK, n0 = blockIdx.y * BN;
+    const int N = g.Cout, K = g.K;
+    const int64_t mbeg = (int64_t)blockIdx.z * m_per_split;
+    const int64_t mend = (mbeg + m_per_split < Mtot) ? mbeg + m_per_split : Mtot;
+
+    // DMA lanes: A instruction j covers reduction rows j*A_RPI.. ; lane -> (row-in-instr, 16-byte position)
+    constexpr int ACH = BK / 4, BCH = BN / 4;  // 16-byte chunks per row
+    const int a_r = lane / ACH, a_p = lane % ACH, b_r = lane / BCH, b_p = lane % BCH;
+    int a_tap[2];  // element offset inside the input patch of this lane's k-chunk, for even / odd reduction rows
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        int k = k0row + ((a_p ^ (par << 3)) << 2);
+        k = k < K ? k : 0;  // weight rows past K are never stored
+        a_tap[par] = tap_offset<false>(g, (uint32_t)k);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < TN; ++b_)
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+
+    auto issue = [&](int64_t mc, int stage) {
+        float *sa = lds + stage * STAGE, *sb = sa + BK * 32;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int j = i * 4 + wave, row = j * A_RPI + a_r;
+            int64_t m = mc + row;
+            m = m < mend ? m : mend - 1;  // annihilated by the zero dY row below
+            const uint32_t smp = fdiv((uint32_t)m, g.dOHOW), pix = (uint32_t)m - smp * (uint32_t)(g.OH * g.OW);
+            const float *src = in + (int64_t)smp * in_stride + patch_origin<false>(g, pix) + a_tap[row & 1];
+            GLDS16(src, sa + j * 256);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int j = i * 4 + wave, row = j * B_RPI + b_r;
+            const int64_t m = mc + row;
+            int n = n0 + ((b_p ^ ((row & 1) << 3)) << 2);
+            n = n < N ? n : 0;  // columns past N are never stored
+            const float *src = m < mend ? dy + m * N + n : sf_zero_page;
+            GLDS16(src, sb + j * 256);
+        }
+    };
+    const bool do_colsum = partial_b != nullptr && blockIdx.x == 0 && tid < BN;
+    float colacc = 0.f;
+    if (mbeg < mend) issue(mbeg, 0);
+    int stage = 0;
+    for (int64_t mc = mbeg; mc < mend; mc += 32, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (mc + 32 < mend) issue(mc + 32, stage ^ 1);
+        const float *sa = lds + stage * STAGE, *sb = sa + BK * 32;
+        if (do_colsum) {
+#pragma unroll 8
+            for (int kk = 0; kk < 32; ++kk) colacc += sb[kk * BN + ((((tid >> 2) ^ ((kk & 1) << 3)) << 2) | (tid & 3))];
+        }
+        // lane (i, h) reads words TM*i.. of A row 2s+h and TN*i.. of dY row 2s+h; odd rows: halves swapped
+        const int i = lane & 31, h = lane >> 5;
+        const int acol = ((((wm * TM * 32 + TM * i) >> 2) ^ (h << 3)) << 2) | ((TM * i) & 3);
+        const int bcol = ((((wn * TN * 32 + TN * i) >> 2) ^ (h << 3)) << 2) | ((TN * i) & 3);
+        const float *ap = sa + h * BK + acol, *bp = sb + h * BN + bcol;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const typename VecW<TM>::T a = *reinterpret_cast<const typename VecW<TM>::T *>(ap + 2 * s * BK);
+            const typename VecW<TN>::T b = *reinterpret_cast<const typename VecW<TN>::T *>(bp + 2 * s * BN);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_elem<TM>(a, tm), vec_elem<TN>(b, tn),
+                                                                       acc[tm][tn], 0, 0, 0);
+        }
+    }
+    if (do_colsum && n0 + tid < N) partial_b[(int64_t)blockIdx.z * N + n0 + tid] = colacc;
+    float *dst = partial + (int64_t)blockIdx.z * K * N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * TN * 32 + TN * (lane & 31) + tn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0row + wm * TM * 32 + TM * FRAG_ROW(r, lane) + tm;
+                if (k < K && n < N) dst[(int64_t)k * N + n] = acc[tm][tn][r];
+            }
+        }
+}
+
+// ============================================================================================== FORWARD, raw u8 frames
+// First conv layer on raw NCHW u8 observations (Nature-CNN conv1: 4x84x84 -> 32, 8x8 stride 4, K = 256).
+// Measured on MI355X (tools/ubench/mfma_peak.hip): f32 MFMA alone sustains 153-155 TFLOP/s, but every VALU
+// instruction issued next to it costs ~3-4 cycles of matrix-pipe time (3 VALU per 16x16x4 MFMA: 118 TFLOP/s).  The
+// im2col kernel converts every input byte u8 -> f32 KH*KW/S^2 = 4 times (cvt + scale per MFMA operand) and re-gathers
+// it 4 times through the vector-memory path; a version that kept the frames as BYTES in LDS and converted at
+// fragment-read time hit the same 90 TFLOP/s wall (2 VALU per MFMA).  So: convert ONCE.
+//   A block owns SMP = 2 samples and walks the image in strips of R = 4 output rows (20 input rows).  The strip's
+//   bytes are loaded with plain coalesced 4-byte loads (prefetched into registers during the previous strip's MFMAs),
+//   converted ((x - mean) * 1/scale, the arithmetic of k_conv_fwd's loader) and stored to LDS as f32
+//   [smp][c][20][W].  The MFMA A operand is then read straight out of that image: lane (row = output pixel, kg)
+//   fetches the 4 floats (c, kh, kw..kw+3) of its patch with ONE ds_read_b128 and feeds 4 MFMAs — the k-loop contains
+//   no VALU work besides the address add, and no global memory traffic at all.
+//   The weight fragment of the wave's 16 output channels lives in 64 VGPRs for the whole kernel.
+// v_mfma_f32_16x16x4_f32 (same peak as 32x32x2) gives 16-row fragments: SMP * R * OW = 160 rows = 10 fragments, split
+// evenly over 2 (row) x 2 (16-channel column) waves = TMF = 5 per wave and strip — no ragged tile anywhere.
+// Reduction order inside a 16-group: MFMA j consumes k = 16g + 4*kg + j from lane group kg (A and B agree on it).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int SMP, int R, int TMF, int KG, bool SUB>
+__global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                     const int32_t *__restrict__ index, int64_t offset,
+                                                     const float *__restrict__ w, const float *__restrict__ bias,
+                                                     float *__restrict__ out, int nsamples) {
+    extern __shared__ __attribute__((aligned(16))) float strip[];  // [SMP][Cin][RS][W] f32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Geometry is compile-time (the launcher checks it): the 80 fragment addresses of a strip then differ from 5
+    // per-lane bases only by IMMEDIATE ds_read offsets; with run-time geometry hipcc materialised all 80 in VGPRs
+    // (256 registers, one wave per SIMD).
+    constexpr int H = 84, W = 84, Cin = 4, KH = 8, KW = 8, S = 4, OH = 20, OW = 20, OHOW = OH * OW;
+    static_assert(KG * 16 == Cin * KH * KW && SMP * R * OW == 32 * TMF && OH % R == 0, "Nature-CNN conv1 geometry");
+    const int N = g.Cout;
+    constexpr int RS = (R - 1) * S + KH;  // input rows per strip
+    constexpr int W4 = W >> 2;            // 4-byte words per input row
+    const int words = Cin * RS * W4;     // u32 words per strip and sample
+    constexpr int NLD = 7;               // u32 loads per thread, sample and strip (launcher: words <= 256 * NLD)
+    const int s0 = blockIdx.x * SMP;
+    // ---- per-thread strip words: word q -> (c, row, x4), the same for every sample of the block; the sample bases
+    // are wave-uniform, so a load is "SGPR base + 32-bit VGPR offset"
+    int gofs[NLD], lofs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        int q = tid + 256 * i;
+        const bool ok = q < words;
+        q = ok ? q : 0;
+        const int x4 = q % W4, t1 = q / W4, row = t1 % RS, c = t1 / RS;
+        gofs[i] = (c * H + row) * W + x4 * 4;
+        lofs[i] = ok ? (c * RS + row) * W + x4 * 4 : -1;
+    }
+    const uint8_t *sbase[SMP];
+#pragma unroll
+    for (int z = 0; z < SMP; ++z) {
+        int sg = s0 + z;
+        sg = sg < nsamples ? sg : nsamples - 1;
+        sbase[z] = in + sample_base(g, index, offset, in_stride, (uint32_t)sg);
+    }
+    uint32_t pre[SMP][NLD];
+    auto load_strip = [&](int st) {
+        const int rowoff = st * R * S * W;
+#pragma unroll
+        for (int z = 0; z < SMP; ++z)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) pre[z][i] = *reinterpret_cast<const uint32_t *>(sbase[z] + rowoff + gofs[i]);
+    };
+    const float sub = g.sub_mean, scl = g.inv_scale;
+    auto store_strip = [&]() {
+#pragma unroll
+        for (int z = 0; z < SMP; ++z)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float b8 = (float)((pre[z][i] >> (8 * j)) & 0xFFu);
+                    v[j] = (SUB ? b8 - sub : b8) * scl;  // SUB = false: mean == 0 (x - 0 is exact anyway)
+                }
+                if (lofs[i] >= 0)
+                    *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(strip + z * Cin * RS * W + lofs[i], 16)) = v;
+            }
+    };
+    load_strip(0);
+    // ---- weight fragment of this wave's 16 output channels -> registers; tap offsets of this lane's kg slot
+    const int col = wn * 16 + (lane & 15), kg = lane >> 4;
+    const int colc = col < N ? col : N - 1;
+    f32x4 breg[KG];
+    int tapv[KG];
+#pragma unroll
+    for (int gi = 0; gi < KG; ++gi) {
+        const int k = 16 * gi + 4 * kg;  // k = (c*KH + kh)*KW + kw
+#pragma unroll
+        for (int j = 0; j < 4; ++j) breg[gi][j] = w[(int64_t)(k + j) * N + colc];
+        // 16*gi advances (c, kh) by whole rows, 4*kg stays inside two kw-rows: tap = uniform(gi) + lane(kg)
+        tapv[gi] = ((16 * gi) / (KH * KW) * RS + ((16 * gi) % (KH * KW)) / KW) * W;
+    }
+    const int lanetap = (kg >> 1) * W + (kg & 1) * 4;
+    const float bv = bias ? bias[colc] : 0.f;
+    // fragment rows of this wave inside a strip: row = (smp, oh_l, ow), fixed for all strips
+    int origin[TMF];
+#pragma unroll
+    for (int t = 0; t < TMF; ++t) {
+        const int row = (2 * t + wm) * 16 + (lane & 15);  // < SMP * R * OW by construction
+        const int smp = row / (R * OW), p = row - smp * (R * OW), ohl = p / OW, ow = p - ohl * OW;
+        origin[t] = (smp * Cin * RS + ohl * S) * W + ow * S + lanetap;
+    }
+    constexpr int nstrips = OH / R;
+    for (int st = 0; st < nstrips; ++st) {
+        store_strip();  // first use of the prefetched bytes
+        __syncthreads();
+        if (st + 1 < nstrips) load_strip(st + 1);  // lands during the MFMA phase
+        f32x4 acc[TMF];
+#pragma unroll
+        for (int t = 0; t < TMF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // fragments double-buffered one 16-group ahead; sched_barrier keeps hipcc from hoisting ALL 80 reads (320
+        // VGPRs) to the top of the strip
+        f32x4 a[2][TMF];
+        auto fetch = [&](int gi) {
+#pragma unroll
+            for (int t = 0; t < TMF; ++t)
+                a[gi & 1][t] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(strip + origin[t] + tapv[gi], 16));
+        };
+        fetch(0);
+#pragma unroll
+        for (int gi = 0; gi < KG; ++gi) {
+            if (gi + 1 < KG) fetch(gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < TMF; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi & 1][t][j], breg[gi][j], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < TMF; ++t) {
+            const int rbase = (2 * t + wm) * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + r;
+                const int smp = row / (R * OW), p = row - smp * (R * OW);
+                const int64_t m = (int64_t)(s0 + smp) * OHOW + st * (R * OW) + p;
+                if (s0 + smp < nsamples && col < N) out[m * N + col] = act_fwd(acc[t][r] + bv, g.relu);
+            }
+        }
+        __syncthreads();  // everybody is done reading this strip before it is overwritten
+    }
 }

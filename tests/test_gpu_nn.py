@@ -126,8 +126,10 @@ def test_glds_fwd_dgrad_large_grids_vs_torch(lib, geom, n):
     out = torch.empty((n * OH * OW, Cout), device="cuda")
     lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d)
     xr = x.clone().requires_grad_(True)
-    pre = F.conv2d(xr, w_ref, b, stride=S)
-    ref = F.relu(pre)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    pre = F.conv2d(xr, wr, br, stride=S)
+    ref = F.relu(pre).detach()
     got = out.view(n, OH, OW, Cout).permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), "forward"
     out_old = torch.empty_like(out)
@@ -144,6 +146,43 @@ def test_glds_fwd_dgrad_large_grids_vs_torch(lib, geom, n):
     assert (din.cpu() - dref).abs().max().item() < 3e-5 * max(1.0, s_), "dgrad"
     lib.conv_dgrad(dy_dev, wk, None, din, n, d)
     assert (din.cpu() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 3e-5 * max(1.0, s_), "dgrad nomask"
+    # weight / bias gradient: reduction over n*OH*OW >= 65536 rows -> LDS-DMA kernel; fp32 sums of ~1e5 terms
+    dw = torch.zeros_like(wk)
+    db = torch.zeros(Cout, device="cuda")
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    lib.conv_wgrad(x_dev, Cin * H * W, None, 0, dy_dev, dw, db, n, d, ws)
+    dw_got = from_kmajor(dw.cpu(), Cout, Cin, K, K, 0)
+    sw = wr.grad.abs().max().item() + 1e-6
+    assert (dw_got - wr.grad).abs().max().item() < 2e-4 * max(1.0, sw), "wgrad"
+    assert (db.cpu() - br.grad).abs().max().item() < 2e-4 * max(1.0, br.grad.abs().max().item()), "bgrad"
+
+
+@pytest.mark.parametrize("geom,n,mean", [((4, 84, 84, 32, 8, 4), 515, 3.0), ((4, 84, 84, 32, 8, 4), 300, 0.0),
+                                         ((4, 36, 36, 32, 8, 4), 1001, 0.0), ((4, 84, 84, 24, 8, 4), 258, 1.5)])
+def test_conv1_lds_image_kernel_vs_torch(lib, geom, n, mean):
+    """raw-u8 first layer through the LDS-image kernel (n >= 256): odd sample counts (ragged last block), index
+    gather, Cout < 32, with and without mean subtraction; must also agree with the im2col kernel."""
+    Cin, H, W, Cout, K, S = geom
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 256, (n + 7, Cin, H, W), generator=g, dtype=torch.uint8)
+    inv = float(np.float32(1 / 255.0))
+    d = desc(lib, Cin, H, W, Cout, K, S, in_u8=1, sub_mean=mean, inv_scale=inv)
+    w_ref = torch.randn((Cout, Cin, K, K), generator=g) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    wk = to_kmajor(w_ref, 1).cuda()
+    idx = torch.randperm(n + 7, generator=g)[:n].to(torch.int32)
+    x_dev = x.cuda()
+    out = torch.empty((n * d.OH * d.OW, Cout), device="cuda")
+    lib.conv_fwd(x_dev, Cin * H * W, idx.cuda(), 0, wk, b.cuda(), out, n, d)
+    ref = F.relu(F.conv2d((x[idx.long()].float() - mean) * inv, w_ref, b, stride=S))
+    got = out.view(n, d.OH, d.OW, Cout).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    out2 = torch.empty_like(out)   # dense (offset) addressing of the same samples, small batches -> im2col kernel
+    xs = x_dev[idx.long().cuda()].contiguous()
+    for i in range(0, n, 100):
+        m = min(100, n - i)
+        lib.conv_fwd(xs, Cin * H * W, None, i, wk, b.cuda(), out2[i * d.OH * d.OW:], m, d)
+    assert (out - out2).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64)])
