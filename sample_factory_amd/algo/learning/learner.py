@@ -182,6 +182,7 @@ class Learner:
         self.actor_critic.train()
         if self.world > 1:  # identical initial weights on every replica
             self.group.broadcast(self.actor_critic.flat_params, src=0)
+            self.actor_critic.params_changed()
         P = self.actor_critic.num_flat
         self.exp_avg = torch.zeros(P, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=self.device)
@@ -273,6 +274,7 @@ class Learner:
         ac.load_state_dict(sd, strict=False)
         flat.copy_(ac.flat_params)
         ac.flat_params.copy_(keep_p)
+        ac.params_changed()
 
     def load_from_checkpoint(self, policy_id, load_progress=True) -> None:
         cps = self.get_checkpoints(self.checkpoint_dir(self.cfg, policy_id))
@@ -474,6 +476,7 @@ class Learner:
                 lib.adam_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
                               actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
                               cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None)
+                ac.params_changed()
                 num_sgd_steps += 1
                 self.train_step += 1
                 if need_kl_each_mb:

@@ -373,7 +373,7 @@ def conv_fwd_t_supported(n, desc: sf_conv_desc) -> bool:
 def conv_fwd_t(inp, in_sample_stride, wt, bias, out, n, desc: sf_conv_desc) -> None:
     """glds forward: wt is the [Cout, K] transpose of the canonical weights"""
     with _timed(_dkey("fwd_t", n, desc)):
-        _check(load().sf_conv_fwd_t(ptr(inp, "f32", "in"), i64(in_sample_stride), ptr(wt, "f32", "wt"),
+        _check(load().sf_conv_fwd_t(_raw_in(inp, desc), i64(in_sample_stride), ptr(wt, "f32", "wt"),
                                     ptr(bias, "f32", "bias"), ptr(out, "f32", "out"), i64(n), C.byref(desc), stream()),
                "sf_conv_fwd_t")
 

@@ -65,7 +65,7 @@ class _Layer:
         self.first_fc_chw = first_fc_chw
         self.K = desc.KH * desc.KW * desc.Cin
         self.N = desc.Cout
-        self.w = self.b = self.gw = self.gb = None  # views into the flat buffers
+        self.w = self.b = self.gw = self.gb = self.wt = None  # views into the flat buffers (wt: [N, K] copy)
 
     @property
     def out_pixels(self):
@@ -208,6 +208,12 @@ class ActorCritic:
             L.b = self.flat_params[ob:ob + L.N]
             L.gw = self.flat_grads[o:o + L.K * L.N].view(L.K, L.N)
             L.gb = self.flat_grads[ob:ob + L.N]
+        # Cout-major copies [N, K] of the weights of the layers the gfx950 LDS-DMA forward can take (sf_conv_fwd_t);
+        # refreshed by params_changed() after every parameter update
+        self.flat_params_t = torch.zeros_like(self.flat_params)
+        for L, (o, ob) in zip(self.layers, self._segs):
+            ok = L.role == "chain" and not L.desc.in_u8 and L.desc.Cin % 32 == 0 and L.N >= 32
+            L.wt = self.flat_params_t[o:o + L.K * L.N].view(L.N, L.K) if ok else None
         self.obs_normalizer = None
         if cfg.normalize_input:
             from sample_factory_amd.utils.normalize import ObservationNormalizer
@@ -319,6 +325,7 @@ class ActorCritic:
             H.b.copy_(torch.cat([torch.as_tensor(sd["critic_linear.bias"], dtype=torch.float32).reshape(1),
                                  torch.as_tensor(sd["action_parameterization.distribution_linear.bias"],
                                                  dtype=torch.float32).reshape(-1), torch.zeros(pad)]))
+            self.params_changed()
             if self.obs_normalizer is not None and "obs_normalizer.running_mean_std.running_mean_std.obs.count" in sd:
                 self.obs_normalizer.load_state_dict(sd)
             if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
@@ -358,6 +365,12 @@ class ActorCritic:
             self._bufs[key] = t
         return t
 
+    def params_changed(self) -> None:
+        """call after ANY write to flat_params (optimiser step, load_state_dict, broadcast): refresh derived copies"""
+        for L in self.layers:
+            if L.wt is not None:
+                lib.transpose(L.w, L.wt, L.K, L.N)
+
     def _workspace(self, nbytes: int) -> torch.Tensor:
         """split-K / wgrad scratch; one per stream role so that the rollout and learner streams never share it"""
         key = self._role
@@ -372,9 +385,11 @@ class ActorCritic:
     # ping-pongs two device copies so a rollout never sees a half-updated buffer and nothing blocks.
     def enable_weight_snapshots(self) -> None:
         self._snap = [self.flat_params.clone(), self.flat_params.clone()]
+        self._snap_t = [self.flat_params_t.clone(), self.flat_params_t.clone()]
         self._snap_views = []
-        for buf in self._snap:
-            self._snap_views.append([(buf[o:o + L.K * L.N].view(L.K, L.N), buf[ob:ob + L.N])
+        for buf, buft in zip(self._snap, self._snap_t):
+            self._snap_views.append([(buf[o:o + L.K * L.N].view(L.K, L.N), buf[ob:ob + L.N],
+                                      buft[o:o + L.K * L.N].view(L.N, L.K) if L.wt is not None else None)
                                      for L, (o, ob) in zip(self.layers, self._segs)])
         self.snap_read = 0
         on = self.obs_normalizer
@@ -382,6 +397,7 @@ class ActorCritic:
 
     def publish_weights(self, slot: int) -> None:
         self._snap[slot].copy_(self.flat_params)
+        self._snap_t[slot].copy_(self.flat_params_t)
         if self._snap_tabs is not None:
             self._snap_tabs[slot][0].copy_(self.obs_normalizer.mu_tab)
             self._snap_tabs[slot][1].copy_(self.obs_normalizer.rstd_tab)
@@ -390,7 +406,7 @@ class ActorCritic:
         if tag == "inf" and self._snap is not None:
             return self._snap_views[self.snap_read][li]
         L = self.layers[li]
-        return L.w, L.b
+        return L.w, L.b, L.wt
 
     def _gemm(self, li, x, stride, index, offset, traj_T, out, n, tag):
         L = self.layers[li]
@@ -398,7 +414,10 @@ class ActorCritic:
         if traj_T:
             d = lib.sf_conv_desc.from_buffer_copy(L.desc)
             d.traj_T = int(traj_T)
-        w, b = self._wb(li, tag)
+        w, b, wt = self._wb(li, tag)
+        if wt is not None and index is None and not traj_T and lib.conv_fwd_t_supported(n, d):
+            lib.conv_fwd_t(x, stride, wt, b, out, n, d)  # dense f32 input, grid fills the chip: LDS-DMA kernel
+            return
         wsb = lib.conv_fwd_workspace(n, d) if index is None and not traj_T else 0  # split-K for chip-starving launches
         lib.conv_fwd_raw(x, stride, index, offset, w, b, out, n, d, self._workspace(wsb) if wsb else None)
 
@@ -449,7 +468,7 @@ class ActorCritic:
         st = rnn["states"]
         assert st.shape == (n, S) and st.stride(1) == 1
         gh = self._buf((tag, "gh"), (n, Lh.N))
-        w_hh, b_hh = self._wb(li + 1, tag)
+        w_hh, b_hh, _ = self._wb(li + 1, tag)
         lib.conv_fwd_raw(st, st.stride(0), None, 0, w_hh, b_hh, gh, n, Lh.desc)
         h_out = self._buf((tag, "h_out"), (n, H))
         c_out = self._buf((tag, "c_out"), (n, H)) if kind == 1 else None
