@@ -780,7 +780,7 @@ extern "C" int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *h_desc) {
 }
 #define GLDS_FWD(BM, BN, WM, WN, NS)                                                                              \
     k_fwd_glds<BM, BN, WM, WN, NS><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN)), dim3(256), 0, STREAM(stream)>>>( \
-        g, in, in_sample_stride, wt, bias, out, Mtot, ablate_f)
+        g, in, in_sample_stride, wt, bias, out, Mtot)
 extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
                              int64_t n, const sf_conv_desc *h_desc, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_fwd_t");
@@ -793,7 +793,6 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     const int64_t Mtot = n * g.OH * g.OW;
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd_t: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
     static const int cfg = getenv("SF_GLDS_CFG") ? atoi(getenv("SF_GLDS_CFG")) : 0;
-    static const int ablate_f = getenv("SF_ABLATE") ? atoi(getenv("SF_ABLATE")) : 0;
     if (cfg == 1) GLDS_FWD(128, 64, 2, 2, 3);
     else if (cfg == 2) GLDS_FWD(128, 128, 2, 2, 2);
     else if (cfg == 3) GLDS_FWD(128, 128, 2, 2, 3);
@@ -942,27 +941,23 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     const bool vec = g.vecB && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0;
     // pixel-major LDS-DMA kernel: needs enough samples to fill BM-sample row tiles and Cout % 32 == 0
     static const int pix_cfg = getenv("SF_DGRAD_PIX") ? atoi(getenv("SF_DGRAD_PIX")) : 1;
-    static const int ablate = getenv("SF_ABLATE") ? atoi(getenv("SF_ABLATE")) : 0;
     if (pix_cfg && vec && g.Cout % 32 == 0 && n >= 1024) {
 #define DGRAD_PIX(BM, BN, WM, WN)                                                                          \
     do {                                                                                                   \
         const int ntiles = (int)((n + BM - 1) / BM), tiles8 = (ntiles + 7) / 8, ctiles = (g.Cin + BN - 1) / BN; \
         k_dgrad_pix<BM, BN, WM, WN><<<dim3((unsigned)(tiles8 * 8 * g.H * ctiles)), dim3(256), 0, st>>>(    \
-            g, dout, w, in_act, din, (int)n, ntiles, tiles8, ablate);                                      \
+            g, dout, w, in_act, din, (int)n, ntiles, tiles8);                                              \
     } while (0)
+        if (g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0 && pix_cfg != 3) {
+            // strided conv, row-walking tiles of (sample, group-column) rows: contiguous activation / gradient rows
+            const int Wg = g.W / g.S;
+            const int64_t Mrows = n * Wg;
+            k_dgrad_quadrow<128, 128, 2, 2><<<dim3(cdiv64(Mrows, 128), cdiv64(g.S * g.S * g.Cin, 128)), dim3(256), 0,
+                                              st>>>(g, dout, w, in_act, din, Mrows, make_fastdiv((uint32_t)Wg));
+            return sf_launch_status("sf_conv_dgrad");
+        }
         if (g.Cin <= 32) { if (pix_cfg == 2) DGRAD_PIX(128, 32, 4, 1); else DGRAD_PIX(256, 32, 4, 1); }
         else DGRAD_PIX(128, 64, 2, 2);
-        return sf_launch_status("sf_conv_dgrad");
-    }
-    // gfx950 LDS-DMA path: reduction chunks must not straddle a tap (Cout % 32 == 0) and the grid must be large
-    static const int glds_cfg = getenv("SF_GLDS_DGRAD") ? atoi(getenv("SF_GLDS_DGRAD")) : 0;
-    if (glds_cfg && vec && g.Cout % 32 == 0 && Mc * ((g.Cin + 63) / 64) >= 128LL * 1024) {
-#define DGRAD_GLDS(BM, BN, WM, WN)                                                                          \
-    k_dgrad_glds<BM, BN, WM, WN><<<dim3(cdiv64(Mc, BM), cdiv64(g.Cin, BN), classes), dim3(256), 0, st>>>(   \
-        g, dout, w, in_act, din, n)
-        if (g.Cin <= 32) { if (glds_cfg == 2) DGRAD_GLDS(256, 32, 4, 1); else DGRAD_GLDS(128, 32, 4, 1); }
-        else if (glds_cfg == 2) DGRAD_GLDS(128, 128, 2, 2);
-        else DGRAD_GLDS(128, 64, 2, 2);
         return sf_launch_status("sf_conv_dgrad");
     }
     if (g.Cin <= 32) DGRAD_LAUNCH(128, 32, 4, 1);
@@ -1001,7 +996,9 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         const int Hc = (g.H + g.S - 1) / g.S, Wc = (g.W + g.S - 1) / g.S;
         const int64_t Mc = n * Hc * Wc;
         const char *v = g.vecB ? "true" : "false";
-        if (g.vecB && g.Cout % 32 == 0 && n >= 1024)
+        if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
+            snprintf(out, cap, "k_dgrad_quadrow<128, 128, 2, 2>");
+        else if (g.vecB && g.Cout % 32 == 0 && n >= 1024)
             snprintf(out, cap, g.Cin <= 32 ? "k_dgrad_pix<256, 32, 4, 1>" : "k_dgrad_pix<128, 64, 2, 2>");
         else if (g.Cin <= 32) snprintf(out, cap, "k_conv_dgrad<128, 32, 4, 1, %s>", v);
         else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) snprintf(out, cap, "k_conv_dgrad<64, 64, 2, 2, %s>", v);

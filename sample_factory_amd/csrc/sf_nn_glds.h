@@ -66,7 +66,7 @@ __device__ __forceinline__ void mma_chunk_rows(const float *__restrict__ As, con
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                                   const float *__restrict__ wt, const float *__restrict__ bias,
-                                                  float *__restrict__ out, int64_t Mtot, int ablate) {
+                                                  float *__restrict__ out, int64_t Mtot) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     for (int k0 = 0; k0 < K; k0 += 32) {
         if (NS == 3 && k0 + 32 < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(ablate & 4)) BARRIER_NOFENCE();  // chunk k0 is visible to all waves, and the stage about to be refilled is no longer read
+        BARRIER_NOFENCE();  // chunk k0 is visible to all waves, and the stage about to be refilled is no longer read
         const int kn = k0 + (NS - 1) * 32;
         int sn = stage + NS - 1;
         sn = sn >= NS ? sn - NS : sn;
-        if (kn < K && !(ablate & 1)) issue(kn, sn);
-        const float *sa = lds + ((ablate & 2) ? 0 : stage * STAGE);
+        if (kn < K) issue(kn, sn);
+        const float *sa = lds + stage * STAGE;
         mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
@@ -164,113 +164,8 @@ __global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ w, 
     }
 }
 
-// ============================================================================================== DATA GRADIENT (glds)
-// din[m'][c] = act'(in_act) * sum_{(a,b),co} dY[smp, ihh-a, iww-b, co] * W[((ph+a*S)*KW + pw+b*S)*Cin + c][co]
-// per stride-parity class (ph, pw) = blockIdx.z, rows m' = (smp, ihh, iww) over the class's input pixels — the same
-// decomposition as k_conv_dgrad.  Both operands have the reduction index co contiguous (dY rows; the canonical
-// K-major weights ARE Cin-row-major for this product), so no transposed copy is needed.  A tap that falls outside dY
-// for a given row must contribute zero: its DMA source is redirected to a page of zeros.
+// A DMA source for rows that must contribute nothing (taps outside dY, reduction rows past the end).
 __device__ __attribute__((aligned(128))) const float sf_zero_page[32] = {};
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_dgrad_glds(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
-                                                    const float *__restrict__ in_act, float *__restrict__ din,
-                                                    int64_t nsamples) {
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AI = BM / 32, BI = BN / 32;
-    constexpr int STAGE = (BM + BN) * 32;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BI >= 1, "4 waves per block");
-    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int ph = blockIdx.z / g.S, pw = blockIdx.z % g.S;
-    const int Hc = (g.H - ph + g.S - 1) / g.S, Wc = (g.W - pw + g.S - 1) / g.S;
-    const int KHs = (g.KH - ph + g.S - 1) / g.S, KWs = (g.KW - pw + g.S - 1) / g.S;
-    const int64_t Mc = nsamples * Hc * Wc;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    if (m0 >= Mc || Hc <= 0 || Wc <= 0) return;
-    const int n0 = blockIdx.y * BN;
-    const int Cin = g.Cin, Cout = g.Cout;
-    const int Kp = KHs * KWs * Cout;
-    const FastDiv fHW = g.dHcWc[blockIdx.z], fW = g.dWc[blockIdx.z], fKWs = g.dKWs[blockIdx.z];
-    const uint32_t HcWc = (uint32_t)(Hc * Wc);
-
-    const int lrow = lane >> 3, lpos = lane & 7;
-    int arow[AI], aih[AI], aiw[AI], apos[AI];
-    const float *bsrc[BI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int row = (i * 4 + wave) * 8 + lrow;
-        int64_t m = m0 + row;
-        m = m < Mc ? m : Mc - 1;
-        const uint32_t smp = fdiv((uint32_t)m, fHW), pix = (uint32_t)m - smp * HcWc;
-        aih[i] = (int)fdiv(pix, fW);
-        aiw[i] = (int)pix - aih[i] * Wc;
-        arow[i] = (int)(smp * (uint32_t)(g.OH * g.OW)) + aih[i] * g.OW + aiw[i];
-        apos[i] = (lpos ^ ((row >> 1) & 7)) << 2;
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-        const int row = (i * 4 + wave) * 8 + lrow;
-        int c = n0 + row;
-        c = c < Cin ? c : Cin - 1;
-        bsrc[i] = w + (int64_t)c * Cout + ((lpos ^ ((row >> 1) & 7)) << 2);
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a_ = 0; a_ < TM; ++a_)
-#pragma unroll
-        for (int b_ = 0; b_ < TN; ++b_)
-#pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
-
-    auto issue = [&](int k0, int stage) {
-        const int tap = (int)fdiv((uint32_t)k0, g.dCout), co0 = k0 - tap * Cout;  // wave-uniform
-        const int a = (int)fdiv((uint32_t)tap, fKWs), b = tap - a * KWs;
-        const int drow = a * g.OW + b;
-        const int64_t wrow = (int64_t)(((ph + a * g.S) * g.KW + (pw + b * g.S)) * Cin) * Cout + co0;
-        float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int oh = aih[i] - a, ow = aiw[i] - b;
-            const bool ok = oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
-            const float *src = ok ? dy + (int64_t)(arow[i] - drow) * Cout + co0 + apos[i] : sf_zero_page + apos[i];
-            GLDS16(src, sa + (i * 4 + wave) * 256);
-        }
-#pragma unroll
-        for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + wrow, sb + (i * 4 + wave) * 256);
-    };
-    if (Kp > 0) issue(0, 0);
-    int stage = 0;
-    for (int k0 = 0; k0 < Kp; k0 += 32, stage ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (k0 + 32 < Kp) issue(k0 + 32, stage ^ 1);
-        const float *sa = lds + stage * STAGE;
-        mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
-    }
-    const int akind = g.relu;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + wm * TM * 32 + tm * 32 + FRAG_ROW(r, lane);
-            const bool mok = m < Mc;
-            const uint32_t mm = mok ? (uint32_t)m : 0u;
-            const uint32_t smp = fdiv(mm, fHW), pix = mm - smp * HcWc;
-            const int ihh = (int)fdiv(pix, fW), iww = (int)pix - ihh * Wc;
-            const int64_t obase = (((int64_t)smp * g.H + (ihh * g.S + ph)) * g.W + (iww * g.S + pw)) * Cin;
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int c = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
-                if (mok && c < Cin) {
-                    float v = acc[tm][tn][r];
-                    if (in_act) v *= act_bwd(in_act[obase + c], akind);
-                    din[obase + c] = v;
-                }
-            }
-        }
-}
 
 // ============================================================================================== DATA GRADIENT, pixel-major
 // The class-decomposed gather form above still multiplies by structural zeros at the image border: a row tile mixes
@@ -286,7 +181,7 @@ __global__ __launch_bounds__(256) void k_dgrad_glds(ConvG g, const float *__rest
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
                                                    const float *__restrict__ in_act, float *__restrict__ din,
-                                                   int nsamples, int ntiles, int tiles8, int ablate) {
+                                                   int nsamples, int ntiles, int tiles8) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;
@@ -346,7 +241,7 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
     // drain sits in front of a vmcnt(0).
     float pend[TM][TN][16], actv[TM][TN][16];
     auto prefetch_act = [&](int iw) {
-        if (!in_act || (ablate & 2)) return;
+        if (!in_act) return;
         const uint32_t pix = (uint32_t)iw * (uint32_t)Cin;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -370,7 +265,7 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[tm][tn][r];
-                    if (in_act && !(ablate & 2)) v *= act_bwd(actv[tm][tn][r], akind);
+                    if (in_act) v *= act_bwd(actv[tm][tn][r], akind);
                     pend[tm][tn][r] = v;
                 }
     };
@@ -385,7 +280,6 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
                 for (int tn = 0; tn < TN; ++tn) {
                     if (rc < slim && ccol + tn * 32 < Cin) {
                         const uint32_t o = obase + pix + (uint32_t)rc * sstride + (uint32_t)(tn * 32);
-                        if ((ablate & 1) && pend[tm][tn][r] != 12345.678f) continue;
                         din[o] = pend[tm][tn][r];
                     }
                 }
@@ -422,9 +316,8 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
         const int64_t aoff = (int64_t)(oh * OW + ow) * Cout + cc * 32;
         const int64_t boff = (int64_t)((kh * g.KW + kw) * Cin) * Cout + cc * 32;
         float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
-        if (ablate & 4) return;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) GLDS16(asrc[i] + ((ablate & 8) ? 0 : aoff), sa + (i * 4 + wave) * 256);
+        for (int i = 0; i < AI; ++i) GLDS16(asrc[i] + aoff, sa + (i * 4 + wave) * 256);
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + boff, sb + (i * 4 + wave) * 256);
     };
@@ -717,5 +610,180 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
             }
         }
         __syncthreads();  // everybody is done reading this strip before it is overwritten
+    }
+}
+
+// ============================================================================================== DATA GRADIENT, stride groups
+// Strided convolutions (conv2: 4x4 stride 2, Cin = 32): with one input pixel per tile the GEMM is only N = Cin = 32
+// columns wide and K = 2x2 taps x Cout deep, so twice the operand traffic per MFMA of an N = 64 tile and a 8-chunk
+// reduction per epilogue.  But the S x S input pixels (ihc*S + ph, iwc*S + pw) all read the SAME (KH/S) x (KW/S) block
+// of dY pixels (ihc - a, iwc - b) — only the filter tap (ph + S*a, pw + S*b) differs.  So per S x S pixel group:
+//   A[row][(a, b, co)]         = dY[s, ihc - a, iwc - b, co]
+//   B[(ph, pw, c)][(a, b, co)] = W[((ph + S*a)*KW + pw + S*b)*Cin + c][co]         N = S*S*Cin = 128, K = 256 (conv2)
+// i.e. every filter tap is used exactly once per group: a dense N = 128, K = 256 GEMM with 64 x 64 wave tiles.  Same
+// DMA pipeline and swizzle as k_dgrad_pix.
+//
+// Tiling.  A first version tiled BM SAMPLES at one pixel group (like k_dgrad_pix); its epilogue then touches BM
+// scattered 256-byte pieces (one per sample, 50 KB apart) and was no faster.  Here a tile is 128 consecutive rows
+// m = (sample, iwc) — about 13 whole image rows of groups — and the block walks DOWN the image (ihc = 0..Hg-1): per
+// step every sample of the tile reads/writes two complete contiguous image rows (2 x 2.5 KB for conv2), dY rows are
+// contiguous 256-byte neighbours, and the per-row (sample, iwc) decode is done once per block (row offsets parked in
+// LDS).  (a, b) blocks outside dY: a is uniform per step and skipped; b depends on iwc, i.e. on the row, so a row whose
+// tap column falls outside dY takes its DMA from the zero page (10 % of the rows x taps for conv2 — the only
+// structural-zero work left).  Measured (n = 32768, conv2): class-decomposed im2col kernel 2.98 ms, pixel-major
+// 2.51 ms, this kernel 2.33 ms; with all memory traffic removed 1.65 ms — the epilogue's 64 loads + 64 stores per lane
+// and step, not the matrix pipe, are what is left.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *__restrict__ dy,
+                                                         const float *__restrict__ w, const float *__restrict__ in_act,
+                                                         float *__restrict__ din, int64_t Mrows, FastDiv dWg) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per block");
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    __shared__ uint32_t rowoff[BM];  // element offset of (sample, iwc) inside din / in_act, 0xFFFFFFFF = row past M
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int Cin = g.Cin, Cout = g.Cout, S = g.S, OH = g.OH, OW = g.OW, H = g.H, W = g.W;
+    const int Hg = (H + S - 1) / S, Wg = (int)dWg.d, N = S * S * Cin;
+    const int KHs = g.KH / S, KWs = g.KW / S, CC = Cout >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const uint32_t sstride = (uint32_t)(H * W * Cin);
+    if (tid < BM) {
+        const int64_t m = m0 + tid;
+        const uint32_t mm = m < Mrows ? (uint32_t)m : 0u;
+        const uint32_t s = fdiv(mm, dWg), iwc = mm - s * (uint32_t)Wg;
+        rowoff[tid] = m < Mrows ? s * sstride + iwc * (uint32_t)(S * Cin) : 0xFFFFFFFFu;
+    }
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const float *asrc[AI], *bsrc[BI];
+    int aiwc[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int64_t m = m0 + row;
+        m = m < Mrows ? m : Mrows - 1;
+        const uint32_t s = fdiv((uint32_t)m, dWg);
+        aiwc[i] = (int)((uint32_t)m - s * (uint32_t)Wg);
+        asrc[i] = dy + ((int64_t)s * (OH * OW) + aiwc[i]) * Cout + ((lpos ^ ((row >> 1) & 7)) << 2);
+    }
+    const int zpos = lpos << 2;  // any 16 bytes of the zero page
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int n = n0 + row;
+        n = n < N ? n : N - 1;
+        const int pp = (int)fdiv((uint32_t)n, g.dCin), c = n - pp * Cin, ph = pp / S, pw = pp - ph * S;
+        bsrc[i] = w + (int64_t)((ph * g.KW + pw) * Cin + c) * Cout + ((lpos ^ ((row >> 1) & 7)) << 2);
+    }
+    f32x16 acc[TM][TN];
+    // column fragment tn of this lane = (pixel (ph, pw) of the group, channel c)
+    uint32_t cbase[TN];
+    bool colok[TN];
+    int phv[TN], pwv[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
+        const int nc = n < N ? n : 0;
+        const int pp = (int)fdiv((uint32_t)nc, g.dCin), c = nc - pp * Cin;
+        phv[tn] = pp / S;
+        pwv[tn] = pp - phv[tn] * S;
+        colok[tn] = n < N;
+        cbase[tn] = (uint32_t)((phv[tn] * W + pwv[tn]) * Cin + c);
+    }
+    const int rbase = wm * TM * 32 + 4 * (lane >> 5);
+    float actv[TM][TN][16];
+    __syncthreads();  // rowoff visible
+    auto prefetch_act = [&](int ihc) {
+        if (!in_act) return;
+        const uint32_t gy = (uint32_t)(ihc * S * W * Cin);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t ro = rowoff[rbase + tm * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const bool ok = ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H;
+                    actv[tm][tn][r] = in_act[ok ? ro + gy + cbase[tn] : 0u];
+                }
+            }
+    };
+    auto store_step = [&](int ihc, bool zero) {
+        const uint32_t gy = (uint32_t)(ihc * S * W * Cin);
+        const int akind = g.relu;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t ro = rowoff[rbase + tm * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    if (ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H) {
+                        float v = zero ? 0.f : acc[tm][tn][r];
+                        if (in_act && !zero) v *= act_bwd(actv[tm][tn][r], akind);
+                        din[ro + gy + cbase[tn]] = v;
+                    }
+            }
+    };
+    // (the last group column of an image whose width is not a multiple of S has pixels past W: never the case for the
+    // launcher's contract W % S == 0)
+    struct St { int ihc, a_lo, na, total; };
+    auto step = [&](int ihc) {
+        St p;
+        p.ihc = ihc;
+        p.a_lo = ihc - OH + 1 > 0 ? ihc - OH + 1 : 0;
+        const int a_hi = ihc < KHs - 1 ? ihc : KHs - 1;
+        p.na = a_hi - p.a_lo + 1;
+        p.na = p.na > 0 ? p.na : 0;
+        p.total = p.na * KWs * CC;
+        return p;
+    };
+    auto next_step = [&](int ihc) {  // first step >= ihc with work (Hg: none)
+        St p = step(ihc);
+        while (p.ihc < Hg && p.total == 0) p = step(p.ihc + 1);
+        return p;
+    };
+    auto issue = [&](const St &p, int q, int stage) {
+        const int blk = q / CC, cc = q - blk * CC;
+        const int a = p.a_lo + blk / KWs, b = blk % KWs;
+        const int64_t aoff = (int64_t)((p.ihc - a) * OW - b) * Cout + cc * 32;
+        const int64_t boff = (int64_t)((S * a * g.KW + S * b) * Cin) * Cout + cc * 32;
+        float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int ow = aiwc[i] - b;
+            const float *src = (ow >= 0 && ow < OW) ? asrc[i] + aoff : sf_zero_page + zpos;
+            GLDS16(src, sa + (i * 4 + wave) * 256);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + boff, sb + (i * 4 + wave) * 256);
+    };
+    St cur = next_step(0);
+    for (int z = 0; z < cur.ihc && z < Hg; ++z) store_step(z, true);
+    if (cur.ihc < Hg) issue(cur, 0, 0);
+    int stage = 0;
+    while (cur.ihc < Hg) {
+        const St nx = next_step(cur.ihc + 1);
+#pragma unroll
+        for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < TN; ++b_)
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+        for (int q = 0; q < cur.total; ++q, stage ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (q + 1 < cur.total) issue(cur, q + 1, stage ^ 1);
+            else if (nx.ihc < Hg) issue(nx, 0, stage ^ 1);
+            if (q == 0) prefetch_act(cur.ihc);
+            const float *sa = lds + stage * STAGE;
+            mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+        }
+        store_step(cur.ihc, false);
+        for (int z = cur.ihc + 1; z < nx.ihc && z < Hg; ++z) store_step(z, true);
+        cur = nx;
     }
 }
