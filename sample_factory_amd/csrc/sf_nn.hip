@@ -890,6 +890,25 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
     hipStream_t st = STREAM(stream);
     static const int glds_on = getenv("SF_WGRAD_GLDS") ? atoi(getenv("SF_WGRAD_GLDS")) : 1;
     int Zused = p.Z;
+    static const int img_on = getenv("SF_CONV1_IMG") ? atoi(getenv("SF_CONV1_IMG")) : 1;
+    if (img_on && conv1_img_ok(g, mode, n) && N == 32 && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0 &&
+        ((uintptr_t)dout & 15) == 0) {
+        // Nature-CNN conv1 on raw frames: strip-image kernel, persistent blocks, one partial per block
+        const int npairs = (int)((n + 1) / 2);
+        int nb = npairs < 512 ? npairs : 512;
+        if (nb > p.Z) nb = p.Z;  // the workspace was sized for p.Z partials
+        partial_b = partial_w + (int64_t)nb * K * N;
+        Zused = nb;
+        const unsigned lds_bytes = (unsigned)((160 * 32 + 2 * 4 * 20 * 84) * sizeof(float));
+        if (g.sub_mean != 0.f)
+            k_conv1_wgrad_img<2, 4, true><<<dim3(nb), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
+                db ? partial_b : nullptr, (int)n, npairs);
+        else
+            k_conv1_wgrad_img<2, 4, false><<<dim3(nb), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
+                db ? partial_b : nullptr, (int)n, npairs);
+    } else
     if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && Mtot >= 65536) {
         // gfx950 LDS-DMA kernel (dense f32 NHWC input): different tiles, so its own split plan and partial layout
         const WgradGlds q = plan_wgrad_glds(Mtot, K, N);
@@ -985,6 +1004,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
     } else if (op == 3) {
         snprintf(out, cap, "k_fwd_glds<128, 64, 2, 2>");
+    } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
+        snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
     } else if (op == 1 && mode == MODE_F32 && Mtot >= 65536) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
         snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"

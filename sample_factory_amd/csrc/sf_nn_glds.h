@@ -787,3 +787,190 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
         cur = nx;
     }
 }
+
+// ============================================================================================== WEIGHT GRADIENT, raw u8 frames
+// dW[(c, kh, kw)][n] = sum over (sample, oh, ow) of x[s, c, oh*S + kh, ow*S + kw] * dY[s, oh, ow, n]  for Nature-CNN conv1.
+// Same strip image as k_conv_u8_img (bytes converted ONCE into an f32 LDS image; the im2col kernel converts every byte
+// 4 times and spends 2 VALU per MFMA operand, which costs matrix-pipe time).  The reduction runs over output pixels,
+// so the whole 256 x 32 gradient (8 KB per lane-set = 128 accumulator registers) stays resident in EVERY wave and
+// each wave reduces its own quarter of the strip's pixels:
+//   16x16x4 MFMA: 4 reduction indices per instruction = 4 consecutive output pixels m (lane group kg = lane >> 4).
+//   A operand, lane (i, kg): ONE ds_read_b128 at image position (c, oh*S + i/2, ow*S + 4*(i%2)) of pixel m_kg gives
+//     x for k = c*64 + 4i .. 4i+3 — four different weight ROWS.  Output rows are relabelled (tile j holds rows
+//     c*64 + 4i + j) so that those four words feed four MFMAs on four accumulator tiles.
+//   B operand, lane (n, kg): dY[m_kg][n] and dY[m_kg][n + 16] straight from a DMA'd copy of the strip's dY rows.
+//   => per pixel quad: 4 ds_read_b128 + 2 ds_read_b32 feed 32 MFMAs, no VALU.
+// Blocks are persistent over sample pairs; the four waves' accumulators are summed through LDS at the end and written
+// as ONE partial per block (reduced by k_reduce_partials, deterministic).  The bias gradient (column sums of dY) rides
+// along from the LDS copy of dY.
+template <int SMP, int R, bool SUB>
+__global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                           const int32_t *__restrict__ index, int64_t offset,
+                                                           const float *__restrict__ dy, float *__restrict__ partial,
+                                                           float *__restrict__ partial_b, int nsamples, int npairs) {
+    constexpr int H = 84, W = 84, Cin = 4, KH = 8, KW = 8, S = 4, OH = 20, OW = 20, OHOW = OH * OW, N = 32, K = 256;
+    constexpr int RS = (R - 1) * S + KH, W4 = W >> 2, NLD = 7;
+    constexpr int ROWS = SMP * R * OW;       // output pixels per strip (160)
+    constexpr int QW = ROWS / 4 / 4;         // pixel quads per wave and strip (10)
+    static_assert(ROWS % 16 == 0 && Cin * RS * W4 <= 256 * NLD, "strip geometry");
+    constexpr int IMG_F = SMP * Cin * RS * W;  // floats of the image strip
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    float *dys = smem;                 // [ROWS][32] dY rows of the strip (DMA destination, 1 KiB granules)
+    float *strip = smem + ROWS * N;    // [SMP][Cin][RS][W]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int words = Cin * RS * W4;
+    int gofs[NLD], lofs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        int q = tid + 256 * i;
+        const bool ok = q < words;
+        q = ok ? q : 0;
+        const int x4 = q % W4, t1 = q / W4, row = t1 % RS, c = t1 / RS;
+        gofs[i] = (c * H + row) * W + x4 * 4;
+        lofs[i] = ok ? (c * RS + row) * W + x4 * 4 : -1;
+    }
+    // this lane's image origin for each of its wave's quads: pixel m = (wave*QW + q)*4 + kg inside the strip
+    int origin[QW];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+        const int m = (wave * QW + q) * 4 + kg;
+        const int smp = m / (R * OW), p = m - smp * (R * OW), ohl = p / OW, ow = p - ohl * OW;
+        origin[q] = (smp * Cin * RS + ohl * S + (i16 >> 1)) * W + ow * S + 4 * (i16 & 1);
+    }
+    f32x4 acc[Cin][4][2];
+#pragma unroll
+    for (int c = 0; c < Cin; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[c][j][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float colacc = 0.f;
+    const float sub = g.sub_mean, scl = g.inv_scale;
+    uint32_t pre[SMP][NLD];
+    const uint8_t *sbase[SMP];
+    auto set_pair = [&](int pair) {
+#pragma unroll
+        for (int z = 0; z < SMP; ++z) {
+            int sg = pair * SMP + z;
+            sg = sg < nsamples ? sg : nsamples - 1;
+            sbase[z] = in + sample_base(g, index, offset, in_stride, (uint32_t)sg);
+        }
+    };
+    auto load_strip = [&](int st) {
+        const int rowoff = st * R * S * W;
+#pragma unroll
+        for (int z = 0; z < SMP; ++z)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) pre[z][i] = *reinterpret_cast<const uint32_t *>(sbase[z] + rowoff + gofs[i]);
+    };
+    auto store_strip = [&]() {
+#pragma unroll
+        for (int z = 0; z < SMP; ++z)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float b8 = (float)((pre[z][i] >> (8 * j)) & 0xFFu);
+                    v[j] = (SUB ? b8 - sub : b8) * scl;
+                }
+                if (lofs[i] >= 0)
+                    *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(strip + z * Cin * RS * W + lofs[i], 16)) = v;
+            }
+    };
+    // dY rows of (pair, strip): SMP runs of R*OW rows x 128 B; ROWS*128/1024 = 20 DMA instructions, 5 per wave
+    auto dma_dy = [&](int pair, int st) {
+#pragma unroll
+        for (int i = 0; i < ROWS * N / 256 / 4; ++i) {
+            const int j = i * 4 + wave, e = j * 256 + lane * 4;       // float index inside dys
+            const int m = e >> 5, n4 = e & 31, smp = m / (R * OW), p = m - smp * (R * OW);
+            int sg = pair * SMP + smp;
+            const bool ok = sg < nsamples;
+            sg = ok ? sg : nsamples - 1;
+            const float *src = ok ? dy + ((int64_t)sg * OHOW + st * (R * OW) + p) * N + n4 : sf_zero_page;
+            GLDS16(src, dys + j * 256);
+        }
+    };
+    constexpr int nstrips = OH / R;
+    int pair = blockIdx.x;
+    if (pair < npairs) { set_pair(pair); load_strip(0); dma_dy(pair, 0); }
+    for (; pair < npairs; pair += gridDim.x) {
+        for (int st = 0; st < nstrips; ++st) {
+            store_strip();  // VALU + ds_write: runs while this strip's dY DMA (issued one phase ago) is in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // prefetch the next strip's bytes (next strip of this pair, or strip 0 of the block's next pair)
+            if (st + 1 < nstrips) load_strip(st + 1);
+            else if (pair + (int)gridDim.x < npairs) { set_pair(pair + gridDim.x); load_strip(0); }
+            if (partial_b) {  // bias gradient: thread (n, part) sums every 8th row; parts are combined at the end
+#pragma unroll 4
+                for (int m = tid >> 5; m < ROWS; m += 8) colacc += dys[m * N + (tid & 31)];
+            }
+#pragma unroll
+            for (int q = 0; q < QW; ++q) {
+                const float *bp = dys + ((wave * QW + q) * 4 + kg) * N + i16;
+                const float b0 = bp[0], b1 = bp[16];
+#pragma unroll
+                for (int c = 0; c < Cin; ++c) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(
+                        __builtin_assume_aligned(strip + origin[q] + c * RS * W, 16));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[c][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0, acc[c][j][0], 0, 0, 0);
+                        acc[c][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1, acc[c][j][1], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();  // strip and dys are free again
+            if (st + 1 < nstrips) dma_dy(pair, st + 1);
+            else if (pair + (int)gridDim.x < npairs) dma_dy(pair + gridDim.x, 0);
+        }
+    }
+    // ---- block reduction of the four waves' accumulators (fixed order: wave 0 + 1 + 2 + 3), then one partial per block
+    float *red = smem;  // 4 x 8192 floats = 128 KiB would not fit: reduce in two rounds of pairs through 2 x 32 KiB
+    // C layout of tile (c, j, h): reg r -> weight row k = c*64 + 4*(4*kg + r) + j, column n = 16*h + i16
+    auto put = [&](float *dst) {
+#pragma unroll
+        for (int c = 0; c < Cin; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(c * 64 + 4 * (4 * kg + r) + j) * N + 16 * h + i16] = acc[c][j][h][r];
+    };
+    auto add = [&](const float *src) {
+#pragma unroll
+        for (int c = 0; c < Cin; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[c][j][h][r] += src[(c * 64 + 4 * (4 * kg + r) + j) * N + 16 * h + i16];
+    };
+    if (wave & 1) put(red + (wave >> 1) * K * N);   // waves 1, 3 -> slots 0, 1
+    __syncthreads();
+    if (!(wave & 1)) add(red + (wave >> 1) * K * N);  // wave 0 += wave 1, wave 2 += wave 3
+    __syncthreads();
+    if (wave == 2) put(red);
+    __syncthreads();
+    if (wave == 0) {
+        add(red);
+        put(partial + (int64_t)blockIdx.x * K * N);
+    }
+    if (partial_b) {
+        __syncthreads();
+        red[tid] = colacc;
+        __syncthreads();
+        if (tid < N) {
+            float sum = 0.f;
+#pragma unroll
+            for (int part = 0; part < 8; ++part) sum += red[part * 32 + tid];
+            partial_b[(int64_t)blockIdx.x * N + tid] = sum;
+        }
+    }
+}

@@ -183,6 +183,20 @@ def test_conv1_lds_image_kernel_vs_torch(lib, geom, n, mean):
         m = min(100, n - i)
         lib.conv_fwd(xs, Cin * H * W, None, i, wk, b.cuda(), out2[i * d.OH * d.OW:], m, d)
     assert (out - out2).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # weight / bias gradient of the same layer (strip-image kernel for the 84x84 geometry with 32 filters)
+    dy = torch.randn((n, Cout, d.OH, d.OW), generator=g)
+    dy_dev = dy.permute(0, 2, 3, 1).contiguous().cuda().view(n * d.OH * d.OW, Cout)
+    dw = torch.zeros_like(wk)
+    db = torch.zeros(Cout, device="cuda")
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    lib.conv_wgrad(x_dev, Cin * H * W, idx.cuda(), 0, dy_dev, dw, db, n, d, ws)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    F.conv2d((x[idx.long()].double() - mean) * inv, wr.double(), br.double(), stride=S).backward(dy.double())
+    dw_got = from_kmajor(dw.cpu().double(), Cout, Cin, K, K, 1)
+    sw = wr.grad.abs().max().item()
+    assert (dw_got - wr.grad.double()).abs().max().item() < 3e-5 * max(1.0, sw), "wgrad"
+    assert (db.cpu().double() - br.grad.double()).abs().max().item() < 3e-5 * max(1.0, br.grad.abs().max().item())
 
 
 @pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64)])
