@@ -666,6 +666,16 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// resident blocks per CU of a 256-thread kernel (registers + static LDS), for grid-quantisation decisions
+template <class KernelT>
+static int occupancy_of(KernelT kern) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, 0) != hipSuccess || nb < 1) nb = 2;
+    (void)hipGetLastError();
+    return nb;
+}
+
+
 static int pick_mode(const ConvG &g) {
     if (!g.vecA || !g.vecB) return MODE_GENERIC;
     return g.in_u8 ? MODE_U8 : MODE_F32;
@@ -793,9 +803,16 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     const int64_t Mtot = n * g.OH * g.OW;
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd_t: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
     static const int cfg = getenv("SF_GLDS_CFG") ? atoi(getenv("SF_GLDS_CFG")) : 0;
-    if (cfg == 1) GLDS_FWD(128, 64, 2, 2, 3);
-    else if (cfg == 2) GLDS_FWD(128, 128, 2, 2, 2);
-    else if (cfg == 3) GLDS_FWD(128, 128, 2, 2, 3);
+    // tile choice by grid quantisation: efficiency = rounds / ceil(rounds) with the kernel's own occupancy
+    static const int occ64 = occupancy_of(k_fwd_glds<128, 64, 2, 2, 2>), occ128 = occupancy_of(k_fwd_glds<128, 128, 2, 2, 2>);
+    bool wide = false;
+    if (g.Cout >= 128 && cfg == 0) {
+        const double u64 = (double)(cdiv64(Mtot, 128) * (int64_t)cdiv64(g.Cout, 64)) / (256.0 * occ64);
+        const double u128 = (double)(cdiv64(Mtot, 128) * (int64_t)cdiv64(g.Cout, 128)) / (256.0 * occ128);
+        const double e64 = u64 / (double)(int64_t)(u64 + 0.999999), e128 = u128 / (double)(int64_t)(u128 + 0.999999);
+        wide = e128 * 1.03 >= e64;  // 64x64 wave tiles: fewer LDS reads and DMA instructions per MFMA
+    }
+    if (cfg == 2 || wide) GLDS_FWD(128, 128, 2, 2, 2);
     else GLDS_FWD(128, 64, 2, 2, 2);
     return sf_launch_status("sf_conv_fwd_t");
 }
@@ -810,18 +827,42 @@ struct SplitPlan {
     int Z;
     int64_t m_per_split;
 };
-static SplitPlan plan_splits(int64_t Mtot, int K, int N, int BM, int BN) {
+// bpc = resident blocks per CU of the kernel that will run (hipOccupancy...), 0 = unknown (workspace query: return the
+// largest split count any bpc can lead to).  The reduction is split so that the grid fills the chip in WHOLE rounds:
+// 200 tiles x Z = 8 on 1024 slots is 1.56 rounds, i.e. 2 rounds at 78 % — Z = 5 (0.98 rounds) is 25 % faster.
+static SplitPlan plan_splits(int64_t Mtot, int K, int N, int BM, int BN, int bpc = 0) {
     const int64_t tiles = (int64_t)((K + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int64_t chunks = (Mtot + 31) / 32;
-    int64_t Z = (1536 + tiles - 1) / tiles;  // aim for ~1.5k blocks (6 per CU)
-    const int64_t zmax = (chunks + 7) / 8;   // at least 8 chunks (256 reduction rows) per split
-    if (Z > zmax) Z = zmax;
-    if (Z < 1) Z = 1;
-    if (Z > 1024) Z = 1024;
+    int64_t zcap = (2304 + tiles - 1) / tiles;  // never more than ~9 blocks per CU
+    const int64_t zmax = (chunks + 7) / 8;      // at least 8 chunks (256 reduction rows) per split
+    if (zcap > zmax) zcap = zmax;
+    if (zcap < 1) zcap = 1;
+    if (zcap > 1024) zcap = 1024;
+    int64_t Z = zcap;
+    if (bpc > 0) {
+        const double slots = 256.0 * bpc;
+        double best = -1.0;
+        for (int64_t z = 1; z <= zcap; ++z) {
+            const double u = (double)(tiles * z) / slots, rounds = u <= 1.0 ? 1.0 : (double)(int64_t)(u + 0.999999);
+            double eff = u / rounds;
+            if (tiles * z < 256) eff *= 0.5;          // fewer blocks than CUs: strictly worse than the formula says
+            if (eff > best + 0.02) { best = eff; Z = z; }  // ties / near-ties: the smaller split (less partial traffic)
+        }
+    }
     SplitPlan p;
     p.m_per_split = ((chunks + Z - 1) / Z) * 32;
     p.Z = (int)((Mtot + p.m_per_split - 1) / p.m_per_split);
     return p;
+}
+template <int BN, int WM, int WN, int MODE>
+static int occ_wgrad() {
+    static const int v = occupancy_of(k_conv_wgrad<BN, WM, WN, MODE>);
+    return v;
+}
+template <int BK, int BN, int WM, int WN>
+static int occ_wgrad_glds() {
+    static const int v = occupancy_of(k_wgrad_glds<BK, BN, WM, WN>);
+    return v;
 }
 static inline int wgrad_bn(int N) { return N <= 32 ? 32 : 64; }
 struct WgradGlds {
@@ -829,14 +870,20 @@ struct WgradGlds {
     int BK, BN, Z;
     int64_t m_per_split;
 };
-static WgradGlds plan_wgrad_glds(int64_t Mtot, int K, int N) {
+static WgradGlds plan_wgrad_glds(int64_t Mtot, int K, int N, bool query_occupancy = false) {
     static const int force = getenv("SF_WGRAD_GLDS") ? atoi(getenv("SF_WGRAD_GLDS")) : 1;
     WgradGlds q;
-    q.cfg = N >= 128 ? 1 : (K >= 256 ? 0 : 2);
+    // 256-row weight tiles only when they do not add padded rows over 128-row tiles (K = 576: 768 vs 640 rows)
+    const bool k256 = K >= 256 && (K + 255) / 256 * 256 <= (K + 127) / 128 * 128;
+    q.cfg = N >= 128 ? 1 : (k256 ? 0 : 2);
     if (force >= 2) q.cfg = force - 2;
     q.BK = q.cfg == 0 ? 256 : 128;
     q.BN = q.cfg == 1 ? 128 : 64;
-    const SplitPlan p = plan_splits(Mtot, K, N, q.BK, q.BN);
+    int bpc = 0;
+    if (query_occupancy)
+        bpc = q.cfg == 0 ? occ_wgrad_glds<256, 64, 4, 1>() : q.cfg == 1 ? occ_wgrad_glds<128, 128, 2, 2>()
+                                                                        : occ_wgrad_glds<128, 64, 2, 2>();
+    const SplitPlan p = plan_splits(Mtot, K, N, q.BK, q.BN, bpc);
     q.Z = p.Z;
     q.m_per_split = p.m_per_split;
     return q;
@@ -878,15 +925,21 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_wgrad: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
     const int K = g.K, N = g.Cout;
     const int BN = wgrad_bn(N);
-    const SplitPlan p = plan_splits(Mtot, K, N, 128, BN);
-    float *partial_w = reinterpret_cast<float *>(workspace);
-    float *partial_b = partial_w + (int64_t)p.Z * K * N;
     int mode = pick_mode(g);
     if (mode != MODE_GENERIC) {
         const bool al = h_desc->in_u8 ? (((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0)
                                       : (((uintptr_t)in & 15) == 0 && in_sample_stride % 4 == 0);
         if (!al || ((uintptr_t)dout & 15) != 0) mode = MODE_GENERIC;
     }
+    int bpc;
+    if (BN == 32) bpc = mode == MODE_F32 ? occ_wgrad<32, 4, 1, MODE_F32>() : mode == MODE_U8 ? occ_wgrad<32, 4, 1, MODE_U8>()
+                                                                                              : occ_wgrad<32, 4, 1, MODE_GENERIC>();
+    else bpc = mode == MODE_F32 ? occ_wgrad<64, 2, 2, MODE_F32>() : mode == MODE_U8 ? occ_wgrad<64, 2, 2, MODE_U8>()
+                                                                                     : occ_wgrad<64, 2, 2, MODE_GENERIC>();
+    const SplitPlan p = plan_splits(Mtot, K, N, 128, BN, bpc);
+    const int Zws = plan_splits(Mtot, K, N, 128, BN).Z;  // what sf_conv_wgrad_workspace promised room for
+    float *partial_w = reinterpret_cast<float *>(workspace);
+    float *partial_b = partial_w + (int64_t)p.Z * K * N;
     hipStream_t st = STREAM(stream);
     static const int glds_on = getenv("SF_WGRAD_GLDS") ? atoi(getenv("SF_WGRAD_GLDS")) : 1;
     int Zused = p.Z;
@@ -896,7 +949,7 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
         // Nature-CNN conv1 on raw frames: strip-image kernel, persistent blocks, one partial per block
         const int npairs = (int)((n + 1) / 2);
         int nb = npairs < 512 ? npairs : 512;
-        if (nb > p.Z) nb = p.Z;  // the workspace was sized for p.Z partials
+        if (nb > Zws) nb = Zws;  // the workspace was sized for Zws partials
         partial_b = partial_w + (int64_t)nb * K * N;
         Zused = nb;
         const unsigned lds_bytes = (unsigned)((160 * 32 + 2 * 4 * 20 * 84) * sizeof(float));
@@ -911,7 +964,7 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
     } else
     if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && Mtot >= 65536) {
         // gfx950 LDS-DMA kernel (dense f32 NHWC input): different tiles, so its own split plan and partial layout
-        const WgradGlds q = plan_wgrad_glds(Mtot, K, N);
+        const WgradGlds q = plan_wgrad_glds(Mtot, K, N, true);
         partial_b = partial_w + (int64_t)q.Z * K * N;
         Zused = q.Z;
         dim3 gq(cdiv64(K, q.BK), cdiv64(N, q.BN), (unsigned)q.Z);
@@ -1003,7 +1056,7 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
     } else if (op == 3) {
-        snprintf(out, cap, "k_fwd_glds<128, 64, 2, 2>");
+        snprintf(out, cap, g.Cout >= 128 ? "k_fwd_glds<128, *, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
     } else if (op == 1 && mode == MODE_F32 && Mtot >= 65536) {
