@@ -130,6 +130,11 @@ typedef struct {
     int32_t exploration_kind;
     int32_t action_kind;
     int32_t dense_adv;
+    /* Tuple of Discrete spaces (action_distributions.py:197-287: independent heads; log-prob, entropy, KL and
+     * symmetric-KL are sums over the heads): num_heads > 1 and head_n[h] = size of head h, sum = A; `actions` then
+     * holds num_heads floats per sample.  num_heads <= 1: one Discrete(A). */
+    int32_t num_heads;
+    int32_t head_n[8];
 } sf_loss_cfg;
 
 int sf_ppo_loss(const float *params, int ld_params, const float *values, int ld_values, const float *actions,
@@ -174,6 +179,16 @@ int sf_sample_write_step(const float *logits, int ld_logits, const float *values
                          int action_kind, float *traj_actions,
                          float *traj_logits, float *traj_logp, float *traj_values, float *traj_policy_version,
                          int32_t *env_actions, void *stream);
+
+/* Tuple-of-Discrete variant of sf_sample_write_step (TupleActionDistribution.sample_actions_log_probs,
+ * action_distributions.py:241-245): head h (size head_n[h], host array of num_heads <= 8 entries) is sampled by inverse
+ * CDF from its own Philox uniform (counter (step, h, 2, 0)); traj_actions gets num_heads floats per step, traj_logp the
+ * SUM of the heads' log-probs, env_actions [B, num_heads] int32. */
+int sf_sample_write_step_tuple(const float *logits, int ld_logits, const float *values, int ld_values, int B,
+                               int num_heads, const int32_t *head_n, int T, int t, uint32_t seed, uint32_t step,
+                               uint32_t row0, float policy_version, int deterministic, float *traj_actions,
+                               float *traj_logits, float *traj_logp, float *traj_values, float *traj_policy_version,
+                               int32_t *env_actions, void *stream);
 
 /* ---- K1/K6: env outputs -> trajectory step ---------------------------------------------------------------------
  * batched_sampling.py:208-213 (reward*scale, clamp +-clip), :319-335 (rewards/dones/time_outs/policy_id into

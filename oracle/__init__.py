@@ -111,7 +111,7 @@ SCALAR_NAMES = ("policy_loss", "exploration_loss", "kl_loss", "value_loss", "kl_
 
 def ppo_loss(params, values, actions, old_logp, old_params, old_values, adv, targets, valids, *, action_kind=0,
              clip_ratio=0.1, clip_value=1.0, value_loss_coeff=0.5, exploration_coeff=0.003, exploration_kind=1,
-             kl_coeff=0.0, ext_moments=None):
+             kl_coeff=0.0, ext_moments=None, head_sizes=None):
     params = _f32(params)
     N, A = params.shape
     values, actions, old_logp = _f32(values), _f32(actions), _f32(old_logp)
@@ -127,7 +127,9 @@ def ppo_loss(params, values, actions, old_logp, old_params, old_values, adv, tar
                        C.c_double(value_loss_coeff), C.c_double(exploration_coeff), int(exploration_kind),
                        C.c_double(kl_coeff),
                        _p(np.ascontiguousarray(ext_moments, dtype=np.float64), C.c_double) if ext_moments is not None else None,
-                       _p(sc, C.c_float), _p(gp, C.c_float), _p(gv, C.c_float))
+                       _p(sc, C.c_float), _p(gp, C.c_float), _p(gv, C.c_float),
+                       (C.c_int * len(head_sizes))(*[int(x) for x in head_sizes]) if head_sizes else None,
+                       len(head_sizes) if head_sizes else 0)
     out = {k: float(sc[i]) for i, k in enumerate(SCALAR_NAMES)}
     out["grad_params"] = gp
     out["grad_values"] = gv
@@ -146,6 +148,17 @@ def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-6):
     lib().sfo_adam_step(_p(p, C.c_float), _p(g, C.c_float), _p(m, C.c_float), _p(v, C.c_float), C.c_long(p.size),
                         int(step), C.c_double(lr), C.c_double(b1), C.c_double(b2), C.c_double(eps))
     return p, m, v
+
+
+def sample_tuple(logits, head_sizes, seed, step, row0=0):
+    logits = _f32(logits)
+    N, H = logits.shape[0], len(head_sizes)
+    actions = np.zeros((N, H), np.float32)
+    logp = np.zeros(N, np.float32)
+    lib().sfo_sample_tuple(_p(logits, C.c_float), C.c_long(N), (C.c_int * H)(*[int(x) for x in head_sizes]), H,
+                           C.c_uint32(seed), C.c_uint32(step), C.c_uint32(row0), _p(actions, C.c_float),
+                           _p(logp, C.c_float))
+    return actions, logp
 
 
 def categorical(logits, actions):

@@ -22,6 +22,7 @@ from sample_factory.algo.learning.learner import Learner
 from sample_factory.algo.utils.action_distributions import (
     CategoricalActionDistribution,
     ContinuousActionDistribution,
+    TupleActionDistribution,
     get_action_distribution,
 )
 from sample_factory.algo.utils.env_info import EnvInfo
@@ -194,6 +195,19 @@ def gen_action_dist():
                        f"con{i}_log_prob_actions": d.log_prob(act).numpy(), f"con{i}_entropy": d.entropy().numpy(),
                        f"con{i}_kl": d.kl_divergence(do).numpy()})
     arrays["num_con"] = 2
+    # Tuple of Discrete spaces (action_distributions.py:197-287)
+    for i, heads in enumerate([(3, 5, 2), (6, 3)]):
+        N, A = 45, sum(heads)
+        space = gym.spaces.Tuple([gym.spaces.Discrete(n) for n in heads])
+        z = torch.randn(N, A, generator=g) * 2.0
+        zo = torch.randn(N, A, generator=g) * 2.0
+        act = torch.cat([torch.randint(0, n, (N, 1), generator=g) for n in heads], dim=1).float()
+        d, do = TupleActionDistribution(space, z), TupleActionDistribution(space, zo)
+        arrays.update({f"tup{i}_heads": np.array(heads), f"tup{i}_logits": z.numpy(), f"tup{i}_old_logits": zo.numpy(),
+                       f"tup{i}_actions": act.numpy(), f"tup{i}_log_prob_actions": d.log_prob(act).numpy(),
+                       f"tup{i}_entropy": d.entropy().numpy(), f"tup{i}_kl": d.kl_divergence(do).numpy(),
+                       f"tup{i}_symkl_uniform": d.symmetric_kl_with_uniform_prior().numpy()})
+    arrays["num_tup"] = 2
     save("action_dist", **arrays)
 
 
@@ -229,11 +243,17 @@ def gen_prepare_and_losses():
              D=3, fill={}),
         dict(name="ff_vtrace", args=["--with_vtrace=True", "--normalize_returns=False", "--recurrence=8",
                                       "--vtrace_rho=0.9", "--vtrace_c=0.8"], E=12, T=8, A=5, fill={}),
+        dict(name="ff_tuple", args=["--kl_loss_coeff=0.1", "--exploration_loss_coeff=0.01"], E=12, T=8, A=10,
+             heads=(3, 5, 2), fill={}),
+        dict(name="ff_tuple_symkl", args=["--exploration_loss=symmetric_kl", "--exploration_loss_coeff=0.02"], E=10,
+             T=8, A=9, heads=(6, 3), fill=dict(p_other_policy=0.1)),
     ]
     for vi, var in enumerate(variants):
         E, T = var["E"], var["T"]
         continuous = var.get("A") is None
         action_space = gym.spaces.Box(-1, 1, (var["D"],), np.float32) if continuous else gym.spaces.Discrete(var["A"])
+        if "heads" in var:
+            action_space = gym.spaces.Tuple([gym.spaces.Discrete(n) for n in var["heads"]])
         nb = 2
         cfg = make_cfg(MLP_ARGS + [f"--rollout={T}", f"--batch_size={E * T // nb}", f"--num_batches_per_epoch={nb}",
                                    "--num_epochs=1"] + var["args"])
@@ -248,10 +268,14 @@ def gen_prepare_and_losses():
         g = torch.Generator().manual_seed(1000 + vi)
         b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
         fill_batch(b, g, var.get("A"), continuous=continuous, **var["fill"])
+        if "heads" in var:  # one action per head, each within its own head's range
+            b["actions"].copy_(torch.cat([torch.randint(0, n, (E, T, 1), generator=g) for n in var["heads"]], dim=2).float())
         arrays = {"ref": "sample_factory/algo/learning/learner.py:943-1034 Learner._prepare_batch; "
                          ":537-669 Learner._calculate_losses", "argv": " ".join(var["args"]),
                   "param_seed": 7, "train_step": learner.train_step}
         arrays.update(batch_arrays(b))
+        if "heads" in var:
+            arrays["head_sizes"] = np.array(var["heads"])
         if cfg.normalize_returns:
             rn = learner.actor_critic.returns_normalizer
             arrays["in_rms"] = np.array([rn.running_mean.item(), rn.running_var.item(), rn.count.item()])

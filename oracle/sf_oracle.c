@@ -203,7 +203,16 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
                           const float *targets, const uint8_t *valids, long N, int A, int action_kind,
                           double clip_ratio, double clip_value, double value_loss_coeff, double exploration_coeff,
                           int exploration_kind, double kl_coeff, const double *ext_moments, float *out_scalars,
-                          float *g_params, float *g_values) {
+                          float *g_params, float *g_values, const int *head_n, int num_heads) {
+    /* head_n/num_heads: Tuple of Discrete spaces (action_distributions.py:197-287) = independent categorical heads
+     * whose log-prob / entropy / KL / symmetric-KL add up; actions then holds num_heads floats per sample.
+     * NULL / <= 1: one Discrete(A). */
+    int one_head[1];
+    one_head[0] = A;
+    if (!head_n || num_heads <= 1) { head_n = one_head; num_heads = 1; }
+    const int H = num_heads;
+    float ent_h[8], kl_h[8], klpu_h[8];
+    int acts[8];
     const float clip_hi = (float)(1.0 + clip_ratio);
     const float clip_lo = (float)(1.0 / (1.0 + clip_ratio));
     const float cv = (float)clip_value;
@@ -240,25 +249,32 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
             float logp_a, ent = 0.f, kl = 0.f, symkl = 0.f;
             float *gz = g_params + i * A;
             if (pass == 1) for (int k = 0; k < A; ++k) gz[k] = 0.f;
-            int act = 0;
             if (action_kind == 0) {
-                float mx = z[0]; for (int k = 1; k < A; ++k) mx = z[k] > mx ? z[k] : mx;
-                float se = 0.f; for (int k = 0; k < A; ++k) se += expf(z[k] - mx);
-                const float lse = logf(se);
-                for (int k = 0; k < A; ++k) { lp[k] = (z[k] - mx) - lse; p[k] = expf(lp[k]); }
                 const float *zo = old_params + i * A;
-                float mxo = zo[0]; for (int k = 1; k < A; ++k) mxo = zo[k] > mxo ? zo[k] : mxo;
-                float seo = 0.f; for (int k = 0; k < A; ++k) seo += expf(zo[k] - mxo);
-                const float lseo = logf(seo);
-                for (int k = 0; k < A; ++k) q[k] = (zo[k] - mxo) - lseo;
-                act = (int)actions[i];
-                logp_a = lp[act];
-                for (int k = 0; k < A; ++k) { ent -= p[k] * lp[k]; kl += p[k] * (lp[k] - q[k]); }
-                if (exploration_kind == 2) {
-                    const float u = 1.0f / (float)A, lu = logf(u);
+                logp_a = 0.f;
+                int off = 0;
+                for (int hd = 0; hd < H; ++hd) {
+                    const int nh = head_n[hd];
+                    const float *zh = z + off, *zoh = zo + off;
+                    float mx = zh[0]; for (int k = 1; k < nh; ++k) mx = zh[k] > mx ? zh[k] : mx;
+                    float se = 0.f; for (int k = 0; k < nh; ++k) se += expf(zh[k] - mx);
+                    const float lse = logf(se);
+                    for (int k = 0; k < nh; ++k) { lp[off + k] = (zh[k] - mx) - lse; p[off + k] = expf(lp[off + k]); }
+                    float mxo = zoh[0]; for (int k = 1; k < nh; ++k) mxo = zoh[k] > mxo ? zoh[k] : mxo;
+                    float seo = 0.f; for (int k = 0; k < nh; ++k) seo += expf(zoh[k] - mxo);
+                    const float lseo = logf(seo);
+                    for (int k = 0; k < nh; ++k) q[off + k] = (zoh[k] - mxo) - lseo;
+                    acts[hd] = (int)actions[i * H + hd];
+                    logp_a += lp[off + acts[hd]];
+                    float e = 0.f, kk = 0.f;
+                    for (int k = 0; k < nh; ++k) { e -= p[off + k] * lp[off + k]; kk += p[off + k] * (lp[off + k] - q[off + k]); }
+                    ent_h[hd] = e; kl_h[hd] = kk; ent += e; kl += kk;
+                    const float u = 1.0f / (float)nh, lu = logf(u);
                     float a1 = 0.f, a2 = 0.f;
-                    for (int k = 0; k < A; ++k) { a1 += p[k] * (lp[k] - lu); a2 += u * (lu - lp[k]); }
-                    symkl = 0.5f * (a1 + a2);
+                    for (int k = 0; k < nh; ++k) { a1 += p[off + k] * (lp[off + k] - lu); a2 += u * (lu - lp[off + k]); }
+                    klpu_h[hd] = a1;
+                    if (exploration_kind == 2) symkl += 0.5f * (a1 + a2);
+                    off += nh;
                 }
             } else {
                 /* Normal(mu, clamp(exp(log_std), 1e-4, 1e4)); Independent sums over D */
@@ -306,17 +322,20 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
             const int in_hard = raw_ratio >= 0.05f && raw_ratio <= 20.0f;
             const float dL_dlogp = in_hard ? (-inv_n) * dpl_dr * raw_ratio : 0.f;
             if (action_kind == 0) {
-                for (int k = 0; k < A; ++k) {
-                    float gk = dL_dlogp * ((k == act ? 1.f : 0.f) - p[k]);
-                    if (exploration_kind == 1) gk += (float)exploration_coeff * inv_n * (p[k] * (lp[k] + ent));
-                    if (exploration_kind == 2) {
-                        const float u = 1.0f / (float)A, lu = logf(u);
-                        float klpu = 0.f; for (int j = 0; j < A; ++j) klpu += p[j] * (lp[j] - lu);
-                        gk += symkl_gate * (float)exploration_coeff * inv_n * 0.5f *
-                              (p[k] * ((lp[k] - lu) - klpu) + p[k] - u);
+                int off = 0;
+                for (int hd = 0; hd < H; ++hd) {
+                    const int nh = head_n[hd];
+                    const float u = 1.0f / (float)nh, lu = logf(u);
+                    for (int k = off; k < off + nh; ++k) {
+                        float gk = dL_dlogp * ((k - off == acts[hd] ? 1.f : 0.f) - p[k]);
+                        if (exploration_kind == 1) gk += (float)exploration_coeff * inv_n * (p[k] * (lp[k] + ent_h[hd]));
+                        if (exploration_kind == 2)
+                            gk += symkl_gate * (float)exploration_coeff * inv_n * 0.5f *
+                                  (p[k] * ((lp[k] - lu) - klpu_h[hd]) + p[k] - u);
+                        if (kl_coeff != 0.0) gk += (float)kl_coeff * inv_n * (p[k] * ((lp[k] - q[k]) - kl_h[hd]));
+                        gz[k] = gk;
                     }
-                    if (kl_coeff != 0.0) gk += (float)kl_coeff * inv_n * (p[k] * ((lp[k] - q[k]) - kl));
-                    gz[k] = gk;
+                    off += nh;
                 }
             } else {
                 const float *zo = old_params + i * A;
@@ -493,6 +512,34 @@ SFO_API void sfo_sample_categorical(const float *logits, long N, int A, uint32_t
         }
         actions[i] = (float)a;
         logp[i] = (z[a] - mx) - lse;
+    }
+}
+
+/* Tuple of Discrete heads as sampled by sf_sample_write_step_tuple: head h draws from Philox counter (step, h, 2, 0);
+ * actions [N, H], logp = sum of the heads' log-probs (TupleActionDistribution._calc_log_probs). */
+SFO_API void sfo_sample_tuple(const float *logits, long N, const int *head_n, int H, uint32_t seed, uint32_t step,
+                              uint32_t row0, float *actions, float *logp) {
+    int A = 0;
+    for (int h = 0; h < H; ++h) A += head_n[h];
+    for (long i = 0; i < N; ++i) {
+        const float *z = logits + i * A;
+        float lps = 0.f;
+        int off = 0;
+        for (int h = 0; h < H; ++h) {
+            const int nh = head_n[h];
+            float mx = z[off]; for (int k = 1; k < nh; ++k) mx = z[off + k] > mx ? z[off + k] : mx;
+            float se = 0.f; for (int k = 0; k < nh; ++k) se += expf(z[off + k] - mx);
+            const float lse = logf(se);
+            uint32_t w[4];
+            philox4x32_10(step, (uint32_t)h, 2u, 0u, seed, row0 + (uint32_t)i, w);
+            const float u = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+            float acc = 0.f; int a = nh - 1;
+            for (int k = 0; k < nh; ++k) { acc += expf((z[off + k] - mx) - lse); if (u < acc) { a = k; break; } }
+            actions[i * H + h] = (float)a;
+            lps += (z[off + a] - mx) - lse;
+            off += nh;
+        }
+        logp[i] = lps;
     }
 }
 

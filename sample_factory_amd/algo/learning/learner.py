@@ -33,7 +33,8 @@ import torch
 from sample_factory_amd import lib
 from sample_factory_amd.algo.learning.dp import ReplicaGroup
 from sample_factory_amd.algo.utils.tensor_dict import TensorDict
-from sample_factory_amd.envs.spaces import calc_num_action_parameters, calc_num_actions, is_discrete
+from sample_factory_amd.envs.spaces import (action_head_sizes, calc_num_action_parameters, calc_num_actions, is_box,
+                                             is_discrete)
 from sample_factory_amd.model.actor_critic import ActorCritic
 from sample_factory_amd.utils.attr_dict import AttrDict
 
@@ -297,7 +298,14 @@ class Learner:
             clip_ratio=cfg.ppo_clip_ratio, clip_value=cfg.ppo_clip_value, value_loss_coeff=cfg.value_loss_coeff,
             exploration_coeff=cfg.exploration_loss_coeff, kl_coeff=cfg.kl_loss_coeff,
             exploration_kind=0 if cfg.exploration_loss_coeff == 0.0 else (1 if cfg.exploration_loss == "entropy" else 2),
-            action_kind=0 if is_discrete(self.env_info.action_space) else 1, dense_adv=int(bool(cfg.with_vtrace)))
+            action_kind=1 if is_box(self.env_info.action_space) else 0, dense_adv=int(bool(cfg.with_vtrace)))
+        heads = action_head_sizes(self.env_info.action_space)
+        if len(heads) > 1 and cfg.with_vtrace:
+            raise NotImplementedError("with_vtrace together with a Tuple action space")
+        if len(heads) > 1:  # Tuple of Discrete spaces: independent categorical heads
+            self.loss_cfg.num_heads = len(heads)
+            for i, nh in enumerate(heads):
+                self.loss_cfg.head_n[i] = nh
 
     def _maybe_update_cfg(self) -> None:
         """learner.py:394-413: apply the new values; a PBT-optimised learning rate only with the constant schedule.

@@ -18,6 +18,7 @@ import torch
 
 from sample_factory_amd import lib
 from sample_factory_amd.algo.utils.tensor_dict import TensorDict
+from sample_factory_amd.envs.spaces import action_head_sizes, is_box
 
 
 class BatchedVectorEnvRunner:
@@ -32,7 +33,9 @@ class BatchedVectorEnvRunner:
         dev = actor_critic.device
         self.device = dev
         assert traj["rewards"].shape == (self.B, self.T), "one slab row per agent (sync mode: one rollout per dataset)"
-        self.env_actions = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.heads = action_head_sizes(env_info.action_space)  # [n] | [n1, n2, ...] (Tuple of Discrete) | [] (Box)
+        self.env_actions = torch.zeros((self.B, len(self.heads)) if len(self.heads) > 1 else self.B, dtype=torch.int32,
+                                       device=dev)
         self.ep_return = torch.zeros(self.B, dtype=torch.float32, device=dev)
         self.ep_len = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.ep_stats = torch.zeros(3, dtype=torch.float64, device=dev)  # sum_return, sum_len, episodes
@@ -46,7 +49,7 @@ class BatchedVectorEnvRunner:
         self._started = False
         self.A = actor_critic.num_action_params
         self.ld = actor_critic.heads_ld
-        self.continuous = not hasattr(self.env_info.action_space, "n")  # Box(D): params = [means | log_std]
+        self.continuous = is_box(self.env_info.action_space)  # Box(D): params = [means | log_std]
 
     def reset(self) -> None:
         """First observation into slab obs[:, 0] (batched_sampling.py:172-206)."""
@@ -71,10 +74,16 @@ class BatchedVectorEnvRunner:
         for t in range(T):
             rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
             heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf", rnn=rnn)[-1]
-            lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
-                                  self.global_step, self.row0, ver, deterministic, tr["actions"], tr["action_logits"],
-                                  tr["log_prob_actions"], tr["values"], tr["policy_version"],
-                                  None if self.continuous else self.env_actions, action_kind=int(self.continuous))
+            if len(self.heads) > 1:  # Tuple of Discrete spaces: one categorical per head, actions [B, H]
+                lib.sample_write_step_tuple(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, self.heads, T, t,
+                                            self.sample_seed, self.global_step, self.row0, ver, deterministic,
+                                            tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
+                                            tr["policy_version"], self.env_actions)
+            else:
+                lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
+                                      self.global_step, self.row0, ver, deterministic, tr["actions"],
+                                      tr["action_logits"], tr["log_prob_actions"], tr["values"], tr["policy_version"],
+                                      None if self.continuous else self.env_actions, action_kind=int(self.continuous))
             env_actions = tr["actions"][:, t] if self.continuous else self.env_actions  # Box: f32 [B, D] view
             if self.zero_copy:
                 rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])

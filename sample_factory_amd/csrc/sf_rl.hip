@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 1; }
+extern "C" int sf_abi_version(void) { return 2; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -336,6 +336,7 @@ extern "C" int sf_vtrace(const float *params, int ld_params, const float *values
 struct LossDev {
     float clip_lo, clip_hi, clip_value, value_coeff, expl_coeff, kl_coeff;
     int expl_kind, action_kind, dense_adv;
+    int num_heads, head_n[8];
 };
 
 __device__ __forceinline__ void atomic_max_float(double *addr, float v) {
@@ -521,6 +522,138 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float *__restrict__ para
     }
 }
 
+
+// Tuple of Discrete heads (TupleActionDistribution, action_distributions.py:197-287): independent categoricals whose
+// log-prob / entropy / KL / symmetric-KL add up.  Same loss and backward as k_ppo_loss, per-head softmax statistics;
+// heads are read from global memory in place (this kernel is ~0.1 % of a step: clarity over register blocking).
+// sym_pass != 0: only accumulate the symmetric-KL sum (pre-pass for its mean gate) into sums[7].
+__global__ __launch_bounds__(256) void k_ppo_loss_md(const float *__restrict__ params, int ldp,
+                                                     const float *__restrict__ values, int ldv,
+                                                     const float *__restrict__ actions,
+                                                     const float *__restrict__ old_logp,
+                                                     const float *__restrict__ old_params,
+                                                     const float *__restrict__ old_values, const float *__restrict__ adv,
+                                                     const float *__restrict__ targets,
+                                                     const uint8_t *__restrict__ valids,
+                                                     const int32_t *__restrict__ index, int64_t offset, int64_t n, int A,
+                                                     LossDev h, const double *__restrict__ moments,
+                                                     double *__restrict__ sums, float *__restrict__ g_params,
+                                                     float *__restrict__ g_values, int sym_pass) {
+    __shared__ double lds[4 * 4];
+    __shared__ float lds_max[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double mn = moments[2];
+    const double mean64 = moments[0] / mn;
+    const double var64 = (moments[1] - moments[0] * mean64) / (mn - 1.0);
+    const float adv_mean = (float)mean64;
+    const float adv_std = (float)sqrt(var64 > 0.0 ? var64 : (mn > 1.0 ? 0.0 : NAN));
+    const float denom = fmaxf(adv_std, 1e-7f);
+    const float inv_n = 1.0f / (float)mn;
+    const float symkl_gate = (h.expl_kind == 2 && !sym_pass) ? (float)sums[6] : 1.0f;
+    const int H = h.num_heads;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    float kl_max = -1.0f;
+    if (i < n) {
+        const int64_t d = index ? (int64_t)index[i] : offset + i;
+        const bool valid = valids[d] != 0;
+        const float *z = params + i * ldp, *zo = old_params + d * A;
+        float *gz = g_params + i * ldp;
+        float logp_a = 0.f, ent = 0.f, kl = 0.f, symkl = 0.f;
+        float mx[8], lse[8], mxo[8], lseo[8], ent_h[8], kl_h[8], klpu_h[8];
+        int off = 0;
+        for (int hd = 0; hd < H; ++hd) {
+            const int nh = h.head_n[hd];
+            float m1 = -INFINITY, m2 = -INFINITY;
+            for (int k = 0; k < nh; ++k) { m1 = fmaxf(m1, z[off + k]); m2 = fmaxf(m2, zo[off + k]); }
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < nh; ++k) { s1 += expf(z[off + k] - m1); s2 += expf(zo[off + k] - m2); }
+            mx[hd] = m1; lse[hd] = logf(s1); mxo[hd] = m2; lseo[hd] = logf(s2);
+            const int act = (int)actions[d * H + hd];
+            const float u = 1.0f / (float)nh, lu = logf(u);
+            float e = 0.f, kk = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int k = 0; k < nh; ++k) {
+                const float lp = (z[off + k] - m1) - lse[hd], p = expf(lp), q = (zo[off + k] - m2) - lseo[hd];
+                if (k == act) logp_a += lp;
+                e -= p * lp;
+                kk += p * (lp - q);
+                a1 += p * (lp - lu);
+                a2 += u * (lu - lp);
+            }
+            ent_h[hd] = e; kl_h[hd] = kk; klpu_h[hd] = a1;
+            ent += e; kl += kk; symkl += 0.5f * (a1 + a2);
+            off += nh;
+        }
+        if (sym_pass) {
+            if (valid) acc[0] = symkl;
+        } else {
+            const float raw_ratio = expf(logp_a - old_logp[d]);
+            const float ratio = clampf(raw_ratio, 0.05f, 20.0f);
+            const int64_t da = h.dense_adv ? i : d;
+            const float advn = (adv[da] - adv_mean) / denom;
+            const float clipped = clampf(ratio, h.clip_lo, h.clip_hi);
+            const float lu_ = ratio * advn, lc_ = clipped * advn;
+            const float pl = fminf(lu_, lc_);
+            const float v = values[i * ldv], vo = old_values[d], R = targets[da];
+            const float vclip = vo + clampf(v - vo, -h.clip_value, h.clip_value);
+            const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+            const float vl = fmaxf(l1, l2);
+            if (valid) {
+                acc[0] = pl;
+                acc[1] = (h.expl_kind == 2) ? symkl : ent;
+                acc[2] = kl;
+                acc[3] = vl;
+                kl_max = kl;
+                float dpl_dr;
+                const bool in_clip = ratio >= h.clip_lo && ratio <= h.clip_hi;
+                if (lu_ < lc_) dpl_dr = advn;
+                else if (lu_ > lc_) dpl_dr = in_clip ? advn : 0.f;
+                else dpl_dr = 0.5f * advn + (in_clip ? 0.5f * advn : 0.f);
+                const bool in_hard = raw_ratio >= 0.05f && raw_ratio <= 20.0f;
+                const float dL_dlogp = in_hard ? (-inv_n) * dpl_dr * raw_ratio : 0.f;
+                off = 0;
+                for (int hd = 0; hd < H; ++hd) {
+                    const int nh = h.head_n[hd];
+                    const int act = (int)actions[d * H + hd];
+                    const float u = 1.0f / (float)nh, lu = logf(u);
+                    for (int k = 0; k < nh; ++k) {
+                        const float lp = (z[off + k] - mx[hd]) - lse[hd], p = expf(lp);
+                        const float q = (zo[off + k] - mxo[hd]) - lseo[hd];
+                        float gk = dL_dlogp * ((k == act ? 1.f : 0.f) - p);
+                        if (h.expl_kind == 1) gk += h.expl_coeff * inv_n * (p * (lp + ent_h[hd]));
+                        if (h.expl_kind == 2)
+                            gk += symkl_gate * h.expl_coeff * inv_n * 0.5f * (p * ((lp - lu) - klpu_h[hd]) + p - u);
+                        if (h.kl_coeff != 0.f) gk += h.kl_coeff * inv_n * (p * ((lp - q) - kl_h[hd]));
+                        gz[off + k] = gk;
+                    }
+                    off += nh;
+                }
+                const bool in_v = (v - vo) >= -h.clip_value && (v - vo) <= h.clip_value;
+                float dvl;
+                if (l1 > l2) dvl = 2.f * (v - R);
+                else if (l2 > l1) dvl = in_v ? 2.f * (vclip - R) : 0.f;
+                else dvl = (v - R) + (in_v ? (vclip - R) : 0.f);
+                g_values[i * ldv] = h.value_coeff * inv_n * dvl;
+            } else {
+                for (int k = 0; k < A; ++k) gz[k] = 0.f;
+                g_values[i * ldv] = 0.f;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    kl_max = sf_wave_max(kl_max);
+    if (lane == 0) lds_max[wave] = kl_max;
+    sf_block_sum<4>(acc, lds);
+    if (threadIdx.x == 0) {
+        if (sym_pass) { atomicAdd(&sums[7], acc[0]); return; }
+        atomicAdd(&sums[0], acc[0]);
+        atomicAdd(&sums[1], acc[1]);
+        atomicAdd(&sums[2], acc[2]);
+        atomicAdd(&sums[3], acc[3]);
+        const float m = fmaxf(fmaxf(lds_max[0], lds_max[1]), fmaxf(lds_max[2], lds_max[3]));
+        if (m > -1.0f) atomic_max_float(&sums[4], m);
+    }
+}
+
 // pre-pass for the symmetric-KL exploration loss: mean over valid samples decides clamp(max=30) / isfinite gate
 template <int MAXA>
 __global__ __launch_bounds__(256) void k_symkl_sum(const float *__restrict__ params, int ldp,
@@ -570,6 +703,8 @@ static LossDev make_loss_dev(const sf_loss_cfg *c) {
     h.expl_kind = c->exploration_coeff == 0.f ? 0 : c->exploration_kind;
     h.action_kind = c->action_kind;
     h.dense_adv = c->dense_adv;
+    h.num_heads = c->num_heads > 1 ? c->num_heads : 1;
+    for (int i = 0; i < 8; ++i) h.head_n[i] = c->num_heads > 1 ? c->head_n[i] : 0;
     return h;
 }
 
@@ -596,6 +731,22 @@ extern "C" int sf_ppo_loss(const float *params, int ld_params, const float *valu
         else if (A <= 32) KERNEL<32><<<grid, block, 0, STREAM(stream)>>>(__VA_ARGS__);  \
         else KERNEL<128><<<grid, block, 0, STREAM(stream)>>>(__VA_ARGS__);              \
     } while (0)
+    if (h.action_kind == 0 && h.num_heads > 1) {
+        int tot = 0;
+        SF_REQUIRE(h.num_heads <= 8, "sf_ppo_loss: at most 8 action heads");
+        for (int i = 0; i < h.num_heads; ++i) { SF_REQUIRE(h.head_n[i] > 0, "sf_ppo_loss: empty action head"); tot += h.head_n[i]; }
+        SF_REQUIRE(tot == A, "sf_ppo_loss: head sizes sum to %d, A = %d", tot, A);
+        if (h.expl_kind == 2) {
+            k_ppo_loss_md<<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, old_params,
+                                                              old_values, adv, targets, valids, index, offset, n, A, h, moments,
+                                                              sums, g_params, g_values, 1);
+            k_symkl_gate<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(sums, moments);
+        }
+        k_ppo_loss_md<<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, old_params,
+                                                          old_values, adv, targets, valids, index, offset, n, A, h, moments, sums,
+                                                          g_params, g_values, 0);
+        return sf_launch_status("sf_ppo_loss");
+    }
     if (h.expl_kind == 2) {
         PL_DISPATCH(k_symkl_sum, params, ld_params, valids, index, offset, n, A, sums + 7);
         k_symkl_gate<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(sums, moments);
@@ -877,6 +1028,78 @@ extern "C" int sf_sample_write_step(const float *logits, int ld_logits, const fl
     else SW_LAUNCH(128);
 #undef SW_LAUNCH
     return sf_launch_status("sf_sample_write_step");
+}
+
+
+// Tuple of Discrete heads: every head is sampled from its own Philox uniform (counter lane 1 = head index)
+__global__ __launch_bounds__(256) void k_sample_write_tuple(const float *__restrict__ logits, int ldl,
+                                                            const float *__restrict__ values, int ldv, int B, int A, int T,
+                                                            int t, uint32_t seed, uint32_t step, uint32_t row0,
+                                                            float version, int deterministic, LossDev hd,
+                                                            float *__restrict__ t_actions, float *__restrict__ t_logits,
+                                                            float *__restrict__ t_logp, float *__restrict__ t_values,
+                                                            float *__restrict__ t_version,
+                                                            int32_t *__restrict__ env_actions) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *z = logits + (int64_t)b * ldl;
+    const int64_t it = (int64_t)b * T + t;
+    const int H = hd.num_heads;
+    float lp_sum = 0.f;
+    int off = 0;
+    for (int h = 0; h < H; ++h) {
+        const int nh = hd.head_n[h];
+        float mx = -INFINITY;
+        for (int k = 0; k < nh; ++k) mx = fmaxf(mx, z[off + k]);
+        float se = 0.f;
+        for (int k = 0; k < nh; ++k) se += expf(z[off + k] - mx);
+        const float lse = logf(se);
+        int a = nh - 1;
+        if (deterministic) {
+            for (int k = nh - 1; k >= 0; --k) if (z[off + k] == mx) a = k;  // first maximum, as torch.argmax
+        } else {
+            uint32_t w[4];
+            sf_philox4x32_10(step, (uint32_t)h, 2u, 0u, seed, row0 + (uint32_t)b, w);
+            const float u = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+            float acc = 0.f;
+            for (int k = 0; k < nh; ++k) {
+                acc += expf((z[off + k] - mx) - lse);
+                if (u < acc) { a = k; break; }
+            }
+        }
+        lp_sum += (z[off + a] - mx) - lse;
+        t_actions[it * H + h] = (float)a;
+        if (env_actions) env_actions[(int64_t)b * H + h] = a;
+        off += nh;
+    }
+    for (int k = 0; k < A; ++k) t_logits[it * A + k] = z[k];
+    t_logp[it] = lp_sum;
+    t_version[it] = version;
+    t_values[(int64_t)b * (T + 1) + t] = values[(int64_t)b * ldv];
+}
+
+extern "C" int sf_sample_write_step_tuple(const float *logits, int ld_logits, const float *values, int ld_values, int B,
+                                          int num_heads, const int32_t *head_n, int T, int t, uint32_t seed,
+                                          uint32_t step, uint32_t row0, float policy_version, int deterministic,
+                                          float *traj_actions, float *traj_logits, float *traj_logp, float *traj_values,
+                                          float *traj_policy_version, int32_t *env_actions, void *stream) {
+    SF_REQUIRE(logits && values && head_n && traj_actions && traj_logits && traj_logp && traj_values &&
+                   traj_policy_version, "sf_sample_write_step_tuple: null pointer");
+    SF_REQUIRE(num_heads >= 1 && num_heads <= 8 && B > 0 && T > 0 && t >= 0 && t < T,
+               "sf_sample_write_step_tuple: bad shape heads=%d B=%d T=%d t=%d", num_heads, B, T, t);
+    LossDev hd = {};
+    hd.num_heads = num_heads;
+    int A = 0;
+    for (int i = 0; i < num_heads; ++i) {
+        SF_REQUIRE(head_n[i] > 0, "sf_sample_write_step_tuple: empty action head");
+        hd.head_n[i] = head_n[i];
+        A += head_n[i];
+    }
+    SF_REQUIRE(ld_logits >= A && ld_values >= 1, "sf_sample_write_step_tuple: bad strides");
+    k_sample_write_tuple<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        logits, ld_logits, values, ld_values, B, A, T, t, seed, step, row0, policy_version, deterministic, hd,
+        traj_actions, traj_logits, traj_logp, traj_values, traj_policy_version, env_actions);
+    return sf_launch_status("sf_sample_write_step_tuple");
 }
 
 // =========================================================================================== K1/K6 env step -> traj

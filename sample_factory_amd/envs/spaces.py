@@ -43,8 +43,45 @@ class Dict:
         return self.spaces[k]
 
 
+class Tuple:
+    """gymnasium.spaces.Tuple stand-in (multi-head action spaces, e.g. VizDoom: move / turn / attack)"""
+
+    def __init__(self, spaces):
+        self.spaces = tuple(spaces)
+
+    def __iter__(self):
+        return iter(self.spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __getitem__(self, i):
+        return self.spaces[i]
+
+    def __repr__(self):
+        return f"Tuple({', '.join(repr(s) for s in self.spaces)})"
+
+
 def is_discrete(space) -> bool:
     return hasattr(space, "n")
+
+
+def is_tuple(space) -> bool:
+    return hasattr(space, "spaces") and not hasattr(space, "keys")
+
+
+def action_head_sizes(action_space):
+    """sizes of the categorical heads: [n] for Discrete(n), [n1, n2, ...] for a Tuple of Discrete spaces (the only
+    Tuple the native loss / sampler kernels take; a Tuple containing a Box is rejected)"""
+    if is_discrete(action_space):
+        return [int(action_space.n)]
+    if is_tuple(action_space):
+        if not all(is_discrete(sp) for sp in action_space.spaces):
+            raise NotImplementedError("Tuple action spaces are supported for Discrete members only")
+        if len(action_space.spaces) > 8:
+            raise NotImplementedError("at most 8 action heads")
+        return [int(sp.n) for sp in action_space.spaces]
+    return []
 
 
 def is_box(space) -> bool:
@@ -55,6 +92,8 @@ def calc_num_actions(action_space) -> int:
     """action_distributions.py:14-26"""
     if is_discrete(action_space):
         return 1
+    if is_tuple(action_space):
+        return sum(calc_num_actions(a) for a in action_space.spaces)
     if is_box(action_space):
         if len(action_space.shape) != 1:
             raise Exception("Non-trivial shape Box action spaces not currently supported. Try to flatten the space.")
@@ -66,6 +105,8 @@ def calc_num_action_parameters(action_space) -> int:
     """action_distributions.py:29-38"""
     if is_discrete(action_space):
         return action_space.n
+    if is_tuple(action_space):
+        return sum(calc_num_action_parameters(a) for a in action_space.spaces)
     if is_box(action_space):
         return int(np.prod(action_space.shape)) * 2
     raise NotImplementedError(f"Action space type {type(action_space)} not supported!")

@@ -97,6 +97,30 @@ class SyntheticContinuousEnv:
         pass
 
 
+class SyntheticTupleEnv(SyntheticVecEnv):
+    """Multi-head variant (Tuple(Discrete(n0), Discrete(n1), ...), the VizDoom-style action space of
+    action_distributions.py:197-287): same frames; the reward rule looks at head 0, the other heads are free."""
+
+    def __init__(self, head_sizes=(6, 3), **kw):
+        super().__init__(num_actions=int(head_sizes[0]), **kw)
+        self.action_space = spaces.Tuple([spaces.Discrete(int(n)) for n in head_sizes])
+
+    def step_into(self, actions: torch.Tensor, obs_out: torch.Tensor):
+        a = actions.reshape(self.num_agents, -1)[:, 0].contiguous()
+        return super().step_into(a, obs_out)
+
+    def step(self, actions):
+        a = torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(self.num_agents, -1)[:, 0]
+        return super().step(a)
+
+
+def make_synthetic_tuple_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    n = getattr(cfg, "synthetic_num_agents", 4096) if cfg is not None else 4096
+    seed = (getattr(cfg, "seed", None) or 0) if cfg is not None else 0
+    return SyntheticTupleEnv(head_sizes=getattr(cfg, "synthetic_head_sizes", (6, 3)) if cfg is not None else (6, 3),
+                             num_agents=n, seed=seed)
+
+
 def make_synthetic_continuous_env(full_env_name, cfg=None, env_config=None, render_mode=None):
     n = getattr(cfg, "synthetic_num_agents", 2048) if cfg is not None else 2048
     return SyntheticContinuousEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0)

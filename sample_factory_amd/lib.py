@@ -23,7 +23,8 @@ class SfHipError(RuntimeError):
 class sf_loss_cfg(C.Structure):
     _fields_ = [("clip_ratio", C.c_float), ("clip_value", C.c_float), ("value_loss_coeff", C.c_float),
                 ("exploration_coeff", C.c_float), ("kl_coeff", C.c_float), ("exploration_kind", C.c_int32),
-                ("action_kind", C.c_int32), ("dense_adv", C.c_int32)]
+                ("action_kind", C.c_int32), ("dense_adv", C.c_int32), ("num_heads", C.c_int32),
+                ("head_n", C.c_int32 * 8)]
 
 
 class sf_conv_desc(C.Structure):
@@ -37,7 +38,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
-    "sf_adam_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
+    "sf_adam_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_sample_write_step_tuple", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
     "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_conv_kernel_name",
     "sf_conv_fwd_t_supported", "sf_conv_fwd_t", "sf_transpose",
     "sf_linear_fwd",
@@ -302,6 +303,20 @@ def sample_write_step(logits, ld_logits, values, ld_values, B, A, T, t, seed, st
                                        ptr(traj_logp, "f32"), ptr(traj_values, "f32"),
                                        ptr(traj_policy_version, "f32"), ptr(env_actions, "i32"), stream()),
            "sf_sample_write_step")
+
+
+def sample_write_step_tuple(logits, ld_logits, values, ld_values, B, head_n, T, t, seed, step, row0, policy_version,
+                            deterministic, traj_actions, traj_logits, traj_logp, traj_values, traj_policy_version,
+                            env_actions) -> None:
+    """Tuple of Discrete heads; env_actions int32 [B, len(head_n)]"""
+    hn = (C.c_int32 * 8)(*[int(x) for x in head_n])
+    _check(load().sf_sample_write_step_tuple(_raw(logits, "f32", "logits"), int(ld_logits),
+                                             _raw(values, "f32", "values"), int(ld_values), int(B), len(head_n), hn,
+                                             int(T), int(t), u32(seed), u32(step), u32(row0), f(policy_version),
+                                             int(bool(deterministic)), ptr(traj_actions, "f32"), ptr(traj_logits, "f32"),
+                                             ptr(traj_logp, "f32"), ptr(traj_values, "f32"),
+                                             ptr(traj_policy_version, "f32"), ptr(env_actions, "i32"), stream()),
+           "sf_sample_write_step_tuple")
 
 
 def traj_write_env_step(rewards, terminated, truncated, T, t, reward_scale, reward_clip, policy_id, traj_rewards,

@@ -168,7 +168,8 @@ def run_loss(lib, cfg, params, values, actions, old_logp, old_params, old_values
     return res
 
 
-@pytest.mark.parametrize("case", ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous", "ff_vtrace"])
+@pytest.mark.parametrize("case", ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous", "ff_vtrace",
+                                  "ff_tuple", "ff_tuple_symkl"])
 @pytest.mark.parametrize("fused_heads", [False, True])
 def test_ppo_loss_golden(lib, golden, case, fused_heads):
     g = golden("learner_" + case)
@@ -176,6 +177,10 @@ def test_ppo_loss_golden(lib, golden, case, fused_heads):
     n = int(g["mb_size"])
     continuous = case == "ff_continuous"
     cfg = _loss_cfg(lib, kv, continuous, dense_adv=case == "ff_vtrace")
+    if "head_sizes" in g:  # Tuple of Discrete spaces
+        cfg.num_heads = len(g["head_sizes"])
+        for i, nh in enumerate(g["head_sizes"]):
+            cfg.head_n[i] = int(nh)
     A = g["l_params"].shape[1]
     if case == "ff_vtrace":
         vs = torch.zeros(n, device="cuda")
@@ -369,6 +374,37 @@ def test_sample_write_step_vs_oracle(lib, B, A):
     lib.sample_write_step(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, B, A, T, t, 11, 77, 5, 42.0, True, tr["actions"],
                           tr["logits"], tr["logp"], tr["values"], tr["ver"], env_a)
     np.testing.assert_array_equal(env_a.cpu().numpy(), logits.argmax(1).astype(np.int32))
+
+
+def test_sample_tuple_vs_oracle(lib):
+    """Tuple of Discrete heads (TupleActionDistribution): per-head inverse-CDF sampling, log-prob = sum over heads;
+    head 0 draws from the same Philox stream as the single-head sampler."""
+    rng = np.random.default_rng(17)
+    B, hs, T, t = 3000, [6, 3, 4], 4, 2
+    A, H = sum(hs), len(hs)
+    logits = (rng.standard_normal((B, A)) * 1.5).astype(np.float32)
+    values = rng.standard_normal(B).astype(np.float32)
+    heads = dev(np.concatenate([values[:, None], logits, np.zeros((B, 2), np.float32)], 1))
+    ld = heads.shape[1]
+    z = lambda *s: torch.full(s, -7.0, device="cuda")
+    ta, tl, tp, tv, tver = z(B, T, H), z(B, T, A), z(B, T), z(B, T + 1), z(B, T)
+    env_a = torch.zeros((B, H), dtype=torch.int32, device="cuda")
+    lib.sample_write_step_tuple(heads[:, 1:], ld, heads[:, 0], ld, B, hs, T, t, 11, 77, 5, 9.0, False, ta, tl, tp, tv,
+                                tver, env_a)
+    a_ref, lp_ref = oracle.sample_tuple(logits, hs, 11, 77, row0=5)
+    np.testing.assert_array_equal(ta[:, t].cpu().numpy(), a_ref)                         # integer actions: exact
+    np.testing.assert_array_equal(env_a.cpu().numpy(), a_ref.astype(np.int32))
+    np.testing.assert_allclose(tp[:, t].cpu().numpy(), lp_ref, atol=4e-6)
+    np.testing.assert_array_equal(tl[:, t].cpu().numpy(), logits)
+    np.testing.assert_array_equal(tv[:, t].cpu().numpy(), values)
+    assert torch.all(tver[:, t] == 9.0) and torch.all(ta[:, t + 1] == -7.0)
+    a0, _ = oracle.sample_categorical(logits[:, :hs[0]].copy(), 11, 77, row0=5)
+    np.testing.assert_array_equal(a_ref[:, 0], a0)
+    lib.sample_write_step_tuple(heads[:, 1:], ld, heads[:, 0], ld, B, hs, T, t, 11, 77, 5, 9.0, True, ta, tl, tp, tv,
+                                tver, env_a)
+    off = np.cumsum([0] + hs)
+    am = np.stack([logits[:, off[i]:off[i + 1]].argmax(1) for i in range(H)], 1)
+    np.testing.assert_array_equal(env_a.cpu().numpy(), am.astype(np.int32))
 
 
 def test_sample_continuous_vs_oracle(lib):

@@ -92,7 +92,7 @@ def _loss_kwargs(kv, continuous):
                 exploration_coeff=coeff, exploration_kind=kind, kl_coeff=float(kv.get("kl_loss_coeff", 0.0)))
 
 
-@pytest.mark.parametrize("case", LEARNER_CASES + ["ff_vtrace"])
+@pytest.mark.parametrize("case", LEARNER_CASES + ["ff_vtrace", "ff_tuple", "ff_tuple_symkl"])
 def test_ppo_loss_matches_reference(golden, case):
     g = golden("learner_" + case)
     kv = _cfg_from_argv(g["argv"])
@@ -109,6 +109,7 @@ def test_ppo_loss_matches_reference(golden, case):
         np.testing.assert_array_equal(targets, g["l_targets"])
     out = oracle.ppo_loss(g["l_params"], g["l_values"], g["pb_actions"][:n], g["pb_log_prob_actions"][:n],
                           g["pb_action_logits"][:n], g["pb_values"][:n], adv, targets, g["pb_valids"][:n],
+                          head_sizes=[int(x) for x in g["head_sizes"]] if "head_sizes" in g else None,
                           **_loss_kwargs(kv, continuous))
     assert abs(out["adv_mean"] - float(g["l_adv_mean"])) < 1e-6
     assert abs(out["adv_std"] - float(g["l_adv_std"])) < 2e-6
