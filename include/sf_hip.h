@@ -164,6 +164,16 @@ int sf_grad_sumsq(const float *g, int64_t P, double *sumsq, void *stream);
 int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
                  float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale, void *stream);
 
+/* Lamb (cfg.optimizer = "lamb"; algo/utils/optimizers.py:14-189 as configured by learner.py:228-243: Adam direction
+ * with bias correction + weight_decay * w, then per-TENSOR trust ratio min(||w||, 10)/||step|| clamped to
+ * [min_trust, 1/min_trust]; the reference's `step` starts at 1).  seg_id[P] (u8): index of the reference tensor each
+ * flat element belongs to, 255 = padding (skipped); scratch[P] f32; seg_sums: device double[128] (zeroed by the call).
+ * Gradient clipping as in sf_adam_step. */
+int sf_lamb_step(float *p, const float *g, float *m, float *v, float *scratch, const uint8_t *seg_id, double *seg_sums,
+                 int64_t P, int num_segments, int step, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, float min_trust, float max_grad_norm, const double *sumsq, float grad_scale,
+                 void *stream);
+
 /* ---- K4/K5: action sampling + policy outputs -> trajectory step ------------------------------------------------
  * action_distributions.py:110-148 (softmax, multinomial, log_softmax, gather), actor_critic.py:112-117,
  * inference_worker.py:235-269,330-339 and batched_sampling.py:308-311 (policy outputs copied into traj[:, t]).

@@ -161,6 +161,15 @@ def sample_tuple(logits, head_sizes, seed, step, row0=0):
     return actions, logp
 
 
+def lamb_step(p, g, m, v, seg_id, nseg, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-6, weight_decay=1e-4, min_trust=0.01):
+    p, m, v = _f32(p).copy(), _f32(m).copy(), _f32(v).copy()
+    g, seg_id = _f32(g), _u8(seg_id)
+    lib().sfo_lamb_step(_p(p, C.c_float), _p(g, C.c_float), _p(m, C.c_float), _p(v, C.c_float), _p(seg_id, C.c_uint8),
+                        C.c_long(p.size), int(nseg), int(step), C.c_double(lr), C.c_double(b1), C.c_double(b2),
+                        C.c_double(eps), C.c_double(weight_decay), C.c_double(min_trust))
+    return p, m, v
+
+
 def categorical(logits, actions):
     logits = _f32(logits)
     N, A = logits.shape

@@ -449,6 +449,7 @@ def main():
     if "train" in which:
         gen_train("mlp", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2)
         gen_train("mlp_inv", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=4, epochs=1, extra=["--kl_loss_coeff=0.1"])
+        gen_train("mlp_lamb", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2, extra=["--optimizer=lamb"])
         cnn_obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 36, 36), np.uint8)})
         gen_train("cnn36", cnn_obs, ["--encoder_conv_architecture=convnet_atari", "--nonlinearity=relu",
                                      "--obs_scale=255.0", "--normalize_input=False",

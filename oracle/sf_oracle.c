@@ -495,6 +495,39 @@ SFO_API void sfo_synth_step(const int32_t *actions, int n, int env0, int num_act
  * the HIP sampler (sf_sample_categorical).  The reference uses torch.multinomial (action_distributions.py:136-142)
  * whose RNG stream cannot be reproduced; parity on sampling is distributional, this function pins the
  * HIP sampler bit-for-bit instead. */
+/* Lamb, list-params path of algo/utils/optimizers.py:99-135 with the Learner's configuration (weight decay, trust
+ * ratio per tensor = per segment id; seg 255 = padding).  The reference's per-parameter `step` starts at 1. */
+SFO_API void sfo_lamb_step(float *p, const float *g, float *m, float *v, const uint8_t *seg, long P, int nseg,
+                           int step, double lr, double b1, double b2, double eps, double wd, double min_trust) {
+    const float fb1 = (float)b1, fb2 = (float)b2, w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2);
+    const float ib1 = (float)(1.0 / (1.0 - pow(b1, (double)step)));
+    const float ib2 = (float)(1.0 / sqrt(1.0 - pow(b2, (double)step)));
+    float *u = (float *)malloc(sizeof(float) * P);
+    double *wn = (double *)calloc(2 * (nseg > 0 ? nseg : 1), sizeof(double));
+    for (long i = 0; i < P; ++i) {
+        if (seg[i] >= nseg) continue;
+        m[i] = m[i] * fb1 + w1 * g[i];
+        v[i] = v[i] * fb2 + w2 * (g[i] * g[i]);
+        const float mh = m[i] * ib1, vh = sqrtf(v[i]) * ib2;
+        float s = mh / (vh + (float)eps);
+        if (wd > 0.0) s = s + (float)wd * p[i];
+        u[i] = s;
+        wn[2 * seg[i]] += (double)p[i] * p[i];
+        wn[2 * seg[i] + 1] += (double)s * s;
+    }
+    for (long i = 0; i < P; ++i) {
+        if (seg[i] >= nseg) continue;
+        const float a = (float)sqrt(wn[2 * seg[i]]), b = (float)sqrt(wn[2 * seg[i] + 1]);
+        float tr = 1.0f;
+        if (min_trust != 1.0 && a != 0.f && b != 0.f) {
+            tr = (a < 10.0f ? a : 10.0f) / b;
+            tr = tr < (float)min_trust ? (float)min_trust : (tr > (float)(1.0 / min_trust) ? (float)(1.0 / min_trust) : tr);
+        }
+        p[i] = p[i] + (-(float)lr * tr) * u[i];
+    }
+    free(u); free(wn);
+}
+
 SFO_API void sfo_sample_categorical(const float *logits, long N, int A, uint32_t seed, uint32_t step,
                                     uint32_t row0, float *actions, float *logp) {
     for (long i = 0; i < N; ++i) {

@@ -167,8 +167,8 @@ class Learner:
         cfg = self.cfg
         if cfg.exploration_loss not in ("entropy", "symmetric_kl"):
             raise NotImplementedError(f"{cfg.exploration_loss} not supported!")
-        if cfg.optimizer != "adam":
-            raise NotImplementedError("only the default Adam optimizer is native (Lamb: SURVEY.md §2.1 '★-minor')")
+        if cfg.optimizer not in ("adam", "lamb"):
+            raise RuntimeError(f"Unknown optimizer {cfg.optimizer}")  # learner.py:228-230
         if cfg.seed is not None:
             torch.manual_seed(cfg.seed)
             np.random.seed(cfg.seed)
@@ -188,6 +188,7 @@ class Learner:
         self.exp_avg = torch.zeros(P, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=self.device)
         self.adam_step_count = 0
+        self._lamb = None  # (segment ids, #segments, direction scratch, per-segment sums) — built on first use
         # small device scratch
         dev = self.device
         self._num_invalid = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -481,9 +482,19 @@ class Learner:
                     lib.grad_sumsq(ac.flat_grads, self._sumsq)
                     if getattr(cfg, "record_grad_norm", False):
                         self._grad_norms.append(float(self._sumsq.sqrt().item()))
-                lib.adam_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
-                              actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
-                              cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None)
+                if cfg.optimizer == "lamb":  # optimizers.py:14-189 (its own defaults: weight_decay 1e-4, min_trust 0.01)
+                    if self._lamb is None:
+                        seg, nseg = ac.tensor_segment_ids()
+                        self._lamb = (seg, nseg, torch.empty_like(ac.flat_params),
+                                      torch.zeros(128, dtype=torch.float64, device=self.device))
+                    seg, nseg, scratch, seg_sums = self._lamb
+                    lib.lamb_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, scratch, seg, seg_sums,
+                                  nseg, self.adam_step_count, actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
+                                  1e-4, 0.01, cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None)
+                else:
+                    lib.adam_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
+                                  actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
+                                  cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None)
                 ac.params_changed()
                 num_sgd_steps += 1
                 self.train_step += 1

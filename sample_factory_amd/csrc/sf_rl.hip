@@ -932,6 +932,94 @@ extern "C" int sf_adam_step(float *p, const float *g, float *m, float *v, int64_
     return sf_launch_status("sf_adam_step");
 }
 
+// =========================================================================================== Lamb (cfg.optimizer=lamb)
+// sample_factory/algo/utils/optimizers.py:14-189 as the Learner configures it (learner.py:228-243: lr, betas, eps;
+// weight_decay 1e-4, min_trust 0.01, bias correction, no look-ahead), list-params path: Adam direction + weight decay,
+// then a per-TENSOR trust ratio min(||w||, 10) / ||step|| clamped to [min_trust, 1/min_trust].  The flat buffer carries
+// a segment id per element (one id per reference tensor; 255 = padding), so two streaming passes suffice:
+//   pass 1: moments, direction u -> scratch, per-segment sum w^2 / sum u^2 (LDS bins -> one atomic per bin and block)
+//   pass 2: w -= lr * trust[seg] * u
+struct LambC {
+    float inv_bc1, inv_bc2_sqrt, w1, b1, b2, w2, eps, wd, max_norm, grad_scale, lr, min_trust;
+};
+constexpr int LAMB_MAX_SEG = 64;
+
+__global__ __launch_bounds__(256) void k_lamb_dir(const float *__restrict__ p, const float *__restrict__ g,
+                                                  float *__restrict__ m, float *__restrict__ v,
+                                                  float *__restrict__ upd, const uint8_t *__restrict__ seg, int64_t P,
+                                                  LambC c, const double *__restrict__ sumsq,
+                                                  double *__restrict__ seg_sums) {
+    __shared__ double bins[2 * LAMB_MAX_SEG];
+    for (int i = threadIdx.x; i < 2 * LAMB_MAX_SEG; i += blockDim.x) bins[i] = 0.0;
+    __syncthreads();
+    float coef = c.grad_scale;
+    if (sumsq && c.max_norm > 0.f) {
+        const float total = (float)sqrt(*sumsq) * fabsf(c.grad_scale);
+        coef = c.grad_scale * fminf(c.max_norm / (total + 1e-6f), 1.0f);
+    }
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < P; i += nt) {
+        const int sg = seg[i];
+        if (sg >= LAMB_MAX_SEG) continue;  // padding
+        const float gg = g[i] * coef, w = p[i];
+        const float mm = m[i] * c.b1 + c.w1 * gg;          // exp_avg.mul_(b1).add_(grad, alpha=1-b1)
+        const float vv = v[i] * c.b2 + c.w2 * (gg * gg);   // exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1-b2)
+        m[i] = mm; v[i] = vv;
+        const float mh = mm * c.inv_bc1, vh = sqrtf(vv) * c.inv_bc2_sqrt;
+        float u = mh / (vh + c.eps);
+        if (c.wd > 0.f) u = u + c.wd * w;
+        upd[i] = u;
+        atomicAdd(&bins[2 * sg], (double)w * (double)w);
+        atomicAdd(&bins[2 * sg + 1], (double)u * (double)u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * LAMB_MAX_SEG; i += blockDim.x)
+        if (bins[i] != 0.0) atomicAdd(&seg_sums[i], bins[i]);
+}
+
+__global__ __launch_bounds__(256) void k_lamb_apply(float *__restrict__ p, const float *__restrict__ upd,
+                                                    const uint8_t *__restrict__ seg, int64_t P, LambC c,
+                                                    const double *__restrict__ seg_sums) {
+    __shared__ float trust[LAMB_MAX_SEG];
+    for (int i = threadIdx.x; i < LAMB_MAX_SEG; i += blockDim.x) {
+        const float wn = (float)sqrt(seg_sums[2 * i]), sn = (float)sqrt(seg_sums[2 * i + 1]);
+        float tr = 1.0f;
+        if (c.min_trust != 1.0f && wn != 0.f && sn != 0.f) {
+            tr = fminf(wn, 10.0f) / sn;
+            tr = fminf(fmaxf(tr, c.min_trust), 1.0f / c.min_trust);
+        }
+        trust[i] = tr;
+    }
+    __syncthreads();
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < P; i += nt) {
+        const int sg = seg[i];
+        if (sg < LAMB_MAX_SEG) p[i] = p[i] + (-c.lr * trust[sg]) * upd[i];  // p.add_(adam_step, alpha=-lr*trust)
+    }
+}
+
+extern "C" int sf_lamb_step(float *p, const float *g, float *m, float *v, float *scratch, const uint8_t *seg_id,
+                            double *seg_sums, int64_t P, int num_segments, int step, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, float min_trust, float max_grad_norm, const double *sumsq,
+                            float grad_scale, void *stream) {
+    SF_REQUIRE(p && g && m && v && scratch && seg_id && seg_sums && P > 0 && step >= 1, "sf_lamb_step: bad args");
+    SF_REQUIRE(num_segments >= 1 && num_segments <= LAMB_MAX_SEG, "sf_lamb_step: 1..%d segments", LAMB_MAX_SEG);
+    LambC c;
+    c.inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    c.b1 = beta1; c.w1 = (float)(1.0 - (double)beta1);
+    c.b2 = beta2; c.w2 = (float)(1.0 - (double)beta2);
+    c.eps = eps; c.wd = weight_decay; c.max_norm = max_grad_norm; c.grad_scale = grad_scale; c.lr = lr;
+    c.min_trust = min_trust;
+    int rc = sf_hip_status(hipMemsetAsync(seg_sums, 0, 2 * LAMB_MAX_SEG * sizeof(double), STREAM(stream)), "sf_lamb_step");
+    if (rc) return rc;
+    const int64_t blocks = (P + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024));
+    k_lamb_dir<<<grid, dim3(256), 0, STREAM(stream)>>>(p, g, m, v, scratch, seg_id, P, c, sumsq, seg_sums);
+    k_lamb_apply<<<grid, dim3(256), 0, STREAM(stream)>>>(p, scratch, seg_id, P, c, seg_sums);
+    return sf_launch_status("sf_lamb_step");
+}
+
 // =========================================================================================== K4/K5 sample + write
 template <int MAXA>
 __global__ __launch_bounds__(256) void k_sample_write(const float *__restrict__ logits, int ldl,

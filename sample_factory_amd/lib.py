@@ -38,7 +38,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
-    "sf_adam_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_sample_write_step_tuple", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_sample_write_step_tuple", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
     "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_conv_kernel_name",
     "sf_conv_fwd_t_supported", "sf_conv_fwd_t", "sf_transpose",
     "sf_linear_fwd",
@@ -290,6 +290,15 @@ def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, max_grad_norm, sumsq, gra
                                ptr(v, "f32", "exp_avg_sq"), i64(p.numel()), int(step), f(lr), f(beta1), f(beta2),
                                f(eps), f(max_grad_norm), ptr(sumsq, "f64", "sumsq"), f(grad_scale), stream()),
            "sf_adam_step")
+
+
+def lamb_step(p, g, m, v, scratch, seg_id, seg_sums, num_segments, step, lr, beta1, beta2, eps, weight_decay, min_trust,
+              max_grad_norm, sumsq, grad_scale=1.0) -> None:
+    _check(load().sf_lamb_step(ptr(p, "f32", "p"), ptr(g, "f32", "g"), ptr(m, "f32", "m"), ptr(v, "f32", "v"),
+                               ptr(scratch, "f32", "scratch"), ptr(seg_id, "u8", "seg_id"), ptr(seg_sums, "f64", "seg_sums"),
+                               i64(p.numel()), int(num_segments), int(step), f(lr), f(beta1), f(beta2), f(eps),
+                               f(weight_decay), f(min_trust), f(max_grad_norm), ptr(sumsq, "f64", "sumsq"),
+                               f(grad_scale), stream()), "sf_lamb_step")
 
 
 def sample_write_step(logits, ld_logits, values, ld_values, B, A, T, t, seed, step, row0, policy_version, deterministic,

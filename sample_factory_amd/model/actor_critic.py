@@ -365,6 +365,27 @@ class ActorCritic:
             self._bufs[key] = t
         return t
 
+    def tensor_segment_ids(self):
+        """(seg_id u8 [num_flat], num_segments): which REFERENCE parameter tensor every flat element belongs to
+        (per-tensor statistics of Lamb, optimizers.py:108-135); 255 = padding.  The fused heads matrix [feat, 1+A+pad]
+        holds two reference tensors column-wise: critic_linear (column 0) and distribution_linear (columns 1..A)."""
+        seg = torch.full((self.num_flat,), 255, dtype=torch.uint8)
+        nseg = 0
+        for L, (o, ob) in zip(self.layers[:-1], self._segs[:-1]):
+            seg[o:o + L.K * L.N] = nseg
+            seg[ob:ob + L.N] = nseg + 1
+            nseg += 2
+        H, (o, ob), A = self.layers[-1], self._segs[-1], self.num_action_params
+        hw = torch.full((H.K, H.N), 255, dtype=torch.uint8)
+        hw[:, 0] = nseg          # critic_linear.weight
+        hw[:, 1:1 + A] = nseg + 2  # distribution_linear.weight
+        seg[o:o + H.K * H.N] = hw.reshape(-1)
+        hb = torch.full((H.N,), 255, dtype=torch.uint8)
+        hb[0] = nseg + 1         # critic_linear.bias
+        hb[1:1 + A] = nseg + 3   # distribution_linear.bias
+        seg[ob:ob + H.N] = hb
+        return seg.to(self.device), nseg + 4
+
     def params_changed(self) -> None:
         """call after ANY write to flat_params (optimiser step, load_state_dict, broadcast): refresh derived copies"""
         for L in self.layers:

@@ -363,7 +363,7 @@ def test_learner_train_matches_reference_cnn36(lib, golden, tmp_path):
     assert "encoder.encoders.obs.enc.conv_head.0.weight" in cp["model"] and cp["model"]["returns_normalizer.count"].dtype == torch.float64
 
 
-@pytest.mark.parametrize("name", ["mlp", "mlp_inv"])
+@pytest.mark.parametrize("name", ["mlp", "mlp_inv", "mlp_lamb"])
 def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
     """vector-observation MLP encoder with tanh (the reference's Mujoco-style model), 2 epochs / KL loss / invalid rows:
     full Learner.train vs the reference's post-training state (train_mlp*.npz)."""
@@ -378,7 +378,7 @@ def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
     cfg = default_cfg(use_rnn=False, recurrence=1, nonlinearity="tanh", normalize_input=False, encoder_mlp_layers=[32, 32],
                       rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]),
                       kl_loss_coeff=kl, seed=0, serial_mode=True, train_dir=str(tmp_path), experiment="t",
-                      record_grad_norm=True)
+                      record_grad_norm=True, optimizer="lamb" if "optimizer=lamb" in str(g["argv"]) else "adam")
     obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
     env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
     pv = torch.zeros(1, dtype=torch.int32)

@@ -376,6 +376,35 @@ def test_sample_write_step_vs_oracle(lib, B, A):
     np.testing.assert_array_equal(env_a.cpu().numpy(), logits.argmax(1).astype(np.int32))
 
 
+def test_lamb_step_vs_oracle(lib):
+    """Lamb (optimizers.py:14-189): per-tensor trust ratios over a flat buffer with a segment-id map, padding skipped,
+    gradient clipping folded in; three consecutive steps vs the C oracle."""
+    rng = np.random.default_rng(5)
+    sizes = [4096, 64, 100000, 512, 3, 1, 777]
+    seg = np.concatenate([np.full(s, i, np.uint8) for i, s in enumerate(sizes)] + [np.full(13, 255, np.uint8)])
+    rng.shuffle(seg[:5000])      # ids need not be contiguous (the fused heads matrix interleaves two tensors)
+    P = seg.size
+    p = (rng.standard_normal(P) * np.where(seg == 2, 3.0, 0.05)).astype(np.float32)
+    p[seg == 4] = 0.0            # a zero tensor: trust ratio 1
+    m, v = np.zeros(P, np.float32), np.zeros(P, np.float32)
+    pd, md, vd = dev(p), dev(m), dev(v)
+    segd = dev(seg, torch.uint8)
+    scratch, sums = torch.empty(P, device="cuda"), torch.zeros(128, dtype=torch.float64, device="cuda")
+    sumsq = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for step in (1, 2, 3):
+        g = (rng.standard_normal(P) * 0.3).astype(np.float32)
+        gd = dev(g)
+        lib.grad_sumsq(gd, sumsq)
+        lib.lamb_step(pd, gd, md, vd, scratch, segd, sums, len(sizes), step, 3e-3, 0.9, 0.999, 1e-6, 1e-4, 0.01, 4.0, sumsq)
+        gc, _ = oracle.clip_grad_norm(g, 4.0)
+        p, m, v = oracle.lamb_step(p, gc, m, v, seg, len(sizes), step, lr=3e-3)
+        # the clip coefficient is an f32 function of an f64 (device) / f32 (oracle) norm: ~1e-5 relative in g^2
+        np.testing.assert_allclose(md.cpu().numpy()[seg < 255], m[seg < 255], rtol=3e-5, atol=1e-9)
+        np.testing.assert_allclose(vd.cpu().numpy()[seg < 255], v[seg < 255], rtol=6e-5, atol=1e-12)
+        np.testing.assert_allclose(pd.cpu().numpy(), p, rtol=3e-5, atol=3e-7)
+    assert np.array_equal(pd.cpu().numpy()[seg == 255], p[seg == 255])   # padding untouched
+
+
 def test_sample_tuple_vs_oracle(lib):
     """Tuple of Discrete heads (TupleActionDistribution): per-head inverse-CDF sampling, log-prob = sum over heads;
     head 0 draws from the same Philox stream as the single-head sampler."""
