@@ -36,6 +36,7 @@ from sample_factory_amd.algo.utils.tensor_dict import TensorDict
 from sample_factory_amd.envs.spaces import (action_head_sizes, calc_num_action_parameters, calc_num_actions, is_box,
                                              is_discrete)
 from sample_factory_amd.model.actor_critic import ActorCritic
+from sample_factory_amd.model.model_factory import create_actor_critic
 from sample_factory_amd.utils.attr_dict import AttrDict
 
 LEARNER_ENV_STEPS, POLICY_ID_KEY, STATS_KEY, TRAIN_STATS = "learner_env_steps", "policy_id", "stats", "train"
@@ -178,8 +179,9 @@ class Learner:
         self.device = torch.device("cuda", torch.cuda.current_device())
         ar = self._all_reduce if self.world > 1 else None
         cfg.dp_world = self.world
-        self.actor_critic = ActorCritic(cfg, self.env_info.obs_space, self.env_info.action_space, self.device,
-                                        all_reduce=ar)
+        # the native model, or a torch fallback around a user-registered module (model/model_factory.py)
+        self.actor_critic = create_actor_critic(cfg, self.env_info.obs_space, self.env_info.action_space, self.device,
+                                                all_reduce=ar)
         self.actor_critic.train()
         if self.world > 1:  # identical initial weights on every replica
             self.group.broadcast(self.actor_critic.flat_params, src=0)

@@ -1,0 +1,66 @@
+"""Model plugin surface — sample_factory/model/model_factory.py:16-60 + algo/utils/context.py (global_model_factory).
+
+    global_model_factory().register_actor_critic_factory(make_actor_critic_func)   # (cfg, obs_space, action_space) -> nn.Module
+    global_model_factory().register_encoder_factory(make_encoder_func)             # (cfg, obs_space) -> Encoder module
+    global_model_factory().register_model_core_factory / register_decoder_factory  # (cfg, in_size) -> module
+
+The DEFAULT models (Nature-CNN / MLP encoders, GRU/LSTM core, MLP decoder) run on the native HIP path
+(`model/actor_critic.py`).  A user-registered torch module keeps working: `create_actor_critic` wraps it in
+`TorchPolicyAdapter` (model/torch_policy.py), which drives the user's module through torch autograd on the GPU while
+everything around the network — rollout sampling, slab protocol, GAE, returns normaliser, PPO loss forward/backward,
+gradient clipping, Adam/Lamb on one flat buffer, data-parallel all-reduce — stays on the native kernels (SURVEY.md §8b:
+"native fast-path only when the factory is the default, otherwise fall back to autograd through the user module").
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+
+class ModelFactory:
+    def __init__(self):
+        self.make_actor_critic_func: Optional[Callable] = None   # None = the native default
+        self.make_model_encoder_func: Optional[Callable] = None
+        self.make_model_core_func: Optional[Callable] = None
+        self.make_model_decoder_func: Optional[Callable] = None
+
+    def register_actor_critic_factory(self, make_actor_critic_func: Callable):
+        """Override the default actor-critic with a custom model: f(cfg, obs_space, action_space) -> nn.Module"""
+        self.make_actor_critic_func = make_actor_critic_func
+
+    def register_encoder_factory(self, make_model_encoder_func: Callable):
+        """observations -> ENCODER -> core -> decoder -> heads: f(cfg, obs_space) -> module with get_out_size()"""
+        self.make_model_encoder_func = make_model_encoder_func
+
+    def register_model_core_factory(self, make_model_core_func: Callable):
+        self.make_model_core_func = make_model_core_func
+
+    def register_decoder_factory(self, make_model_decoder_func: Callable):
+        self.make_model_decoder_func = make_model_decoder_func
+
+    def is_default(self) -> bool:
+        return (self.make_actor_critic_func is None and self.make_model_encoder_func is None and
+                self.make_model_core_func is None and self.make_model_decoder_func is None)
+
+    def reset(self):
+        self.__init__()
+
+
+_FACTORY = ModelFactory()
+
+
+def global_model_factory() -> ModelFactory:
+    return _FACTORY
+
+
+def create_actor_critic(cfg, obs_space, action_space, device, all_reduce=None):
+    """model/actor_critic.py:337-342 create_actor_critic: the native model unless the user registered something"""
+    f = global_model_factory()
+    if f.is_default():
+        from sample_factory_amd.model.actor_critic import ActorCritic
+        return ActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter, build_torch_actor_critic
+    if f.make_actor_critic_func is not None:
+        module = f.make_actor_critic_func(cfg, obs_space, action_space)
+    else:
+        module = build_torch_actor_critic(cfg, obs_space, action_space, f)
+    return TorchPolicyAdapter(cfg, obs_space, action_space, device, module, all_reduce=all_reduce)

@@ -1,0 +1,281 @@
+"""Fallback for USER-REGISTERED models (model_factory.py): a torch nn.Module behind the interface the native Learner /
+rollout runner use (forward_heads / backward / flat_params / flat_grads / ...).
+
+Only the network itself runs through torch (autograd on the GPU); the parameters are re-seated as views into ONE flat
+fp32 buffer and the gradients into a second one, so the native gradient-norm / Adam / Lamb kernels, the data-parallel
+all-reduce and the checkpoint code work unchanged.  The module must follow the reference's ActorCritic calling
+convention (model/actor_critic.py:23-133):
+
+    module(normalized_obs_dict, rnn_states, values_only=False) -> dict with "values" [n] and "action_logits" [n, A]
+
+Sampling stays native (sf_sample_write_step), so "actions"/"log_prob_actions" in the returned dict are ignored.
+Recurrent custom models and async weight snapshots are not supported on this path (NotImplementedError).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
+from sample_factory_amd.envs.spaces import calc_num_action_parameters
+
+
+class TorchObsNormalizer:
+    """utils/normalize.py:24-70 + running_mean_std.py:22-136 in torch (the native normaliser writes NHWC for the native
+    conv stack; user modules expect the reference's NCHW float observations)."""
+
+    def __init__(self, cfg, obs_shape, device, all_reduce=None, world: int = 1):
+        self.sub_mean = float(cfg.obs_subtract_mean) if abs(cfg.obs_subtract_mean) > 1e-5 else 0.0
+        self.scale = float(cfg.obs_scale)
+        self.running = bool(cfg.normalize_input)
+        self.mean = torch.zeros(obs_shape, dtype=torch.float64, device=device)
+        self.var = torch.ones(obs_shape, dtype=torch.float64, device=device)
+        self.count = torch.ones(1, dtype=torch.float64, device=device)
+        self._all_reduce, self.world = all_reduce, world
+
+    def _scale(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.float()
+        if self.sub_mean != 0.0:
+            x = x - self.sub_mean
+        if abs(self.scale - 1.0) > 1e-5:
+            x = x * (1.0 / self.scale)
+        return x
+
+    def update(self, obs: torch.Tensor, stride: int, n: int, **_):
+        """training-mode statistics update over the whole dataset (learner.py:957-961)"""
+        if not self.running:
+            return
+        x = self._scale(obs.reshape((-1,) + tuple(self.mean.shape))[:n]).double()
+        s, ss = x.sum(0), (x * x).sum(0)
+        if self._all_reduce is not None:
+            self._all_reduce(s)
+            self._all_reduce(ss)
+        bn = float(n * self.world)
+        bmean = s / bn
+        bvar = (ss - s * bmean) / (bn - 1.0)  # unbiased, as torch.var
+        delta = bmean - self.mean
+        tot = self.count + bn
+        m_a, m_b = self.var * self.count, bvar * bn
+        self.mean = self.mean + delta * bn / tot
+        self.var = (m_a + m_b + delta * delta * self.count * bn / tot) / tot
+        self.count = tot
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._scale(x)
+        if self.running:
+            x = ((x - self.mean.float()) / torch.sqrt(self.var.float() + 1e-5)).clamp(-5.0, 5.0)
+        return x
+
+    def state_dict(self, prefix="obs_normalizer.running_mean_std.running_mean_std.obs."):
+        if not self.running:
+            return {}
+        return {prefix + "running_mean": self.mean.cpu().clone(), prefix + "running_var": self.var.cpu().clone(),
+                prefix + "count": self.count.cpu().clone()}
+
+    def load_state_dict(self, sd, prefix="obs_normalizer.running_mean_std.running_mean_std.obs."):
+        if self.running and prefix + "count" in sd:
+            self.mean.copy_(torch.as_tensor(sd[prefix + "running_mean"], dtype=torch.float64))
+            self.var.copy_(torch.as_tensor(sd[prefix + "running_var"], dtype=torch.float64))
+            self.count.copy_(torch.as_tensor(sd[prefix + "count"], dtype=torch.float64).reshape(-1))
+
+
+def _nonlinearity(cfg) -> nn.Module:
+    return dict(elu=nn.ELU, relu=nn.ReLU, tanh=nn.Tanh)[cfg.nonlinearity]()
+
+
+class _DefaultTorchTail(nn.Module):
+    """encoder -> [core] -> [decoder] -> critic_linear / distribution_linear, for a user-registered ENCODER (or core /
+    decoder) with the remaining parts in their default form (model/actor_critic.py:136-195, decoder.py:15-31)."""
+
+    def __init__(self, cfg, obs_space, action_space, factory):
+        super().__init__()
+        if cfg.use_rnn and factory.make_model_core_func is None:
+            raise NotImplementedError("custom encoder together with the default RNN core on the torch fallback path")
+        self.encoder = factory.make_model_encoder_func(cfg, obs_space) if factory.make_model_encoder_func else None
+        if self.encoder is None:
+            raise NotImplementedError("register an encoder (or a whole actor-critic) when customising core/decoder")
+        size = int(self.encoder.get_out_size())
+        self.core = factory.make_model_core_func(cfg, size) if factory.make_model_core_func else None
+        if self.core is not None:
+            size = int(self.core.get_out_size())
+        if factory.make_model_decoder_func is not None:
+            self.decoder = factory.make_model_decoder_func(cfg, size)
+            size = int(self.decoder.get_out_size())
+        else:
+            layers = []
+            for h in list(getattr(cfg, "decoder_mlp_layers", []) or []):
+                layers += [nn.Linear(size, int(h)), _nonlinearity(cfg)]
+                size = int(h)
+            self.decoder = nn.Sequential(*layers)
+        self.critic_linear = nn.Linear(size, 1)
+        self.distribution_linear = nn.Linear(size, calc_num_action_parameters(action_space))
+        gain = cfg.policy_init_gain
+        for m in self.modules():  # actor_critic.py:73-96
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                if cfg.policy_initialization == "orthogonal":
+                    nn.init.orthogonal_(m.weight, gain=gain)
+                elif cfg.policy_initialization == "xavier_uniform":
+                    nn.init.xavier_uniform_(m.weight, gain=gain)
+                if cfg.policy_initialization != "torch_default" and m.bias is not None:
+                    m.bias.data.fill_(0)
+
+    def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False):
+        x = self.encoder(normalized_obs_dict)
+        new_rnn = rnn_states
+        if self.core is not None:
+            x, new_rnn = self.core(x, rnn_states)
+        x = self.decoder(x)
+        res = dict(values=self.critic_linear(x).squeeze(-1), new_rnn_states=new_rnn)
+        if not values_only:
+            res["action_logits"] = self.distribution_linear(x)
+        return res
+
+
+def build_torch_actor_critic(cfg, obs_space, action_space, factory) -> nn.Module:
+    return _DefaultTorchTail(cfg, obs_space, action_space, factory)
+
+
+class TorchPolicyAdapter:
+    def __init__(self, cfg, obs_space, action_space, device, module: nn.Module, all_reduce=None):
+        if cfg.use_rnn:
+            raise NotImplementedError("recurrent user models are not supported on the torch fallback path")
+        self.cfg, self.device = cfg, torch.device(device)
+        self.module = module.to(self.device).float()
+        space = obs_space["obs"] if hasattr(obs_space, "keys") else obs_space
+        self.obs_shape = tuple(space.shape)
+        self.obs_elems = int(np.prod(self.obs_shape))
+        self.num_action_params = int(calc_num_action_parameters(action_space))
+        self.heads_ld = (1 + self.num_action_params + 3) // 4 * 4
+        self.rnn_kind = None
+        self.new_rnn_states = None
+        self.training = True
+        # ---- re-seat parameters / gradients as views into flat buffers (16-byte aligned segments)
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        self._names = [n for n, p in self.module.named_parameters() if p.requires_grad]
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.num_flat = off
+        self.flat_params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        self._params, self._offs = params, offs
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                self.flat_params[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_params[o:o + p.numel()].view(p.shape)
+                p.grad = self.flat_grads[o:o + p.numel()].view(p.shape)
+        world = int(getattr(cfg, "dp_world", 1) or 1)
+        self._norm = TorchObsNormalizer(cfg, self.obs_shape, self.device, all_reduce, world)  # scale/shift always applies
+        self.obs_normalizer = self._norm if cfg.normalize_input else None  # what the Learner updates once per dataset
+        self.returns_normalizer: Optional[RunningMeanStdInPlace] = None
+        if cfg.normalize_returns:
+            self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
+        self._bufs: Dict = {}
+        self._train_heads = None
+
+    def num_params(self) -> int:
+        return sum(p.numel() for p in self._params)
+
+    def ref_param_shapes(self):
+        return [(n, tuple(p.shape)) for n, p in zip(self._names, self._params)]
+
+    def train(self, mode=True):
+        self.training = mode
+        self.module.train(mode)
+        if self.returns_normalizer is not None:
+            self.returns_normalizer.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def params_changed(self) -> None:
+        pass  # the module's parameters ARE views of flat_params
+
+    def enable_weight_snapshots(self):
+        raise NotImplementedError("async_rl with a user-registered torch model")
+
+    def _buf(self, key, shape, dtype=torch.float32):
+        t = self._bufs.get(key)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def _zbuf(self, key, shape):
+        t = self._bufs.get(key)
+        if t is None or t.shape != torch.Size(shape):
+            t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def tensor_segment_ids(self):
+        seg = torch.full((self.num_flat,), 255, dtype=torch.uint8)
+        for i, (p, o) in enumerate(zip(self._params, self._offs)):
+            seg[o:o + p.numel()] = i
+        if len(self._params) > 64:
+            raise NotImplementedError("Lamb with more than 64 parameter tensors")
+        return seg.to(self.device), len(self._params)
+
+    # ---- gather the logical samples exactly as the native loaders address them
+    def _gather(self, obs, n, index, offset, traj_T):
+        if traj_T:
+            flat = obs.reshape((-1,) + self.obs_shape)
+            d = index.long() if index is not None else torch.arange(offset, offset + n, device=self.device)
+            return flat[d + d // traj_T]                     # dataset index e*T+t -> slab row e*(T+1)+t
+        x = obs.reshape((-1,) + self.obs_shape) if obs.is_contiguous() else obs
+        if index is not None:
+            return x[index.long()]
+        return x[offset:offset + n]
+
+    def forward_heads(self, obs, n, *, sample_stride, index=None, offset=0, traj_T=0, tag="inf", rnn=None) -> List[torch.Tensor]:
+        x = self._norm(self._gather(obs, n, index, offset, traj_T))
+        train = tag == "train"
+        with torch.set_grad_enabled(train):
+            res = self.module({"obs": x}, None, values_only=False)
+            heads = torch.cat([res["values"].reshape(n, 1), res["action_logits"].reshape(n, self.num_action_params),
+                               torch.zeros((n, self.heads_ld - 1 - self.num_action_params), device=self.device)], dim=1)
+        if train:
+            self._train_heads = heads
+        return [heads.detach()]
+
+    def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
+        obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
+        heads = self.forward_heads(obs, obs.shape[0], sample_stride=self.obs_elems)[-1]
+        res = dict(values=heads[:, 0], new_rnn_states=rnn_states)
+        if not values_only:
+            res["action_logits"] = heads[:, 1:1 + self.num_action_params]
+        return res
+
+    def backward(self, acts, g_heads, obs, n, *, sample_stride, index=None, offset=0, traj_T=0) -> None:
+        self.flat_grads.zero_()
+        self._train_heads.backward(g_heads)   # accumulates into the p.grad views of flat_grads
+        self._train_heads = None
+
+    # ---- checkpoints in the module's own names (+ the reference's normaliser keys)
+    def state_dict(self):
+        sd = {k: v.detach().cpu().clone() for k, v in self.module.state_dict().items()}
+        sd.update(self._norm.state_dict())
+        if self.returns_normalizer is not None:
+            sd.update(self.returns_normalizer.state_dict("returns_normalizer."))
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        own = self.module.state_dict()
+        with torch.no_grad():
+            for k, v in own.items():
+                if k in sd:
+                    v.copy_(torch.as_tensor(sd[k]).to(v.dtype))
+                elif strict:
+                    raise KeyError(k)
+        self._norm.load_state_dict(sd)
+        if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
+            self.returns_normalizer.load_state_dict(sd, "returns_normalizer.")
+
+    def flat_to_ref(self, flat: torch.Tensor):
+        return {n: flat[o:o + p.numel()].view(p.shape).detach().cpu().clone()
+                for n, p, o in zip(self._names, self._params, self._offs)}

@@ -802,6 +802,86 @@ def test_async_rl_two_streams_equal_same_schedule_on_one_stream(lib, variant):
     assert (ra.slabs[1]["policy_version"] == 8.0).all() and ra.learner.train_step == 10
 
 
+def test_user_registered_torch_model_trains_through_the_native_path(lib, tmp_path):
+    """Model plugin surface (model/model_factory.py:16-60): a custom encoder registered with
+    global_model_factory().register_encoder_factory keeps working — the network runs through torch autograd, everything
+    around it (sampling, slab, GAE, PPO loss fwd/bwd, clip, Adam on the flat buffer, checkpoints) stays native.  The
+    fallback must agree with the NATIVE model when the custom encoder is the default MLP with the same weights."""
+    from torch import nn
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.model_factory import global_model_factory
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter
+
+    class MyEncoder(nn.Module):
+        def __init__(self, cfg, obs_space):
+            super().__init__()
+            self.net = nn.Sequential(nn.Linear(8, 32), nn.Tanh(), nn.Linear(32, 32), nn.Tanh())
+
+        def forward(self, obs_dict):
+            return self.net(obs_dict["obs"])
+
+        def get_out_size(self):
+            return 32
+
+    E, T, A = 16, 8, 6
+    cfgkw = dict(use_rnn=False, recurrence=1, nonlinearity="tanh", normalize_input=False, encoder_mlp_layers=[32, 32],
+                 rollout=T, batch_size=E * T // 2, num_batches_per_epoch=2, num_epochs=2, seed=0, serial_mode=True,
+                 experiment="t", kl_loss_coeff=0.1)
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    native = Learner(default_cfg(train_dir=str(tmp_path / "a"), **cfgkw), env_info, pv, 0, ParameterServer(0, pv))
+    native.init()
+    global_model_factory().register_encoder_factory(lambda cfg, obs_space: MyEncoder(cfg, obs_space))
+    try:
+        custom = Learner(default_cfg(train_dir=str(tmp_path / "b"), **cfgkw), env_info, pv, 0, ParameterServer(0, pv))
+        custom.init()
+    finally:
+        global_model_factory().reset()
+    ca = custom.actor_critic
+    assert isinstance(ca, TorchPolicyAdapter) and ca.num_params() == native.actor_critic.num_params()
+    # same weights in both: reference-layout state dict of the native model -> the torch module
+    sd = native.actor_critic.state_dict()
+    ca.load_state_dict({"encoder.net.0.weight": sd["encoder.encoders.obs.mlp_head.0.weight"],
+                        "encoder.net.0.bias": sd["encoder.encoders.obs.mlp_head.0.bias"],
+                        "encoder.net.2.weight": sd["encoder.encoders.obs.mlp_head.2.weight"],
+                        "encoder.net.2.bias": sd["encoder.encoders.obs.mlp_head.2.bias"],
+                        "critic_linear.weight": sd["critic_linear.weight"], "critic_linear.bias": sd["critic_linear.bias"],
+                        "distribution_linear.weight": sd["action_parameterization.distribution_linear.weight"],
+                        "distribution_linear.bias": sd["action_parameterization.distribution_linear.bias"]}, strict=False)
+    g = torch.Generator().manual_seed(0)
+    batch = alloc_trajectory_tensors(env_info, E, T, 1, "cuda")
+    batch["obs"]["obs"].copy_(torch.randn((E, T + 1, 8), generator=g))
+    batch["actions"].copy_(torch.randint(0, A, (E, T, 1), generator=g).float())
+    batch["action_logits"].copy_(torch.randn((E, T, A), generator=g) * 0.5)
+    batch["log_prob_actions"].copy_(-torch.rand((E, T), generator=g) - 0.5)
+    batch["values"].copy_(torch.randn((E, T + 1), generator=g))
+    batch["rewards"].copy_(torch.randn((E, T), generator=g))
+    batch["dones"].copy_(torch.rand((E, T), generator=g) < 0.1)
+    batch["time_outs"].zero_()
+    batch["policy_id"].zero_()
+    batch["policy_version"].zero_()
+    from sample_factory_amd.algo.utils.tensor_dict import clone_tensordict
+    s1 = native.train(clone_tensordict(batch))
+    s2 = custom.train(clone_tensordict(batch))
+    assert s1["learner_env_steps"] == s2["learner_env_steps"] and custom.train_step == native.train_step == 4
+    assert abs(s1["train"]["loss"] - s2["train"]["loss"]) < 1e-5
+    after_n, after_c = native.actor_critic.state_dict(), ca.state_dict()
+    for kn, kc in [("encoder.encoders.obs.mlp_head.0.weight", "encoder.net.0.weight"),
+                   ("encoder.encoders.obs.mlp_head.2.bias", "encoder.net.2.bias"),
+                   ("critic_linear.weight", "critic_linear.weight"),
+                   ("action_parameterization.distribution_linear.weight", "distribution_linear.weight")]:
+        assert (after_n[kn] - after_c[kc]).abs().max() < 2e-5, kn      # 4 Adam steps at lr 1e-4
+        assert not torch.equal(after_c[kc], sd[kn])                     # ... and it did train
+    custom.save()   # checkpoint round trip with the module's own parameter names
+    assert "encoder.net.0.weight" in torch.load(Learner.get_checkpoints(Learner.checkpoint_dir(custom.cfg, 0))[-1],
+                                                weights_only=False)["model"]
+
+
 def test_cartpole_learns(lib):
     """BASELINE.json configs[0] as a learning test (the reference's own end-to-end check is a learning test too,
     tests/examples/test_example.py:159-174): host CartPole env, MLP policy, sync APPO on the GPU; the mean episode length
