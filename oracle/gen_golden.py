@@ -433,6 +433,67 @@ def gen_minibatch_indices():
          recurrence=4, chunk_start_permutation=perm, minibatches=np.stack(mbs))
 
 
+def gen_host_logic():
+    """SliceMerger (batcher.py:22-86) op traces and BufferMgr (shared_buffers.py:152-239) bookkeeping numbers"""
+    import json
+    import random
+    from sample_factory.algo.learning.batcher import SliceMerger
+    from sample_factory.algo.utils.shared_buffers import BufferMgr
+    rng = random.Random(7)
+    traces = []
+    for case in range(6):
+        unit, total = rng.choice([4, 8, 16]), 256
+        pieces = [slice(i, i + unit) for i in range(0, total, unit)]
+        rng.shuffle(pieces)
+        sm, ops, pending = SliceMerger(), [], list(pieces)
+        while pending or sm.total_num:
+            r = rng.random()
+            if pending and (r < 0.6 or not sm.total_num):
+                s = pending.pop()
+                sm.merge_slices(s)
+                ops.append(["merge", s.start, s.stop, sm.total_num, sorted(sm.slice_starts)])
+            elif r < 0.8:
+                n = rng.choice([unit, 2 * unit, 3 * unit, 64])
+                got = sm.get_exactly(n)
+                ops.append(["exactly", n, None if got is None else [got.start, got.stop], sm.total_num])
+            else:
+                n = rng.choice([unit // 2, unit, 5 * unit])
+                got = sm.get_at_most(n)
+                ops.append(["at_most", n, None if got is None else [got.start, got.stop], sm.total_num])
+        traces.append(ops)
+    mgr = []
+    obs = gym.spaces.Dict({"obs": gym.spaces.Box(-1, 1, (4,), np.float32)})
+    for args, agents in [(["--num_workers=1", "--num_envs_per_worker=1", "--async_rl=False", "--batch_size=512",
+                           "--num_batches_per_epoch=2", "--rollout=8", "--serial_mode=True"], 128),
+                         (["--num_workers=2", "--num_envs_per_worker=2", "--worker_num_splits=2", "--async_rl=True",
+                           "--batch_size=256", "--num_batches_per_epoch=1", "--rollout=16", "--serial_mode=True",
+                           "--num_batches_to_accumulate=2"], 32),
+                         (["--num_workers=1", "--num_envs_per_worker=1", "--async_rl=True", "--batch_size=4096",
+                           "--num_batches_per_epoch=4", "--rollout=32", "--serial_mode=True",
+                           "--num_batches_to_accumulate=2"], 64),
+                         (["--num_workers=4", "--num_envs_per_worker=8", "--batched_sampling=False", "--async_rl=True",
+                           "--batch_size=128", "--num_batches_per_epoch=1", "--rollout=8", "--serial_mode=True",
+                           "--worker_num_splits=2"], 1)]:
+        cfg = make_cfg(MLP_ARGS + args)
+        env_info = EnvInfo(obs, gym.spaces.Discrete(3), agents, False, False, None, None, 1)
+        bm = BufferMgr(cfg, env_info)
+        (dev, nbuf), = bm.buffers_per_device.items()
+        q = bm.traj_buffer_queues[dev]
+        items = []
+        while not q.empty():
+            it = q.get()
+            items.append([it.start, it.stop] if isinstance(it, slice) else int(it))
+        mgr.append(dict(argv=args, num_agents=agents, buffers_for_device=int(nbuf),
+                        allocated=int(bm.traj_tensors_torch[dev]["rewards"].shape[0]),
+                        trajectories_per_training_iteration=int(bm.trajectories_per_training_iteration),
+                        sampling_trajectories_per_iteration=int(bm.sampling_trajectories_per_iteration),
+                        max_batches_to_accumulate=int(bm.max_batches_to_accumulate), queue=items))
+    json.dump(dict(ref="sample_factory/algo/learning/batcher.py:22-86; algo/utils/shared_buffers.py:152-239",
+                   slice_merger_traces=traces, buffer_mgr=mgr),
+              open(os.path.join(OUT, "host_logic.json"), "w"))
+    print("  wrote host_logic.json")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb", "cfg"]
@@ -468,6 +529,8 @@ def main():
                                         "--normalize_input=True"], E=16, T=8, A=6, nb=2, epochs=1)
     if "model" in which:
         gen_model_fwd()
+    if "host" in which:
+        gen_host_logic()
     if "cfg" in which:
         import json
         p, a = parse_sf_args(["--algo=APPO", "--env=x", "--experiment=e"])

@@ -53,3 +53,63 @@ def alloc_trajectory_tensors(env_info, num_traj, rollout, rnn_size, device, shar
     t["policy_id"] = torch.full([num_traj, rollout], -1, dtype=torch.int32, device=device)
     t["valids"] = torch.zeros([num_traj, rollout + 1], dtype=torch.bool, device=device)
     return t
+
+
+def trajectories_per_minibatch(cfg) -> int:
+    return cfg.batch_size // cfg.rollout
+
+
+def trajectories_per_training_iteration(cfg) -> int:
+    return cfg.num_batches_per_epoch * trajectories_per_minibatch(cfg)
+
+
+class BufferMgr:
+    """Slab bookkeeping of shared_buffers.py:152-239 for ONE process per GPU: how many trajectory rows the device slab
+    needs (agents x envs per worker, x2 when rollouts overlap training or several policies share the sampler, never
+    fewer than the learner needs to accumulate `max_batches_to_accumulate` datasets), the queue of free row slices of
+    `sampling_trajectories_per_iteration` rows handed to the sampler, and the policy-version tensor.  The slab itself
+    is the device-resident TensorDict of alloc_trajectory_tensors; the learner trains on row slices IN PLACE (no
+    batcher copy), so a slice goes sampler -> learner -> back to this queue."""
+
+    def __init__(self, cfg, env_info, device, allocate: bool = True):
+        import math
+        from collections import deque
+        self.cfg, self.env_info, self.device = cfg, env_info, device
+        num_buffers = sum(env_info.num_agents * cfg.num_envs_per_worker for _ in range(cfg.num_workers))
+        self.trajectories_per_training_iteration = trajectories_per_training_iteration(cfg)
+        if cfg.batched_sampling:
+            per_iter = (env_info.num_agents * cfg.num_envs_per_worker) // cfg.worker_num_splits
+            assert math.gcd(self.trajectories_per_training_iteration, per_iter) == min(
+                self.trajectories_per_training_iteration, per_iter), \
+                f"worker_traj_per_iteration={per_iter} should divide {self.trajectories_per_training_iteration} or vice versa"
+            self.sampling_trajectories_per_iteration = per_iter
+        else:
+            self.sampling_trajectories_per_iteration = -1
+        if cfg.async_rl or cfg.num_policies > 1:
+            num_buffers *= 2  # one set of buffers to sample into, one to learn from
+        self.max_batches_to_accumulate = cfg.num_batches_to_accumulate if cfg.async_rl else 1
+        self.buffers_per_device = {str(device): num_buffers}
+        # at the very least enough rows to feed the learner (shared_buffers.py:206-211)
+        num_buffers = max(num_buffers, self.max_batches_to_accumulate * self.trajectories_per_training_iteration *
+                          cfg.num_policies)
+        self.num_buffers = num_buffers
+        self.traj_buffer_queue = deque()
+        if cfg.batched_sampling:
+            for i in range(0, num_buffers, self.sampling_trajectories_per_iteration):
+                self.traj_buffer_queue.append(slice(i, i + self.sampling_trajectories_per_iteration))
+        else:
+            for i in range(num_buffers):
+                self.traj_buffer_queue.append(i)
+        self.policy_versions = torch.zeros([cfg.num_policies], dtype=torch.int32)
+        self.traj_tensors = None
+        if allocate:
+            from sample_factory_amd.model.actor_critic import get_rnn_size
+            self.traj_tensors = alloc_trajectory_tensors(env_info, num_buffers, cfg.rollout, get_rnn_size(cfg), device)
+
+    def get_free_slice(self):
+        """next free row slice for the sampler, or None when every slab row is in flight (sampler must pause:
+        inference_worker.py:175-181)"""
+        return self.traj_buffer_queue.popleft() if self.traj_buffer_queue else None
+
+    def release(self, s) -> None:
+        self.traj_buffer_queue.append(s)

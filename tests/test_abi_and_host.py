@@ -162,3 +162,49 @@ def test_oracle_is_not_imported_by_the_product():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "sf_oracle" in src or "/root/reference" in src:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_slice_merger_and_buffer_mgr_match_reference(golden_json):
+    """host-side slab bookkeeping vs traces recorded from the reference's SliceMerger / BufferMgr"""
+    from sample_factory_amd.algo.learning.batcher import Batcher, SliceMerger
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import BufferMgr
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    g = golden_json("host_logic")
+    for ops in g["slice_merger_traces"]:
+        sm = SliceMerger()
+        for op in ops:
+            if op[0] == "merge":
+                sm.merge_slices(slice(op[1], op[2]))
+                assert sm.total_num == op[3] and sorted(sm.slice_starts) == op[4]
+            else:
+                got = sm.get_exactly(op[1]) if op[0] == "exactly" else sm.get_at_most(op[1])
+                assert (None if got is None else [got.start, got.stop]) == op[2] and sm.total_num == op[3]
+    obs = spaces.Dict({"obs": spaces.Box(-1, 1, (4,), np.float32)})
+    for m in g["buffer_mgr"]:
+        kv = {}
+        for a in m["argv"]:
+            k, v = a[2:].split("=")
+            kv[k] = {"True": True, "False": False}.get(v, int(v) if v.lstrip("-").isdigit() else v)
+        cfg = default_cfg(**kv)
+        bm = BufferMgr(cfg, EnvInfo(obs, spaces.Discrete(3), m["num_agents"]), "cpu", allocate=False)
+        assert bm.buffers_per_device["cpu"] == m["buffers_for_device"] and bm.num_buffers == m["allocated"]
+        assert bm.trajectories_per_training_iteration == m["trajectories_per_training_iteration"]
+        assert bm.sampling_trajectories_per_iteration == m["sampling_trajectories_per_iteration"]
+        assert bm.max_batches_to_accumulate == m["max_batches_to_accumulate"]
+        q = [[s.start, s.stop] if isinstance(s, slice) else s for s in bm.traj_buffer_queue]
+        assert q == m["queue"]
+    # the slab protocol end to end: sampler slices -> datasets for the learner -> back to the free queue
+    cfg = default_cfg(num_workers=1, num_envs_per_worker=1, worker_num_splits=2, batched_sampling=True, async_rl=True,
+                      batch_size=1024, num_batches_per_epoch=2, rollout=8, num_batches_to_accumulate=2)
+    bm = BufferMgr(cfg, EnvInfo(obs, spaces.Discrete(3), 256), "cpu", allocate=False)
+    assert bm.num_buffers == 512 and bm.sampling_trajectories_per_iteration == 128 and len(bm.traj_buffer_queue) == 4
+    b = Batcher(bm, cfg)
+    s = [bm.get_free_slice() for _ in range(4)]
+    assert bm.get_free_slice() is None                                   # every row in flight: the sampler must pause
+    assert b.on_new_trajectories(s[1]) == [] and b.on_new_trajectories(s[3]) == []
+    assert b.on_new_trajectories(s[0]) == [slice(0, 256)]                # adjacent slices merged into one dataset
+    assert b.on_new_trajectories(s[2]) == [slice(256, 512)]
+    assert b.on_training_batch_released(slice(0, 256)) == 2 and len(bm.traj_buffer_queue) == 2
+    assert bm.get_free_slice() == slice(0, 128)
