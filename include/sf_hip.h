@@ -190,6 +190,14 @@ int sf_sample_write_step(const float *logits, int ld_logits, const float *values
                          float *traj_logits, float *traj_logp, float *traj_values, float *traj_policy_version,
                          int32_t *env_actions, void *stream);
 
+/* Discrete(A) with obs["action_mask"] (u8 [B, A], row stride ld_mask; inference_worker.py:324-331): sampling and
+ * log-prob follow masked_softmax / masked_log_softmax (action_distributions.py:84-96); raw logits are recorded. */
+int sf_sample_write_step_masked(const float *logits, int ld_logits, const float *values, int ld_values,
+                                const uint8_t *action_mask, int64_t ld_mask, int B, int A, int T, int t, uint32_t seed,
+                                uint32_t step, uint32_t row0, float policy_version, int deterministic,
+                                float *traj_actions, float *traj_logits, float *traj_logp, float *traj_values,
+                                float *traj_policy_version, int32_t *env_actions, void *stream);
+
 /* Tuple-of-Discrete variant of sf_sample_write_step (TupleActionDistribution.sample_actions_log_probs,
  * action_distributions.py:241-245): head h (size head_n[h], host array of num_heads <= 8 entries) is sampled by inverse
  * CDF from its own Philox uniform (counter (step, h, 2, 0)); traj_actions gets num_heads floats per step, traj_logp the

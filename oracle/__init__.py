@@ -150,6 +150,15 @@ def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-6):
     return p, m, v
 
 
+def sample_masked(logits, mask, seed, step, row0=0):
+    logits, mask = _f32(logits), _u8(mask)
+    N, A = logits.shape
+    actions, logp = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    lib().sfo_sample_masked(_p(logits, C.c_float), _p(mask, C.c_uint8), C.c_long(N), A, C.c_uint32(seed),
+                            C.c_uint32(step), C.c_uint32(row0), _p(actions, C.c_float), _p(logp, C.c_float))
+    return actions, logp
+
+
 def sample_tuple(logits, head_sizes, seed, step, row0=0):
     logits = _f32(logits)
     N, H = logits.shape[0], len(head_sizes)

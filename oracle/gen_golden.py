@@ -208,6 +208,15 @@ def gen_action_dist():
                        f"tup{i}_entropy": d.entropy().numpy(), f"tup{i}_kl": d.kl_divergence(do).numpy(),
                        f"tup{i}_symkl_uniform": d.symmetric_kl_with_uniform_prior().numpy()})
     arrays["num_tup"] = 2
+    # masked categorical (obs["action_mask"]): masked_softmax / masked_log_softmax, action_distributions.py:84-96
+    N, A = 300, 7
+    z = torch.randn(N, A, generator=g) * 2.0
+    mask = (torch.rand(N, A, generator=g) < 0.6).float()
+    mask[:5] = 0.0          # rows with every action masked out
+    mask[5:10] = 1.0
+    d = CategoricalActionDistribution(z, mask)
+    arrays.update(dict(mask_logits=z.numpy(), mask_mask=mask.numpy().astype(np.uint8), mask_probs=d.probs.numpy(),
+                       mask_log_probs=d.log_probs.numpy()))
     save("action_dist", **arrays)
 
 

@@ -548,6 +548,36 @@ SFO_API void sfo_sample_categorical(const float *logits, long N, int A, uint32_t
     }
 }
 
+/* Discrete(A) with an action mask, as sf_sample_write_step_masked (action_distributions.py:84-96,110-142) */
+SFO_API void sfo_sample_masked(const float *logits, const uint8_t *mask, long N, int A, uint32_t seed, uint32_t step,
+                               uint32_t row0, float *actions, float *logp) {
+    for (long i = 0; i < N; ++i) {
+        const float *z = logits + i * A; const uint8_t *mk = mask + i * A;
+        float mx = -INFINITY;
+        for (int k = 0; k < A; ++k) { const float v = z[k] + (mk[k] ? 0.f : -1e9f); mx = v > mx ? v : mx; }
+        float se = 0.f;
+        for (int k = 0; k < A; ++k) se += expf((z[k] + (mk[k] ? 0.f : -1e9f)) - mx);
+        const float lse = logf(se);
+        float psum = 0.f;
+        for (int k = 0; k < A; ++k) psum += mk[k] ? expf((z[k] - mx) - lse) : 0.f;
+        const int all_zero = psum == 0.f;
+        const float inv = 1.0f / (psum + 1e-13f);
+        const float tot = all_zero ? (float)A * 1e-6f : psum * inv;
+        uint32_t w[4];
+        philox4x32_10(step, 0u, 2u, 0u, seed, row0 + (uint32_t)i, w);
+        const float u = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+        float acc = 0.f; int a = A - 1;
+        for (int k = 0; k < A; ++k) {
+            const float p = all_zero ? 1e-6f : (mk[k] ? expf((z[k] - mx) - lse) * inv : 0.f);
+            acc += p / tot;
+            if (u < acc) { a = k; break; }
+        }
+        if (!all_zero && !mk[a]) for (int k = A - 1; k >= 0; --k) if (mk[k]) { a = k; break; }
+        actions[i] = (float)a;
+        logp[i] = ((z[a] + (mk[a] ? 0.f : -1e9f)) - mx) - lse;
+    }
+}
+
 /* Tuple of Discrete heads as sampled by sf_sample_write_step_tuple: head h draws from Philox counter (step, h, 2, 0);
  * actions [N, H], logp = sum of the heads' log-probs (TupleActionDistribution._calc_log_probs). */
 SFO_API void sfo_sample_tuple(const float *logits, long N, const int *head_n, int H, uint32_t seed, uint32_t step,

@@ -50,6 +50,12 @@ class BatchedVectorEnvRunner:
         self.A = actor_critic.num_action_params
         self.ld = actor_critic.heads_ld
         self.continuous = is_box(self.env_info.action_space)  # Box(D): params = [means | log_std]
+        # obs["action_mask"] (inference_worker.py:324-331): kept in the slab like every other obs key, used by the sampler
+        self.masked = "action_mask" in traj["obs"]
+        if self.masked and (self.continuous or len(self.heads) != 1):
+            raise NotImplementedError("action masks are supported for a single Discrete action space")
+        if self.masked and self.zero_copy:
+            raise NotImplementedError("action masks with a zero-copy (step_into) env")
 
     def reset(self) -> None:
         """First observation into slab obs[:, 0] (batched_sampling.py:172-206)."""
@@ -57,8 +63,13 @@ class BatchedVectorEnvRunner:
             self.env.reset_into(self.obs[:, 0])
         else:
             o, _ = self.env.reset()
-            self.obs[:, 0].copy_(torch.as_tensor(o["obs"] if isinstance(o, dict) else o, device=self.device))
+            self._store_obs(o, 0)
         self._started = True
+
+    def _store_obs(self, o, t: int) -> None:
+        self.obs[:, t].copy_(torch.as_tensor(o["obs"] if isinstance(o, dict) else o, device=self.device))
+        if self.masked:
+            self.traj["obs"]["action_mask"][:, t].copy_(torch.as_tensor(o["action_mask"], device=self.device))
 
     def policy_version(self) -> float:
         return float(self.policy_versions[self.policy_id].item()) if self.policy_versions is not None else 0.0
@@ -74,7 +85,13 @@ class BatchedVectorEnvRunner:
         for t in range(T):
             rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
             heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf", rnn=rnn)[-1]
-            if len(self.heads) > 1:  # Tuple of Discrete spaces: one categorical per head, actions [B, H]
+            if self.masked:
+                mk = tr["obs"]["action_mask"][:, t]
+                lib.sample_write_step_masked(heads[:, 1:], self.ld, heads[:, 0], self.ld, mk, mk.stride(0), B, A, T, t,
+                                             self.sample_seed, self.global_step, self.row0, ver, deterministic,
+                                             tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
+                                             tr["policy_version"], self.env_actions)
+            elif len(self.heads) > 1:  # Tuple of Discrete spaces: one categorical per head, actions [B, H]
                 lib.sample_write_step_tuple(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, self.heads, T, t,
                                             self.sample_seed, self.global_step, self.row0, ver, deterministic,
                                             tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
@@ -89,7 +106,7 @@ class BatchedVectorEnvRunner:
                 rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])
             else:
                 o, rew, term, trunc, _ = self.env.step(env_actions)
-                self.obs[:, t + 1].copy_(torch.as_tensor(o["obs"] if isinstance(o, dict) else o, device=self.device))
+                self._store_obs(o, t + 1)
                 rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
                 term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()
                 trunc = torch.as_tensor(trunc, dtype=torch.bool, device=self.device).contiguous()
@@ -107,6 +124,8 @@ class BatchedVectorEnvRunner:
         self.obs = traj["obs"]["obs"]
         if carry_from is not None:
             self.obs[:, 0].copy_(carry_from["obs"]["obs"][:, self.T])
+            if self.masked:
+                traj["obs"]["action_mask"][:, 0].copy_(carry_from["obs"]["action_mask"][:, self.T])
             if self.rnn:
                 traj["rnn_states"][:, 0].copy_(carry_from["rnn_states"][:, self.T])
         elif self.rnn:
@@ -115,6 +134,9 @@ class BatchedVectorEnvRunner:
     def carry_over(self) -> None:
         """The next rollout starts from the last observation: slab obs[:, 0] <- obs[:, T] (one frame per agent)."""
         self.obs[:, 0].copy_(self.obs[:, self.T])
+        if self.masked:
+            mk = self.traj["obs"]["action_mask"]
+            mk[:, 0].copy_(mk[:, self.T])
         if self.rnn:
             self.traj["rnn_states"][:, 0].copy_(self.traj["rnn_states"][:, self.T])
 

@@ -1119,6 +1119,79 @@ extern "C" int sf_sample_write_step(const float *logits, int ld_logits, const fl
 }
 
 
+// Discrete(A) with an action mask (obs["action_mask"], inference_worker.py:324-331; action_distributions.py:84-96,
+// 110-142): logits of masked-out actions get -1e9, probs = softmax * mask / (sum + 1e-13), an all-zero row falls back to
+// uniform (the reference substitutes 1e-6 everywhere before torch.multinomial), log-prob from the masked log-softmax.
+// The RAW logits go to the trajectory (the learner re-evaluates the unmasked distribution, as the reference does).
+__global__ __launch_bounds__(256) void k_sample_write_masked(const float *__restrict__ logits, int ldl,
+                                                             const float *__restrict__ values, int ldv,
+                                                             const uint8_t *__restrict__ mask, int64_t ldm, int B, int A,
+                                                             int T, int t, uint32_t seed, uint32_t step, uint32_t row0,
+                                                             float version, int deterministic,
+                                                             float *__restrict__ t_actions, float *__restrict__ t_logits,
+                                                             float *__restrict__ t_logp, float *__restrict__ t_values,
+                                                             float *__restrict__ t_version,
+                                                             int32_t *__restrict__ env_actions) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *z = logits + (int64_t)b * ldl;
+    const uint8_t *mk = mask + (int64_t)b * ldm;
+    float mx = -INFINITY;
+    for (int k = 0; k < A; ++k) mx = fmaxf(mx, z[k] + (mk[k] ? 0.f : -1e9f));
+    float se = 0.f;
+    for (int k = 0; k < A; ++k) se += expf((z[k] + (mk[k] ? 0.f : -1e9f)) - mx);
+    const float lse = logf(se);
+    float psum = 0.f;
+    for (int k = 0; k < A; ++k) psum += mk[k] ? expf(((z[k]) - mx) - lse) : 0.f;
+    const bool all_zero = psum == 0.f;
+    const float inv = 1.0f / (psum + 1e-13f);
+    int a = A - 1;
+    if (deterministic) {
+        float best = -1.f;
+        for (int k = 0; k < A; ++k) {
+            const float p = all_zero ? 1e-6f : (mk[k] ? expf((z[k] - mx) - lse) * inv : 0.f);
+            if (p > best) { best = p; a = k; }
+        }
+    } else {
+        uint32_t w[4];
+        sf_philox4x32_10(step, 0u, 2u, 0u, seed, row0 + (uint32_t)b, w);
+        const float u = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+        float acc = 0.f;
+        const float tot = all_zero ? (float)A * 1e-6f : psum * inv;  // multinomial normalises its weights
+        for (int k = 0; k < A; ++k) {
+            const float p = all_zero ? 1e-6f : (mk[k] ? expf((z[k] - mx) - lse) * inv : 0.f);
+            acc += p / tot;
+            if (u < acc) { a = k; break; }
+        }
+        if (!all_zero && !mk[a]) {  // rounding left u beyond the last allowed action: take the last allowed one
+            for (int k = A - 1; k >= 0; --k) if (mk[k]) { a = k; break; }
+        }
+    }
+    const int64_t it = (int64_t)b * T + t;
+    t_actions[it] = (float)a;
+    t_logp[it] = ((z[a] + (mk[a] ? 0.f : -1e9f)) - mx) - lse;
+    t_version[it] = version;
+    t_values[(int64_t)b * (T + 1) + t] = values[(int64_t)b * ldv];
+    for (int k = 0; k < A; ++k) t_logits[it * A + k] = z[k];
+    if (env_actions) env_actions[b] = a;
+}
+
+extern "C" int sf_sample_write_step_masked(const float *logits, int ld_logits, const float *values, int ld_values,
+                                           const uint8_t *action_mask, int64_t ld_mask, int B, int A, int T, int t,
+                                           uint32_t seed, uint32_t step, uint32_t row0, float policy_version,
+                                           int deterministic, float *traj_actions, float *traj_logits, float *traj_logp,
+                                           float *traj_values, float *traj_policy_version, int32_t *env_actions,
+                                           void *stream) {
+    SF_REQUIRE(logits && values && action_mask && traj_actions && traj_logits && traj_logp && traj_values &&
+                   traj_policy_version, "sf_sample_write_step_masked: null pointer");
+    SF_REQUIRE(B > 0 && A > 0 && T > 0 && t >= 0 && t < T && ld_logits >= A && ld_values >= 1 && ld_mask >= A,
+               "sf_sample_write_step_masked: bad shape B=%d A=%d T=%d t=%d", B, A, T, t);
+    k_sample_write_masked<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        logits, ld_logits, values, ld_values, action_mask, ld_mask, B, A, T, t, seed, step, row0, policy_version,
+        deterministic, traj_actions, traj_logits, traj_logp, traj_values, traj_policy_version, env_actions);
+    return sf_launch_status("sf_sample_write_step_masked");
+}
+
 // Tuple of Discrete heads: every head is sampled from its own Philox uniform (counter lane 1 = head index)
 __global__ __launch_bounds__(256) void k_sample_write_tuple(const float *__restrict__ logits, int ldl,
                                                             const float *__restrict__ values, int ldv, int B, int A, int T,

@@ -114,6 +114,50 @@ class SyntheticTupleEnv(SyntheticVecEnv):
         return super().step(a)
 
 
+class MaskedBanditEnv:
+    """GPU vector env with an action mask in the observation dict (obs["action_mask"], u8 [N, A]): a contextual bandit
+    whose rewarded action (obs one-hot) is always allowed while a random subset of the others is masked out."""
+
+    def __init__(self, num_agents=64, num_actions=6, seed=0, device="cuda"):
+        self.num_agents, self.A = int(num_agents), int(num_actions)
+        self.observation_space = spaces.Dict({"obs": spaces.Box(0, 1, (self.A,), np.float32),
+                                              "action_mask": spaces.Box(0, 1, (self.A,), np.uint8)})
+        self.action_space = spaces.Discrete(self.A)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self._draw()
+
+    def _draw(self):
+        self.target = torch.randint(0, self.A, (self.num_agents,), generator=self.gen, device=self.device)
+        self.mask = (torch.rand((self.num_agents, self.A), generator=self.gen, device=self.device) < 0.5)
+        self.mask[torch.arange(self.num_agents, device=self.device), self.target] = True
+        self.obs = torch.nn.functional.one_hot(self.target, self.A).float()
+
+    def _out(self):
+        return {"obs": self.obs, "action_mask": self.mask.to(torch.uint8)}
+
+    def reset(self, **kwargs):
+        self._draw()
+        return self._out(), {}
+
+    def step(self, actions):
+        a = torch.as_tensor(actions, device=self.device).reshape(-1).long()
+        self.last_allowed = self.mask[torch.arange(self.num_agents, device=self.device), a].clone()
+        rew = (a == self.target).float()
+        term = torch.ones(self.num_agents, dtype=torch.bool, device=self.device)  # one-step episodes, auto-reset
+        self._draw()
+        return self._out(), rew, term, torch.zeros_like(term), {}
+
+    def close(self):
+        pass
+
+
+def make_masked_bandit_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    n = getattr(cfg, "synthetic_num_agents", 64) if cfg is not None else 64
+    return MaskedBanditEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0)
+
+
 def make_synthetic_tuple_env(full_env_name, cfg=None, env_config=None, render_mode=None):
     n = getattr(cfg, "synthetic_num_agents", 4096) if cfg is not None else 4096
     seed = (getattr(cfg, "seed", None) or 0) if cfg is not None else 0

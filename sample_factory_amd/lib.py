@@ -38,7 +38,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_sample_write_step_tuple", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
     "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_conv_kernel_name",
     "sf_conv_fwd_t_supported", "sf_conv_fwd_t", "sf_transpose",
     "sf_linear_fwd",
@@ -312,6 +312,22 @@ def sample_write_step(logits, ld_logits, values, ld_values, B, A, T, t, seed, st
                                        ptr(traj_logp, "f32"), ptr(traj_values, "f32"),
                                        ptr(traj_policy_version, "f32"), ptr(env_actions, "i32"), stream()),
            "sf_sample_write_step")
+
+
+def sample_write_step_masked(logits, ld_logits, values, ld_values, mask, ld_mask, B, A, T, t, seed, step, row0,
+                             policy_version, deterministic, traj_actions, traj_logits, traj_logp, traj_values,
+                             traj_policy_version, env_actions) -> None:
+    """mask: u8/bool [B, A] view with row stride ld_mask (e.g. the slab's obs["action_mask"][:, t])"""
+    if mask.dtype not in (torch.uint8, torch.bool) or not mask.is_cuda:
+        raise SfHipError(f"action_mask: expected a u8/bool CUDA tensor, got {mask.dtype} on {mask.device}")
+    _check(load().sf_sample_write_step_masked(_raw(logits, "f32", "logits"), int(ld_logits),
+                                              _raw(values, "f32", "values"), int(ld_values),
+                                              C.c_void_p(mask.data_ptr()), i64(ld_mask), int(B), int(A), int(T), int(t),
+                                              u32(seed), u32(step), u32(row0), f(policy_version),
+                                              int(bool(deterministic)), ptr(traj_actions, "f32"),
+                                              ptr(traj_logits, "f32"), ptr(traj_logp, "f32"), ptr(traj_values, "f32"),
+                                              ptr(traj_policy_version, "f32"), ptr(env_actions, "i32"), stream()),
+           "sf_sample_write_step_masked")
 
 
 def sample_write_step_tuple(logits, ld_logits, values, ld_values, B, head_n, T, t, seed, step, row0, policy_version,

@@ -120,9 +120,9 @@ class ActorCritic:
             raise NotImplementedError("normalize_input_keys other than the 'obs' key")
         if not is_discrete(action_space) and not cfg.adaptive_stddev:
             raise NotImplementedError("non-adaptive stddev parameterisation not built yet")
-        keys = sorted(obs_space.spaces.keys())
+        keys = sorted(k for k in obs_space.spaces.keys() if k != "action_mask")  # obs_space_without_action_mask
         if keys != ["obs"]:
-            raise NotImplementedError(f"single 'obs' key only, got {keys}")
+            raise NotImplementedError(f"single 'obs' key (+ optional 'action_mask') only, got {keys}")
         space = obs_space["obs"]
         self.obs_shape = tuple(space.shape)
         self.obs_u8 = np.dtype(space.dtype) == np.uint8
@@ -560,7 +560,7 @@ class ActorCritic:
         """Inference-style forward on a dense obs batch [B, ...]; returns dict(values, action_logits, new_rnn_states)
         (GPU tensors).  Sampling is a separate fused kernel (sf_sample_write_step) driven by the rollout runner."""
         obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
-        assert action_mask is None, "action masks are not supported by the native sampler yet"
+        # action masks only affect SAMPLING (actor_critic.py:169-181); the rollout runner hands them to the sampler kernel
         B = obs.shape[0]
         rnn = dict(states=rnn_states) if self.rnn_kind is not None else None
         heads = self.forward_heads(obs, B, sample_stride=self.obs_elems if obs.is_contiguous() else obs.stride(0),

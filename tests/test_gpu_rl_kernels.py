@@ -405,6 +405,34 @@ def test_lamb_step_vs_oracle(lib):
     assert np.array_equal(pd.cpu().numpy()[seg == 255], p[seg == 255])   # padding untouched
 
 
+def test_sample_masked_vs_oracle(lib, golden):
+    """action masks: kernel == oracle (actions exact), log-prob == the reference's masked_log_softmax gather, the
+    deterministic action is the argmax of the reference's masked probabilities; mask read through a row stride."""
+    g = golden("action_dist")
+    z, mask, probs, lps = g["mask_logits"], g["mask_mask"], g["mask_probs"], g["mask_log_probs"]
+    B, A = z.shape
+    T, t = 3, 1
+    heads = dev(np.concatenate([np.zeros((B, 1), np.float32), z], 1))
+    slab_mask = torch.zeros((B, T + 1, A), dtype=torch.uint8, device="cuda")
+    slab_mask[:, t] = dev(mask, torch.uint8)
+    zz = lambda *s: torch.full(s, -7.0, device="cuda")
+    ta, tl, tp, tv, tver = zz(B, T, 1), zz(B, T, A), zz(B, T), zz(B, T + 1), zz(B, T)
+    env_a = torch.zeros(B, dtype=torch.int32, device="cuda")
+    mview = slab_mask[:, t]
+    lib.sample_write_step_masked(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, mview, mview.stride(0), B, A, T, t, 9, 4, 2,
+                                 1.0, False, ta, tl, tp, tv, tver, env_a)
+    a_ref, lp_ref = oracle.sample_masked(z, mask, 9, 4, row0=2)
+    np.testing.assert_array_equal(env_a.cpu().numpy(), a_ref.astype(np.int32))
+    np.testing.assert_allclose(tp[:, t].cpu().numpy(), lp_ref, atol=3e-6)
+    ok = mask.sum(1) > 0
+    ai = a_ref.astype(int)
+    np.testing.assert_allclose(tp[:, t].cpu().numpy()[ok], lps[np.arange(B)[ok], ai[ok]], atol=3e-6)
+    np.testing.assert_array_equal(tl[:, t].cpu().numpy(), z)             # RAW logits are recorded
+    lib.sample_write_step_masked(heads[:, 1:], 1 + A, heads[:, 0], 1 + A, mview, mview.stride(0), B, A, T, t, 9, 4, 2,
+                                 1.0, True, ta, tl, tp, tv, tver, env_a)
+    np.testing.assert_array_equal(env_a.cpu().numpy()[ok], probs[ok].argmax(1).astype(np.int32))
+
+
 def test_sample_tuple_vs_oracle(lib):
     """Tuple of Discrete heads (TupleActionDistribution): per-head inverse-CDF sampling, log-prob = sum over heads;
     head 0 draws from the same Philox stream as the single-head sampler."""

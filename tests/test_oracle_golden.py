@@ -125,3 +125,24 @@ def test_minibatch_index_expansion(golden):
     starts = g["chunk_start_permutation"]
     full = (starts[:, None] + np.arange(rec)[None, :]).reshape(-1)
     np.testing.assert_array_equal(full.reshape(-1, bs), g["minibatches"])
+
+
+def test_masked_categorical_matches_reference(golden):
+    """obs["action_mask"]: the oracle's masked sampler draws only allowed actions, its log-prob is the reference's
+    masked_log_softmax at the drawn action, and the empirical frequencies follow the reference's masked_softmax."""
+    g = golden("action_dist")
+    z, mask, probs, logp = g["mask_logits"], g["mask_mask"], g["mask_probs"], g["mask_log_probs"]
+    N, A = z.shape
+    counts = np.zeros((N, A))
+    for step in range(400):
+        a, lp = oracle.sample_masked(z, mask, seed=3, step=step)
+        ai = a.astype(int)
+        rows = np.arange(N)
+        ok = mask.sum(1) > 0
+        assert mask[rows[ok], ai[ok]].all()                                  # never a masked-out action
+        np.testing.assert_allclose(lp[ok], logp[rows[ok], ai[ok]], atol=3e-6)
+        counts[rows, ai] += 1
+    freq = counts / 400.0
+    ok = mask.sum(1) > 0
+    assert np.abs(freq[ok] - probs[ok]).max() < 0.12                         # 400 draws: 4 sigma of p(1-p)/400
+    assert np.abs(freq[~ok] - 1.0 / A).max() < 0.12                           # all-masked rows: uniform fallback
