@@ -141,6 +141,7 @@ int sf_ppo_loss(const float *params, int ld_params, const float *values, int ld_
                 const float *old_logp, const float *old_params, const float *old_values, const float *adv,
                 const float *targets, const uint8_t *valids, const int32_t *index, int64_t offset, int64_t n, int A,
                 const sf_loss_cfg *h_cfg, const double *moments, double *sums, float *g_params, float *g_values,
+                float *ratio_out /* [n] clamped pi/pi_old per sample for the summaries (learner.py:886-903), or NULL */,
                 void *stream);
 /* out[0..3] = policy, exploration, kl, value losses; [4] kl mean; [5] kl max; [6] adv mean; [7] adv std;
  * [8] n_valid; [9] entropy (or symkl) mean — device float[16]. */

@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 2; }
+extern "C" int sf_abi_version(void) { return 3; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float *__restrict__ para
                                                   const int32_t *__restrict__ index, int64_t offset, int64_t n, int A,
                                                   LossDev h, const double *__restrict__ moments,
                                                   double *__restrict__ sums, float *__restrict__ g_params,
-                                                  float *__restrict__ g_values) {
+                                                  float *__restrict__ g_values, float *__restrict__ ratio_out) {
     __shared__ double lds[4 * 4];
     __shared__ float lds_max[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float *__restrict__ para
         }
         const float raw_ratio = expf(logp_a - old_logp[d]);
         const float ratio = clampf(raw_ratio, 0.05f, 20.0f);
+        if (ratio_out) ratio_out[i] = ratio;  // summaries (learner.py:886-903)
         const int64_t da = h.dense_adv ? i : d;
         const float advn = (adv[da] - adv_mean) / denom;
         const float clipped = clampf(ratio, h.clip_lo, h.clip_hi);
@@ -538,7 +539,8 @@ __global__ __launch_bounds__(256) void k_ppo_loss_md(const float *__restrict__ p
                                                      const int32_t *__restrict__ index, int64_t offset, int64_t n, int A,
                                                      LossDev h, const double *__restrict__ moments,
                                                      double *__restrict__ sums, float *__restrict__ g_params,
-                                                     float *__restrict__ g_values, int sym_pass) {
+                                                     float *__restrict__ g_values, float *__restrict__ ratio_out,
+                                                     int sym_pass) {
     __shared__ double lds[4 * 4];
     __shared__ float lds_max[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -588,6 +590,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_md(const float *__restrict__ p
         } else {
             const float raw_ratio = expf(logp_a - old_logp[d]);
             const float ratio = clampf(raw_ratio, 0.05f, 20.0f);
+            if (ratio_out) ratio_out[i] = ratio;
             const int64_t da = h.dense_adv ? i : d;
             const float advn = (adv[da] - adv_mean) / denom;
             const float clipped = clampf(ratio, h.clip_lo, h.clip_hi);
@@ -712,7 +715,8 @@ extern "C" int sf_ppo_loss(const float *params, int ld_params, const float *valu
                            const float *actions, const float *old_logp, const float *old_params,
                            const float *old_values, const float *adv, const float *targets, const uint8_t *valids,
                            const int32_t *index, int64_t offset, int64_t n, int A, const sf_loss_cfg *h_cfg,
-                           const double *moments, double *sums, float *g_params, float *g_values, void *stream) {
+                           const double *moments, double *sums, float *g_params, float *g_values, float *ratio_out,
+                           void *stream) {
     SF_REQUIRE(ld_params >= A && ld_values >= 1, "sf_ppo_loss: bad strides");
     SF_REQUIRE(params && values && actions && old_logp && old_params && old_values && adv && targets && valids &&
                    h_cfg && moments && sums && g_params && g_values,
@@ -739,12 +743,12 @@ extern "C" int sf_ppo_loss(const float *params, int ld_params, const float *valu
         if (h.expl_kind == 2) {
             k_ppo_loss_md<<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, old_params,
                                                               old_values, adv, targets, valids, index, offset, n, A, h, moments,
-                                                              sums, g_params, g_values, 1);
+                                                              sums, g_params, g_values, nullptr, 1);
             k_symkl_gate<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(sums, moments);
         }
         k_ppo_loss_md<<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, old_params,
                                                           old_values, adv, targets, valids, index, offset, n, A, h, moments, sums,
-                                                          g_params, g_values, 0);
+                                                          g_params, g_values, ratio_out, 0);
         return sf_launch_status("sf_ppo_loss");
     }
     if (h.expl_kind == 2) {
@@ -752,7 +756,7 @@ extern "C" int sf_ppo_loss(const float *params, int ld_params, const float *valu
         k_symkl_gate<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(sums, moments);
     }
     PL_DISPATCH(k_ppo_loss, params, ld_params, values, ld_values, actions, old_logp, old_params, old_values, adv, targets, valids, index,
-                offset, n, A, h, moments, sums, g_params, g_values);
+                offset, n, A, h, moments, sums, g_params, g_values, ratio_out);
 #undef PL_DISPATCH
     return sf_launch_status("sf_ppo_loss");
 }

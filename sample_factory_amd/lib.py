@@ -259,7 +259,7 @@ def vtrace(params, ld_params, values, ld_values, actions, old_logp, rewards, don
 
 
 def ppo_loss(params, ld_params, values, ld_values, actions, old_logp, old_params, old_values, adv, targets, valids,
-             index, offset, n, A, cfg: sf_loss_cfg, mom, sums, g_params, g_values) -> None:
+             index, offset, n, A, cfg: sf_loss_cfg, mom, sums, g_params, g_values, ratio_out=None) -> None:
     """params/values (and g_params/g_values) may be strided column views of one [n, ld] matrix."""
     _check(load().sf_ppo_loss(_raw(params, "f32", "params"), int(ld_params), _raw(values, "f32", "values"),
                               int(ld_values), ptr(actions, "f32", "actions"), ptr(old_logp, "f32", "old_logp"),
@@ -267,7 +267,8 @@ def ppo_loss(params, ld_params, values, ld_values, actions, old_logp, old_params
                               ptr(adv, "f32", "adv"), ptr(targets, "f32", "targets"), ptr(valids, "u8", "valids"),
                               ptr(index, "i32", "index"), i64(offset), i64(n), int(A), C.byref(cfg),
                               ptr(mom, "f64", "moments"), ptr(sums, "f64", "sums"), _raw(g_params, "f32", "g_params"),
-                              _raw(g_values, "f32", "g_values"), stream()), "sf_ppo_loss")
+                              _raw(g_values, "f32", "g_values"), ptr(ratio_out, "f32", "ratio_out"), stream()),
+           "sf_ppo_loss")
 
 
 def loss_scalars(sums, mom, cfg: sf_loss_cfg, out) -> None:

@@ -779,6 +779,19 @@ def test_end_to_end_rollout_and_train_small(lib):
     assert torch.isfinite(runner.learner.actor_critic.flat_params).all()
     assert not torch.equal(p0, runner.learner.actor_critic.flat_params)
     assert (tr["policy_version"] == 4.0).all()   # third rollout was collected by the policy after 2*2 SGD steps
+    # the reference's train/* summary set (learner.py:843-923), device-reduced, one readback
+    ts = stats["train"]
+    for k in ["lr", "actual_lr", "valids_fraction", "same_policy_fraction", "grad_norm", "loss", "value", "entropy",
+              "policy_loss", "kl_loss", "value_loss", "exploration_loss", "act_min", "act_max", "adv_min", "adv_max",
+              "adv_std", "adv_mean", "max_abs_logprob", "kl_divergence", "kl_divergence_max", "value_delta",
+              "value_delta_max", "fraction_clipped", "ratio_mean", "ratio_min", "ratio_max", "num_sgd_steps",
+              "adam_max_second_moment", "version_diff_avg", "version_diff_min", "version_diff_max"]:
+        assert k in ts and np.isfinite(ts[k]), k
+    assert ts["valids_fraction"] == 1.0 and ts["same_policy_fraction"] == 1.0 and ts["num_sgd_steps"] == 2
+    assert ts["ratio_min"] <= 1.0 <= ts["ratio_max"] and 0.0 <= ts["fraction_clipped"] <= 1.0 and ts["ratio_mean"] >= 0
+    assert 0 <= ts["act_min"] <= ts["act_max"] <= 5 and ts["adv_min"] <= ts["adv_mean"] <= ts["adv_max"]
+    assert ts["version_diff_min"] == ts["version_diff_max"] == 2.0     # data is two SGD steps old at the last minibatch
+    assert ts["grad_norm"] > 0 and ts["adam_max_second_moment"] > 0 and ts["value_delta_max"] >= ts["value_delta"]
     # rewards follow the env rule given the recorded actions (identical-rollout bookkeeping)
     import oracle
     step_last = 3 * 8 - 1
