@@ -23,6 +23,7 @@ the early-stop test / KL for the LR schedulers) instead of ~6 per minibatch.
 from __future__ import annotations
 
 import glob
+import time
 import os
 from os.path import join
 from typing import Dict, List, Optional, Tuple
@@ -528,9 +529,23 @@ class Learner:
                          kl_divergence_max=float(last[5]), adv_mean=float(last[6]), adv_std=float(last[7]),
                          entropy=float(last[9]), loss=float(last[0] + last[1] + last[2] + last[3]),
                          num_sgd_steps=num_sgd_steps)
-        stats.update(self._record_summaries(buff))
+        if self._should_save_summaries():  # learner.py:312-317: every 2 s early on, decaying to every 2 min
+            stats.update(self._record_summaries(buff))
+            self._last_summary_time = time.time()
         self.last_summary = stats
         return stats
+
+    _last_summary_time = 0.0
+
+    def _should_save_summaries(self) -> bool:
+        pts = [(0, 2.0), (100000, 60.0), (1000000, 120.0)]  # LinearDecay of learner.py:164 over train_step
+        s = float(self.train_step)
+        every = pts[-1][1]
+        for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+            if s <= x1:
+                every = y0 + (y1 - y0) * max(0.0, s - x0) / (x1 - x0)
+                break
+        return time.time() - self._last_summary_time >= every or getattr(self.cfg, "summaries_every_train", False)
 
     def _record_summaries(self, buff: AttrDict) -> Dict[str, float]:
         """The rest of learner.py:843-923 for the LAST minibatch of the call: ratio / clipping / value-delta statistics,

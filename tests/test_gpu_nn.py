@@ -765,7 +765,8 @@ def test_end_to_end_rollout_and_train_small(lib):
     cfg = default_cfg(env="synthetic_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
                       encoder_conv_architecture="convnet_atari", rollout=8, batch_size=256, num_batches_per_epoch=2,
                       num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=False, seed=1, serial_mode=True,
-                      synthetic_num_agents=64, exploration_loss_coeff=0.01, shuffle_minibatches=True)
+                      synthetic_num_agents=64, exploration_loss_coeff=0.01, shuffle_minibatches=True,
+                      summaries_every_train=True)
     cfg, runner = make_runner(cfg)
     runner.init()
     p0 = runner.learner.actor_critic.flat_params.clone()
