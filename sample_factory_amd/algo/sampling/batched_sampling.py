@@ -14,6 +14,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from sample_factory_amd import lib
@@ -50,6 +51,12 @@ class BatchedVectorEnvRunner:
         self.A = actor_critic.num_action_params
         self.ld = actor_critic.heads_ld
         self.continuous = is_box(self.env_info.action_space)  # Box(D): params = [means | log_std]
+        self.host_env = None
+        self._pin, self._pin_flip = {}, {}
+        self._act_event = torch.cuda.Event()
+        self._rew = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        self._term = torch.zeros(self.B, dtype=torch.bool, device=dev)
+        self._trunc = torch.zeros(self.B, dtype=torch.bool, device=dev)
         # obs["action_mask"] (inference_worker.py:324-331): kept in the slab like every other obs key, used by the sampler
         self.masked = "action_mask" in traj["obs"]
         if self.masked and (self.continuous or len(self.heads) != 1):
@@ -63,13 +70,43 @@ class BatchedVectorEnvRunner:
             self.env.reset_into(self.obs[:, 0])
         else:
             o, _ = self.env.reset()
+            first = o["obs"] if isinstance(o, dict) else o
+            self.host_env = not (isinstance(first, torch.Tensor) and first.is_cuda)
             self._store_obs(o, 0)
         self._started = True
 
+    # ---- host (CPU) envs: pinned staging, asynchronous H2D straight into the slab slot.  The only
+    # host sync of a step is the one the data dependency demands: the env needs the sampled actions.
+    def _pinned(self, key, shape, dtype, nbuf=1):
+        bufs = self._pin.get(key)
+        if bufs is None or bufs[0].shape != torch.Size(shape) or bufs[0].dtype != dtype:
+            bufs = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(nbuf)]
+            self._pin[key] = bufs
+        self._pin_flip[key] = (self._pin_flip.get(key, -1) + 1) % len(bufs)
+        return bufs[self._pin_flip[key]]
+
+    def _to_device(self, key, src, dst: torch.Tensor) -> None:
+        """dst (device view, e.g. slab[:, t]) <- src (device tensor | numpy / list from a host env)"""
+        if isinstance(src, torch.Tensor) and src.is_cuda:
+            dst.copy_(src)
+            return
+        a = np.asarray(src.cpu() if isinstance(src, torch.Tensor) else src)
+        stage = self._pinned(key, dst.shape, dst.dtype, nbuf=2)  # two buffers: the previous H2D may still be in flight
+        np.copyto(stage.numpy(), a.reshape(stage.shape), casting="unsafe")
+        dst.copy_(stage, non_blocking=True)
+
+    def _actions_to_host(self, env_actions: torch.Tensor):
+        """device actions -> pinned host array the env can read in place (ONE event wait)"""
+        stage = self._pinned("act", env_actions.shape, env_actions.dtype)
+        stage.copy_(env_actions, non_blocking=True)
+        self._act_event.record()
+        self._act_event.synchronize()
+        return stage.numpy()
+
     def _store_obs(self, o, t: int) -> None:
-        self.obs[:, t].copy_(torch.as_tensor(o["obs"] if isinstance(o, dict) else o, device=self.device))
+        self._to_device("obs", o["obs"] if isinstance(o, dict) else o, self.obs[:, t])
         if self.masked:
-            self.traj["obs"]["action_mask"][:, t].copy_(torch.as_tensor(o["action_mask"], device=self.device))
+            self._to_device("mask", o["action_mask"], self.traj["obs"]["action_mask"][:, t])
 
     def policy_version(self) -> float:
         return float(self.policy_versions[self.policy_id].item()) if self.policy_versions is not None else 0.0
@@ -105,11 +142,20 @@ class BatchedVectorEnvRunner:
             if self.zero_copy:
                 rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])
             else:
-                o, rew, term, trunc, _ = self.env.step(env_actions)
+                if self.host_env is None:  # decided by what reset() returned
+                    self.host_env = False
+                o, rew, term, trunc, _ = self.env.step(self._actions_to_host(env_actions) if self.host_env
+                                                       else env_actions)
                 self._store_obs(o, t + 1)
-                rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
-                term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()
-                trunc = torch.as_tensor(trunc, dtype=torch.bool, device=self.device).contiguous()
+                if self.host_env:
+                    self._to_device("rew", rew, self._rew)
+                    self._to_device("term", term, self._term)
+                    self._to_device("trunc", trunc, self._trunc)
+                    rew, term, trunc = self._rew, self._term, self._trunc
+                else:
+                    rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
+                    term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()
+                    trunc = torch.as_tensor(trunc, dtype=torch.bool, device=self.device).contiguous()
             lib.traj_write_env_step(rew, term, trunc, T, t, cfg.reward_scale, cfg.reward_clip, self.policy_id,
                                     tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
                                     self.ep_len, self.ep_stats)
