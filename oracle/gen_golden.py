@@ -348,15 +348,17 @@ def gen_prepare_and_losses():
         save("learner_" + var["name"], **arrays)
 
 
-def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1, use_rnn=False):
+def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1, use_rnn=False,
+              box_dims=0):
     cfg = make_cfg(list(model_args) + [f"--rollout={T}", f"--batch_size={E * T // nb}",
                                        f"--num_batches_per_epoch={nb}", f"--num_epochs={epochs}"] + list(extra),
                    use_rnn=use_rnn)
-    learner, env_info = make_learner(cfg, obs_space, gym.spaces.Discrete(A), E)
+    action_space = gym.spaces.Box(-1, 1, (box_dims,), np.float32) if box_dims else gym.spaces.Discrete(A)
+    learner, env_info = make_learner(cfg, obs_space, action_space, E)
     shapes = load_seeded(learner.actor_critic, seed=param_seed)
     g = torch.Generator().manual_seed(4242)
     b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
-    fill_batch(b, g, A, p_done=0.08, p_other_policy=0.05 if "inv" in name else 0.0)
+    fill_batch(b, g, A, continuous=bool(box_dims), p_done=0.08, p_other_policy=0.05 if "inv" in name else 0.0)
     arrays = {"ref": "sample_factory/algo/learning/learner.py:1036-1067 Learner.train (prepare_batch + _train: "
                      "losses, backward, clip_grad_norm_, torch.optim.Adam)", "argv": " ".join(list(model_args) + list(extra)),
               "param_seed": param_seed, "E": E, "T": T, "A": A, "num_batches": nb, "num_epochs": epochs,
@@ -520,6 +522,8 @@ def main():
         gen_train("mlp", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2)
         gen_train("mlp_inv", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=4, epochs=1, extra=["--kl_loss_coeff=0.1"])
         gen_train("mlp_lamb", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2, extra=["--optimizer=lamb"])
+        gen_train("mlp_nonadaptive", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2, box_dims=3,
+                  extra=["--adaptive_stddev=False", "--initial_stddev=0.7", "--kl_loss_coeff=0.1"])
         cnn_obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 36, 36), np.uint8)})
         gen_train("cnn36", cnn_obs, ["--encoder_conv_architecture=convnet_atari", "--nonlinearity=relu",
                                      "--obs_scale=255.0", "--normalize_input=False",

@@ -24,7 +24,7 @@ import torch
 
 from sample_factory_amd import lib
 from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
-from sample_factory_amd.envs.spaces import calc_num_action_parameters, is_discrete
+from sample_factory_amd.envs.spaces import is_box, calc_num_action_parameters, is_discrete
 
 ACT_KIND = {"relu": 1, "tanh": 2, "elu": 3}  # model/model_utils.py:27-35; fused into the GEMM epilogues
 
@@ -118,8 +118,13 @@ class ActorCritic:
         act = ACT_KIND[cfg.nonlinearity]
         if cfg.normalize_input and cfg.normalize_input_keys not in (None, [], ["obs"]):
             raise NotImplementedError("normalize_input_keys other than the 'obs' key")
-        if not is_discrete(action_space) and not cfg.adaptive_stddev:
-            raise NotImplementedError("non-adaptive stddev parameterisation not built yet")
+        # ActionParameterizationContinuousNonAdaptiveStddev (action_parameterization.py:42-78): the network outputs the
+        # means only, log-stddev is one learned vector.  In the fused heads GEMM the log-stddev columns keep ZERO weights
+        # (their weight gradient is discarded) and their BIAS is the learned vector, so params = [means | log_std] comes
+        # out of the same launch and the bias gradient (column sums) is exactly d loss / d learned_stddev.
+        self.nonadaptive_std = is_box(action_space) and not cfg.adaptive_stddev
+        if self.nonadaptive_std and cfg.continuous_tanh_scale > 0:
+            raise NotImplementedError("continuous_tanh_scale > 0")
         keys = sorted(k for k in obs_space.spaces.keys() if k != "action_mask")  # obs_space_without_action_mask
         if keys != ["obs"]:
             raise NotImplementedError(f"single 'obs' key (+ optional 'action_mask') only, got {keys}")
@@ -257,7 +262,9 @@ class ActorCritic:
         sd = {}
         for name, shape in self.ref_param_shapes():
             t = torch.empty(shape, dtype=torch.float32)
-            if name.startswith("core.core."):  # nn.GRU/nn.LSTM keep torch's default init (initialize_weights skips them)
+            if name.endswith("learned_stddev"):  # action_parameterization.py:58-60
+                t.fill_(math.log(cfg.initial_stddev))
+            elif name.startswith("core.core."):  # nn.GRU/nn.LSTM keep torch's default init (initialize_weights skips them)
                 bound = 1.0 / math.sqrt(self.rnn_H)
                 t.uniform_(-bound, bound)
             elif name.endswith(".bias"):
@@ -290,9 +297,14 @@ class ActorCritic:
             out.append((L.wname, tuple(L.ref_w_shape)))
             out.append((L.bname, (L.N,)))
         A, F = self.num_action_params, self.feat
-        out += [("critic_linear.weight", (1, F)), ("critic_linear.bias", (1,)),
-                ("action_parameterization.distribution_linear.weight", (A, F)),
-                ("action_parameterization.distribution_linear.bias", (A,))]
+        out += [("critic_linear.weight", (1, F)), ("critic_linear.bias", (1,))]
+        if self.nonadaptive_std:  # torch lists a module's own parameters before its children's
+            out += [("action_parameterization.learned_stddev", (A // 2,)),
+                    ("action_parameterization.distribution_linear.weight", (A // 2, F)),
+                    ("action_parameterization.distribution_linear.bias", (A // 2,))]
+        else:
+            out += [("action_parameterization.distribution_linear.weight", (A, F)),
+                    ("action_parameterization.distribution_linear.bias", (A,))]
         return out
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -308,8 +320,11 @@ class ActorCritic:
         w = H.w.detach().cpu()
         sd["critic_linear.weight"] = w[:, 0:1].t().contiguous()
         sd["critic_linear.bias"] = H.b.detach().cpu()[0:1].clone()
-        sd["action_parameterization.distribution_linear.weight"] = w[:, 1:1 + A].t().contiguous()
-        sd["action_parameterization.distribution_linear.bias"] = H.b.detach().cpu()[1:1 + A].clone()
+        Aw = A // 2 if self.nonadaptive_std else A  # columns the network really produces
+        sd["action_parameterization.distribution_linear.weight"] = w[:, 1:1 + Aw].t().contiguous()
+        sd["action_parameterization.distribution_linear.bias"] = H.b.detach().cpu()[1:1 + Aw].clone()
+        if self.nonadaptive_std:
+            sd["action_parameterization.learned_stddev"] = H.b.detach().cpu()[1 + Aw:1 + A].clone()
         return sd
 
     def load_state_dict(self, sd, strict=True):
@@ -321,10 +336,14 @@ class ActorCritic:
             cw = torch.as_tensor(sd["critic_linear.weight"], dtype=torch.float32)
             aw = torch.as_tensor(sd["action_parameterization.distribution_linear.weight"], dtype=torch.float32)
             pad = self.heads_ld - 1 - A
+            ab = torch.as_tensor(sd["action_parameterization.distribution_linear.bias"], dtype=torch.float32).reshape(-1)
+            if self.nonadaptive_std:  # log-stddev columns: zero weights, bias = the learned vector
+                aw = torch.cat([aw, torch.zeros((A // 2, self.feat))], dim=0)
+                ab = torch.cat([ab, torch.as_tensor(sd["action_parameterization.learned_stddev"],
+                                                    dtype=torch.float32).reshape(-1)])
             H.w.copy_(torch.cat([cw, aw, torch.zeros((pad, self.feat))], dim=0).t().contiguous())
-            H.b.copy_(torch.cat([torch.as_tensor(sd["critic_linear.bias"], dtype=torch.float32).reshape(1),
-                                 torch.as_tensor(sd["action_parameterization.distribution_linear.bias"],
-                                                 dtype=torch.float32).reshape(-1), torch.zeros(pad)]))
+            H.b.copy_(torch.cat([torch.as_tensor(sd["critic_linear.bias"], dtype=torch.float32).reshape(1), ab,
+                                 torch.zeros(pad)]))
             self.params_changed()
             if self.obs_normalizer is not None and "obs_normalizer.running_mean_std.running_mean_std.obs.count" in sd:
                 self.obs_normalizer.load_state_dict(sd)
@@ -345,8 +364,11 @@ class ActorCritic:
         b = flat[ob:ob + H.N].cpu()
         out["critic_linear.weight"] = w[:, 0:1].t().contiguous()
         out["critic_linear.bias"] = b[0:1].clone()
-        out["action_parameterization.distribution_linear.weight"] = w[:, 1:1 + A].t().contiguous()
-        out["action_parameterization.distribution_linear.bias"] = b[1:1 + A].clone()
+        Aw = A // 2 if self.nonadaptive_std else A
+        out["action_parameterization.distribution_linear.weight"] = w[:, 1:1 + Aw].t().contiguous()
+        out["action_parameterization.distribution_linear.bias"] = b[1:1 + Aw].clone()
+        if self.nonadaptive_std:
+            out["action_parameterization.learned_stddev"] = b[1 + Aw:1 + A].clone()
         return out
 
     # ------------------------------------------------------------------------------------------ compute
@@ -378,13 +400,16 @@ class ActorCritic:
         H, (o, ob), A = self.layers[-1], self._segs[-1], self.num_action_params
         hw = torch.full((H.K, H.N), 255, dtype=torch.uint8)
         hw[:, 0] = nseg          # critic_linear.weight
-        hw[:, 1:1 + A] = nseg + 2  # distribution_linear.weight
+        Aw = A // 2 if self.nonadaptive_std else A
+        hw[:, 1:1 + Aw] = nseg + 2  # distribution_linear.weight (the frozen zero columns of learned_stddev stay 255)
         seg[o:o + H.K * H.N] = hw.reshape(-1)
         hb = torch.full((H.N,), 255, dtype=torch.uint8)
-        hb[0] = nseg + 1         # critic_linear.bias
-        hb[1:1 + A] = nseg + 3   # distribution_linear.bias
+        hb[0] = nseg + 1          # critic_linear.bias
+        hb[1:1 + Aw] = nseg + 3   # distribution_linear.bias
+        if self.nonadaptive_std:
+            hb[1 + Aw:1 + A] = nseg + 4  # learned_stddev
         seg[ob:ob + H.N] = hb
-        return seg.to(self.device), nseg + 4
+        return seg.to(self.device), nseg + (5 if self.nonadaptive_std else 4)
 
     def params_changed(self) -> None:
         """call after ANY write to flat_params (optimiser step, load_state_dict, broadcast): refresh derived copies"""
@@ -606,3 +631,6 @@ class ActorCritic:
                     gs = self._buf(("g", "x_sm"), (n, L.K))
                     gs.view(Cn, R, L.K).copy_(g.view(R, Cn, L.K).transpose(0, 1))
                     g = gs
+            if self.nonadaptive_std and li == len(self.layers) - 1:
+                A = self.num_action_params  # the log-stddev columns have no weights in the reference: keep them at zero
+                L.gw[:, 1 + A // 2:1 + A].zero_()
