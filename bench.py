@@ -94,17 +94,23 @@ def main():
     warm_prof = None
     if args.warmup > 0:
         if not args.no_kernel_events:
-            lib.PROFILE = {}
+            lib.PROFILE, lib.PROFILE_SYNC = {}, True  # ranking pass: every launch timed in isolation
         runner.iteration()
         torch.cuda.synchronize()
-        warm_prof, lib.PROFILE = lib.PROFILE, None
+        warm_prof, lib.PROFILE, lib.PROFILE_SYNC = lib.PROFILE, None, False
     if not args.no_kernel_events:
         if not warm_prof:
             raise SystemExit("need --warmup >= 1 to rank kernels (or pass --no_kernel_events)")
         # "kernel" = one instantiation (key[-1], the name rocprofv3 prints), summed over the shapes it is launched at
+        # robust total per shape = median launch time x launches: a single launch that happens to bracket a one-off
+        # host-side stall (allocator growth, lazy code-object load) must not decide which kernel is "dominant"
+        def robust_total(evs):
+            ms = sorted(s_.elapsed_time(e_) for s_, e_ in evs)
+            return ms[len(ms) // 2] * len(ms)
+
         by_name = {}
         for key, evs in warm_prof.items():
-            by_name[key[-1]] = by_name.get(key[-1], 0.0) + sum(s_.elapsed_time(e_) for s_, e_ in evs)
+            by_name[key[-1]] = by_name.get(key[-1], 0.0) + robust_total(evs)
         dominant = max(by_name, key=by_name.get)
         lib.PROFILE, lib.PROFILE_ONLY = {}, {key for key in warm_prof if key[-1] == dominant}
     barrier()
@@ -148,8 +154,9 @@ def main():
             traffic, traffic_src = ent["hbm_bytes"], "profiles/r01_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
     kern = []  # ranking of all network kernels from the instrumented warm-up step (NOT the timed region)
     for k2, evs2 in warm_prof.items():
-        m2 = [s_.elapsed_time(e_) for s_, e_ in evs2]
-        kern.append((sum(m2), k2, len(m2), sum(m2) / len(m2)))
+        m2 = sorted(s_.elapsed_time(e_) for s_, e_ in evs2)
+        med = m2[len(m2) // 2]
+        kern.append((med * len(m2), k2, len(m2), med))
     kern.sort(reverse=True, key=lambda k: k[0])
     roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -173,7 +180,7 @@ def main():
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
                    "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},
         "roofline": roofline,
-        "network_kernels": {"source": "instrumented warm-up step (every launch timed; not the timed region)",
+        "network_kernels": {"source": "instrumented warm-up step (every launch timed in isolation; not the timed region)",
                             "ms_per_step": round(net_ms, 2), "tflops_avg": round(net_flops / (net_ms * 1e-3) / 1e12, 2),
                             "top": breakdown},
     }

@@ -51,6 +51,9 @@ _lib: Optional[C.CDLL] = None
 # torch's CURRENT stream, which is the stream every call below launches on.  PROFILE maps key -> [(start, end), ...].
 PROFILE: Optional[dict] = None
 PROFILE_ONLY: Optional[set] = None  # when set, only these keys are timed (bench: the dominant kernel only)
+PROFILE_SYNC = False  # ranking pass: drain the device before every timed launch, so that an event pair brackets the
+#                       kernel alone (with every launch instrumented the host falls behind and queueing delays would be
+#                       charged to whatever small kernel happens to be launched next)
 
 
 class _timed:
@@ -62,6 +65,8 @@ class _timed:
         if self.key is not None:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
+            if PROFILE_SYNC:
+                torch.cuda.synchronize()
             self.s.record()
         return self
 
