@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
                 for (int tn = 0; tn < TN; ++tn) {
                     const bool ok = rc < slim && ccol + tn * 32 < Cin;
                     const uint32_t o = obase + pix + (uint32_t)rc * sstride + (uint32_t)(tn * 32);
-                    actv[tm][tn][r] = in_act[ok ? o : obase];
+                    actv[tm][tn][r] = in_act[ok ? o : 0u];  // rows past the last sample: any valid address
                 }
             }
     };

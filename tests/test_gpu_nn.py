@@ -157,6 +157,65 @@ def test_glds_fwd_dgrad_large_grids_vs_torch(lib, geom, n):
     assert (db.cpu() - br.grad).abs().max().item() < 2e-4 * max(1.0, br.grad.abs().max().item()), "bgrad"
 
 
+def test_glds_kernels_geometry_fuzz(lib):
+    """random conv geometries through the large-grid dispatch of forward (sf_conv_fwd_t), weight gradient and data
+    gradient (pixel-major for stride 1 / odd kernels, stride-group row-walking when KH, KW, W are multiples of S) vs
+    torch; sizes chosen so that every LDS-DMA kernel is actually selected."""
+    rng = np.random.default_rng(2024)
+    cases = 0
+    while cases < 14:
+        Cin, Cout = int(rng.choice([32, 64, 96])), int(rng.choice([32, 64, 96, 160]))
+        K, S = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+        H, W = int(rng.integers(K, K + 9)), int(rng.integers(K, K + 9))
+        if cases % 3 == 0 and S > 1:  # make some cases hit the stride-group kernel
+            K, W = S * int(rng.integers(1, 3)), S * int(rng.integers(2, 6))
+            H = max(H, K)
+            W = max(W, K)
+        OH, OW = (H - K) // S + 1, (W - K) // S + 1
+        if OH < 1 or OW < 1:
+            continue
+        n = int(max(1100, -(-140000 // (OH * OW))))
+        if n * H * W * Cin > 6e7:
+            continue
+        cases += 1
+        g = torch.Generator().manual_seed(cases)
+        x = torch.randn((n, Cin, H, W), generator=g)
+        d = desc(lib, Cin, H, W, Cout, K, S)
+        x_dev = x.permute(0, 2, 3, 1).contiguous().cuda()
+        w_ref = torch.randn((Cout, Cin, K, K), generator=g) / np.sqrt(Cin * K * K)
+        b = torch.randn(Cout, generator=g) * 0.1
+        wk = to_kmajor(w_ref, 0).cuda()
+        tag = f"Cin={Cin} H={H} W={W} Cout={Cout} K={K} S={S} n={n}"
+        print("fuzz case", cases, tag, flush=True)
+        xr, wr, br = x.clone().requires_grad_(True), w_ref.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        pre = F.conv2d(xr, wr, br, stride=S)
+        out = torch.empty((n * OH * OW, Cout), device="cuda")
+        if lib.conv_fwd_t_supported(n, d):
+            wt = torch.empty((Cout, K * K * Cin), device="cuda")
+            lib.transpose(wk, wt, K * K * Cin, Cout)
+            lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d)
+        else:
+            lib.conv_fwd(x_dev, Cin * H * W, None, 0, wk, b.cuda(), out, n, d)
+        ref = F.relu(pre).detach()
+        got = out.view(n, OH, OW, Cout).permute(0, 3, 1, 2).cpu()
+        assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), "fwd " + tag
+        dy = torch.randn((n, Cout, OH, OW), generator=g)
+        dy_dev = dy.permute(0, 2, 3, 1).contiguous().cuda().view(n * OH * OW, Cout)
+        pre.backward(dy)
+        din = torch.full((n, H, W, Cin), 7.0, device="cuda")
+        lib.conv_dgrad(dy_dev, wk, x_dev, din, n, d)
+        dref = (xr.grad * (x > 0)).permute(0, 2, 3, 1)
+        s_ = dref.abs().max().item() + 1e-6
+        assert (din.cpu() - dref).abs().max().item() < 3e-5 * max(1.0, s_), "dgrad " + tag
+        dw, db = torch.zeros_like(wk), torch.zeros(Cout, device="cuda")
+        ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+        lib.conv_wgrad(x_dev, Cin * H * W, None, 0, dy_dev, dw, db, n, d, ws)
+        dw_got = from_kmajor(dw.cpu(), Cout, Cin, K, K, 0)
+        sw = wr.grad.abs().max().item() + 1e-6
+        assert (dw_got - wr.grad).abs().max().item() < 3e-4 * max(1.0, sw), "wgrad " + tag
+        assert (db.cpu() - br.grad).abs().max().item() < 3e-4 * max(1.0, br.grad.abs().max().item()), "bgrad " + tag
+
+
 @pytest.mark.parametrize("geom,n,mean", [((4, 84, 84, 32, 8, 4), 515, 3.0), ((4, 84, 84, 32, 8, 4), 300, 0.0),
                                          ((4, 36, 36, 32, 8, 4), 1001, 0.0), ((4, 84, 84, 24, 8, 4), 258, 1.5)])
 def test_conv1_lds_image_kernel_vs_torch(lib, geom, n, mean):
