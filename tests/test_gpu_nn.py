@@ -338,6 +338,47 @@ def test_conv1_reads_slab_in_place(lib):
     assert torch.equal(out5, out6)
 
 
+def test_conv1_strip_image_kernels_read_slab_in_place(lib):
+    """the same exactness contract for the 84x84 strip-image kernels (forward AND weight gradient, n >= 256): index
+    gather + dataset->slab row mapping, contiguous offset slices and the strided slab[:, t] view are bit-identical to
+    a dense gathered copy."""
+    E, T, n = 40, 8, 300
+    g = torch.Generator().manual_seed(11)
+    slab = torch.randint(0, 256, (E, T + 1, 4, 84, 84), generator=g, dtype=torch.uint8).cuda()
+    idx = torch.randperm(E * T, generator=g)[:n].to(torch.int32).cuda()
+    inv = float(np.float32(1 / 255.0))
+    d = desc(lib, 4, 84, 84, 32, 8, 4, in_u8=1, inv_scale=inv, traj_T=T)
+    d0 = desc(lib, 4, 84, 84, 32, 8, 4, in_u8=1, inv_scale=inv)
+    w = (torch.randn((256, 32), generator=g) / 16).cuda()
+    b = torch.randn(32, generator=g).cuda()
+    S = 4 * 84 * 84
+    out1 = torch.empty((n * 400, 32), device="cuda")
+    lib.conv_fwd(slab, S, idx, 0, w, b, out1, n, d)
+    e, t = idx.long() // T, idx.long() % T
+    dense = slab[e, t].contiguous()
+    out2 = torch.empty_like(out1)
+    lib.conv_fwd(dense, S, None, 0, w, b, out2, n, d0)
+    assert torch.equal(out1, out2)
+    out3 = torch.empty((264 * 400, 32), device="cuda")
+    lib.conv_fwd(slab, S, None, 8, w, b, out3, 264, d)
+    ii = torch.arange(8, 272)
+    out4 = torch.empty_like(out3)
+    lib.conv_fwd(slab[ii // T, ii % T].contiguous(), S, None, 0, w, b, out4, 264, d0)
+    assert torch.equal(out3, out4)
+    big = torch.randint(0, 256, (256, 3, 4, 84, 84), generator=g, dtype=torch.uint8).cuda()
+    out5 = torch.empty((256 * 400, 32), device="cuda")
+    lib.conv_fwd(big[:, 1], big.stride(0), None, 0, w, b, out5, 256, d0)       # rollout-style strided view
+    out6 = torch.empty_like(out5)
+    lib.conv_fwd(big[:, 1].contiguous(), S, None, 0, w, b, out6, 256, d0)
+    assert torch.equal(out5, out6)
+    dy = torch.randn((n * 400, 32), generator=g).cuda()
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    dw1, db1, dw2, db2 = torch.zeros_like(w), torch.zeros(32, device="cuda"), torch.zeros_like(w), torch.zeros(32, device="cuda")
+    lib.conv_wgrad(slab, S, idx, 0, dy, dw1, db1, n, d, ws)
+    lib.conv_wgrad(dense, S, None, 0, dy, dw2, db2, n, d0, ws)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
 def make_model(cfg_over, obs_shape, A):
     from sample_factory_amd.cfg.arguments import default_cfg
     from sample_factory_amd.envs import spaces
