@@ -191,6 +191,7 @@ class Learner:
         self.exp_avg = torch.zeros(P, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=self.device)
         self.adam_step_count = 0
+        self._dp_reduce_each_mb = True
         self._lamb = None  # (segment ids, #segments, direction scratch, per-segment sums) — built on first use
         # small device scratch
         dev = self.device
@@ -450,7 +451,7 @@ class Learner:
                      adv_arr, tgt_arr, buff.valids, index, offset, n, A, self.loss_cfg, self._moments, self._sums,
                      g_heads[:, 1:], g_heads[:, 0], ratio_out=self._ratio)
         self._last_mb = (index, offset, n, values, adv_arr)  # for _record_summaries
-        if self.world > 1:
+        if self.world > 1 and self._dp_reduce_each_mb:  # only the per-minibatch KL-adaptive LR needs global values NOW
             self.group.loss_sums(self._sums)
         out = scalars_out if scalars_out is not None else torch.zeros(16, dtype=torch.float32, device=self.device)
         lib.loss_scalars(self._sums, self._moments, self.loss_cfg, out)
@@ -468,6 +469,7 @@ class Learner:
         self._scalars = torch.zeros((cfg.num_epochs * n_mb, 16), dtype=torch.float32, device=self.device)
         global_size = experience_size * self.world
         need_kl_each_mb = self.lr_scheduler.invoke_after_each_minibatch() and isinstance(self.lr_scheduler, KlAdaptiveScheduler)
+        self._dp_reduce_each_mb = need_kl_each_mb
         self._grad_norms = []
         for epoch in range(cfg.num_epochs):
             minibatches = self._get_minibatches(batch_size, experience_size)
@@ -512,7 +514,18 @@ class Learner:
                 # K20: same-process inference reads the same flat buffer in stream order; publishing = version bump
                 self.policy_versions_tensor[self.policy_id] = self.train_step
             # ---- end of epoch: ONE readback (actor losses for early stopping, KLs for the per-epoch scheduler)
-            rows = self._scalars[epoch * n_mb:(epoch + 1) * n_mb].cpu()
+            blk = self._scalars[epoch * n_mb:(epoch + 1) * n_mb]
+            if self.world > 1 and not need_kl_each_mb:
+                # data-parallel: every replica divided its LOCAL sums by the GLOBAL n, so the loss / KL / entropy means
+                # add up across ranks; one all-reduce per epoch instead of two per SGD step (max KL: MAX)
+                cols = [0, 1, 2, 3, 4, 9]
+                add = blk[:, cols].contiguous()
+                self._all_reduce(add)
+                blk[:, cols] = add
+                mx = blk[:, 5].contiguous()
+                self.group.all_reduce_max(mx)
+                blk[:, 5] = mx
+            rows = blk.cpu()
             actor_losses = (rows[:, 0] + rows[:, 1] + rows[:, 2]).double().numpy()
             if not need_kl_each_mb:
                 recent_kls.extend(rows[:, 4].double().tolist())

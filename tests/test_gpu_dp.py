@@ -58,6 +58,9 @@ def test_two_replicas_equal_one(tmp_path):
     assert int(r[0]["env_steps"]) == single["env_steps"] == 3 * 64 * 8           # whole-job step accounting
     np.testing.assert_array_equal(r[0]["params"], r[1]["params"])                  # replicas stay in lock-step
     np.testing.assert_array_equal(r[0]["rms"], r[1]["rms"])
+    # loss scalars are all-reduced once per epoch (each replica divides its local sums by the GLOBAL n)
+    assert float(r[0]["loss"]) == float(r[1]["loss"])
+    assert abs(float(r[0]["loss"]) - single["loss"]) < 2e-3 * max(1.0, abs(single["loss"]))
     # identical rollouts (integer actions exact) — requires identical weights after every SGD step, up to sampling
     # thresholds; compare the LAST rollout's actions of the shards with the single run
     acts = np.concatenate([r[0]["actions"], r[1]["actions"]])
