@@ -38,11 +38,12 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step", "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs", "sf_synth_step",
-    "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad", "sf_conv_dgrad", "sf_conv_kernel_name",
-    "sf_conv_fwd_t_supported", "sf_conv_fwd_t", "sf_transpose",
-    "sf_linear_fwd",
-    "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale",
+    "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
+    "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
+    "sf_synth_step", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
+    "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t", "sf_transpose",
+    "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -389,10 +390,10 @@ def conv_fwd_workspace(n, desc: sf_conv_desc) -> int:
 def conv_fwd_raw(inp, in_sample_stride, index, offset, w, bias, out, n, desc: sf_conv_desc, workspace=None) -> None:
     """`inp` may be a strided view (e.g. slab[:, t]); its data_ptr is sample 0, samples are in_sample_stride apart."""
     with _timed(_dkey("fwd", n, desc)):
-      _check(load().sf_conv_fwd(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
-                              i64(offset), ptr(w, "f32", "w"), ptr(bias, "f32", "bias"), ptr(out, "f32", "out"),
-                              i64(n), C.byref(desc), ptr(workspace, "u8", "workspace"),
-                              i64(workspace.numel() if workspace is not None else 0), stream()), "sf_conv_fwd")
+        _check(load().sf_conv_fwd(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
+                                i64(offset), ptr(w, "f32", "w"), ptr(bias, "f32", "bias"), ptr(out, "f32", "out"),
+                                i64(n), C.byref(desc), ptr(workspace, "u8", "workspace"),
+                                i64(workspace.numel() if workspace is not None else 0), stream()), "sf_conv_fwd")
 
 
 def conv_wgrad_workspace(n, desc: sf_conv_desc) -> int:
@@ -401,15 +402,15 @@ def conv_wgrad_workspace(n, desc: sf_conv_desc) -> int:
 
 def conv_wgrad_raw(inp, in_sample_stride, index, offset, dout, dw, db, n, desc: sf_conv_desc, workspace) -> None:
     with _timed(_dkey("wgrad", n, desc)):
-      _check(load().sf_conv_wgrad(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
-                                i64(offset), ptr(dout, "f32", "dout"), ptr(dw, "f32", "dw"), ptr(db, "f32", "db"),
-                                i64(n), C.byref(desc), ptr(workspace, "u8", "workspace"), stream()), "sf_conv_wgrad")
+        _check(load().sf_conv_wgrad(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
+                                  i64(offset), ptr(dout, "f32", "dout"), ptr(dw, "f32", "dw"), ptr(db, "f32", "db"),
+                                  i64(n), C.byref(desc), ptr(workspace, "u8", "workspace"), stream()), "sf_conv_wgrad")
 
 
 def conv_dgrad(dout, w, in_act, din, n, desc: sf_conv_desc) -> None:
     with _timed(_dkey("dgrad", n, desc)):
-      _check(load().sf_conv_dgrad(ptr(dout, "f32", "dout"), ptr(w, "f32", "w"), ptr(in_act, "f32", "in_act"),
-                                ptr(din, "f32", "din"), i64(n), C.byref(desc), stream()), "sf_conv_dgrad")
+        _check(load().sf_conv_dgrad(ptr(dout, "f32", "dout"), ptr(w, "f32", "w"), ptr(in_act, "f32", "in_act"),
+                                  ptr(din, "f32", "din"), i64(n), C.byref(desc), stream()), "sf_conv_dgrad")
 
 
 def conv_fwd_t_supported(n, desc: sf_conv_desc) -> bool:
