@@ -107,7 +107,8 @@ int sf_rows_add_scale(const float *a, const float *b, const float *keep, int64_t
 int sf_vtrace(const float *params, int ld_params, const float *values, int ld_values, const float *actions,
               const float *old_logp, const float *rewards, const uint8_t *dones, const int32_t *index, int64_t offset,
               int64_t n, int A, int action_kind, int recurrence, float gamma, float rho_hat, float c_hat, float *vs,
-              float *adv, void *stream);
+              float *adv, const int32_t *head_n /* host; Tuple of Discrete heads, or NULL */, int num_heads,
+              void *stream);
 
 /* ---- K16: PPO loss head, forward + backward ----------------------------------------------------------------
  * learner.py:586-669 (ratio, clamp [0.05,20], per-minibatch advantage normalisation, clipped surrogate, entropy /

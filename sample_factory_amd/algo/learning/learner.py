@@ -305,8 +305,7 @@ class Learner:
             exploration_kind=0 if cfg.exploration_loss_coeff == 0.0 else (1 if cfg.exploration_loss == "entropy" else 2),
             action_kind=1 if is_box(self.env_info.action_space) else 0, dense_adv=int(bool(cfg.with_vtrace)))
         heads = action_head_sizes(self.env_info.action_space)
-        if len(heads) > 1 and cfg.with_vtrace:
-            raise NotImplementedError("with_vtrace together with a Tuple action space")
+        self._head_sizes = heads
         if len(heads) > 1:  # Tuple of Discrete spaces: independent categorical heads
             self.loss_cfg.num_heads = len(heads)
             for i, nh in enumerate(heads):
@@ -435,7 +434,7 @@ class Learner:
             adv = ac._buf(("vt", "adv"), (n,))
             lib.vtrace(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.rewards, buff.dones, index,
                        offset, n, A, self.loss_cfg.action_kind, cfg.recurrence, cfg.gamma, cfg.vtrace_rho,
-                       cfg.vtrace_c, vs, adv)
+                       cfg.vtrace_c, vs, adv, head_sizes=self._head_sizes)
             valid_dense = buff.valids[index.long()] if index is not None else buff.valids[offset:offset + n]
             lib.moments(adv, valid_dense.contiguous(), None, n, self._moments)
             adv_arr, tgt_arr = adv, vs

@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 3; }
+extern "C" int sf_abi_version(void) { return 4; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -273,6 +273,25 @@ __device__ __forceinline__ float action_logp(const float *__restrict__ z, int A,
 }
 
 // =========================================================================================== K17 V-trace
+struct HeadsDev {
+    int num_heads, head_n[8];
+};
+// log-prob of a Tuple-of-Discrete action: sum over the heads of log_softmax(z_h)[a_h]
+__device__ __forceinline__ float tuple_logp(const float *__restrict__ z, const float *__restrict__ act, const HeadsDev &hd) {
+    float lp = 0.f;
+    int off = 0;
+    for (int h = 0; h < hd.num_heads; ++h) {
+        const int nh = hd.head_n[h];
+        float mx = -INFINITY;
+        for (int k = 0; k < nh; ++k) mx = fmaxf(mx, z[off + k]);
+        float se = 0.f;
+        for (int k = 0; k < nh; ++k) se += expf(z[off + k] - mx);
+        lp += (z[off + (int)act[h]] - mx) - logf(se);
+        off += nh;
+    }
+    return lp;
+}
+
 template <int MAXA>
 __global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params, int ldp,
                                                const float *__restrict__ values, int ldv,
@@ -280,10 +299,10 @@ __global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params,
                                                const float *__restrict__ rewards, const uint8_t *__restrict__ dones,
                                                const int32_t *__restrict__ index, int64_t offset, int64_t ntraj, int A,
                                                int action_kind, int rec, float gamma, float rho_hat, float c_hat,
-                                               float *__restrict__ vs, float *__restrict__ adv) {
+                                               float *__restrict__ vs, float *__restrict__ adv, HeadsDev hd) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ntraj) return;
-    const int nact = action_kind == 0 ? 1 : A / 2;
+    const int nact = hd.num_heads > 1 ? hd.num_heads : (action_kind == 0 ? 1 : A / 2);
     const int64_t base = j * rec;
     const int64_t last = base + rec - 1;
     const int64_t dl = index ? (int64_t)index[last] : offset + last;
@@ -292,7 +311,8 @@ __global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params,
     for (int i = rec - 1; i >= 0; --i) {
         const int64_t k = base + i;
         const int64_t d = index ? (int64_t)index[k] : offset + k;
-        const float lp = action_logp<MAXA>(params + k * ldp, A, action_kind, actions + d * nact);
+        const float lp = hd.num_heads > 1 ? tuple_logp(params + k * ldp, actions + d * nact, hd)
+                                          : action_logp<MAXA>(params + k * ldp, A, action_kind, actions + d * nact);
         const float ratio = clampf(expf(lp - old_logp[d]), 0.05f, 20.0f);  // learner.py:591-594
         const float rho = fminf(rho_hat, ratio), c = fminf(c_hat, ratio);
         const float not_done = 1.0f - (dones[d] ? 1.0f : 0.0f);
@@ -309,8 +329,17 @@ __global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params,
 extern "C" int sf_vtrace(const float *params, int ld_params, const float *values, int ld_values,
                          const float *actions, const float *old_logp, const float *rewards, const uint8_t *dones,
                          const int32_t *index, int64_t offset, int64_t n, int A, int action_kind, int recurrence,
-                         float gamma, float rho_hat, float c_hat, float *vs, float *adv, void *stream) {
+                         float gamma, float rho_hat, float c_hat, float *vs, float *adv, const int32_t *head_n,
+                         int num_heads, void *stream) {
     SF_REQUIRE(ld_params >= A && ld_values >= 1, "sf_vtrace: bad strides");
+    HeadsDev hd = {};
+    if (head_n && num_heads > 1) {
+        SF_REQUIRE(num_heads <= 8 && action_kind == 0, "sf_vtrace: at most 8 Discrete heads");
+        int tot = 0;
+        hd.num_heads = num_heads;
+        for (int i = 0; i < num_heads; ++i) { hd.head_n[i] = head_n[i]; tot += head_n[i]; }
+        SF_REQUIRE(tot == A, "sf_vtrace: head sizes sum to %d, A = %d", tot, A);
+    }
     SF_REQUIRE(params && values && actions && old_logp && rewards && dones && vs && adv, "sf_vtrace: null pointer");
     SF_REQUIRE(recurrence > 0 && n % recurrence == 0, "sf_vtrace: n=%lld not a multiple of recurrence=%d",
                (long long)n, recurrence);
@@ -322,7 +351,7 @@ extern "C" int sf_vtrace(const float *params, int ld_params, const float *values
 #define VT_LAUNCH(M)                                                                                             \
     k_vtrace<M><<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, rewards, dones, index,    \
                                                     offset, ntraj, A, action_kind, recurrence, gamma, rho_hat,   \
-                                                    c_hat, vs, adv)
+                                                    c_hat, vs, adv, hd)
     if (A <= 8) VT_LAUNCH(8);
     else if (A <= 32) VT_LAUNCH(32);
     else VT_LAUNCH(128);

@@ -255,13 +255,15 @@ def rows_add_scale(a, b, keep, Cn, H, y) -> None:
 
 
 def vtrace(params, ld_params, values, ld_values, actions, old_logp, rewards, dones, index, offset, n, A, action_kind,
-           recurrence, gamma, rho_hat, c_hat, vs, adv) -> None:
+           recurrence, gamma, rho_hat, c_hat, vs, adv, head_sizes=None) -> None:
+    hn = (C.c_int32 * 8)(*[int(x) for x in head_sizes]) if head_sizes and len(head_sizes) > 1 else None
     _check(load().sf_vtrace(_raw(params, "f32", "params"), int(ld_params), _raw(values, "f32", "values"),
                             int(ld_values), ptr(actions, "f32", "actions"),
                             ptr(old_logp, "f32", "old_logp"), ptr(rewards, "f32", "rewards"), ptr(dones, "u8", "dones"),
                             ptr(index, "i32", "index"), i64(offset), i64(n), int(A), int(action_kind),
                             int(recurrence), f(gamma), f(rho_hat), f(c_hat), ptr(vs, "f32", "vs"),
-                            ptr(adv, "f32", "adv"), stream()), "sf_vtrace")
+                            ptr(adv, "f32", "adv"), hn, len(head_sizes) if hn is not None else 0, stream()),
+           "sf_vtrace")
 
 
 def ppo_loss(params, ld_params, values, ld_values, actions, old_logp, old_params, old_values, adv, targets, valids,

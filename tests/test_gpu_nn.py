@@ -1049,6 +1049,7 @@ def test_learner_config_matrix_smoke(lib, tmp_path):
     from sample_factory_amd.model.actor_critic import get_rnn_size
     combos = [
         dict(space="disc"), dict(space="tuple", kl_loss_coeff=0.1), dict(space="box", with_vtrace=True, normalize_returns=False),
+        dict(space="tuple", with_vtrace=True, normalize_returns=False, recurrence=8),
         dict(space="box", adaptive_stddev=False, optimizer="lamb"), dict(space="disc", use_rnn=True, rnn_type="gru"),
         dict(space="tuple", use_rnn=True, rnn_type="lstm", exploration_loss="symmetric_kl"),
         dict(space="disc", normalize_input=True, shuffle_minibatches=True, num_epochs=2),
@@ -1113,7 +1114,7 @@ def test_learner_config_matrix_smoke(lib, tmp_path):
         ac.flat_params.copy_(p0 + eps * direction); ac.params_changed(); lp = lossf()
         ac.flat_params.copy_(p0 - eps * direction); ac.params_changed(); lm = lossf()
         fd, an = (lp - lm) / (2 * eps), float(grad.norm())
-        if sp == "box" and cfg.with_vtrace:
+        if cfg.with_vtrace:
             continue  # V-trace targets are recomputed from the perturbed policy (no gradient flows through them)
         assert abs(fd - an) < 0.05 * max(abs(an), 1e-3) + 2e-3, (tag, fd, an)
 

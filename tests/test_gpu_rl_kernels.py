@@ -376,6 +376,33 @@ def test_sample_write_step_vs_oracle(lib, B, A):
     np.testing.assert_array_equal(env_a.cpu().numpy(), logits.argmax(1).astype(np.int32))
 
 
+def test_vtrace_tuple_heads_vs_oracle(lib):
+    """V-trace with a Tuple of Discrete heads: the importance ratio is exp(sum_h log_softmax(z_h)[a_h] - old_logp)"""
+    rng = np.random.default_rng(21)
+    hs, rec, ntraj = [4, 3, 5], 8, 50
+    A, H, n = sum(hs), len(hs), rec * ntraj
+    params = (rng.standard_normal((n, A)) * 1.2).astype(np.float32)
+    values = rng.standard_normal(n).astype(np.float32)
+    actions = np.stack([rng.integers(0, nh, n) for nh in hs], 1).astype(np.float32)
+    old_logp = (-rng.random(n) * 3 - 0.5).astype(np.float32)
+    rewards = rng.standard_normal(n).astype(np.float32)
+    dones = rng.random(n) < 0.1
+    off = np.cumsum([0] + hs)
+    lp = np.zeros(n, np.float32)
+    for h in range(H):
+        z = params[:, off[h]:off[h + 1]].astype(np.float64)
+        ls = z - z.max(1, keepdims=True)
+        ls = ls - np.log(np.exp(ls).sum(1, keepdims=True))
+        lp += ls[np.arange(n), actions[:, h].astype(int)].astype(np.float32)
+    ratio = np.clip(np.exp(lp - old_logp), 0.05, 20.0).astype(np.float32)
+    vs_ref, adv_ref = oracle.vtrace(ratio, values, rewards, dones.astype(np.float32), rec, 0.99, 0.9, 0.8)
+    vs, adv = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    lib.vtrace(dev(params), A, dev(values), 1, dev(actions), dev(old_logp), dev(rewards), dev(dones, torch.bool), None, 0,
+               n, A, 0, rec, 0.99, 0.9, 0.8, vs, adv, head_sizes=hs)
+    np.testing.assert_allclose(vs.cpu().numpy(), vs_ref, atol=3e-5, rtol=1e-5)
+    np.testing.assert_allclose(adv.cpu().numpy(), adv_ref, atol=3e-5, rtol=1e-5)
+
+
 def test_lamb_step_vs_oracle(lib):
     """Lamb (optimizers.py:14-189): per-tensor trust ratios over a flat buffer with a segment-id map, padding skipped,
     gradient clipping folded in; three consecutive steps vs the C oracle."""
