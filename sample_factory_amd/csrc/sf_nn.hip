@@ -21,6 +21,7 @@
 // chunk back-to-back and waits once (the first version branched per load and hipcc serialised them with vmcnt(0)).
 #include "sf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -153,6 +154,14 @@ __device__ __forceinline__ float act_bwd(float y, int kind) {
     return 1.f;
 }
 
+// v * act'(y) with the kind known at compile time (KIND 0: no activation, < 0: run-time kind)
+template <int KIND>
+__device__ __forceinline__ float act_bwd_mul(float v, float y, int kind) {
+    if (KIND == 0) return v;
+    if (KIND == 1) return y > 0.f ? v : 0.f;
+    return v * act_bwd(y, kind);
+}
+
 // Raw (unconverted, unmasked) operand quads.  The value is NOT touched between the global load and the LDS store of
 // the next iteration, so the loads stay in flight across the whole MFMA phase (a select right after the load made
 // hipcc wait for the data before the first MFMA — no overlap at all).
@@ -264,6 +273,40 @@ __device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const fl
 // C/D fragment: reg r of lane l holds (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31)  (cdna_hip_programming.md §3)
 #define FRAG_ROW(r, lane) (((r) & 3) + 8 * ((r) >> 2) + 4 * ((lane) >> 5))
 
+// act_fwd with the kind known at compile time (KIND < 0: run-time kind)
+template <int KIND>
+__device__ __forceinline__ float act_fwd_c(float x, int kind) {
+    if (KIND == 0) return x;
+    if (KIND == 1) return fmaxf(x, 0.f);
+    return act_fwd(x, kind);
+}
+
+// Store one wave's TM x TN accumulator fragments (32x32x2 layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col =
+// lane&31) as act(acc + bias) into a row-major [rows][N] matrix.  ob = uniform pointer to the tile's (0, 0);
+// voff = this lane's (4*(lane>>5))*N + (lane&31); rows_left / cols_left = number of existing rows / columns counted
+// from THIS LANE's first row / column (FULL: the whole tile exists, no per-element test); bias0 = bias + tile column,
+// lcol = lane&31.
+template <int TM, int TN, int KIND, bool FULL>
+__device__ __forceinline__ void store_fwd_tile(const f32x16 (&acc)[TM][TN], float *__restrict__ ob, uint32_t voff, int N,
+                                               int rows_left, int cols_left, const float *__restrict__ bias0, int lcol,
+                                               int kind) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const bool cok = FULL || tn * 32 < cols_left;
+        const float bv = (bias0 && cok) ? bias0[tn * 32 + lcol] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = tm * 32 + (r & 3) + 8 * (r >> 2);
+                float *p = ob + (int64_t)rr * N + tn * 32;  // uniform
+                const float v = act_fwd_c<KIND>(acc[tm][tn][r] + bv, kind);
+                if (FULL || (cok && rr < rows_left)) p[voff] = v;
+            }
+    }
+}
+
+
 template <int BM, int BN, int WM, int WN>
 struct Tile {
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -366,22 +409,21 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvG g, const void *__restric
     // epilogue: bias + ReLU, NHWC store (split-K: raw partial, finished by k_splitk_finish)
     float *dst = partial ? partial + (int64_t)blockIdx.z * Mtot * N : out;
     const bool fin = partial == nullptr;
-#pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < T::TN; ++tn) {
-            const int n = n0 + wn * T::TN * 32 + tn * 32 + (lane & 31);
-            const float bv = (fin && n < N && bias) ? bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * T::TM * 32 + tm * 32 + FRAG_ROW(r, lane);
-                if (m < Mtot && n < N) {
-                    float v = acc[tm][tn][r] + bv;
-                    if (fin) v = act_fwd(v, g.relu);
-                    dst[m * N + n] = v;
-                }
-            }
-        }
+    float *ob = dst + (m0 + wm * T::TM * 32) * N + (n0 + wn * T::TN * 32);
+    const int rows_left = (int)min((int64_t)(T::TM * 32), Mtot - m0 - wm * T::TM * 32) - 4 * (lane >> 5);
+    const int cols_left = N - (n0 + wn * T::TN * 32) - (lane & 31);
+    const uint32_t voff = (uint32_t)(4 * (lane >> 5)) * (uint32_t)N + (uint32_t)(lane & 31);
+    const bool full = m0 + BM <= Mtot && n0 + BN <= N;
+    const float *b0 = (fin && bias) ? bias + n0 + wn * T::TN * 32 : nullptr;
+    if (!fin) {
+        if (full) store_fwd_tile<T::TM, T::TN, 0, true>(acc, ob, voff, N, rows_left, cols_left, nullptr, lane & 31, 0);
+        else store_fwd_tile<T::TM, T::TN, 0, false>(acc, ob, voff, N, rows_left, cols_left, nullptr, lane & 31, 0);
+    } else if (g.relu == 1) {
+        if (full) store_fwd_tile<T::TM, T::TN, 1, true>(acc, ob, voff, N, rows_left, cols_left, b0, lane & 31, 1);
+        else store_fwd_tile<T::TM, T::TN, 1, false>(acc, ob, voff, N, rows_left, cols_left, b0, lane & 31, 1);
+    } else {
+        store_fwd_tile<T::TM, T::TN, -1, false>(acc, ob, voff, N, rows_left, cols_left, b0, lane & 31, g.relu);
+    }
 }
 
 // out[m][n] = act(sum_z partial[z][m][n] + bias[n]), z ascending (deterministic)

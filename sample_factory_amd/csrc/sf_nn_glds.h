@@ -133,18 +133,20 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
         mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn * TN * 32 + tn * 32 + (lane & 31);
-            const float bv = (n < N && bias) ? bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * TM * 32 + tm * 32 + FRAG_ROW(r, lane);
-                if (m < Mtot && n < N) out[m * N + n] = act_fwd(acc[tm][tn][r] + bv, g.relu);
-            }
-        }
+    // epilogue: uniform base pointer + one 32-bit lane offset; the activation kind and the "tile is complete" test
+    // are hoisted out of the 16*TM*TN element loop (per element: bias add, max, address add, store — the first
+    // version re-derived a 64-bit m*N+n and branched on the kind per element: 13 VALU + 3 quarter-rate multiplies)
+    float *ob = out + (m0 + wm * TM * 32) * N + (n0 + wn * TN * 32);
+    const int rows_left = (int)min((int64_t)(TM * 32), Mtot - m0 - wm * TM * 32) - 4 * (lane >> 5);
+    const int cols_left = N - (n0 + wn * TN * 32) - (lane & 31);
+    const uint32_t voff = (uint32_t)(4 * (lane >> 5)) * (uint32_t)N + (uint32_t)(lane & 31);
+    const bool full = m0 + BM <= Mtot && n0 + BN <= N;
+    if (g.relu == 1) {
+        if (full) store_fwd_tile<TM, TN, 1, true>(acc, ob, voff, N, rows_left, cols_left, bias ? bias + n0 + wn * TN * 32 : nullptr, lane & 31, 1);
+        else store_fwd_tile<TM, TN, 1, false>(acc, ob, voff, N, rows_left, cols_left, bias ? bias + n0 + wn * TN * 32 : nullptr, lane & 31, 1);
+    } else {
+        store_fwd_tile<TM, TN, -1, false>(acc, ob, voff, N, rows_left, cols_left, bias ? bias + n0 + wn * TN * 32 : nullptr, lane & 31, g.relu);
+    }
 }
 
 // wt[n][k] = w[k][n]  (weights are kept K-major for the data-gradient; the glds forward wants them Cout-major)
@@ -240,9 +242,24 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
     // registers and written out during the first chunk of the NEXT pixel, so neither the load latency nor the store
     // drain sits in front of a vmcnt(0).
     float pend[TM][TN][16], actv[TM][TN][16];
+    // Complete tiles (every row a real sample, every column a real channel — all but the last tile) take the paths
+    // without per-element predicates: address = uniform (pixel, fragment row, fragment column) part + obase.
+    const bool full = s0 + BM <= nsamples && n0 + BN <= Cin;
     auto prefetch_act = [&](int iw) {
         if (!in_act) return;
         const uint32_t pix = (uint32_t)iw * (uint32_t)Cin;
+        if (full) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rc = tm * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        actv[tm][tn][r] = (in_act + (size_t)(pix + (uint32_t)rc * sstride + (uint32_t)(tn * 32)))[obase];
+                }
+            return;
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -258,19 +275,34 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
     };
     auto park_pixel = [&]() {
         const int akind = g.relu;
+        auto park = [&](auto kc) {
+            constexpr int KIND = decltype(kc)::value;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[tm][tn][r];
-                    if (in_act) v *= act_bwd(actv[tm][tn][r], akind);
-                    pend[tm][tn][r] = v;
-                }
+                    for (int r = 0; r < 16; ++r)
+                        pend[tm][tn][r] = act_bwd_mul<KIND>(acc[tm][tn][r], actv[tm][tn][r], akind);
+        };
+        if (!in_act) park(std::integral_constant<int, 0>{});
+        else if (akind == 1) park(std::integral_constant<int, 1>{});
+        else park(std::integral_constant<int, -1>{});
     };
     auto store_pixel = [&](int iw) {
         const uint32_t pix = (uint32_t)iw * (uint32_t)Cin;
+        if (full) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rc = tm * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        (din + (size_t)(pix + (uint32_t)rc * sstride + (uint32_t)(tn * 32)))[obase] = pend[tm][tn][r];
+                }
+            return;
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -496,7 +528,8 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
     // per-lane bases only by IMMEDIATE ds_read offsets; with run-time geometry hipcc materialised all 80 in VGPRs
     // (256 registers, one wave per SIMD).
     constexpr int H = 84, W = 84, Cin = 4, KH = 8, KW = 8, S = 4, OH = 20, OW = 20, OHOW = OH * OW;
-    static_assert(KG * 16 == Cin * KH * KW && SMP * R * OW == 32 * TMF && OH % R == 0, "Nature-CNN conv1 geometry");
+    static_assert(KG * 16 == Cin * KH * KW && SMP * R * OW == 32 * TMF && OH % R == 0 && (R * OW) % 16 == 0,
+                  "Nature-CNN conv1 geometry");
     const int N = g.Cout;
     constexpr int RS = (R - 1) * S + KH;  // input rows per strip
     constexpr int W4 = W >> 2;            // 4-byte words per input row
@@ -570,6 +603,7 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
         const int smp = row / (R * OW), p = row - smp * (R * OW), ohl = p / OW, ow = p - ohl * OW;
         origin[t] = (smp * Cin * RS + ohl * S) * W + ow * S + lanetap;
     }
+    const uint32_t voff = (uint32_t)(4 * (lane >> 4)) * (uint32_t)N + (uint32_t)col;
     constexpr int nstrips = OH / R;
     for (int st = 0; st < nstrips; ++st) {
         store_strip();  // first use of the prefetched bytes
@@ -598,17 +632,24 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi & 1][t][j], breg[gi][j], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // epilogue: R*OW is a multiple of 16, so a fragment never straddles a sample -> uniform base pointer per
+        // fragment, one 32-bit lane offset, activation kind hoisted (see store_fwd_tile)
+        auto epilogue = [&](auto kc) {
+            constexpr int KIND = decltype(kc)::value;
 #pragma unroll
-        for (int t = 0; t < TMF; ++t) {
-            const int rbase = (2 * t + wm) * 16 + 4 * (lane >> 4);
+            for (int t = 0; t < TMF; ++t) {
+                const int f = 2 * t + wm, smp = f / (R * OW / 16), prow = f * 16 - smp * (R * OW);
+                float *ob = out + ((int64_t)(s0 + smp) * OHOW + st * (R * OW) + prow) * N;
+                const bool ok = s0 + smp < nsamples && col < N;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rbase + r;
-                const int smp = row / (R * OW), p = row - smp * (R * OW);
-                const int64_t m = (int64_t)(s0 + smp) * OHOW + st * (R * OW) + p;
-                if (s0 + smp < nsamples && col < N) out[m * N + col] = act_fwd(acc[t][r] + bv, g.relu);
+                for (int r = 0; r < 4; ++r) {
+                    const float v = act_fwd_c<KIND>(acc[t][r] + bv, g.relu);
+                    if (ok) (ob + r * N)[voff] = v;
+                }
             }
-        }
+        };
+        if (g.relu == 1) epilogue(std::integral_constant<int, 1>{});
+        else epilogue(std::integral_constant<int, -1>{});
         __syncthreads();  // everybody is done reading this strip before it is overwritten
     }
 }
@@ -696,9 +737,26 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
     const int rbase = wm * TM * 32 + 4 * (lane >> 5);
     float actv[TM][TN][16];
     __syncthreads();  // rowoff visible
+    // Complete tiles (all rows real, all columns real, no group row hanging over the image) skip the per-element
+    // predicates; the activation kind is hoisted out of the element loops.
+    const bool full = m0 + BM <= Mrows && n0 + BN <= N && H % S == 0;
     auto prefetch_act = [&](int ihc) {
         if (!in_act) return;
         const uint32_t gy = (uint32_t)(ihc * S * W * Cin);
+        if (full) {
+            uint32_t cb[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) cb[tn] = gy + cbase[tn];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t ro = rowoff[rbase + tm * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) actv[tm][tn][r] = in_act[ro + cb[tn]];
+                }
+            return;
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -714,19 +772,35 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
     auto store_step = [&](int ihc, bool zero) {
         const uint32_t gy = (uint32_t)(ihc * S * W * Cin);
         const int akind = g.relu;
+        auto body = [&](auto kc, auto fc) {
+            constexpr int KIND = decltype(kc)::value;
+            constexpr bool FULL = decltype(fc)::value;
+            uint32_t cb[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+            for (int tn = 0; tn < TN; ++tn) cb[tn] = gy + cbase[tn];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t ro = rowoff[rbase + tm * 32 + (r & 3) + 8 * (r >> 2)];
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    if (ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H) {
-                        float v = zero ? 0.f : acc[tm][tn][r];
-                        if (in_act && !zero) v *= act_bwd(actv[tm][tn][r], akind);
-                        din[ro + gy + cbase[tn]] = v;
-                    }
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t ro = rowoff[rbase + tm * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        if (FULL || (ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H)) {
+                            float v = zero ? 0.f : acc[tm][tn][r];
+                            if (!zero) v = act_bwd_mul<KIND>(v, actv[tm][tn][r], akind);
+                            din[ro + cb[tn]] = v;
+                        }
+                }
+        };
+        if (!in_act || zero) {
+            if (full) body(std::integral_constant<int, 0>{}, std::true_type{});
+            else body(std::integral_constant<int, 0>{}, std::false_type{});
+        } else if (akind == 1) {
+            if (full) body(std::integral_constant<int, 1>{}, std::true_type{});
+            else body(std::integral_constant<int, 1>{}, std::false_type{});
+        } else {
+            body(std::integral_constant<int, -1>{}, std::false_type{});
+        }
     };
     // (the last group column of an image whose width is not a multiple of S has pixels past W: never the case for the
     // launcher's contract W % S == 0)
