@@ -1004,7 +1004,8 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
                 db ? partial_b : nullptr, (int)n, npairs);
     } else
-    if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && Mtot >= 65536) {
+    if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && Mtot >= 65536 &&
+        n * max(in_sample_stride, (int64_t)g.H * g.W * g.Cin) < ((int64_t)1 << 30)) {  // 32-bit byte offsets in the kernel
         // gfx950 LDS-DMA kernel (dense f32 NHWC input): different tiles, so its own split plan and partial layout
         const WgradGlds q = plan_wgrad_glds(Mtot, K, N, true);
         partial_b = partial_w + (int64_t)q.Z * K * N;
@@ -1101,7 +1102,7 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         snprintf(out, cap, g.Cout >= 128 ? "k_fwd_glds<128, *, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
-    } else if (op == 1 && mode == MODE_F32 && Mtot >= 65536) {
+    } else if (op == 1 && mode == MODE_F32 && Mtot >= 65536 && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
         snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"
                                                                                   : "k_wgrad_glds<128, 64, 2, 2>");

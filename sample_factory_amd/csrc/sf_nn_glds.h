@@ -413,15 +413,36 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
     const int64_t mbeg = (int64_t)blockIdx.z * m_per_split;
     const int64_t mend = (mbeg + m_per_split < Mtot) ? mbeg + m_per_split : Mtot;
 
-    // DMA lanes: A instruction j covers reduction rows j*A_RPI.. ; lane -> (row-in-instr, 16-byte position)
+    // DMA lanes: A instruction j covers reduction rows j*A_RPI.. ; lane -> (row-in-instr, 16-byte position).
+    // A reduction row m = (sample, oh, ow) moves every chunk, so its decode (two fast divisions, the patch origin)
+    // sits inside the k-loop.  A wave's AI instructions touch only NROW = AI*A_RPI = 8 distinct rows per chunk: lane
+    // L decodes row L & 7 ONCE and every instruction fetches its row's byte offset with one ds_bpermute, then adds the
+    // lane's loop-invariant tap offset.  (First version: every lane decoded the row of every instruction — 206 VALU
+    // incl. 62 quarter-rate multiplies per 64 MFMAs, 4.4 VALU per MFMA in the SQ counters.  Doing the decode on the
+    // scalar unit instead — rows are wave-uniform for BK = 256 — was SLOWER: 280 dependent SALU instructions per
+    // chunk delay the DMA issue.)  Offsets are 32-bit bytes: the launcher guarantees n * in_stride * 4 < 2^32.
     constexpr int ACH = BK / 4, BCH = BN / 4;  // 16-byte chunks per row
+    constexpr int NROW = AI * A_RPI;
+    static_assert(B_RPI % 2 == 0 && (A_RPI == 1 || A_RPI % 2 == 0) && NROW == 8, "row parity must be a lane constant");
     const int a_r = lane / ACH, a_p = lane % ACH, b_r = lane / BCH, b_p = lane % BCH;
-    int a_tap[2];  // element offset inside the input patch of this lane's k-chunk, for even / odd reduction rows
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
+    const int dl = lane & (NROW - 1);
+    const int drow = ((dl / A_RPI) * 4 + wave) * A_RPI + (dl % A_RPI);  // row (inside a chunk) this lane decodes
+    // byte offset inside the input patch of this lane's k-chunk (row parity: A_RPI == 1 -> parity of j = wave & 1)
+    uint32_t a_tapb;
+    {
+        const int par = A_RPI == 1 ? (wave & 1) : (a_r & 1);
         int k = k0row + ((a_p ^ (par << 3)) << 2);
         k = k < K ? k : 0;  // weight rows past K are never stored
-        a_tap[par] = tap_offset<false>(g, (uint32_t)k);
+        a_tapb = (uint32_t)tap_offset<false>(g, (uint32_t)k) << 2;
+    }
+    uint32_t b_offb[BI];  // byte offset of (row inside the chunk, column chunk) inside dY, per instruction
+    int b_row[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        b_row[i] = (i * 4 + wave) * B_RPI + b_r;
+        int n = n0 + ((b_p ^ ((b_r & 1) << 3)) << 2);
+        n = n < N ? n : 0;  // columns past N are never stored
+        b_offb[i] = (uint32_t)(b_row[i] * N + n) << 2;
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -431,25 +452,24 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
 #pragma unroll
             for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
 
+    const char *inb = reinterpret_cast<const char *>(in);
     auto issue = [&](int64_t mc, int stage) {
         float *sa = lds + stage * STAGE, *sb = sa + BK * 32;
+        int64_t m = mc + drow;
+        m = m < mend ? m : mend - 1;  // annihilated by the zero dY row below
+        const uint32_t smp = fdiv((uint32_t)m, g.dOHOW), pix = (uint32_t)m - smp * (uint32_t)(g.OH * g.OW);
+        const int rowb = (int)((smp * (uint32_t)in_stride + (uint32_t)patch_origin<false>(g, pix)) << 2);
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int j = i * 4 + wave, row = j * A_RPI + a_r;
-            int64_t m = mc + row;
-            m = m < mend ? m : mend - 1;  // annihilated by the zero dY row below
-            const uint32_t smp = fdiv((uint32_t)m, g.dOHOW), pix = (uint32_t)m - smp * (uint32_t)(g.OH * g.OW);
-            const float *src = in + (int64_t)smp * in_stride + patch_origin<false>(g, pix) + a_tap[row & 1];
-            GLDS16(src, sa + j * 256);
+            const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute((i * A_RPI + a_r) << 2, rowb) + a_tapb;
+            GLDS16(reinterpret_cast<const float *>(inb + (size_t)ob), sa + (i * 4 + wave) * 256);
         }
+        const char *dyb = reinterpret_cast<const char *>(dy + mc * N);
+        const int left = (int)min((int64_t)32, mend - mc);  // rows of this chunk that exist
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const int j = i * 4 + wave, row = j * B_RPI + b_r;
-            const int64_t m = mc + row;
-            int n = n0 + ((b_p ^ ((row & 1) << 3)) << 2);
-            n = n < N ? n : 0;  // columns past N are never stored
-            const float *src = m < mend ? dy + m * N + n : sf_zero_page;
-            GLDS16(src, sb + j * 256);
+            const float *src = b_row[i] < left ? reinterpret_cast<const float *>(dyb + (size_t)b_offb[i]) : sf_zero_page;
+            GLDS16(src, sb + (i * 4 + wave) * 256);
         }
     };
     const bool do_colsum = partial_b != nullptr && blockIdx.x == 0 && tid < BN;
