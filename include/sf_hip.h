@@ -275,10 +275,13 @@ int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float 
 /* Forward for the dense hot layers through the gfx950 LDS-DMA path: same result contract as sf_conv_fwd, but the
  * weights are given Cout-major, wt[Cout, K] (sf_transpose of the canonical [K, Cout] array), the input must be f32
  * NHWC with Cin % 32 == 0, dense samples (no index gather), 16-byte aligned.  sf_conv_fwd_t_supported says whether a
- * launch qualifies (and is large enough to be worth it); everything else goes through sf_conv_fwd. */
+ * launch qualifies (and is large enough to be worth it); everything else goes through sf_conv_fwd.  A wide layer with
+ * a long reduction and few rows (the fc layer of one rollout step) is split along K: sf_conv_fwd_t_workspace gives the
+ * scratch bytes such a launch needs (0 = none; 16-byte aligned; the call fails loudly if it is missing). */
 int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *desc);
+int64_t sf_conv_fwd_t_workspace(int64_t n, const sf_conv_desc *desc);
 int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
-                  int64_t n, const sf_conv_desc *desc, void *stream);
+                  int64_t n, const sf_conv_desc *desc, void *workspace, int64_t workspace_bytes, void *stream);
 int sf_transpose(const float *w, float *wt, int K, int N, void *stream); /* wt[N,K] = w[K,N]^T */
 
 /* Profiling aid (no reference counterpart): the kernel instantiation a conv/linear launch resolves to, spelled as

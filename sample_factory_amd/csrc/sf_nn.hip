@@ -824,17 +824,66 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
 static bool glds_fwd_ok(const sf_conv_desc *d) {
     return !d->in_u8 && d->Cin % 32 == 0 && d->traj_T == 0;
 }
+// Launch plan of the LDS-DMA forward.  Grids of >= 768 128x64 tiles run unsplit (tile width by grid quantisation).
+// A wide layer with a long reduction and too few rows to fill the chip (the fc layer of a rollout step: 4096 x 512,
+// K = 3136 -> 128 tiles of 128x128) is split along K so that ~2 blocks land on every CU; the slices go through
+// k_splitk_finish (ascending z: deterministic).  Measured at n = 4096: register-staged split-K kernel 140 us, this
+// plan 4 x 128 blocks.
+struct GldsFwdPlan {
+    bool ok, wide;
+    int Z, k_per_split;
+};
+static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
+    static const int cfg = getenv("SF_GLDS_CFG") ? atoi(getenv("SF_GLDS_CFG")) : 0;
+    static const int split_on = getenv("SF_GLDS_SPLITK") ? atoi(getenv("SF_GLDS_SPLITK")) : 1;
+    static const int occ64 = occupancy_of(k_fwd_glds<128, 64, 2, 2, 2>), occ128 = occupancy_of(k_fwd_glds<128, 128, 2, 2, 2>);
+    GldsFwdPlan p;
+    p.ok = false; p.wide = false; p.Z = 1; p.k_per_split = (K + 31) / 32 * 32;
+    const int64_t t64 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 64), t128 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 128);
+    if (t64 >= 768) {
+        p.ok = true;
+        if (N >= 128 && cfg == 0) {  // efficiency = rounds / ceil(rounds) with the kernel's own occupancy
+            const double u64 = (double)t64 / (256.0 * occ64), u128 = (double)t128 / (256.0 * occ128);
+            const double e64 = u64 / (double)(int64_t)(u64 + 0.999999), e128 = u128 / (double)(int64_t)(u128 + 0.999999);
+            p.wide = e128 * 1.03 >= e64;  // 64x64 wave tiles: fewer LDS reads and DMA instructions per MFMA
+        }
+        if (cfg == 2) p.wide = true;
+        return p;
+    }
+    if (split_on && N >= 128 && K >= 1024 && t128 >= 32) {
+        const int slots = 256 * occ128;
+        int z = (int)((slots + t128 - 1) / t128);
+        const int zmax = K / 256;  // >= 8 chunks per slice
+        z = z > zmax ? zmax : z;
+        z = z > 16 ? 16 : z;
+        if (z > 1) {
+            const int chunks = (K + 31) / 32;
+            p.k_per_split = ((chunks + z - 1) / z) * 32;
+            p.Z = (K + p.k_per_split - 1) / p.k_per_split;
+            p.ok = p.Z > 1;
+            p.wide = true;
+        }
+    }
+    return p;
+}
 extern "C" int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *h_desc) {
     if (!h_desc || n <= 0 || !glds_fwd_ok(h_desc)) return 0;
     // small grids keep the split-K register-staged kernel (a 128-row tile grid must fill 256 CUs a few times over)
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
-    return ((Mtot + 127) / 128) * ((h_desc->Cout + 63) / 64) >= 768;
+    return plan_fwd_t(Mtot, h_desc->Cout, h_desc->KH * h_desc->KW * h_desc->Cin).ok ? 1 : 0;
 }
-#define GLDS_FWD(BM, BN, WM, WN, NS)                                                                              \
-    k_fwd_glds<BM, BN, WM, WN, NS><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN)), dim3(256), 0, STREAM(stream)>>>( \
-        g, in, in_sample_stride, wt, bias, out, Mtot)
+extern "C" int64_t sf_conv_fwd_t_workspace(int64_t n, const sf_conv_desc *h_desc) {
+    if (!h_desc || n <= 0 || !glds_fwd_ok(h_desc)) return 0;
+    const int64_t Mtot = n * h_desc->OH * h_desc->OW;
+    const GldsFwdPlan p = plan_fwd_t(Mtot, h_desc->Cout, h_desc->KH * h_desc->KW * h_desc->Cin);
+    return p.ok && p.Z > 1 ? (int64_t)sizeof(float) * p.Z * Mtot * h_desc->Cout + 256 : 0;
+}
+#define GLDS_FWD(BM, BN, WM, WN, NS)                                                                           \
+    k_fwd_glds<BM, BN, WM, WN, NS><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), p.Z), dim3(256), 0, st>>>(     \
+        g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial)
 extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
-                             int64_t n, const sf_conv_desc *h_desc, void *stream) {
+                             int64_t n, const sf_conv_desc *h_desc, void *workspace, int64_t workspace_bytes,
+                             void *stream) {
     int rc = check_desc(h_desc, "sf_conv_fwd_t");
     if (rc) return rc;
     SF_REQUIRE(in && wt && out && n > 0, "sf_conv_fwd_t: bad args");
@@ -844,18 +893,26 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     const ConvG g = make_geom(h_desc);
     const int64_t Mtot = n * g.OH * g.OW;
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd_t: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
-    static const int cfg = getenv("SF_GLDS_CFG") ? atoi(getenv("SF_GLDS_CFG")) : 0;
-    // tile choice by grid quantisation: efficiency = rounds / ceil(rounds) with the kernel's own occupancy
-    static const int occ64 = occupancy_of(k_fwd_glds<128, 64, 2, 2, 2>), occ128 = occupancy_of(k_fwd_glds<128, 128, 2, 2, 2>);
-    bool wide = false;
-    if (g.Cout >= 128 && cfg == 0) {
-        const double u64 = (double)(cdiv64(Mtot, 128) * (int64_t)cdiv64(g.Cout, 64)) / (256.0 * occ64);
-        const double u128 = (double)(cdiv64(Mtot, 128) * (int64_t)cdiv64(g.Cout, 128)) / (256.0 * occ128);
-        const double e64 = u64 / (double)(int64_t)(u64 + 0.999999), e128 = u128 / (double)(int64_t)(u128 + 0.999999);
-        wide = e128 * 1.03 >= e64;  // 64x64 wave tiles: fewer LDS reads and DMA instructions per MFMA
+    GldsFwdPlan p = plan_fwd_t(Mtot, g.Cout, g.K);
+    if (!p.ok) {  // not a grid sf_conv_fwd_t_supported recommends: still correct, one unsplit launch
+        p.Z = 1;
+        p.k_per_split = (g.K + 31) / 32 * 32;
     }
-    if (cfg == 2 || wide) GLDS_FWD(128, 128, 2, 2, 2);
+    float *partial = nullptr;
+    if (p.Z > 1) {
+        SF_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 &&
+                       workspace_bytes >= (int64_t)sizeof(float) * p.Z * Mtot * g.Cout,
+                   "sf_conv_fwd_t: this launch is split along K and needs sf_conv_fwd_t_workspace() bytes of workspace");
+        partial = reinterpret_cast<float *>(workspace);
+    }
+    hipStream_t st = STREAM(stream);
+    if (p.wide) GLDS_FWD(128, 128, 2, 2, 2);
     else GLDS_FWD(128, 64, 2, 2, 2);
+    if (partial) {
+        const int64_t MN = Mtot * g.Cout;
+        k_splitk_finish<<<dim3(cdiv64(MN, 256) < 4096 ? cdiv64(MN, 256) : 4096), dim3(256), 0, st>>>(
+            partial, bias, out, MN, g.Cout, p.Z, g.relu);
+    }
     return sf_launch_status("sf_conv_fwd_t");
 }
 extern "C" int sf_transpose(const float *w, float *wt, int K, int N, void *stream) {
@@ -931,6 +988,15 @@ static WgradGlds plan_wgrad_glds(int64_t Mtot, int K, int N, bool query_occupanc
     return q;
 }
 
+// Which reductions go to the LDS-DMA weight-gradient kernel: long ones, and mid-sized ones with a large K x N (the fc
+// layer at n = 32768: 1044 -> 911 us; the 8-column heads stay on the register-staged kernel).  SF_WGRAD_GLDS_MIN
+// overrides the row threshold (A/B switch).
+static bool wgrad_glds_wanted(int64_t Mtot, int K, int N) {
+    static const int64_t v = getenv("SF_WGRAD_GLDS_MIN") ? atoll(getenv("SF_WGRAD_GLDS_MIN")) : -1;
+    if (v >= 0) return Mtot >= v;
+    return Mtot >= 65536 || (Mtot >= 16384 && K >= 1024 && N >= 64);
+}
+
 extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc) {
     if (!h_desc || n <= 0) return 0;
     const int K = h_desc->KH * h_desc->KW * h_desc->Cin, N = h_desc->Cout;
@@ -1004,7 +1070,7 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
                 db ? partial_b : nullptr, (int)n, npairs);
     } else
-    if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && Mtot >= 65536 &&
+    if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && wgrad_glds_wanted(Mtot, K, N) &&
         n * max(in_sample_stride, (int64_t)g.H * g.W * g.Cin) < ((int64_t)1 << 30)) {  // 32-bit byte offsets in the kernel
         // gfx950 LDS-DMA kernel (dense f32 NHWC input): different tiles, so its own split plan and partial layout
         const WgradGlds q = plan_wgrad_glds(Mtot, K, N, true);
@@ -1099,10 +1165,10 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
     } else if (op == 3) {
-        snprintf(out, cap, g.Cout >= 128 ? "k_fwd_glds<128, *, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
+        snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
-    } else if (op == 1 && mode == MODE_F32 && Mtot >= 65536 && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
+    } else if (op == 1 && mode == MODE_F32 && wgrad_glds_wanted(Mtot, g.K, g.Cout) && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
         snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"
                                                                                   : "k_wgrad_glds<128, 64, 2, 2>");

@@ -66,7 +66,8 @@ __device__ __forceinline__ void mma_chunk_rows(const float *__restrict__ As, con
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                                   const float *__restrict__ wt, const float *__restrict__ bias,
-                                                  float *__restrict__ out, int64_t Mtot) {
+                                                  float *__restrict__ out, int64_t Mtot, int k_per_split,
+                                                  float *__restrict__ partial) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
@@ -77,6 +78,9 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int N = g.Cout, K = g.K;
+    // split-K (grids too small to fill the chip): slice z reduces k in [kbeg, kend) into partial[z], k_splitk_finish
+    // adds the slices in ascending z, the bias and the activation
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
 
     // per-lane DMA sources: lane = (row-in-group lrow, chunk position lpos); position p holds chunk p ^ swz(row)
     const int lrow = lane >> 3, lpos = lane & 7;
@@ -118,17 +122,17 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     // NS-stage DMA pipeline: chunk t+NS-1 is issued while chunk t is in the matrix pipe.  Loads retire in order, so
     // "at most (NS-2) chunks' worth of DMA instructions outstanding" == "chunk t has landed" — never a vmcnt(0)
     // inside the loop for NS = 3.
-    issue(0, 0);
-    if (NS == 3 && 32 < K) issue(32, 1);
+    issue(kbeg, 0);
+    if (NS == 3 && kbeg + 32 < kend) issue(kbeg + 32, 1);
     int stage = 0;
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        if (NS == 3 && k0 + 32 < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        if (NS == 3 && k0 + 32 < kend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BARRIER_NOFENCE();  // chunk k0 is visible to all waves, and the stage about to be refilled is no longer read
         const int kn = k0 + (NS - 1) * 32;
         int sn = stage + NS - 1;
         sn = sn >= NS ? sn - NS : sn;
-        if (kn < K) issue(kn, sn);
+        if (kn < kend) issue(kn, sn);
         const float *sa = lds + stage * STAGE;
         mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
         stage = stage + 1 == NS ? 0 : stage + 1;
@@ -136,12 +140,15 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     // epilogue: uniform base pointer + one 32-bit lane offset; the activation kind and the "tile is complete" test
     // are hoisted out of the 16*TM*TN element loop (per element: bias add, max, address add, store — the first
     // version re-derived a 64-bit m*N+n and branched on the kind per element: 13 VALU + 3 quarter-rate multiplies)
-    float *ob = out + (m0 + wm * TM * 32) * N + (n0 + wn * TN * 32);
+    float *ob = (partial ? partial + (int64_t)blockIdx.z * Mtot * N : out) + (m0 + wm * TM * 32) * N + (n0 + wn * TN * 32);
     const int rows_left = (int)min((int64_t)(TM * 32), Mtot - m0 - wm * TM * 32) - 4 * (lane >> 5);
     const int cols_left = N - (n0 + wn * TN * 32) - (lane & 31);
     const uint32_t voff = (uint32_t)(4 * (lane >> 5)) * (uint32_t)N + (uint32_t)(lane & 31);
     const bool full = m0 + BM <= Mtot && n0 + BN <= N;
-    if (g.relu == 1) {
+    if (partial) {
+        if (full) store_fwd_tile<TM, TN, 0, true>(acc, ob, voff, N, rows_left, cols_left, nullptr, lane & 31, 0);
+        else store_fwd_tile<TM, TN, 0, false>(acc, ob, voff, N, rows_left, cols_left, nullptr, lane & 31, 0);
+    } else if (g.relu == 1) {
         if (full) store_fwd_tile<TM, TN, 1, true>(acc, ob, voff, N, rows_left, cols_left, bias ? bias + n0 + wn * TN * 32 : nullptr, lane & 31, 1);
         else store_fwd_tile<TM, TN, 1, false>(acc, ob, voff, N, rows_left, cols_left, bias ? bias + n0 + wn * TN * 32 : nullptr, lane & 31, 1);
     } else {

@@ -42,7 +42,7 @@ SYMBOLS = [
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
-    "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t", "sf_transpose",
+    "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
 
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
         lib.sf_last_error.restype = C.c_char_p
         lib.sf_conv_wgrad_workspace.restype = C.c_int64
         lib.sf_conv_fwd_workspace.restype = C.c_int64
+        lib.sf_conv_fwd_t_workspace.restype = C.c_int64
         lib.sf_linear_wgrad_workspace.restype = C.c_int64
         _lib = lib
     return _lib
@@ -419,11 +420,18 @@ def conv_fwd_t_supported(n, desc: sf_conv_desc) -> bool:
     return bool(load().sf_conv_fwd_t_supported(i64(n), C.byref(desc)))
 
 
-def conv_fwd_t(inp, in_sample_stride, wt, bias, out, n, desc: sf_conv_desc) -> None:
-    """glds forward: wt is the [Cout, K] transpose of the canonical weights"""
+def conv_fwd_t_workspace(n, desc: sf_conv_desc) -> int:
+    return int(load().sf_conv_fwd_t_workspace(i64(n), C.byref(desc)))
+
+
+def conv_fwd_t(inp, in_sample_stride, wt, bias, out, n, desc: sf_conv_desc, workspace=None) -> None:
+    """glds forward: wt is the [Cout, K] transpose of the canonical weights; workspace: conv_fwd_t_workspace(n, desc)
+    bytes (u8 tensor) when that is non-zero (split-K launch)"""
     with _timed(_dkey("fwd_t", n, desc)):
         _check(load().sf_conv_fwd_t(_raw_in(inp, desc), i64(in_sample_stride), ptr(wt, "f32", "wt"),
-                                    ptr(bias, "f32", "bias"), ptr(out, "f32", "out"), i64(n), C.byref(desc), stream()),
+                                    ptr(bias, "f32", "bias"), ptr(out, "f32", "out"), i64(n), C.byref(desc),
+                                    ptr(workspace, "u8", "workspace"),
+                                    i64(workspace.numel() if workspace is not None else 0), stream()),
                "sf_conv_fwd_t")
 
 

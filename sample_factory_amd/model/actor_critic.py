@@ -462,7 +462,8 @@ class ActorCritic:
             d.traj_T = int(traj_T)
         w, b, wt = self._wb(li, tag)
         if wt is not None and index is None and not traj_T and lib.conv_fwd_t_supported(n, d):
-            lib.conv_fwd_t(x, stride, wt, b, out, n, d)  # dense f32 input, grid fills the chip: LDS-DMA kernel
+            wsb = lib.conv_fwd_t_workspace(n, d)  # non-zero: wide layer, few rows -> split along K
+            lib.conv_fwd_t(x, stride, wt, b, out, n, d, self._workspace(wsb) if wsb else None)  # LDS-DMA kernel
             return
         wsb = lib.conv_fwd_workspace(n, d) if index is None and not traj_T else 0  # split-K for chip-starving launches
         lib.conv_fwd_raw(x, stride, index, offset, w, b, out, n, d, self._workspace(wsb) if wsb else None)

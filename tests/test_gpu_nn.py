@@ -103,6 +103,43 @@ def test_conv_fwd_wgrad_dgrad_vs_torch(lib, geom, n):
         assert (din2.cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() < 3e-5 * max(1.0, s), "dgrad nomask"
 
 
+def fwd_t_ws(lib, n, d):
+    nb = lib.conv_fwd_t_workspace(n, d)
+    return torch.empty(nb, dtype=torch.uint8, device="cuda") if nb else None
+
+
+@pytest.mark.parametrize("geom,n,act", [((3136, 1, 1, 512, 1, 1), 4096, 1), ((1024, 1, 1, 200, 1, 1), 4001, 2),
+                                        ((64, 5, 5, 136, 5, 1), 4500, 1), ((1056, 1, 1, 128, 1, 1), 8200, 0)])
+def test_glds_fwd_splitk_small_grids_vs_torch(lib, geom, n, act):
+    """wide layer, long reduction, too few rows to fill the chip (the fc layer of a rollout step): sf_conv_fwd_t splits
+    along K into workspace slices + k_splitk_finish.  Ragged row tile, Cout not a multiple of 128, K slices of unequal
+    length, ReLU / tanh / no activation in the finisher; missing workspace must fail loudly."""
+    Cin, H, W, Cout, K, S = geom
+    g = torch.Generator().manual_seed(Cin + n)
+    x = torch.randn((n, Cin, H, W), generator=g)
+    d = desc(lib, Cin, H, W, Cout, K, S)
+    d.relu = act
+    x_dev = x.permute(0, 2, 3, 1).contiguous().cuda()
+    w_ref = torch.randn((Cout, Cin, K, K), generator=g) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    wk = to_kmajor(w_ref, 0).cuda()
+    assert lib.conv_fwd_t_supported(n, d)
+    nb = lib.conv_fwd_t_workspace(n, d)
+    assert nb > 0, "this geometry is meant to take the split-K plan"
+    wt = wk.t().contiguous()
+    out = torch.full((n * d.OH * d.OW, Cout), 7.0, device="cuda")
+    with pytest.raises(lib.SfHipError):
+        lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d, None)
+    lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d, fwd_t_ws(lib, n, d))
+    pre = F.conv2d(x, w_ref, b, stride=S)
+    ref = F.relu(pre) if act == 1 else torch.tanh(pre) if act == 2 else pre
+    got = out.view(n, d.OH, d.OW, Cout).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    out2 = torch.empty_like(out)
+    lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out2, n, d, fwd_t_ws(lib, n, d))
+    assert torch.equal(out, out2), "slices are added in a fixed order: bit-reproducible"
+
+
 @pytest.mark.parametrize("geom,n", [((32, 20, 20, 64, 4, 2), 2500), ((64, 9, 9, 64, 3, 1), 2500),
                                     ((32, 11, 13, 96, 3, 2), 4100), ((96, 1, 1, 160, 1, 1), 70001),
                                     ((32, 12, 14, 64, 3, 2), 4300)])  # last: input row/col no filter tap reaches
@@ -124,7 +161,7 @@ def test_glds_fwd_dgrad_large_grids_vs_torch(lib, geom, n):
     lib.transpose(wk, wt, K * K * Cin, Cout)
     assert torch.equal(wt, wk.t().contiguous())
     out = torch.empty((n * OH * OW, Cout), device="cuda")
-    lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d)
+    lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d, fwd_t_ws(lib, n, d))
     xr = x.clone().requires_grad_(True)
     wr = w_ref.clone().requires_grad_(True)
     br = b.clone().requires_grad_(True)
@@ -193,7 +230,7 @@ def test_glds_kernels_geometry_fuzz(lib):
         if lib.conv_fwd_t_supported(n, d):
             wt = torch.empty((Cout, K * K * Cin), device="cuda")
             lib.transpose(wk, wt, K * K * Cin, Cout)
-            lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d)
+            lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d, fwd_t_ws(lib, n, d))
         else:
             lib.conv_fwd(x_dev, Cin * H * W, None, 0, wk, b.cuda(), out, n, d)
         ref = F.relu(pre).detach()

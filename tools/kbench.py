@@ -42,7 +42,8 @@ def main():
                 assert torch.equal(wt, w.t().contiguous())
                 ref = out.clone(); out.zero_()
                 for cfg in os.environ.get("GLDS_CFGS", "0").split(","):
-                    t = timeit(lambda: lib.conv_fwd_t(x, stride, wt, b, out, n, d), reps)
+                    nb = lib.conv_fwd_t_workspace(n, d); wst = torch.empty(nb,dtype=torch.uint8,device="cuda") if nb else None
+                    t = timeit(lambda: lib.conv_fwd_t(x, stride, wt, b, out, n, d, wst), reps)
                     err = (out - ref).abs().max().item() / ref.abs().max().item()
                     res.append(f"fwd_t {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF relerr {err:.1e}")
             if "wgrad" in which and n == 32768:
