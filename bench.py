@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
+    ap.add_argument("--env_instances", type=int, default=1,
+                    help="split the envs of a GPU into this many vector-env instances (num_envs_per_worker = "
+                         "worker_num_splits = this): their rollouts run on separate HIP streams")
     ap.add_argument("--async_rl", action="store_true", help="overlap rollout k+1 with train(k) (policy lag of one dataset)")
     args = ap.parse_args()
 
@@ -75,9 +78,9 @@ def main():
         normalize_returns=True, rollout=T, batch_size=B * T // args.num_batches, num_batches_per_epoch=args.num_batches,
         num_epochs=args.num_epochs, gamma=0.99, gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0,
         value_loss_coeff=0.5, exploration_loss_coeff=0.01, max_grad_norm=4.0, learning_rate=1e-4, adam_eps=1e-6,
-        async_rl=args.async_rl, serial_mode=not args.async_rl, batched_sampling=True, num_workers=1, num_envs_per_worker=1,
-        worker_num_splits=1, env_gpu_observations=True, env_gpu_actions=True, actor_worker_gpus=[0], seed=0,
-        synthetic_num_agents=B, synthetic_env0=rank * B, data_parallel=world > 1)
+        async_rl=args.async_rl, serial_mode=not args.async_rl, batched_sampling=True, num_workers=1,
+        num_envs_per_worker=args.env_instances, worker_num_splits=args.env_instances, env_gpu_observations=True, env_gpu_actions=True, actor_worker_gpus=[0], seed=0,
+        synthetic_num_agents=B // args.env_instances, synthetic_env0=rank * B, data_parallel=world > 1)
     cfg, runner = make_runner(cfg)
     runner.init()
 

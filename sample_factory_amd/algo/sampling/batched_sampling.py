@@ -24,8 +24,9 @@ from sample_factory_amd.envs.spaces import action_head_sizes, is_box
 
 class BatchedVectorEnvRunner:
     def __init__(self, cfg, env_info, env, actor_critic, traj: TensorDict, policy_id: int = 0,
-                 policy_versions: Optional[torch.Tensor] = None, sample_seed: int = 0, row0: int = 0):
+                 policy_versions: Optional[torch.Tensor] = None, sample_seed: int = 0, row0: int = 0, tag: str = "inf"):
         self.cfg, self.env_info, self.env, self.ac = cfg, env_info, env, actor_critic
+        self.tag = tag  # activation / workspace namespace inside the model: one per concurrently running env group
         self.traj = traj
         self.policy_id = policy_id
         self.policy_versions = policy_versions
@@ -114,14 +115,24 @@ class BatchedVectorEnvRunner:
     def rollout(self, policy_version: Optional[float] = None, deterministic: bool = False) -> None:
         """Collect cfg.rollout steps for all agents into the slab; leaves obs[:, T] = last observation
         (_finalize_trajectories, batched_sampling.py:289-296)."""
+        self.begin_rollout(policy_version, deterministic)
+        for t in range(self.T):
+            self.rollout_step(t)
+
+    def begin_rollout(self, policy_version: Optional[float] = None, deterministic: bool = False) -> None:
         if not self._started:
             self.reset()
+        self._ver = self.policy_version() if policy_version is None else float(policy_version)
+        self._deterministic = bool(deterministic)
+
+    def rollout_step(self, t: int) -> None:
+        """step t of the current rollout (the Runner interleaves the steps of several env groups, each on its own HIP
+        stream: the reference's double-buffered sampling, worker_num_splits / batched_sampling.py:298-388)"""
         tr, T, B, A = self.traj, self.T, self.B, self.A
-        ver = self.policy_version() if policy_version is None else float(policy_version)
-        cfg = self.cfg
-        for t in range(T):
+        ver, deterministic, cfg = self._ver, self._deterministic, self.cfg
+        if True:  # (one step; the body keeps the indentation of the former loop)
             rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
-            heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag="inf", rnn=rnn)[-1]
+            heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag=self.tag, rnn=rnn)[-1]
             if self.masked:
                 mk = tr["obs"]["action_mask"][:, t]
                 lib.sample_write_step_masked(heads[:, 1:], self.ld, heads[:, 0], self.ld, mk, mk.stride(0), B, A, T, t,

@@ -174,4 +174,7 @@ def make_synthetic_env(full_env_name, cfg=None, env_config=None, render_mode=Non
     n = getattr(cfg, "synthetic_num_agents", 4096) if cfg is not None else 4096
     seed = (getattr(cfg, "seed", None) or 0) if cfg is not None else 0
     env0 = getattr(cfg, "synthetic_env0", 0) if cfg is not None else 0
+    # instance e of a multi-instance run simulates global envs [env0 + e*n, env0 + (e+1)*n): the union over instances
+    # is the env set of ONE instance with E*n agents (bit-identical rollouts, tests/test_gpu_nn.py)
+    env0 += int(getattr(env_config, "env_id", 0) or 0) * n if env_config is not None else 0
     return SyntheticVecEnv(num_agents=n, seed=seed, env0=env0)

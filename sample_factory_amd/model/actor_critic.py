@@ -449,7 +449,7 @@ class ActorCritic:
             self._snap_tabs[slot][1].copy_(self.obs_normalizer.rstd_tab)
 
     def _wb(self, li, tag):
-        if tag == "inf" and self._snap is not None:
+        if tag.startswith("inf") and self._snap is not None:
             return self._snap_views[self.snap_read][li]
         L = self.layers[li]
         return L.w, L.b, L.wt
@@ -479,11 +479,11 @@ class ActorCritic:
         """
         acts: List[Optional[torch.Tensor]] = [None] * len(self.layers)
         inputs: List[Optional[torch.Tensor]] = [None] * len(self.layers)
-        self._role = "rollout" if tag == "inf" else "learner"
+        self._role = "rollout" + tag[3:] if tag.startswith("inf") else "learner"  # "inf", "inf1", ...: env groups
         x, stride, idx, off, tT = obs, sample_stride, index, offset, traj_T
         if self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
             xn = self._buf((tag, "obsn"), (n, self.obs_elems))
-            tabs = self._snap_tabs[self.snap_read] if (tag == "inf" and self._snap is not None) else None
+            tabs = self._snap_tabs[self.snap_read] if (tag.startswith("inf") and self._snap is not None) else None
             self.obs_normalizer.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T, tabs=tabs)
             x, stride, idx, off, tT = xn, self.obs_elems, None, 0, 0
         first_in = (x, stride, idx, off, tT)

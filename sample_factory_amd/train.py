@@ -50,25 +50,44 @@ class Runner:
                 torch.distributed.init_process_group(os.environ.get("SF_DP_BACKEND", "nccl"))  # nccl = RCCL on ROCm
             cfg.data_parallel = True
             if getattr(cfg, "synthetic_env0", None) in (None, 0):  # env shard of this replica (weak scaling)
-                cfg.synthetic_env0 = self.rank * getattr(cfg, "synthetic_num_agents", 4096)
-        env_config = AttrDict(worker_index=0, vector_index=0, env_id=0)
-        self.env = create_env(cfg.env, cfg, env_config)
+                cfg.synthetic_env0 = (self.rank * getattr(cfg, "synthetic_num_agents", 4096) *
+                                      max(1, int(cfg.num_workers) * int(cfg.num_envs_per_worker)))
+        # Env instances: num_workers * num_envs_per_worker vector envs, as in the reference (rollout_worker.py:96-117,
+        # each with its own env_config); here they all live in this process and fill consecutive row blocks of ONE
+        # slab.  With more than one instance their rollouts run on cfg.worker_num_splits HIP streams (the reference's
+        # double-buffered sampling: while one group's envs step, the other group's policy forward runs), which fills
+        # the tails of the small-batch kernels: measured in tools/split_probe.py and DESIGN.md §5.
+        E = max(1, int(cfg.num_workers) * int(cfg.num_envs_per_worker))
+        self.envs = [create_env(cfg.env, cfg, AttrDict(worker_index=e // int(cfg.num_envs_per_worker),
+                                                       vector_index=e % int(cfg.num_envs_per_worker), env_id=e))
+                     for e in range(E)]
+        self.env = self.envs[0]
         self.env_info = extract_env_info(self.env, cfg)
+        n = self.env_info.num_agents
+        if any(env.num_agents != n for env in self.envs):
+            raise ValueError("all env instances must have the same number of agents")
         if not preprocess_cfg(cfg, self.env_info):
             raise ValueError("Invalid config! See above for details.")
         self.policy_versions = torch.zeros(cfg.num_policies, dtype=torch.int32)
         self.learner = Learner(cfg, self.env_info, self.policy_versions, 0, ParameterServer(0, self.policy_versions))
         self.learner.init()
         dev = self.learner.device
-        self.traj = alloc_trajectory_tensors(self.env_info, self.env_info.num_agents, cfg.rollout, get_rnn_size(cfg), dev)
-        # one sampling stream for the whole job: key = (seed, global env row) -> a G-replica rollout is bit-identical to
-        # the single-replica rollout of the concatenated env set
-        self.sampler = BatchedVectorEnvRunner(cfg, self.env_info, self.env, self.learner.actor_critic, self.traj, 0,
-                                              self.policy_versions, sample_seed=(cfg.seed or 0),
-                                              row0=self.rank * self.env_info.num_agents)
+        self.num_rows = E * n
+        self.traj = alloc_trajectory_tensors(self.env_info, self.num_rows, cfg.rollout, get_rnn_size(cfg), dev)
+        # one sampling stream for the whole job: key = (seed, global env row) -> a G-replica (or G-instance) rollout is
+        # bit-identical to the single-replica rollout of the concatenated env set
+        self.samplers = [BatchedVectorEnvRunner(cfg, self.env_info, env, self.learner.actor_critic,
+                                                self.traj[e * n:(e + 1) * n], 0, self.policy_versions,
+                                                sample_seed=(cfg.seed or 0), row0=self.rank * self.num_rows + e * n,
+                                                tag="inf" if e == 0 else f"inf{e}")
+                         for e, env in enumerate(self.envs)]
+        self.sampler = self.samplers[0]
+        S = max(1, min(int(cfg.worker_num_splits), E))
+        self.split_streams = [torch.cuda.Stream() for _ in range(S)] if E > 1 else None
+        self._ev_fork = torch.cuda.Event()
+        self._ev_join = [torch.cuda.Event() for _ in range(S)]
         if cfg.async_rl:  # rollout k+1 overlaps Learner.train(k): two slabs, two streams, published weight snapshots
-            self.traj2 = alloc_trajectory_tensors(self.env_info, self.env_info.num_agents, cfg.rollout,
-                                                  get_rnn_size(cfg), dev)
+            self.traj2 = alloc_trajectory_tensors(self.env_info, self.num_rows, cfg.rollout, get_rnn_size(cfg), dev)
             self.slabs = [self.traj, self.traj2]
             self.rollout_stream = torch.cuda.Stream()
             self.ev_rollout = [torch.cuda.Event(), torch.cuda.Event()]
@@ -79,13 +98,44 @@ class Runner:
             self.published_version = float(self.learner.train_step)
         return ExperimentStatus.SUCCESS
 
+    def _rollout_all(self, policy_version: float, slab=None, carry_from=None) -> None:
+        """one rollout of every env instance into its row block of `slab` (default: the current slab), enqueued behind
+        everything already on the current stream; returns with the current stream waiting for all of them"""
+        n = self.env_info.num_agents
+        if slab is not None:
+            for e, sm in enumerate(self.samplers):
+                sm.set_slab(slab[e * n:(e + 1) * n], carry_from=carry_from[e * n:(e + 1) * n] if carry_from is not None else None)
+        if self.split_streams is None:
+            self.sampler.rollout(policy_version=policy_version)
+            return
+        base, S = torch.cuda.current_stream(), len(self.split_streams)
+        for sm in self.samplers:
+            sm.begin_rollout(policy_version)  # (first call: env reset into slab obs[:, 0], on the base stream)
+        self._ev_fork.record(base)
+        for st in self.split_streams:
+            st.wait_event(self._ev_fork)
+        for t in range(self.cfg.rollout):  # steps of the groups interleaved on the host, concurrent on the device
+            for e, sm in enumerate(self.samplers):
+                with torch.cuda.stream(self.split_streams[e % S]):
+                    sm.rollout_step(t)
+        for i, st in enumerate(self.split_streams):
+            self._ev_join[i].record(st)
+            base.wait_event(self._ev_join[i])
+
+    def episode_stats(self):
+        """episode statistics over all env instances"""
+        tot = sum(sm.ep_stats.cpu() for sm in self.samplers)
+        k = float(tot[2])
+        return dict(episodes=k, mean_return=float(tot[0]) / k if k else 0.0, mean_len=float(tot[1]) / k if k else 0.0)
+
     def iteration(self):
         """one dataset: rollout of all envs, then Learner.train on the slab in place"""
         if self.cfg.async_rl:
             return self.iteration_async()
-        self.sampler.rollout(policy_version=float(self.learner.train_step))
+        self._rollout_all(float(self.learner.train_step))
         stats = self.learner.train(self.traj)
-        self.sampler.carry_over()
+        for sm in self.samplers:
+            sm.carry_over()
         return stats
 
     def iteration_async(self):
@@ -103,8 +153,7 @@ class Runner:
             if k >= 1:
                 self.rollout_stream.wait_event(self.ev_publish)        # ... and snapshot k % 2 is complete
             ac.snap_read = k % 2
-            self.sampler.set_slab(cur, carry_from=prev if k >= 1 else None)
-            self.sampler.rollout(policy_version=self.published_version)
+            self._rollout_all(self.published_version, slab=cur, carry_from=prev if k >= 1 else None)
             self.ev_rollout[k % 2].record(self.rollout_stream)
         stats = None
         if k >= 1:

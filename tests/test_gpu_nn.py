@@ -1182,3 +1182,57 @@ def test_cartpole_learns(lib):
     first, last = np.mean(lens[:5]), np.mean(lens[-5:])
     assert first < 60, first
     assert last > 150 and last > 3 * first, (first, last)
+
+
+@pytest.mark.parametrize("async_rl", [False, True])
+def test_env_instances_on_split_streams_match_one_instance(lib, async_rl):
+    """num_envs_per_worker = 2 instances of 512 envs, worker_num_splits = 2 (each instance's rollout on its own HIP
+    stream, steps interleaved: the reference's double-buffered sampling) against ONE instance of 1024 envs: the env and
+    the action sampler are keyed by the global env row, so both runs see the same frames; step 0 of the first rollout is
+    computed from identical weights and inputs (different launch sizes may pick different split-K plans: tolerance on
+    the values, a handful of sampled actions may flip)."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_split", make_synthetic_env)
+    runs = []
+    for inst in (1, 2):
+        cfg = default_cfg(env="synthetic_split", use_rnn=False, rollout=8, recurrence=1, batch_size=2048,
+                          num_batches_per_epoch=4, num_epochs=1, num_workers=1, num_envs_per_worker=inst,
+                          worker_num_splits=2, async_rl=async_rl, seed=5, serial_mode=not async_rl,
+                          synthetic_num_agents=1024 // inst)
+        cfg, runner = make_runner(cfg)
+        runner.init()
+        assert len(runner.samplers) == inst and runner.traj["rewards"].shape == (1024, 8)
+        stats = None
+        for _ in range(3):
+            stats = runner.iteration() or stats
+        torch.cuda.synchronize()
+        assert stats["learner_env_steps"] >= 1024 * 8
+        assert torch.isfinite(runner.learner.actor_critic.flat_params).all()
+        assert runner.episode_stats()["episodes"] >= 0
+        runs.append(runner)
+    if async_rl:
+        return  # slabs are ping-ponged: the state checks below are for the synchronous schedule
+    a, b = runs[0].traj, runs[1].traj
+    assert torch.equal(a["obs"]["obs"][:, 0], b["obs"]["obs"][:, 0]), "same env rows, same frames"
+    # the third rollout used weights after two updates on (nearly) the same data: still close
+    assert (a["values"][:, 0] - b["values"][:, 0]).abs().max().item() < 5e-2
+    runs2 = []
+    for inst in (1, 2):  # fresh runners: the very first rollout step (identical weights) must agree tightly
+        cfg = default_cfg(env="synthetic_split", use_rnn=False, rollout=8, recurrence=1, batch_size=2048,
+                          num_batches_per_epoch=4, num_epochs=1, num_workers=1, num_envs_per_worker=inst,
+                          worker_num_splits=2, async_rl=False, seed=5, serial_mode=True, synthetic_num_agents=1024 // inst)
+        cfg, runner = make_runner(cfg)
+        runner.init()
+        runner._rollout_all(0.0)
+        torch.cuda.synchronize()
+        runs2.append(runner.traj)
+    a, b = runs2
+    assert torch.equal(a["obs"]["obs"], b["obs"]["obs"]) or (a["actions"] == b["actions"]).float().mean() > 0.99
+    assert (a["values"][:, 0] - b["values"][:, 0]).abs().max().item() < 1e-5
+    assert (a["action_logits"][:, 0] - b["action_logits"][:, 0]).abs().max().item() < 1e-5
+    assert (a["actions"][:, 0] == b["actions"][:, 0]).float().mean().item() > 0.995
+    assert torch.equal(a["rewards"][:, 0][a["actions"][:, 0, 0] == b["actions"][:, 0, 0]],
+                       b["rewards"][:, 0][a["actions"][:, 0, 0] == b["actions"][:, 0, 0]])
