@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && (NS == 2 || NS == 3), "4 waves per block");
     __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
     constexpr int STAGE = (BM + BN) * 32;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BI >= 1, "4 waves per block");
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
     const int Cin = g.Cin, Cout = g.Cout, S = g.S, OH = g.OH, OW = g.OW;
     // (sample tile, input row, Cin tile) from the XCD-swizzled linear id
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
     constexpr int AI = 32 / A_RPI / 4, BI = 32 / B_RPI / 4;  // DMA instructions per wave and chunk
     constexpr int STAGE = (BK + BN) * 32;
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
     const int k0row = blockIdx.x * BK, n0 = blockIdx.y * BN;
     const int N = g.Cout, K = g.K;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
                                                      const float *__restrict__ w, const float *__restrict__ bias,
                                                      float *__restrict__ out, int nsamples) {
     extern __shared__ __attribute__((aligned(16))) float strip[];  // [SMP][Cin][RS][W] f32
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave >> 1, wn = wave & 1;
     // Geometry is compile-time (the launcher checks it): the 80 fragment addresses of a strip then differ from 5
     // per-lane bases only by IMMEDIATE ds_read offsets; with run-time geometry hipcc materialised all 80 in VGPRs
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per block");
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
     __shared__ uint32_t rowoff[BM];  // element offset of (sample, iwc) inside din / in_act, 0xFFFFFFFF = row past M
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
     const int Cin = g.Cin, Cout = g.Cout, S = g.S, OH = g.OH, OW = g.OW, H = g.H, W = g.W;
     const int Hg = (H + S - 1) / S, Wg = (int)dWg.d, N = S * S * Cin;
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     float *dys = smem;                 // [ROWS][32] dY rows of the strip (DMA destination, 1 KiB granules)
     float *strip = smem + ROWS * N;    // [SMP][Cin][RS][W]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int i16 = lane & 15, kg = lane >> 4;
     const int words = Cin * RS * W4;
     int gofs[NLD], lofs[NLD];
