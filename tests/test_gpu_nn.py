@@ -1236,3 +1236,64 @@ def test_env_instances_on_split_streams_match_one_instance(lib, async_rl):
     assert (a["actions"][:, 0] == b["actions"][:, 0]).float().mean().item() > 0.995
     assert torch.equal(a["rewards"][:, 0][a["actions"][:, 0, 0] == b["actions"][:, 0, 0]],
                        b["rewards"][:, 0][a["actions"][:, 0, 0] == b["actions"][:, 0, 0]])
+
+
+def test_runner_plugin_hooks_observer_msg_handlers_training_info(lib):
+    """The plugin points of the reference runner (algo/runners/runner.py:52-73, 232-249, 481-495) and of the env
+    (envs/env_utils.py:110-133): an AlgoObserver sees init / start / every training step / stop, a registered episodic
+    stats handler receives {EPISODIC: {reward, len, ...}, policy_id}, a message handler keyed on "train" sees the
+    learner's report, and an env implementing TrainingInfoInterface is told approx_total_training_steps before every
+    rollout."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import TrainingInfoInterface, register_env
+    from sample_factory_amd.envs.synthetic import SyntheticVecEnv
+    from sample_factory_amd.train import EPISODIC, AlgoObserver, make_runner
+
+    class CurriculumEnv(SyntheticVecEnv, TrainingInfoInterface):
+        def __init__(self, **kw):
+            SyntheticVecEnv.__init__(self, **kw)
+            TrainingInfoInterface.__init__(self)
+            self.seen = []
+
+        def set_training_info(self, training_info):
+            super().set_training_info(training_info)
+            self.seen.append(training_info["approx_total_training_steps"])
+
+    register_env("synthetic_curriculum", lambda name, cfg=None, env_config=None, render_mode=None:
+                 CurriculumEnv(num_agents=256, seed=1))
+
+    class Obs(AlgoObserver):
+        def __init__(self):
+            self.calls = []
+
+        def on_init(self, runner): self.calls.append("init")
+        def on_connect_components(self, runner): self.calls.append("connect")
+        def on_start(self, runner): self.calls.append("start")
+        def on_training_step(self, runner, it): self.calls.append(("step", it))
+        def extra_summaries(self, runner, policy_id, env_steps, writer): self.calls.append("summaries")
+        def on_stop(self, runner): self.calls.append("stop")
+
+    cfg = default_cfg(env="synthetic_curriculum", use_rnn=False, rollout=8, recurrence=1, batch_size=1024,
+                      num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=False, seed=1,
+                      serial_mode=True, train_for_env_steps=3 * 256 * 8, train_for_seconds=600, stats_avg=10)
+    cfg, runner = make_runner(cfg)
+    obs = Obs()
+    runner.register_observer(obs)
+    episodic, train_msgs = [], []
+    runner.register_episodic_stats_handler(lambda r, msg, pid: episodic.append((dict(msg[EPISODIC]), pid)))
+    runner.register_msg_handler("train", lambda r, msg: train_msgs.append(msg["train"]["loss"]))
+    runner.report_interval_sec = 0.0  # report after every iteration
+    assert runner.init() == 0
+    assert obs.calls == ["init", "connect"]
+    assert runner.run() == 0
+    assert obs.calls[2] == "start" and obs.calls[-1] == "stop"
+    assert [c for c in obs.calls if isinstance(c, tuple)] == [("step", 1), ("step", 2), ("step", 3)]
+    assert obs.calls.count("summaries") == 3
+    assert len(train_msgs) == 3 and all(np.isfinite(x) for x in train_msgs)
+    assert runner.env.seen == [0, 256 * 8, 2 * 256 * 8], runner.env.seen
+    # Bernoulli(1/1024) terminations over 3 * 2048 env steps: a few episodes finish; their stats arrive as the
+    # reference's message and land in policy_avg_stats through the default handler
+    assert episodic and all(pid == 0 and set(m) >= {"reward", "len", "episodes"} for m, pid in episodic)
+    assert sum(m["episodes"] for m, _ in episodic) >= 1
+    assert len(runner.policy_avg_stats["reward"][0]) == len(episodic)
+    assert all(m["len"] >= 1 for m, _ in episodic)
