@@ -61,6 +61,48 @@ __device__ __forceinline__ void mma_chunk_rows(const float *__restrict__ As, con
     }
 }
 
+// Same chunk, with the caller's DMA instructions for the NEXT chunk spread between the MFMA groups: mid(c) is called in
+// the middle of group c's 4*TM*TN MFMAs (after 2 of its 4 k-steps), the fragment reads of group c+1 follow it.  A DMA
+// instruction keeps its wave's issue port for ~64 cycles; issued in a burst in front of the MFMA phase (6 per wave)
+// that is ~400 cycles with none of this wave's MFMAs in flight, issued one or two at a time between MFMAs it sits in
+// the shadow of the previous MFMA's 64-cycle pass through the matrix pipe.
+template <int TM, int TN, typename F>
+__device__ __forceinline__ void mma_chunk_rows_mid(const float *__restrict__ As, const float *__restrict__ Bs, int arow0,
+                                                   int brow0, int lane, f32x16 (&acc)[TM][TN], F &&mid) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+    const float *ap = As + (arow0 + r) * 32, *bp = Bs + (brow0 + r) * 32;
+    float4 a[2][TM], b[2][TN];
+    auto fetch = [&](int c) {
+        const int pos = (((2 * c + h) ^ sw) << 2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[c & 1][i] = *reinterpret_cast<const float4 *>(ap + i * 32 * 32 + pos);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) b[c & 1][i] = *reinterpret_cast<const float4 *>(bp + i * 32 * 32 + pos);
+    };
+    auto mfmas = [&](int c, int j) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    j == 0 ? a[c & 1][tm].x : j == 1 ? a[c & 1][tm].y : j == 2 ? a[c & 1][tm].z : a[c & 1][tm].w,
+                    j == 0 ? b[c & 1][tn].x : j == 1 ? b[c & 1][tn].y : j == 2 ? b[c & 1][tn].z : b[c & 1][tn].w,
+                    acc[tm][tn], 0, 0, 0);
+    };
+    fetch(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mfmas(c, 0);
+        mfmas(c, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mid(c);
+        if (c + 1 < 4) fetch(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(c, 2);
+        mfmas(c, 3);
+    }
+}
+
 // ============================================================================================== FORWARD (glds)
 // out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ),  A = im2col view of the NHWC input, Wt = weights [Cout, K].
 template <int BM, int BN, int WM, int WN, int NS>
@@ -122,20 +164,47 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     // NS-stage DMA pipeline: chunk t+NS-1 is issued while chunk t is in the matrix pipe.  Loads retire in order, so
     // "at most (NS-2) chunks' worth of DMA instructions outstanding" == "chunk t has landed" — never a vmcnt(0)
     // inside the loop for NS = 3.
+    static_assert(NS == 2, "two LDS stages");
     issue(kbeg, 0);
-    if (NS == 3 && kbeg + 32 < kend) issue(kbeg + 32, 1);
-    int stage = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        if (NS == 3 && k0 + 32 < kend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BARRIER_NOFENCE();  // chunk k0 is visible to all waves, and the stage about to be refilled is no longer read
-        const int kn = k0 + (NS - 1) * 32;
-        int sn = stage + NS - 1;
-        sn = sn >= NS ? sn - NS : sn;
-        if (kn < kend) issue(kn, sn);
+    int stage = 0, k0 = kbeg;
+    if constexpr (TM * TN <= 2) {
+        // chunk k0 is multiplied out of `stage` while chunk k0+32 streams into the other stage; its DMA instructions
+        // are spread over the first three MFMA groups (mma_chunk_rows_mid).  Measured: +0..+3 % for the 64x32 wave
+        // tile, -11 % for the 64x64 one (16 MFMAs per group: the fences cost more fragment-read overlap than the DMA
+        // placement wins), which therefore keeps the burst form below.
+        for (; k0 + 32 < kend; k0 += 32, stage ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            BARRIER_NOFENCE();  // chunk k0 is visible to all waves, the stage about to be refilled is no longer read
+            const int kn = k0 + 32;
+            const uint32_t tap = fdiv((uint32_t)kn, g.dCin), c0 = (uint32_t)kn - tap * (uint32_t)g.Cin;
+            const uint32_t kh = fdiv(tap, g.dKW), kw = tap - kh * (uint32_t)g.KW;
+            const int aoff = (int)((kh * (uint32_t)g.W + kw) * (uint32_t)g.Cin + c0);
+            float *na = lds + (stage ^ 1) * STAGE, *nb = na + BM * 32;
+            const float *sa = lds + stage * STAGE;
+            mma_chunk_rows_mid<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc, [&](int c) {
+                constexpr int TOT = AI + BI, PER = (TOT + 2) / 3;
+#pragma unroll
+                for (int q = 0; q < TOT; ++q) {
+                    if (q / PER != c) continue;
+                    if (q < AI) GLDS16(asrc[q < AI ? q : 0] + aoff, na + (q * 4 + wave) * 256);
+                    else GLDS16(bsrc[q >= AI ? q - AI : 0] + kn, nb + ((q - AI) * 4 + wave) * 256);
+                }
+            });
+        }
+    } else {
+        for (; k0 + 32 < kend; k0 += 32, stage ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            BARRIER_NOFENCE();
+            issue(k0 + 32, stage ^ 1);
+            const float *sa = lds + stage * STAGE;
+            mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BARRIER_NOFENCE();
+    {
         const float *sa = lds + stage * STAGE;
         mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
-        stage = stage + 1 == NS ? 0 : stage + 1;
     }
     // epilogue: uniform base pointer + one 32-bit lane offset; the activation kind and the "tile is complete" test
     // are hoisted out of the 16*TM*TN element loop (per element: bias add, max, address add, store — the first
