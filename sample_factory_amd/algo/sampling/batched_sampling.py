@@ -130,50 +130,49 @@ class BatchedVectorEnvRunner:
         stream: the reference's double-buffered sampling, worker_num_splits / batched_sampling.py:298-388)"""
         tr, T, B, A = self.traj, self.T, self.B, self.A
         ver, deterministic, cfg = self._ver, self._deterministic, self.cfg
-        if True:  # (one step; the body keeps the indentation of the former loop)
-            rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
-            heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag=self.tag, rnn=rnn)[-1]
-            if self.masked:
-                mk = tr["obs"]["action_mask"][:, t]
-                lib.sample_write_step_masked(heads[:, 1:], self.ld, heads[:, 0], self.ld, mk, mk.stride(0), B, A, T, t,
-                                             self.sample_seed, self.global_step, self.row0, ver, deterministic,
-                                             tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
-                                             tr["policy_version"], self.env_actions)
-            elif len(self.heads) > 1:  # Tuple of Discrete spaces: one categorical per head, actions [B, H]
-                lib.sample_write_step_tuple(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, self.heads, T, t,
-                                            self.sample_seed, self.global_step, self.row0, ver, deterministic,
-                                            tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
-                                            tr["policy_version"], self.env_actions)
+        rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
+        heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag=self.tag, rnn=rnn)[-1]
+        if self.masked:
+            mk = tr["obs"]["action_mask"][:, t]
+            lib.sample_write_step_masked(heads[:, 1:], self.ld, heads[:, 0], self.ld, mk, mk.stride(0), B, A, T, t,
+                                         self.sample_seed, self.global_step, self.row0, ver, deterministic,
+                                         tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
+                                         tr["policy_version"], self.env_actions)
+        elif len(self.heads) > 1:  # Tuple of Discrete spaces: one categorical per head, actions [B, H]
+            lib.sample_write_step_tuple(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, self.heads, T, t,
+                                        self.sample_seed, self.global_step, self.row0, ver, deterministic,
+                                        tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
+                                        tr["policy_version"], self.env_actions)
+        else:
+            lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
+                                  self.global_step, self.row0, ver, deterministic, tr["actions"],
+                                  tr["action_logits"], tr["log_prob_actions"], tr["values"], tr["policy_version"],
+                                  None if self.continuous else self.env_actions, action_kind=int(self.continuous))
+        env_actions = tr["actions"][:, t] if self.continuous else self.env_actions  # Box: f32 [B, D] view
+        if self.zero_copy:
+            rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])
+        else:
+            if self.host_env is None:  # decided by what reset() returned
+                self.host_env = False
+            o, rew, term, trunc, _ = self.env.step(self._actions_to_host(env_actions) if self.host_env
+                                                   else env_actions)
+            self._store_obs(o, t + 1)
+            if self.host_env:
+                self._to_device("rew", rew, self._rew)
+                self._to_device("term", term, self._term)
+                self._to_device("trunc", trunc, self._trunc)
+                rew, term, trunc = self._rew, self._term, self._trunc
             else:
-                lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
-                                      self.global_step, self.row0, ver, deterministic, tr["actions"],
-                                      tr["action_logits"], tr["log_prob_actions"], tr["values"], tr["policy_version"],
-                                      None if self.continuous else self.env_actions, action_kind=int(self.continuous))
-            env_actions = tr["actions"][:, t] if self.continuous else self.env_actions  # Box: f32 [B, D] view
-            if self.zero_copy:
-                rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])
-            else:
-                if self.host_env is None:  # decided by what reset() returned
-                    self.host_env = False
-                o, rew, term, trunc, _ = self.env.step(self._actions_to_host(env_actions) if self.host_env
-                                                       else env_actions)
-                self._store_obs(o, t + 1)
-                if self.host_env:
-                    self._to_device("rew", rew, self._rew)
-                    self._to_device("term", term, self._term)
-                    self._to_device("trunc", trunc, self._trunc)
-                    rew, term, trunc = self._rew, self._term, self._trunc
-                else:
-                    rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
-                    term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()
-                    trunc = torch.as_tensor(trunc, dtype=torch.bool, device=self.device).contiguous()
-            lib.traj_write_env_step(rew, term, trunc, T, t, cfg.reward_scale, cfg.reward_clip, self.policy_id,
-                                    tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
-                                    self.ep_len, self.ep_stats)
-            if self.rnn:  # batched_sampling.py:332-335: next-step state = new_rnn_states * (1 - done)
-                keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
-                torch.mul(self.ac.new_rnn_states, keep, out=tr["rnn_states"][:, t + 1])
-            self.global_step += 1
+                rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
+                term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()
+                trunc = torch.as_tensor(trunc, dtype=torch.bool, device=self.device).contiguous()
+        lib.traj_write_env_step(rew, term, trunc, T, t, cfg.reward_scale, cfg.reward_clip, self.policy_id,
+                                tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
+                                self.ep_len, self.ep_stats)
+        if self.rnn:  # batched_sampling.py:332-335: next-step state = new_rnn_states * (1 - done)
+            keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
+            torch.mul(self.ac.new_rnn_states, keep, out=tr["rnn_states"][:, t + 1])
+        self.global_step += 1
 
     def set_slab(self, traj: TensorDict, carry_from: Optional[TensorDict] = None) -> None:
         """async mode: switch to another slab; its step 0 continues from the last step of `carry_from`"""
