@@ -704,15 +704,16 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 }
 
 #include "sf_nn_glds.h"
+#include "sf_nn_img.h"
 
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // resident blocks per CU of a 256-thread kernel (registers + static LDS), for grid-quantisation decisions
 template <class KernelT>
-static int occupancy_of(KernelT kern) {
+static int occupancy_of(KernelT kern, int threads = 256) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, 0) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, 0) != hipSuccess || nb < 1) nb = 2;
     (void)hipGetLastError();
     return nb;
 }
@@ -820,6 +821,50 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
     return sf_launch_status("sf_conv_fwd");
 }
 
+// ---- LDS-image forward (sf_nn_img.h): compile-time geometries (Cin, H, W, K, S, fragments per step, wave sets).
+// Nature-CNN conv3 (64 x 9 x 9, 3x3 stride 1): two independent persistent work-groups per CU, +5 % (n = 32768) / +8 %
+// (n = 4096) over k_fwd_glds.  conv2 (32 x 20 x 20, 4x4 stride 2) was measured too — X(32, 20, 20, 4, 2, 2, 2): its
+// 51 KB images allow only ONE work-group per CU, whose 8 waves all stop at the same block barrier: 110 vs 117
+// TFLOP/s, so it stays on k_fwd_glds.
+#define IMG_FWD_GEOMS(X) X(64, 9, 9, 3, 1, 2, 1)
+static int img_fwd_index(const ConvG &g, int64_t n) {
+    static const int on = getenv("SF_FWD_IMG") ? atoi(getenv("SF_FWD_IMG")) : 1;
+    if (!on || g.Cout != 64 || g.KH != g.KW || n < 512) return -1;
+    int idx = 0;
+#define X(CIN, HH, WW, KS, ST, TMF, WS)                                                          \
+    if (g.Cin == CIN && g.H == HH && g.W == WW && g.KH == KS && g.S == ST) return idx;           \
+    ++idx;
+    IMG_FWD_GEOMS(X)
+#undef X
+    return -1;
+}
+static int num_cus() {
+    static int v = 0;
+    if (!v) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        v = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    return v;
+}
+static bool launch_img_fwd(const ConvG &g, const float *in, int64_t in_stride, const float *wt, const float *bias,
+                           float *out, int64_t n, hipStream_t st) {
+    const int which = img_fwd_index(g, n);
+    if (which < 0) return false;
+    int idx = 0;
+#define X(CIN, HH, WW, KS, ST, TMF, WS)                                                                              \
+    if (which == idx) {                                                                                              \
+        /* persistent: as many work-groups as fit on the chip at once */                                            \
+        static const int bpc = occupancy_of(k_fwd_img<CIN, HH, WW, KS, ST, TMF, WS>, 256 * WS);                      \
+        k_fwd_img<CIN, HH, WW, KS, ST, TMF, WS><<<dim3(num_cus() * (bpc > 0 ? bpc : 1)), dim3(256 * WS), 0, st>>>(   \
+            in, in_stride, wt, bias, out, (int)n, g.relu);                                                           \
+    }                                                                                                                \
+    ++idx;
+    IMG_FWD_GEOMS(X)
+#undef X
+    return true;
+}
+
 // ---- glds forward (pre-transposed weights)
 static bool glds_fwd_ok(const sf_conv_desc *d) {
     return !d->in_u8 && d->Cin % 32 == 0 && d->traj_T == 0;
@@ -870,11 +915,13 @@ extern "C" int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *h_desc) {
     if (!h_desc || n <= 0 || !glds_fwd_ok(h_desc)) return 0;
     // small grids keep the split-K register-staged kernel (a 128-row tile grid must fill 256 CUs a few times over)
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
+    if (img_fwd_index(make_geom(h_desc), n) >= 0) return 1;
     return plan_fwd_t(Mtot, h_desc->Cout, h_desc->KH * h_desc->KW * h_desc->Cin).ok ? 1 : 0;
 }
 extern "C" int64_t sf_conv_fwd_t_workspace(int64_t n, const sf_conv_desc *h_desc) {
     if (!h_desc || n <= 0 || !glds_fwd_ok(h_desc)) return 0;
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
+    if (img_fwd_index(make_geom(h_desc), n) >= 0) return 0;
     const GldsFwdPlan p = plan_fwd_t(Mtot, h_desc->Cout, h_desc->KH * h_desc->KW * h_desc->Cin);
     return p.ok && p.Z > 1 ? (int64_t)sizeof(float) * p.Z * Mtot * h_desc->Cout + 256 : 0;
 }
@@ -893,6 +940,8 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     const ConvG g = make_geom(h_desc);
     const int64_t Mtot = n * g.OH * g.OW;
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd_t: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
+    if (n * in_sample_stride < ((int64_t)1 << 40) && launch_img_fwd(g, in, in_sample_stride, wt, bias, out, n, STREAM(stream)))
+        return sf_launch_status("sf_conv_fwd_t");
     GldsFwdPlan p = plan_fwd_t(Mtot, g.Cout, g.K);
     if (!p.ok) {  // not a grid sf_conv_fwd_t_supported recommends: still correct, one unsplit launch
         p.Z = 1;
@@ -1165,7 +1214,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
     } else if (op == 3) {
-        snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
+        if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1>", g.Cin, g.H, g.W, g.KH, g.S);
+        else snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
     } else if (op == 1 && mode == MODE_F32 && wgrad_glds_wanted(Mtot, g.K, g.Cout) && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {

@@ -1,0 +1,169 @@
+// LDS-image forward for the stride-S convolutions behind conv1 (Nature-CNN conv2 / conv3 and relatives):
+//   out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ),  m = (sample, oh, ow),  k = (kh*KS + kw)*CIN + c,  Cout = 64.
+//
+// The im2col DMA kernel (k_fwd_glds) moves every input element KS*KS/S^2 times through the vector-memory path (conv3:
+// 9x, conv2: 4x) plus the whole weight matrix once per 128-row tile: 3.45 KB per output row for conv3, and the DMA
+// issue is what holds it at 0.71 MFMA-busy.  Here
+//   * a work-group is PERSISTENT (one per CU) and owns a contiguous range of output rows = a contiguous run of samples;
+//     each sample's NHWC image is copied into LDS exactly once (ring of RING image slots, LDS-DMA, one sample ahead);
+//   * im2col happens in the LDS ADDRESS: lane (row = output pixel, kg) reads the 4 consecutive channels of its tap with
+//     one ds_read_b128 whose tap / channel-block part is an IMMEDIATE offset (compile-time geometry), so the k-loop has
+//     no VALU and no vector-memory instruction at all: 1 ds_read_b128 per 4 MFMAs;
+//   * the 4 waves split the 64 output channels; a wave's 16 weight columns for the WHOLE reduction live in registers
+//     (K/16 x f32x4 = 144 VGPRs for conv3), loaded once per kernel: the weight matrix is read 256 times per launch
+//     instead of once per tile (conv3 at n = 32768: 12544 times);
+//   * v_mfma_f32_16x16x4_f32: 16-row fragments, so the only padding is the last fragment of the launch.
+// LDS image layout (16-byte chunks): [channel chunk c][w-parity pw][ih][iw / S] — consecutive output pixels of a row
+// read consecutive chunks (conflict-free for any stride), and (kh, kw, c) only move the immediate.
+// Vector-memory traffic: one image per sample + 147 KB of weights per CU: 0.6 KB per output row (conv3).
+#pragma once
+
+template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS>
+struct ImgFwdGeom {
+    static constexpr int OH = (H - KS) / ST + 1, OW = (W - KS) / ST + 1, OHW = OH * OW;
+    static constexpr int K = KS * KS * CIN, KG = K / 16;  // 16-deep reduction groups (one f32x4 of weights per lane)
+    static constexpr int C4 = CIN / 4, WQ = W / ST;       // 16-byte chunks per pixel, columns per w-parity class
+    static constexpr int PLANE = ST * H * WQ;             // chunks per channel chunk
+    static constexpr int IMG_CH = C4 * PLANE;             // chunks per image
+    static constexpr int IMG_B = (IMG_CH * 16 + 1023) / 1024 * 1024;  // slot size: whole 1-KiB DMA instructions
+    // samples touched by two consecutive row blocks (the one being multiplied + the one being fetched)
+    static constexpr int BROWS = WSETS * TMF * 16;  // output rows per block step (WSETS wave sets x TMF fragments)
+    static constexpr int RING = (2 * BROWS - 2) / OHW + 2;
+    static_assert(CIN % 16 == 0 && W % ST == 0 && K % 16 == 0, "geometry");
+    static_assert(RING * IMG_B <= 160 * 1024, "LDS");
+};
+
+template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS>
+__global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restrict__ in, int64_t in_stride,
+                                                    const float *__restrict__ wt, const float *__restrict__ bias,
+                                                    float *__restrict__ out, int nsamples, int act) {
+    typedef ImgFwdGeom<CIN, H, W, KS, ST, TMF, WSETS> G;
+    constexpr int NW = 4 * WSETS, TB = TMF * WSETS;  // waves per block, fragments per block step
+    constexpr int OW = G::OW, OHW = G::OHW, K = G::K, KG = G::KG, WQ = G::WQ, PLANE = G::PLANE, RING = G::RING;
+    constexpr int IMG_B = G::IMG_B, N = 64;
+    __shared__ __attribute__((aligned(1024))) char ring[RING * IMG_B];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, kg = lane >> 4, n = (wave & 3) * 16 + col, wset = wave >> 2;
+    const int64_t Mtot = (int64_t)nsamples * OHW;
+    // ---- this work-group's rows: a contiguous run of 16-row fragments
+    const int total_frags = (int)((Mtot + 15) >> 4);
+    const int per = (total_frags + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int f_beg = (int)blockIdx.x * per, f_end = min(total_frags, f_beg + per);
+    if (f_beg >= f_end) return;
+    // ---- weights of this wave's 16 columns, whole reduction: lane (col, kg) holds Wt[n][16g + 4kg .. +3]
+    f32x4 breg[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+        breg[g] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(wt + (int64_t)n * K + 16 * g + 4 * kg, 16));
+    const float bv = bias ? bias[n] : 0.f;
+
+    // ---- image loader: sample s -> slot s % RING; the 4 waves share the 1-KiB DMA instructions of an image.  The
+    // per-lane source offsets of this wave's instructions are the same for every image: decoded once.
+    constexpr int NDMA = IMG_B / 1024, NI = (NDMA + NW - 1) / NW;
+    int srcoff[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        int q = (wave + NW * j) * 64 + lane;  // chunk index inside the slot: (c, pw, ih, iwq)
+        q = q < G::IMG_CH ? q : 0;           // slot padding: any valid address
+        const int c = q / PLANE, r0 = q - c * PLANE, pw = r0 / (H * WQ), r1 = r0 - pw * (H * WQ);
+        const int ih = r1 / WQ, iwq = r1 - ih * WQ;
+        srcoff[j] = (ih * W + iwq * ST + pw) * CIN + c * 4;
+    }
+    auto load_image = [&](int s) {
+        const float *img = in + (int64_t)(s < nsamples ? s : nsamples - 1) * in_stride;
+        char *dst = ring + (s % RING) * IMG_B;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (wave + NW * j < NDMA) GLDS16(img + srcoff[j], dst + (wave + NW * j) * 1024);
+    };
+    const uint32_t M32 = (uint32_t)Mtot;  // the launcher guarantees Mtot < 2^31
+    auto last_sample = [&](int fb, int nf) {  // last sample a block of nf fragments starting at fragment fb touches
+        uint32_t m = (uint32_t)(fb + nf) * 16u - 1u;
+        m = m < M32 ? m : M32 - 1u;
+        return (int)(m / (uint32_t)OHW);
+    };
+    int loaded = (int)(((uint32_t)f_beg * 16u) / (uint32_t)OHW);  // next sample to fetch
+    {
+        const int hi = last_sample(f_beg, min(TB, f_end - f_beg));
+        for (; loaded <= hi; ++loaded) load_image(loaded);
+    }
+    // the finished block is stored during the NEXT block's MFMA phase: a store issued right before the s_waitcnt
+    // vmcnt(0) of the block barrier would put its whole drain latency in front of every block (one wave per SIMD:
+    // nothing else to run meanwhile)
+    f32x4 pend[TMF];
+    int pend_fb = -1, pend_nf = 0;
+    auto store_pend = [&]() {
+        float *ob = out + ((int64_t)pend_fb * 16 + 4 * kg) * N + n;
+        const int rows_left = (int)(M32 - ((uint32_t)pend_fb * 16u + 4u * (uint32_t)kg));
+#pragma unroll
+        for (int f = 0; f < TMF; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (f < pend_nf && f * 16 + r < rows_left) ob[(f * 16 + r) * N] = pend[f][r];
+    };
+    for (int fb0 = f_beg; fb0 < f_end; fb0 += TB) {
+        const int fb = fb0 + wset * TMF;                     // this wave set's fragments: fb .. fb + nf - 1
+        const int nf = max(0, min(TMF, f_end - fb));         // (0: nothing left for this set in the last step)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // this block's images have landed; the previous block's reads are over
+        if (fb0 + TB < f_end) {  // fetch what the NEXT step needs beyond what is there (never a slot still in use)
+            const int hi = last_sample(fb0 + TB, min(TB, f_end - fb0 - TB));
+            for (; loaded <= hi; ++loaded) load_image(loaded);
+        }
+        if (pend_fb >= 0) store_pend();
+        // ---- per fragment: this lane's row -> LDS address of its patch origin (+ its channel chunk kg)
+        int base[TMF];
+#pragma unroll
+        for (int f = 0; f < TMF; ++f) {
+            uint32_t m = (uint32_t)(nf > 0 ? fb + (f < nf ? f : 0) : fb0) * 16u + (uint32_t)col;
+            m = m < M32 ? m : M32 - 1u;
+            const uint32_t s = m / (uint32_t)OHW, p = m - s * (uint32_t)OHW, oh = p / (uint32_t)OW, ow = p - oh * (uint32_t)OW;
+            base[f] = (int)((s % (uint32_t)RING) * (uint32_t)IMG_B + ((uint32_t)kg * PLANE + (oh * ST) * WQ + ow) * 16u);
+        }
+        f32x4 acc[TMF];
+#pragma unroll
+        for (int f = 0; f < TMF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a[2][TMF];
+        auto fetch = [&](int g) {  // g is a compile-time constant after unrolling: the whole offset is an immediate
+            const int tap = (16 * g) / CIN, cb = ((16 * g) % CIN) / 4, kh = tap / KS, kw = tap % KS;
+            const int imm = (cb * PLANE + ((kw % ST) * H + kh) * WQ + kw / ST) * 16;
+#pragma unroll
+            for (int f = 0; f < TMF; ++f)
+                a[g & 1][f] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(ring + base[f] + imm, 16));
+        };
+        // The fragment reads of group g+1 sit in the MIDDLE of group g's MFMAs: hipcc waits with lgkmcnt(0), i.e. for the
+        // youngest read, so reads issued right in front of a group boundary expose the whole LDS latency there
+        // (measured: 18 such stalls per block = 25 % of the block with one wave per SIMD).
+        fetch(0);
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int f = 0; f < TMF; ++f)
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][f][j], breg[g][j], acc[f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < KG) fetch(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 2; j < 4; ++j)
+#pragma unroll
+                for (int f = 0; f < TMF; ++f)
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][f][j], breg[g][j], acc[f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue into the parking registers: pend[f][r] = out[(fb + f)*16 + 4*kg + r][n]
+        auto park = [&](auto kc) {
+            constexpr int KIND = decltype(kc)::value;
+#pragma unroll
+            for (int f = 0; f < TMF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pend[f][r] = act_fwd_c<KIND>(acc[f][r] + bv, act);
+        };
+        if (act == 1) park(std::integral_constant<int, 1>{});
+        else park(std::integral_constant<int, -1>{});
+        pend_fb = fb;
+        pend_nf = nf;
+    }
+    if (pend_fb >= 0) store_pend();
+}

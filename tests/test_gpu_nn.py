@@ -1297,3 +1297,40 @@ def test_runner_plugin_hooks_observer_msg_handlers_training_info(lib):
     assert sum(m["episodes"] for m, _ in episodic) >= 1
     assert len(runner.policy_avg_stats["reward"][0]) == len(episodic)
     assert all(m["len"] >= 1 for m, _ in episodic)
+
+
+@pytest.mark.parametrize("n,act", [(512, 1), (777, 2), (4099, 1), (600, 0)])
+def test_lds_image_forward_conv3_vs_torch(lib, n, act):
+    """sf_nn_img.h (persistent work-groups, sample images resident in an LDS ring, im2col in the LDS address, weights in
+    registers) takes the 64 x 9 x 9 / 3x3 geometry from n = 512 up: ragged last fragment (n * 49 is not a multiple of
+    16), fewer fragments than resident work-groups, every activation kind, result equal to the im2col kernel's."""
+    Cin, H, W, Cout, K, S = 64, 9, 9, 64, 3, 1
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn((n, Cin, H, W), generator=g)
+    d = desc(lib, Cin, H, W, Cout, K, S)
+    d.relu = act
+    assert lib.conv_kernel_name(3, n, d).startswith("k_fwd_img<64, 9, 9, 3, 1"), lib.conv_kernel_name(3, n, d)
+    x_dev = x.permute(0, 2, 3, 1).contiguous().cuda()
+    w_ref = torch.randn((Cout, Cin, K, K), generator=g) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    wk = to_kmajor(w_ref, 0).cuda()
+    wt = wk.t().contiguous()
+    out = torch.full((n * d.OH * d.OW + 7, Cout), 7.0, device="cuda")  # guard rows behind the last one
+    assert lib.conv_fwd_t_supported(n, d) and lib.conv_fwd_t_workspace(n, d) == 0
+    lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out, n, d)
+    pre = F.conv2d(x, w_ref, b, stride=S)
+    ref = F.relu(pre) if act == 1 else torch.tanh(pre) if act == 2 else pre
+    got = out[:n * d.OH * d.OW].view(n, d.OH, d.OW, Cout).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    assert (out[n * d.OH * d.OW:] == 7.0).all(), "rows past the end must not be written"
+    out_old = torch.empty((n * d.OH * d.OW, Cout), device="cuda")
+    lib.conv_fwd(x_dev, Cin * H * W, None, 0, wk, b.cuda(), out_old, n, d)
+    assert (out[:n * d.OH * d.OW] - out_old).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    # strided samples (a view into a larger buffer) and no bias
+    big = torch.randn((n, 2, H, W, Cin), generator=g).cuda()
+    out2 = torch.empty((n * d.OH * d.OW, Cout), device="cuda")
+    lib.conv_fwd_t(big[:, 1], 2 * Cin * H * W, wt, None, out2, n, d)
+    pre2 = F.conv2d(big[:, 1].permute(0, 3, 1, 2).cpu(), w_ref, None, stride=S)
+    ref2 = F.relu(pre2) if act == 1 else torch.tanh(pre2) if act == 2 else pre2
+    got2 = out2.view(n, d.OH, d.OW, Cout).permute(0, 3, 1, 2).cpu()
+    assert (got2 - ref2).abs().max().item() < 3e-5 * max(1.0, ref2.abs().max().item())
