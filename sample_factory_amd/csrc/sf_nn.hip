@@ -821,17 +821,19 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
     return sf_launch_status("sf_conv_fwd");
 }
 
-// ---- LDS-image forward (sf_nn_img.h): compile-time geometries (Cin, H, W, K, S, fragments per step, wave sets).
-// Nature-CNN conv3 (64 x 9 x 9, 3x3 stride 1): two independent persistent work-groups per CU, +5 % (n = 32768) / +8 %
-// (n = 4096) over k_fwd_glds.  conv2 (32 x 20 x 20, 4x4 stride 2) was measured too — X(32, 20, 20, 4, 2, 2, 2): its
-// 51 KB images allow only ONE work-group per CU, whose 8 waves all stop at the same block barrier: 110 vs 117
-// TFLOP/s, so it stays on k_fwd_glds.
-#define IMG_FWD_GEOMS(X) X(64, 9, 9, 3, 1, 2, 1)
+// ---- LDS-image forward (sf_nn_img.h): compile-time geometries (Cin, H, W, K, S, fragments per step, wave sets, output
+// rows per unit).  Nature-CNN conv3 (64 x 9 x 9, 3x3 stride 1, whole images): two independent persistent work-groups
+// per CU, +5 % (n = 32768) / +8 % (n = 4096) over k_fwd_glds.  conv2 (32 x 20 x 20, 4x4 stride 2) was measured in two
+// forms and stays on k_fwd_glds: whole 51 KB images — X(32, 20, 20, 4, 2, 2, 2, 9) — allow only ONE
+// work-group per CU whose 8 waves all stop at the same block barrier (110 vs 117 TFLOP/s); strips of 3 output rows —
+// X(32, 20, 20, 4, 2, 2, 1, 3), 20 KB per strip, two work-groups per CU — reach 115: a third more image bytes (strip
+// overlap), 2-way bank conflicts where a fragment wraps to the next output row, fewer MFMAs per block step.
+#define IMG_FWD_GEOMS(X) X(64, 9, 9, 3, 1, 2, 1, 7)
 static int img_fwd_index(const ConvG &g, int64_t n) {
     static const int on = getenv("SF_FWD_IMG") ? atoi(getenv("SF_FWD_IMG")) : 1;
     if (!on || g.Cout != 64 || g.KH != g.KW || n < 512) return -1;
     int idx = 0;
-#define X(CIN, HH, WW, KS, ST, TMF, WS)                                                          \
+#define X(CIN, HH, WW, KS, ST, TMF, WS, R)                                                       \
     if (g.Cin == CIN && g.H == HH && g.W == WW && g.KH == KS && g.S == ST) return idx;           \
     ++idx;
     IMG_FWD_GEOMS(X)
@@ -852,11 +854,12 @@ static bool launch_img_fwd(const ConvG &g, const float *in, int64_t in_stride, c
     const int which = img_fwd_index(g, n);
     if (which < 0) return false;
     int idx = 0;
-#define X(CIN, HH, WW, KS, ST, TMF, WS)                                                                              \
+#define X(CIN, HH, WW, KS, ST, TMF, WS, R)                                                                           \
     if (which == idx) {                                                                                              \
         /* persistent: as many work-groups as fit on the chip at once */                                            \
-        static const int bpc = occupancy_of(k_fwd_img<CIN, HH, WW, KS, ST, TMF, WS>, 256 * WS);                      \
-        k_fwd_img<CIN, HH, WW, KS, ST, TMF, WS><<<dim3(num_cus() * (bpc > 0 ? bpc : 1)), dim3(256 * WS), 0, st>>>(   \
+        static const int bpc = occupancy_of(k_fwd_img<CIN, HH, WW, KS, ST, TMF, WS, R>, 256 * WS);                      \
+        if (getenv("SF_DEBUG_IMG")) fprintf(stderr, "k_fwd_img R=%d: %d work-groups per CU\n", R, bpc);                 \
+        k_fwd_img<CIN, HH, WW, KS, ST, TMF, WS, R><<<dim3(num_cus() * (bpc > 0 ? bpc : 1)), dim3(256 * WS), 0, st>>>(   \
             in, in_stride, wt, bias, out, (int)n, g.relu);                                                           \
     }                                                                                                                \
     ++idx;
@@ -1214,7 +1217,7 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
     } else if (op == 3) {
-        if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1>", g.Cin, g.H, g.W, g.KH, g.S);
+        if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1, %d>", g.Cin, g.H, g.W, g.KH, g.S, g.OH);
         else snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");

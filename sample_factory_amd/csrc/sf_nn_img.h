@@ -18,33 +18,38 @@
 // Vector-memory traffic: one image per sample + 147 KB of weights per CU: 0.6 KB per output row (conv3).
 #pragma once
 
-template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS>
+// R = output rows per UNIT: a unit is a horizontal strip of one sample (R = OH: the whole image).  Units are numbered
+// sample-major, so output row m = unit * (R*OW) + pixel-in-strip — the same flat row space as without strips; a strip
+// needs HU = (R-1)*S + KS input rows (consecutive strips overlap by KS - S rows, loaded twice).
+template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS, int R>
 struct ImgFwdGeom {
-    static constexpr int OH = (H - KS) / ST + 1, OW = (W - KS) / ST + 1, OHW = OH * OW;
+    static constexpr int OH = (H - KS) / ST + 1, OW = (W - KS) / ST + 1, OHW = R * OW;  // rows per unit
+    static constexpr int U = OH / R, HU = (R - 1) * ST + KS;  // units per sample, input rows per unit
     static constexpr int K = KS * KS * CIN, KG = K / 16;  // 16-deep reduction groups (one f32x4 of weights per lane)
     static constexpr int C4 = CIN / 4, WQ = W / ST;       // 16-byte chunks per pixel, columns per w-parity class
-    static constexpr int PLANE = ST * H * WQ;             // chunks per channel chunk
+    static constexpr int PLANE = ST * HU * WQ;            // chunks per channel chunk
     static constexpr int IMG_CH = C4 * PLANE;             // chunks per image
     static constexpr int IMG_B = (IMG_CH * 16 + 1023) / 1024 * 1024;  // slot size: whole 1-KiB DMA instructions
     // samples touched by two consecutive row blocks (the one being multiplied + the one being fetched)
     static constexpr int BROWS = WSETS * TMF * 16;  // output rows per block step (WSETS wave sets x TMF fragments)
     static constexpr int RING = (2 * BROWS - 2) / OHW + 2;
-    static_assert(CIN % 16 == 0 && W % ST == 0 && K % 16 == 0, "geometry");
+    static_assert(CIN % 16 == 0 && W % ST == 0 && K % 16 == 0 && OH % R == 0, "geometry");
     static_assert(RING * IMG_B <= 160 * 1024, "LDS");
 };
 
-template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS>
+template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS, int R>
 __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restrict__ in, int64_t in_stride,
                                                     const float *__restrict__ wt, const float *__restrict__ bias,
                                                     float *__restrict__ out, int nsamples, int act) {
-    typedef ImgFwdGeom<CIN, H, W, KS, ST, TMF, WSETS> G;
+    typedef ImgFwdGeom<CIN, H, W, KS, ST, TMF, WSETS, R> G;
     constexpr int NW = 4 * WSETS, TB = TMF * WSETS;  // waves per block, fragments per block step
     constexpr int OW = G::OW, OHW = G::OHW, K = G::K, KG = G::KG, WQ = G::WQ, PLANE = G::PLANE, RING = G::RING;
-    constexpr int IMG_B = G::IMG_B, N = 64;
+    constexpr int IMG_B = G::IMG_B, N = 64, U = G::U, HU = G::HU;
     __shared__ __attribute__((aligned(1024))) char ring[RING * IMG_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, kg = lane >> 4, n = (wave & 3) * 16 + col, wset = wave >> 2;
-    const int64_t Mtot = (int64_t)nsamples * OHW;
+    const int nunits = nsamples * U;
+    const int64_t Mtot = (int64_t)nunits * OHW;
     // ---- this work-group's rows: a contiguous run of 16-row fragments
     const int total_frags = (int)((Mtot + 15) >> 4);
     const int per = (total_frags + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -65,12 +70,13 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
     for (int j = 0; j < NI; ++j) {
         int q = (wave + NW * j) * 64 + lane;  // chunk index inside the slot: (c, pw, ih, iwq)
         q = q < G::IMG_CH ? q : 0;           // slot padding: any valid address
-        const int c = q / PLANE, r0 = q - c * PLANE, pw = r0 / (H * WQ), r1 = r0 - pw * (H * WQ);
+        const int c = q / PLANE, r0 = q - c * PLANE, pw = r0 / (HU * WQ), r1 = r0 - pw * (HU * WQ);
         const int ih = r1 / WQ, iwq = r1 - ih * WQ;
         srcoff[j] = (ih * W + iwq * ST + pw) * CIN + c * 4;
     }
-    auto load_image = [&](int s) {
-        const float *img = in + (int64_t)(s < nsamples ? s : nsamples - 1) * in_stride;
+    auto load_image = [&](int s) {  // s: unit index
+        const int u = s < nunits ? s : nunits - 1, smp = u / U, strip = u - smp * U;
+        const float *img = in + (int64_t)smp * in_stride + strip * (R * ST * W * CIN);
         char *dst = ring + (s % RING) * IMG_B;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
         f32x4 a[2][TMF];
         auto fetch = [&](int g) {  // g is a compile-time constant after unrolling: the whole offset is an immediate
             const int tap = (16 * g) / CIN, cb = ((16 * g) % CIN) / 4, kh = tap / KS, kw = tap % KS;
-            const int imm = (cb * PLANE + ((kw % ST) * H + kh) * WQ + kw / ST) * 16;
+            const int imm = (cb * PLANE + ((kw % ST) * HU + kh) * WQ + kw / ST) * 16;
 #pragma unroll
             for (int f = 0; f < TMF; ++f)
                 a[g & 1][f] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(ring + base[f] + imm, 16));

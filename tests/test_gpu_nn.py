@@ -1309,7 +1309,7 @@ def test_lds_image_forward_conv3_vs_torch(lib, n, act):
     x = torch.randn((n, Cin, H, W), generator=g)
     d = desc(lib, Cin, H, W, Cout, K, S)
     d.relu = act
-    assert lib.conv_kernel_name(3, n, d).startswith("k_fwd_img<64, 9, 9, 3, 1"), lib.conv_kernel_name(3, n, d)
+    assert lib.conv_kernel_name(3, n, d) == "k_fwd_img<64, 9, 9, 3, 1, 2, 1, 7>", lib.conv_kernel_name(3, n, d)
     x_dev = x.permute(0, 2, 3, 1).contiguous().cuda()
     w_ref = torch.randn((Cout, Cin, K, K), generator=g) / np.sqrt(Cin * K * K)
     b = torch.randn(Cout, generator=g) * 0.1
