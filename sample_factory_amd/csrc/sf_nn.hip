@@ -719,6 +719,16 @@ static int occupancy_of(KernelT kern, int threads = 256) {
 }
 
 
+static int num_cus() {
+    static int v = 0;
+    if (!v) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        v = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    return v;
+}
+
 static int pick_mode(const ConvG &g) {
     if (!g.vecA || !g.vecB) return MODE_GENERIC;
     return g.in_u8 ? MODE_U8 : MODE_F32;
@@ -797,11 +807,22 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
     static const int img_on = getenv("SF_CONV1_IMG") ? atoi(getenv("SF_CONV1_IMG")) : 1;
     if (img_on && conv1_img_ok(g, mode, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0) {
         const unsigned lds_bytes = (unsigned)(2 * 4 * 20 * 84 * sizeof(float));  // [SMP][Cin][RS][W] f32
+        // persistent work-groups: as many as are resident at once (two per CU: 53.8 KB of LDS each), each walks the
+        // sample pairs b, b + grid, ...
+        static int bpc = 0;
+        if (!bpc) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_conv_u8_img<2, 4, 5, 16, false>, 256, lds_bytes) !=
+                    hipSuccess || bpc < 1)
+                bpc = 2;
+            (void)hipGetLastError();
+        }
+        const int64_t npairs = cdiv64(n, 2);
+        const unsigned grid_img = (unsigned)(npairs < (int64_t)num_cus() * bpc ? npairs : (int64_t)num_cus() * bpc);
         if (g.sub_mean != 0.f)
-            k_conv_u8_img<2, 4, 5, 16, true><<<dim3(cdiv64(n, 2)), dim3(256), lds_bytes, st>>>(
+            k_conv_u8_img<2, 4, 5, 16, true><<<dim3(grid_img), dim3(256), lds_bytes, st>>>(
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
         else
-            k_conv_u8_img<2, 4, 5, 16, false><<<dim3(cdiv64(n, 2)), dim3(256), lds_bytes, st>>>(
+            k_conv_u8_img<2, 4, 5, 16, false><<<dim3(grid_img), dim3(256), lds_bytes, st>>>(
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
         return sf_launch_status("sf_conv_fwd");
     }
@@ -839,15 +860,6 @@ static int img_fwd_index(const ConvG &g, int64_t n) {
     IMG_FWD_GEOMS(X)
 #undef X
     return -1;
-}
-static int num_cus() {
-    static int v = 0;
-    if (!v) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        v = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
-    }
-    return v;
 }
 static bool launch_img_fwd(const ConvG &g, const float *in, int64_t in_stride, const float *wt, const float *bias,
                            float *out, int64_t n, hipStream_t st) {

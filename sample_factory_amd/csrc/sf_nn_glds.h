@@ -631,7 +631,14 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
     constexpr int W4 = W >> 2;            // 4-byte words per input row
     const int words = Cin * RS * W4;     // u32 words per strip and sample
     constexpr int NLD = 7;               // u32 loads per thread, sample and strip (launcher: words <= 256 * NLD)
-    const int s0 = blockIdx.x * SMP;
+    // PERSISTENT work-groups: block b takes the sample pairs b, b + gridDim.x, ... — the 64 weight registers, the tap
+    // table and the strip decode below are set up once per work-group instead of once per pair, and the byte prefetch
+    // runs across pair boundaries.
+    constexpr int nstrips = OH / R;
+    const int npairs = (nsamples + SMP - 1) / SMP;
+    const int my_pairs = (int)blockIdx.x < npairs ? (npairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total_units = my_pairs * nstrips;  // unit = (local pair, strip)
+    if (total_units == 0) return;
     // ---- per-thread strip words: word q -> (c, row, x4), the same for every sample of the block; the sample bases
     // are wave-uniform, so a load is "SGPR base + 32-bit VGPR offset"
     int gofs[NLD], lofs[NLD];
@@ -644,20 +651,19 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
         gofs[i] = (c * H + row) * W + x4 * 4;
         lofs[i] = ok ? (c * RS + row) * W + x4 * 4 : -1;
     }
-    const uint8_t *sbase[SMP];
-#pragma unroll
-    for (int z = 0; z < SMP; ++z) {
-        int sg = s0 + z;
-        sg = sg < nsamples ? sg : nsamples - 1;
-        sbase[z] = in + sample_base(g, index, offset, in_stride, (uint32_t)sg);
-    }
     uint32_t pre[SMP][NLD];
-    auto load_strip = [&](int st) {
+    auto load_strip = [&](int unit) {
+        const int lp = unit / nstrips, st = unit - lp * nstrips;
+        const int s0u = ((int)blockIdx.x + lp * (int)gridDim.x) * SMP;
         const int rowoff = st * R * S * W;
 #pragma unroll
-        for (int z = 0; z < SMP; ++z)
+        for (int z = 0; z < SMP; ++z) {
+            int sg = s0u + z;
+            sg = sg < nsamples ? sg : nsamples - 1;
+            const uint8_t *sb = in + sample_base(g, index, offset, in_stride, (uint32_t)sg);  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) pre[z][i] = *reinterpret_cast<const uint32_t *>(sbase[z] + rowoff + gofs[i]);
+            for (int i = 0; i < NLD; ++i) pre[z][i] = *reinterpret_cast<const uint32_t *>(sb + rowoff + gofs[i]);
+        }
     };
     const float sub = g.sub_mean, scl = g.inv_scale;
     auto store_strip = [&]() {
@@ -700,11 +706,12 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
         origin[t] = (smp * Cin * RS + ohl * S) * W + ow * S + lanetap;
     }
     const uint32_t voff = (uint32_t)(4 * (lane >> 4)) * (uint32_t)N + (uint32_t)col;
-    constexpr int nstrips = OH / R;
-    for (int st = 0; st < nstrips; ++st) {
+    for (int unit = 0; unit < total_units; ++unit) {
+        const int lp = unit / nstrips, st = unit - lp * nstrips;
+        const int s0 = ((int)blockIdx.x + lp * (int)gridDim.x) * SMP;
         store_strip();  // first use of the prefetched bytes
         __syncthreads();
-        if (st + 1 < nstrips) load_strip(st + 1);  // lands during the MFMA phase
+        if (unit + 1 < total_units) load_strip(unit + 1);  // lands during the MFMA phase
         f32x4 acc[TMF];
 #pragma unroll
         for (int t = 0; t < TMF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
