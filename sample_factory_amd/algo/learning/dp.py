@@ -17,6 +17,11 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    def wait(self) -> None:
+        return None
+
+
 class ReplicaGroup:
     def __init__(self, process_group=None):
         self.pg = process_group
@@ -40,6 +45,15 @@ class ReplicaGroup:
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         return self._collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.pg), t)
+
+    def all_reduce_sum_async(self, t: torch.Tensor):
+        """Start summing `t` over the replicas and return a handle whose wait() orders the CURRENT stream behind the
+        result (nccl/RCCL: the collective runs on the backend's own stream, behind everything already enqueued on the
+        current one — the DDP bucket pattern).  Staged gloo runs have nothing to overlap with: reduced on the spot."""
+        if self.world <= 1 or (self._stage and t.is_cuda) or not t.is_cuda:
+            self.all_reduce_sum(t)
+            return _Done()
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
         return self._collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.pg), t)

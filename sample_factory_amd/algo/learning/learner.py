@@ -192,6 +192,17 @@ class Learner:
         self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=self.device)
         self.adam_step_count = 0
         self._dp_reduce_each_mb = True
+        # C1 overlap: layers finish last -> first, so the tail of the flat gradient that starts at the largest layer
+        # (Nature-CNN: the 3136x512 fc matrix + heads = 95 % of the bytes) is all-reduced on the collective's own
+        # stream while conv3/conv2/conv1 are still being back-propagated; the small head of the buffer follows after the
+        # backward pass.  Every element is still summed exactly once over the same replicas.
+        self._dp_split = None
+        ac_ = self.actor_critic
+        if self.world > 1 and getattr(cfg, "dp_overlap", True) and hasattr(ac_, "_segs") and ac_.rnn_kind is None:
+            sizes = [L.K * L.N for L in ac_.layers]
+            li = int(np.argmax(sizes))
+            if li > 0 and sum(sizes[li:]) * 2 >= sum(sizes):
+                self._dp_split = li
         self._lamb = None  # (segment ids, #segments, direction scratch, per-segment sums) — built on first use
         # small device scratch
         dev = self.device
@@ -476,10 +487,21 @@ class Learner:
                 row = self._scalars[epoch * n_mb + batch_num]
                 acts, g_heads, _ = self._calculate_losses(buff, mb, num_invalids, row)
                 index, offset, n = mb
-                ac.backward(acts, g_heads, buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
-                            traj_T=buff.T)
-                # C1: one fp32 bucket; every replica's gradient already carries the GLOBAL 1/n_valid
-                self._all_reduce(ac.flat_grads)
+                # C1: every replica's gradient already carries the GLOBAL 1/n_valid -> SUM over replicas
+                if self._dp_split is not None:
+                    cut = ac._segs[self._dp_split][0]
+                    pending = []
+                    ac.backward(acts, g_heads, buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
+                                traj_T=buff.T,
+                                on_layer_done=lambda li: pending.append(self.group.all_reduce_sum_async(
+                                    ac.flat_grads[cut:])) if li == self._dp_split else None)
+                    self._all_reduce(ac.flat_grads[:cut])
+                    for work in pending:
+                        work.wait()
+                else:
+                    ac.backward(acts, g_heads, buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
+                                traj_T=buff.T)
+                    self._all_reduce(ac.flat_grads)
                 actual_lr = self.curr_lr
                 if self._global_invalids > 0:  # learner.py:788-794
                     actual_lr = self.curr_lr * (global_size - self._global_invalids) / global_size

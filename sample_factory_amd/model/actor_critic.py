@@ -598,9 +598,11 @@ class ActorCritic:
         return res
 
     def backward(self, acts: List[torch.Tensor], g_heads: torch.Tensor, obs: torch.Tensor, n: int, *,
-                 sample_stride: int, index=None, offset: int = 0, traj_T: int = 0) -> None:
+                 sample_stride: int, index=None, offset: int = 0, traj_T: int = 0, on_layer_done=None) -> None:
         """Back-propagate d(loss)/d(heads) [n, heads_ld] through the stack of the last "train" forward into
-        self.flat_grads (overwritten)."""
+        self.flat_grads (overwritten).  on_layer_done(li): called once the launches that produce layer li's weight and
+        bias gradient are enqueued (layers are finished last -> first: the data-parallel learner starts the all-reduce
+        of a finished tail of the flat gradient while the earlier layers are still being back-propagated)."""
         ctx = self._ctx["train"]
         self._role = "learner"
         inputs = ctx["inputs"]
@@ -635,3 +637,5 @@ class ActorCritic:
             if self.nonadaptive_std and li == len(self.layers) - 1:
                 A = self.num_action_params  # the log-stddev columns have no weights in the reference: keep them at zero
                 L.gw[:, 1 + A // 2:1 + A].zero_()
+            if on_layer_done is not None:
+                on_layer_done(li)
