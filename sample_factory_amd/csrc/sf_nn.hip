@@ -306,6 +306,35 @@ __device__ __forceinline__ void store_fwd_tile(const f32x16 (&acc)[TM][TN], floa
     }
 }
 
+// The same tile as v * act'(y): the data gradient of a linear layer is this forward GEMM on dY with the (untransposed)
+// weight matrix, finished with the derivative of the activation that produced the layer's input y (mk: pointer to the
+// tile's (0, 0) inside y, same [rows][N] layout).  KIND 0: no mask, 1: ReLU, < 0: run-time kind.
+template <int TM, int TN, int KIND, bool FULL>
+__device__ __forceinline__ void store_dgrad_tile(const f32x16 (&acc)[TM][TN], float *__restrict__ ob,
+                                                 const float *__restrict__ mk, uint32_t voff, int N, int rows_left,
+                                                 int cols_left, int kind) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const bool cok = FULL || tn * 32 < cols_left;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            float y[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // all 16 loads in flight before the first store
+                const int rr = tm * 32 + (r & 3) + 8 * (r >> 2);
+                const bool ok = FULL || (cok && rr < rows_left);
+                y[r] = (KIND != 0 && ok) ? (mk + (int64_t)rr * N + tn * 32)[voff] : 1.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = tm * 32 + (r & 3) + 8 * (r >> 2);
+                const float v = act_bwd_mul<KIND>(acc[tm][tn][r], y[r], kind);
+                if (FULL || (cok && rr < rows_left)) (ob + (int64_t)rr * N + tn * 32)[voff] = v;
+            }
+        }
+    }
+}
+
 
 template <int BM, int BN, int WM, int WN>
 struct Tile {
@@ -942,7 +971,7 @@ extern "C" int64_t sf_conv_fwd_t_workspace(int64_t n, const sf_conv_desc *h_desc
 }
 #define GLDS_FWD(BM, BN, WM, WN, NS)                                                                           \
     k_fwd_glds<BM, BN, WM, WN, NS><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), p.Z), dim3(256), 0, st>>>(     \
-        g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial)
+        g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial, nullptr, 0)
 extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
                              int64_t n, const sf_conv_desc *h_desc, void *workspace, int64_t workspace_bytes,
                              void *stream) {
@@ -1167,6 +1196,11 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
         else k_conv_dgrad<BM, BN, WM, WN, false><<<grid, dim3(256), 0, st>>>(g, dout, w, in_act, din, n);     \
     } while (0)
 
+static sf_conv_desc linear_desc(int K, int N, int relu);
+static bool linear_dgrad_glds_ok(const ConvG &g, int64_t n) {
+    return g.H == 1 && g.W == 1 && g.KH == 1 && g.KW == 1 && g.Cout % 32 == 0 && g.Cin >= 128 &&
+           cdiv64(n, 128) * (int64_t)cdiv64(g.Cin, 128) >= 512;
+}
 extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                              const sf_conv_desc *h_desc, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_dgrad");
@@ -1184,6 +1218,17 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     hipStream_t st = STREAM(stream);
     const unsigned classes = (unsigned)(g.S * g.S);
     const bool vec = g.vecB && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0;
+    // Linear layer (1x1 on a 1x1 image): din[n, Cin] = dY[n, Cout] * W^T is the forward GEMM of the LDS-DMA kernel with
+    // the canonical [Cin, Cout] weight array AS its Cout-major operand (no transpose needed) and a mask epilogue:
+    // 128x128 tiles, 64x64 per wave (fc layer at n = 32768: 105 -> 120 TFLOP/s against the pixel-major kernel).
+    static const int lin_on = getenv("SF_DGRAD_LINEAR") ? atoi(getenv("SF_DGRAD_LINEAR")) : 1;
+    if (lin_on && linear_dgrad_glds_ok(g, n) && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+        sf_conv_desc d2 = linear_desc(g.Cout, g.Cin, g.relu);  // reduction = Cout, columns = Cin, relu = kind of in_act
+        const ConvG g2 = make_geom(&d2);
+        k_fwd_glds<128, 128, 2, 2, 2><<<dim3(cdiv64(n, 128), cdiv64(g.Cin, 128), 1), dim3(256), 0, st>>>(
+            g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1);
+        return sf_launch_status("sf_conv_dgrad");
+    }
     // pixel-major LDS-DMA kernel: needs enough samples to fill BM-sample row tiles and Cout % 32 == 0
     static const int pix_cfg = getenv("SF_DGRAD_PIX") ? atoi(getenv("SF_DGRAD_PIX")) : 1;
     if (pix_cfg && vec && g.Cout % 32 == 0 && n >= 1024) {
@@ -1244,7 +1289,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         const int Hc = (g.H + g.S - 1) / g.S, Wc = (g.W + g.S - 1) / g.S;
         const int64_t Mc = n * Hc * Wc;
         const char *v = g.vecB ? "true" : "false";
-        if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
+        if (g.vecB && linear_dgrad_glds_ok(g, n)) snprintf(out, cap, "k_fwd_glds<128, 128, 2, 2, 2>");
+        else if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
             snprintf(out, cap, "k_dgrad_quadrow<128, 128, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024)
             snprintf(out, cap, g.Cin <= 32 ? "k_dgrad_pix<256, 32, 4, 1>" : "k_dgrad_pix<128, 64, 2, 2>");

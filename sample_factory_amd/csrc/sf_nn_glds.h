@@ -109,7 +109,8 @@ template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                                   const float *__restrict__ wt, const float *__restrict__ bias,
                                                   float *__restrict__ out, int64_t Mtot, int k_per_split,
-                                                  float *__restrict__ partial) {
+                                                  float *__restrict__ partial, const float *__restrict__ dmask,
+                                                  int dmask_on) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
@@ -214,7 +215,18 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     const int cols_left = N - (n0 + wn * TN * 32) - (lane & 31);
     const uint32_t voff = (uint32_t)(4 * (lane >> 5)) * (uint32_t)N + (uint32_t)(lane & 31);
     const bool full = m0 + BM <= Mtot && n0 + BN <= N;
-    if (partial) {
+    if (dmask_on) {  // data gradient of a linear layer (sf_conv_dgrad): out = acc * act'(dmask), no bias
+        const float *mk = dmask ? dmask + (m0 + wm * TM * 32) * N + (n0 + wn * TN * 32) : nullptr;
+        if (!dmask) {
+            if (full) store_dgrad_tile<TM, TN, 0, true>(acc, ob, mk, voff, N, rows_left, cols_left, 0);
+            else store_dgrad_tile<TM, TN, 0, false>(acc, ob, mk, voff, N, rows_left, cols_left, 0);
+        } else if (g.relu == 1) {
+            if (full) store_dgrad_tile<TM, TN, 1, true>(acc, ob, mk, voff, N, rows_left, cols_left, 1);
+            else store_dgrad_tile<TM, TN, 1, false>(acc, ob, mk, voff, N, rows_left, cols_left, 1);
+        } else {
+            store_dgrad_tile<TM, TN, -1, false>(acc, ob, mk, voff, N, rows_left, cols_left, g.relu);
+        }
+    } else if (partial) {
         if (full) store_fwd_tile<TM, TN, 0, true>(acc, ob, voff, N, rows_left, cols_left, nullptr, lane & 31, 0);
         else store_fwd_tile<TM, TN, 0, false>(acc, ob, voff, N, rows_left, cols_left, nullptr, lane & 31, 0);
     } else if (g.relu == 1) {

@@ -142,7 +142,8 @@ def test_glds_fwd_splitk_small_grids_vs_torch(lib, geom, n, act):
 
 @pytest.mark.parametrize("geom,n", [((32, 20, 20, 64, 4, 2), 2500), ((64, 9, 9, 64, 3, 1), 2500),
                                     ((32, 11, 13, 96, 3, 2), 4100), ((96, 1, 1, 160, 1, 1), 70001),
-                                    ((32, 12, 14, 64, 3, 2), 4300)])  # last: input row/col no filter tap reaches
+                                    ((32, 12, 14, 64, 3, 2), 4300),  # input row/col no filter tap reaches
+                                    ((384, 1, 1, 160, 1, 1), 33001)])  # linear layer: dgrad = masked forward GEMM
 def test_glds_fwd_dgrad_large_grids_vs_torch(lib, geom, n):
     """the gfx950 LDS-DMA kernels (sf_nn_glds.h) only take launches that fill the chip: forward through
     sf_conv_fwd_t (transposed weights), data gradient through sf_conv_dgrad's internal dispatch.  Odd sizes, boundary
