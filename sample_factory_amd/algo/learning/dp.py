@@ -50,7 +50,7 @@ class ReplicaGroup:
         """Start summing `t` over the replicas and return a handle whose wait() orders the CURRENT stream behind the
         result (nccl/RCCL: the collective runs on the backend's own stream, behind everything already enqueued on the
         current one — the DDP bucket pattern).  Staged gloo runs have nothing to overlap with: reduced on the spot."""
-        if self.world <= 1 or (self._stage and t.is_cuda) or not t.is_cuda:
+        if self.world <= 1 or (self._stage and t.is_cuda):
             self.all_reduce_sum(t)
             return _Done()
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

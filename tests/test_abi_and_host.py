@@ -208,3 +208,51 @@ def test_slice_merger_and_buffer_mgr_match_reference(golden_json):
     assert b.on_new_trajectories(s[2]) == [slice(256, 512)]
     assert b.on_training_batch_released(slice(0, 256)) == 2 and len(bm.traj_buffer_queue) == 2
     assert bm.get_free_slice() == slice(0, 128)
+
+
+def test_env_plugin_interfaces_follow_the_wrapper_chain():
+    """envs/env_utils.py:60-133 of the reference: the optional interfaces are looked up through the gym-style `.env`
+    wrapper chain down to `.unwrapped`."""
+    from sample_factory_amd.envs.env_utils import (RewardShapingInterface, TrainingInfoInterface, find_training_info_interface,
+                                                   find_wrapper_interface, get_default_reward_shaping, set_reward_shaping,
+                                                   set_training_info)
+
+    class Base:
+        def __init__(self):
+            self.unwrapped = self
+
+    class Shaped(Base, RewardShapingInterface):
+        def __init__(self):
+            Base.__init__(self)
+            self.scheme, self.idx = dict(kill=1.0), None
+
+        def get_default_reward_shaping(self):
+            return dict(self.scheme)
+
+        def set_reward_shaping(self, reward_shaping, agent_idx):
+            self.scheme, self.idx = dict(reward_shaping), agent_idx
+
+    class Wrapper:
+        def __init__(self, env):
+            self.env, self.unwrapped = env, env.unwrapped
+
+    class Curriculum(Wrapper, TrainingInfoInterface):
+        def __init__(self, env):
+            Wrapper.__init__(self, env)
+            TrainingInfoInterface.__init__(self)
+
+    inner = Shaped()
+    env = Wrapper(Curriculum(Wrapper(inner)))
+    assert find_wrapper_interface(env, RewardShapingInterface) is inner
+    assert get_default_reward_shaping(env) == dict(kill=1.0)
+    set_reward_shaping(env, dict(kill=2.0), slice(0, 4))
+    assert inner.scheme == dict(kill=2.0) and inner.idx == slice(0, 4)
+    set_reward_shaping(env, None, 0)  # no-op
+    assert inner.idx == slice(0, 4)
+    iface = find_training_info_interface(env)
+    assert isinstance(iface, Curriculum)
+    set_training_info(iface, dict(approx_total_training_steps=123))
+    assert iface.training_info["approx_total_training_steps"] == 123
+    plain = Wrapper(Base())
+    assert find_training_info_interface(plain) is None and get_default_reward_shaping(plain) is None
+    set_training_info(None, dict(approx_total_training_steps=1))  # tolerated, as in the reference

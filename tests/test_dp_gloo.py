@@ -58,7 +58,15 @@ def _worker(rank, world, port, out_dir):
     # (2) the flat gradient bucket: heads wgrad of this shard, SUM-all-reduced (each shard already carries 1/n_global)
     g_heads = np.concatenate([out["grad_values"][:, None], out["grad_params"]], 1)
     bucket = torch.from_numpy(s["feats"].T.astype(np.float64) @ g_heads.astype(np.float64))
+    bucket2 = bucket.clone().reshape(-1)
     grp.all_reduce_sum(bucket)
+    # (2b) the learner's two-bucket form: the tail goes out asynchronously (while the backward pass would still be
+    # producing the head), then the head, then wait — every element summed once, same result
+    cut = bucket2.numel() // 3
+    work = grp.all_reduce_sum_async(bucket2[cut:])
+    grp.all_reduce_sum(bucket2[:cut])
+    work.wait()
+    assert torch.equal(bucket2, bucket.reshape(-1))
     # (3) additive loss sums + max KL
     n_loc = float(va.sum())
     sums = torch.tensor([-out["policy_loss"] * mom[2].item(), 0.0, 0.0, 0.0, out["kl_max"], n_loc, 0.0, 0.0],
