@@ -129,33 +129,38 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
         f32x4 acc[TMF];
 #pragma unroll
         for (int f = 0; f < TMF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 a[2][TMF];
-        auto fetch = [&](int g) {  // g is a compile-time constant after unrolling: the whole offset is an immediate
+        // k-groups are processed in PAIRS: the fragment reads of the next pair sit between the two groups of the
+        // current pair.  hipcc waits with lgkmcnt(0), i.e. for the youngest read, so what matters is the distance
+        // from the LAST read to the wait: one whole group of 4*TMF MFMAs here (first version: reads right in front of
+        // the wait, 18 exposed LDS latencies per block step = 25 % of the step with one wave per SIMD).
+        static_assert(KG % 2 == 0, "k-groups come in pairs");
+        f32x4 a[2][2][TMF];
+        auto fetch = [&](int g, int slot) {  // g is a compile-time constant after unrolling: the offset is an immediate
             const int tap = (16 * g) / CIN, cb = ((16 * g) % CIN) / 4, kh = tap / KS, kw = tap % KS;
             const int imm = (cb * PLANE + ((kw % ST) * HU + kh) * WQ + kw / ST) * 16;
 #pragma unroll
             for (int f = 0; f < TMF; ++f)
-                a[g & 1][f] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(ring + base[f] + imm, 16));
+                a[slot][g & 1][f] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(ring + base[f] + imm, 16));
         };
-        // The fragment reads of group g+1 sit in the MIDDLE of group g's MFMAs: hipcc waits with lgkmcnt(0), i.e. for the
-        // youngest read, so reads issued right in front of a group boundary expose the whole LDS latency there
-        // (measured: 18 such stalls per block = 25 % of the block with one wave per SIMD).
-        fetch(0);
+        auto mfmas = [&](int g, int slot) {
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int f = 0; f < TMF; ++f)
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][f][j], breg[g][j], acc[f], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 1 < KG) fetch(g + 1);
-            __builtin_amdgcn_sched_barrier(0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][g & 1][f][j], breg[g][j], acc[f], 0, 0, 0);
+        };
+        fetch(0, 0);
+        fetch(1, 0);
 #pragma unroll
-            for (int j = 2; j < 4; ++j)
-#pragma unroll
-                for (int f = 0; f < TMF; ++f)
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][f][j], breg[g][j], acc[f], 0, 0, 0);
+        for (int gp = 0; gp < KG / 2; ++gp) {
+            mfmas(2 * gp, gp & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gp + 1 < KG / 2) {
+                fetch(2 * gp + 2, (gp + 1) & 1);
+                fetch(2 * gp + 3, (gp + 1) & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(2 * gp + 1, gp & 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue into the parking registers: pend[f][r] = out[(fb + f)*16 + 4*kg + r][n]
