@@ -67,8 +67,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group("nccl")  # RCCL on ROCm
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        torch.distributed.init_process_group(os.environ.get("SF_DP_BACKEND", "nccl"))  # nccl = RCCL on ROCm (gloo: tests)
 
     register_env("synthetic_atari", make_synthetic_env)
     B, T = args.envs, args.rollout
