@@ -272,6 +272,12 @@ int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index
 int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                   const sf_conv_desc *h_desc, void *stream);
 
+/* action means squashed to [-scale, scale] (continuous_tanh_scale > 0, model/action_parameterization.py:62-66), in
+ * place on columns [col0, col0+ncols) of a row-major [n, ld] matrix: y = tanh(x/scale)*scale; backward: g *= 1-(y/scale)^2
+ * with y the squashed output. */
+int sf_tanh_scale_fwd(float *x, int ld, int64_t n, int col0, int ncols, float scale, void *stream);
+int sf_tanh_scale_bwd(float *g, const float *y, int ld, int64_t n, int col0, int ncols, float scale, void *stream);
+
 /* Forward for the dense hot layers through the gfx950 LDS-DMA path: same result contract as sf_conv_fwd, but the
  * weights are given Cout-major, wt[Cout, K] (sf_transpose of the canonical [K, Cout] array), the input must be f32
  * NHWC with Cin % 32 == 0, dense samples (no index gather), 16-byte aligned.  sf_conv_fwd_t_supported says whether a

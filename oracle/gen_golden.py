@@ -524,6 +524,9 @@ def main():
         gen_train("mlp_lamb", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2, extra=["--optimizer=lamb"])
         gen_train("mlp_nonadaptive", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2, box_dims=3,
                   extra=["--adaptive_stddev=False", "--initial_stddev=0.7", "--kl_loss_coeff=0.1"])
+        gen_train("mlp_nonadaptive_tanh", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2, box_dims=3,
+                  extra=["--adaptive_stddev=False", "--initial_stddev=0.7", "--kl_loss_coeff=0.1",
+                         "--continuous_tanh_scale=2.0"])
         cnn_obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 36, 36), np.uint8)})
         gen_train("cnn36", cnn_obs, ["--encoder_conv_architecture=convnet_atari", "--nonlinearity=relu",
                                      "--obs_scale=255.0", "--normalize_input=False",

@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 5; }
+extern "C" int sf_abi_version(void) { return 6; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -1651,4 +1651,32 @@ extern "C" int sf_rows_add_scale(const float *a, const float *b, const float *ke
     SF_REQUIRE(a && y && C > 0 && H > 0, "sf_rows_add_scale: bad args");
     k_rows_add_scale<<<dim3((unsigned)((C * H + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(a, b, keep, C, H, y);
     return sf_launch_status("sf_rows_add_scale");
+}
+
+
+// ---- ActionParameterizationContinuousNonAdaptiveStddev with continuous_tanh_scale > 0 (model/action_parameterization.py
+// :62-66): action means y = tanh(x / s) * s, in place on `ncols` columns of the heads matrix; backward g *= 1 - (y/s)^2.
+__global__ __launch_bounds__(256) void k_tanh_scale(float *__restrict__ x, float *__restrict__ gy, const float *__restrict__ y,
+                                                    int ld, int64_t n, int col0, int ncols, float s, float inv_s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * ncols; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ncols;
+        const int64_t o = r * ld + col0 + (i - r * ncols);
+        if (x) x[o] = tanhf(x[o] * inv_s) * s;
+        else { const float t = y[o] * inv_s; gy[o] *= 1.f - t * t; }
+    }
+}
+extern "C" int sf_tanh_scale_fwd(float *x, int ld, int64_t n, int col0, int ncols, float scale, void *stream) {
+    SF_REQUIRE(x && n > 0 && ncols > 0 && col0 >= 0 && col0 + ncols <= ld && scale > 0.f, "sf_tanh_scale_fwd: bad args");
+    const int64_t tot = n * ncols;
+    k_tanh_scale<<<dim3((unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096)), dim3(256), 0, STREAM(stream)>>>(
+        x, nullptr, nullptr, ld, n, col0, ncols, scale, 1.f / scale);
+    return sf_launch_status("sf_tanh_scale_fwd");
+}
+extern "C" int sf_tanh_scale_bwd(float *g, const float *y, int ld, int64_t n, int col0, int ncols, float scale,
+                                 void *stream) {
+    SF_REQUIRE(g && y && n > 0 && ncols > 0 && col0 >= 0 && col0 + ncols <= ld && scale > 0.f, "sf_tanh_scale_bwd: bad args");
+    const int64_t tot = n * ncols;
+    k_tanh_scale<<<dim3((unsigned)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096)), dim3(256), 0, STREAM(stream)>>>(
+        nullptr, g, y, ld, n, col0, ncols, scale, 1.f / scale);
+    return sf_launch_status("sf_tanh_scale_bwd");
 }

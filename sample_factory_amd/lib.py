@@ -43,6 +43,7 @@ SYMBOLS = [
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
     "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
+    "sf_tanh_scale_fwd", "sf_tanh_scale_bwd",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
 ]
 
@@ -433,6 +434,16 @@ def conv_fwd_t(inp, in_sample_stride, wt, bias, out, n, desc: sf_conv_desc, work
                                     ptr(workspace, "u8", "workspace"),
                                     i64(workspace.numel() if workspace is not None else 0), stream()),
                "sf_conv_fwd_t")
+
+
+def tanh_scale_fwd(x, ld, n, col0, ncols, scale) -> None:
+    _check(load().sf_tanh_scale_fwd(ptr(x, "f32", "x"), int(ld), i64(n), int(col0), int(ncols), C.c_float(scale), stream()),
+           "sf_tanh_scale_fwd")
+
+
+def tanh_scale_bwd(g, y, ld, n, col0, ncols, scale) -> None:
+    _check(load().sf_tanh_scale_bwd(ptr(g, "f32", "g"), ptr(y, "f32", "y"), int(ld), i64(n), int(col0), int(ncols),
+                                    C.c_float(scale), stream()), "sf_tanh_scale_bwd")
 
 
 def transpose(w, wt, K, N) -> None:

@@ -123,8 +123,9 @@ class ActorCritic:
         # (their weight gradient is discarded) and their BIAS is the learned vector, so params = [means | log_std] comes
         # out of the same launch and the bias gradient (column sums) is exactly d loss / d learned_stddev.
         self.nonadaptive_std = is_box(action_space) and not cfg.adaptive_stddev
-        if self.nonadaptive_std and cfg.continuous_tanh_scale > 0:
-            raise NotImplementedError("continuous_tanh_scale > 0")
+        # continuous_tanh_scale > 0 (non-adaptive case only, as in the reference): means = tanh(x / s) * s, applied in
+        # place to the mean columns of the heads matrix (sf_tanh_scale_fwd / _bwd)
+        self.tanh_scale = float(cfg.continuous_tanh_scale) if self.nonadaptive_std else 0.0
         keys = sorted(k for k in obs_space.spaces.keys() if k != "action_mask")  # obs_space_without_action_mask
         if keys != ["obs"]:
             raise NotImplementedError(f"single 'obs' key (+ optional 'action_mask') only, got {keys}")
@@ -504,6 +505,8 @@ class ActorCritic:
             if L.role == "rnn_ih":
                 x = self._rnn_sequence_fwd(li, out, n, rnn, tag) if seq else self._rnn_step(li, out, n, rnn, tag)
             stride, idx, off, tT = x.numel() // n, None, 0, 0  # elements per sample of the activation just produced
+        if self.tanh_scale > 0:  # action_parameterization.py:62-66 (col 0 = value, then the means)
+            lib.tanh_scale_fwd(acts[-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
         self._ctx = getattr(self, "_ctx", {})
         self._ctx[tag] = dict(acts=acts, inputs=inputs, first_in=first_in, rnn=rnn)
         return acts
@@ -608,6 +611,8 @@ class ActorCritic:
         inputs = ctx["inputs"]
         x0, stride0, idx0, off0, tT0 = ctx["first_in"]
         g = g_heads
+        if self.tanh_scale > 0:  # d tanh(x/s)*s / dx = 1 - (y/s)^2 on the mean columns
+            lib.tanh_scale_bwd(g_heads, ctx["acts"][-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
         chain = [li for li, L in enumerate(self.layers) if L.role != "rnn_hh"]
         for pos in range(len(chain) - 1, -1, -1):
             li = chain[pos]

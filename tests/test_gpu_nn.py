@@ -501,7 +501,7 @@ def test_learner_train_matches_reference_cnn36(lib, golden, tmp_path):
     assert "encoder.encoders.obs.enc.conv_head.0.weight" in cp["model"] and cp["model"]["returns_normalizer.count"].dtype == torch.float64
 
 
-@pytest.mark.parametrize("name", ["mlp", "mlp_inv", "mlp_lamb", "mlp_nonadaptive"])
+@pytest.mark.parametrize("name", ["mlp", "mlp_inv", "mlp_lamb", "mlp_nonadaptive", "mlp_nonadaptive_tanh"])
 def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
     """vector-observation MLP encoder with tanh (the reference's Mujoco-style model), 2 epochs / KL loss / invalid rows:
     full Learner.train vs the reference's post-training state (train_mlp*.npz)."""
@@ -519,8 +519,9 @@ def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
                       record_grad_norm=True, optimizer="lamb" if "optimizer=lamb" in str(g["argv"]) else "adam")
     obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
     action_space = spaces.Discrete(A)
-    if name == "mlp_nonadaptive":  # Box(3) with one learned log-stddev vector (action_parameterization.py:42-78)
+    if name.startswith("mlp_nonadaptive"):  # Box(3) with one learned log-stddev vector (action_parameterization.py:42-78)
         cfg.adaptive_stddev, cfg.initial_stddev = False, 0.7
+        cfg.continuous_tanh_scale = 2.0 if name.endswith("tanh") else 0.0  # means squashed to [-2, 2] (:62-66)
         action_space = spaces.Box(-1, 1, (3,), np.float32)
     env_info = EnvInfo(obs_space, action_space, E)
     pv = torch.zeros(1, dtype=torch.int32)
@@ -528,7 +529,7 @@ def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
     learner.init()
     ac = learner.actor_critic
     assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
-    if name == "mlp_nonadaptive":
+    if name.startswith("mlp_nonadaptive"):
         assert abs(float(ac.state_dict()["action_parameterization.learned_stddev"][0]) - np.log(0.7)) < 1e-6
     load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
     batch = alloc_trajectory_tensors(env_info, E, T, 1, "cuda")

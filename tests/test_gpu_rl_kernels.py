@@ -553,3 +553,25 @@ def test_no_cpu_fallback(lib):
     """the product path refuses CPU tensors instead of silently computing elsewhere"""
     with pytest.raises(lib.SfHipError):
         lib.grad_sumsq(torch.zeros(16), torch.zeros(1, dtype=torch.float64, device="cuda"))
+
+
+def test_tanh_scale_fwd_bwd_vs_torch(lib):
+    """continuous_tanh_scale (model/action_parameterization.py:62-66): y = tanh(x/s)*s on the mean columns of the
+    heads matrix, in place; backward g *= 1 - (y/s)^2 — against torch autograd; untouched columns stay bit-identical."""
+    g = torch.Generator().manual_seed(3)
+    n, ld, col0, D, s = 1000, 8, 1, 3, 2.0
+    x = (torch.randn((n, ld), generator=g) * 3).cuda()
+    xr = x.clone().requires_grad_(True)
+    yr = torch.tanh(xr[:, col0:col0 + D] / s) * s
+    gy = torch.randn((n, ld), generator=g).cuda()
+    yr.backward(gy[:, col0:col0 + D])
+    y = x.clone()
+    lib.tanh_scale_fwd(y, ld, n, col0, D, s)
+    assert (y[:, col0:col0 + D] - yr.detach()).abs().max().item() < 1e-6
+    assert torch.equal(y[:, :col0], x[:, :col0]) and torch.equal(y[:, col0 + D:], x[:, col0 + D:])
+    gx = gy.clone()
+    lib.tanh_scale_bwd(gx, y, ld, n, col0, D, s)
+    assert (gx[:, col0:col0 + D] - xr.grad[:, col0:col0 + D]).abs().max().item() < 1e-5
+    assert torch.equal(gx[:, :col0], gy[:, :col0]) and torch.equal(gx[:, col0 + D:], gy[:, col0 + D:])
+    with pytest.raises(lib.SfHipError):
+        lib.tanh_scale_fwd(y, ld, n, col0, ld, s)  # columns past the row
