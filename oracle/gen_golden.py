@@ -430,6 +430,31 @@ def gen_model_fwd():
          param_names=np.array([k for k, _ in shapes]), param_shapes=np.array([str(s) for _, s in shapes]))
 
 
+def gen_model_fwd_multi():
+    """MultiInputEncoder (model/encoder.py:33-69): image + vector observation keys, per-key normalisation
+    (utils/normalize.py:51-70: obs_scale only on "obs"), encodings concatenated in sorted key order."""
+    obs_space = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 36, 36), np.uint8),
+                                 "measurements": gym.spaces.Box(-1, 1, (5,), np.float32)})
+    cfg = make_cfg(["--encoder_conv_architecture=convnet_impala", "--nonlinearity=relu", "--obs_scale=255.0",
+                    "--normalize_input=False", "--encoder_conv_mlp_layers", "32", "--encoder_mlp_layers", "16", "16",
+                    "--rollout=4", "--batch_size=8", "--num_batches_per_epoch=1"])
+    learner, env_info = make_learner(cfg, obs_space, gym.spaces.Discrete(6), 2)
+    shapes = load_seeded(learner.actor_critic, seed=9)
+    g = torch.Generator().manual_seed(78)
+    obs = torch.randint(0, 256, (6, 4, 36, 36), generator=g, dtype=torch.uint8)
+    meas = torch.rand((6, 5), generator=g) * 2 - 1
+    ac = learner.actor_critic
+    ac.eval()
+    with torch.no_grad():
+        nobs = ac.normalize_obs({"obs": obs, "measurements": meas})
+        head = ac.forward_head(nobs)
+        res = ac.forward_tail(head, values_only=False, sample_actions=False)
+    save("model_fwd_multi", ref="model/encoder.py:33-69 MultiInputEncoder inside ActorCriticSharedWeights", param_seed=9,
+         obs=obs.numpy(), measurements=meas.numpy(), head=head.numpy(), action_logits=res["action_logits"].numpy(),
+         values=res["values"].numpy(), param_names=np.array([k for k, _ in shapes]),
+         param_shapes=np.array([str(s) for _, s in shapes]))
+
+
 def gen_minibatch_indices():
     """Learner._get_minibatches — learner.py:498-526: contiguous slices by default; shuffled = permutation of
     recurrence-aligned chunk starts expanded to full index runs, np.split into minibatches."""
@@ -545,6 +570,7 @@ def main():
                                         "--normalize_input=True"], E=16, T=8, A=6, nb=2, epochs=1)
     if "model" in which:
         gen_model_fwd()
+        gen_model_fwd_multi()
     if "host" in which:
         gen_host_logic()
     if "cfg" in which:

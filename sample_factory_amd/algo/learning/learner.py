@@ -350,7 +350,9 @@ class Learner:
         exactly where the reference mutates it (valids, values[:, -1], rewards under value_bootstrap, sanitised
         actions/log-probs).  Returns (buff, experience_size, num_invalids); buff holds FLAT [E*T] dataset arrays."""
         cfg, ac = self.cfg, self.actor_critic
-        obs = batch["obs"]["obs"]
+        # several observation keys (torch fallback model, model/torch_policy.py): the model takes {key: slab view}
+        multi = getattr(ac, "multi_key", False)
+        obs = {k: batch["obs"][k] for k in ac.obs_keys} if multi else batch["obs"]["obs"]
         E, T = batch["rewards"].shape
         N = E * T
         lib.valid_mask(batch["policy_id"], batch["policy_version"], batch["valids"], batch["actions"],
@@ -361,9 +363,9 @@ class Learner:
         if ac.obs_normalizer is not None:  # learner.py:957-961: statistics updated once per dataset, over all T+1 columns
             ac.obs_normalizer.update(obs, ac.obs_elems, E * (T + 1))
         # K9: bootstrap value of the T+1-th observation, read from the slab in place
-        last = obs[:, T]
+        last = {k: v[:, T] for k, v in obs.items()} if multi else obs[:, T]
         rnn = dict(states=batch["rnn_states"][:, T]) if cfg.use_rnn else None
-        heads = ac.forward_heads(last, E, sample_stride=obs.stride(0), tag="boot", rnn=rnn)[-1]  # learner weights
+        heads = ac.forward_heads(last, E, sample_stride=0 if multi else obs.stride(0), tag="boot", rnn=rnn)[-1]  # learner weights
         batch["values"][:, T].copy_(heads[:, 0])
         adv = torch.empty((E, T), dtype=torch.float32, device=self.device)
         ret = torch.empty((E, T), dtype=torch.float32, device=self.device)

@@ -44,8 +44,11 @@ class BatchedVectorEnvRunner:
         self.sample_seed = int(sample_seed)
         self.row0 = int(row0)  # global index of this replica's first env (Philox key of the action sampler)
         self.global_step = 0
-        self.zero_copy = hasattr(env, "step_into")
-        self.obs = traj["obs"]["obs"]
+        # observation keys besides the action mask; more than one: the model (torch fallback) takes {key: view} dicts
+        self.obs_keys = sorted(k for k in traj["obs"].keys() if k != "action_mask")
+        self.multi_key = len(self.obs_keys) > 1
+        self.zero_copy = hasattr(env, "step_into") and not self.multi_key
+        self.obs = traj["obs"]["obs" if "obs" in traj["obs"] else self.obs_keys[0]]
         self.rnn = actor_critic.rnn_kind is not None
         traj["rnn_states"].zero_()
         self._started = False
@@ -71,7 +74,7 @@ class BatchedVectorEnvRunner:
             self.env.reset_into(self.obs[:, 0])
         else:
             o, _ = self.env.reset()
-            first = o["obs"] if isinstance(o, dict) else o
+            first = (o["obs"] if "obs" in o else o[self.obs_keys[0]]) if isinstance(o, dict) else o
             self.host_env = not (isinstance(first, torch.Tensor) and first.is_cuda)
             self._store_obs(o, 0)
         self._started = True
@@ -105,7 +108,11 @@ class BatchedVectorEnvRunner:
         return stage.numpy()
 
     def _store_obs(self, o, t: int) -> None:
-        self._to_device("obs", o["obs"] if isinstance(o, dict) else o, self.obs[:, t])
+        if self.multi_key:
+            for k in self.obs_keys:
+                self._to_device("obs." + k, o[k], self.traj["obs"][k][:, t])
+        else:
+            self._to_device("obs", o["obs"] if isinstance(o, dict) else o, self.obs[:, t])
         if self.masked:
             self._to_device("mask", o["action_mask"], self.traj["obs"]["action_mask"][:, t])
 
@@ -131,7 +138,8 @@ class BatchedVectorEnvRunner:
         tr, T, B, A = self.traj, self.T, self.B, self.A
         ver, deterministic, cfg = self._ver, self._deterministic, self.cfg
         rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
-        heads = self.ac.forward_heads(self.obs[:, t], B, sample_stride=self.obs.stride(0), tag=self.tag, rnn=rnn)[-1]
+        x = {k: tr["obs"][k][:, t] for k in self.obs_keys} if self.multi_key else self.obs[:, t]
+        heads = self.ac.forward_heads(x, B, sample_stride=self.obs.stride(0), tag=self.tag, rnn=rnn)[-1]
         if self.masked:
             mk = tr["obs"]["action_mask"][:, t]
             lib.sample_write_step_masked(heads[:, 1:], self.ld, heads[:, 0], self.ld, mk, mk.stride(0), B, A, T, t,
@@ -177,9 +185,10 @@ class BatchedVectorEnvRunner:
     def set_slab(self, traj: TensorDict, carry_from: Optional[TensorDict] = None) -> None:
         """async mode: switch to another slab; its step 0 continues from the last step of `carry_from`"""
         self.traj = traj
-        self.obs = traj["obs"]["obs"]
+        self.obs = traj["obs"]["obs" if "obs" in traj["obs"] else self.obs_keys[0]]
         if carry_from is not None:
-            self.obs[:, 0].copy_(carry_from["obs"]["obs"][:, self.T])
+            for k in self.obs_keys:
+                traj["obs"][k][:, 0].copy_(carry_from["obs"][k][:, self.T])
             if self.masked:
                 traj["obs"]["action_mask"][:, 0].copy_(carry_from["obs"]["action_mask"][:, self.T])
             if self.rnn:
@@ -189,7 +198,8 @@ class BatchedVectorEnvRunner:
 
     def carry_over(self) -> None:
         """The next rollout starts from the last observation: slab obs[:, 0] <- obs[:, T] (one frame per agent)."""
-        self.obs[:, 0].copy_(self.obs[:, self.T])
+        for k in self.obs_keys:
+            self.traj["obs"][k][:, 0].copy_(self.traj["obs"][k][:, self.T])
         if self.masked:
             mk = self.traj["obs"]["action_mask"]
             mk[:, 0].copy_(mk[:, self.T])

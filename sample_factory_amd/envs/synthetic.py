@@ -153,6 +153,49 @@ class MaskedBanditEnv:
         pass
 
 
+class DictObsBanditEnv:
+    """GPU vector env whose observation is a dict of SEVERAL keys (the reference's MultiInputEncoder case,
+    model/encoder.py:33-69): "obs" = a random u8 image (pure distraction), "measurements" = one-hot of the rewarded
+    action.  The policy can only learn the bandit through the vector key."""
+
+    def __init__(self, num_agents=64, num_actions=4, image_shape=(4, 36, 36), seed=0, device="cuda"):
+        self.num_agents, self.A, self.image_shape = int(num_agents), int(num_actions), tuple(image_shape)
+        self.observation_space = spaces.Dict({"obs": spaces.Box(0, 255, self.image_shape, np.uint8),
+                                              "measurements": spaces.Box(0, 1, (self.A,), np.float32)})
+        self.action_space = spaces.Discrete(self.A)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self._draw()
+
+    def _draw(self):
+        self.target = torch.randint(0, self.A, (self.num_agents,), generator=self.gen, device=self.device)
+        self.img = torch.randint(0, 256, (self.num_agents,) + self.image_shape, generator=self.gen, device=self.device,
+                                 dtype=torch.int32).to(torch.uint8)
+
+    def _out(self):
+        return {"obs": self.img, "measurements": torch.nn.functional.one_hot(self.target, self.A).float()}
+
+    def reset(self, **kwargs):
+        self._draw()
+        return self._out(), {}
+
+    def step(self, actions):
+        a = torch.as_tensor(actions, device=self.device).reshape(-1).long()
+        rew = (a == self.target).float()
+        term = torch.ones(self.num_agents, dtype=torch.bool, device=self.device)  # one-step episodes, auto-reset
+        self._draw()
+        return self._out(), rew, term, torch.zeros_like(term), {}
+
+    def close(self):
+        pass
+
+
+def make_dict_obs_bandit_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    n = getattr(cfg, "synthetic_num_agents", 64) if cfg is not None else 64
+    return DictObsBanditEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0)
+
+
 def make_masked_bandit_env(full_env_name, cfg=None, env_config=None, render_mode=None):
     n = getattr(cfg, "synthetic_num_agents", 64) if cfg is not None else 64
     return MaskedBanditEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0)

@@ -55,10 +55,13 @@ def global_model_factory() -> ModelFactory:
 def create_actor_critic(cfg, obs_space, action_space, device, all_reduce=None):
     """model/actor_critic.py:337-342 create_actor_critic: the native model unless the user registered something"""
     f = global_model_factory()
-    if f.is_default():
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter, build_torch_actor_critic, obs_keys_of
+    if f.is_default() and len(obs_keys_of(obs_space)) <= 1:
         from sample_factory_amd.model.actor_critic import ActorCritic
         return ActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
-    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter, build_torch_actor_critic
+    # observation dicts of several keys (model/encoder.py:33-69, MultiInputEncoder: one encoder per key, concatenated)
+    # run the default architecture in torch: same fallback as a user-registered model, everything around the network
+    # stays native
     if f.make_actor_critic_func is not None:
         module = f.make_actor_critic_func(cfg, obs_space, action_space)
     else:

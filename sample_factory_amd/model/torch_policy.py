@@ -27,10 +27,14 @@ class TorchObsNormalizer:
     """utils/normalize.py:24-70 + running_mean_std.py:22-136 in torch (the native normaliser writes NHWC for the native
     conv stack; user modules expect the reference's NCHW float observations)."""
 
-    def __init__(self, cfg, obs_shape, device, all_reduce=None, world: int = 1):
-        self.sub_mean = float(cfg.obs_subtract_mean) if abs(cfg.obs_subtract_mean) > 1e-5 else 0.0
-        self.scale = float(cfg.obs_scale)
-        self.running = bool(cfg.normalize_input)
+    def __init__(self, cfg, obs_shape, device, all_reduce=None, world: int = 1, key: str = "obs"):
+        # obs_subtract_mean / obs_scale touch the "obs" key only (utils/normalize.py:59-65); the running statistics
+        # exist per key, for the keys in cfg.normalize_input_keys (None: all) — running_mean_std.py:113-131
+        self.key = key
+        self.sub_mean = float(cfg.obs_subtract_mean) if (key == "obs" and abs(cfg.obs_subtract_mean) > 1e-5) else 0.0
+        self.scale = float(cfg.obs_scale) if key == "obs" else 1.0
+        keys = getattr(cfg, "normalize_input_keys", None)
+        self.running = bool(cfg.normalize_input) and (not keys or key in keys)
         self.mean = torch.zeros(obs_shape, dtype=torch.float64, device=device)
         self.var = torch.ones(obs_shape, dtype=torch.float64, device=device)
         self.count = torch.ones(1, dtype=torch.float64, device=device)
@@ -69,13 +73,15 @@ class TorchObsNormalizer:
             x = ((x - self.mean.float()) / torch.sqrt(self.var.float() + 1e-5)).clamp(-5.0, 5.0)
         return x
 
-    def state_dict(self, prefix="obs_normalizer.running_mean_std.running_mean_std.obs."):
+    def state_dict(self, prefix=None):
+        prefix = prefix or f"obs_normalizer.running_mean_std.running_mean_std.{self.key}."
         if not self.running:
             return {}
         return {prefix + "running_mean": self.mean.cpu().clone(), prefix + "running_var": self.var.cpu().clone(),
                 prefix + "count": self.count.cpu().clone()}
 
-    def load_state_dict(self, sd, prefix="obs_normalizer.running_mean_std.running_mean_std.obs."):
+    def load_state_dict(self, sd, prefix=None):
+        prefix = prefix or f"obs_normalizer.running_mean_std.running_mean_std.{self.key}."
         if self.running and prefix + "count" in sd:
             self.mean.copy_(torch.as_tensor(sd[prefix + "running_mean"], dtype=torch.float64))
             self.var.copy_(torch.as_tensor(sd[prefix + "running_var"], dtype=torch.float64))
@@ -86,15 +92,112 @@ def _nonlinearity(cfg) -> nn.Module:
     return dict(elu=nn.ELU, relu=nn.ReLU, tanh=nn.Tanh)[cfg.nonlinearity]()
 
 
+class _DictObsNormalizer:
+    """what the Learner updates once per dataset when the observation is a dict of several keys"""
+
+    def __init__(self, norms: Dict[str, "TorchObsNormalizer"]):
+        self.norms = norms
+
+    def update(self, obs, stride: int, n: int, **_):
+        for k, nm in self.norms.items():
+            nm.update(obs[k], 0, n)
+
+
+class _TorchMlpEncoder(nn.Module):
+    """model/encoder.py:72-87 (MlpEncoder): mlp_head = Linear + activation per cfg.encoder_mlp_layers entry"""
+
+    def __init__(self, cfg, space):
+        super().__init__()
+        size, layers = int(space.shape[0]), []
+        for h in list(cfg.encoder_mlp_layers):
+            layers += [nn.Linear(size, int(h)), _nonlinearity(cfg)]
+            size = int(h)
+        self.mlp_head = nn.Sequential(*layers)
+        self.out_size = size
+
+    def forward(self, x):
+        return self.mlp_head(x)
+
+    def get_out_size(self) -> int:
+        return self.out_size
+
+
+class _TorchConvImpl(nn.Module):
+    def __init__(self, cfg, space):
+        super().__init__()
+        from sample_factory_amd.model.actor_critic import CONV_ARCHS
+        c, h, w = (int(v) for v in space.shape)
+        layers = []
+        for cout, k, st in CONV_ARCHS[cfg.encoder_conv_architecture]:
+            layers += [nn.Conv2d(c, cout, k, stride=st), _nonlinearity(cfg)]
+            c, h, w = cout, (h - k) // st + 1, (w - k) // st + 1
+        self.conv_head = nn.Sequential(*layers)
+        size, mlp = c * h * w, []
+        self.conv_head_out_size = size
+        for hdim in list(cfg.encoder_conv_mlp_layers):
+            mlp += [nn.Linear(size, int(hdim)), _nonlinearity(cfg)]
+            size = int(hdim)
+        self.mlp_layers = nn.Sequential(*mlp)
+        self.out_size = size
+
+    def forward(self, x):
+        x = self.conv_head(x)
+        return self.mlp_layers(x.contiguous().view(-1, self.conv_head_out_size))
+
+
+class _TorchConvEncoder(nn.Module):
+    """model/encoder.py:90-150 (ConvEncoder wrapping ConvEncoderImpl as .enc)"""
+
+    def __init__(self, cfg, space):
+        super().__init__()
+        self.enc = _TorchConvImpl(cfg, space)
+
+    def forward(self, x):
+        return self.enc(x)
+
+    def get_out_size(self) -> int:
+        return self.enc.out_size
+
+
+class _TorchMultiInputEncoder(nn.Module):
+    """model/encoder.py:33-69 (MultiInputEncoder): one encoder per observation key (sorted; vectors -> MLP, images ->
+    conv), outputs concatenated.  Parameter names equal the reference's (encoders.<key>.mlp_head.* /
+    encoders.<key>.enc.conv_head.* / .enc.mlp_layers.*)."""
+
+    def __init__(self, cfg, obs_space):
+        super().__init__()
+        self.obs_keys = sorted(k for k in obs_space.spaces.keys() if k != "action_mask")
+        self.encoders = nn.ModuleDict()
+        self.out_size = 0
+        for k in self.obs_keys:
+            space = obs_space[k]
+            if len(space.shape) == 1:
+                self.encoders[k] = _TorchMlpEncoder(cfg, space)
+            elif len(space.shape) == 3:
+                if not cfg.encoder_conv_architecture.startswith("convnet"):
+                    raise NotImplementedError(f"{cfg.encoder_conv_architecture} encoders")
+                self.encoders[k] = _TorchConvEncoder(cfg, space)
+            else:
+                raise NotImplementedError(f"Unsupported observation space {space}")
+            self.out_size += self.encoders[k].get_out_size()
+
+    def forward(self, obs_dict):
+        return torch.cat([self.encoders[k](obs_dict[k]) for k in self.obs_keys], 1)
+
+    def get_out_size(self) -> int:
+        return self.out_size
+
+
 class _DefaultTorchTail(nn.Module):
     """encoder -> [core] -> [decoder] -> critic_linear / distribution_linear, for a user-registered ENCODER (or core /
     decoder) with the remaining parts in their default form (model/actor_critic.py:136-195, decoder.py:15-31)."""
 
-    def __init__(self, cfg, obs_space, action_space, factory):
+    def __init__(self, cfg, obs_space, action_space, factory, encoder=None):
         super().__init__()
         if cfg.use_rnn and factory.make_model_core_func is None:
             raise NotImplementedError("custom encoder together with the default RNN core on the torch fallback path")
-        self.encoder = factory.make_model_encoder_func(cfg, obs_space) if factory.make_model_encoder_func else None
+        self.encoder = encoder if encoder is not None else (
+            factory.make_model_encoder_func(cfg, obs_space) if factory.make_model_encoder_func else None)
         if self.encoder is None:
             raise NotImplementedError("register an encoder (or a whole actor-critic) when customising core/decoder")
         size = int(self.encoder.get_out_size())
@@ -111,7 +214,9 @@ class _DefaultTorchTail(nn.Module):
                 size = int(h)
             self.decoder = nn.Sequential(*layers)
         self.critic_linear = nn.Linear(size, 1)
-        self.distribution_linear = nn.Linear(size, calc_num_action_parameters(action_space))
+        # same parameter path as the reference (model/action_parameterization.py:20-37)
+        self.action_parameterization = nn.Module()
+        self.action_parameterization.distribution_linear = nn.Linear(size, calc_num_action_parameters(action_space))
         gain = cfg.policy_init_gain
         for m in self.modules():  # actor_critic.py:73-96
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -130,12 +235,22 @@ class _DefaultTorchTail(nn.Module):
         x = self.decoder(x)
         res = dict(values=self.critic_linear(x).squeeze(-1), new_rnn_states=new_rnn)
         if not values_only:
-            res["action_logits"] = self.distribution_linear(x)
+            res["action_logits"] = self.action_parameterization.distribution_linear(x)
         return res
 
 
+def obs_keys_of(obs_space) -> List[str]:
+    keys = list(obs_space.spaces.keys()) if hasattr(obs_space, "spaces") else ["obs"]
+    return sorted(k for k in keys if k != "action_mask")
+
+
 def build_torch_actor_critic(cfg, obs_space, action_space, factory) -> nn.Module:
-    return _DefaultTorchTail(cfg, obs_space, action_space, factory)
+    """the default actor-critic in torch around whatever the user registered; with nothing registered (observation
+    dicts of several keys land here) the reference's MultiInputEncoder"""
+    enc = None
+    if factory.make_model_encoder_func is None and len(obs_keys_of(obs_space)) > 1:
+        enc = _TorchMultiInputEncoder(cfg, obs_space)
+    return _DefaultTorchTail(cfg, obs_space, action_space, factory, encoder=enc)
 
 
 class TorchPolicyAdapter:
@@ -144,8 +259,12 @@ class TorchPolicyAdapter:
             raise NotImplementedError("recurrent user models are not supported on the torch fallback path")
         self.cfg, self.device = cfg, torch.device(device)
         self.module = module.to(self.device).float()
-        space = obs_space["obs"] if hasattr(obs_space, "keys") else obs_space
-        self.obs_shape = tuple(space.shape)
+        self.obs_keys = obs_keys_of(obs_space)
+        self.multi_key = len(self.obs_keys) > 1  # the Learner / rollout runner then pass {key: slab view} dicts
+        self.obs_shapes = {k: tuple(obs_space[k].shape) for k in self.obs_keys} if hasattr(obs_space, "spaces") else \
+            {"obs": tuple(obs_space.shape)}
+        main = "obs" if "obs" in self.obs_shapes else self.obs_keys[0]
+        self.obs_shape = self.obs_shapes[main]
         self.obs_elems = int(np.prod(self.obs_shape))
         self.num_action_params = int(calc_num_action_parameters(action_space))
         self.heads_ld = (1 + self.num_action_params + 3) // 4 * 4
@@ -169,8 +288,14 @@ class TorchPolicyAdapter:
                 p.data = self.flat_params[o:o + p.numel()].view(p.shape)
                 p.grad = self.flat_grads[o:o + p.numel()].view(p.shape)
         world = int(getattr(cfg, "dp_world", 1) or 1)
-        self._norm = TorchObsNormalizer(cfg, self.obs_shape, self.device, all_reduce, world)  # scale/shift always applies
-        self.obs_normalizer = self._norm if cfg.normalize_input else None  # what the Learner updates once per dataset
+        self._norms = {k: TorchObsNormalizer(cfg, self.obs_shapes[k], self.device, all_reduce, world, key=k)
+                       for k in self.obs_shapes}
+        self._norm = self._norms[main]  # scale/shift always applies
+        # what the Learner updates once per dataset
+        if not cfg.normalize_input:
+            self.obs_normalizer = None
+        else:
+            self.obs_normalizer = _DictObsNormalizer(self._norms) if self.multi_key else self._norm
         self.returns_normalizer: Optional[RunningMeanStdInPlace] = None
         if cfg.normalize_returns:
             self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
@@ -222,21 +347,26 @@ class TorchPolicyAdapter:
         return seg.to(self.device), len(self._params)
 
     # ---- gather the logical samples exactly as the native loaders address them
-    def _gather(self, obs, n, index, offset, traj_T):
+    def _gather(self, obs, n, index, offset, traj_T, shape=None):
+        shape = self.obs_shape if shape is None else shape
         if traj_T:
-            flat = obs.reshape((-1,) + self.obs_shape)
+            flat = obs.reshape((-1,) + shape)
             d = index.long() if index is not None else torch.arange(offset, offset + n, device=self.device)
             return flat[d + d // traj_T]                     # dataset index e*T+t -> slab row e*(T+1)+t
-        x = obs.reshape((-1,) + self.obs_shape) if obs.is_contiguous() else obs
+        x = obs.reshape((-1,) + shape) if obs.is_contiguous() else obs
         if index is not None:
             return x[index.long()]
         return x[offset:offset + n]
 
     def forward_heads(self, obs, n, *, sample_stride, index=None, offset=0, traj_T=0, tag="inf", rnn=None) -> List[torch.Tensor]:
-        x = self._norm(self._gather(obs, n, index, offset, traj_T))
+        if isinstance(obs, dict):  # several observation keys: every key gathered / normalised on its own
+            xd = {k: self._norms[k](self._gather(obs[k], n, index, offset, traj_T, self.obs_shapes[k]))
+                  for k in self.obs_keys}
+        else:
+            xd = {"obs": self._norm(self._gather(obs, n, index, offset, traj_T))}
         train = tag == "train"
         with torch.set_grad_enabled(train):
-            res = self.module({"obs": x}, None, values_only=False)
+            res = self.module(xd, None, values_only=False)
             heads = torch.cat([res["values"].reshape(n, 1), res["action_logits"].reshape(n, self.num_action_params),
                                torch.zeros((n, self.heads_ld - 1 - self.num_action_params), device=self.device)], dim=1)
         if train:
@@ -244,8 +374,13 @@ class TorchPolicyAdapter:
         return [heads.detach()]
 
     def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
-        obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
-        heads = self.forward_heads(obs, obs.shape[0], sample_stride=self.obs_elems)[-1]
+        if self.multi_key:
+            obs = normalized_obs_dict
+            nrows = next(iter(obs.values())).shape[0]
+        else:
+            obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
+            nrows = obs.shape[0]
+        heads = self.forward_heads(obs, nrows, sample_stride=self.obs_elems)[-1]
         res = dict(values=heads[:, 0], new_rnn_states=rnn_states)
         if not values_only:
             res["action_logits"] = heads[:, 1:1 + self.num_action_params]
@@ -259,7 +394,8 @@ class TorchPolicyAdapter:
     # ---- checkpoints in the module's own names (+ the reference's normaliser keys)
     def state_dict(self):
         sd = {k: v.detach().cpu().clone() for k, v in self.module.state_dict().items()}
-        sd.update(self._norm.state_dict())
+        for nm in self._norms.values():
+            sd.update(nm.state_dict())
         if self.returns_normalizer is not None:
             sd.update(self.returns_normalizer.state_dict("returns_normalizer."))
         return sd
@@ -272,7 +408,8 @@ class TorchPolicyAdapter:
                     v.copy_(torch.as_tensor(sd[k]).to(v.dtype))
                 elif strict:
                     raise KeyError(k)
-        self._norm.load_state_dict(sd)
+        for nm in self._norms.values():
+            nm.load_state_dict(sd)
         if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
             self.returns_normalizer.load_state_dict(sd, "returns_normalizer.")
 
