@@ -256,3 +256,39 @@ def test_env_plugin_interfaces_follow_the_wrapper_chain():
     plain = Wrapper(Base())
     assert find_training_info_interface(plain) is None and get_default_reward_shaping(plain) is None
     set_training_info(None, dict(approx_total_training_steps=1))  # tolerated, as in the reference
+
+
+def test_multi_input_architecture_matches_reference_on_cpu():
+    """model/encoder.py:33-69 (MultiInputEncoder) as built for observation dicts with several keys: parameter names,
+    shapes and — with the same seeded weights — logits / values of the REFERENCE model (tests/golden/model_fwd_multi.npz).
+    The network of this path is plain torch, so the check runs without a GPU; per-key normaliser rules included."""
+    import os
+    import types
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.model_factory import create_actor_critic
+    from sample_factory_amd.model.torch_policy import TorchObsNormalizer, TorchPolicyAdapter
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_fwd_multi.npz"), allow_pickle=True)
+    cfg = default_cfg(encoder_conv_architecture="convnet_impala", nonlinearity="relu", obs_scale=255.0,
+                      normalize_input=False, encoder_conv_mlp_layers=[32], encoder_mlp_layers=[16, 16], use_rnn=False,
+                      normalize_returns=False)
+    cfg.dp_world = 1
+    obs_space = spaces.Dict({"obs": spaces.Box(0, 255, (4, 36, 36), np.uint8),
+                             "measurements": spaces.Box(-1, 1, (5,), np.float32)})
+    ac = create_actor_critic(cfg, obs_space, spaces.Discrete(6), torch.device("cpu"))
+    assert isinstance(ac, TorchPolicyAdapter) and ac.multi_key and ac.obs_keys == ["measurements", "obs"]
+    assert [(n, tuple(s)) for n, s in ac.ref_param_shapes()] == \
+        [(str(n), tuple(eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])]
+    from oracle.weights import seeded_state  # the deterministic weight generator the golden was made with
+    st = seeded_state([(str(n), eval(str(s))) for n, s in zip(g["param_names"], g["param_shapes"])], int(g["param_seed"]))
+    sd = {k: torch.from_numpy(v) for k, v in st.items()}
+    ac.load_state_dict(sd, strict=True)
+    ac.eval()
+    res = ac.forward({"obs": torch.from_numpy(g["obs"]), "measurements": torch.from_numpy(g["measurements"])}, None)
+    np.testing.assert_allclose(res["action_logits"].numpy(), g["action_logits"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(res["values"].numpy(), g["values"], atol=2e-5, rtol=1e-4)
+    # normaliser rules: scale / mean shift only on "obs"; running statistics only for the keys listed
+    c2 = types.SimpleNamespace(obs_subtract_mean=3.0, obs_scale=255.0, normalize_input=True, normalize_input_keys=["measurements"])
+    n_obs, n_meas = TorchObsNormalizer(c2, (2,), "cpu", key="obs"), TorchObsNormalizer(c2, (2,), "cpu", key="measurements")
+    assert n_obs.scale == 255.0 and n_obs.sub_mean == 3.0 and not n_obs.running
+    assert n_meas.scale == 1.0 and n_meas.sub_mean == 0.0 and n_meas.running
