@@ -9,7 +9,8 @@ convention (model/actor_critic.py:23-133):
     module(normalized_obs_dict, rnn_states, values_only=False) -> dict with "values" [n] and "action_logits" [n, A]
 
 Sampling stays native (sf_sample_write_step), so "actions"/"log_prob_actions" in the returned dict are ignored.
-Recurrent custom models and async weight snapshots are not supported on this path (NotImplementedError).
+Recurrent models run their core step by step (forward_head / forward_core / forward_tail, one-layer default GRU/LSTM);
+async weight snapshots are not supported on this path (NotImplementedError).
 """
 from __future__ import annotations
 
@@ -188,20 +189,45 @@ class _TorchMultiInputEncoder(nn.Module):
         return self.out_size
 
 
+class _TorchRnnCore(nn.Module):
+    """model/core.py:19-64 (ModelCoreRNN), one layer: x [n, F], rnn_states [n, S] -> (out [n, H], new_states [n, S]);
+    LSTM state = [h | c].  Parameter names core.core.weight_ih_l0 ... as in the reference."""
+
+    def __init__(self, cfg, input_size):
+        super().__init__()
+        if cfg.rnn_num_layers != 1 or cfg.rnn_type not in ("gru", "lstm"):
+            raise NotImplementedError("recurrent core: one-layer GRU or LSTM only")
+        self.is_gru, self.H = cfg.rnn_type == "gru", int(cfg.rnn_size)
+        self.core = (nn.GRU if self.is_gru else nn.LSTM)(input_size, self.H, 1)
+
+    def forward(self, x, rnn_states):
+        x = x.unsqueeze(0)
+        if self.is_gru:
+            out, h = self.core(x, rnn_states.unsqueeze(0).contiguous())
+            return out.squeeze(0), h.squeeze(0)
+        h, c = torch.split(rnn_states.unsqueeze(0), self.H, dim=2)
+        out, (h, c) = self.core(x, (h.contiguous(), c.contiguous()))
+        return out.squeeze(0), torch.cat((h, c), dim=2).squeeze(0)
+
+    def get_out_size(self) -> int:
+        return self.H
+
+
 class _DefaultTorchTail(nn.Module):
     """encoder -> [core] -> [decoder] -> critic_linear / distribution_linear, for a user-registered ENCODER (or core /
     decoder) with the remaining parts in their default form (model/actor_critic.py:136-195, decoder.py:15-31)."""
 
     def __init__(self, cfg, obs_space, action_space, factory, encoder=None):
         super().__init__()
-        if cfg.use_rnn and factory.make_model_core_func is None:
-            raise NotImplementedError("custom encoder together with the default RNN core on the torch fallback path")
         self.encoder = encoder if encoder is not None else (
             factory.make_model_encoder_func(cfg, obs_space) if factory.make_model_encoder_func else None)
         if self.encoder is None:
             raise NotImplementedError("register an encoder (or a whole actor-critic) when customising core/decoder")
         size = int(self.encoder.get_out_size())
-        self.core = factory.make_model_core_func(cfg, size) if factory.make_model_core_func else None
+        if factory.make_model_core_func is not None:
+            self.core = factory.make_model_core_func(cfg, size)
+        else:
+            self.core = _TorchRnnCore(cfg, size) if cfg.use_rnn else None
         if self.core is not None:
             size = int(self.core.get_out_size())
         if factory.make_model_decoder_func is not None:
@@ -227,15 +253,26 @@ class _DefaultTorchTail(nn.Module):
                 if cfg.policy_initialization != "torch_default" and m.bias is not None:
                     m.bias.data.fill_(0)
 
-    def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False):
-        x = self.encoder(normalized_obs_dict)
-        new_rnn = rnn_states
-        if self.core is not None:
-            x, new_rnn = self.core(x, rnn_states)
+    # head / core / tail as in model/actor_critic.py:160-195 (the recurrent training pass runs the core step by step)
+    def forward_head(self, normalized_obs_dict):
+        return self.encoder(normalized_obs_dict)
+
+    def forward_core(self, x, rnn_states):
+        if self.core is None:
+            return x, rnn_states
+        return self.core(x, rnn_states)
+
+    def forward_tail(self, x, values_only: bool = False):
         x = self.decoder(x)
-        res = dict(values=self.critic_linear(x).squeeze(-1), new_rnn_states=new_rnn)
+        res = dict(values=self.critic_linear(x).squeeze(-1))
         if not values_only:
             res["action_logits"] = self.action_parameterization.distribution_linear(x)
+        return res
+
+    def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False):
+        x, new_rnn = self.forward_core(self.forward_head(normalized_obs_dict), rnn_states)
+        res = self.forward_tail(x, values_only)
+        res["new_rnn_states"] = new_rnn
         return res
 
 
@@ -255,9 +292,10 @@ def build_torch_actor_critic(cfg, obs_space, action_space, factory) -> nn.Module
 
 class TorchPolicyAdapter:
     def __init__(self, cfg, obs_space, action_space, device, module: nn.Module, all_reduce=None):
-        if cfg.use_rnn:
-            raise NotImplementedError("recurrent user models are not supported on the torch fallback path")
         self.cfg, self.device = cfg, torch.device(device)
+        if cfg.use_rnn and not all(hasattr(module, m) for m in ("forward_head", "forward_core", "forward_tail")):
+            raise NotImplementedError("a recurrent user model must expose forward_head / forward_core / forward_tail "
+                                      "(model/actor_critic.py:23-133)")
         self.module = module.to(self.device).float()
         self.obs_keys = obs_keys_of(obs_space)
         self.multi_key = len(self.obs_keys) > 1  # the Learner / rollout runner then pass {key: slab view} dicts
@@ -268,7 +306,7 @@ class TorchPolicyAdapter:
         self.obs_elems = int(np.prod(self.obs_shape))
         self.num_action_params = int(calc_num_action_parameters(action_space))
         self.heads_ld = (1 + self.num_action_params + 3) // 4 * 4
-        self.rnn_kind = None
+        self.rnn_kind = (0 if cfg.rnn_type == "gru" else 1) if cfg.use_rnn else None  # the rollout runner's switch
         self.new_rnn_states = None
         self.training = True
         # ---- re-seat parameters / gradients as views into flat buffers (16-byte aligned segments)
@@ -366,7 +404,24 @@ class TorchPolicyAdapter:
             xd = {"obs": self._norm(self._gather(obs, n, index, offset, traj_T))}
         train = tag == "train"
         with torch.set_grad_enabled(train):
-            res = self.module(xd, None, values_only=False)
+            if rnn is None:
+                res = self.module(xd, None, values_only=False)
+            elif "R" not in rnn:  # one inference step on the stored state (rollout, bootstrap value)
+                x, new_states = self.module.forward_core(self.module.forward_head(xd), rnn["states"])
+                res = self.module.forward_tail(x, values_only=False)
+                self.new_rnn_states = new_states.detach()
+            else:
+                # BPTT over recurrence-length chunks as a masked time loop: rows are chunk-major (Cn chunks x R steps),
+                # the state is zeroed after a done / invalid step — the loop form of rnn_utils.py:114-158 that the
+                # reference's tests/algo/test_rnn.py proves equal to its PackedSequence path
+                R, Cn = rnn["R"], n // rnn["R"]
+                feats = self.module.forward_head(xd).reshape(Cn, R, -1)
+                h, keep, outs = rnn["h0"], rnn["keep_tm"], []
+                for t in range(R):
+                    out, h = self.module.forward_core(feats[:, t], h)
+                    outs.append(out)
+                    h = h * keep[t].unsqueeze(1)
+                res = self.module.forward_tail(torch.stack(outs, 1).reshape(n, -1), values_only=False)
             heads = torch.cat([res["values"].reshape(n, 1), res["action_logits"].reshape(n, self.num_action_params),
                                torch.zeros((n, self.heads_ld - 1 - self.num_action_params), device=self.device)], dim=1)
         if train:
@@ -380,8 +435,9 @@ class TorchPolicyAdapter:
         else:
             obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
             nrows = obs.shape[0]
-        heads = self.forward_heads(obs, nrows, sample_stride=self.obs_elems)[-1]
-        res = dict(values=heads[:, 0], new_rnn_states=rnn_states)
+        rnn = dict(states=rnn_states) if (self.rnn_kind is not None and rnn_states is not None) else None
+        heads = self.forward_heads(obs, nrows, sample_stride=self.obs_elems, rnn=rnn)[-1]
+        res = dict(values=heads[:, 0], new_rnn_states=self.new_rnn_states if rnn is not None else rnn_states)
         if not values_only:
             res["action_logits"] = heads[:, 1:1 + self.num_action_params]
         return res

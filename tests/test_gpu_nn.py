@@ -1409,3 +1409,83 @@ def test_multi_input_model_forward_matches_reference(lib, golden):
                      None)
     np.testing.assert_allclose(res["action_logits"].cpu().numpy(), g["action_logits"], atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(res["values"].cpu().numpy(), g["values"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["gru", "lstm_inv"])
+def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden, tmp_path, name):
+    """The recurrent goldens once more, through the TORCH model path (a registered encoder, here the default
+    architecture itself; also what observation dicts with several keys use): default one-layer GRU / LSTM core with
+    the reference's parameter names, BPTT as a masked time loop under autograd, everything around the network native —
+    against the reference's Learner.train (PackedSequence BPTT)."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import get_rnn_size
+    from sample_factory_amd.model.model_factory import global_model_factory
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter, _TorchMultiInputEncoder
+    g = golden("train_" + name)
+    E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
+    rnn_type = "gru" if name == "gru" else "lstm"
+    cfg = default_cfg(use_rnn=True, rnn_type=rnn_type, rnn_size=32, recurrence=8, nonlinearity="relu", normalize_input=False,
+                      encoder_mlp_layers=[32], rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb,
+                      num_epochs=int(g["num_epochs"]), kl_loss_coeff=0.1 if name == "lstm_inv" else 0.0, seed=0,
+                      serial_mode=True, train_dir=str(tmp_path), experiment="t", record_grad_norm=True)
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    global_model_factory().register_encoder_factory(lambda c, o: _TorchMultiInputEncoder(c, o))
+    try:
+        learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+        learner.init()
+    finally:
+        global_model_factory().reset()
+    ac = learner.actor_critic
+    assert isinstance(ac, TorchPolicyAdapter) and ac.rnn_kind == (0 if rnn_type == "gru" else 1)
+    assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
+    load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
+    batch = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    stats = learner.train(batch)
+    assert stats["learner_env_steps"] == int(g["env_steps"]) and learner.train_step == int(g["train_step"])
+    np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=5e-4)
+    after, m = ac.state_dict(), ac.flat_to_ref(learner.exp_avg)
+    for pname in g["param_names"]:
+        np.testing.assert_allclose(m[pname].reshape(-1).numpy(), g["m_" + pname], rtol=5e-3, atol=5e-8, err_msg=pname)
+        np.testing.assert_allclose(after[pname].reshape(-1).numpy(), g["after_" + pname], rtol=0, atol=2e-5, err_msg=pname)
+
+
+def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tmp_path):
+    """the reference's DEFAULT configuration for a dict observation: MultiInputEncoder + GRU core (use_rnn=True) — state
+    carried through the slab by the native rollout runner, BPTT on the torch model path"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_dict_obs_bandit_env
+    from sample_factory_amd.train import make_runner
+    register_env("dict_bandit_rnn", make_dict_obs_bandit_env)
+    cfg = default_cfg(env="dict_bandit_rnn", use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=8, nonlinearity="relu",
+                      normalize_input=False, obs_scale=255.0, encoder_conv_architecture="convnet_impala",
+                      encoder_conv_mlp_layers=[32], encoder_mlp_layers=[32], rollout=8, batch_size=256,
+                      num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=False, seed=4,
+                      serial_mode=True, synthetic_num_agents=64, learning_rate=3e-3, gamma=0.0, normalize_returns=False,
+                      train_dir=str(tmp_path), experiment="dict_rnn")
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    ac = runner.learner.actor_critic
+    assert ac.rnn_kind == 0 and "core.core.weight_hh_l0" in [n for n, _ in ac.ref_param_shapes()]
+    p0 = ac.flat_params.clone()
+    first = None
+    for _ in range(30):
+        stats = runner.iteration()
+        r = float(runner.traj["rewards"].mean())
+        first = r if first is None else first
+    tr = runner.traj
+    assert tr["rnn_states"].shape == (64, 9, 32)
+    # every episode is one step long: the state handed to the next step is zero, the state the policy produced is not
+    assert (tr["rnn_states"][:, 1:] == 0).all() and ac.new_rnn_states.abs().max() > 0
+    assert torch.isfinite(ac.flat_params).all() and not torch.equal(p0, ac.flat_params)
+    assert np.isfinite(stats["train"]["loss"]) and r > first + 0.3 and r > 0.75, (first, r)
