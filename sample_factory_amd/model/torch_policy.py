@@ -360,7 +360,8 @@ class TorchPolicyAdapter:
         pass  # the module's parameters ARE views of flat_params
 
     def enable_weight_snapshots(self):
-        raise NotImplementedError("async_rl with a user-registered torch model")
+        raise NotImplementedError("async_rl=True is not available on the torch model path (user-registered models, "
+                                  "observation dicts with several keys): run with --async_rl=False")
 
     def _buf(self, key, shape, dtype=torch.float32):
         t = self._bufs.get(key)
