@@ -116,8 +116,10 @@ class ActorCritic:
         if cfg.nonlinearity not in ACT_KIND:
             raise NotImplementedError(f"Unknown nonlinearity {cfg.nonlinearity}")
         act = ACT_KIND[cfg.nonlinearity]
-        if cfg.normalize_input and cfg.normalize_input_keys not in (None, [], ["obs"]):
-            raise NotImplementedError("normalize_input_keys other than the 'obs' key")
+        # running input statistics exist for the keys in cfg.normalize_input_keys (None / []: all keys,
+        # running_mean_std.py:113-131); this model has the single key "obs"
+        keys_ = getattr(cfg, "normalize_input_keys", None)
+        norm_input = bool(cfg.normalize_input) and (not keys_ or "obs" in keys_)
         # ActionParameterizationContinuousNonAdaptiveStddev (action_parameterization.py:42-78): the network outputs the
         # means only, log-stddev is one learned vector.  In the fused heads GEMM the log-stddev columns keep ZERO weights
         # (their weight gradient is discarded) and their BIAS is the learned vector, so params = [means | log_std] comes
@@ -147,7 +149,7 @@ class ActorCritic:
             cin, h, w = C, H, W
             for i, (cout, k, s) in enumerate(CONV_ARCHS[cfg.encoder_conv_architecture]):
                 oh, ow = (h - k) // s + 1, (w - k) // s + 1
-                first = i == 0 and not cfg.normalize_input  # normalised frames arrive as f32 NHWC (utils/normalize.py)
+                first = i == 0 and not norm_input  # normalised frames arrive as f32 NHWC (utils/normalize.py)
                 desc = lib.sf_conv_desc(Cin=cin, H=h, W=w, Cout=cout, KH=k, KW=k, stride=s, OH=oh, OW=ow,
                                         in_u8=int(first), relu=act, traj_T=0,
                                         sub_mean=sub_mean if first else 0.0, inv_scale=inv_scale if first else 1.0)
@@ -160,7 +162,7 @@ class ActorCritic:
                                           "linear_after_conv" if j == 0 else "linear", first_fc_chw=chw))
                 feat = size
         elif len(self.obs_shape) == 1:
-            if self.obs_u8 or ((sub_mean != 0.0 or inv_scale != 1.0) and not cfg.normalize_input):
+            if self.obs_u8 or ((sub_mean != 0.0 or inv_scale != 1.0) and not norm_input):
                 raise NotImplementedError("vector observations must be f32; obs_scale/obs_subtract_mean on vectors "
                                           "need normalize_input=True")
             feat = self.obs_shape[0]
@@ -221,7 +223,7 @@ class ActorCritic:
             ok = L.role == "chain" and not L.desc.in_u8 and L.desc.Cin % 32 == 0 and L.N >= 32
             L.wt = self.flat_params_t[o:o + L.K * L.N].view(L.N, L.K) if ok else None
         self.obs_normalizer = None
-        if cfg.normalize_input:
+        if norm_input:
             from sample_factory_amd.utils.normalize import ObservationNormalizer
             self.obs_normalizer = ObservationNormalizer(cfg, self.obs_shape, self.obs_u8, self.device,
                                                         all_reduce=all_reduce, world=getattr(cfg, "dp_world", 1))

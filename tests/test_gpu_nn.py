@@ -1489,3 +1489,18 @@ def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tm
     assert (tr["rnn_states"][:, 1:] == 0).all() and ac.new_rnn_states.abs().max() > 0
     assert torch.isfinite(ac.flat_params).all() and not torch.equal(p0, ac.flat_params)
     assert np.isfinite(stats["train"]["loss"]) and r > first + 0.3 and r > 0.75, (first, r)
+
+
+def test_normalize_input_keys_subset_on_the_native_model(lib):
+    """cfg.normalize_input_keys (running_mean_std.py:113-131): running statistics only for the listed keys — a list
+    without "obs" leaves the native single-key model without a running normaliser, exactly like normalize_input=False"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import ActorCritic
+    obs_space = spaces.Dict({"obs": spaces.Box(-1, 1, (8,), np.float32)})
+    for keys, expect in ((None, True), (["obs"], True), (["measurements"], False)):
+        cfg = default_cfg(use_rnn=False, nonlinearity="relu", normalize_input=True, normalize_input_keys=keys,
+                          encoder_mlp_layers=[16])
+        ac = ActorCritic(cfg, obs_space, spaces.Discrete(4), "cuda")
+        assert (ac.obs_normalizer is not None) == expect, keys
+        assert ("obs_normalizer.running_mean_std.running_mean_std.obs.running_mean" in ac.state_dict()) == expect
