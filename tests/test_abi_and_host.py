@@ -292,3 +292,15 @@ def test_multi_input_architecture_matches_reference_on_cpu():
     n_obs, n_meas = TorchObsNormalizer(c2, (2,), "cpu", key="obs"), TorchObsNormalizer(c2, (2,), "cpu", key="measurements")
     assert n_obs.scale == 255.0 and n_obs.sub_mean == 3.0 and not n_obs.running
     assert n_meas.scale == 1.0 and n_meas.sub_mean == 0.0 and n_meas.running
+
+
+def test_every_module_imports_without_a_gpu():
+    """the whole host package must import on a CPU-only box (the HIP library is only dlopen'ed on first use)"""
+    import importlib
+    import pkgutil
+    import sample_factory_amd
+    names = [m.name for m in pkgutil.walk_packages(sample_factory_amd.__path__, "sample_factory_amd.")
+             if not m.name.endswith("libsf_hip")]  # (the C-ABI shared object sits in the package directory)
+    assert len(names) > 20
+    for name in names:
+        importlib.import_module(name)
