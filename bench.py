@@ -8,7 +8,14 @@ Nature-CNN actor-critic, 1xMI355X") with the NS-2 learner preset of SURVEY.md §
 torch.distributed.run, one rank per GPU) every rank runs the same per-GPU workload on its own env shard and gradients /
 advantage moments are all-reduced over RCCL: weak scaling, value = whole-job env-steps/s.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c5]
+
+`--workload c5` = BASELINE.json configs[4] on one GPU per rank: Ant-shaped synthetic continuous env (obs f32[27],
+Box(8)), 2048 envs, MLP[64,64] tanh encoder + LSTM-512 core, V-trace, KL loss, rollout = recurrence = 32.
+
+`--gpus N` without a torchrun environment re-launches itself as `python -m torch.distributed.run --nproc-per-node N`
+(one rank per GPU, RCCL); every rank checks it has its own device and the JSON line carries `rccl_ranks` (the result of
+a rank-stamped all-reduce) and the device of every rank.
 """
 from __future__ import annotations
 
@@ -32,15 +39,105 @@ def kernel_flops(key):
     return 2.0 * n * OH * OW * Cout * (K * K * Cin)  # fwd, wgrad and (gather-form, no zero taps) dgrad are equal
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: become the launcher (one rank per GPU on this node)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    return subprocess.call(cmd, env=env)
+
+
+def init_replicas(world: int, rank: int, need_gpu: bool = True):
+    """process group + a self-check of the collective path: all-reduce of a rank-stamped tensor must give
+    sum(2^r) = 2^world - 1 (every rank contributed exactly once) and the ranks must sit on distinct devices.
+    Returns (rccl_ranks, [device index of every rank], backend)."""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("SF_DP_BACKEND", "nccl")  # nccl = RCCL on ROCm (gloo: CPU tests)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and need_gpu and ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit(f"[rank {rank}] bench.py --gpus {world}: need {world} devices on this node, found {ndev} "
+                         f"(one rank per GPU; SF_DP_BACKEND=gloo shares a device for protocol tests)")
+    if ndev:
+        torch.cuda.set_device(local % ndev)
+    dist.init_process_group(backend)
+    dev = torch.device("cuda", torch.cuda.current_device()) if (ndev and backend == "nccl") else torch.device("cpu")
+    stamp = torch.tensor([float(2 ** rank), float(local % ndev if ndev else -1)], dtype=torch.float64, device=dev)
+    devs = [torch.zeros_like(stamp) for _ in range(world)]
+    dist.all_gather(devs, stamp)
+    tot = stamp[:1].clone()
+    dist.all_reduce(tot)
+    if int(tot.item()) != 2 ** world - 1:
+        raise SystemExit(f"[rank {rank}] collective self-check failed: {tot.item()} != {2 ** world - 1}")
+    dev_ids = [int(d[1].item()) for d in devs]
+    if backend == "nccl" and len(set(dev_ids)) != world:
+        raise SystemExit(f"[rank {rank}] ranks share devices {dev_ids}: one rank per GPU expected")
+    return world, dev_ids, backend
+
+
+def workload_cfg(args, rank, world):
+    """(cfg, env name, env factory, description, metric) of the selected BASELINE.json configuration"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env, make_synthetic_env
+    B, T = args.envs, args.rollout
+    common = dict(rollout=T, batch_size=B * T // args.num_batches, num_batches_per_epoch=args.num_batches,
+                  num_epochs=args.num_epochs, async_rl=args.async_rl, serial_mode=not args.async_rl, batched_sampling=True,
+                  num_workers=1, num_envs_per_worker=args.env_instances, worker_num_splits=args.env_instances,
+                  env_gpu_observations=True, env_gpu_actions=True, actor_worker_gpus=[0], seed=0,
+                  synthetic_num_agents=B // args.env_instances, data_parallel=world > 1)
+    mode = "async (rollout k+1 || train k)" if args.async_rl else "sync"
+    if args.workload == "c2":
+        cfg = default_cfg(
+            env="synthetic_atari", use_rnn=False, recurrence=1, encoder_conv_architecture="convnet_atari",
+            nonlinearity="relu", encoder_conv_mlp_layers=[512], obs_scale=255.0, normalize_input=False,
+            normalize_returns=True, gamma=0.99, gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0,
+            value_loss_coeff=0.5, exploration_loss_coeff=0.01, max_grad_norm=4.0, learning_rate=1e-4, adam_eps=1e-6,
+            synthetic_env0=rank * B, **common)
+        desc = (f"BASELINE.json configs[1]: synthetic vector env {B} envs/GPU, 84x84x4 u8 obs, Discrete(6), Nature-CNN "
+                f"actor-critic (1,687,719 params), APPO {mode}, rollout={T}, batch_size={cfg.batch_size} x "
+                f"{args.num_batches} minibatches x {args.num_epochs} epoch(s)")
+        return cfg, "synthetic_atari", make_synthetic_env, desc, "env-steps/sec (whole node), 4096 envs, 84x84x4 obs"
+    if args.workload == "c5":  # sf_examples/mujoco/mujoco_params.py:1-38 + LSTM core + V-trace (SURVEY.md §8d C5)
+        cfg = default_cfg(
+            env="synthetic_ant", use_rnn=True, rnn_type="lstm", rnn_size=512, recurrence=T, encoder_mlp_layers=[64, 64],
+            nonlinearity="tanh", normalize_input=True, normalize_returns=False, with_vtrace=True, kl_loss_coeff=0.1,
+            adaptive_stddev=False, policy_initialization="torch_default", value_bootstrap=True, max_grad_norm=3.5,
+            ppo_clip_ratio=0.2, value_loss_coeff=1.3, exploration_loss_coeff=0.0, learning_rate=0.00295, gamma=0.99,
+            gae_lambda=0.95, **common)
+        cfg.seed = rank  # torch-generator env: a different stream per replica
+        desc = (f"BASELINE.json configs[4]: Ant-shaped synthetic continuous env {B} envs/GPU (obs f32[27], Box(8)), "
+                f"MLP[64,64] tanh + LSTM-512 core + learned stddev, V-trace + KL loss + value bootstrap, APPO {mode}, "
+                f"rollout=recurrence={T}, batch_size={cfg.batch_size} x {args.num_batches} minibatches x "
+                f"{args.num_epochs} epoch(s)")
+        return cfg, "synthetic_ant", make_synthetic_continuous_env, desc, \
+            "env-steps/sec (whole node), 2048 envs, obs f32[27], Box(8), LSTM-512 + V-trace"
+    raise SystemExit(f"unknown workload {args.workload}")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--check_launch", action="store_true",
+                    help="stop after the replica-group self-check (launcher / env plumbing test; needs no GPU with "
+                         "SF_DP_BACKEND=gloo)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: 4096 for c2, 2048 for c5)")
     ap.add_argument("--rollout", type=int, default=32)
     ap.add_argument("--num_batches", type=int, default=4)
-    ap.add_argument("--num_epochs", type=int, default=1)
+    ap.add_argument("--num_epochs", type=int, default=None, help="default: 1 for c2, 2 for c5 (mujoco preset)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
@@ -49,38 +146,40 @@ def main():
                          "worker_num_splits = this): their rollouts run on separate HIP streams")
     ap.add_argument("--async_rl", action="store_true", help="overlap rollout k+1 with train(k) (policy lag of one dataset)")
     args = ap.parse_args()
+    if args.envs is None:
+        args.envs = 4096 if args.workload == "c2" else 2048
+    if args.num_epochs is None:
+        args.num_epochs = 1 if args.workload == "c2" else 2
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     import torch
 
-    from sample_factory_amd import lib
-    from sample_factory_amd.cfg.arguments import default_cfg
-    from sample_factory_amd.envs.env_utils import register_env
-    from sample_factory_amd.envs.synthetic import make_synthetic_env
-    from sample_factory_amd.train import make_runner
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} must be launched as `python -m torch.distributed.run --nproc-per-node "
-                         f"{args.gpus} bench.py --gpus {args.gpus} ...` (WORLD_SIZE={world})")
+    rccl_ranks, rank_devices, backend = 1, [0], None
+    if world > 1:
+        rccl_ranks, rank_devices, backend = init_replicas(world, rank, need_gpu=not args.check_launch)
+    if args.check_launch:
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+                              "backend": backend, "n_gpus": world, "workload": args.workload}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-        torch.distributed.init_process_group(os.environ.get("SF_DP_BACKEND", "nccl"))  # nccl = RCCL on ROCm (gloo: tests)
 
-    register_env("synthetic_atari", make_synthetic_env)
+    from sample_factory_amd import lib
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.train import make_runner
+
+    cfg, env_name, env_factory, workload_desc, metric = workload_cfg(args, rank, world)
+    register_env(env_name, env_factory)
     B, T = args.envs, args.rollout
-    cfg = default_cfg(
-        env="synthetic_atari", use_rnn=False, recurrence=1, encoder_conv_architecture="convnet_atari",
-        nonlinearity="relu", encoder_conv_mlp_layers=[512], obs_scale=255.0, normalize_input=False,
-        normalize_returns=True, rollout=T, batch_size=B * T // args.num_batches, num_batches_per_epoch=args.num_batches,
-        num_epochs=args.num_epochs, gamma=0.99, gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0,
-        value_loss_coeff=0.5, exploration_loss_coeff=0.01, max_grad_norm=4.0, learning_rate=1e-4, adam_eps=1e-6,
-        async_rl=args.async_rl, serial_mode=not args.async_rl, batched_sampling=True, num_workers=1,
-        num_envs_per_worker=args.env_instances, worker_num_splits=args.env_instances, env_gpu_observations=True, env_gpu_actions=True, actor_worker_gpus=[0], seed=0,
-        synthetic_num_agents=B // args.env_instances, synthetic_env0=rank * B, data_parallel=world > 1)
     cfg, runner = make_runner(cfg)
     runner.init()
 
@@ -132,7 +231,11 @@ def main():
 
     if not prof:
         if rank == 0:
-            print(json.dumps({"value": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": world}))
+            print(json.dumps({"metric": metric, "value": round(value, 1), "unit": "env-steps/s",
+                              "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": world, "rccl_ranks": rccl_ranks,
+                              "rank_devices": rank_devices, "config": {"workload": workload_desc}}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     # ---- roofline of the dominant kernel instantiation (largest total time; HIP events over the timed region).
     # achieved = mean algorithmic FLOPs per launch / mean launch duration = sum(flops) / sum(duration) over its launches;
@@ -173,13 +276,11 @@ def main():
                   "tflops": round(kernel_flops(k[1]) / (k[3] * 1e-3) / 1e12, 1)} for k in kern[:12]]
 
     out = {
-        "metric": "env-steps/sec (whole node), 4096 envs, 84x84x4 obs", "value": round(value, 1), "unit": "env-steps/s",
+        "metric": metric, "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1]: synthetic vector env {B} envs/GPU, 84x84x4 u8 obs, "
-                               f"Discrete(6), Nature-CNN actor-critic (1,687,719 params), APPO "
-                               f"{'async (rollout k+1 || train k)' if args.async_rl else 'sync'}, rollout={T}, "
-                               f"batch_size={cfg.batch_size} x {args.num_batches} minibatches x {args.num_epochs} epoch(s)",
+        "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+        "config": {"workload": workload_desc,
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
                    "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},
         "roofline": roofline,
@@ -187,7 +288,7 @@ def main():
                             "ms_per_step": round(net_ms, 2), "tflops_avg": round(net_flops / (net_ms * 1e-3) / 1e12, 2),
                             "top": breakdown},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c2":
         from oracle import cpu_baseline  # checker/baseline leg only; never on the measured path
         out["cpu_baseline"] = cpu_baseline.run(num_envs=args.cpu_baseline_envs, rollout=T, num_minibatches=args.num_batches)
         out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 1)

@@ -348,8 +348,13 @@ def gen_prepare_and_losses():
         save("learner_" + var["name"], **arrays)
 
 
+def np_frames(seed, shape):
+    """u8 frames too large to commit (C2 geometry): regenerated on both sides from numpy's PCG64 stream"""
+    return np.random.default_rng(seed).integers(0, 256, size=shape, dtype=np.uint8)
+
+
 def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1, use_rnn=False,
-              box_dims=0):
+              box_dims=0, obs_seed=None, p_other_policy=None, fill_extra=None):
     cfg = make_cfg(list(model_args) + [f"--rollout={T}", f"--batch_size={E * T // nb}",
                                        f"--num_batches_per_epoch={nb}", f"--num_epochs={epochs}"] + list(extra),
                    use_rnn=use_rnn)
@@ -358,12 +363,21 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
     shapes = load_seeded(learner.actor_critic, seed=param_seed)
     g = torch.Generator().manual_seed(4242)
     b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
-    fill_batch(b, g, A, continuous=bool(box_dims), p_done=0.08, p_other_policy=0.05 if "inv" in name else 0.0)
+    if p_other_policy is None:
+        p_other_policy = 0.05 if "inv" in name else 0.0
+    fill_batch(b, g, A, continuous=bool(box_dims), p_done=0.08, p_other_policy=p_other_policy, **(fill_extra or {}))
+    if obs_seed is not None:
+        b["obs"]["obs"].copy_(torch.from_numpy(np_frames(obs_seed, tuple(b["obs"]["obs"].shape))))
     arrays = {"ref": "sample_factory/algo/learning/learner.py:1036-1067 Learner.train (prepare_batch + _train: "
                      "losses, backward, clip_grad_norm_, torch.optim.Adam)", "argv": " ".join(list(model_args) + list(extra)),
               "param_seed": param_seed, "E": E, "T": T, "A": A, "num_batches": nb, "num_epochs": epochs,
               "subsample": subsample}
     arrays.update(batch_arrays(b))
+    if obs_seed is not None:
+        del arrays["in_obs_obs"]
+        arrays["obs_seed"] = obs_seed
+        arrays["obs_crc"] = int(b["obs"]["obs"].long().sum())
+    sd0 = {k: v.clone() for k, v in learner.actor_critic.state_dict().items()}
     # record per-SGD-step grad norms by wrapping clip_grad_norm_
     norms = []
     orig_clip = torch.nn.utils.clip_grad_norm_
@@ -383,13 +397,15 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
     opt = learner.optimizer.state_dict()["state"]
     for i, (k, shape) in enumerate(shapes):
         arrays["after_" + k] = sd[k].numpy().reshape(-1)[::subsample].copy()
+        arrays["delta_" + k] = (sd[k].double() - sd0[k].double()).numpy().reshape(-1)[::subsample].copy()
         arrays["m_" + k] = opt[i]["exp_avg"].numpy().reshape(-1)[::subsample].copy()
         arrays["v_" + k] = opt[i]["exp_avg_sq"].numpy().reshape(-1)[::subsample].copy()
         arrays["sum_after_" + k] = float(sd[k].double().sum())
     arrays["param_names"] = np.array([k for k, _ in shapes])
     arrays["param_shapes"] = np.array([str(s) for _, s in shapes])
     rn = learner.actor_critic.returns_normalizer
-    arrays["out_rms"] = np.array([rn.running_mean.item(), rn.running_var.item(), rn.count.item()])
+    if rn is not None:
+        arrays["out_rms"] = np.array([rn.running_mean.item(), rn.running_var.item(), rn.count.item()])
     if cfg.normalize_input:  # obs normaliser state + an eval-mode forward with the post-training weights and statistics
         on = learner.actor_critic.obs_normalizer.running_mean_std.running_mean_std["obs"]
         arrays["obsn_mean"] = on.running_mean.numpy().reshape(-1)[::subsample].copy()
@@ -400,10 +416,45 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
         with torch.no_grad():
             o = {k: v[:, 0].clone() for k, v in b["obs"].items()}
             nobs = ac.normalize_obs(o)
-            res = ac.forward_tail(ac.forward_head(nobs), values_only=False, sample_actions=False)
+            if use_rnn:  # one inference step through the core as well (model/core.py:37-64)
+                x, new_rnn = ac.forward_core(ac.forward_head(nobs), b["rnn_states"][:, 0].clone())
+                res = ac.forward_tail(x, values_only=False, sample_actions=False)
+                arrays["eval_new_rnn_states"] = new_rnn.numpy().copy()
+            else:
+                res = ac.forward_tail(ac.forward_head(nobs), values_only=False, sample_actions=False)
         arrays["eval_logits"] = res["action_logits"].numpy().copy()
         arrays["eval_values"] = res["values"].numpy().copy()
     save("train_" + name, **arrays)
+
+
+C2_MODEL_ARGS = ["--encoder_conv_architecture=convnet_atari", "--nonlinearity=relu", "--obs_scale=255.0",
+                 "--normalize_input=False", "--encoder_conv_mlp_layers", "512"]
+
+
+def gen_train_cnn84():
+    """The BASELINE configs[1] geometry at the Learner.train level: real Nature-CNN on 84x84x4 u8 frames, 512-wide fc,
+    E=64 trajectories x T=32, 2 minibatches of 1024 samples (the launch sizes that take the LDS-DMA / LDS-image kernel
+    families on the GPU), 5 % rows of another policy + stale versions (invalid rows)."""
+    obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 84, 84), np.uint8)})
+    gen_train("cnn84", obs, C2_MODEL_ARGS, E=64, T=32, A=6, nb=2, epochs=1, subsample=37, obs_seed=8484,
+              p_other_policy=0.05, extra=["--exploration_loss_coeff=0.01"])
+
+
+C5_OBS = gym.spaces.Dict({"obs": gym.spaces.Box(-10, 10, (27,), np.float32)})
+# sf_examples/mujoco/mujoco_params.py:1-38 + what BASELINE configs[4] adds (LSTM core, V-trace; SURVEY.md §8d "C5")
+C5_MODEL_ARGS = ["--encoder_mlp_layers", "64", "64", "--nonlinearity=tanh", "--normalize_input=True",
+                 "--adaptive_stddev=False", "--use_rnn=True", "--rnn_type=lstm", "--rnn_size=512"]
+C5_ALGO_ARGS = ["--recurrence=32", "--with_vtrace=True", "--normalize_returns=False", "--kl_loss_coeff=0.1",
+                "--value_bootstrap=True", "--max_grad_norm=3.5", "--ppo_clip_ratio=0.2", "--value_loss_coeff=1.3",
+                "--exploration_loss_coeff=0.0", "--learning_rate=0.00295", "--gamma=0.99"]
+
+
+def gen_train_c5():
+    """BASELINE configs[4] as ONE Learner.train replay: Ant-shaped obs f32[27], Box(8) with the learned stddev,
+    MLP[64,64] tanh encoder, LSTM-512 core (packed-sequence BPTT in the reference, rnn_utils.py:114-158), V-trace
+    (learner.py:601-640) + KL loss + value bootstrap on time-outs, input normalisation, invalid rows."""
+    gen_train("c5", C5_OBS, C5_MODEL_ARGS, E=32, T=32, A=None, nb=2, epochs=1, subsample=37, use_rnn=True, box_dims=8,
+              p_other_policy=0.04, extra=C5_ALGO_ARGS, fill_extra=dict(p_timeout=0.3))
 
 
 def gen_model_fwd():
@@ -543,6 +594,10 @@ def main():
         gen_prepare_and_losses()
     if "mb" in which:
         gen_minibatch_indices()
+    if "cnn84" in which:
+        gen_train_cnn84()
+    if "c5" in which:
+        gen_train_c5()
     if "train" in which:
         gen_train("mlp", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2)
         gen_train("mlp_inv", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=4, epochs=1, extra=["--kl_loss_coeff=0.1"])
@@ -566,6 +621,8 @@ def main():
         gen_train("gru", MLP_OBS, rnn_common + ["--rnn_type=gru"], E=16, T=8, A=6, nb=2, epochs=1, use_rnn=True)
         gen_train("lstm_inv", MLP_OBS, rnn_common + ["--rnn_type=lstm", "--kl_loss_coeff=0.1"], E=16, T=16, A=6, nb=2,
                   epochs=2, use_rnn=True, extra=["--recurrence=8"])
+        gen_train_cnn84()
+        gen_train_c5()
         gen_train("mlp_norm", MLP_OBS, ["--encoder_mlp_layers", "32", "32", "--nonlinearity=elu",
                                         "--normalize_input=True"], E=16, T=8, A=6, nb=2, epochs=1)
     if "model" in which:

@@ -376,7 +376,11 @@ class Learner:
                             rms, cfg.gamma, cfg.gae_lambda, cfg.value_bootstrap, adv, ret)
             buff.advantages, buff.returns = adv.view(N), ret.view(N)
         elif cfg.value_bootstrap:
-            raise NotImplementedError("value_bootstrap together with with_vtrace")
+            # learner.py:980-990 runs before (and independently of) the advantage estimator: rewards += gamma * v(t) on
+            # timed-out terminal steps.  The GAE launch performs exactly that in-place update; V-trace recomputes the
+            # advantages per minibatch, so its adv/ret outputs are scratch here (normalize_returns is off with V-trace).
+            lib.gae_returns(batch["rewards"], batch["dones"], batch["time_outs"], batch["values"], batch["valids"],
+                            None, cfg.gamma, cfg.gae_lambda, True, adv, ret)
         # flat dataset views (index e*T + t); [E,T+1] tensors lose their last column by a small compact copy
         buff.obs = obs
         buff.actions = batch["actions"].view(N, self.num_actions)

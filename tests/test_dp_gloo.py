@@ -110,3 +110,33 @@ def test_two_replicas_equal_one_on_the_concatenated_minibatch(tmp_path):
     st = oracle.rms_update(np.array([0.0, 1.0, 1.0]), b["returns"])
     delta, tot = np.float32(bm) - 0.0, 1.0 + n
     np.testing.assert_allclose([delta * n / tot, (1.0 + np.float32(bv) * n + delta * delta * n / tot) / tot, tot], st, rtol=1e-6)
+
+
+def test_bench_self_launches_replicas_and_checks_the_collective():
+    """`python bench.py --gpus 2` outside torchrun re-launches itself under torch.distributed.run (one rank per GPU),
+    every rank joins the group, the rank-stamped all-reduce proves both contributed; --check_launch stops before any GPU
+    work so the launcher / argument / env plumbing is testable on a CPU box (gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SF_DP_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check_launch", "--workload", "c5"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["launch_check"] and out["rccl_ranks"] == 2 and out["n_gpus"] == 2 and out["backend"] == "gloo"
+    assert len(out["rank_devices"]) == 2 and out["workload"] == "c5"
+
+
+def test_bench_rccl_launch_without_enough_devices_fails_in_rank_code():
+    """with the production backend (nccl = RCCL) on a box with fewer GPUs than ranks the error comes from the rank code
+    ("need N devices"), not from a launcher guard"""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SF_DP_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "need 2 devices on this node" in (r.stderr + r.stdout)
