@@ -353,8 +353,40 @@ def np_frames(seed, shape):
     return np.random.default_rng(seed).integers(0, 256, size=shape, dtype=np.uint8)
 
 
+def _to_double(x):
+    if isinstance(x, dict):
+        return type(x)({k: _to_double(v) for k, v in x.items()})
+    return x.double() if torch.is_tensor(x) and x.is_floating_point() else x
+
+
+def first_step_grads_fp64(learner, b, cfg, names, subsample):
+    # NB: `learner` is consumed (its model is converted to double)
+    """The gradient of the first SGD step once more, with the REFERENCE's own _calculate_losses + autograd executed in
+    float64 (model.double(), minibatch cast to double after the fp32 _prepare_batch): the round-off-free value both
+    fp32 implementations (torch-CPU in the reference, the HIP kernels here) approximate.  Lets the GPU test state how
+    far each of them is from the truth instead of only how far they are from each other."""
+    l64 = learner  # a fresh learner with the same seeded weights (the scripted conv head does not survive deepcopy)
+    buff, _size, num_invalids = l64._prepare_batch(clone_tensordict(b))
+    mb = AttrDict(l64._get_minibatch(buff, slice(0, cfg.batch_size)))
+    l64.actor_critic.double()
+    mb = AttrDict(_to_double(dict(mb)))
+    (_d, policy_loss, exploration_loss, _kl_old, kl_loss, value_loss, _s) = l64._calculate_losses(mb, num_invalids)
+    loss = policy_loss + exploration_loss + kl_loss + value_loss
+    for p_ in l64.actor_critic.parameters():
+        p_.grad = None
+    loss.backward()
+    out = {"g1_fp64_loss": float(loss)}
+    g = dict(l64.actor_critic.named_parameters())
+    print("  fp64 loss", float(loss), [k for k in names if g[k].grad is None])
+    for k in names:
+        assert g[k].grad.dtype == torch.float64
+        out["g1_fp64_" + k] = g[k].grad.numpy().reshape(-1)[::subsample].copy()
+    out["g1_fp64_norm"] = float(torch.sqrt(sum((g[k].grad ** 2).sum() for k in names)))
+    return out
+
+
 def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1, use_rnn=False,
-              box_dims=0, obs_seed=None, p_other_policy=None, fill_extra=None):
+              box_dims=0, obs_seed=None, p_other_policy=None, fill_extra=None, fp64_first_step=False):
     cfg = make_cfg(list(model_args) + [f"--rollout={T}", f"--batch_size={E * T // nb}",
                                        f"--num_batches_per_epoch={nb}", f"--num_epochs={epochs}"] + list(extra),
                    use_rnn=use_rnn)
@@ -378,11 +410,19 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
         arrays["obs_seed"] = obs_seed
         arrays["obs_crc"] = int(b["obs"]["obs"].long().sum())
     sd0 = {k: v.clone() for k, v in learner.actor_critic.state_dict().items()}
+    if fp64_first_step:
+        l64, _ = make_learner(cfg, obs_space, action_space, E)
+        load_seeded(l64.actor_critic, seed=param_seed)
+        arrays.update(first_step_grads_fp64(l64, b, cfg, [k for k, _ in shapes], subsample))
     # record per-SGD-step grad norms by wrapping clip_grad_norm_
     norms = []
     orig_clip = torch.nn.utils.clip_grad_norm_
+    first_grads = {}
 
     def spy_clip(params, max_norm, *a, **k):
+        if not norms:  # gradient of the FIRST SGD step as the reference's fp32 autograd produced it (before clipping)
+            for kname, p_ in learner.actor_critic.named_parameters():
+                first_grads[kname] = p_.grad.detach().clone()
         n = orig_clip(params, max_norm, *a, **k)
         norms.append(float(n))
         return n
@@ -391,6 +431,8 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
     stats = learner.train(clone_tensordict(b))
     torch.nn.utils.clip_grad_norm_ = orig_clip
     arrays["grad_norms"] = np.array(norms)
+    for k, _ in shapes:
+        arrays["g1_" + k] = first_grads[k].numpy().reshape(-1)[::subsample].copy()
     arrays["train_step"] = learner.train_step
     arrays["env_steps"] = stats["learner_env_steps"]
     sd = learner.actor_critic.state_dict()
@@ -437,7 +479,7 @@ def gen_train_cnn84():
     families on the GPU), 5 % rows of another policy + stale versions (invalid rows)."""
     obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 84, 84), np.uint8)})
     gen_train("cnn84", obs, C2_MODEL_ARGS, E=64, T=32, A=6, nb=2, epochs=1, subsample=37, obs_seed=8484,
-              p_other_policy=0.05, extra=["--exploration_loss_coeff=0.01"])
+              p_other_policy=0.05, extra=["--exploration_loss_coeff=0.01"], fp64_first_step=True)
 
 
 C5_OBS = gym.spaces.Dict({"obs": gym.spaces.Box(-10, 10, (27,), np.float32)})
@@ -454,7 +496,7 @@ def gen_train_c5():
     MLP[64,64] tanh encoder, LSTM-512 core (packed-sequence BPTT in the reference, rnn_utils.py:114-158), V-trace
     (learner.py:601-640) + KL loss + value bootstrap on time-outs, input normalisation, invalid rows."""
     gen_train("c5", C5_OBS, C5_MODEL_ARGS, E=32, T=32, A=None, nb=2, epochs=1, subsample=37, use_rnn=True, box_dims=8,
-              p_other_policy=0.04, extra=C5_ALGO_ARGS, fill_extra=dict(p_timeout=0.3))
+              p_other_policy=0.04, extra=C5_ALGO_ARGS, fill_extra=dict(p_timeout=0.3), fp64_first_step=True)
 
 
 def gen_model_fwd():

@@ -80,6 +80,12 @@ class Batcher:
 
     def on_new_trajectories(self, trajectory_slice: slice) -> List[slice]:
         self.slices_for_training.merge_slices(trajectory_slice)
+        return self.ready_batches()
+
+    def ready_batches(self) -> List[slice]:
+        """datasets that can go to the learner NOW: complete (exactly one training iteration of adjacent rows) and
+        within the cap of max_batches_to_accumulate datasets in flight (batcher.py:170-218: no free training batch ->
+        the rows wait in the merger and, once the slab has no free slice left, the sampler pauses)"""
         out = []
         while self.in_flight + len(out) < self.buffer_mgr.max_batches_to_accumulate:
             s = self.slices_for_training.get_exactly(self.traj_per_training_iteration)

@@ -255,17 +255,39 @@ class Learner:
         return dict(train_step=self.train_step, env_steps=self.env_steps, best_performance=self.best_performance,
                     model=ac.state_dict(), optimizer=opt, curr_lr=self.curr_lr)
 
-    def save(self) -> bool:
-        """learner.py:334-362: atomic temp+rename, keep cfg.keep_checkpoints newest."""
+    def _save_impl(self, name_prefix: str, name_suffix: str, keep_checkpoints: int) -> bool:
+        """learner.py:334-360: atomic temp+rename, keep the `keep_checkpoints` newest files of this prefix"""
+        if not self.is_initialized:
+            return False
         d = self.checkpoint_dir(self.cfg, self.policy_id)
-        tmp = join(d, "checkpoint_temp")
-        name = join(d, f"checkpoint_{self.train_step:09d}_{self.env_steps}.pth")
+        tmp = join(d, f"{name_prefix}_temp")
+        name = join(d, f"{name_prefix}_{self.train_step:09d}_{self.env_steps}{name_suffix}.pth")
         torch.save(self._get_checkpoint_dict(), tmp)
         os.rename(tmp, name)
-        cps = self.get_checkpoints(d)
-        while len(cps) > self.cfg.keep_checkpoints:
-            os.remove(cps.pop(0))
+        while len(cps := self.get_checkpoints(d, f"{name_prefix}_*")) > keep_checkpoints:
+            if os.path.isfile(cps[0]):
+                os.remove(cps[0])
         return True
+
+    def save(self) -> bool:
+        """learner.py:362-363"""
+        return self._save_impl("checkpoint", "", self.cfg.keep_checkpoints)
+
+    def save_milestone(self) -> None:
+        """learner.py:365-374: a copy under checkpoint_p<id>/milestones/ that is never rotated out"""
+        d = join(self.checkpoint_dir(self.cfg, self.policy_id), "milestones")
+        os.makedirs(d, exist_ok=True)
+        torch.save(self._get_checkpoint_dict(), join(d, f"checkpoint_{self.train_step:09d}_{self.env_steps}.pth"))
+
+    def save_best(self, policy_id, metric, metric_value) -> bool:
+        """learner.py:376-386: keep ONE best_* file, replaced when the metric improved by more than 1e-3"""
+        if policy_id != self.policy_id:
+            return False
+        p = 3  # precision, number of significant digits
+        if metric_value - self.best_performance > 1 / 10 ** p:
+            self.best_performance = metric_value
+            return self._save_impl("best", f"_{metric}_{metric_value:.{p}f}", 1)
+        return False
 
     def _load_state(self, cp, load_progress=True):
         """learner.py:289-298"""
@@ -294,7 +316,9 @@ class Learner:
         ac.params_changed()
 
     def load_from_checkpoint(self, policy_id, load_progress=True) -> None:
-        cps = self.get_checkpoints(self.checkpoint_dir(self.cfg, policy_id))
+        """learner.py:300-310: the newest checkpoint_* (cfg.load_checkpoint_kind == "latest") or best_* ("best")"""
+        prefix = dict(latest="checkpoint", best="best")[self.cfg.load_checkpoint_kind]
+        cps = self.get_checkpoints(self.checkpoint_dir(self.cfg, policy_id), pattern=f"{prefix}_*")
         cp = self.load_checkpoint(cps, self.device)
         if cp is not None:
             self._load_state(cp, load_progress)

@@ -123,6 +123,12 @@ def verify_cfg(cfg, env_info) -> bool:
         ok = False
         print(f"[sample_factory_amd] config error: {msg}")
 
+    if cfg.num_policies != 1:
+        err(f"{cfg.num_policies=}: this engine trains ONE policy per process group (multi-policy / PBT populations are "
+            "outside the hot-path scope)")
+    if cfg.num_envs_per_worker % cfg.worker_num_splits != 0:
+        err(f"{cfg.num_envs_per_worker=} must be a multiple of {cfg.worker_num_splits=}"
+            " (for double-buffered sampling you need to use even number of envs per worker)")
     if cfg.normalize_returns and cfg.with_vtrace:
         err("Normalized returns are not supported with vtrace!")
     if cfg.with_vtrace and not (cfg.recurrence == cfg.rollout and cfg.recurrence > 1):

@@ -6,6 +6,7 @@ torchrun (WORLD_SIZE>1) each rank runs a replica on its own env shard and gradie
 """
 from __future__ import annotations
 
+import json
 import os
 import time
 from collections import deque
@@ -18,10 +19,10 @@ import torch
 from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
 from sample_factory_amd.algo.sampling.batched_sampling import BatchedVectorEnvRunner
 from sample_factory_amd.algo.utils.env_info import extract_env_info
-from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+from sample_factory_amd.algo.learning.batcher import Batcher
+from sample_factory_amd.algo.utils.shared_buffers import BufferMgr
 from sample_factory_amd.cfg.arguments import preprocess_cfg
 from sample_factory_amd.envs.env_utils import create_env, find_training_info_interface, set_training_info
-from sample_factory_amd.model.actor_critic import get_rnn_size
 from sample_factory_amd.utils.attr_dict import AttrDict
 
 
@@ -121,6 +122,8 @@ class Runner:
         reference round-trips dones/rewards to the host every step, batched_sampling.py:215-287).  At every report they
         are read back ONCE, turned into the reference's message {EPISODIC: {reward, len}, policy_id} (one entry = the
         mean over the episodes that finished since the previous report, plus their count under "episodes") and reset."""
+        if self.cfg.async_rl:  # rollout kernels add to ep_stats on their own stream: drain it before read + reset
+            self.rollout_stream.synchronize()
         tot = sum(sm.ep_stats.cpu() for sm in self.samplers)
         for sm in self.samplers:
             sm.ep_stats.zero_()
@@ -128,6 +131,32 @@ class Runner:
         if k > 0:
             self._process_msg({EPISODIC: dict(reward=float(tot[0]) / k, len=float(tot[1]) / k, episodes=k),
                                POLICY_ID_KEY: 0})
+
+    # ------------------------------------------------------------------------------------------ experiment directory
+    def _handle_restart(self) -> None:
+        """runner.py:207-230: resume (default) keeps the directory, restart moves it aside, overwrite removes it"""
+        import shutil
+        exp_dir = os.path.join(self.cfg.train_dir, self.cfg.experiment)
+        if not os.path.isdir(exp_dir) or self.cfg.restart_behavior == "resume":
+            return
+        if self.cfg.restart_behavior == "restart":
+            attempt, old = 0, exp_dir
+            while os.path.isdir(old):
+                attempt += 1
+                old = f"{exp_dir}_old{attempt:04d}"
+            shutil.move(exp_dir, old)
+        elif self.cfg.restart_behavior == "overwrite":
+            shutil.rmtree(exp_dir)
+        else:
+            raise ValueError(f"Unknown restart behavior {self.cfg.restart_behavior}")
+
+    def _save_cfg(self) -> None:
+        """runner.py:497-501: config.json next to the checkpoints (what enjoy / resume read back)"""
+        d = os.path.join(self.cfg.train_dir, self.cfg.experiment)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "config.json"), "w") as f:
+            json.dump({k: v for k, v in vars(self.cfg).items() if isinstance(v, (int, float, str, bool, list, type(None)))},
+                      f, indent=2)
 
     def init(self) -> int:
         cfg = self.cfg
@@ -139,11 +168,15 @@ class Runner:
             if getattr(cfg, "synthetic_env0", None) in (None, 0):  # env shard of this replica (weak scaling)
                 cfg.synthetic_env0 = (self.rank * getattr(cfg, "synthetic_num_agents", 4096) *
                                       max(1, int(cfg.num_workers) * int(cfg.num_envs_per_worker)))
+        if self.rank == 0:
+            self._handle_restart()
+        if self.world > 1:
+            torch.distributed.barrier()  # nobody looks for checkpoints before rank 0 has dealt with the directory
         # Env instances: num_workers * num_envs_per_worker vector envs, as in the reference (rollout_worker.py:96-117,
-        # each with its own env_config); here they all live in this process and fill consecutive row blocks of ONE
-        # slab.  With more than one instance their rollouts run on cfg.worker_num_splits HIP streams (the reference's
-        # double-buffered sampling: while one group's envs step, the other group's policy forward runs), which fills
-        # the tails of the small-batch kernels: measured in tools/split_probe.py and DESIGN.md §5.
+        # each with its own env_config); here they all live in this process.  The instances of one worker are grouped
+        # into cfg.worker_num_splits SAMPLING UNITS (the reference's double-buffered sampling); a unit fills one free
+        # slice of the slab per rollout and the units' rollouts run on worker_num_splits HIP streams, which fills the
+        # tails of the small-batch kernels: measured in tools/split_probe.py and DESIGN.md §5.
         E = max(1, int(cfg.num_workers) * int(cfg.num_envs_per_worker))
         self.envs = [create_env(cfg.env, cfg, AttrDict(worker_index=e // int(cfg.num_envs_per_worker),
                                                        vector_index=e % int(cfg.num_envs_per_worker), env_id=e))
@@ -153,14 +186,31 @@ class Runner:
         n = self.env_info.num_agents
         if any(env.num_agents != n for env in self.envs):
             raise ValueError("all env instances must have the same number of agents")
+        if int(cfg.num_envs_per_worker) % int(cfg.worker_num_splits) != 0:
+            cfg.worker_num_splits = 1  # (the reference rejects this; one unit per worker is the natural reading)
         if not preprocess_cfg(cfg, self.env_info):
             raise ValueError("Invalid config! See above for details.")
-        self.policy_versions = torch.zeros(cfg.num_policies, dtype=torch.int32)
+        if self.rank == 0:
+            self._save_cfg()
+        if not torch.cuda.is_available():
+            from sample_factory_amd import lib
+            raise lib.SfHipError("Runner.init(): no GPU visible. sample_factory_amd has no CPU path.")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        # Slab + free-slice queue + policy versions (shared_buffers.py:152-239).  Rows: agents x env instances, twice
+        # that when rollouts overlap training (async), never fewer than the learner's dataset(s).
+        cfg.batched_sampling = True  # this engine only has the batched sampler
+        self.buffer_mgr = BufferMgr(cfg, self.env_info, dev)
+        self.batcher = Batcher(self.buffer_mgr, cfg)
+        self.traj = self.buffer_mgr.traj_tensors
+        self.policy_versions = self.buffer_mgr.policy_versions
         self.learner = Learner(cfg, self.env_info, self.policy_versions, 0, ParameterServer(0, self.policy_versions))
         self.learner.init()
-        dev = self.learner.device
-        self.num_rows = E * n
-        self.traj = alloc_trajectory_tensors(self.env_info, self.num_rows, cfg.rollout, get_rnn_size(cfg), dev)
+        self.num_rows = E * n  # trajectories per sampling round (all units)
+        # sampling units: (worker, split) -> env instances [e0, e0 + per_unit)
+        per_unit = int(cfg.num_envs_per_worker) // int(cfg.worker_num_splits)
+        self.unit_rows = per_unit * n
+        assert self.unit_rows == self.buffer_mgr.sampling_trajectories_per_iteration
+        self.units = [list(range(e0, e0 + per_unit)) for e0 in range(0, E, per_unit)]
         # one sampling stream for the whole job: key = (seed, global env row) -> a G-replica (or G-instance) rollout is
         # bit-identical to the single-replica rollout of the concatenated env set
         self.samplers = [BatchedVectorEnvRunner(cfg, self.env_info, env, self.learner.actor_critic,
@@ -169,66 +219,109 @@ class Runner:
                                                 tag="inf" if e == 0 else f"inf{e}")
                          for e, env in enumerate(self.envs)]
         self.sampler = self.samplers[0]
+        self._prev_rows: List = [None] * E          # slab view each env instance wrote its previous rollout into
         S = max(1, min(int(cfg.worker_num_splits), E))
         self.split_streams = [torch.cuda.Stream() for _ in range(S)] if E > 1 else None
         self._ev_fork = torch.cuda.Event()
         self._ev_join = [torch.cuda.Event() for _ in range(S)]
         self._training_info_ifaces = [find_training_info_interface(env) for env in self.envs]
-        if cfg.async_rl:  # rollout k+1 overlaps Learner.train(k): two slabs, two streams, published weight snapshots
-            self.traj2 = alloc_trajectory_tensors(self.env_info, self.num_rows, cfg.rollout, get_rnn_size(cfg), dev)
-            self.slabs = [self.traj, self.traj2]
+        self._ready: List[slice] = []               # complete datasets waiting for the learner
+        self._round_events: Dict[int, torch.cuda.Event] = {}   # sampling slice start -> "rollout written" event
+        self._free_events: Dict[int, torch.cuda.Event] = {}    # sampling slice start -> "learner done with rows" event
+        self.sampling_rounds = 0
+        if cfg.async_rl:  # rollouts overlap Learner.train: second stream, published weight snapshots
             self.rollout_stream = torch.cuda.Stream()
-            self.ev_rollout = [torch.cuda.Event(), torch.cuda.Event()]
-            self.ev_train = [torch.cuda.Event(), torch.cuda.Event()]
             self.ev_publish = torch.cuda.Event()
             self.learner.actor_critic.enable_weight_snapshots()
-            self.k = 0
+            self._pub_slot = 0                      # snapshot slot holding the most recently published weights
+            self._slot_last_read = [None, None]     # last sampling-round event that read each slot
             self.published_version = float(self.learner.train_step)
         self._observers_call("on_init", self)
         self._observers_call("on_connect_components", self)
         return ExperimentStatus.SUCCESS
 
-    def _rollout_all(self, policy_version: float, slab=None, carry_from=None) -> None:
-        """one rollout of every env instance into its row block of `slab` (default: the current slab), enqueued behind
-        everything already on the current stream; returns with the current stream waiting for all of them"""
+    @property
+    def slabs(self):
+        """the row blocks of the slab one sampling round fills (async mode: two of them in flight)"""
+        R = self.num_rows
+        return [self.traj[i:i + R] for i in range(0, self.buffer_mgr.num_buffers, R)]
+
+    # ------------------------------------------------------------------------------------------ sampling
+    def _acquire_round(self):
+        """one free slab slice per sampling unit, or None if the slab has no room for a whole round (every row is
+        with the learner: the sampler pauses, inference_worker.py:175-181)"""
+        if len(self.buffer_mgr.traj_buffer_queue) < len(self.units):
+            return None
+        return [self.buffer_mgr.get_free_slice() for _ in self.units]
+
+    def _rollout_all(self, policy_version: float, slices=None) -> List[slice]:
+        """One sampling round: every unit rolls its env instances out into its slice of the slab, enqueued behind
+        everything already on the current stream; returns with the current stream waiting for all of them."""
         n = self.env_info.num_agents
+        if slices is None:
+            slices = self._acquire_round()
+            assert slices is not None, "no free trajectory rows"
         for iface in self._training_info_ifaces:  # curricula: batched_sampling.py:352-355
             set_training_info(iface, dict(approx_total_training_steps=int(self.learner.env_steps)))
-        if slab is not None:
-            for e, sm in enumerate(self.samplers):
-                sm.set_slab(slab[e * n:(e + 1) * n], carry_from=carry_from[e * n:(e + 1) * n] if carry_from is not None else None)
+        cur = torch.cuda.current_stream()
+        for unit, sl in zip(self.units, slices):
+            ev = self._free_events.pop(sl.start, None)
+            if ev is not None:
+                cur.wait_event(ev)  # the learner has finished reading these rows
+            for j, e in enumerate(unit):
+                rows = self.traj[sl.start + j * n: sl.start + (j + 1) * n]
+                self.samplers[e].set_slab(rows, carry_from=self._prev_rows[e])
+                self._prev_rows[e] = rows
         if self.split_streams is None:
             self.sampler.rollout(policy_version=policy_version)
-            return
-        base, S = torch.cuda.current_stream(), len(self.split_streams)
-        for sm in self.samplers:
-            sm.begin_rollout(policy_version)  # (first call: env reset into slab obs[:, 0], on the base stream)
-        self._ev_fork.record(base)
-        for st in self.split_streams:
-            st.wait_event(self._ev_fork)
-        for t in range(self.cfg.rollout):  # steps of the groups interleaved on the host, concurrent on the device
-            for e, sm in enumerate(self.samplers):
-                with torch.cuda.stream(self.split_streams[e % S]):
-                    sm.rollout_step(t)
-        for i, st in enumerate(self.split_streams):
-            self._ev_join[i].record(st)
-            base.wait_event(self._ev_join[i])
+        else:
+            base, S = cur, len(self.split_streams)
+            for sm in self.samplers:
+                sm.begin_rollout(policy_version)  # (first call: env reset into slab obs[:, 0], on the base stream)
+            self._ev_fork.record(base)
+            for st in self.split_streams:
+                st.wait_event(self._ev_fork)
+            for t in range(self.cfg.rollout):  # steps of the groups interleaved on the host, concurrent on the device
+                for e, sm in enumerate(self.samplers):
+                    with torch.cuda.stream(self.split_streams[e % S]):
+                        sm.rollout_step(t)
+            for i, st in enumerate(self.split_streams):
+                self._ev_join[i].record(st)
+                base.wait_event(self._ev_join[i])
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for sl in slices:
+            self._round_events[sl.start] = ev
+            self._ready += self.batcher.on_new_trajectories(sl)   # SliceMerger: adjacent slices -> datasets
+        self.sampling_rounds += 1
+        self._last_round_event = ev
+        return slices
 
     def episode_stats(self):
         """episode statistics over all env instances"""
+        if self.cfg.async_rl:
+            self.rollout_stream.synchronize()
         tot = sum(sm.ep_stats.cpu() for sm in self.samplers)
         k = float(tot[2])
         return dict(episodes=k, mean_return=float(tot[0]) / k if k else 0.0, mean_len=float(tot[1]) / k if k else 0.0)
 
-    def iteration(self):
-        """one dataset: rollout of all envs, then Learner.train on the slab in place"""
-        if self.cfg.async_rl:
-            stats = self.iteration_async()
-        else:
-            self._rollout_all(float(self.learner.train_step))
-            stats = self.learner.train(self.traj)
-            for sm in self.samplers:
-                sm.carry_over()
+    # ------------------------------------------------------------------------------------------ learning
+    def _train_dataset(self, ds: slice):
+        """Learner.train on slab rows [ds) IN PLACE (the reference copies them into a training batch first,
+        batcher.py:192-212), then hand the rows back: training slice -> SliceMerger -> free sampling slices"""
+        main = torch.cuda.current_stream()
+        unit = self.unit_rows
+        for start in range(ds.start - ds.start % unit, ds.stop, unit):
+            ev = self._round_events.get(start)
+            if ev is not None:
+                main.wait_event(ev)
+        stats = self.learner.train(self.traj[ds])
+        ev = torch.cuda.Event()
+        ev.record(main)
+        for start in range(ds.start - ds.start % unit, ds.stop, unit):
+            self._free_events[start] = ev
+        self.batcher.on_training_batch_released(ds)
+        self._ready += self.batcher.ready_batches()  # a dataset that was waiting for a free training batch
         if stats is not None:
             self.training_iteration_since_resume += 1
             if self.msg_handlers or len(self.policy_msg_handlers) > 1:  # learner report -> registered handlers
@@ -236,38 +329,60 @@ class Runner:
             self._observers_call("on_training_step", self, self.training_iteration_since_resume)
         return stats
 
-    def iteration_async(self):
-        """Asynchronous APPO as stream-level overlap (the reference's async mode is process-level: batcher.py:214-218,
-        inference_worker.py:175-181).  Iteration k enqueues rollout k on the rollout stream (reading weight snapshot
-        k % 2, i.e. the weights after train(k-2): policy lag of one dataset, recorded in policy_version as the
-        reference does) and then trains on the slab of rollout k-1 on the main stream.  Slab / snapshot hand-offs are
-        HIP events; the only host syncs are the learner's own (one per dataset, one per epoch)."""
-        k, ac = self.k, self.learner.actor_critic
-        cur, prev = self.slabs[k % 2], self.slabs[(k + 1) % 2]
-        main = torch.cuda.current_stream()
-        with torch.cuda.stream(self.rollout_stream):
-            if k >= 2:
-                self.rollout_stream.wait_event(self.ev_train[k % 2])   # the learner is done with this slab ...
-            if k >= 1:
-                self.rollout_stream.wait_event(self.ev_publish)        # ... and snapshot k % 2 is complete
-            ac.snap_read = k % 2
-            self._rollout_all(self.published_version, slab=cur, carry_from=prev if k >= 1 else None)
-            self.ev_rollout[k % 2].record(self.rollout_stream)
+    def iteration(self):
+        """Synchronous APPO (rollout_worker.py:108-126): sampling rounds until a dataset is complete (one round when
+        batch_size * num_batches_per_epoch == agents * rollout, k rounds when it is k times that), then the learner
+        trains on every complete dataset (several per round when a dataset is a fraction of a round) while the
+        sampler waits: zero policy lag at the first minibatch."""
+        if self.cfg.async_rl:
+            return self.iteration_async()
+        while not self._ready:
+            self._rollout_all(float(self.learner.train_step))
         stats = None
-        if k >= 1:
-            main.wait_event(self.ev_rollout[(k + 1) % 2])
-            stats = self.learner.train(prev)
-            ac.publish_weights((k + 1) % 2)                            # read by rollout k+1
-            self.ev_publish.record(main)
-            self.ev_train[(k + 1) % 2].record(main)
-            self.published_version = float(self.learner.train_step)
-        self.k += 1
+        while self._ready:
+            stats = self._train_dataset(self._ready.pop(0)) or stats
         return stats
 
+    def iteration_async(self):
+        """Asynchronous APPO as stream-level overlap (the reference's async mode is process-level: batcher.py:214-218,
+        inference_worker.py:175-181).  An iteration enqueues one sampling round on the rollout stream — into free slab
+        slices, reading the most recently PUBLISHED weight snapshot (policy lag recorded in policy_version as the
+        reference does) — and then trains, on the main stream, on the datasets that were complete BEFORE this round:
+        rollout k+1 overlaps train(k).  The sampler pauses when the slab has no free slice (every row is with the
+        learner or waiting in one of the num_batches_to_accumulate datasets).  Hand-offs are HIP events; the only host
+        syncs are the learner's own (one per dataset, one per epoch)."""
+        ac = self.learner.actor_critic
+        main = torch.cuda.current_stream()
+        todo, self._ready = self._ready, []
+        slices = self._acquire_round()
+        if slices is not None:
+            with torch.cuda.stream(self.rollout_stream):
+                if self.sampling_rounds >= 1:
+                    self.rollout_stream.wait_event(self.ev_publish)    # the snapshot being read is complete
+                ac.snap_read = self._pub_slot
+                self._rollout_all(self.published_version, slices)
+                self._slot_last_read[self._pub_slot] = self._last_round_event
+        stats = None
+        for ds in todo:
+            stats = self._train_dataset(ds) or stats
+        if todo:
+            slot = 1 - self._pub_slot                                  # never the slot a running round reads
+            if self._slot_last_read[slot] is not None:
+                main.wait_event(self._slot_last_read[slot])            # ... and its last reader has finished
+            ac.publish_weights(slot)
+            self.ev_publish.record(main)
+            self._pub_slot = slot
+            self.published_version = float(self.learner.train_step)
+        elif slices is None:
+            raise RuntimeError("async iteration made no progress: no free rows and no complete dataset "
+                               "(slab smaller than one dataset?)")
+        return stats
+
+    # ------------------------------------------------------------------------------------------ reports / checkpoints
     def _report(self, t0: float) -> None:
         """the periodic console report of the reference (runner.py:314-346) + observers' extra_summaries"""
         self._emit_episodic_stats()
-        fps = self.learner.env_steps / max(1e-9, time.time() - t0)
+        fps = (self.learner.env_steps - self._env_steps0) / max(1e-9, time.time() - t0)
         if self.rank == 0:
             print(f"Fps is {fps:.1f}. Total num frames: {self.learner.env_steps}.")
             if "reward" in self.policy_avg_stats and len(self.policy_avg_stats["reward"][0]):
@@ -275,21 +390,58 @@ class Runner:
                 print("Avg episode reward: %r" % [(0, f"{avg:.3f}")])
         self._observers_call("extra_summaries", self, 0, int(self.learner.env_steps), None)
 
+    def _save_policy(self) -> None:
+        """runner.py:453-454 -> learner.save(); rank 0 only: replicas hold identical weights and share the directory"""
+        if self.rank == 0:
+            self.learner.save()
+
+    def _save_milestone_policy(self) -> None:
+        if self.rank == 0:
+            self.learner.save_milestone()
+
+    def _save_best_policy(self) -> None:
+        """runner.py:459-475: once save_best_after env steps are in, save when the running average of
+        cfg.save_best_metric improved (the threshold test is Learner.save_best's)"""
+        metric = self.cfg.save_best_metric
+        if self.rank != 0 or metric not in self.policy_avg_stats or self.learner.env_steps < self.cfg.save_best_after:
+            return
+        stats = self.policy_avg_stats[metric][0]
+        if len(stats) > 0:
+            self.learner.save_best(0, metric, float(np.mean(stats)))
+
     def run(self) -> int:
         cfg = self.cfg
         t0 = time.time()
-        last_report = t0
+        self._env_steps0 = self.learner.env_steps
+        last = dict(report=t0, save=t0, best=t0, milestone=t0)
         self._observers_call("on_start", self)
-        while self.learner.env_steps < cfg.train_for_env_steps and time.time() - t0 < cfg.train_for_seconds:
-            self.iteration()
-            if time.time() - last_report >= self.report_interval_sec:
-                last_report = time.time()
-                self._report(t0)
+        try:
+            while self.learner.env_steps < cfg.train_for_env_steps and time.time() - t0 < cfg.train_for_seconds:
+                self.iteration()
+                now = time.time()
+                if now - last["report"] >= self.report_interval_sec:
+                    last["report"] = now
+                    self._report(t0)
+                # the reference's periodic timers (runner.py:170-176), checked between iterations
+                if cfg.save_every_sec > 0 and now - last["save"] >= cfg.save_every_sec:
+                    last["save"] = now
+                    self._save_policy()
+                if cfg.save_best_every_sec > 0 and now - last["best"] >= cfg.save_best_every_sec:
+                    last["best"] = now
+                    self._emit_episodic_stats()
+                    self._save_best_policy()
+                if cfg.save_milestones_sec > 0 and now - last["milestone"] >= cfg.save_milestones_sec:
+                    last["milestone"] = now
+                    self._save_milestone_policy()
+        except KeyboardInterrupt:
+            self.status = ExperimentStatus.INTERRUPTED
         torch.cuda.synchronize()
         self.env_steps = self.learner.env_steps
-        self.fps = self.env_steps / max(1e-9, time.time() - t0)
+        self.fps = (self.env_steps - self._env_steps0) / max(1e-9, time.time() - t0)
         self._emit_episodic_stats()
         self._observers_call("on_stop", self)
+        self._save_policy()        # runner.py:685-698 (_stop_training): final checkpoint + best check
+        self._save_best_policy()
         if self.rank == 0:
             print(f"Collected {{0: {self.env_steps}}}, FPS: {self.fps:.1f}")
         return self.status

@@ -33,3 +33,12 @@ def golden_json():
             return json.load(f)
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _isolated_train_dir(tmp_path, monkeypatch):
+    """every test gets its own default --train_dir: Runner.run() writes checkpoints on stop and restart_behavior
+    defaults to "resume" (as in the reference), so a shared directory would leak weights between tests"""
+    from sample_factory_amd.cfg import arguments
+    flags = [(("train_dir", str, str(tmp_path / "train_dir")) if f[0] == "train_dir" else f) for f in arguments.FLAGS]
+    monkeypatch.setattr(arguments, "FLAGS", flags)

@@ -68,12 +68,21 @@ def test_verify_cfg_rules():
     from sample_factory_amd.algo.utils.env_info import EnvInfo
     from sample_factory_amd.cfg.arguments import default_cfg, preprocess_cfg
     ei = EnvInfo(None, None, 4096)
-    ok = default_cfg(use_rnn=False, async_rl=False, num_workers=1, num_envs_per_worker=1, rollout=32, batch_size=32768,
-                     num_batches_per_epoch=4)
+    ok = default_cfg(use_rnn=False, async_rl=False, num_workers=1, num_envs_per_worker=1, worker_num_splits=1, rollout=32,
+                     batch_size=32768, num_batches_per_epoch=4)
     assert preprocess_cfg(ok, ei) and ok.recurrence == 1
-    bad = default_cfg(use_rnn=False, with_vtrace=True, normalize_returns=True)
+    # a dataset of k rollouts (the Batcher accumulates them) is fine in sync mode, a non-multiple is not
+    assert preprocess_cfg(default_cfg(use_rnn=False, async_rl=False, num_workers=1, num_envs_per_worker=1,
+                                      worker_num_splits=1, rollout=32, batch_size=65536, num_batches_per_epoch=4), ei)
+    # cfg/arguments.py:124-128: envs per worker must split evenly into the double-buffered sampling groups
+    assert not preprocess_cfg(default_cfg(use_rnn=False, async_rl=True, num_workers=1, num_envs_per_worker=1,
+                                          worker_num_splits=2), ei)
+    assert not preprocess_cfg(default_cfg(use_rnn=False, async_rl=True, num_workers=1, num_envs_per_worker=2,
+                                          worker_num_splits=2, num_policies=2), ei)
+    bad = default_cfg(use_rnn=False, with_vtrace=True, normalize_returns=True, num_envs_per_worker=2)
     assert not preprocess_cfg(bad, ei)
-    bad2 = default_cfg(use_rnn=False, async_rl=False, num_workers=1, num_envs_per_worker=1, batch_size=1024)
+    bad2 = default_cfg(use_rnn=False, async_rl=False, num_workers=1, num_envs_per_worker=1, worker_num_splits=1,
+                       batch_size=1024)
     assert not preprocess_cfg(bad2, ei)
 
 

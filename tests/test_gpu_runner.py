@@ -1,0 +1,141 @@
+"""Runner data plane and life-cycle on the GPU: the slab bookkeeping of BufferMgr / Batcher / SliceMerger wired into the
+rollout -> train loop (shared_buffers.py:152-239, batcher.py:170-234, rollout_worker.py:108-126), and the checkpoint
+life-cycle of runner.py:170-176,207-230,685-698 + learner.py:300-386."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic_cfg(**over):
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    register_env("synthetic_atari", make_synthetic_env)
+    base = dict(env="synthetic_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                encoder_conv_architecture="convnet_atari", rollout=8, num_epochs=1, num_workers=1, num_envs_per_worker=1,
+                worker_num_splits=1, async_rl=False, seed=2, serial_mode=True, synthetic_num_agents=64,
+                summaries_every_train=True)
+    base.update(over)
+    return default_cfg(**base)
+
+
+def test_sync_dataset_accumulated_from_two_rollouts():
+    """batch_size * num_batches_per_epoch = 2 x (agents * rollout): the slab has two sampling slices, the Batcher merges
+    them into one dataset, the learner trains once per two rollouts — both collected by the same policy version (sync
+    mode: lag 0 at the first minibatch, tests/envs/mujoco/test_envpool_mujoco.py:99-114 in the reference)."""
+    from sample_factory_amd.train import make_runner
+    cfg, runner = make_runner(_synthetic_cfg(batch_size=512, num_batches_per_epoch=2))
+    runner.init()
+    assert runner.buffer_mgr.num_buffers == 128 and runner.traj["rewards"].shape == (128, 8)
+    assert list(runner.buffer_mgr.traj_buffer_queue) == [slice(0, 64), slice(64, 128)]
+    stats = runner.iteration()
+    torch.cuda.synchronize()
+    assert runner.sampling_rounds == 2 and stats["learner_env_steps"] == 1024 and runner.learner.train_step == 2
+    tr = runner.traj
+    assert (tr["policy_version"] == 0.0).all() and (tr["policy_id"] == 0).all()
+    assert stats["train"]["version_diff_min"] == 2.0 and stats["train"]["version_diff_max"] == 2.0  # after the LAST minibatch
+    # the second rollout continues the first one: obs[:, 0] of rows 64.. is obs[:, T] of rows 0..63
+    assert torch.equal(tr["obs"]["obs"][64:, 0], tr["obs"]["obs"][:64, 8])
+    import oracle
+    np.testing.assert_array_equal(tr["obs"]["obs"][64:, 8].cpu().numpy().reshape(64, -1), oracle.synth_obs(64, 0, 28224, 2, 16))
+    # every row went back to the free queue, in sampling-slice units
+    assert sorted(s.start for s in runner.buffer_mgr.traj_buffer_queue) == [0, 64] and runner.batcher.in_flight == 0
+    stats = runner.iteration()
+    assert runner.sampling_rounds == 4 and stats["learner_env_steps"] == 2048
+    assert (runner.traj["policy_version"] == 2.0).all()
+
+
+def test_async_round_split_into_two_datasets():
+    """agents * rollout = 2 x (batch_size * num_batches_per_epoch) (only legal in async mode, cfg/arguments.py:147-155):
+    one sampling round yields two datasets, both handed to the learner (num_batches_to_accumulate = 2) while the next
+    round is being collected; the second one sees the policy lag of the first one's SGD steps (parity trap 14)."""
+    from sample_factory_amd.train import make_runner
+    cfg, runner = make_runner(_synthetic_cfg(synthetic_num_agents=128, batch_size=256, num_batches_per_epoch=2,
+                                             async_rl=True, serial_mode=False, num_batches_to_accumulate=2))
+    runner.init()
+    assert runner.buffer_mgr.num_buffers == 256 and runner.buffer_mgr.trajectories_per_training_iteration == 64
+    assert runner.iteration() is None                   # round 0 only
+    stats = runner.iteration()                          # round 1 || train(D0a), train(D0b)
+    torch.cuda.synchronize()
+    assert runner.sampling_rounds == 2 and runner.learner.train_step == 4 and stats["learner_env_steps"] == 1024
+    assert runner.training_iteration_since_resume == 2
+    assert stats["train"]["version_diff_min"] == 4.0  # second dataset: sampled 4 SGD steps before its last update
+    assert runner.batcher.in_flight == 2 and len(runner._ready) == 2  # round 1's two datasets wait for the learner
+    # sync mode rejects this shape, as the reference does
+    with pytest.raises(ValueError):
+        make_runner(_synthetic_cfg(synthetic_num_agents=128, batch_size=256, num_batches_per_epoch=2))[1].init()
+
+
+def test_async_accumulates_and_throttles():
+    """async mode with a dataset of two sampling rounds: slab = max(2 x round, num_batches_to_accumulate x dataset) rows;
+    the rollout stream keeps sampling into free slices while the learner trains, and pauses when none is free."""
+    from sample_factory_amd.train import make_runner
+    cfg, runner = make_runner(_synthetic_cfg(async_rl=True, serial_mode=False, batch_size=512, num_batches_per_epoch=2,
+                                             num_batches_to_accumulate=2))
+    runner.init()
+    assert runner.buffer_mgr.num_buffers == 256 and runner.buffer_mgr.max_batches_to_accumulate == 2
+    trained = 0
+    for _ in range(9):
+        stats = runner.iteration()
+        trained += stats is not None
+    torch.cuda.synchronize()
+    assert runner.sampling_rounds == 9 and trained == 4 and runner.learner.env_steps == 4 * 1024
+    assert torch.isfinite(runner.learner.actor_critic.flat_params).all()
+    lag = runner.learner.last_summary
+    assert lag["version_diff_min"] >= 1.0 and lag["version_diff_max"] <= cfg.max_policy_lag
+
+
+def test_run_checkpoint_life_cycle(tmp_path):
+    """Runner.run(): periodic save, milestone, best-policy save (after save_best_after steps, on the running mean of
+    cfg.save_best_metric), final save on stop, config.json; a new Runner resumes from the latest checkpoint;
+    restart_behavior=restart moves the old experiment aside; load_checkpoint_kind=best loads best_*."""
+    from sample_factory_amd.algo.learning.learner import Learner
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.cartpole import make_cartpole_env
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.train import ExperimentStatus, make_runner
+    register_env("CartPole-v1", make_cartpole_env)
+
+    def cfg_(**over):
+        base = dict(env="CartPole-v1", use_rnn=False, nonlinearity="tanh", normalize_input=True, encoder_mlp_layers=[32, 32],
+                    rollout=16, batch_size=512, num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1,
+                    worker_num_splits=1, async_rl=False, seed=3, serial_mode=True, cartpole_num_agents=64,
+                    train_dir=str(tmp_path), experiment="life", train_for_env_steps=12 * 1024, save_every_sec=1e-4,
+                    save_best_every_sec=1e-4, save_best_after=2048, save_milestones_sec=1e-4, keep_checkpoints=2)
+        base.update(over)
+        return default_cfg(**base)
+
+    cfg, runner = make_runner(cfg_())
+    assert runner.init() == ExperimentStatus.SUCCESS and runner.run() == ExperimentStatus.SUCCESS
+    d = Learner.checkpoint_dir(cfg, 0)
+    cps = Learner.get_checkpoints(d)
+    assert len(cps) == 2 and cps[-1].endswith(f"checkpoint_{runner.learner.train_step:09d}_{runner.learner.env_steps}.pth")
+    assert runner.learner.env_steps == 12 * 1024
+    assert len(glob.glob(os.path.join(d, "milestones", "checkpoint_*.pth"))) >= 2
+    best = Learner.get_checkpoints(d, "best_*")
+    assert len(best) == 1 and "_reward_" in best[0] and runner.learner.best_performance > 0
+    assert json.load(open(os.path.join(str(tmp_path), "life", "config.json")))["rollout"] == 16
+    steps, params = runner.learner.train_step, runner.learner.actor_critic.flat_params.clone()
+    # resume (default)
+    cfg2, r2 = make_runner(cfg_(train_for_env_steps=14 * 1024))
+    r2.init()
+    assert r2.learner.train_step == steps and r2.learner.env_steps == 12 * 1024
+    assert torch.equal(r2.learner.actor_critic.flat_params, params) and r2.learner.best_performance == runner.learner.best_performance
+    r2.run()
+    assert r2.learner.env_steps == 14 * 1024 and r2.learner.train_step == steps + 4
+    # best checkpoint instead of the latest
+    cfg3, r3 = make_runner(cfg_(load_checkpoint_kind="best"))
+    r3.init()
+    cp = torch.load(Learner.get_checkpoints(d, "best_*")[-1], weights_only=False)
+    assert r3.learner.train_step == cp["train_step"] and r3.learner.env_steps == cp["env_steps"]
+    # restart: the old experiment directory is moved aside and training starts from scratch
+    cfg4, r4 = make_runner(cfg_(restart_behavior="restart"))
+    r4.init()
+    assert r4.learner.train_step == 0 and os.path.isdir(os.path.join(str(tmp_path), "life_old0001"))
+    assert not Learner.get_checkpoints(Learner.checkpoint_dir(cfg4, 0))
