@@ -155,6 +155,11 @@ int sf_loss_scalars(const double *sums, const double *moments, const sf_loss_cfg
  * (contiguous slices, the reference default). */
 int sf_minibatch_indices(int32_t *out, int64_t experience_size, int recurrence, int shuffle, uint32_t seed,
                          uint32_t epoch, void *stream);
+/* learner.py:507-519 with the REFERENCE's permutation: chunk_starts (device int32[experience_size / recurrence]) is the
+ * host's seeded np.random.permutation(np.arange(0, experience_size, recurrence)), uploaded as is; out receives the
+ * expanded index runs [s, s+1, .., s+recurrence-1] per chunk, i.e. exactly np.concatenate(...) of :512-515. */
+int sf_minibatch_expand(const int32_t *chunk_starts, int32_t *out, int64_t experience_size, int recurrence,
+                        void *stream);
 
 /* ---- K18/K19: global-norm clip + Adam ------------------------------------------------------------------------
  * learner.py:782-797: torch.nn.utils.clip_grad_norm_(max_grad_norm) then torch.optim.Adam.step (eps=cfg.adam_eps,

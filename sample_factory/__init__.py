@@ -1,0 +1,46 @@
+"""`sample_factory` import surface for the MI355X-native engine.
+
+A training script written against Sample Factory —
+
+    from sample_factory.cfg.arguments import parse_full_cfg, parse_sf_args
+    from sample_factory.envs.env_utils import register_env
+    from sample_factory.algo.utils.context import global_model_factory
+    from sample_factory.train import run_rl
+
+— runs unchanged on this engine when this repository is first on `sys.path`: every `sample_factory.<module>` resolves
+to `sample_factory_amd.<module>` (the same module object under both names, so registries are shared).  Modules of the
+reference that are outside the hot-path scope do not exist and fail with ModuleNotFoundError.
+"""
+import importlib
+import importlib.abc
+import importlib.util
+import sys
+
+import sample_factory_amd as _impl
+
+_PREFIX, _REAL = "sample_factory.", "sample_factory_amd."
+
+
+class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        if not fullname.startswith(_PREFIX):
+            return None
+        real = _REAL + fullname[len(_PREFIX):]
+        try:
+            if importlib.util.find_spec(real) is None:
+                return None
+        except ModuleNotFoundError:
+            return None
+        return importlib.util.spec_from_loader(fullname, self, is_package=hasattr(importlib.import_module(real), "__path__"))
+
+    def create_module(self, spec):
+        return importlib.import_module(_REAL + spec.name[len(_PREFIX):])
+
+    def exec_module(self, module):  # the real module is already initialised
+        pass
+
+
+if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
+    sys.meta_path.insert(0, _AliasFinder())
+
+__version__ = getattr(_impl, "__version__", "0")

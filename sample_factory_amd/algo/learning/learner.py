@@ -431,8 +431,12 @@ class Learner:
 
     # ------------------------------------------------------------------------------------------ minibatches
     def _get_minibatches(self, batch_size, experience_size):
-        """learner.py:498-526.  Returns a list of (index_tensor|None, offset, n).  Shuffling permutes
-        recurrence-aligned chunk starts on the device (sf_minibatch_indices); nothing is gathered."""
+        """learner.py:498-526.  Returns a list of (index_tensor|None, offset, n); nothing is gathered, the consumers
+        read through the index.  shuffle_minibatches: the permutation of the recurrence-aligned chunk starts is the
+        REFERENCE's — host np.random.permutation from the global stream seeded in init() as learner.py:199-204 does —
+        uploaded (4 B per chunk) and expanded on the device (sf_minibatch_expand), so the index sets are equal to the
+        reference's element for element.  cfg.device_shuffle=True keeps everything on the device instead (stateless
+        Feistel permutation, sf_minibatch_indices: no host RNG, no upload; a different but equally valid shuffle)."""
         cfg = self.cfg
         assert cfg.rollout % cfg.recurrence == 0
         assert experience_size % batch_size == 0, f"experience size: {experience_size}, batch size: {batch_size}"
@@ -441,16 +445,40 @@ class Learner:
             return [(None, 0, experience_size)]
         if cfg.shuffle_minibatches:
             idx = torch.empty(experience_size, dtype=torch.int32, device=self.device)
-            seed = (cfg.seed or 0) * 7919 + self.policy_id
-            lib.minibatch_indices(idx, experience_size, cfg.recurrence, True, seed, self._shuffle_epoch)
-            self._shuffle_epoch += 1
+            if getattr(cfg, "device_shuffle", False):
+                seed = (cfg.seed or 0) * 7919 + self.policy_id
+                lib.minibatch_indices(idx, experience_size, cfg.recurrence, True, seed, self._shuffle_epoch)
+                self._shuffle_epoch += 1
+            else:
+                starts = np.random.permutation(np.arange(0, experience_size, cfg.recurrence))  # learner.py:509-510
+                starts_dev = torch.from_numpy(starts.astype(np.int32)).to(self.device, non_blocking=True)
+                lib.minibatch_expand(starts_dev, idx, experience_size, cfg.recurrence)
             return [(idx[i * batch_size:(i + 1) * batch_size], 0, batch_size) for i in range(experience_size // batch_size)]
         return [(None, i * batch_size, batch_size) for i in range(n_mb)]
 
     _shuffle_epoch = 0
 
     # ------------------------------------------------------------------------------------------ losses
-    def _calculate_losses(self, buff: AttrDict, mb, num_invalids: int, scalars_out: Optional[torch.Tensor] = None):
+    def _calculate_losses(self, mb: AttrDict, num_invalids: int):
+        """The reference's signature and return value (learner.py:537-669):
+        `(action_distribution, policy_loss, exploration_loss, kl_old, kl_loss, value_loss, loss_summaries)` for the
+        minibatch `mb` — a dataset as returned by `_prepare_batch` (the whole of it is the minibatch, as in
+        tests/algo/test_learner.py:21-39 of the reference) or `(dataset, (index|None, offset, n))` for a part of it.
+        The losses are 0-dim device tensors produced by the fused HIP loss kernel; `kl_old` is the mean KL(old || new)
+        over the valid samples (the reference returns the per-sample tensor whose mean that is); `action_distribution`
+        exposes the raw action parameters (`.raw_logits`), which is all the reference's callers read.  The training
+        loop itself uses `_losses_native` (same kernels, no tensor unpacking, gradient at the loss heads kept)."""
+        buff, part = (mb if isinstance(mb, tuple) else (mb, None))
+        if part is None:
+            part = (None, 0, buff.E * buff.T)
+        acts, g_heads, sc = self._losses_native(buff, part, num_invalids)
+        heads = acts[-1]
+        dist = AttrDict(raw_logits=heads[:part[2], 1:1 + self.num_action_params], values=heads[:part[2], 0])
+        summaries = AttrDict(adv_mean=sc[6], adv_std=sc[7], num_valid=sc[8], entropy=sc[9], kl_divergence_max=sc[5],
+                             ratio=self._ratio[:part[2]], values=heads[:part[2], 0], g_heads=g_heads)
+        return dist, sc[0].clone(), sc[1].clone(), sc[4].clone(), sc[2].clone(), sc[3].clone(), summaries
+
+    def _losses_native(self, buff: AttrDict, mb, num_invalids: int, scalars_out: Optional[torch.Tensor] = None):
         """learner.py:537-669 for one minibatch mb=(index, offset, n): forward, (v-trace), advantage moments,
         fused loss forward+backward.  Returns (acts, g_heads, scalars[16] device tensor) — scalars follow
         sf_loss_scalars: policy, exploration, kl, value losses, kl mean/max, adv mean/std, n_valid, entropy."""
@@ -515,7 +543,7 @@ class Learner:
             minibatches = self._get_minibatches(batch_size, experience_size)
             for batch_num, mb in enumerate(minibatches):
                 row = self._scalars[epoch * n_mb + batch_num]
-                acts, g_heads, _ = self._calculate_losses(buff, mb, num_invalids, row)
+                acts, g_heads, _ = self._losses_native(buff, mb, num_invalids, row)
                 index, offset, n = mb
                 # C1: every replica's gradient already carries the GLOBAL 1/n_valid -> SUM over replicas
                 if self._dp_split is not None:

@@ -838,15 +838,20 @@ __device__ __forceinline__ uint32_t feistel(uint32_t x, int half, uint32_t key) 
     return (l << half) | r;
 }
 
+// chunk_starts != NULL: the permutation comes from the host (the reference's seeded np.random.permutation of the
+// recurrence-aligned chunk starts, learner.py:507-510), given as dataset indices; only the expansion runs here.
 __global__ __launch_bounds__(256) void k_minibatch_indices(int32_t *__restrict__ out, int64_t n_chunks, int rec,
-                                                           int shuffle, int half, uint32_t key) {
+                                                           int shuffle, int half, uint32_t key,
+                                                           const int32_t *__restrict__ chunk_starts) {
     const int64_t wave_first = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63;  // first chunk of wave
     const int lane = threadIdx.x & 63;
     const int64_t j = wave_first + lane;
     uint32_t start = 0;
     if (j < n_chunks) {
         uint32_t x = (uint32_t)j;
-        if (shuffle) {
+        if (chunk_starts) {
+            x = (uint32_t)chunk_starts[j] / (uint32_t)rec;
+        } else if (shuffle) {
             do { x = feistel(x, half, key); } while ((int64_t)x >= n_chunks);  // cycle walking keeps it a bijection
         }
         start = x;
@@ -873,8 +878,19 @@ extern "C" int sf_minibatch_indices(int32_t *out, int64_t experience_size, int r
     const int half = (bits + 1) / 2;
     const uint32_t key = seed * 0x9E3779B1u + epoch * 0x85EBCA77u + 0x165667B1u;
     k_minibatch_indices<<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
-        out, n_chunks, recurrence, shuffle, half, key);
+        out, n_chunks, recurrence, shuffle, half, key, nullptr);
     return sf_launch_status("sf_minibatch_indices");
+}
+
+extern "C" int sf_minibatch_expand(const int32_t *chunk_starts, int32_t *out, int64_t experience_size, int recurrence,
+                                   void *stream) {
+    SF_REQUIRE(chunk_starts && out && experience_size > 0 && recurrence > 0 && experience_size % recurrence == 0,
+               "sf_minibatch_expand: experience_size=%lld recurrence=%d", (long long)experience_size, recurrence);
+    SF_REQUIRE(experience_size < (1LL << 31), "sf_minibatch_expand: experience too large for int32 indices");
+    const int64_t n_chunks = experience_size / recurrence;
+    k_minibatch_indices<<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        out, n_chunks, recurrence, 0, 0, 0u, chunk_starts);
+    return sf_launch_status("sf_minibatch_expand");
 }
 
 // =========================================================================================== K18/K19 clip + Adam

@@ -37,7 +37,7 @@ class sf_conv_desc(C.Structure):
 # every symbol include/sf_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
-    "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_grad_sumsq",
+    "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
     "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
@@ -289,6 +289,11 @@ def loss_scalars(sums, mom, cfg: sf_loss_cfg, out) -> None:
 def minibatch_indices(out, experience_size, recurrence, shuffle, seed, epoch) -> None:
     _check(load().sf_minibatch_indices(ptr(out, "i32", "indices"), i64(experience_size), int(recurrence),
                                        int(bool(shuffle)), u32(seed), u32(epoch), stream()), "sf_minibatch_indices")
+
+
+def minibatch_expand(chunk_starts, out, experience_size, recurrence) -> None:
+    _check(load().sf_minibatch_expand(ptr(chunk_starts, "i32", "chunk_starts"), ptr(out, "i32", "out"),
+                                      i64(experience_size), int(recurrence), stream()), "sf_minibatch_expand")
 
 
 def grad_sumsq(g, sumsq) -> None:

@@ -26,11 +26,8 @@ from sample_factory_amd.envs.env_utils import create_env, find_training_info_int
 from sample_factory_amd.utils.attr_dict import AttrDict
 
 
-class ExperimentStatus:
-    SUCCESS, FAILURE, INTERRUPTED = 0, 1, 2
-
-
-EPISODIC, POLICY_ID_KEY, TRAIN_STATS, LEARNER_ENV_STEPS = "episodic", "policy_id", "train", "learner_env_steps"  # misc.py:7-16
+from sample_factory_amd.algo.utils.misc import (EPISODIC, LEARNER_ENV_STEPS, POLICY_ID_KEY, TRAIN_STATS,  # noqa: F401
+                                                 ExperimentStatus)
 
 
 class AlgoObserver:

@@ -313,3 +313,28 @@ def test_every_module_imports_without_a_gpu():
     assert len(names) > 20
     for name in names:
         importlib.import_module(name)
+
+
+def test_sample_factory_import_surface_resolves_to_this_engine():
+    """a script written against `sample_factory.*` (examples/train_gym_env.py, the shape of the reference's
+    sf_examples/train_gym_env.py) imports and parses its arguments here; without a GPU run_rl fails LOUDLY (no CPU
+    fallback).  Subprocess: the oracle tooling imports the real reference under the same package name."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.argv=['x','--env=CartPole-v1','--use_rnn=False','--rollout=16'];"
+            "import examples.train_gym_env as m, sample_factory, sample_factory_amd;"
+            "from sample_factory.algo.learning.learner import Learner;"
+            "from sample_factory.algo.utils.context import global_model_factory, global_env_registry;"
+            "from sample_factory.algo.runners.runner import Runner, AlgoObserver;"
+            "import sample_factory.train as t, sample_factory_amd.train as t2; assert t is t2;"
+            "m.register_custom_components(); assert 'CartPole-v1' in global_env_registry();"
+            "cfg = m.parse_custom_args(); assert cfg.rollout == 16 and cfg.env_agents == 16;"
+            "print('OK', Learner.__module__)")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK sample_factory_amd.algo.learning.learner" in r.stdout, r.stderr[-1500:]
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_gym_env.py"), "--env=CartPole-v1",
+                            "--use_rnn=False", "--num_workers=1", "--num_envs_per_worker=1", "--worker_num_splits=1",
+                            "--async_rl=False", "--batch_size=512", f"--train_dir={ROOT}/gpurun_out/td_cpu"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "no GPU visible" in r.stderr

@@ -773,7 +773,7 @@ def test_learner_prepare_batch_and_losses_match_reference(lib, golden, tmp_path,
     if cfg.normalize_returns:
         np.testing.assert_allclose(ac.returns_normalizer.stats.cpu().numpy(), g["out_rms"], rtol=1e-6)
     mb = int(g["mb_size"])
-    acts, g_heads, sc = learner._calculate_losses(buff, (None, 0, mb), num_invalids)
+    acts, g_heads, sc = learner._losses_native(buff, (None, 0, mb), num_invalids)
     sc = sc.cpu().numpy()
     heads = acts[-1].cpu().numpy()
     np.testing.assert_allclose(heads[:, 1:1 + A], g["l_params"], atol=3e-6, rtol=1e-5)
@@ -1147,11 +1147,11 @@ def test_learner_config_matrix_smoke(lib, tmp_path):
         mb = learner._get_minibatches(cfg.batch_size, size)[0]
         if cfg.shuffle_minibatches or cfg.normalize_input:
             continue  # the index set / normaliser statistics change between calls: the probe needs a fixed function
-        acts, g_heads, sc = learner._calculate_losses(buff, mb, ninv)
+        acts, g_heads, sc = learner._losses_native(buff, mb, ninv)
         ac.backward(acts, g_heads, buff.obs, mb[2], sample_stride=ac.obs_elems, index=mb[0], offset=mb[1], traj_T=buff.T)
         grad = ac.flat_grads.clone()
         direction = grad / (grad.norm() + 1e-12)
-        lossf = lambda: float(learner._calculate_losses(buff, mb, ninv)[2][:4].sum().item())
+        lossf = lambda: float(learner._losses_native(buff, mb, ninv)[2][:4].sum().item())
         eps = 2e-3
         ac.flat_params.copy_(p0 + eps * direction); ac.params_changed(); lp = lossf()
         ac.flat_params.copy_(p0 - eps * direction); ac.params_changed(); lm = lossf()

@@ -323,6 +323,42 @@ def test_minibatch_expansion_golden(lib, golden):
     np.testing.assert_array_equal(g["minibatches"].reshape(-1, rec), starts[:, None] + np.arange(rec)[None])
 
 
+def test_shuffled_minibatches_equal_the_reference_index_sets(lib, golden, tmp_path):
+    """Learner._get_minibatches with shuffle_minibatches=True returns, element for element, the index sets the
+    reference's Learner._get_minibatches returned under the same np.random seed (golden minibatch_indices.npz:
+    learner.py:498-526 — seeded host permutation of chunk starts, expansion, np.split)."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    g = golden("minibatch_indices")
+    N, B, rec = int(g["experience_size"]), int(g["batch_size"]), int(g["recurrence"])
+    cfg = default_cfg(use_rnn=False, recurrence=rec, nonlinearity="tanh", normalize_input=False, encoder_mlp_layers=[32, 32],
+                      rollout=8, batch_size=B, num_batches_per_epoch=N // B, shuffle_minibatches=True, seed=0,
+                      serial_mode=True, train_dir=str(tmp_path), experiment="t")
+    env_info = EnvInfo(spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)}), spaces.Discrete(3), 16)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    np.random.seed(123)
+    mbs = learner._get_minibatches(B, N)
+    assert len(mbs) == len(g["minibatches"])
+    for (idx, offset, n), want in zip(mbs, g["minibatches"]):
+        assert offset == 0 and n == B and idx.dtype == torch.int32
+        np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    # a second epoch continues the SAME host stream, as the reference does
+    second = np.concatenate([m[0].cpu().numpy() for m in learner._get_minibatches(B, N)])
+    np.random.seed(123)
+    np.random.permutation(np.arange(0, N, rec))
+    want2 = np.random.permutation(np.arange(0, N, rec))
+    np.testing.assert_array_equal(second.reshape(-1, rec)[:, 0], want2)
+    # cfg.device_shuffle: stateless on-device permutation instead (still a permutation of whole chunks)
+    cfg.device_shuffle = True
+    dev_idx = np.concatenate([m[0].cpu().numpy() for m in learner._get_minibatches(B, N)])
+    np.testing.assert_array_equal(np.sort(dev_idx), np.arange(N))
+    assert np.all(dev_idx.reshape(-1, rec)[:, 0] % rec == 0)
+
+
 def test_synthetic_env_bit_exact(lib):
     from sample_factory_amd.envs.synthetic import SyntheticVecEnv
     env = SyntheticVecEnv(num_agents=96, obs_shape=(4, 84, 84), num_actions=6, seed=3, env0=1000)

@@ -139,3 +139,93 @@ def test_run_checkpoint_life_cycle(tmp_path):
     r4.init()
     assert r4.learner.train_step == 0 and os.path.isdir(os.path.join(str(tmp_path), "life_old0001"))
     assert not Learner.get_checkpoints(Learner.checkpoint_dir(cfg4, 0))
+
+
+def test_example_script_written_against_sample_factory_runs(tmp_path):
+    """examples/train_gym_env.py (imports only `sample_factory.*`, the reference's sf_examples/train_gym_env.py shape,
+    BASELINE configs[0]) trains CartPole through run_rl and leaves a checkpoint + config.json behind"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "train_gym_env.py"), "--env=CartPole-v1",
+                        "--use_rnn=False", "--serial_mode=True", "--async_rl=False", "--num_workers=1",
+                        "--num_envs_per_worker=1", "--worker_num_splits=1", "--batch_size=512", "--rollout=32",
+                        "--train_for_env_steps=4096", f"--train_dir={tmp_path}", "--experiment=example_gym_cartpole-v1",
+                        "--seed=0", "--normalize_input=True", "--encoder_mlp_layers", "64", "64"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Collected {0: 4096}" in r.stdout
+    d = os.path.join(str(tmp_path), "example_gym_cartpole-v1")
+    assert os.path.exists(os.path.join(d, "config.json")) and glob.glob(os.path.join(d, "checkpoint_p0", "checkpoint_*.pth"))
+
+
+@pytest.mark.parametrize("use_rnn", [False, True])
+def test_losses_invariant_to_spliced_invalid_data(use_rnn):
+    """The logic of the reference's tests/algo/test_learner.py:43-168 (TestValidMasks.test_losses_match) re-hosted on
+    trajectories collected by this engine's sampler (the reference needs mujoco for its data): the reference-shaped
+    `Learner._calculate_losses(dataset, num_invalids)` is deterministic, and splicing a rollout's worth of garbage
+    marked policy_id = -1 into every trajectory leaves all four losses unchanged within the reference's tolerance."""
+    import copy
+    import random
+    from sample_factory_amd.algo.utils.tensor_dict import TensorDict
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+    T = 8
+    cfg = default_cfg(env="synthetic_ant", use_rnn=use_rnn, rnn_type="gru", rnn_size=32, recurrence=T if use_rnn else 1,
+                      encoder_mlp_layers=[64, 64], nonlinearity="tanh", normalize_input=False, normalize_returns=False,
+                      rollout=T, batch_size=32 * T, num_batches_per_epoch=1, num_epochs=1, num_workers=1,
+                      num_envs_per_worker=1, worker_num_splits=1, async_rl=False, serial_mode=True, seed=0,
+                      synthetic_num_agents=32, exploration_loss_coeff=0.001, kl_loss_coeff=0.1, adaptive_stddev=False)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    learner = runner.learner
+    runner._rollout_all(0.0)
+    torch.cuda.synchronize()
+
+    def clone(td):
+        return TensorDict({k: clone(v) if isinstance(v, dict) else v.clone() for k, v in td.items()})
+
+    og = clone(runner.traj)
+    og["dones"][:] = False  # (the reference test data has no dones inside the spliced region either)
+
+    def losses(dataset, invalids):
+        _dist, policy_loss, exploration_loss, kl_old, kl_loss, value_loss, _summ = learner._calculate_losses(dataset, invalids)
+        return dict(policy_loss=policy_loss, exploration_loss=exploration_loss, kl_old=kl_old, kl_loss=kl_loss,
+                    value_loss=value_loss)
+
+    dataset, experience_size, invalids = learner._prepare_batch(clone(og))
+    assert invalids == 0 and experience_size == 32 * T
+    res = prev = None
+    for _ in range(3):  # sanity check: the same losses on the same batch
+        res = losses(dataset, invalids)
+        if prev is not None:
+            for k in res:
+                assert torch.equal(res[k], prev[k]), k
+        prev = res
+    # splice T steps of invalid data into every trajectory at a random position j
+    random.seed(0)
+    j = random.randint(0, T // 2)
+    spliced = TensorDict()
+
+    def splice(v, rollout_len):
+        sh = v.shape
+        extra = sh[1] - rollout_len  # 1 for [E, T+1, ...] tensors
+        if v.dtype == torch.bool:
+            junk = torch.randint(0, 2, (sh[0], T) + sh[2:], device=v.device).bool()
+        else:
+            junk = (torch.randint(-1, 1, (sh[0], T) + sh[2:], device=v.device) * 4242).to(v.dtype)
+        return torch.cat([v[:, :j], junk, v[:, j:]], dim=1)
+
+    for k, v in og.items():
+        spliced[k] = TensorDict({kk: splice(vv, T) for kk, vv in v.items()}) if isinstance(v, dict) else splice(v, T)
+    spliced["policy_id"][:, j:j + T] = -1
+    spliced["dones"][:, j:j + T] = False
+    spliced["time_outs"][:, j:j + T] = False
+    inv_dataset, inv_size, invalids2 = learner._prepare_batch(spliced)
+    assert inv_size == experience_size * 2 and invalids2 == experience_size
+    inv = losses(inv_dataset, invalids2)
+    for k in ("policy_loss", "exploration_loss", "kl_loss", "value_loss"):
+        assert torch.allclose(res[k], inv[k], atol=0.02, rtol=0.02), (k, float(res[k]), float(inv[k]))

@@ -47,7 +47,7 @@ def main():
     batch["obs"]["obs"].copy_(torch.from_numpy(fr))
     buff, size, ninv = ln._prepare_batch(batch)
     mb = ln._get_minibatches(cfg.batch_size, size)[0]
-    acts, g_heads, _ = ln._calculate_losses(buff, mb, ninv)
+    acts, g_heads, _ = ln._losses_native(buff, mb, ninv)
     index, offset, n = mb
     ac.backward(acts, g_heads, buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset, traj_T=buff.T)
     torch.cuda.synchronize()
