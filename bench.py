@@ -122,12 +122,28 @@ def workload_cfg(args, rank, world):
                 f"{args.num_epochs} epoch(s)")
         return cfg, "synthetic_ant", make_synthetic_continuous_env, desc, \
             "env-steps/sec (whole node), 2048 envs, obs f32[27], Box(8), LSTM-512 + V-trace"
+    if args.workload == "c3":  # sf_examples/envpool/atari/envpool_atari_params.py:26-45 on a HOST vector env
+        from sample_factory_amd.envs.synthetic import make_host_frame_env
+        cfg = default_cfg(
+            env="host_atari", use_rnn=False, recurrence=1, encoder_conv_architecture="convnet_atari", nonlinearity="relu",
+            encoder_conv_mlp_layers=[512], obs_scale=255.0, normalize_input=False, normalize_returns=False, gamma=0.99,
+            gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0, value_loss_coeff=0.5, exploration_loss_coeff=0.01,
+            max_grad_norm=0.5, learning_rate=0.00025, adam_eps=1e-5, host_env_sim_ms=args.host_env_sim_ms, **common)
+        cfg.seed = rank
+        cfg.env_gpu_observations = cfg.env_gpu_actions = False
+        desc = (f"BASELINE.json configs[2] stand-in: HOST vector env {B} envs/GPU in {args.env_instances} instance(s) "
+                f"(numpy u8 [4,84,84] frames as envpool returns them -> pinned staging -> pitched H2D into the slab, int32 "
+                f"actions D2H), Discrete(6), Nature-CNN, APPO {mode}, rollout={T}, batch_size={cfg.batch_size} x "
+                f"{args.num_batches} minibatches x {args.num_epochs} epoch(s) (envpool-Atari preset)")
+        return cfg, "host_atari", make_host_frame_env, desc, \
+            "env-steps/sec (whole node), 1024 host envs, 84x84x4 obs ingested over PCIe"
     raise SystemExit(f"unknown workload {args.workload}")
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c3"])
+    ap.add_argument("--host_env_sim_ms", type=float, default=0.0, help="c3: simulated emulator time per env step")
     ap.add_argument("--check_launch", action="store_true",
                     help="stop after the replica-group self-check (launcher / env plumbing test; needs no GPU with "
                          "SF_DP_BACKEND=gloo)")
@@ -144,12 +160,18 @@ def main():
     ap.add_argument("--env_instances", type=int, default=1,
                     help="split the envs of a GPU into this many vector-env instances (num_envs_per_worker = "
                          "worker_num_splits = this): their rollouts run on separate HIP streams")
+    ap.add_argument("--sync_rl", action="store_true", help="c3: synchronous instead of the configuration's async mode")
+    ap.add_argument("--one_instance", action="store_true", help="c3: a single env instance (no double-buffered sampling)")
     ap.add_argument("--async_rl", action="store_true", help="overlap rollout k+1 with train(k) (policy lag of one dataset)")
     args = ap.parse_args()
     if args.envs is None:
-        args.envs = 4096 if args.workload == "c2" else 2048
+        args.envs = dict(c2=4096, c5=2048, c3=1024)[args.workload]
     if args.num_epochs is None:
-        args.num_epochs = 1 if args.workload == "c2" else 2
+        args.num_epochs = dict(c2=1, c5=2, c3=4)[args.workload]
+    if args.workload == "c3":  # config 3 is "async APPO" with double-buffered sampling (worker_num_splits = 2)
+        args.async_rl = not args.sync_rl
+        if args.env_instances == 1 and not args.one_instance:
+            args.env_instances = 2
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
@@ -215,25 +237,50 @@ def main():
             by_name[key[-1]] = by_name.get(key[-1], 0.0) + robust_total(evs)
         dominant = max(by_name, key=by_name.get)
         lib.PROFILE, lib.PROFILE_ONLY = {}, {key for key in warm_prof if key[-1] == dominant}
+    env_steps0, rounds0 = runner.learner.env_steps, runner.sampling_rounds
+    if args.workload == "c3":
+        for sm in runner.samplers:
+            sm.ingest_prof, sm.h2d_bytes = {}, 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.iteration()
     barrier()
     dt = time.perf_counter() - t0
+    runner.stop_sampler_thread()  # (threaded async mode, host envs) no-op otherwise
+    ingest = None
+    if args.workload == "c3":
+        tot = dict(act_wait_s=0.0, env_step_s=0.0, stage_s=0.0)
+        dma_ms, dma_bytes = 0.0, 0
+        for sm in runner.samplers:
+            for k in tot:
+                tot[k] += sm.ingest_prof.get(k, 0.0)
+            for e0, e1, nbytes in sm.ingest_prof.get("dma_events", []):
+                dma_ms += e0.elapsed_time(e1)
+                dma_bytes += nbytes
+            sm.ingest_prof = None
+        h2d = sum(sm.h2d_bytes for sm in runner.samplers)
+        rounds = max(1, runner.sampling_rounds - rounds0)
+        ingest = {"h2d_bytes_per_env_step": round(h2d / (rounds * B * T), 1), "h2d_total_gb": round(h2d / 1e9, 3),
+                  "obs_dma_gbs": round(dma_bytes / (dma_ms * 1e-3) / 1e9, 2) if dma_ms else None,
+                  "obs_dma_ms_total": round(dma_ms, 1), "h2d_gbs_over_wall_clock": round(h2d / dt / 1e9, 2),
+                  "host_s": {k: round(v, 3) for k, v in tot.items()}, "wall_s": round(dt, 3), "sampling_rounds": rounds,
+                  "sampler_thread": bool(runner.threaded),
+                  "dma_share_of_wall_clock": round(dma_ms * 1e-3 / dt, 4)}
     prof, lib.PROFILE, lib.PROFILE_ONLY = lib.PROFILE, None, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    env_steps = args.steps * B * T * world
+    env_steps = (runner.learner.env_steps - env_steps0) if args.workload == "c3" else args.steps * B * T * world
     value = env_steps / dt
 
     if not prof:
         if rank == 0:
             print(json.dumps({"metric": metric, "value": round(value, 1), "unit": "env-steps/s",
                               "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": world, "rccl_ranks": rccl_ranks,
-                              "rank_devices": rank_devices, "config": {"workload": workload_desc}}))
+                              "rank_devices": rank_devices, "config": {"workload": workload_desc},
+                              **({"ingest": ingest} if ingest is not None else {})}))
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -284,6 +331,7 @@ def main():
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
                    "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},
         "roofline": roofline,
+        **({"ingest": ingest} if ingest is not None else {}),
         "network_kernels": {"source": "instrumented warm-up step (every launch timed in isolation; not the timed region)",
                             "ms_per_step": round(net_ms, 2), "tflops_avg": round(net_flops / (net_ms * 1e-3) / 1e12, 2),
                             "top": breakdown},

@@ -224,6 +224,14 @@ int sf_traj_write_env_step(const float *rewards, const uint8_t *terminated, cons
                            uint8_t *traj_dones, uint8_t *traj_time_outs, int32_t *traj_policy_id, float *ep_return,
                            int32_t *ep_len, double *ep_stats, void *stream);
 
+/* ---- host-env ingest ---------------------------------------------------------------------
+ * batched_sampling.py:62-82 / rl_utils.py:38: observations of a CPU vector env (envpool: one [B, ...] host array per
+ * step) go into slot t of the device slab.  Rows of `row_bytes` bytes, `rows` of them, from (pinned) host memory with
+ * pitch src_pitch to device memory with pitch dst_pitch (= (T+1) * row_bytes for slab[:, t]): ONE pitched DMA
+ * (hipMemcpy2DAsync) on `stream` — no contiguous device staging copy, no kernel.  Returns without synchronising. */
+int sf_h2d_rows(void *dst, int64_t dst_pitch, const void *src, int64_t src_pitch, int64_t row_bytes, int64_t rows,
+                void *stream);
+
 /* ---- synthetic vector env (SURVEY.md §8d "C2 synthetic inputs") ------------------------------------------------
  * Device-resident stand-in for a GPU env (the reference's pattern: sf_examples/brax/train_brax.py:160-204).
  * sf_synth_obs writes frame `step` of envs [env0, env0+B) as u8 [obs_bytes] each, env b at obs + b*env_stride —

@@ -499,6 +499,42 @@ def gen_train_c5():
               p_other_policy=0.04, extra=C5_ALGO_ARGS, fill_extra=dict(p_timeout=0.3), fp64_first_step=True)
 
 
+def gen_ref_checkpoint():
+    """A checkpoint WRITTEN BY THE REFERENCE (Learner.save after one Learner.train, learner.py:323-363) + the logits /
+    values its model produces on a probe batch: this engine must resume from it (same progress counters, weights, Adam
+    moments, normaliser statistics) and reproduce the outputs — SURVEY.md §8(f1)."""
+    import glob
+    import shutil
+    E, T, A, nb = 16, 8, 6, 2
+    args = ["--encoder_mlp_layers", "32", "32", "--nonlinearity=elu", "--normalize_input=True"]
+    shutil.rmtree("/tmp/sf_golden/ckpt", ignore_errors=True)
+    argv = ["--algo=APPO", "--env=synthetic", "--experiment=ckpt", "--train_dir=/tmp/sf_golden", "--device=cpu",
+            "--serial_mode=True", "--seed=0", "--use_rnn=False", "--recurrence=1", f"--rollout={T}",
+            f"--batch_size={E * T // nb}", f"--num_batches_per_epoch={nb}", "--num_epochs=2"] + args
+    parser, _ = parse_sf_args(argv)
+    cfg = parse_full_cfg(parser, argv)
+    learner, env_info = make_learner(cfg, MLP_OBS, gym.spaces.Discrete(A), E)
+    load_seeded(learner.actor_critic, seed=11)
+    g = torch.Generator().manual_seed(777)
+    b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
+    fill_batch(b, g, A)
+    learner.train(clone_tensordict(b))
+    learner.best_performance = 12.5
+    assert learner.save()
+    path = sorted(glob.glob("/tmp/sf_golden/ckpt/checkpoint_p0/checkpoint_*.pth"))[-1]
+    shutil.copy(path, os.path.join(OUT, "ref_checkpoint_mlp.pth"))
+    ac = learner.actor_critic
+    ac.eval()
+    probe = torch.randn((32, 8), generator=g)
+    with torch.no_grad():
+        res = ac.forward_tail(ac.forward_head(ac.normalize_obs({"obs": probe.clone()})), values_only=False,
+                              sample_actions=False)
+    save("ref_checkpoint_mlp", ref="learner.py:323-363 Learner.save (checkpoint written by the reference)",
+         file_name=os.path.basename(path), train_step=learner.train_step, env_steps=learner.env_steps, probe=probe.numpy(),
+         logits=res["action_logits"].numpy(), values=res["values"].numpy(), argv=" ".join(args), E=E, T=T, A=A,
+         num_batches=nb, **batch_arrays(b))
+
+
 def gen_model_fwd():
     """Nature-CNN actor-critic forward on u8 frames — model/encoder.py:90-150, model/actor_critic.py:160-195,
     utils/normalize.py:51-70 (obs_scale=255)."""
@@ -625,7 +661,7 @@ def gen_host_logic():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb", "cfg"]
+    which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb", "cfg", "ckpt", "host"]
     if "gae" in which:
         gen_gae()
     if "rms" in which:
@@ -636,6 +672,8 @@ def main():
         gen_prepare_and_losses()
     if "mb" in which:
         gen_minibatch_indices()
+    if "ckpt" in which:
+        gen_ref_checkpoint()
     if "cnn84" in which:
         gen_train_cnn84()
     if "c5" in which:

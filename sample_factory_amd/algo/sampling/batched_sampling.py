@@ -12,6 +12,7 @@ CPU every step: batched_sampling.py:216,323,390-392; torch_utils.py:58-66).
 """
 from __future__ import annotations
 
+import time
 from typing import Dict, Optional
 
 import numpy as np
@@ -58,6 +59,10 @@ class BatchedVectorEnvRunner:
         self.host_env = None
         self._pin, self._pin_flip = {}, {}
         self._act_event = torch.cuda.Event()
+        self.h2d_bytes = 0  # host-env ingest volume (bench --workload c3)
+        # optional host-timeline probe of the ingest path (bench --workload c3): seconds spent waiting for the actions
+        # (= exposed inference latency), inside env.step, staging into pinned memory; HIP-event pairs around obs DMAs
+        self.ingest_prof: Optional[dict] = None
         self._rew = torch.zeros(self.B, dtype=torch.float32, device=dev)
         self._term = torch.zeros(self.B, dtype=torch.bool, device=dev)
         self._trunc = torch.zeros(self.B, dtype=torch.bool, device=dev)
@@ -94,17 +99,35 @@ class BatchedVectorEnvRunner:
         if isinstance(src, torch.Tensor) and src.is_cuda:
             dst.copy_(src)
             return
+        prof = self.ingest_prof
+        t0 = time.perf_counter() if prof is not None else 0.0
         a = np.asarray(src.cpu() if isinstance(src, torch.Tensor) else src)
         stage = self._pinned(key, dst.shape, dst.dtype, nbuf=2)  # two buffers: the previous H2D may still be in flight
         np.copyto(stage.numpy(), a.reshape(stage.shape), casting="unsafe")
-        dst.copy_(stage, non_blocking=True)
+        timed = prof is not None and key.startswith("obs")
+        if prof is not None:
+            prof["stage_s"] = prof.get("stage_s", 0.0) + time.perf_counter() - t0
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        if dst.dim() >= 1 and (dst.is_contiguous() or (dst.dim() > 1 and dst[0].is_contiguous())):
+            lib.h2d_rows(dst, stage)  # ONE pitched DMA straight into slab[:, t] (no contiguous device temp + copy kernel)
+        else:
+            dst.copy_(stage, non_blocking=True)
+        if timed:
+            ev1.record()
+            prof.setdefault("dma_events", []).append((ev0, ev1, stage.numel() * stage.element_size()))
+        self.h2d_bytes += stage.numel() * stage.element_size()
 
     def _actions_to_host(self, env_actions: torch.Tensor):
         """device actions -> pinned host array the env can read in place (ONE event wait)"""
         stage = self._pinned("act", env_actions.shape, env_actions.dtype)
         stage.copy_(env_actions, non_blocking=True)
         self._act_event.record()
+        t0 = time.perf_counter()
         self._act_event.synchronize()
+        if self.ingest_prof is not None:
+            self.ingest_prof["act_wait_s"] = self.ingest_prof.get("act_wait_s", 0.0) + time.perf_counter() - t0
         return stage.numpy()
 
     def _store_obs(self, o, t: int) -> None:
@@ -162,8 +185,11 @@ class BatchedVectorEnvRunner:
         else:
             if self.host_env is None:  # decided by what reset() returned
                 self.host_env = False
-            o, rew, term, trunc, _ = self.env.step(self._actions_to_host(env_actions) if self.host_env
-                                                   else env_actions)
+            acts_in = self._actions_to_host(env_actions) if self.host_env else env_actions
+            t0 = time.perf_counter()
+            o, rew, term, trunc, _ = self.env.step(acts_in)
+            if self.ingest_prof is not None:
+                self.ingest_prof["env_step_s"] = self.ingest_prof.get("env_step_s", 0.0) + time.perf_counter() - t0
             self._store_obs(o, t + 1)
             if self.host_env:
                 self._to_device("rew", rew, self._rew)

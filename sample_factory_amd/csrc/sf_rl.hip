@@ -820,6 +820,18 @@ extern "C" int sf_loss_scalars(const double *sums, const double *moments, const 
     return sf_launch_status("sf_loss_scalars");
 }
 
+// =========================================================================================== host-env ingest
+extern "C" int sf_h2d_rows(void *dst, int64_t dst_pitch, const void *src, int64_t src_pitch, int64_t row_bytes,
+                           int64_t rows, void *stream) {
+    SF_REQUIRE(dst && src && row_bytes > 0 && rows > 0 && dst_pitch >= row_bytes && src_pitch >= row_bytes,
+               "sf_h2d_rows: row_bytes=%lld rows=%lld pitches %lld/%lld", (long long)row_bytes, (long long)rows,
+               (long long)dst_pitch, (long long)src_pitch);
+    const hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)row_bytes,
+                                          (size_t)rows, hipMemcpyHostToDevice, STREAM(stream));
+    SF_REQUIRE(e == hipSuccess, "sf_h2d_rows: hipMemcpy2DAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // =========================================================================================== K14 minibatch indices
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;

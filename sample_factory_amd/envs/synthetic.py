@@ -97,6 +97,48 @@ class SyntheticContinuousEnv:
         pass
 
 
+class HostFrameVecEnv:
+    """Atari-shaped HOST vector env (BASELINE configs[2] stand-in: envpool is not installed on the boxes): N agents,
+    u8 [4,84,84] frames living in ordinary host memory, returned as numpy arrays exactly as envpool hands over its own
+    buffers (batched_sampling.py:62-82) — so every step costs the real ingest path: host array -> pinned staging ->
+    pitched H2D DMA into the slab, and a D2H of the int32 actions.  Frames come from a small pre-generated ring (the
+    simulator's own cost is not what is being measured); rewards follow the synthetic env's rule."""
+
+    def __init__(self, num_agents=1024, obs_shape=(4, 84, 84), num_actions=6, seed=0, ring=4, sim_ms=0.0):
+        self.num_agents, self.obs_shape, self.num_actions = int(num_agents), tuple(obs_shape), int(num_actions)
+        self.observation_space = spaces.Dict({"obs": spaces.Box(0, 255, self.obs_shape, np.uint8)})
+        self.action_space = spaces.Discrete(num_actions)
+        rng = np.random.default_rng(seed)
+        self.ring = rng.integers(0, 256, size=(ring, self.num_agents) + self.obs_shape, dtype=np.uint8)
+        self.step_count = 0
+        self.sim_ms = float(sim_ms)  # optional simulated emulator time per step (host sleep)
+        self._ids = np.arange(self.num_agents)
+        self._rng = rng
+
+    def reset(self, **kwargs):
+        self.step_count = 0
+        return {"obs": self.ring[0]}, {}
+
+    def step(self, actions):
+        a = np.asarray(actions).reshape(-1)
+        rew = (a == (self.step_count + self._ids) % self.num_actions).astype(np.float32)
+        term = self._rng.random(self.num_agents) < (1.0 / 1024.0)
+        self.step_count += 1
+        if self.sim_ms > 0:
+            import time
+            time.sleep(self.sim_ms * 1e-3)
+        return {"obs": self.ring[self.step_count % len(self.ring)]}, rew, term, np.zeros(self.num_agents, bool), {}
+
+    def close(self):
+        pass
+
+
+def make_host_frame_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    n = getattr(cfg, "synthetic_num_agents", 1024) if cfg is not None else 1024
+    seed = ((getattr(cfg, "seed", None) or 0) if cfg is not None else 0) + int(getattr(env_config, "env_id", 0) or 0)
+    return HostFrameVecEnv(num_agents=n, seed=seed, sim_ms=getattr(cfg, "host_env_sim_ms", 0.0) if cfg is not None else 0.0)
+
+
 class SyntheticTupleEnv(SyntheticVecEnv):
     """Multi-head variant (Tuple(Discrete(n0), Discrete(n1), ...), the VizDoom-style action space of
     action_distributions.py:197-287): same frames; the reward rule looks at head 0, the other heads are free."""

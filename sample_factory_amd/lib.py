@@ -41,7 +41,7 @@ SYMBOLS = [
     "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
-    "sf_synth_step", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
+    "sf_synth_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
     "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
     "sf_tanh_scale_fwd", "sf_tanh_scale_bwd",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
@@ -369,6 +369,25 @@ def traj_write_env_step(rewards, terminated, truncated, T, t, reward_scale, rewa
                                          ptr(traj_dones, "u8"), ptr(traj_time_outs, "u8"), ptr(traj_policy_id, "i32"),
                                          ptr(ep_return, "f32"), ptr(ep_len, "i32"), ptr(ep_stats, "f64"), stream()),
            "sf_traj_write_env_step")
+
+
+def h2d_rows(dst: torch.Tensor, src_pinned: torch.Tensor) -> None:
+    """dst: device view [rows, ...] whose rows are contiguous (any row pitch, e.g. slab[:, t]); src_pinned: contiguous
+    pinned host tensor of the same shape/dtype.  One pitched DMA on the current stream."""
+    if not dst.is_cuda or src_pinned.is_cuda or not src_pinned.is_pinned() or not src_pinned.is_contiguous():
+        raise SfHipError("h2d_rows: dst must be a device view, src a contiguous pinned host tensor")
+    if dst.shape != src_pinned.shape or dst.dtype != src_pinned.dtype or (dst.dim() > 1 and not dst[0].is_contiguous()):
+        raise SfHipError(f"h2d_rows: shape/dtype/row layout mismatch {tuple(dst.shape)} {dst.dtype} vs "
+                         f"{tuple(src_pinned.shape)} {src_pinned.dtype}")
+    if dst.is_contiguous():  # one flat row
+        rows, row_bytes = 1, dst.numel() * dst.element_size()
+        pitch = row_bytes
+    else:
+        rows = dst.shape[0]
+        row_bytes = (dst[0].numel() if dst.dim() > 1 else 1) * dst.element_size()
+        pitch = dst.stride(0) * dst.element_size()
+    _check(load().sf_h2d_rows(C.c_void_p(dst.data_ptr()), i64(pitch), C.c_void_p(src_pinned.data_ptr()), i64(row_bytes),
+                              i64(row_bytes), i64(rows), stream()), "sf_h2d_rows")
 
 
 def synth_obs(obs_slot_ptr: int, env_stride, B, env0, obs_bytes, seed, step) -> None:

@@ -17,6 +17,7 @@ actor/critic weights raise — there is no silent PyTorch fallback.
 from __future__ import annotations
 
 import math
+import threading
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -233,7 +234,7 @@ class ActorCritic:
             self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
         self._bufs: Dict = {}
         self._wss: Dict = {}
-        self._role = "learner"
+        self._tls = threading.local()  # per-thread "which scratch am I using": a sampler thread may run beside the learner
         self._snap = None
         self.initialize_weights()
 
@@ -422,7 +423,7 @@ class ActorCritic:
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         """split-K / wgrad scratch; one per stream role so that the rollout and learner streams never share it"""
-        key = self._role
+        key = getattr(self._tls, "role", "learner")
         ws = self._wss.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
@@ -482,7 +483,7 @@ class ActorCritic:
         """
         acts: List[Optional[torch.Tensor]] = [None] * len(self.layers)
         inputs: List[Optional[torch.Tensor]] = [None] * len(self.layers)
-        self._role = "rollout" + tag[3:] if tag.startswith("inf") else "learner"  # "inf", "inf1", ...: env groups
+        self._tls.role = "rollout" + tag[3:] if tag.startswith("inf") else "learner"  # "inf", "inf1", ...: env groups
         x, stride, idx, off, tT = obs, sample_stride, index, offset, traj_T
         if self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
             xn = self._buf((tag, "obsn"), (n, self.obs_elems))
@@ -609,7 +610,7 @@ class ActorCritic:
         bias gradient are enqueued (layers are finished last -> first: the data-parallel learner starts the all-reduce
         of a finished tail of the flat gradient while the earlier layers are still being back-propagated)."""
         ctx = self._ctx["train"]
-        self._role = "learner"
+        self._tls.role = "learner"
         inputs = ctx["inputs"]
         x0, stride0, idx0, off0, tT0 = ctx["first_in"]
         g = g_heads

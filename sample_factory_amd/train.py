@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import json
 import os
+import threading
 import time
 from collections import deque
 from typing import Any, Callable, Dict, List, Tuple
@@ -119,11 +120,15 @@ class Runner:
         reference round-trips dones/rewards to the host every step, batched_sampling.py:215-287).  At every report they
         are read back ONCE, turned into the reference's message {EPISODIC: {reward, len}, policy_id} (one entry = the
         mean over the episodes that finished since the previous report, plus their count under "episodes") and reset."""
-        if self.cfg.async_rl:  # rollout kernels add to ep_stats on their own stream: drain it before read + reset
-            self.rollout_stream.synchronize()
-        tot = sum(sm.ep_stats.cpu() for sm in self.samplers)
-        for sm in self.samplers:
-            sm.ep_stats.zero_()
+        if self.threaded and self._thread is not None:  # the sampler thread reads + resets between two rounds
+            with self._cv:
+                self._ep_stats_request = True
+                while self._ep_stats_request and self._thread_error is None and self._thread.is_alive():
+                    self._cv.wait(0.05)
+                tot = self._ep_stats_result if self._ep_stats_result is not None else torch.zeros(3, dtype=torch.float64)
+                self._ep_stats_result = None
+        else:
+            tot = self._read_ep_stats()
         k = float(tot[2])
         if k > 0:
             self._process_msg({EPISODIC: dict(reward=float(tot[0]) / k, len=float(tot[1]) / k, episodes=k),
@@ -154,6 +159,18 @@ class Runner:
         with open(os.path.join(d, "config.json"), "w") as f:
             json.dump({k: v for k, v in vars(self.cfg).items() if isinstance(v, (int, float, str, bool, list, type(None)))},
                       f, indent=2)
+
+    def _read_ep_stats(self):
+        """sum of {return, length, count} over the env instances since the last call, then reset — on the stream the
+        rollout kernels add to them on (async: the rollout stream), so no episode is lost between read and reset"""
+        if self.cfg.async_rl and not self.threaded:
+            self.rollout_stream.synchronize()
+        st = self.rollout_stream if (self.cfg.async_rl and self.threaded) else torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            tot = sum(sm.ep_stats.cpu() for sm in self.samplers)
+            for sm in self.samplers:
+                sm.ep_stats.zero_()
+        return tot
 
     def init(self) -> int:
         cfg = self.cfg
@@ -222,6 +239,7 @@ class Runner:
         self._ev_fork = torch.cuda.Event()
         self._ev_join = [torch.cuda.Event() for _ in range(S)]
         self._training_info_ifaces = [find_training_info_interface(env) for env in self.envs]
+        self._cv = threading.Condition(threading.RLock())   # guards queue / merger / event maps / publish state
         self._ready: List[slice] = []               # complete datasets waiting for the learner
         self._round_events: Dict[int, torch.cuda.Event] = {}   # sampling slice start -> "rollout written" event
         self._free_events: Dict[int, torch.cuda.Event] = {}    # sampling slice start -> "learner done with rows" event
@@ -232,7 +250,18 @@ class Runner:
             self.learner.actor_critic.enable_weight_snapshots()
             self._pub_slot = 0                      # snapshot slot holding the most recently published weights
             self._slot_last_read = [None, None]     # last sampling-round event that read each slot
+            self._reading_slot = None               # slot the round being enqueued right now reads (sampler thread)
             self.published_version = float(self.learner.train_step)
+        # A HOST env blocks the Python thread once per step (it needs the actions), so stream-level overlap alone would
+        # serialise sampling and learning; with a sampler THREAD (the reference's rollout-worker / learner-worker split,
+        # rollout_worker.py:79-308, learner_worker.py:50-164) the learner's launches are issued while the sampler waits
+        # for its env.  cfg.sampler_thread: None = automatic (async mode with a host env), True / False = forced.
+        for sm in self.samplers:
+            sm.reset()  # first observation into slab obs[:, 0]; tells us whether the env lives on the host
+        want = getattr(cfg, "sampler_thread", None)
+        self.threaded = bool(cfg.async_rl and (want if want is not None else any(sm.host_env for sm in self.samplers)))
+        self._thread, self._stop, self._thread_error = None, False, None
+        self._ep_stats_request, self._ep_stats_result = False, None
         self._observers_call("on_init", self)
         self._observers_call("on_connect_components", self)
         return ExperimentStatus.SUCCESS
@@ -247,9 +276,10 @@ class Runner:
     def _acquire_round(self):
         """one free slab slice per sampling unit, or None if the slab has no room for a whole round (every row is
         with the learner: the sampler pauses, inference_worker.py:175-181)"""
-        if len(self.buffer_mgr.traj_buffer_queue) < len(self.units):
-            return None
-        return [self.buffer_mgr.get_free_slice() for _ in self.units]
+        with self._cv:
+            if len(self.buffer_mgr.traj_buffer_queue) < len(self.units):
+                return None
+            return [self.buffer_mgr.get_free_slice() for _ in self.units]
 
     def _rollout_all(self, policy_version: float, slices=None) -> List[slice]:
         """One sampling round: every unit rolls its env instances out into its slice of the slab, enqueued behind
@@ -262,7 +292,8 @@ class Runner:
             set_training_info(iface, dict(approx_total_training_steps=int(self.learner.env_steps)))
         cur = torch.cuda.current_stream()
         for unit, sl in zip(self.units, slices):
-            ev = self._free_events.pop(sl.start, None)
+            with self._cv:
+                ev = self._free_events.pop(sl.start, None)
             if ev is not None:
                 cur.wait_event(ev)  # the learner has finished reading these rows
             for j, e in enumerate(unit):
@@ -287,11 +318,13 @@ class Runner:
                 base.wait_event(self._ev_join[i])
         ev = torch.cuda.Event()
         ev.record(cur)
-        for sl in slices:
-            self._round_events[sl.start] = ev
-            self._ready += self.batcher.on_new_trajectories(sl)   # SliceMerger: adjacent slices -> datasets
-        self.sampling_rounds += 1
-        self._last_round_event = ev
+        with self._cv:
+            for sl in slices:
+                self._round_events[sl.start] = ev
+                self._ready += self.batcher.on_new_trajectories(sl)   # SliceMerger: adjacent slices -> datasets
+            self.sampling_rounds += 1
+            self._last_round_event = ev
+            self._cv.notify_all()
         return slices
 
     def episode_stats(self):
@@ -308,17 +341,20 @@ class Runner:
         batcher.py:192-212), then hand the rows back: training slice -> SliceMerger -> free sampling slices"""
         main = torch.cuda.current_stream()
         unit = self.unit_rows
-        for start in range(ds.start - ds.start % unit, ds.stop, unit):
-            ev = self._round_events.get(start)
+        with self._cv:
+            evs = [self._round_events.get(start) for start in range(ds.start - ds.start % unit, ds.stop, unit)]
+        for ev in evs:
             if ev is not None:
                 main.wait_event(ev)
         stats = self.learner.train(self.traj[ds])
         ev = torch.cuda.Event()
         ev.record(main)
-        for start in range(ds.start - ds.start % unit, ds.stop, unit):
-            self._free_events[start] = ev
-        self.batcher.on_training_batch_released(ds)
-        self._ready += self.batcher.ready_batches()  # a dataset that was waiting for a free training batch
+        with self._cv:
+            for start in range(ds.start - ds.start % unit, ds.stop, unit):
+                self._free_events[start] = ev
+            self.batcher.on_training_batch_released(ds)
+            self._ready += self.batcher.ready_batches()  # a dataset that was waiting for a free training batch
+            self._cv.notify_all()
         if stats is not None:
             self.training_iteration_since_resume += 1
             if self.msg_handlers or len(self.policy_msg_handlers) > 1:  # learner report -> registered handlers
@@ -348,6 +384,8 @@ class Runner:
         rollout k+1 overlaps train(k).  The sampler pauses when the slab has no free slice (every row is with the
         learner or waiting in one of the num_batches_to_accumulate datasets).  Hand-offs are HIP events; the only host
         syncs are the learner's own (one per dataset, one per epoch)."""
+        if self.threaded:
+            return self._iteration_threaded()
         ac = self.learner.actor_critic
         main = torch.cuda.current_stream()
         todo, self._ready = self._ready, []
@@ -363,16 +401,90 @@ class Runner:
         for ds in todo:
             stats = self._train_dataset(ds) or stats
         if todo:
-            slot = 1 - self._pub_slot                                  # never the slot a running round reads
-            if self._slot_last_read[slot] is not None:
-                main.wait_event(self._slot_last_read[slot])            # ... and its last reader has finished
-            ac.publish_weights(slot)
-            self.ev_publish.record(main)
-            self._pub_slot = slot
-            self.published_version = float(self.learner.train_step)
+            self._publish()
         elif slices is None:
             raise RuntimeError("async iteration made no progress: no free rows and no complete dataset "
                                "(slab smaller than one dataset?)")
+        return stats
+
+    def _publish(self) -> None:
+        """K20 in async mode: copy the learner's weights into the snapshot slot no sampling round is reading (the one
+        being enqueued right now reads _reading_slot; finished rounds are waited for through their events)"""
+        main = torch.cuda.current_stream()
+        with self._cv:
+            slot = 1 - (self._reading_slot if self._reading_slot is not None else self._pub_slot)
+            if self._slot_last_read[slot] is not None:
+                main.wait_event(self._slot_last_read[slot])            # its last reader has finished
+            self.learner.actor_critic.publish_weights(slot)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.ev_publish = ev
+            self._pub_slot = slot
+            self.published_version = float(self.learner.train_step)
+
+    # ---- sampler thread (host envs in async mode)
+    def _sampler_loop(self) -> None:
+        try:
+            torch.cuda.set_device(self.learner.device)
+            ac = self.learner.actor_critic
+            with torch.cuda.stream(self.rollout_stream):
+                while True:
+                    with self._cv:
+                        while not self._stop and (slices := self._acquire_round()) is None:
+                            self._service_ep_stats()
+                            self._cv.wait(0.05)   # every row is with the learner: the sampler pauses
+                        if self._stop:
+                            return
+                        slot, version, ev_pub = self._pub_slot, self.published_version, self.ev_publish
+                        self._reading_slot = slot
+                    if self.sampling_rounds >= 1 or self.learner.train_step > 0:
+                        self.rollout_stream.wait_event(ev_pub)
+                    ac.snap_read = slot
+                    self._rollout_all(version, slices)
+                    with self._cv:
+                        self._slot_last_read[slot] = self._last_round_event
+                        self._reading_slot = None
+                        self._service_ep_stats()
+                        self._cv.notify_all()
+        except BaseException as e:  # surfaced by the learner thread
+            with self._cv:
+                self._thread_error = e
+                self._cv.notify_all()
+
+    def _service_ep_stats(self) -> None:
+        """(sampler thread, lock held) the thread that owns the rollout stream reads + resets the episode statistics"""
+        if self._ep_stats_request:
+            self._ep_stats_result = self._read_ep_stats()
+            self._ep_stats_request = False
+            self._cv.notify_all()
+
+    def _start_sampler_thread(self) -> None:
+        if self._thread is None:
+            self._stop = False
+            self._thread = threading.Thread(target=self._sampler_loop, name="sf-sampler", daemon=True)
+            self._thread.start()
+
+    def stop_sampler_thread(self) -> None:
+        if self._thread is not None:
+            with self._cv:
+                self._stop = True
+                self._cv.notify_all()
+            self._thread.join()
+            self._thread = None
+            self.rollout_stream.synchronize()
+
+    def _iteration_threaded(self):
+        """learner side of the threaded async mode: take the next complete dataset (waiting for the sampler thread if
+        there is none), train, publish"""
+        self._start_sampler_thread()
+        with self._cv:
+            while not self._ready:
+                if self._thread_error is not None:
+                    raise RuntimeError("sampler thread died") from self._thread_error
+                self._cv.wait(0.05)
+            ds = self._ready.pop(0)
+        stats = self._train_dataset(ds)
+        self._publish()
         return stats
 
     # ------------------------------------------------------------------------------------------ reports / checkpoints
@@ -432,10 +544,11 @@ class Runner:
                     self._save_milestone_policy()
         except KeyboardInterrupt:
             self.status = ExperimentStatus.INTERRUPTED
+        self._emit_episodic_stats()
+        self.stop_sampler_thread()
         torch.cuda.synchronize()
         self.env_steps = self.learner.env_steps
         self.fps = (self.env_steps - self._env_steps0) / max(1e-9, time.time() - t0)
-        self._emit_episodic_stats()
         self._observers_call("on_stop", self)
         self._save_policy()        # runner.py:685-698 (_stop_training): final checkpoint + best check
         self._save_best_policy()

@@ -229,3 +229,117 @@ def test_losses_invariant_to_spliced_invalid_data(use_rnn):
     inv = losses(inv_dataset, invalids2)
     for k in ("policy_loss", "exploration_loss", "kl_loss", "value_loss"):
         assert torch.allclose(res[k], inv[k], atol=0.02, rtol=0.02), (k, float(res[k]), float(inv[k]))
+
+
+def _mlp_ckpt_setup(tmp_path, golden):
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    g = golden("ref_checkpoint_mlp")
+    E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
+    cfg = default_cfg(use_rnn=False, recurrence=1, nonlinearity="elu", normalize_input=True, encoder_mlp_layers=[32, 32],
+                      rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb, num_epochs=2, seed=0, serial_mode=True,
+                      train_dir=str(tmp_path), experiment="ckpt")
+    env_info = EnvInfo(spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)}), spaces.Discrete(A), E)
+    return g, cfg, env_info, (E, T)
+
+
+def test_resume_from_a_checkpoint_written_by_the_reference(tmp_path, golden):
+    """tests/golden/ref_checkpoint_mlp.pth was written by the reference's Learner.save() (oracle/gen_golden.py ckpt):
+    Learner.init() here resumes from it — progress counters, best_performance, weights, Adam moments, normaliser
+    statistics — and the model reproduces the reference's outputs on a probe batch."""
+    import shutil
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    g, cfg, env_info, _ = _mlp_ckpt_setup(tmp_path, golden)
+    d = Learner.checkpoint_dir(cfg, 0)
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_checkpoint_mlp.pth")
+    shutil.copy(src, os.path.join(d, str(g["file_name"])))
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    assert learner.train_step == int(g["train_step"]) == 4 and learner.env_steps == int(g["env_steps"])
+    assert learner.best_performance == 12.5 and int(pv[0]) == 4 and learner.adam_step_count == 4
+    cp = torch.load(src, weights_only=False)
+    ac = learner.actor_critic
+    sd = ac.state_dict()
+    for k, v in cp["model"].items():
+        assert torch.equal(sd[k].cpu().reshape(v.shape), v), k
+    m, v2 = ac.flat_to_ref(learner.exp_avg), ac.flat_to_ref(learner.exp_avg_sq)
+    names = [n for n, _ in ac.ref_param_shapes()]
+    for i, n in enumerate(names):
+        assert torch.equal(m[n], cp["optimizer"]["state"][i]["exp_avg"]), n
+        assert torch.equal(v2[n], cp["optimizer"]["state"][i]["exp_avg_sq"]), n
+    ac.eval()
+    res = ac.forward({"obs": torch.from_numpy(g["probe"]).cuda()}, None)
+    np.testing.assert_allclose(res["action_logits"].cpu().numpy(), g["logits"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(res["values"].cpu().numpy(), g["values"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_array_equal(res["action_logits"].argmax(1).cpu().numpy(), g["logits"].argmax(1))
+
+
+def test_write_a_checkpoint_for_the_reference(tmp_path, golden):
+    """the other direction: train one dataset here, Learner.save(), and export the file + this model's outputs on the
+    probe batch to gpurun_out/interop/ — committed as tests/golden/ours_checkpoint_mlp.{pth,npz}, which the CPU test
+    test_reference_loads_a_checkpoint_written_here feeds to the REFERENCE's Learner.load_from_checkpoint."""
+    import shutil
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    g, cfg, env_info, (E, T) = _mlp_ckpt_setup(tmp_path, golden)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    batch = alloc_trajectory_tensors(env_info, E, T, 1, "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    learner.train(batch)
+    assert learner.save()
+    path = Learner.get_checkpoints(Learner.checkpoint_dir(cfg, 0))[-1]
+    ac = learner.actor_critic
+    ac.eval()
+    res = ac.forward({"obs": torch.from_numpy(g["probe"]).cuda()}, None)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "interop")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(path, os.path.join(out, "ours_checkpoint_mlp.pth"))
+    np.savez(os.path.join(out, "ours_checkpoint_mlp.npz"), file_name=os.path.basename(path), probe=g["probe"],
+             logits=res["action_logits"].cpu().numpy(), values=res["values"].cpu().numpy(),
+             train_step=learner.train_step, env_steps=learner.env_steps, argv=str(g["argv"]))
+    cp = torch.load(path, weights_only=False)
+    assert all(not t.is_cuda for t in cp["model"].values()) and cp["optimizer"]["state"][0]["exp_avg"].device.type == "cpu"
+
+
+def test_host_env_async_with_sampler_thread_and_pitched_ingest():
+    """BASELINE configs[2] shape at test size: a HOST vector env (numpy frames, as envpool returns them) in async mode ->
+    the Runner samples on a thread of its own (the learner's launches are issued while the sampler waits for its env),
+    frames reach the slab through ONE pitched H2D DMA per step (sf_h2d_rows): the slab holds exactly the env's frames."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_host_frame_env
+    from sample_factory_amd.train import make_runner
+    register_env("host_atari", make_host_frame_env)
+    cfg = default_cfg(env="host_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                      encoder_conv_architecture="convnet_atari", rollout=8, batch_size=512, num_batches_per_epoch=2,
+                      num_epochs=1, num_workers=1, num_envs_per_worker=2, worker_num_splits=2, async_rl=True,
+                      serial_mode=False, seed=4, synthetic_num_agents=64, env_gpu_observations=False, env_gpu_actions=False)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    assert runner.threaded and all(sm.host_env for sm in runner.samplers) and len(runner.units) == 2
+    trained = 0
+    for _ in range(5):
+        stats = runner.iteration()
+        trained += stats is not None
+    runner.stop_sampler_thread()
+    torch.cuda.synchronize()
+    assert trained == 5 and runner.learner.env_steps == 5 * 1024 and runner.sampling_rounds >= 5
+    assert torch.isfinite(runner.learner.actor_critic.flat_params).all()
+    assert runner.learner.last_summary["num_sgd_steps"] == 2
+    # every frame in the slab is a frame of the env's ring, bit for bit, in step order (row block of instance 0)
+    env = runner.envs[0]
+    rows = runner._prev_rows[0]["obs"]["obs"]          # [64, T+1, 4, 84, 84] view of the slab
+    host = rows.cpu().numpy()
+    last = env.step_count                               # frames are ring[step % ring]
+    for t in range(9):
+        np.testing.assert_array_equal(host[:, t], env.ring[(last - 8 + t) % len(env.ring)])
+    assert sum(sm.h2d_bytes for sm in runner.samplers) >= runner.sampling_rounds * 2 * 64 * 8 * 28224
+    s = runner.episode_stats()
+    assert s["episodes"] >= 0

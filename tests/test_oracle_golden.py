@@ -1,5 +1,7 @@
 """The CPU oracle (oracle/sf_oracle.c) against golden vectors produced by the reference itself
 (oracle/gen_golden.py ran Sample Factory's own functions).  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,20 @@ def test_masked_categorical_matches_reference(golden):
     ok = mask.sum(1) > 0
     assert np.abs(freq[ok] - probs[ok]).max() < 0.12                         # 400 draws: 4 sigma of p(1-p)/400
     assert np.abs(freq[~ok] - 1.0 / A).max() < 0.12                           # all-masked rows: uniform fallback
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/sample_factory"), reason="the reference only exists in the build container")
+def test_reference_loads_a_checkpoint_written_here():
+    """tests/golden/ours_checkpoint_mlp.pth was written by THIS engine's Learner.save() on the GPU
+    (tests/test_gpu_runner.py::test_write_a_checkpoint_for_the_reference).  The reference's Learner.init() resumes from
+    it through its own load_from_checkpoint (strict nn.Module.load_state_dict + torch.optim.Adam.load_state_dict) and
+    its model reproduces the outputs this engine recorded for the probe batch.  Subprocess: this process may already
+    hold this repo's `sample_factory` alias package."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tests", "golden", "ours_checkpoint_mlp.pth")):
+        pytest.skip("fixture not generated yet")
+    r = subprocess.run([sys.executable, "-m", "oracle.check_our_checkpoint"], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "INTEROP OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
