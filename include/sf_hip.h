@@ -285,6 +285,25 @@ int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index
 int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                   const sf_conv_desc *h_desc, void *stream);
 
+/* ---- fused LSTM sequence passes (config 5: LSTM-512 core, BPTT over recurrence-length chunks) -------------------
+ * model/core.py:19-64 + algo/learning/rnn_utils.py:114-158 as ONE persistent launch per pass instead of
+ * {recurrent GEMM, cell, carries} x R launches: every work-group keeps its slice of W_hh in LDS for all R steps and
+ * exchanges h_t (forward) / gate gradients (backward) with the other work-groups of its row group through L2.
+ * Layouts (all f32, row-major, time-major over the R steps of Cn chunks): gx [R][Cn][4H] = x W_ih^T + b_ih;
+ * whh [H][4H] (K-major, torch gate order i,f,g,o); keep [R][Cn] = 1 - done_or_invalid; gates [R][Cn][4H] (post-
+ * activation); hprev / cprev [R+1][Cn][H] with slot 0 = the chunk-start state on entry, slot t+1 = state_t * keep[t];
+ * hout / cout [R][Cn][H] the unmasked new state.  sync: >= 129 device uint32 (zeroed by the call; word 128 != 0
+ * afterwards = the pass was aborted because a work-group never arrived).  sf_lstm_seq_supported: 1 when (Cn, H) can
+ * take this path on the current device (H == 512; grid <= #CUs), else use sf_rnn_cell_fwd/bwd per step.
+ * sf_lstm_seq_bwd: dout [R][Cn][H] = dL/d hout; writes dgx [R][Cn][4H] = dL/d(gate pre-activations) (= the gradient of
+ * both gx and h W_hh^T + b_hh); carry_h / carry_c: [Cn][H] scratch. */
+int sf_lstm_seq_supported(int Cn, int H);
+int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates, float *hprev,
+                    float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H, void *stream);
+int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout, const float *keep,
+                    const float *whh, float *dgx, float *carry_h, float *carry_c, uint32_t *sync, int R, int Cn, int H,
+                    void *stream);
+
 /* action means squashed to [-scale, scale] (continuous_tanh_scale > 0, model/action_parameterization.py:62-66), in
  * place on columns [col0, col0+ncols) of a row-major [n, ld] matrix: y = tanh(x/scale)*scale; backward: g *= 1-(y/scale)^2
  * with y the squashed output. */

@@ -14,6 +14,7 @@ LIB = os.path.join(HERE, "libsf_hip.so")
 SOURCES = [
     ("sf_rl.hip", ["-ffp-contract=off"]),
     ("sf_nn.hip", []),
+    ("sf_rnn.hip", ["-ffp-contract=off"]),  # the fused cell arithmetic must equal k_rnn_cell_* of sf_rl.hip
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]

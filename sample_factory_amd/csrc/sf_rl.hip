@@ -58,47 +58,76 @@ extern "C" int sf_valid_mask(const int32_t *policy_id, const float *policy_versi
 }
 
 // =========================================================================================== K10+K11 GAE / returns
-// One wavefront owns 64 consecutive envs.  The env-major [E,T] rows are staged through LDS in [64 x 32]-step tiles
-// (row stride 33 words -> the per-lane row walk of the scan is bank-conflict-free) so that every global access is a
-// run of consecutive words across consecutive lanes; the time recursion itself lives in one register per lane.
+// A 256-thread block owns 64 consecutive envs.  The env-major [E,T] rows are staged through LDS in [64 x 32]-step tiles
+// (row stride 33 words -> the per-lane row walk of the scan is bank-conflict-free): all four waves issue the tile's
+// loads as coalesced runs of consecutive words — every load of a tile is in flight before the first LDS write (the
+// one-wave version waited for each load in turn: 330 serialised round trips, 68 us at (4096, 32)) — wave 0 runs the
+// time recursion with one register per lane (= env) in the reference's op order, all four waves store the results.
 constexpr int GAE_TC = 32;
 constexpr int GAE_LD = GAE_TC + 1;
+constexpr int GAE_NT = 256;
+constexpr int GAE_IT = (64 * GAE_LD + GAE_NT - 1) / GAE_NT;  // loads per thread and array: 9
 
-__device__ __forceinline__ void gae_tile_load_f32(float (*s)[GAE_LD], const float *g, int64_t row_stride, int e0,
-                                                  int E, int t0, int ncols, int lane) {
-    for (int idx = lane; idx < 64 * ncols; idx += 64) {
+struct GaeTile {
+    float v[GAE_IT];
+};
+__device__ __forceinline__ GaeTile gae_fetch_f32(const float *g, int64_t row_stride, int e0, int E, int t0, int ncols,
+                                                 int tid) {
+    GaeTile r;
+#pragma unroll
+    for (int i = 0; i < GAE_IT; ++i) {
+        const int idx = i * GAE_NT + tid;
         const int row = idx / ncols, col = idx - row * ncols;
         const int e = e0 + row;
-        s[row][col] = (e < E) ? g[(int64_t)e * row_stride + t0 + col] : 0.0f;
+        const bool ok = row < 64 && e < E;
+        const float x = g[ok ? (int64_t)e * row_stride + t0 + col : 0];  // branch-free: clamped address, late select
+        r.v[i] = ok ? x : 0.0f;
     }
+    return r;
 }
-__device__ __forceinline__ void gae_tile_load_u8(float (*s)[GAE_LD], const uint8_t *g, int64_t row_stride, int e0,
-                                                 int E, int t0, int ncols, int lane) {
-    for (int idx = lane; idx < 64 * ncols; idx += 64) {
+__device__ __forceinline__ GaeTile gae_fetch_u8(const uint8_t *g, int64_t row_stride, int e0, int E, int t0, int ncols,
+                                                int tid) {
+    GaeTile r;
+#pragma unroll
+    for (int i = 0; i < GAE_IT; ++i) {
+        const int idx = i * GAE_NT + tid;
         const int row = idx / ncols, col = idx - row * ncols;
         const int e = e0 + row;
-        s[row][col] = (e < E && g[(int64_t)e * row_stride + t0 + col]) ? 1.0f : 0.0f;
+        const bool ok = row < 64 && e < E;
+        const uint8_t x = g[ok ? (int64_t)e * row_stride + t0 + col : 0];
+        r.v[i] = (ok && x) ? 1.0f : 0.0f;
+    }
+    return r;
+}
+__device__ __forceinline__ void gae_put(float (*s)[GAE_LD], const GaeTile &r, int ncols, int tid) {
+#pragma unroll
+    for (int i = 0; i < GAE_IT; ++i) {
+        const int idx = i * GAE_NT + tid;
+        const int row = idx / ncols, col = idx - row * ncols;
+        if (row < 64) s[row][col] = r.v[i];
     }
 }
 __device__ __forceinline__ void gae_tile_store_f32(const float (*s)[GAE_LD], float *g, int64_t row_stride, int e0,
-                                                   int E, int t0, int ncols, int lane) {
-    for (int idx = lane; idx < 64 * ncols; idx += 64) {
+                                                   int E, int t0, int ncols, int tid) {
+#pragma unroll
+    for (int i = 0; i < GAE_IT; ++i) {
+        const int idx = i * GAE_NT + tid;
         const int row = idx / ncols, col = idx - row * ncols;
         const int e = e0 + row;
-        if (e < E) g[(int64_t)e * row_stride + t0 + col] = s[row][col];
+        if (row < 64 && e < E) g[(int64_t)e * row_stride + t0 + col] = s[row][col];
     }
 }
 
-__global__ __launch_bounds__(64) void k_gae_returns(float *__restrict__ rewards, const uint8_t *__restrict__ dones,
-                                                    const uint8_t *__restrict__ time_outs,
-                                                    const float *__restrict__ values,
-                                                    const uint8_t *__restrict__ valids,
-                                                    const double *__restrict__ rms_stats, int E, int T, float gamma,
-                                                    float gl, int value_bootstrap, float *__restrict__ adv_out,
-                                                    float *__restrict__ ret_out) {
+__global__ __launch_bounds__(GAE_NT) void k_gae_returns(float *__restrict__ rewards, const uint8_t *__restrict__ dones,
+                                                        const uint8_t *__restrict__ time_outs,
+                                                        const float *__restrict__ values,
+                                                        const uint8_t *__restrict__ valids,
+                                                        const double *__restrict__ rms_stats, int E, int T, float gamma,
+                                                        float gl, int value_bootstrap, float *__restrict__ adv_out,
+                                                        float *__restrict__ ret_out) {
     __shared__ float s_r[64][GAE_LD], s_v[64][GAE_LD], s_d[64][GAE_LD], s_to[64][GAE_LD], s_va[64][GAE_LD],
         s_adv[64][GAE_LD], s_ret[64][GAE_LD];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid;  // the scan runs on wave 0: lane == tid < 64
     const int e0 = blockIdx.x * 64;
     const bool denorm = rms_stats != nullptr;
     float mu = 0.f, sigma = 1.f;
@@ -109,40 +138,49 @@ __global__ __launch_bounds__(64) void k_gae_returns(float *__restrict__ rewards,
     float cum = 0.0f;
     for (int t0 = ((T - 1) / GAE_TC) * GAE_TC; t0 >= 0; t0 -= GAE_TC) {
         const int tc = min(GAE_TC, T - t0);
+        // every load of the tile is issued before the first LDS write
+        const GaeTile fr = gae_fetch_f32(rewards, T, e0, E, t0, tc, tid);
+        const GaeTile fd = gae_fetch_u8(dones, T, e0, E, t0, tc, tid);
+        const GaeTile fv = gae_fetch_f32(values, T + 1, e0, E, t0, tc + 1, tid);
+        const GaeTile fa = gae_fetch_u8(valids, T + 1, e0, E, t0, tc + 1, tid);
+        GaeTile ft;
+        if (value_bootstrap) ft = gae_fetch_u8(time_outs, T, e0, E, t0, tc, tid);
+        __syncthreads();  // the previous tile's stores have read s_adv / s_ret / s_r
+        gae_put(s_r, fr, tc, tid);
+        gae_put(s_d, fd, tc, tid);
+        gae_put(s_v, fv, tc + 1, tid);
+        gae_put(s_va, fa, tc + 1, tid);
+        if (value_bootstrap) gae_put(s_to, ft, tc, tid);
         __syncthreads();
-        gae_tile_load_f32(s_r, rewards, T, e0, E, t0, tc, lane);
-        gae_tile_load_u8(s_d, dones, T, e0, E, t0, tc, lane);
-        if (value_bootstrap) gae_tile_load_u8(s_to, time_outs, T, e0, E, t0, tc, lane);
-        gae_tile_load_f32(s_v, values, T + 1, e0, E, t0, tc + 1, lane);
-        gae_tile_load_u8(s_va, valids, T + 1, e0, E, t0, tc + 1, lane);
-        __syncthreads();
-        // per-lane backward scan over this tile (lane = env)
-        for (int c = tc; c >= 0; --c) {  // de-normalise the values of this row first (learner.py:969-979)
-            float v = s_v[lane][c];
-            if (denorm) v = clampf(v, -5.0f, 5.0f) * sigma + mu;
-            s_v[lane][c] = v;
-        }
-        for (int c = tc - 1; c >= 0; --c) {
-            const float v = s_v[lane][c], vn = s_v[lane][c + 1];
-            const float valid = s_va[lane][c], valid_n = s_va[lane][c + 1];
-            const float done = s_d[lane][c];
-            float r = s_r[lane][c];
-            if (value_bootstrap) {  // learner.py:990
-                r = r + ((gamma * v) * s_to[lane][c]) * done;
-                s_r[lane][c] = r;
+        if (tid < 64) {
+            // per-lane backward scan over this tile (lane = env)
+            for (int c = tc; c >= 0; --c) {  // de-normalise the values of this row first (learner.py:969-979)
+                float v = s_v[lane][c];
+                if (denorm) v = clampf(v, -5.0f, 5.0f) * sigma + mu;
+                s_v[lane][c] = v;
             }
-            const float a = (r - v) * valid;
-            const float b = (1.0f - done) * ((gamma * vn) * valid_n);
-            const float delta = a + b;
-            const float disc = gl * valid + (1.0f - valid);
-            cum = delta + (disc * cum) * (1.0f - done);
-            s_adv[lane][c] = cum;
-            s_ret[lane][c] = cum + valid * v;  // learner.py:1003
+            for (int c = tc - 1; c >= 0; --c) {
+                const float v = s_v[lane][c], vn = s_v[lane][c + 1];
+                const float valid = s_va[lane][c], valid_n = s_va[lane][c + 1];
+                const float done = s_d[lane][c];
+                float r = s_r[lane][c];
+                if (value_bootstrap) {  // learner.py:990
+                    r = r + ((gamma * v) * s_to[lane][c]) * done;
+                    s_r[lane][c] = r;
+                }
+                const float a = (r - v) * valid;
+                const float b = (1.0f - done) * ((gamma * vn) * valid_n);
+                const float delta = a + b;
+                const float disc = gl * valid + (1.0f - valid);
+                cum = delta + (disc * cum) * (1.0f - done);
+                s_adv[lane][c] = cum;
+                s_ret[lane][c] = cum + valid * v;  // learner.py:1003
+            }
         }
         __syncthreads();
-        gae_tile_store_f32(s_adv, adv_out, T, e0, E, t0, tc, lane);
-        gae_tile_store_f32(s_ret, ret_out, T, e0, E, t0, tc, lane);
-        if (value_bootstrap) gae_tile_store_f32(s_r, rewards, T, e0, E, t0, tc, lane);
+        gae_tile_store_f32(s_adv, adv_out, T, e0, E, t0, tc, tid);
+        gae_tile_store_f32(s_ret, ret_out, T, e0, E, t0, tc, tid);
+        if (value_bootstrap) gae_tile_store_f32(s_r, rewards, T, e0, E, t0, tc, tid);
     }
 }
 
@@ -155,7 +193,7 @@ extern "C" int sf_gae_returns(float *rewards, const uint8_t *dones, const uint8_
     SF_REQUIRE(!value_bootstrap || time_outs, "sf_gae_returns: value_bootstrap needs time_outs");
     // the reference multiplies the python doubles gamma*lambda before the cast to f32 (rl_utils.py:90)
     const float gl = (float)((double)gamma * (double)gae_lambda);
-    k_gae_returns<<<dim3((unsigned)((E + 63) / 64)), dim3(64), 0, STREAM(stream)>>>(
+    k_gae_returns<<<dim3((unsigned)((E + 63) / 64)), dim3(GAE_NT), 0, STREAM(stream)>>>(
         rewards, dones, time_outs, values, valids, rms_stats, E, T, gamma, gl, value_bootstrap, advantages, returns);
     return sf_launch_status("sf_gae_returns");
 }
@@ -188,8 +226,10 @@ extern "C" int sf_moments(const float *x, const uint8_t *valids, const int32_t *
     SF_REQUIRE(x && moments && n >= 0, "sf_moments: bad args");
     int rc = sf_hip_status(hipMemsetAsync(moments, 0, 3 * sizeof(double), STREAM(stream)), "sf_moments memset");
     if (rc || n == 0) return rc;
-    const int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
-    k_moments<<<dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, STREAM(stream)>>>(x, valids, index, n,
+    // latency-bound at minibatch sizes (32768 elements = 164 KB): one element per thread and one round trip, not an
+    // 8-deep dependent loop on 16 CUs; large inputs grid-stride over 2048 blocks (8 per CU)
+    const int64_t blocks = (n + 255) / 256;
+    k_moments<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, STREAM(stream)>>>(x, valids, index, n,
                                                                                                    moments);
     return sf_launch_status("sf_moments");
 }

@@ -1,0 +1,385 @@
+// libsf_hip.so — persistent LSTM sequence kernels for gfx950 (one launch per BPTT pass instead of ~6 launches per step).
+//
+// Reference path: model/core.py:19-64 (nn.LSTM over a PackedSequence) + algo/learning/rnn_utils.py:114-158; here the
+// masked time loop over recurrence-length chunks (state zeroed after done/invalid steps), the loop form the reference's
+// tests/algo/test_rnn.py proves equal to its packed path.
+//
+// The per-step recurrent GEMM of config 5 (512 chunk rows x 512 hidden x 2048 gate columns, 1.07 GFLOP) is too small
+// to fill the chip as a launch of its own: measured 31 us forward / 65 us backward per step at 15-27 TFLOP/s, plus the
+// cell and carry kernels (profiles/r02_c5_a_kernel_stats.csv).  Instead ONE launch walks all R steps:
+//   * a work-group owns JB hidden units (= 4*JB gate columns; JB = 16 for H = 512) of one ROW GROUP of chunks and keeps
+//     its slice of W_hh RESIDENT IN LDS for the whole pass (64 x 516 floats = 129 KB forward, 16 x 2052 backward);
+//   * per step only the h (forward: 128 KB per group) / gate-gradient (backward: 512 KB) rows come from L2; the
+//     products run on v_mfma_f32_16x16x4_f32 (exact f32), one ds_read_b128 + one 16-byte global load per 4 MFMAs;
+//   * the cell non-linearity, the done/invalid masking, the carries of dL/dh and dL/dc and all saves for the backward
+//     pass are fused into the epilogue (the MFMA accumulator layout hands every lane all four gates of its (row, unit));
+//   * the work-groups of a row group (H/JB of them; block b -> group b % ngroups, i.e. one XCD per group under the
+//     observed round-robin dispatch — a speed bonus only) exchange h_t / dgates_t through L2 with the placement-
+//     independent write-through protocol of MI355X_MICROARCH.md (16-byte sc1 stores -> s_waitcnt vmcnt(0) -> barrier ->
+//     relaxed agent-scope counter; consumer: relaxed poll -> sc1 loads), one hand-off per step, no grid-wide barrier.
+// Work-groups spin on the counter, so all of them must be co-resident: the grid is ngroups * H/JB <= #CUs with one
+// work-group per CU (LDS-limited).  A bounded spin turns a lost work-group (GPU shared with another process) into an
+// error flag instead of a hang.
+#include "sf_common.h"
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((__vector_size__(16)));
+
+namespace {
+
+constexpr int SEQ_SYNC_STRIDE = 16;       // one counter per 64-byte line
+constexpr int SEQ_ABORT_SLOT = 8 * SEQ_SYNC_STRIDE;
+constexpr uint32_t SEQ_SPIN_LIMIT = 1u << 22;
+constexpr uint32_t OOB = 0x7FFFFFF0u;     // byte offset past every buffer: loads return 0, stores are dropped
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float ld_sc1(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// arrive: every wave has drained its write-through stores, then one relaxed agent-scope increment
+__device__ __forceinline__ void seq_arrive(unsigned *counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until `counter` >= target; returns false if the pass was aborted (bounded spin)
+__device__ __forceinline__ bool seq_wait(unsigned *counter, unsigned target, unsigned *abort_flag, float *lds_flag) {
+    if (threadIdx.x == 0) {
+        uint32_t spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 1023u) == 0 &&
+                (spins >= SEQ_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+        *lds_flag = ok ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    const bool ok = *lds_flag != 0.0f;
+    __syncthreads();  // the flag word may be rewritten by the next wait
+    return ok;
+}
+
+struct LstmSeqFwd {
+    const float *gx, *whh, *bhh, *keep;
+    float *gates, *hprev, *hout, *cprev, *cout;
+    unsigned *sync;
+    int R, Cn, ngroups, rows_per_group;
+};
+
+// JB hidden units per work-group, H = 8192 / JB (so that the W_hh slice fills ~129 KB of LDS): JB = 16 <-> H = 512.
+template <int JB>
+__global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
+    constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
+    constexpr int KU = 8, NKB = H / 16 / KU;
+    constexpr int STG = 16 * JB;  // floats of one wave's staging tile
+    static_assert(NKB * KU * 16 == H && NU >= 1, "shape");
+    __shared__ __attribute__((aligned(16))) float lds[NC * LDW + 4 * STG + 4];
+    float *wt = lds, *flag = lds + NC * LDW + 4 * STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    float *stg = lds + NC * LDW + wave * STG;
+    const int group = blockIdx.x % p.ngroups, j0 = (blockIdx.x / p.ngroups) * JB;
+    const unsigned ncol = H / JB;
+    const int Cn = p.Cn, R = p.R;
+    unsigned *counter = p.sync + group * SEQ_SYNC_STRIDE, *abort_flag = p.sync + SEQ_ABORT_SLOT;
+    // ---- W_hh slice, transposed into LDS: wt[q*JB + u][k] = whh[k][q*H + j0 + u]
+    for (int idx = tid; idx < NC * H; idx += 256) {
+        const int lc = idx % NC, k = idx / NC, q = lc / JB, u = lc % JB;
+        wt[lc * LDW + k] = p.whh[(int64_t)k * G4 + q * H + j0 + u];
+    }
+    float bias[4][NU];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) bias[q][u] = p.bhh[q * H + j0 + u * 16 + c];
+    __syncthreads();
+    const auto h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.hprev, 0, (int)((int64_t)(R + 1) * Cn * H * 4), 0x00020000);
+    const int g_row0 = group * p.rows_per_group;
+    const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
+    const int nsub = (p.rows_per_group + 63) / 64;
+
+    for (int t = 0; t < R; ++t) {
+        if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+            if (row0 >= g_rows_end) continue;  // (wave-uniform; no block barrier inside the sub-tile body)
+            // ---- epilogue operands first: they fly during the MFMA phase
+            float xg[4][4][NU], cp[4][NU], kp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
+                const int64_t tr = (int64_t)t * Cn + r;
+                kp[i] = p.keep[tr];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int j = j0 + u * 16 + c;
+                    cp[i][u] = ld_sc1(p.cprev + tr * H + j);  // written by this very lane one step ago
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xg[i][q][u] = p.gx[tr * G4 + q * H + j];
+                }
+            }
+            // ---- gh = h_{t-1} W_hh: A rows from L2 (write-through hand-off: sc1 loads), B from the resident LDS slice
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int arow = row0 + c;
+            const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * H + 4 * g) * 4) : OOB;
+            i32x4 abuf[2][KU];
+            auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku)
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+            };
+            load_block(0, abuf[0]);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb + 1 < NKB) load_block(kb + 1, abuf[(kb + 1) & 1]);
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku) {
+                    const f32x4 a4 = __builtin_bit_cast(f32x4, abuf[kb & 1][ku]);
+                    const float *bp = wt + c * LDW + (kb * KU + ku) * 16 + 4 * g;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + nt * 16 * LDW);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b4[j], acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- LSTM cell (k_rnn_cell_fwd's arithmetic), saves for the backward pass, masked state for step t+1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i;
+                const bool ok = row < g_rows_end;
+                const int64_t tr = (int64_t)t * Cn + (ok ? row : g_rows_end - 1);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int j = j0 + u * 16 + c;
+                    const float ig = sigm(xg[i][0][u] + (acc[0 * NU + u][i] + bias[0][u]));
+                    const float fg = sigm(xg[i][1][u] + (acc[1 * NU + u][i] + bias[1][u]));
+                    const float gg = tanhf(xg[i][2][u] + (acc[2 * NU + u][i] + bias[2][u]));
+                    const float og = sigm(xg[i][3][u] + (acc[3 * NU + u][i] + bias[3][u]));
+                    const float cn = fg * cp[i][u] + ig * gg;
+                    const float h = og * tanhf(cn);
+                    stg[(4 * g + i) * JB + u * 16 + c] = h * kp[i];
+                    if (ok) {
+                        float *go = p.gates + tr * G4 + j;
+                        go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+                        p.hout[tr * H + j] = h;
+                        p.cout[tr * H + j] = cn;
+                        st_sc1(p.cprev + (tr + Cn) * H + j, cn * kp[i]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // h_t * keep -> hprev[t+1]: 16-byte write-through stores (the hand-off payload)
+#pragma unroll
+            for (int v = 0; v < NU; ++v) {
+                const int f = v * 64 + lane, r = f / (JB / 4), c4 = f % (JB / 4), row = row0 + r;
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + r * JB + c4 * 4);
+                const uint32_t off = row < g_rows_end ? (uint32_t)((((int64_t)(t + 1) * Cn + row) * H + j0 + c4 * 4) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), h_rsrc, off, 0, 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (t + 1 < R) seq_arrive(counter);
+    }
+}
+
+struct LstmSeqBwd {
+    const float *dout, *gates, *cprev, *cout, *keep, *whh;
+    float *dgx, *carry_h, *carry_c;
+    unsigned *sync;
+    int R, Cn, ngroups, rows_per_group;
+};
+
+template <int JB>
+__global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
+    constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NU = JB / 16, LDK = G4 + 4;
+    constexpr int KU = 8, NKB = G4 / 16 / KU;
+    constexpr int STG = 16 * NC;
+    static_assert(NKB * KU * 16 == G4 && NKB % 2 == 0, "shape");
+    __shared__ __attribute__((aligned(16))) float lds[JB * LDK + 4 * STG + 4];
+    float *wk = lds, *flag = lds + JB * LDK + 4 * STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    float *stg = lds + JB * LDK + wave * STG;
+    const int group = blockIdx.x % p.ngroups, j0 = (blockIdx.x / p.ngroups) * JB;
+    const unsigned ncol = H / JB;
+    const int Cn = p.Cn, R = p.R;
+    unsigned *counter = p.sync + group * SEQ_SYNC_STRIDE, *abort_flag = p.sync + SEQ_ABORT_SLOT;
+    // ---- W_hh rows j0 .. j0+JB-1 (all 4H gate columns of this group's hidden units): wk[kk][n] = whh[j0 + kk][n]
+    for (int idx = tid; idx < JB * (G4 / 4); idx += 256) {
+        const int kk = idx / (G4 / 4), n4 = idx % (G4 / 4);
+        *reinterpret_cast<f32x4 *>(wk + kk * LDK + n4 * 4) =
+            *reinterpret_cast<const f32x4 *>(p.whh + (int64_t)(j0 + kk) * G4 + n4 * 4);
+    }
+    __syncthreads();
+    const auto d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.dgx, 0, (int)((int64_t)R * Cn * G4 * 4), 0x00020000);
+    const int g_row0 = group * p.rows_per_group;
+    const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
+    const int nsub = (p.rows_per_group + 63) / 64;
+
+    for (int s = 0; s < R; ++s) {
+        const int t = R - 1 - s;
+        // ---- phase A: cell backward (k_rnn_cell_bwd's arithmetic) for this group's (rows, units); dgates -> dgx[t]
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+            if (row0 >= g_rows_end) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i;
+                const bool ok = row < g_rows_end;
+                const int r = ok ? row : g_rows_end - 1;
+                const int64_t tr = (int64_t)t * Cn + r;
+                const float kprev = t > 0 ? p.keep[tr - Cn] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int j = j0 + u * 16 + c;
+                    const float *go = p.gates + tr * G4 + j;
+                    const float ig = go[0], fg = go[H], gg = go[2 * H], og = go[3 * H];
+                    float d = p.dout[tr * H + j];
+                    float dc_in = 0.0f;
+                    if (s > 0) {  // carries written by this very lane one step ago
+                        d = d + ld_sc1(p.carry_h + (int64_t)r * H + j);
+                        dc_in = ld_sc1(p.carry_c + (int64_t)r * H + j);
+                    }
+                    const float tc = tanhf(p.cout[tr * H + j]);
+                    const float dc = d * og * (1.0f - tc * tc) + dc_in;
+                    const float di = (dc * gg) * (ig * (1.0f - ig)), df = (dc * p.cprev[tr * H + j]) * (fg * (1.0f - fg));
+                    const float dg = (dc * ig) * (1.0f - gg * gg), dob = (d * tc) * (og * (1.0f - og));
+                    float *sp = stg + (4 * g + i) * NC + u * 16 + c;
+                    sp[0] = di; sp[JB] = df; sp[2 * JB] = dg; sp[3 * JB] = dob;
+                    if (ok && t > 0) st_sc1(p.carry_c + (int64_t)r * H + j, (dc * fg) * kprev);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int v = 0; v < STG / 4 / 64; ++v) {  // 16 rows x NC floats as 16-byte write-through stores
+                const int f = v * 64 + lane, r = f / (NC / 4), c4 = f % (NC / 4), row = row0 + r;
+                const int q = (c4 * 4) / JB, u4 = (c4 * 4) % JB;
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + r * NC + c4 * 4);
+                const uint32_t off = row < g_rows_end ? (uint32_t)((((int64_t)t * Cn + row) * G4 + q * H + j0 + u4) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), d_rsrc, off, 0, 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (t == 0) break;  // no state in front of step 0
+        seq_arrive(counter);
+        if (!seq_wait(counter, ncol * (unsigned)(s + 1), abort_flag, flag)) return;
+        // ---- phase B: dL/dh_{t-1}[rows, own units] = dgates_t[rows, :] W_hh[own units, :]^T, masked by keep[t-1]
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+            if (row0 >= g_rows_end) continue;
+            f32x4 acc[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int arow = row0 + c;
+            const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * G4 + 4 * g) * 4) : OOB;
+            i32x4 abuf[2][KU];
+            auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku)
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+            };
+            auto mma_block = [&](int kb, const i32x4 (&src)[KU]) {
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku) {
+                    const f32x4 a4 = __builtin_bit_cast(f32x4, src[ku]);
+                    const float *bp = wk + c * LDK + (kb * KU + ku) * 16 + 4 * g;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + u * 16 * LDK);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b4[j], acc[u], 0, 0, 0);
+                    }
+                }
+            };
+            load_block(0, abuf[0]);
+            for (int kb = 0; kb < NKB; kb += 2) {
+                load_block(kb + 1, abuf[1]);
+                mma_block(kb, abuf[0]);
+                if (kb + 2 < NKB) load_block(kb + 2, abuf[0]);
+                mma_block(kb + 1, abuf[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i;
+                if (row < g_rows_end) {
+                    const float kprev = p.keep[(int64_t)(t - 1) * Cn + row];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u)
+                        st_sc1(p.carry_h + (int64_t)row * H + j0 + u * 16 + c, acc[u][i] * kprev);
+                }
+            }
+        }
+    }
+}
+
+int seq_plan(int Cn, int H, int *ngroups, int *rows_per_group, int *jb) {
+    if (H != 512) return 0;  // JB = 16; other widths take the per-step path (sf_rnn_cell_fwd/bwd)
+    *jb = 8192 / H;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    const int ncol = H / *jb;
+    int ng = cus / ncol;
+    if (ng > 8) ng = 8;
+    const int need = (Cn + 15) / 16;
+    if (ng > need) ng = need;
+    if (ng < 1) return 0;
+    *ngroups = ng;
+    *rows_per_group = ((Cn + ng - 1) / ng + 15) / 16 * 16;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" int sf_lstm_seq_supported(int Cn, int H) {
+    int a, b, c;
+    return Cn > 0 && seq_plan(Cn, H, &a, &b, &c);
+}
+
+extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
+                               float *hprev, float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H,
+                               void *stream) {
+    SF_REQUIRE(gx && whh && bhh && keep && gates && hprev && hout && cprev && cout && sync && R > 0 && Cn > 0,
+               "sf_lstm_seq_fwd: bad args");
+    int ng, rpg, jb;
+    SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_lstm_seq_fwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
+    SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_fwd: state buffer exceeds 2 GiB");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_fwd memset");
+    if (rc) return rc;
+    LstmSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, ng, rpg};
+    const dim3 grid((unsigned)(ng * (H / jb))), block(256);
+    k_lstm_seq_fwd<16><<<grid, block, 0, STREAM(stream)>>>(p);
+    return sf_launch_status("sf_lstm_seq_fwd");
+}
+
+extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout,
+                               const float *keep, const float *whh, float *dgx, float *carry_h, float *carry_c,
+                               uint32_t *sync, int R, int Cn, int H, void *stream) {
+    SF_REQUIRE(dout && gates && cprev && cout && keep && whh && dgx && carry_h && carry_c && sync && R > 0 && Cn > 0,
+               "sf_lstm_seq_bwd: bad args");
+    int ng, rpg, jb;
+    SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_lstm_seq_bwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
+    SF_REQUIRE((int64_t)R * Cn * 4 * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_bwd: gate-gradient buffer exceeds 2 GiB");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_bwd memset");
+    if (rc) return rc;
+    LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, carry_h, carry_c, sync, R, Cn, ng, rpg};
+    const dim3 grid((unsigned)(ng * (H / jb))), block(256);
+    k_lstm_seq_bwd<16><<<grid, block, 0, STREAM(stream)>>>(p);
+    return sf_launch_status("sf_lstm_seq_bwd");
+}

@@ -38,7 +38,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
@@ -249,6 +249,24 @@ def rnn_cell_bwd(kind, dh, dc_in, gates, h_prev, ld_h, c_prev, ld_c, c_out, Cn, 
                                   _rp(h_prev, "h_prev"), i64(ld_h), _rp(c_prev, "c_prev"), i64(ld_c),
                                   ptr(c_out, "f32"), int(Cn), int(H), ptr(dgx, "f32", "dgx"), ptr(dgh, "f32"),
                                   ptr(dh_direct, "f32"), ptr(dc_prev, "f32"), stream()), "sf_rnn_cell_bwd")
+
+
+def lstm_seq_supported(Cn: int, H: int) -> bool:
+    return bool(load().sf_lstm_seq_supported(int(Cn), int(H)))
+
+
+def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H) -> None:
+    _check(load().sf_lstm_seq_fwd(ptr(gx, "f32", "gx"), ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"),
+                                  ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
+                                  ptr(hout, "f32", "hout"), ptr(cprev, "f32", "cprev"), ptr(cout, "f32", "cout"),
+                                  ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_fwd")
+
+
+def lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, carry_h, carry_c, sync, R, Cn, H) -> None:
+    _check(load().sf_lstm_seq_bwd(ptr(dout, "f32", "dout"), ptr(gates, "f32", "gates"), ptr(cprev, "f32", "cprev"),
+                                  ptr(cout, "f32", "cout"), ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"),
+                                  ptr(dgx, "f32", "dgx"), ptr(carry_h, "f32", "carry_h"), ptr(carry_c, "f32", "carry_c"),
+                                  ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_bwd")
 
 
 def rows_add_scale(a, b, keep, Cn, H, y) -> None:

@@ -27,6 +27,10 @@ from sample_factory_amd import lib
 from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
 from sample_factory_amd.envs.spaces import is_box, calc_num_action_parameters, is_discrete
 
+import os
+
+_LSTM_SEQ = os.environ.get("SF_LSTM_SEQ", "1") != "0"  # A/B switch: 0 = per-step launches instead of the fused passes
+
 ACT_KIND = {"relu": 1, "tanh": 2, "elu": 3}  # model/model_utils.py:27-35; fused into the GEMM epilogues
 
 CONV_ARCHS = {  # model/encoder.py:126-134: [out_channels, kernel, stride]
@@ -545,16 +549,21 @@ class ActorCritic:
         Hprev[0].copy_(h0[:, :H])
         if kind == 1:
             Cprev[0].copy_(h0[:, H:])
-        gh = self._buf((tag, "gh_seq"), (Cn, GH))
         GXv = GX.view(R, Cn, GH)
-        for t in range(R):
+        fused = kind == 1 and _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
+        if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS
+            sync = self._buf((tag, "seq_sync"), (192,), dtype=torch.int32)
+            lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, Hout, Cprev, Cout, sync, R, Cn, H)
+            self._seq_sync = sync
+        gh = self._buf((tag, "gh_seq"), (Cn, GH)) if not fused else None
+        for t in range(0 if fused else R):
             lib.conv_fwd_raw(Hprev[t], H, None, 0, Lh.w, Lh.b, gh, Cn, Lh.desc)
             lib.rnn_cell_fwd(kind, GXv[t], gh, Hprev[t], H, Cprev[t] if kind == 1 else None, H, keep[t], Cn, H,
                              gates[t], Hout[t], Cout[t] if kind == 1 else None, Hprev[t + 1],
                              Cprev[t + 1] if kind == 1 else None)
         out = self._buf((tag, "core_out"), (n, H))
         out.view(Cn, R, H).copy_(Hout.transpose(0, 1))
-        self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn)
+        self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=fused)
         return out
 
     def _rnn_sequence_bwd(self, li, d_core, n):
@@ -566,6 +575,14 @@ class ActorCritic:
         dOut = self._buf(("g", "dOut_tm"), (R, Cn, H))
         dOut.copy_(d_core.view(Cn, R, H).transpose(0, 1))
         dGX = self._buf(("g", "dGX"), (R, Cn, GH))
+        if sv.get("fused"):  # the whole backward time loop in one persistent launch (cell backward + W_hh^T product + carries)
+            carry = self._buf(("g", "seq_carry"), (2, Cn, H))
+            sync = self._buf(("g", "seq_sync"), (192,), dtype=torch.int32)
+            lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, carry[0], carry[1], sync, R, Cn, H)
+            self._seq_sync_bwd = sync
+            ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
+            lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGX.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
+            return dGX.view(n, GH)
         dGH = self._buf(("g", "dGH"), (R, Cn, GH)) if kind == 0 else dGX
         dh = self._buf(("g", "dh"), (Cn, H))
         dh_direct = self._buf(("g", "dh_direct"), (Cn, H)) if kind == 0 else None
@@ -587,6 +604,16 @@ class ActorCritic:
         ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
         lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
         return dGX.view(n, GH)
+
+    def rnn_pass_aborted(self) -> bool:
+        """True if a fused LSTM pass gave up waiting for a work-group (GPU shared with another process): its results are
+        garbage and the caller must not use them.  One 4-byte readback; called once per Learner.train()."""
+        bad = False
+        for name in ("_seq_sync", "_seq_sync_bwd"):
+            t = getattr(self, name, None)
+            if t is not None:
+                bad = bad or bool(int(t[128].item()))
+        return bad
 
     def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
         """Inference-style forward on a dense obs batch [B, ...]; returns dict(values, action_logits, new_rnn_states)

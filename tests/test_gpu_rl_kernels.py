@@ -611,3 +611,55 @@ def test_tanh_scale_fwd_bwd_vs_torch(lib):
     assert torch.equal(gx[:, :col0], gy[:, :col0]) and torch.equal(gx[:, col0 + D:], gy[:, col0 + D:])
     with pytest.raises(lib.SfHipError):
         lib.tanh_scale_fwd(y, ld, n, col0, ld, s)  # columns past the row
+
+
+@pytest.mark.parametrize("Cn,R", [(512, 6), (200, 4), (2048, 3), (16, 5)])
+def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R):
+    """sf_lstm_seq_fwd / sf_lstm_seq_bwd (ONE persistent launch per BPTT pass, W_hh slices resident in LDS, per-step
+    write-through hand-offs between the work-groups of a row group) against a float64 torch LSTM loop with the same
+    masking (state zeroed after done/invalid steps): all saved tensors and the gate-pre-activation gradient."""
+    H = 512
+    assert lib.lstm_seq_supported(Cn, H) and not lib.lstm_seq_supported(Cn, 64)
+    g = torch.Generator().manual_seed(Cn + R)
+    gx = torch.randn((R, Cn, 4 * H), generator=g) * 0.7
+    whh = torch.randn((H, 4 * H), generator=g) / np.sqrt(H)
+    bhh = torch.randn((4 * H,), generator=g) * 0.1
+    keep = (torch.rand((R, Cn), generator=g) > 0.15).float()
+    h0, c0 = torch.randn((Cn, H), generator=g) * 0.5, torch.randn((Cn, H), generator=g) * 0.5
+    dout = torch.randn((R, Cn, H), generator=g)
+    # ---- float64 reference with autograd
+    gx64 = gx.double().requires_grad_(True)
+    W, b = whh.double(), bhh.double()
+    h, c = h0.double(), c0.double()
+    ref = dict(gates=[], hout=[], cout=[], hprev=[h], cprev=[c])
+    for t in range(R):
+        pre = gx64[t] + (h @ W + b)
+        i_, f_, g_, o_ = pre.split(H, dim=1)
+        ig, fg, gg, og = torch.sigmoid(i_), torch.sigmoid(f_), torch.tanh(g_), torch.sigmoid(o_)
+        c = fg * c + ig * gg
+        h = og * torch.tanh(c)
+        ref["gates"].append(torch.cat([ig, fg, gg, og], 1)); ref["hout"].append(h); ref["cout"].append(c)
+        h, c = h * keep[t].double()[:, None], c * keep[t].double()[:, None]
+        ref["hprev"].append(h); ref["cprev"].append(c)
+    (torch.stack(ref["hout"]) * dout.double()).sum().backward()
+    # ---- fused kernels
+    d = lambda x: x.cuda().contiguous()
+    gates, hout, cout = (torch.full(s_, 7.0, device="cuda") for s_ in [(R, Cn, 4 * H), (R, Cn, H), (R, Cn, H)])
+    hprev, cprev = torch.full((R + 1, Cn, H), 7.0, device="cuda"), torch.full((R + 1, Cn, H), 7.0, device="cuda")
+    hprev[0], cprev[0] = d(h0), d(c0)
+    sync = torch.zeros(192, dtype=torch.int32, device="cuda")
+    lib.lstm_seq_fwd(d(gx), d(whh), d(bhh), d(keep), gates, hprev, hout, cprev, cout, sync, R, Cn, H)
+    torch.cuda.synchronize()
+    assert int(sync[128]) == 0, "forward pass aborted"
+    tol = dict(atol=3e-6, rtol=2e-5)
+    for name, got in [("gates", gates), ("hout", hout), ("cout", cout), ("hprev", hprev), ("cprev", cprev)]:
+        want = torch.stack([x.detach() for x in ref[name]])
+        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), err_msg=name, **tol)
+    dgx = torch.full((R, Cn, 4 * H), 7.0, device="cuda")
+    carry = torch.zeros((2, Cn, H), device="cuda")
+    lib.lstm_seq_bwd(d(dout), gates, cprev, cout, d(keep), d(whh), dgx, carry[0], carry[1], sync, R, Cn, H)
+    torch.cuda.synchronize()
+    assert int(sync[128]) == 0, "backward pass aborted"
+    want = gx64.grad
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(dgx.cpu().double().numpy(), want.numpy(), atol=2e-6 * scale, rtol=5e-5)
