@@ -679,7 +679,7 @@ class Learner:
         if self._global_invalids >= experience_size * self.world:
             return None
         train_stats = self._train(buff, self.cfg.batch_size, experience_size, num_invalids)
-        if getattr(self.actor_critic, "rnn_kind", None) == 1 and self.actor_critic.rnn_pass_aborted():
+        if hasattr(self.actor_critic, "rnn_pass_aborted") and self.actor_critic.rnn_pass_aborted():
             raise lib.SfHipError("a fused LSTM sequence pass was aborted (a work-group never arrived: is the GPU shared "
                                  "with another process?); set SF_LSTM_SEQ=0 to use the per-step kernels")
         frameskip = self.env_info.frameskip if self.cfg.summaries_use_frameskip else 1

@@ -208,7 +208,8 @@ struct LstmSeqBwd {
 template <int JB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NU = JB / 16, LDK = G4 + 4;
-    constexpr int KU = 8, NKB = G4 / 16 / KU;
+    constexpr int KU = 16, NKB = G4 / 16 / KU;  // 2 x 16 loads of 16 B in flight per lane: one wave per SIMD, so the
+                                                // prefetch depth is all the latency hiding there is
     constexpr int STG = 16 * NC;
     static_assert(NKB * KU * 16 == G4 && NKB % 2 == 0, "shape");
     __shared__ __attribute__((aligned(16))) float lds[JB * LDK + 4 * STG + 4];
