@@ -255,18 +255,28 @@ def lstm_seq_supported(Cn: int, H: int) -> bool:
     return bool(load().sf_lstm_seq_supported(int(Cn), int(H)))
 
 
+def _seq_key(op, R, Cn, H, steps):
+    """profiling key of a fused LSTM pass in bench.py's layout: 2 * (steps*Cn) * 4H * H algorithmic FLOPs of the
+    recurrent products (forward: R steps; backward: R-1, the first step has no state in front of it)"""
+    if PROFILE is None:
+        return None
+    return (op, int(steps * Cn), int(H), 1, 1, int(4 * H), 1, 1, 1, 1, f"k_lstm_seq_{op[5:]}<16>")
+
+
 def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H) -> None:
-    _check(load().sf_lstm_seq_fwd(ptr(gx, "f32", "gx"), ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"),
-                                  ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
-                                  ptr(hout, "f32", "hout"), ptr(cprev, "f32", "cprev"), ptr(cout, "f32", "cout"),
-                                  ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_fwd")
+    with _timed(_seq_key("lstm_fwd", R, Cn, H, R)):
+        _check(load().sf_lstm_seq_fwd(ptr(gx, "f32", "gx"), ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"),
+                                      ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
+                                      ptr(hout, "f32", "hout"), ptr(cprev, "f32", "cprev"), ptr(cout, "f32", "cout"),
+                                      ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_fwd")
 
 
 def lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, carry_h, carry_c, sync, R, Cn, H) -> None:
-    _check(load().sf_lstm_seq_bwd(ptr(dout, "f32", "dout"), ptr(gates, "f32", "gates"), ptr(cprev, "f32", "cprev"),
-                                  ptr(cout, "f32", "cout"), ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"),
-                                  ptr(dgx, "f32", "dgx"), ptr(carry_h, "f32", "carry_h"), ptr(carry_c, "f32", "carry_c"),
-                                  ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_bwd")
+    with _timed(_seq_key("lstm_bwd", R, Cn, H, R - 1)):
+        _check(load().sf_lstm_seq_bwd(ptr(dout, "f32", "dout"), ptr(gates, "f32", "gates"), ptr(cprev, "f32", "cprev"),
+                                      ptr(cout, "f32", "cout"), ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"),
+                                      ptr(dgx, "f32", "dgx"), ptr(carry_h, "f32", "carry_h"), ptr(carry_c, "f32", "carry_c"),
+                                      ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_bwd")
 
 
 def rows_add_scale(a, b, keep, Cn, H, y) -> None:

@@ -11,8 +11,11 @@ with Sample Factory checkpoints; the compute is libsf_hip.so'
  * the u8 -> f32 observation normalisation (utils/normalize.py:51-70) is fused into the first layer's loader;
  * critic_linear and distribution_linear are one fused [F, 1+A] GEMM (column 0 = value).
 
-Feed-forward models (conv or MLP encoder, relu/tanh/elu) are native; RNN cores, input running-mean-std and separate
-actor/critic weights raise — there is no silent PyTorch fallback.
+Native: conv or MLP encoder (relu/tanh/elu), optional one-layer GRU / LSTM core (per-step cell kernels; LSTM-512 BPTT
+passes as ONE persistent launch each, csrc/sf_rnn.hip), MLP decoder, input running-mean-std (normalize_input), Discrete /
+Tuple-of-Discrete / Box action heads.  Separate actor/critic weights and multi-layer RNNs raise; user-registered torch
+modules and multi-key observation dicts go through model/torch_policy.py (the network under autograd, everything around
+it native) — there is no silent fallback.
 """
 from __future__ import annotations
 

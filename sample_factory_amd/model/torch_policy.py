@@ -53,8 +53,13 @@ class TorchObsNormalizer:
         """training-mode statistics update over the whole dataset (learner.py:957-961)"""
         if not self.running:
             return
-        x = self._scale(obs.reshape((-1,) + tuple(self.mean.shape))[:n]).double()
-        s, ss = x.sum(0), (x * x).sum(0)
+        rows = obs.reshape((-1,) + tuple(self.mean.shape))[:n]
+        s, ss = torch.zeros_like(self.mean), torch.zeros_like(self.mean)
+        per = max(1, (64 << 20) // max(1, self.mean.numel() * 8))  # <= 64 MiB of float64 temporaries per chunk
+        for i in range(0, n, per):  # image keys: the whole dataset as float64 would be tens of GB
+            x = self._scale(rows[i:i + per]).double()
+            s += x.sum(0)
+            ss += (x * x).sum(0)
         if self._all_reduce is not None:
             self._all_reduce(s)
             self._all_reduce(ss)

@@ -497,7 +497,28 @@ class Runner:
             if "reward" in self.policy_avg_stats and len(self.policy_avg_stats["reward"][0]):
                 avg = float(np.mean(self.policy_avg_stats["reward"][0]))
                 print("Avg episode reward: %r" % [(0, f"{avg:.3f}")])
+        self._write_summaries(fps)
         self._observers_call("extra_summaries", self, 0, int(self.learner.env_steps), None)
+
+    def _write_summaries(self, fps: float) -> None:
+        """Summary sink.  The reference writes tensorboard events under <experiment>/.summary/<policy_id>/
+        (runner.py:298-346, learner.py:843-923); tensorboardX is not a dependency here, so the same scalars — perf/_fps,
+        policy_stats/avg_<key>, train/* of the learner's last report — go to .summary/0/summaries.jsonl, one JSON object
+        per report with env_steps as the x value (rank 0 only)."""
+        if self.rank != 0:
+            return
+        d = os.path.join(self.cfg.train_dir, self.cfg.experiment, ".summary", "0")
+        os.makedirs(d, exist_ok=True)
+        rec = {"env_steps": int(self.learner.env_steps), "time": time.time(), "perf/_fps": float(fps),
+               "train_step": int(self.learner.train_step)}
+        for key, per_policy in self.policy_avg_stats.items():
+            if len(per_policy[0]):
+                rec[f"policy_stats/avg_{key}"] = float(np.mean(per_policy[0]))
+        for k, v in dict(self.learner.last_summary).items():
+            if isinstance(v, (int, float)):
+                rec[f"train/{k}"] = float(v)
+        with open(os.path.join(d, "summaries.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
 
     def _save_policy(self) -> None:
         """runner.py:453-454 -> learner.save(); rank 0 only: replicas hold identical weights and share the directory"""
@@ -549,6 +570,7 @@ class Runner:
         torch.cuda.synchronize()
         self.env_steps = self.learner.env_steps
         self.fps = (self.env_steps - self._env_steps0) / max(1e-9, time.time() - t0)
+        self._write_summaries(self.fps)
         self._observers_call("on_stop", self)
         self._save_policy()        # runner.py:685-698 (_stop_training): final checkpoint + best check
         self._save_best_policy()

@@ -121,6 +121,9 @@ def test_run_checkpoint_life_cycle(tmp_path):
     best = Learner.get_checkpoints(d, "best_*")
     assert len(best) == 1 and "_reward_" in best[0] and runner.learner.best_performance > 0
     assert json.load(open(os.path.join(str(tmp_path), "life", "config.json")))["rollout"] == 16
+    recs = [json.loads(l) for l in open(os.path.join(str(tmp_path), "life", ".summary", "0", "summaries.jsonl"))]
+    assert recs[-1]["env_steps"] == 12 * 1024 and recs[-1]["perf/_fps"] > 0 and "train/loss" in recs[-1]
+    assert "policy_stats/avg_reward" in recs[-1] and "train/kl_divergence" in recs[-1]
     steps, params = runner.learner.train_step, runner.learner.actor_critic.flat_params.clone()
     # resume (default)
     cfg2, r2 = make_runner(cfg_(train_for_env_steps=14 * 1024))
