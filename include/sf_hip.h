@@ -296,13 +296,12 @@ int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float 
  * afterwards = the pass was aborted because a work-group never arrived).  sf_lstm_seq_supported: 1 when (Cn, H) can
  * take this path on the current device (H == 512; grid <= #CUs), else use sf_rnn_cell_fwd/bwd per step.
  * sf_lstm_seq_bwd: dout [R][Cn][H] = dL/d hout; writes dgx [R][Cn][4H] = dL/d(gate pre-activations) (= the gradient of
- * both gx and h W_hh^T + b_hh); carry_h / carry_c: [Cn][H] scratch. */
+ * both gx and h W_hh^T + b_hh); the carries of dL/dh and dL/dc live in registers.  Cn <= 8 * 256 rows. */
 int sf_lstm_seq_supported(int Cn, int H);
 int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates, float *hprev,
                     float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H, void *stream);
 int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout, const float *keep,
-                    const float *whh, float *dgx, float *carry_h, float *carry_c, uint32_t *sync, int R, int Cn, int H,
-                    void *stream);
+                    const float *whh, float *dgx, uint32_t *sync, int R, int Cn, int H, void *stream);
 
 /* action means squashed to [-scale, scale] (continuous_tanh_scale > 0, model/action_parameterization.py:62-66), in
  * place on columns [col0, col0+ncols) of a row-major [n, ld] matrix: y = tanh(x/scale)*scale; backward: g *= 1-(y/scale)^2

@@ -32,16 +32,10 @@ namespace {
 constexpr int SEQ_SYNC_STRIDE = 16;       // one counter per 64-byte line
 constexpr int SEQ_ABORT_SLOT = 8 * SEQ_SYNC_STRIDE;
 constexpr uint32_t SEQ_SPIN_LIMIT = 1u << 22;
+constexpr int SEQ_MAX_SUB = 4;             // 64-row sub-tiles per work-group (register-resident state): Cn <= ngroups * 256
 constexpr uint32_t OOB = 0x7FFFFFF0u;     // byte offset past every buffer: loads return 0, stores are dropped
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__device__ __forceinline__ float ld_sc1(const float *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_sc1(float *p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // arrive: every wave has drained its write-through stores, then one relaxed agent-scope increment
 __device__ __forceinline__ void seq_arrive(unsigned *counter) {
@@ -109,13 +103,28 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
     const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
     const int nsub = (p.rows_per_group + 63) / 64;
 
+    // the cell state of this lane's (row, unit) elements stays in registers across the steps (the masked copy is also
+    // stored to cprev[t+1] for the backward pass); sub-tiles are unrolled so that the register arrays index statically
+    float cst[SEQ_MAX_SUB][4][NU];
+#pragma unroll
+    for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
+        const int row0 = g_row0 + sub * 64 + wave * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) cst[sub][i][u] = sub < nsub ? p.cprev[(int64_t)r * H + j0 + u * 16 + c] : 0.0f;
+        }
+    }
+
     for (int t = 0; t < R; ++t) {
         if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
-        for (int sub = 0; sub < nsub; ++sub) {
+#pragma unroll
+        for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
             const int row0 = g_row0 + sub * 64 + wave * 16;
-            if (row0 >= g_rows_end) continue;  // (wave-uniform; no block barrier inside the sub-tile body)
+            if (sub >= nsub || row0 >= g_rows_end) continue;  // (wave-uniform; no block barrier inside the sub-tile body)
             // ---- epilogue operands first: they fly during the MFMA phase
-            float xg[4][4][NU], cp[4][NU], kp[4];
+            float xg[4][4][NU], kp[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
@@ -124,7 +133,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int j = j0 + u * 16 + c;
-                    cp[i][u] = ld_sc1(p.cprev + tr * H + j);  // written by this very lane one step ago
 #pragma unroll
                     for (int q = 0; q < 4; ++q) xg[i][q][u] = p.gx[tr * G4 + q * H + j];
                 }
@@ -171,15 +179,16 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
                     const float fg = sigm(xg[i][1][u] + (acc[1 * NU + u][i] + bias[1][u]));
                     const float gg = tanhf(xg[i][2][u] + (acc[2 * NU + u][i] + bias[2][u]));
                     const float og = sigm(xg[i][3][u] + (acc[3 * NU + u][i] + bias[3][u]));
-                    const float cn = fg * cp[i][u] + ig * gg;
+                    const float cn = fg * cst[sub][i][u] + ig * gg;
                     const float h = og * tanhf(cn);
+                    cst[sub][i][u] = cn * kp[i];
                     stg[(4 * g + i) * JB + u * 16 + c] = h * kp[i];
                     if (ok) {
                         float *go = p.gates + tr * G4 + j;
                         go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
                         p.hout[tr * H + j] = h;
                         p.cout[tr * H + j] = cn;
-                        st_sc1(p.cprev + (tr + Cn) * H + j, cn * kp[i]);
+                        p.cprev[(tr + Cn) * H + j] = cn * kp[i];
                     }
                 }
             }
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
 
 struct LstmSeqBwd {
     const float *dout, *gates, *cprev, *cout, *keep, *whh;
-    float *dgx, *carry_h, *carry_c;
+    float *dgx;
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
 };
@@ -232,12 +241,22 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
     const int nsub = (p.rows_per_group + 63) / 64;
 
+    // dL/dh and dL/dc carried from step t+1 to step t for this lane's (row, unit) elements: registers
+    float car_h[SEQ_MAX_SUB][4][NU], car_c[SEQ_MAX_SUB][4][NU];
+#pragma unroll
+    for (int sub = 0; sub < SEQ_MAX_SUB; ++sub)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) car_h[sub][i][u] = car_c[sub][i][u] = 0.0f;
+
     for (int s = 0; s < R; ++s) {
         const int t = R - 1 - s;
         // ---- phase A: cell backward (k_rnn_cell_bwd's arithmetic) for this group's (rows, units); dgates -> dgx[t]
-        for (int sub = 0; sub < nsub; ++sub) {
+#pragma unroll
+        for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
             const int row0 = g_row0 + sub * 64 + wave * 16;
-            if (row0 >= g_rows_end) continue;
+            if (sub >= nsub || row0 >= g_rows_end) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + 4 * g + i;
@@ -252,9 +271,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
                     const float ig = go[0], fg = go[H], gg = go[2 * H], og = go[3 * H];
                     float d = p.dout[tr * H + j];
                     float dc_in = 0.0f;
-                    if (s > 0) {  // carries written by this very lane one step ago
-                        d = d + ld_sc1(p.carry_h + (int64_t)r * H + j);
-                        dc_in = ld_sc1(p.carry_c + (int64_t)r * H + j);
+                    if (s > 0) {
+                        d = d + car_h[sub][i][u];
+                        dc_in = car_c[sub][i][u];
                     }
                     const float tc = tanhf(p.cout[tr * H + j]);
                     const float dc = d * og * (1.0f - tc * tc) + dc_in;
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
                     const float dg = (dc * ig) * (1.0f - gg * gg), dob = (d * tc) * (og * (1.0f - og));
                     float *sp = stg + (4 * g + i) * NC + u * 16 + c;
                     sp[0] = di; sp[JB] = df; sp[2 * JB] = dg; sp[3 * JB] = dob;
-                    if (ok && t > 0) st_sc1(p.carry_c + (int64_t)r * H + j, (dc * fg) * kprev);
+                    car_c[sub][i][u] = (dc * fg) * kprev;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -280,9 +299,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
         seq_arrive(counter);
         if (!seq_wait(counter, ncol * (unsigned)(s + 1), abort_flag, flag)) return;
         // ---- phase B: dL/dh_{t-1}[rows, own units] = dgates_t[rows, :] W_hh[own units, :]^T, masked by keep[t-1]
-        for (int sub = 0; sub < nsub; ++sub) {
+#pragma unroll
+        for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
             const int row0 = g_row0 + sub * 64 + wave * 16;
-            if (row0 >= g_rows_end) continue;
+            if (sub >= nsub || row0 >= g_rows_end) continue;
             f32x4 acc[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -317,13 +337,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = row0 + 4 * g + i;
-                if (row < g_rows_end) {
-                    const float kprev = p.keep[(int64_t)(t - 1) * Cn + row];
+                const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
+                const float kprev = p.keep[(int64_t)(t - 1) * Cn + r];
 #pragma unroll
-                    for (int u = 0; u < NU; ++u)
-                        st_sc1(p.carry_h + (int64_t)row * H + j0 + u * 16 + c, acc[u][i] * kprev);
-                }
+                for (int u = 0; u < NU; ++u) car_h[sub][i][u] = acc[u][i] * kprev;
             }
         }
     }
@@ -343,7 +360,7 @@ int seq_plan(int Cn, int H, int *ngroups, int *rows_per_group, int *jb) {
     if (ng < 1) return 0;
     *ngroups = ng;
     *rows_per_group = ((Cn + ng - 1) / ng + 15) / 16 * 16;
-    return 1;
+    return *rows_per_group <= 64 * SEQ_MAX_SUB;
 }
 
 }  // namespace
@@ -370,16 +387,16 @@ extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *b
 }
 
 extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout,
-                               const float *keep, const float *whh, float *dgx, float *carry_h, float *carry_c,
-                               uint32_t *sync, int R, int Cn, int H, void *stream) {
-    SF_REQUIRE(dout && gates && cprev && cout && keep && whh && dgx && carry_h && carry_c && sync && R > 0 && Cn > 0,
+                               const float *keep, const float *whh, float *dgx, uint32_t *sync, int R, int Cn, int H,
+                               void *stream) {
+    SF_REQUIRE(dout && gates && cprev && cout && keep && whh && dgx && sync && R > 0 && Cn > 0,
                "sf_lstm_seq_bwd: bad args");
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_lstm_seq_bwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)R * Cn * 4 * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_bwd: gate-gradient buffer exceeds 2 GiB");
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_bwd memset");
     if (rc) return rc;
-    LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, carry_h, carry_c, sync, R, Cn, ng, rpg};
+    LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ng, rpg};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     k_lstm_seq_bwd<16><<<grid, block, 0, STREAM(stream)>>>(p);
     return sf_launch_status("sf_lstm_seq_bwd");

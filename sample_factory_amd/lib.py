@@ -271,11 +271,11 @@ def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, C
                                       ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_fwd")
 
 
-def lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, carry_h, carry_c, sync, R, Cn, H) -> None:
+def lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, H) -> None:
     with _timed(_seq_key("lstm_bwd", R, Cn, H, R - 1)):
         _check(load().sf_lstm_seq_bwd(ptr(dout, "f32", "dout"), ptr(gates, "f32", "gates"), ptr(cprev, "f32", "cprev"),
                                       ptr(cout, "f32", "cout"), ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"),
-                                      ptr(dgx, "f32", "dgx"), ptr(carry_h, "f32", "carry_h"), ptr(carry_c, "f32", "carry_c"),
+                                      ptr(dgx, "f32", "dgx"),
                                       ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_bwd")
 
 

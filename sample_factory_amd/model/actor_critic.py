@@ -579,9 +579,8 @@ class ActorCritic:
         dOut.copy_(d_core.view(Cn, R, H).transpose(0, 1))
         dGX = self._buf(("g", "dGX"), (R, Cn, GH))
         if sv.get("fused"):  # the whole backward time loop in one persistent launch (cell backward + W_hh^T product + carries)
-            carry = self._buf(("g", "seq_carry"), (2, Cn, H))
             sync = self._buf(("g", "seq_sync"), (192,), dtype=torch.int32)
-            lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, carry[0], carry[1], sync, R, Cn, H)
+            lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, sync, R, Cn, H)
             self._seq_sync_bwd = sync
             ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
             lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGX.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)

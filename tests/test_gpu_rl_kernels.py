@@ -656,8 +656,7 @@ def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R):
         want = torch.stack([x.detach() for x in ref[name]])
         np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), err_msg=name, **tol)
     dgx = torch.full((R, Cn, 4 * H), 7.0, device="cuda")
-    carry = torch.zeros((2, Cn, H), device="cuda")
-    lib.lstm_seq_bwd(d(dout), gates, cprev, cout, d(keep), d(whh), dgx, carry[0], carry[1], sync, R, Cn, H)
+    lib.lstm_seq_bwd(d(dout), gates, cprev, cout, d(keep), d(whh), dgx, sync, R, Cn, H)
     torch.cuda.synchronize()
     assert int(sync[128]) == 0, "backward pass aborted"
     want = gx64.grad

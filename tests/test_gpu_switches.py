@@ -1,6 +1,8 @@
 """Every A/B switch of the network kernels (SF_CONV1_IMG, SF_DGRAD_PIX, SF_WGRAD_GLDS, SF_GLDS_CFG,
 SF_FWD_IMG, SF_GLDS_SPLITK — read once per process) selects a different kernel for the same operation; each must pass
-the same kernel-vs-torch tests as the default dispatch.  One pytest subprocess per non-default setting."""
+the same kernel-vs-torch tests as the default dispatch.  One pytest subprocess per group of independent (different
+operation) non-default settings; the two tests that assert which kernel / plan the DEFAULT dispatch picks are left out
+where the switch under test changes exactly that."""
 import os
 import subprocess
 import sys
@@ -9,17 +11,22 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECT = "vs_torch or fuzz or in_place"  # the kernel-level numerics tests of tests/test_gpu_nn.py
+SELECT = "(vs_torch or fuzz or in_place)"  # the kernel-level numerics tests of tests/test_gpu_nn.py
+
+GROUPS = [
+    # the register-staged / im2col generation for every operation
+    ("SF_CONV1_IMG=0 SF_DGRAD_PIX=0 SF_WGRAD_GLDS=0 SF_FWD_IMG=0", " and not lds_image_forward_conv3"),
+    # alternative tilings of the LDS-DMA kernels
+    ("SF_DGRAD_PIX=2 SF_WGRAD_GLDS=2 SF_GLDS_CFG=2", ""),
+    ("SF_DGRAD_PIX=3 SF_WGRAD_GLDS=3 SF_GLDS_SPLITK=0", " and not splitk_small_grids"),
+]
 
 
-@pytest.mark.parametrize("switch", ["SF_CONV1_IMG=0", "SF_DGRAD_PIX=0", "SF_DGRAD_PIX=2", "SF_DGRAD_PIX=3",
-                                    "SF_WGRAD_GLDS=0", "SF_WGRAD_GLDS=2", "SF_GLDS_CFG=2", "SF_FWD_IMG=0",
-                                    "SF_GLDS_SPLITK=0"])
-def test_kernel_numerics_under_non_default_switch(switch):
-    k, v = switch.split("=")
-    env = dict(os.environ, **{k: v})
+@pytest.mark.parametrize("switches,minus", GROUPS)
+def test_kernel_numerics_under_non_default_switches(switches, minus):
+    env = dict(os.environ, **dict(kv.split("=") for kv in switches.split()))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_nn.py"), "-q", "-x", "-m", "gpu",
-                        "-k", SELECT, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
+                        "-k", SELECT + minus, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=900)
     tail = r.stdout[-1500:]
-    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, f"{switch}:\n{tail}\n{r.stderr[-500:]}"
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, f"{switches}:\n{tail}\n{r.stderr[-500:]}"
