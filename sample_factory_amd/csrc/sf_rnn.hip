@@ -20,6 +20,8 @@
 // Work-groups spin on the counter, so all of them must be co-resident: the grid is ngroups * H/JB <= #CUs with one
 // work-group per CU (LDS-limited).  A bounded spin turns a lost work-group (GPU shared with another process) into an
 // error flag instead of a hang.
+#include <stdlib.h>
+
 #include "sf_common.h"
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -73,7 +75,7 @@ struct LstmSeqFwd {
 };
 
 // JB hidden units per work-group, H = 8192 / JB (so that the W_hh slice fills ~129 KB of LDS): JB = 16 <-> H = 512.
-template <int JB>
+template <int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
     constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
     constexpr int KU = 8, NKB = H / 16 / KU;
@@ -101,28 +103,27 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
     const auto h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.hprev, 0, (int)((int64_t)(R + 1) * Cn * H * 4), 0x00020000);
     const int g_row0 = group * p.rows_per_group;
     const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
-    const int nsub = (p.rows_per_group + 63) / 64;
 
     // the cell state of this lane's (row, unit) elements stays in registers across the steps (the masked copy is also
     // stored to cprev[t+1] for the backward pass); sub-tiles are unrolled so that the register arrays index statically
-    float cst[SEQ_MAX_SUB][4][NU];
+    float cst[NSUB][4][NU];
 #pragma unroll
-    for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
+    for (int sub = 0; sub < NSUB; ++sub) {
         const int row0 = g_row0 + sub * 64 + wave * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) cst[sub][i][u] = sub < nsub ? p.cprev[(int64_t)r * H + j0 + u * 16 + c] : 0.0f;
+            for (int u = 0; u < NU; ++u) cst[sub][i][u] = p.cprev[(int64_t)r * H + j0 + u * 16 + c];
         }
     }
 
     for (int t = 0; t < R; ++t) {
         if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
 #pragma unroll
-        for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
             const int row0 = g_row0 + sub * 64 + wave * 16;
-            if (sub >= nsub || row0 >= g_rows_end) continue;  // (wave-uniform; no block barrier inside the sub-tile body)
+            if (row0 >= g_rows_end) continue;  // (wave-uniform; no block barrier inside the sub-tile body)
             // ---- epilogue operands first: they fly during the MFMA phase
             float xg[4][4][NU], kp[4];
 #pragma unroll
@@ -212,9 +213,11 @@ struct LstmSeqBwd {
     float *dgx;
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
+    int ablate;  // timing experiments only (SF_LSTM_ABLATE, tools/lstm_bench.py): 1 no hand-off wait, 2 no phase-B loads,
+                 // 4 no phase-B MFMAs, 8 no phase A — results are wrong with any bit set
 };
 
-template <int JB>
+template <int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NU = JB / 16, LDK = G4 + 4;
     constexpr int KU = 16, NKB = G4 / 16 / KU;  // 2 x 16 loads of 16 B in flight per lane: one wave per SIMD, so the
@@ -239,12 +242,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     const auto d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.dgx, 0, (int)((int64_t)R * Cn * G4 * 4), 0x00020000);
     const int g_row0 = group * p.rows_per_group;
     const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
-    const int nsub = (p.rows_per_group + 63) / 64;
 
     // dL/dh and dL/dc carried from step t+1 to step t for this lane's (row, unit) elements: registers
-    float car_h[SEQ_MAX_SUB][4][NU], car_c[SEQ_MAX_SUB][4][NU];
+    float car_h[NSUB][4][NU], car_c[NSUB][4][NU];
 #pragma unroll
-    for (int sub = 0; sub < SEQ_MAX_SUB; ++sub)
+    for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
         const int t = R - 1 - s;
         // ---- phase A: cell backward (k_rnn_cell_bwd's arithmetic) for this group's (rows, units); dgates -> dgx[t]
 #pragma unroll
-        for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
             const int row0 = g_row0 + sub * 64 + wave * 16;
-            if (sub >= nsub || row0 >= g_rows_end) continue;
+            if (row0 >= g_rows_end || (p.ablate & 8)) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + 4 * g + i;
@@ -297,17 +299,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
         }
         if (t == 0) break;  // no state in front of step 0
         seq_arrive(counter);
-        if (!seq_wait(counter, ncol * (unsigned)(s + 1), abort_flag, flag)) return;
+        if (!(p.ablate & 1) && !seq_wait(counter, ncol * (unsigned)(s + 1), abort_flag, flag)) return;
         // ---- phase B: dL/dh_{t-1}[rows, own units] = dgates_t[rows, :] W_hh[own units, :]^T, masked by keep[t-1]
 #pragma unroll
-        for (int sub = 0; sub < SEQ_MAX_SUB; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
             const int row0 = g_row0 + sub * 64 + wave * 16;
-            if (sub >= nsub || row0 >= g_rows_end) continue;
+            if (row0 >= g_rows_end) continue;
             f32x4 acc[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int arow = row0 + c;
-            const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * G4 + 4 * g) * 4) : OOB;
+            const uint32_t abase = (arow < g_rows_end && !(p.ablate & 2)) ? (uint32_t)((((int64_t)t * Cn + arow) * G4 + 4 * g) * 4) : OOB;
             i32x4 abuf[2][KU];
             auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
 #pragma unroll
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
                     dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
             };
             auto mma_block = [&](int kb, const i32x4 (&src)[KU]) {
+                if (p.ablate & 4) return;
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku) {
                     const f32x4 a4 = __builtin_bit_cast(f32x4, src[ku]);
@@ -382,7 +385,10 @@ extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *b
     if (rc) return rc;
     LstmSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, ng, rpg};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
-    k_lstm_seq_fwd<16><<<grid, block, 0, STREAM(stream)>>>(p);
+    const int nsub = (rpg + 63) / 64;  // 64-row sub-tiles per work-group, unrolled at compile time (register-resident state)
+    if (nsub == 1) k_lstm_seq_fwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
+    else if (nsub == 2) k_lstm_seq_fwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
+    else k_lstm_seq_fwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
     return sf_launch_status("sf_lstm_seq_fwd");
 }
 
@@ -396,8 +402,12 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
     SF_REQUIRE((int64_t)R * Cn * 4 * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_bwd: gate-gradient buffer exceeds 2 GiB");
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_bwd memset");
     if (rc) return rc;
-    LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ng, rpg};
+    static const int ablate = getenv("SF_LSTM_ABLATE") ? atoi(getenv("SF_LSTM_ABLATE")) : 0;
+    LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ng, rpg, ablate};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
-    k_lstm_seq_bwd<16><<<grid, block, 0, STREAM(stream)>>>(p);
+    const int nsub = (rpg + 63) / 64;
+    if (nsub == 1) k_lstm_seq_bwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
+    else if (nsub == 2) k_lstm_seq_bwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
+    else k_lstm_seq_bwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
     return sf_launch_status("sf_lstm_seq_bwd");
 }

@@ -260,7 +260,10 @@ def _seq_key(op, R, Cn, H, steps):
     recurrent products (forward: R steps; backward: R-1, the first step has no state in front of it)"""
     if PROFILE is None:
         return None
-    return (op, int(steps * Cn), int(H), 1, 1, int(4 * H), 1, 1, 1, 1, f"k_lstm_seq_{op[5:]}<16>")
+    ng = min(8, (Cn + 15) // 16)
+    rpg = ((Cn + ng - 1) // ng + 15) // 16 * 16
+    nsub = {1: 1, 2: 2}.get((rpg + 63) // 64, 4)
+    return (op, int(steps * Cn), int(H), 1, 1, int(4 * H), 1, 1, 1, 1, f"k_lstm_seq_{op[5:]}<16, {nsub}>")
 
 
 def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H) -> None:
