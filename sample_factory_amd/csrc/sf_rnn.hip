@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
     const int group = blockIdx.x % p.ngroups, j0 = (blockIdx.x / p.ngroups) * JB;
     const unsigned ncol = H / JB;
     const int Cn = p.Cn, R = p.R;
+    const int rot = (int)(blockIdx.x / p.ngroups) % NKB;
     unsigned *counter = p.sync + group * SEQ_SYNC_STRIDE, *abort_flag = p.sync + SEQ_ABORT_SLOT;
     // ---- W_hh slice, transposed into LDS: wt[q*JB + u][k] = whh[k][q*H + j0 + u]
     for (int idx = tid; idx < NC * H; idx += 256) {
@@ -150,14 +151,18 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
                 for (int ku = 0; ku < KU; ++ku)
                     dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
             };
-            load_block(0, abuf[0]);
+            // every work-group of the row group reads the SAME h rows: each starts its reduction at a different k-block
+            // so that at any moment they pull different lines (different L2 channels) instead of all the same one
+            auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
+            load_block(kbe(0), abuf[0]);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                if (kb + 1 < NKB) load_block(kb + 1, abuf[(kb + 1) & 1]);
+                if (kb + 1 < NKB) load_block(kbe(kb + 1), abuf[(kb + 1) & 1]);
+                const float *bpk = wt + c * LDW + kbe(kb) * (KU * 16) + 4 * g;
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku) {
                     const f32x4 a4 = __builtin_bit_cast(f32x4, abuf[kb & 1][ku]);
-                    const float *bp = wt + c * LDW + (kb * KU + ku) * 16 + 4 * g;
+                    const float *bp = bpk + ku * 16;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + nt * 16 * LDW);
@@ -220,8 +225,7 @@ struct LstmSeqBwd {
 template <int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NU = JB / 16, LDK = G4 + 4;
-    constexpr int KU = 16, NKB = G4 / 16 / KU;  // 2 x 16 loads of 16 B in flight per lane: one wave per SIMD, so the
-                                                // prefetch depth is all the latency hiding there is
+    constexpr int KU = 8, NKB = G4 / 16 / KU;  // 2 x 8 loads of 16 B in flight per lane (16 measured the same)
     constexpr int STG = 16 * NC;
     static_assert(NKB * KU * 16 == G4 && NKB % 2 == 0, "shape");
     __shared__ __attribute__((aligned(16))) float lds[JB * LDK + 4 * STG + 4];
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     const int group = blockIdx.x % p.ngroups, j0 = (blockIdx.x / p.ngroups) * JB;
     const unsigned ncol = H / JB;
     const int Cn = p.Cn, R = p.R;
+    const int rot = (int)(blockIdx.x / p.ngroups) % NKB;  // staggered reduction start (see k_lstm_seq_fwd)
     unsigned *counter = p.sync + group * SEQ_SYNC_STRIDE, *abort_flag = p.sync + SEQ_ABORT_SLOT;
     // ---- W_hh rows j0 .. j0+JB-1 (all 4H gate columns of this group's hidden units): wk[kk][n] = whh[j0 + kk][n]
     for (int idx = tid; idx < JB * (G4 / 4); idx += 256) {
@@ -331,12 +336,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
                     }
                 }
             };
-            load_block(0, abuf[0]);
+            auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
+            load_block(kbe(0), abuf[0]);
             for (int kb = 0; kb < NKB; kb += 2) {
-                load_block(kb + 1, abuf[1]);
-                mma_block(kb, abuf[0]);
-                if (kb + 2 < NKB) load_block(kb + 2, abuf[0]);
-                mma_block(kb + 1, abuf[1]);
+                load_block(kbe(kb + 1), abuf[1]);
+                mma_block(kbe(kb), abuf[0]);
+                if (kb + 2 < NKB) load_block(kbe(kb + 2), abuf[0]);
+                mma_block(kbe(kb + 1), abuf[1]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
