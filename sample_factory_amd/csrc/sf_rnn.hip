@@ -119,26 +119,34 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
         }
     }
 
-    for (int t = 0; t < R; ++t) {
-        if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
+    // operands of the cell epilogue for the next step: issued right after this step's hand-off, so they fly during the
+    // wait for the other work-groups and the MFMA phase
+    float xg[NSUB][4][4][NU], kp[NSUB][4];
+    auto prefetch = [&](int t) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             const int row0 = g_row0 + sub * 64 + wave * 16;
-            if (row0 >= g_rows_end) continue;  // (wave-uniform; no block barrier inside the sub-tile body)
-            // ---- epilogue operands first: they fly during the MFMA phase
-            float xg[4][4][NU], kp[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
                 const int64_t tr = (int64_t)t * Cn + r;
-                kp[i] = p.keep[tr];
+                kp[sub][i] = p.keep[tr];
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int j = j0 + u * 16 + c;
+                for (int u = 0; u < NU; ++u)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xg[i][q][u] = p.gx[tr * G4 + q * H + j];
-                }
+                    for (int q = 0; q < 4; ++q) xg[sub][i][q][u] = p.gx[tr * G4 + q * H + j0 + u * 16 + c];
             }
+        }
+    };
+    prefetch(0);
+
+    for (int t = 0; t < R; ++t) {
+        if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
+        float sv[NSUB][4][NU][6];  // i, f, g, o, h, c of this step: stored AFTER the hand-off (nobody waits for them)
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+            if (row0 >= g_rows_end) continue;  // (wave-uniform; no block barrier inside the sub-tile body)
             // ---- gh = h_{t-1} W_hh: A rows from L2 (write-through hand-off: sc1 loads), B from the resident LDS slice
             f32x4 acc[NT];
 #pragma unroll
@@ -172,30 +180,21 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
                     }
                 }
             }
-            // ---- LSTM cell (k_rnn_cell_fwd's arithmetic), saves for the backward pass, masked state for step t+1
+            // ---- LSTM cell (k_rnn_cell_fwd's arithmetic); masked state for step t+1 into the staging tile
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = row0 + 4 * g + i;
-                const bool ok = row < g_rows_end;
-                const int64_t tr = (int64_t)t * Cn + (ok ? row : g_rows_end - 1);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const int j = j0 + u * 16 + c;
-                    const float ig = sigm(xg[i][0][u] + (acc[0 * NU + u][i] + bias[0][u]));
-                    const float fg = sigm(xg[i][1][u] + (acc[1 * NU + u][i] + bias[1][u]));
-                    const float gg = tanhf(xg[i][2][u] + (acc[2 * NU + u][i] + bias[2][u]));
-                    const float og = sigm(xg[i][3][u] + (acc[3 * NU + u][i] + bias[3][u]));
+                    const float ig = sigm(xg[sub][i][0][u] + (acc[0 * NU + u][i] + bias[0][u]));
+                    const float fg = sigm(xg[sub][i][1][u] + (acc[1 * NU + u][i] + bias[1][u]));
+                    const float gg = tanhf(xg[sub][i][2][u] + (acc[2 * NU + u][i] + bias[2][u]));
+                    const float og = sigm(xg[sub][i][3][u] + (acc[3 * NU + u][i] + bias[3][u]));
                     const float cn = fg * cst[sub][i][u] + ig * gg;
                     const float h = og * tanhf(cn);
-                    cst[sub][i][u] = cn * kp[i];
-                    stg[(4 * g + i) * JB + u * 16 + c] = h * kp[i];
-                    if (ok) {
-                        float *go = p.gates + tr * G4 + j;
-                        go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
-                        p.hout[tr * H + j] = h;
-                        p.cout[tr * H + j] = cn;
-                        p.cprev[(tr + Cn) * H + j] = cn * kp[i];
-                    }
+                    cst[sub][i][u] = cn * kp[sub][i];
+                    stg[(4 * g + i) * JB + u * 16 + c] = h * kp[sub][i];
+                    sv[sub][i][u][0] = ig; sv[sub][i][u][1] = fg; sv[sub][i][u][2] = gg; sv[sub][i][u][3] = og;
+                    sv[sub][i][u][4] = h; sv[sub][i][u][5] = cn;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -209,7 +208,31 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if (t + 1 < R) seq_arrive(counter);
+        if (t + 1 < R) {
+            seq_arrive(counter);
+            prefetch(t + 1);
+        }
+        // ---- saves for the backward pass (plain stores: they drain while this work-group waits for the others)
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i;
+                if (row < g_rows_end) {
+                    const int64_t tr = (int64_t)t * Cn + row;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int j = j0 + u * 16 + c;
+                        float *go = p.gates + tr * G4 + j;
+                        go[0] = sv[sub][i][u][0]; go[H] = sv[sub][i][u][1]; go[2 * H] = sv[sub][i][u][2]; go[3 * H] = sv[sub][i][u][3];
+                        p.hout[tr * H + j] = sv[sub][i][u][4];
+                        p.cout[tr * H + j] = sv[sub][i][u][5];
+                        p.cprev[(tr + Cn) * H + j] = cst[sub][i][u];
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -257,6 +280,32 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) car_h[sub][i][u] = car_c[sub][i][u] = 0.0f;
 
+    // operands of the cell backward of the NEXT step (t-1): issued right after this step's hand-off, so they fly during
+    // the wait and the MFMA phase (only the carry of dL/dh links phase A of step t-1 to phase B of step t)
+    float pg[NSUB][4][NU][4], pdo[NSUB][4][NU], pco[NSUB][4][NU], pcp[NSUB][4][NU], pkp[NSUB][4];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
+                const int64_t tr = (int64_t)t * Cn + r;
+                pkp[sub][i] = t > 0 ? p.keep[tr - Cn] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int j = j0 + u * 16 + c;
+                    const float *go = p.gates + tr * G4 + j;
+                    pg[sub][i][u][0] = go[0]; pg[sub][i][u][1] = go[H]; pg[sub][i][u][2] = go[2 * H]; pg[sub][i][u][3] = go[3 * H];
+                    pdo[sub][i][u] = p.dout[tr * H + j];
+                    pco[sub][i][u] = p.cout[tr * H + j];
+                    pcp[sub][i][u] = p.cprev[tr * H + j];
+                }
+            }
+        }
+    };
+    prefetch(R - 1);
+
     for (int s = 0; s < R; ++s) {
         const int t = R - 1 - s;
         // ---- phase A: cell backward (k_rnn_cell_bwd's arithmetic) for this group's (rows, units); dgates -> dgx[t]
@@ -266,25 +315,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
             if (row0 >= g_rows_end || (p.ablate & 8)) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = row0 + 4 * g + i;
-                const bool ok = row < g_rows_end;
-                const int r = ok ? row : g_rows_end - 1;
-                const int64_t tr = (int64_t)t * Cn + r;
-                const float kprev = t > 0 ? p.keep[tr - Cn] : 0.0f;
+                const float kprev = pkp[sub][i];
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const int j = j0 + u * 16 + c;
-                    const float *go = p.gates + tr * G4 + j;
-                    const float ig = go[0], fg = go[H], gg = go[2 * H], og = go[3 * H];
-                    float d = p.dout[tr * H + j];
+                    const float ig = pg[sub][i][u][0], fg = pg[sub][i][u][1], gg = pg[sub][i][u][2], og = pg[sub][i][u][3];
+                    float d = pdo[sub][i][u];
                     float dc_in = 0.0f;
                     if (s > 0) {
                         d = d + car_h[sub][i][u];
                         dc_in = car_c[sub][i][u];
                     }
-                    const float tc = tanhf(p.cout[tr * H + j]);
+                    const float tc = tanhf(pco[sub][i][u]);
                     const float dc = d * og * (1.0f - tc * tc) + dc_in;
-                    const float di = (dc * gg) * (ig * (1.0f - ig)), df = (dc * p.cprev[tr * H + j]) * (fg * (1.0f - fg));
+                    const float di = (dc * gg) * (ig * (1.0f - ig)), df = (dc * pcp[sub][i][u]) * (fg * (1.0f - fg));
                     const float dg = (dc * ig) * (1.0f - gg * gg), dob = (d * tc) * (og * (1.0f - og));
                     float *sp = stg + (4 * g + i) * NC + u * 16 + c;
                     sp[0] = di; sp[JB] = df; sp[2 * JB] = dg; sp[3 * JB] = dob;
@@ -304,6 +347,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
         }
         if (t == 0) break;  // no state in front of step 0
         seq_arrive(counter);
+        prefetch(t - 1);
         if (!(p.ablate & 1) && !seq_wait(counter, ncol * (unsigned)(s + 1), abort_flag, flag)) return;
         // ---- phase B: dL/dh_{t-1}[rows, own units] = dgates_t[rows, :] W_hh[own units, :]^T, masked by keep[t-1]
 #pragma unroll
