@@ -224,6 +224,14 @@ int sf_traj_write_env_step(const float *rewards, const uint8_t *terminated, cons
                            uint8_t *traj_dones, uint8_t *traj_time_outs, int32_t *traj_policy_id, float *ep_return,
                            int32_t *ep_len, double *ep_stats, void *stream);
 
+/* Ant-shaped continuous stand-in env (config 5): f32 observations [B, D], Box actions [B, A] (row stride act_stride
+ * floats, e.g. traj.actions[:, t]).  One launch per env step writes the next observation into `state` (the env's own
+ * [B, D] copy) AND into obs_out (row stride out_stride floats = slot t+1 of the slab); reset != 0: fresh observations
+ * only.  obs' = terminated ? noise : 0.9*obs + 0.1*noise, reward = -mean(a^2) + 0.1*obs[0], terminated ~ Bernoulli(1/256). */
+int sf_synth_vec_step(float *state, const float *actions, int64_t act_stride, float *obs_out, int64_t out_stride, int B,
+                      int D, int A, int env0, uint32_t seed, uint32_t step, int reset, float *rewards,
+                      uint8_t *terminated, void *stream);
+
 /* ---- host-env ingest ---------------------------------------------------------------------
  * batched_sampling.py:62-82 / rl_utils.py:38: observations of a CPU vector env (envpool: one [B, ...] host array per
  * step) go into slot t of the device slab.  Rows of `row_bytes` bytes, `rows` of them, from (pinned) host memory with
@@ -284,6 +292,12 @@ int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index
  * i.e. the previous layer's post-activation output, kind = h_desc->relu; NULL = no activation derivative). */
 int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                   const sf_conv_desc *h_desc, void *stream);
+
+/* rollout: rnn_states[:, t+1] = new_state * (1 - done) (batched_sampling.py:332-335) in one launch; h (and c for an
+ * LSTM) are the cell's [B, H] outputs, dones the u8 [B] column traj.dones[:, t] (element stride done_stride), out the
+ * [B, H or 2H] view traj.rnn_states[:, t+1] (row stride out_stride floats). */
+int sf_rnn_store_state(const float *h, const float *c, const uint8_t *dones, int64_t done_stride, float *out,
+                       int64_t out_stride, int64_t B, int H, void *stream);
 
 /* ---- fused LSTM sequence passes (config 5: LSTM-512 core, BPTT over recurrence-length chunks) -------------------
  * model/core.py:19-64 + algo/learning/rnn_utils.py:114-158 as ONE persistent launch per pass instead of

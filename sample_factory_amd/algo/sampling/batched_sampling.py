@@ -204,8 +204,12 @@ class BatchedVectorEnvRunner:
                                 tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
                                 self.ep_len, self.ep_stats)
         if self.rnn:  # batched_sampling.py:332-335: next-step state = new_rnn_states * (1 - done)
-            keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
-            torch.mul(self.ac.new_rnn_states, keep, out=tr["rnn_states"][:, t + 1])
+            parts = getattr(self.ac, "new_rnn_parts", None)
+            if parts is not None:  # native model: mask + store [h | c] in one launch
+                lib.rnn_store_state(parts[0], parts[1], tr["dones"][:, t], tr["rnn_states"][:, t + 1])
+            else:                  # torch model path
+                keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
+                torch.mul(self.ac.new_rnn_states, keep, out=tr["rnn_states"][:, t + 1])
         self.global_step += 1
 
     def set_slab(self, traj: TensorDict, carry_from: Optional[TensorDict] = None) -> None:

@@ -1459,6 +1459,63 @@ extern "C" int sf_synth_step(const int32_t *actions, int B, int env0, int num_ac
     return sf_launch_status("sf_synth_step");
 }
 
+// ---- Ant-shaped continuous synthetic env (SURVEY.md §8d C5 stand-in), one lane per env:
+// obs' = terminated ? noise : 0.9 * obs + 0.1 * noise, reward = -mean(a^2) + 0.1 * obs[0], terminated ~ Bernoulli(1/256);
+// noise ~ N(0, 1) from Philox4x32-10 keyed by (seed, env), counter (step, block) via Box-Muller.  `state` is the env's
+// own copy of the observation; `obs_out` (row stride out_stride floats) is slot t+1 of the trajectory slab.
+__device__ __forceinline__ void synth_normals(uint32_t seed, uint32_t env, uint32_t step, uint32_t blk, float (&z)[4]) {
+    uint32_t w[4];
+    sf_philox4x32_10(step, blk, 2u, 0u, seed, env, w);
+    const float u0 = ((float)(w[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(w[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = (float)(w[3] >> 8) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    z[0] = r0 * cosf(6.2831853f * u1); z[1] = r0 * sinf(6.2831853f * u1);
+    z[2] = r1 * cosf(6.2831853f * u3); z[3] = r1 * sinf(6.2831853f * u3);
+}
+
+__global__ __launch_bounds__(256) void k_synth_vec_step(float *__restrict__ state, const float *__restrict__ actions,
+                                                        int64_t act_stride, float *__restrict__ obs_out, int64_t out_stride,
+                                                        int B, int D, int A, int env0, uint32_t seed, uint32_t step,
+                                                        int reset, float *__restrict__ rewards,
+                                                        uint8_t *__restrict__ terminated) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t env = (uint32_t)(env0 + b);
+    float *st = state + (int64_t)b * D, *out = obs_out + (int64_t)b * out_stride;
+    bool term = reset != 0;
+    if (!reset) {
+        float sq = 0.0f;
+        for (int a = 0; a < A; ++a) {
+            const float v = actions[(int64_t)b * act_stride + a];
+            sq += v * v;
+        }
+        rewards[b] = -(sq / (float)A) + 0.1f * st[0];
+        uint32_t w[4];
+        sf_philox4x32_10(step, 0u, 1u, 0u, seed, env, w);
+        term = w[0] < (1u << 24);  // 1/256
+        terminated[b] = (uint8_t)term;
+    }
+    for (int d0 = 0; d0 < D; d0 += 4) {
+        float z[4];
+        synth_normals(seed, env, step, (uint32_t)(d0 >> 2), z);
+        for (int k = 0; k < 4 && d0 + k < D; ++k) {
+            const float v = term ? z[k] : 0.9f * st[d0 + k] + 0.1f * z[k];
+            st[d0 + k] = v;
+            out[d0 + k] = v;
+        }
+    }
+}
+
+extern "C" int sf_synth_vec_step(float *state, const float *actions, int64_t act_stride, float *obs_out, int64_t out_stride,
+                                 int B, int D, int A, int env0, uint32_t seed, uint32_t step, int reset, float *rewards,
+                                 uint8_t *terminated, void *stream) {
+    SF_REQUIRE(state && obs_out && B > 0 && D > 0 && (reset || (actions && rewards && terminated && A > 0)),
+               "sf_synth_vec_step: bad args");
+    k_synth_vec_step<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        state, actions, act_stride, obs_out, out_stride, B, D, A, env0, seed, step, reset, rewards, terminated);
+    return sf_launch_status("sf_synth_vec_step");
+}
+
 // =========================================================================================== observation normaliser
 // utils/normalize.py:24-70 (ObservationNormalizer) + running_mean_std.py:22-136 (RunningMeanStd(Dict)InPlace with
 // full-shape statistics): x' = (float(x) - obs_subtract_mean) * (1/obs_scale); per-element running mean/var/count
@@ -1702,6 +1759,28 @@ extern "C" int sf_rnn_cell_bwd(int kind, const float *dh, const float *dc_in, co
     k_rnn_cell_bwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
         kind, dh, dc_in, gates, h_prev, ld_h, c_prev, ld_c, c_out, C, H, dgx, dgh, dh_direct, dc_prev);
     return sf_launch_status("sf_rnn_cell_bwd");
+}
+
+// rollout: state input of step t+1 = new state * (1 - done) (batched_sampling.py:332-335); out row b = [h | c] (c: LSTM)
+__global__ __launch_bounds__(256) void k_rnn_store_state(const float *__restrict__ h, const float *__restrict__ c,
+                                                         const uint8_t *__restrict__ dones, int64_t done_stride,
+                                                         float *__restrict__ out, int64_t out_stride, int64_t B, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = c ? 2 * H : H;
+    if (i >= B * W) return;
+    const int64_t b = i / W;
+    const int j = (int)(i - b * W);
+    const float v = j < H ? h[b * H + j] : c[b * H + j - H];
+    out[b * out_stride + j] = dones[b * done_stride] ? 0.0f : v;
+}
+
+extern "C" int sf_rnn_store_state(const float *h, const float *c, const uint8_t *dones, int64_t done_stride, float *out,
+                                  int64_t out_stride, int64_t B, int H, void *stream) {
+    SF_REQUIRE(h && dones && out && B > 0 && H > 0, "sf_rnn_store_state: bad args");
+    const int64_t n = B * (c ? 2 * H : H);
+    k_rnn_store_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(h, c, dones, done_stride, out,
+                                                                                             out_stride, B, H);
+    return sf_launch_status("sf_rnn_store_state");
 }
 
 // y[c, :] = (a[c, :] + b[c, :]) * keep[c]    (carry of dL/dh across a step boundary; b or keep may be NULL)

@@ -68,30 +68,42 @@ class SyntheticVecEnv:
 
 
 class SyntheticContinuousEnv:
-    """Ant-shaped device-resident env (SURVEY.md §8d C5 stand-in): f32 vector observations, Box actions.  Plain
-    gymnasium-style interface only (no zero-copy hook) — exercises the runner's generic GPU-env path.  Dynamics:
-    obs' = 0.9*obs + 0.1*noise, reward = -mean(action^2) + 0.1*obs[:,0], termination ~ Bernoulli(1/256)."""
+    """Ant-shaped device-resident env (SURVEY.md §8d C5 stand-in): f32 vector observations, Box actions.  One HIP
+    launch per step (sf_synth_vec_step, counter-based Philox noise keyed by the global env id): obs' = 0.9*obs +
+    0.1*noise, reward = -mean(action^2) + 0.1*obs[:,0], termination ~ Bernoulli(1/256) with auto-reset.  Like the image
+    env it offers the zero-copy hooks reset_into / step_into (the next observation lands in slot t+1 of the slab) next to
+    the gymnasium-style reset / step."""
 
-    def __init__(self, num_agents=2048, obs_dim=27, act_dim=8, seed=0, device="cuda"):
+    def __init__(self, num_agents=2048, obs_dim=27, act_dim=8, seed=0, env0=0, device="cuda"):
         self.num_agents, self.obs_dim, self.act_dim = int(num_agents), int(obs_dim), int(act_dim)
         self.observation_space = spaces.Dict({"obs": spaces.Box(-np.inf, np.inf, (obs_dim,), np.float32)})
         self.action_space = spaces.Box(-1.0, 1.0, (act_dim,), np.float32)
         self.device = torch.device(device)
-        self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(int(seed))
-        self.obs = torch.zeros((self.num_agents, obs_dim), dtype=torch.float32, device=self.device)
+        self.seed_, self.env0, self.step_count = int(seed), int(env0), 0
+        self.state = torch.zeros((self.num_agents, obs_dim), dtype=torch.float32, device=self.device)
+        self._obs = torch.zeros_like(self.state)
+        self._rew = torch.zeros(self.num_agents, dtype=torch.float32, device=self.device)
+        self._term = torch.zeros(self.num_agents, dtype=torch.bool, device=self.device)
+        self._trunc = torch.zeros(self.num_agents, dtype=torch.bool, device=self.device)
+
+    def reset_into(self, obs_out: torch.Tensor) -> None:
+        self.step_count = 0
+        lib.synth_vec_step(self.state, None, obs_out, self.env0, self.seed_, 0xFFFFFFFF, True, self._rew, self._term)
+
+    def step_into(self, actions: torch.Tensor, obs_out: torch.Tensor):
+        """actions f32 [N, act_dim] device view (e.g. traj.actions[:, t]); returns (rewards, terminated, truncated)"""
+        lib.synth_vec_step(self.state, actions, obs_out, self.env0, self.seed_, self.step_count, False, self._rew, self._term)
+        self.step_count += 1
+        return self._rew, self._term, self._trunc
 
     def reset(self, **kwargs):
-        self.obs = torch.randn(self.obs.shape, generator=self.gen, device=self.device)
-        return {"obs": self.obs}, {}
+        self.reset_into(self._obs)
+        return {"obs": self._obs}, {}
 
     def step(self, actions):
-        a = torch.as_tensor(actions, device=self.device, dtype=torch.float32).reshape(self.num_agents, self.act_dim)
-        noise = torch.randn(self.obs.shape, generator=self.gen, device=self.device)
-        rew = -(a * a).mean(dim=1) + 0.1 * self.obs[:, 0]
-        term = torch.rand(self.num_agents, generator=self.gen, device=self.device) < (1.0 / 256.0)
-        self.obs = torch.where(term[:, None], noise, 0.9 * self.obs + 0.1 * noise)  # auto-reset is the env's job
-        return {"obs": self.obs}, rew, term, torch.zeros_like(term), {}
+        a = torch.as_tensor(actions, device=self.device, dtype=torch.float32).reshape(self.num_agents, self.act_dim).contiguous()
+        rew, term, trunc = self.step_into(a, self._obs)
+        return {"obs": self._obs}, rew, term, trunc, {}
 
     def close(self):
         pass
@@ -252,7 +264,9 @@ def make_synthetic_tuple_env(full_env_name, cfg=None, env_config=None, render_mo
 
 def make_synthetic_continuous_env(full_env_name, cfg=None, env_config=None, render_mode=None):
     n = getattr(cfg, "synthetic_num_agents", 2048) if cfg is not None else 2048
-    return SyntheticContinuousEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0)
+    env0 = (getattr(cfg, "synthetic_env0", 0) or 0) if cfg is not None else 0
+    env0 += int(getattr(env_config, "env_id", 0) or 0) * n if env_config is not None else 0
+    return SyntheticContinuousEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0, env0=env0)
 
 
 def make_synthetic_env(full_env_name, cfg=None, env_config=None, render_mode=None):

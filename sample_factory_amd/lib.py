@@ -38,10 +38,10 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_rnn_store_state", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
-    "sf_synth_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
+    "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
     "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
     "sf_tanh_scale_fwd", "sf_tanh_scale_bwd",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
@@ -251,6 +251,18 @@ def rnn_cell_bwd(kind, dh, dc_in, gates, h_prev, ld_h, c_prev, ld_c, c_out, Cn, 
                                   ptr(dh_direct, "f32"), ptr(dc_prev, "f32"), stream()), "sf_rnn_cell_bwd")
 
 
+def rnn_store_state(h, c, dones_col, out) -> None:
+    """out[b] = [h[b] | c[b]] * (1 - dones_col[b]); dones_col / out may be strided views of the slab"""
+    B, H = h.shape
+    if dones_col.dtype not in (torch.bool, torch.uint8) or not dones_col.is_cuda or dones_col.shape != (B,):
+        raise SfHipError(f"rnn_store_state: dones must be a device bool/u8 [B] column, got {dones_col.dtype} {tuple(dones_col.shape)}")
+    if out.shape != (B, H if c is None else 2 * H) or out.stride(1) != 1:
+        raise SfHipError(f"rnn_store_state: out must be [B, {H if c is None else 2 * H}] with unit column stride")
+    _check(load().sf_rnn_store_state(ptr(h, "f32", "h"), ptr(c, "f32", "c"), C.c_void_p(dones_col.data_ptr()),
+                                     i64(dones_col.stride(0)), _raw(out, "f32", "out"), i64(out.stride(0)), i64(B), int(H),
+                                     stream()), "sf_rnn_store_state")
+
+
 def lstm_seq_supported(Cn: int, H: int) -> bool:
     return bool(load().sf_lstm_seq_supported(int(Cn), int(H)))
 
@@ -400,6 +412,17 @@ def traj_write_env_step(rewards, terminated, truncated, T, t, reward_scale, rewa
                                          ptr(traj_dones, "u8"), ptr(traj_time_outs, "u8"), ptr(traj_policy_id, "i32"),
                                          ptr(ep_return, "f32"), ptr(ep_len, "i32"), ptr(ep_stats, "f64"), stream()),
            "sf_traj_write_env_step")
+
+
+def synth_vec_step(state, actions, obs_out, env0, seed, step, reset, rewards, terminated) -> None:
+    """state [B, D] contiguous; actions [B, A] view (row stride), obs_out [B, D] view (row stride); see sf_hip.h"""
+    B, D = state.shape
+    A = actions.shape[1] if actions is not None else 0
+    _check(load().sf_synth_vec_step(
+        ptr(state, "f32", "state"), _raw(actions, "f32", "actions") if actions is not None else C.c_void_p(0),
+        i64(actions.stride(0) if actions is not None else 0), _raw(obs_out, "f32", "obs_out"), i64(obs_out.stride(0)),
+        int(B), int(D), int(A), int(env0), u32(seed), u32(step), int(bool(reset)),
+        ptr(rewards, "f32", "rewards"), ptr(terminated, "u8", "terminated"), stream()), "sf_synth_vec_step")
 
 
 def h2d_rows(dst: torch.Tensor, src_pinned: torch.Tensor) -> None:

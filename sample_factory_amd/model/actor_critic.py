@@ -534,7 +534,8 @@ class ActorCritic:
         c_out = self._buf((tag, "c_out"), (n, H)) if kind == 1 else None
         lib.rnn_cell_fwd(kind, gx, gh, st, st.stride(0), st[:, H:] if kind == 1 else None, st.stride(0), None, n, H,
                          None, h_out, c_out, None, None)
-        self.new_rnn_states = h_out if kind == 0 else torch.cat([h_out, c_out], dim=1)
+        self.new_rnn_parts = (h_out, c_out)  # the rollout runner masks + stores them in one launch (sf_rnn_store_state)
+        self._new_rnn_cat = None
         return h_out
 
     def _rnn_sequence_fwd(self, li, GX, n, rnn, tag):
@@ -606,6 +607,14 @@ class ActorCritic:
         ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
         lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
         return dGX.view(n, GH)
+
+    @property
+    def new_rnn_states(self) -> torch.Tensor:
+        """[B, S] state after the last one-step forward (reference output key `new_rnn_states`), built on demand"""
+        if self._new_rnn_cat is None:
+            h, c = self.new_rnn_parts
+            self._new_rnn_cat = h if c is None else torch.cat([h, c], dim=1)
+        return self._new_rnn_cat
 
     def rnn_pass_aborted(self) -> bool:
         """True if a fused LSTM pass gave up waiting for a work-group (GPU shared with another process): its results are

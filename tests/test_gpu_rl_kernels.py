@@ -662,3 +662,46 @@ def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R):
     want = gx64.grad
     scale = float(want.abs().max())
     np.testing.assert_allclose(dgx.cpu().double().numpy(), want.numpy(), atol=2e-6 * scale, rtol=5e-5)
+
+
+def test_synthetic_continuous_env_kernel_rules(lib):
+    """sf_synth_vec_step: reward / termination / dynamics rules of the Ant-shaped stand-in env, zero-copy into a strided
+    slab slot, reproducible from (seed, global env id, step)"""
+    from sample_factory_amd.envs.synthetic import SyntheticContinuousEnv
+    N, D, A, T = 300, 27, 8, 3
+    env = SyntheticContinuousEnv(num_agents=N, seed=5, env0=1000)
+    slab = torch.zeros((N, T + 1, D), device="cuda")
+    env.reset_into(slab[:, 0])
+    o0 = slab[:, 0].clone()
+    assert torch.equal(env.state, o0) and abs(float(o0.mean())) < 0.05 and 0.9 < float(o0.std()) < 1.1
+    acts = torch.randn((N, T, A), device="cuda")
+    for t in range(T):
+        prev = slab[:, t].clone()
+        rew, term, trunc = env.step_into(acts[:, t], slab[:, t + 1])
+        want = -(acts[:, t] ** 2).mean(1) + 0.1 * prev[:, 0]
+        np.testing.assert_allclose(rew.cpu().numpy(), want.cpu().numpy(), atol=1e-6, rtol=1e-6)
+        nxt = slab[:, t + 1]
+        noise = (nxt - 0.9 * prev) / 0.1                     # non-terminated envs: obs' = 0.9 obs + 0.1 noise
+        keep = ~term
+        assert float(noise[keep].std()) > 0.8 and float(noise[keep].std()) < 1.2 and not trunc.any()
+        assert torch.equal(env.state, nxt)
+    # same (seed, env ids) -> same stream; a shard of envs reproduces its slice of the full env set
+    env2 = SyntheticContinuousEnv(num_agents=100, seed=5, env0=1100)
+    s2 = torch.zeros((100, 2, D), device="cuda")
+    env2.reset_into(s2[:, 0])
+    assert torch.equal(s2[:, 0], o0[100:200])
+    r2, t2, _ = env2.step_into(acts[100:200, 0], s2[:, 1])
+    assert torch.equal(s2[:, 1], slab[100:200, 1])
+
+
+def test_rnn_store_state_masks_and_packs(lib):
+    B, H = 77, 24
+    g = torch.Generator().manual_seed(2)
+    h, c = torch.randn((B, H), generator=g).cuda(), torch.randn((B, H), generator=g).cuda()
+    dones = (torch.rand((B, 5), generator=g) < 0.3).cuda()
+    slab = torch.full((B, 4, 2 * H), 9.0, device="cuda")
+    lib.rnn_store_state(h, c, dones[:, 2], slab[:, 3])
+    want = torch.cat([h, c], 1) * (~dones[:, 2]).float()[:, None]
+    assert torch.equal(slab[:, 3], want) and (slab[:, :3] == 9.0).all()
+    lib.rnn_store_state(h, None, dones[:, 0], slab[:, 1, :H])
+    assert torch.equal(slab[:, 1, :H], h * (~dones[:, 0]).float()[:, None]) and (slab[:, 1, H:] == 9.0).all()
