@@ -300,11 +300,13 @@ def main():
     avg_ms = total_ms / launches
     achieved = flops / (total_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "r01_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench
-    if os.path.exists(tj):
-        ent = json.load(open(tj)).get(dominant)
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (tools/profile_round.sh + tools/pmc_traffic.py), newest first
+    for tname in ("r02_traffic.json", "r01_traffic.json"):
+        tj = os.path.join(ROOT, "profiles", tname)
+        ent = json.load(open(tj)).get(dominant) if os.path.exists(tj) else None
         if ent:
-            traffic, traffic_src = ent["hbm_bytes"], "profiles/r01_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+            traffic, traffic_src = ent["hbm_bytes"], f"profiles/{tname} (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+            break
     kern = []  # ranking of all network kernels from the instrumented warm-up step (NOT the timed region)
     for k2, evs2 in warm_prof.items():
         m2 = sorted(s_.elapsed_time(e_) for s_, e_ in evs2)

@@ -443,6 +443,10 @@ class Learner:
         n_mb = cfg.num_batches_per_epoch
         if n_mb == 1:
             return [(None, 0, experience_size)]
+        # a dataset is exactly one training iteration (the Runner's Batcher hands over nothing else): an explicit n at
+        # an offset past the end would be an out-of-bounds device read, a larger dataset would silently skip its tail
+        assert n_mb * batch_size == experience_size, \
+            f"dataset of {experience_size} samples != num_batches_per_epoch {n_mb} x batch_size {batch_size}"
         if cfg.shuffle_minibatches:
             idx = torch.empty(experience_size, dtype=torch.int32, device=self.device)
             if getattr(cfg, "device_shuffle", False):
