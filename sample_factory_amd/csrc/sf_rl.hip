@@ -1473,32 +1473,38 @@ __device__ __forceinline__ void synth_normals(uint32_t seed, uint32_t env, uint3
     z[2] = r1 * cosf(6.2831853f * u3); z[3] = r1 * sinf(6.2831853f * u3);
 }
 
+// one lane per (env, block of 4 observation dims): 7 lanes per env at D = 27
 __global__ __launch_bounds__(256) void k_synth_vec_step(float *__restrict__ state, const float *__restrict__ actions,
                                                         int64_t act_stride, float *__restrict__ obs_out, int64_t out_stride,
                                                         int B, int D, int A, int env0, uint32_t seed, uint32_t step,
                                                         int reset, float *__restrict__ rewards,
                                                         uint8_t *__restrict__ terminated) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const int nblk = (D + 3) >> 2;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * nblk) return;
+    const int b = gid / nblk, blk = gid - b * nblk, d0 = blk * 4;
     const uint32_t env = (uint32_t)(env0 + b);
     float *st = state + (int64_t)b * D, *out = obs_out + (int64_t)b * out_stride;
     bool term = reset != 0;
     if (!reset) {
-        float sq = 0.0f;
-        for (int a = 0; a < A; ++a) {
-            const float v = actions[(int64_t)b * act_stride + a];
-            sq += v * v;
-        }
-        rewards[b] = -(sq / (float)A) + 0.1f * st[0];
         uint32_t w[4];
-        sf_philox4x32_10(step, 0u, 1u, 0u, seed, env, w);
+        sf_philox4x32_10(step, 0u, 1u, 0u, seed, env, w);  // (every lane of the env draws the same word)
         term = w[0] < (1u << 24);  // 1/256
-        terminated[b] = (uint8_t)term;
+        if (blk == 0) {
+            float sq = 0.0f;
+            for (int a = 0; a < A; ++a) {
+                const float v = actions[(int64_t)b * act_stride + a];
+                sq += v * v;
+            }
+            rewards[b] = -(sq / (float)A) + 0.1f * st[0];
+            terminated[b] = (uint8_t)term;
+        }
     }
-    for (int d0 = 0; d0 < D; d0 += 4) {
-        float z[4];
-        synth_normals(seed, env, step, (uint32_t)(d0 >> 2), z);
-        for (int k = 0; k < 4 && d0 + k < D; ++k) {
+    float z[4];
+    synth_normals(seed, env, step, (uint32_t)blk, z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (d0 + k < D) {
             const float v = term ? z[k] : 0.9f * st[d0 + k] + 0.1f * z[k];
             st[d0 + k] = v;
             out[d0 + k] = v;
@@ -1511,7 +1517,8 @@ extern "C" int sf_synth_vec_step(float *state, const float *actions, int64_t act
                                  uint8_t *terminated, void *stream) {
     SF_REQUIRE(state && obs_out && B > 0 && D > 0 && (reset || (actions && rewards && terminated && A > 0)),
                "sf_synth_vec_step: bad args");
-    k_synth_vec_step<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+    const int64_t lanes = (int64_t)B * ((D + 3) / 4);
+    k_synth_vec_step<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
         state, actions, act_stride, obs_out, out_stride, B, D, A, env0, seed, step, reset, rewards, terminated);
     return sf_launch_status("sf_synth_vec_step");
 }
