@@ -929,7 +929,9 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     GldsFwdPlan p;
     p.ok = false; p.wide = false; p.Z = 1; p.k_per_split = (K + 31) / 32 * 32;
     const int64_t t64 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 64), t128 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 128);
-    if (t64 >= 768) {
+    // (wide outputs of moderate height — the recurrent projection of one rollout step, 2048 x 512 x 2048: 512 tiles,
+    //  two per CU — also beat the register-staged kernel: 75 -> measured in profiles/r02_c5_*)
+    if (t64 >= 768 || (t64 >= 448 && N >= 512 && K >= 256)) {
         p.ok = true;
         if (N >= 128 && cfg == 0) {  // efficiency = rounds / ceil(rounds) with the kernel's own occupancy
             const double u64 = (double)t64 / (256.0 * occ64), u128 = (double)t128 / (256.0 * occ128);

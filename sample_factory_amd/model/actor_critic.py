@@ -228,7 +228,7 @@ class ActorCritic:
         # refreshed by params_changed() after every parameter update
         self.flat_params_t = torch.zeros_like(self.flat_params)
         for L, (o, ob) in zip(self.layers, self._segs):
-            ok = L.role == "chain" and not L.desc.in_u8 and L.desc.Cin % 32 == 0 and L.N >= 32
+            ok = not L.desc.in_u8 and L.desc.Cin % 32 == 0 and L.N >= 32  # (incl. the recurrent projections W_ih / W_hh)
             L.wt = self.flat_params_t[o:o + L.K * L.N].view(L.N, L.K) if ok else None
         self.obs_normalizer = None
         if norm_input:
@@ -528,8 +528,12 @@ class ActorCritic:
         st = rnn["states"]
         assert st.shape == (n, S) and st.stride(1) == 1
         gh = self._buf((tag, "gh"), (n, Lh.N))
-        w_hh, b_hh, _ = self._wb(li + 1, tag)
-        lib.conv_fwd_raw(st, st.stride(0), None, 0, w_hh, b_hh, gh, n, Lh.desc)
+        w_hh, b_hh, wt_hh = self._wb(li + 1, tag)
+        if wt_hh is not None and lib.conv_fwd_t_supported(n, Lh.desc):  # LDS-DMA GEMM (2048 envs x 512 x 2048 fills the chip)
+            wsb = lib.conv_fwd_t_workspace(n, Lh.desc)
+            lib.conv_fwd_t(st, st.stride(0), wt_hh, b_hh, gh, n, Lh.desc, self._workspace(wsb) if wsb else None)
+        else:
+            lib.conv_fwd_raw(st, st.stride(0), None, 0, w_hh, b_hh, gh, n, Lh.desc)
         h_out = self._buf((tag, "h_out"), (n, H))
         c_out = self._buf((tag, "c_out"), (n, H)) if kind == 1 else None
         lib.rnn_cell_fwd(kind, gx, gh, st, st.stride(0), st[:, H:] if kind == 1 else None, st.stride(0), None, n, H,
