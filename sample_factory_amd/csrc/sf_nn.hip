@@ -1084,12 +1084,13 @@ static WgradGlds plan_wgrad_glds(int64_t Mtot, int K, int N, bool query_occupanc
 }
 
 // Which reductions go to the LDS-DMA weight-gradient kernel: long ones, and mid-sized ones with a large K x N (the fc
-// layer at n = 32768: 1044 -> 911 us; the 8-column heads stay on the register-staged kernel).  SF_WGRAD_GLDS_MIN
+// layer at n = 32768: 1044 -> 911 us; the LSTM's 512 x 2048 recurrent matrix at 16384 chunk rows; the 8-column heads
+// stay on the register-staged kernel).  SF_WGRAD_GLDS_MIN
 // overrides the row threshold (A/B switch).
 static bool wgrad_glds_wanted(int64_t Mtot, int K, int N) {
     static const int64_t v = getenv("SF_WGRAD_GLDS_MIN") ? atoll(getenv("SF_WGRAD_GLDS_MIN")) : -1;
     if (v >= 0) return Mtot >= v;
-    return Mtot >= 65536 || (Mtot >= 16384 && K >= 1024 && N >= 64);
+    return Mtot >= 65536 || (Mtot >= 16384 && N >= 64 && (K >= 1024 || (int64_t)K * N >= 512 * 1024));
 }
 
 extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc) {
