@@ -1,12 +1,13 @@
-"""Message keys and status codes — sample_factory/algo/utils/misc.py:7-33 (same names, same values)."""
-EPISODIC = "episodic"
-LEARNER_ENV_STEPS = "learner_env_steps"
-TRAIN_STATS = "train"
-STATS_KEY = "stats"
-POLICY_ID_KEY = "policy_id"
-SAMPLES_COLLECTED = "samples_collected"
-TIMING_STATS = "timing"
+"""Message keys and experiment status codes under the reference's module path (sample_factory/algo/utils/misc.py:9-33):
+the key STRINGS and the status VALUES are the plugin API (message handlers, `run_rl`'s return value)."""
+
+# keys of the report dictionaries passed to Runner message handlers
+(EPISODIC, LEARNER_ENV_STEPS, TRAIN_STATS, TIMING_STATS, STATS_KEY, SAMPLES_COLLECTED, POLICY_ID_KEY) = (
+    "episodic", "learner_env_steps", "train", "timing", "stats", "samples_collected", "policy_id")
 
 
 class ExperimentStatus:
-    SUCCESS, FAILURE, INTERRUPTED = range(3)
+    """what Runner.init() / Runner.run() / run_rl() return"""
+    SUCCESS = 0
+    FAILURE = 1
+    INTERRUPTED = 2
