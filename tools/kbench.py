@@ -53,6 +53,9 @@ def main():
             if "dgrad" in which and n == 32768 and not d.in_u8:
                 din = torch.empty((n,d.H,d.W,d.Cin),device="cuda")
                 t = timeit(lambda: lib.conv_dgrad(dy, w, x, din, n, d), reps); res.append(f"dgrad {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+            if "dgrad_noact" in which and n == 32768 and not d.in_u8:  # upper bound of what a mask-free epilogue could win
+                din = torch.empty((n,d.H,d.W,d.Cin),device="cuda")
+                t = timeit(lambda: lib.conv_dgrad(dy, w, None, din, n, d), reps); res.append(f"dgrad(no act read) {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
             print(f"n={n:6d} {name:6s} " + " | ".join(res), flush=True)
 
 if __name__ == "__main__":
