@@ -23,18 +23,21 @@ class _Done:
 
 
 class ReplicaGroup:
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force_collectives: bool = False):
         self.pg = process_group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.active else 1
         self.rank = dist.get_rank(process_group) if self.active else 0
+        # cfg.dp_force_collectives: issue every collective even in a group of ONE rank — the only way to execute the
+        # nccl (= RCCL) branch (dtypes, reduce ops, async bucket slices, stream ordering) on a single-GPU box
+        self.on = self.active and (self.world > 1 or force_collectives)
 
         # gloo (CPU collectives) with device tensors: stage through the host.  Only used to exercise the replica
         # protocol on boxes with fewer GPUs than ranks (tests); production runs use nccl (= RCCL over xGMI).
         self._stage = self.active and dist.get_backend(process_group) == "gloo"
 
     def _collective(self, fn, t: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
+        if self.on:
             if self._stage and t.is_cuda:
                 h = t.detach().cpu()
                 fn(h)
@@ -50,7 +53,7 @@ class ReplicaGroup:
         """Start summing `t` over the replicas and return a handle whose wait() orders the CURRENT stream behind the
         result (nccl/RCCL: the collective runs on the backend's own stream, behind everything already enqueued on the
         current one — the DDP bucket pattern).  Staged gloo runs have nothing to overlap with: reduced on the spot."""
-        if self.world <= 1 or (self._stage and t.is_cuda):
+        if not self.on or (self._stage and t.is_cuda):
             self.all_reduce_sum(t)
             return _Done()
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -67,7 +70,7 @@ class ReplicaGroup:
 
     def loss_sums(self, sums: torch.Tensor) -> torch.Tensor:
         """sums[0..3] additive loss sums, sums[4] = max KL (needs MAX), rest additive."""
-        if self.world > 1:
+        if self.on:
             mx = sums[4:5].clone()
             self.all_reduce_sum(sums)
             self.all_reduce_max(mx)

@@ -156,13 +156,14 @@ class Learner:
         # data-parallel replicas (C1): one rank per GPU; inactive group = single GPU
         self.pg = process_group
         dp_on = process_group is not None or (getattr(cfg, "data_parallel", False) and torch.distributed.is_initialized())
-        self.group = ReplicaGroup(process_group) if dp_on else None
+        self.group = ReplicaGroup(process_group, bool(getattr(cfg, "dp_force_collectives", False))) if dp_on else None
         self.world = self.group.world if self.group is not None else 1
+        self.dp = self.group is not None and self.group.on  # collectives are issued (world > 1, or forced for tests)
         self._grad_norms: List[float] = []
 
     # ------------------------------------------------------------------------------------------ init / checkpoints
     def _all_reduce(self, t: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.dp:
             self.group.all_reduce_sum(t)
 
     def init(self):
@@ -178,13 +179,13 @@ class Learner:
             raise lib.SfHipError("Learner.init(): no GPU visible. sample_factory_amd has no CPU path.")
         lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device())
-        ar = self._all_reduce if self.world > 1 else None
+        ar = self._all_reduce if self.dp else None
         cfg.dp_world = self.world
         # the native model, or a torch fallback around a user-registered module (model/model_factory.py)
         self.actor_critic = create_actor_critic(cfg, self.env_info.obs_space, self.env_info.action_space, self.device,
                                                 all_reduce=ar)
         self.actor_critic.train()
-        if self.world > 1:  # identical initial weights on every replica
+        if self.dp:  # identical initial weights on every replica
             self.group.broadcast(self.actor_critic.flat_params, src=0)
             self.actor_critic.params_changed()
         P = self.actor_critic.num_flat
@@ -198,7 +199,7 @@ class Learner:
         # backward pass.  Every element is still summed exactly once over the same replicas.
         self._dp_split = None
         ac_ = self.actor_critic
-        if self.world > 1 and getattr(cfg, "dp_overlap", True) and hasattr(ac_, "_segs") and ac_.rnn_kind is None:
+        if self.dp and getattr(cfg, "dp_overlap", True) and hasattr(ac_, "_segs") and ac_.rnn_kind is None:
             sizes = [L.K * L.N for L in ac_.layers]
             li = int(np.argmax(sizes))
             if li > 0 and sum(sizes[li:]) * 2 >= sum(sizes):
@@ -421,7 +422,7 @@ class Learner:
         if cfg.normalize_returns and not cfg.with_vtrace:
             ac.returns_normalizer(buff.returns)  # in place: update (all-reduced moments under DP) + normalise
         num_invalids = int(self._num_invalid.item())  # the one host sync per dataset (reference: learner.py:1021)
-        if self.world > 1:
+        if self.dp:
             t = torch.tensor([num_invalids], dtype=torch.int64, device=self.device)
             self._all_reduce(t)
             self._global_invalids = int(t.item())
@@ -523,7 +524,7 @@ class Learner:
                      adv_arr, tgt_arr, buff.valids, index, offset, n, A, self.loss_cfg, self._moments, self._sums,
                      g_heads[:, 1:], g_heads[:, 0], ratio_out=self._ratio)
         self._last_mb = (index, offset, n, values, adv_arr)  # for _record_summaries
-        if self.world > 1 and self._dp_reduce_each_mb:  # only the per-minibatch KL-adaptive LR needs global values NOW
+        if self.dp and self._dp_reduce_each_mb:  # only the per-minibatch KL-adaptive LR needs global values NOW
             self.group.loss_sums(self._sums)
         out = scalars_out if scalars_out is not None else torch.zeros(16, dtype=torch.float32, device=self.device)
         lib.loss_scalars(self._sums, self._moments, self.loss_cfg, out)
@@ -598,7 +599,7 @@ class Learner:
                 self.policy_versions_tensor[self.policy_id] = self.train_step
             # ---- end of epoch: ONE readback (actor losses for early stopping, KLs for the per-epoch scheduler)
             blk = self._scalars[epoch * n_mb:(epoch + 1) * n_mb]
-            if self.world > 1 and not need_kl_each_mb:
+            if self.dp and not need_kl_each_mb:
                 # data-parallel: every replica divided its LOCAL sums by the GLOBAL n, so the loss / KL / entropy means
                 # add up across ranks; one all-reduce per epoch instead of two per SGD step (max KL: MAX)
                 cols = [0, 1, 2, 3, 4, 9]

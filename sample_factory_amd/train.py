@@ -184,7 +184,7 @@ class Runner:
                                       max(1, int(cfg.num_workers) * int(cfg.num_envs_per_worker)))
         if self.rank == 0:
             self._handle_restart()
-        if self.world > 1:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.barrier()  # nobody looks for checkpoints before rank 0 has dealt with the directory
         # Env instances: num_workers * num_envs_per_worker vector envs, as in the reference (rollout_worker.py:96-117,
         # each with its own env_config); here they all live in this process.  The instances of one worker are grouped

@@ -72,3 +72,54 @@ def test_two_replicas_equal_one(tmp_path):
     # up to 3e-3 possible: Adam turns a sum-order sign flip of a near-zero gradient into a full +-lr step.  (The
     # training forward of conv1 runs the strip-image kernel, the rollout the im2col kernel: 1e-6 apart, both exact f32.)
     assert diff.max() < 1e-3 and (diff > 2e-5).mean() < 2e-3, (diff.max(), (diff > 2e-5).mean())
+
+
+def test_rccl_branch_executes_with_one_rank(tmp_path):
+    """The production backend (nccl = RCCL) on the ONE GPU of the test box: a single-rank process group with
+    cfg.dp_force_collectives issues every collective of the data-parallel learner for real — broadcast of the initial
+    weights, the per-minibatch 3-double moment all-reduce, the two-bucket gradient all-reduce (async_op on a slice of
+    the flat gradient while the conv layers are still back-propagated), SUM / MAX of the loss scalars, int64 invalid
+    counts — so dtype / reduce-op / view / stream-ordering mistakes in that branch fail here, not on the 8-GPU node.
+    With one rank every reduction is the identity: the run must equal the run without a process group bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, os, sys, torch
+sys.path.insert(0, %r)
+from sample_factory_amd.cfg.arguments import default_cfg
+from sample_factory_amd.envs.env_utils import register_env
+from sample_factory_amd.envs.synthetic import make_synthetic_env
+from sample_factory_amd.train import make_runner
+force = os.environ.get("FORCE") == "1"
+if force:
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl")
+register_env("synthetic_atari", make_synthetic_env)
+cfg = default_cfg(env="synthetic_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                  encoder_conv_architecture="convnet_atari", rollout=8, batch_size=1024, num_batches_per_epoch=2,
+                  num_epochs=2, num_workers=1, num_envs_per_worker=1, worker_num_splits=1, async_rl=False, seed=1,
+                  serial_mode=True, synthetic_num_agents=256, train_dir=%r, experiment="rccl" + str(int(force)),
+                  data_parallel=force, dp_force_collectives=force, lr_schedule="kl_adaptive_epoch")
+cfg, runner = make_runner(cfg)
+runner.init()
+assert runner.learner.dp == force and (not force or runner.learner._dp_split is not None)
+for _ in range(3):
+    stats = runner.iteration()
+torch.cuda.synchronize()
+p = runner.learner.actor_critic.flat_params
+print("RESULT " + json.dumps(dict(sum=float(p.double().sum()), abs=float(p.double().abs().sum()), loss=stats["train"]["loss"],
+                                  steps=runner.learner.train_step, backend=torch.distributed.get_backend() if force else None)))
+if force:
+    torch.distributed.destroy_process_group()
+''' % (root, str(tmp_path))
+    out = {}
+    for force in ("0", "1"):
+        env = {k: v for k, v in os.environ.items() if k not in ("SF_DP_BACKEND",)}
+        env.update(FORCE=force, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2500:]
+        out[force] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["1"]["backend"] == "nccl" and out["1"]["steps"] == out["0"]["steps"] == 12
+    assert out["1"]["sum"] == out["0"]["sum"] and out["1"]["abs"] == out["0"]["abs"] and out["1"]["loss"] == out["0"]["loss"]
