@@ -74,6 +74,12 @@ def test_two_replicas_equal_one(tmp_path):
     assert diff.max() < 1e-3 and (diff > 2e-5).mean() < 2e-3, (diff.max(), (diff > 2e-5).mean())
 
 
+def _free_port():
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
 def test_rccl_branch_executes_with_one_rank(tmp_path):
     """The production backend (nccl = RCCL) on the ONE GPU of the test box: a single-rank process group with
     cfg.dp_force_collectives issues every collective of the data-parallel learner for real — broadcast of the initial
