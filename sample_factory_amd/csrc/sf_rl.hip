@@ -332,6 +332,24 @@ __device__ __forceinline__ float tuple_logp(const float *__restrict__ z, const f
     return lp;
 }
 
+// phase 1 (parallel over samples): clamped importance ratio pi/pi_old of every step -> ratio_out[k]
+template <int MAXA>
+__global__ __launch_bounds__(256) void k_vtrace_ratio(const float *__restrict__ params, int ldp,
+                                                      const float *__restrict__ actions,
+                                                      const float *__restrict__ old_logp,
+                                                      const int32_t *__restrict__ index, int64_t offset, int64_t n, int A,
+                                                      int action_kind, float *__restrict__ ratio_out, HeadsDev hd) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int nact = hd.num_heads > 1 ? hd.num_heads : (action_kind == 0 ? 1 : A / 2);
+    const int64_t d = index ? (int64_t)index[k] : offset + k;
+    const float lp = hd.num_heads > 1 ? tuple_logp(params + k * ldp, actions + d * nact, hd)
+                                      : action_logp<MAXA>(params + k * ldp, A, action_kind, actions + d * nact);
+    ratio_out[k] = clampf(expf(lp - old_logp[d]), 0.05f, 20.0f);  // learner.py:591-594
+}
+
+// phase 2 (one lane per trajectory): the reverse recursion of learner.py:618-635; vs[k] holds the ratio of step k on
+// entry (read before it is overwritten with the result)
 template <int MAXA>
 __global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params, int ldp,
                                                const float *__restrict__ values, int ldv,
@@ -342,7 +360,6 @@ __global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params,
                                                float *__restrict__ vs, float *__restrict__ adv, HeadsDev hd) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ntraj) return;
-    const int nact = hd.num_heads > 1 ? hd.num_heads : (action_kind == 0 ? 1 : A / 2);
     const int64_t base = j * rec;
     const int64_t last = base + rec - 1;
     const int64_t dl = index ? (int64_t)index[last] : offset + last;
@@ -351,9 +368,7 @@ __global__ __launch_bounds__(64) void k_vtrace(const float *__restrict__ params,
     for (int i = rec - 1; i >= 0; --i) {
         const int64_t k = base + i;
         const int64_t d = index ? (int64_t)index[k] : offset + k;
-        const float lp = hd.num_heads > 1 ? tuple_logp(params + k * ldp, actions + d * nact, hd)
-                                          : action_logp<MAXA>(params + k * ldp, A, action_kind, actions + d * nact);
-        const float ratio = clampf(expf(lp - old_logp[d]), 0.05f, 20.0f);  // learner.py:591-594
+        const float ratio = vs[k];  // written by k_vtrace_ratio
         const float rho = fminf(rho_hat, ratio), c = fminf(c_hat, ratio);
         const float not_done = 1.0f - (dones[d] ? 1.0f : 0.0f);
         const float ndg = not_done * gamma;
@@ -387,14 +402,16 @@ extern "C" int sf_vtrace(const float *params, int ld_params, const float *values
                "sf_vtrace: unsupported action params A=%d kind=%d", A, action_kind);
     const int64_t ntraj = n / recurrence;
     if (ntraj == 0) return SF_OK;
-    const dim3 grid((unsigned)((ntraj + 63) / 64)), block(64);
+    const dim3 grid((unsigned)((ntraj + 63) / 64)), block(64), rgrid((unsigned)((n + 255) / 256));
 #define VT_LAUNCH(M)                                                                                             \
+    k_vtrace_ratio<M><<<rgrid, dim3(256), 0, STREAM(stream)>>>(params, ld_params, actions, old_logp, index, offset, n, A,   \
+                                                               action_kind, vs, hd);                              \
     k_vtrace<M><<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, rewards, dones, index,    \
                                                     offset, ntraj, A, action_kind, recurrence, gamma, rho_hat,   \
                                                     c_hat, vs, adv, hd)
-    if (A <= 8) VT_LAUNCH(8);
-    else if (A <= 32) VT_LAUNCH(32);
-    else VT_LAUNCH(128);
+    if (A <= 8) { VT_LAUNCH(8); }
+    else if (A <= 32) { VT_LAUNCH(32); }
+    else { VT_LAUNCH(128); }
 #undef VT_LAUNCH
     return sf_launch_status("sf_vtrace");
 }
@@ -1644,6 +1661,78 @@ extern "C" int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const
     if (in_u8) k_obsnorm_apply<true><<<dim3(grid), dim3(256), 0, STREAM(stream)>>>(in, stride, index, offset, traj_T, n, D, C, HW, sub_mean, inv_scale, mu, rstd, out);
     else k_obsnorm_apply<false><<<dim3(grid), dim3(256), 0, STREAM(stream)>>>(in, stride, index, offset, traj_T, n, D, C, HW, sub_mean, inv_scale, mu, rstd, out);
     return sf_launch_status("sf_obsnorm_apply");
+}
+
+// =========================================================================================== fused small MLP encoder
+// Inference on VECTOR observations (model/encoder.py:72-87 MlpEncoder behind utils/normalize.py:24-70): input
+// normalisation -> Linear(D, H1) + act -> Linear(H1, H2) + act in ONE launch.  At rollout sizes (2048 envs x 27 floats)
+// each of these layers is a 13 us MFMA-kernel launch doing 7 MFLOP; here a 256-thread block takes 32 samples, keeps both
+// weight matrices in LDS and each thread produces 8 columns of one row with an fmaf chain in ascending k — the same
+// arithmetic (bit for bit) as the exact-f32 MFMA kernels, which the training pass keeps using (it needs the
+// intermediate activations).
+__device__ __forceinline__ float mlp_act(float x, int kind) {
+    if (kind == 1) return fmaxf(x, 0.f);
+    if (kind == 2) return tanhf(x);
+    if (kind == 3) return x > 0.f ? x : expm1f(x);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, int64_t x_stride, int64_t n, int D,
+                                                  float sub_mean, float inv_scale, const float *__restrict__ mu,
+                                                  const float *__restrict__ rstd, const float *__restrict__ w1,
+                                                  const float *__restrict__ b1, int H1, const float *__restrict__ w2,
+                                                  const float *__restrict__ b2, int H2, int act,
+                                                  float *__restrict__ out) {
+    extern __shared__ float sm[];
+    float *sw1 = sm, *sw2 = sw1 + D * H1, *sx = sw2 + H1 * H2, *sh = sx + 32 * D;  // sh: [32][H1]
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    for (int i = tid; i < D * H1; i += 256) sw1[i] = w1[i];
+    for (int i = tid; i < H1 * H2; i += 256) sw2[i] = w2[i];
+    for (int i = tid; i < 32 * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        const int64_t row = r0 + r < n ? r0 + r : n - 1;
+        float v = (x[row * x_stride + d] - sub_mean) * inv_scale;
+        if (mu) v = fminf(fmaxf((v - mu[d]) * rstd[d], -5.0f), 5.0f);
+        sx[i] = v;
+    }
+    __syncthreads();
+    const int r = tid >> 3, cg = tid & 7;
+    for (int c0 = cg * 8; c0 < H1; c0 += 64) {  // 8 consecutive columns per pass
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < D; ++k) {
+            const float a = sx[r * D + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(a, sw1[k * H1 + c0 + j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[r * H1 + c0 + j] = mlp_act(acc[j] + b1[c0 + j], act);
+    }
+    __syncthreads();
+    if (r0 + r >= n) return;
+    for (int c0 = cg * 8; c0 < H2; c0 += 64) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < H1; ++k) {
+            const float a = sh[r * H1 + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(a, sw2[k * H2 + c0 + j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[(r0 + r) * H2 + c0 + j] = mlp_act(acc[j] + b2[c0 + j], act);
+    }
+}
+
+extern "C" int sf_mlp2_fwd(const float *x, int64_t x_stride, int64_t n, int D, float sub_mean, float inv_scale,
+                           const float *mu, const float *rstd, const float *w1, const float *b1, int H1, const float *w2,
+                           const float *b2, int H2, int act, float *out, void *stream) {
+    SF_REQUIRE(x && w1 && b1 && w2 && b2 && out && n > 0 && D > 0, "sf_mlp2_fwd: bad args");
+    SF_REQUIRE(H1 > 0 && H2 > 0 && H1 % 8 == 0 && H2 % 8 == 0 && (mu == nullptr) == (rstd == nullptr),
+               "sf_mlp2_fwd: layer widths must be multiples of 8 (H1=%d H2=%d)", H1, H2);
+    const size_t lds = sizeof(float) * ((size_t)D * H1 + (size_t)H1 * H2 + 32 * (size_t)(D + H1));
+    SF_REQUIRE(lds <= 64 * 1024, "sf_mlp2_fwd: %zu bytes of LDS needed (D=%d H1=%d H2=%d): use the layer kernels", lds, D, H1, H2);
+    k_mlp2_fwd<<<dim3((unsigned)((n + 31) / 32)), dim3(256), lds, STREAM(stream)>>>(x, x_stride, n, D, sub_mean, inv_scale, mu,
+                                                                                   rstd, w1, b1, H1, w2, b2, H2, act, out);
+    return sf_launch_status("sf_mlp2_fwd");
 }
 
 // =========================================================================================== recurrent core cells

@@ -38,7 +38,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_rnn_store_state", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
@@ -249,6 +249,17 @@ def rnn_cell_bwd(kind, dh, dc_in, gates, h_prev, ld_h, c_prev, ld_c, c_out, Cn, 
                                   _rp(h_prev, "h_prev"), i64(ld_h), _rp(c_prev, "c_prev"), i64(ld_c),
                                   ptr(c_out, "f32"), int(Cn), int(H), ptr(dgx, "f32", "dgx"), ptr(dgh, "f32"),
                                   ptr(dh_direct, "f32"), ptr(dc_prev, "f32"), stream()), "sf_rnn_cell_bwd")
+
+
+def mlp2_supported(D, H1, H2) -> bool:
+    return H1 % 8 == 0 and H2 % 8 == 0 and (D * H1 + H1 * H2 + 32 * (D + H1)) * 4 <= 64 * 1024
+
+
+def mlp2_fwd(x, x_stride, n, D, sub_mean, inv_scale, mu, rstd, w1, b1, w2, b2, act, out) -> None:
+    _check(load().sf_mlp2_fwd(_raw(x, "f32", "x"), i64(x_stride), i64(n), int(D), f(sub_mean), f(inv_scale),
+                              ptr(mu, "f32", "mu"), ptr(rstd, "f32", "rstd"), ptr(w1, "f32", "w1"), ptr(b1, "f32", "b1"),
+                              int(w1.shape[1]), ptr(w2, "f32", "w2"), ptr(b2, "f32", "b2"), int(w2.shape[1]), int(act),
+                              ptr(out, "f32", "out"), stream()), "sf_mlp2_fwd")
 
 
 def rnn_store_state(h, c, dones_col, out) -> None:

@@ -33,6 +33,7 @@ from sample_factory_amd.envs.spaces import is_box, calc_num_action_parameters, i
 import os
 
 _LSTM_SEQ = os.environ.get("SF_LSTM_SEQ", "1") != "0"  # A/B switch: 0 = per-step launches instead of the fused passes
+_MLP2 = os.environ.get("SF_MLP2", "1") != "0"          # A/B switch: 0 = layer-by-layer encoder in the rollout as well
 
 ACT_KIND = {"relu": 1, "tanh": 2, "elu": 3}  # model/model_utils.py:27-35; fused into the GEMM epilogues
 
@@ -209,6 +210,11 @@ class ActorCritic:
             L.in_act_kind = prev_kind
             prev_kind = 0 if L.role == "rnn_ih" else L.desc.relu
         self.obs_elems = int(np.prod(self.obs_shape))
+        # vector observations through a two-layer MLP encoder: the rollout can take the fused inference kernel
+        self._mlp2_ok = (len(self.obs_shape) == 1 and len(self.layers) >= 3 and
+                         all(L.kind == "linear" and L.role == "chain" and L.desc.relu == act for L in self.layers[:2]) and
+                         len(cfg.encoder_mlp_layers) == 2 and
+                         lib.mlp2_supported(self.obs_shape[0], self.layers[0].N, self.layers[1].N))
 
         # ---- flat parameter / gradient / Adam buffers
         off = 0
@@ -492,7 +498,23 @@ class ActorCritic:
         inputs: List[Optional[torch.Tensor]] = [None] * len(self.layers)
         self._tls.role = "rollout" + tag[3:] if tag.startswith("inf") else "learner"  # "inf", "inf1", ...: env groups
         x, stride, idx, off, tT = obs, sample_stride, index, offset, traj_T
-        if self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
+        first_layer = 0
+        if self._mlp2_ok and tag.startswith("inf") and index is None and not traj_T and _MLP2:
+            # rollout on vector observations: normalisation + the two encoder layers in ONE launch (sf_mlp2_fwd); the
+            # learner keeps the layer kernels (it needs the intermediate activations for the backward pass)
+            on = self.obs_normalizer
+            tabs = None
+            if on is not None:
+                tabs = self._snap_tabs[self.snap_read] if self._snap is not None else (on.mu_tab, on.rstd_tab)
+            (w1, b1, _), (w2, b2, _) = self._wb(0, tag), self._wb(1, tag)
+            out = self._buf((tag, 1), (n, self.layers[1].N))
+            lib.mlp2_fwd(obs, sample_stride, n, self.obs_elems, on.sub_mean if on is not None else 0.0,
+                         on.inv_scale if on is not None else 1.0, tabs[0] if tabs else None, tabs[1] if tabs else None,
+                         w1, b1, w2, b2, self.act_kind, out)
+            acts[1] = out
+            x, stride, idx, off, tT = out, self.layers[1].N, None, 0, 0
+            first_layer = 2
+        elif self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
             xn = self._buf((tag, "obsn"), (n, self.obs_elems))
             tabs = self._snap_tabs[self.snap_read] if (tag.startswith("inf") and self._snap is not None) else None
             self.obs_normalizer.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T, tabs=tabs)
@@ -500,7 +522,7 @@ class ActorCritic:
         first_in = (x, stride, idx, off, tT)
         seq = rnn is not None and "R" in rnn
         for li, L in enumerate(self.layers):
-            if L.role == "rnn_hh":
+            if L.role == "rnn_hh" or li < first_layer:
                 continue
             if L.role == "rnn_ih" and seq:  # BPTT pass: the recurrent block works time-major ([R, C, .])
                 R, Cn = rnn["R"], n // rnn["R"]

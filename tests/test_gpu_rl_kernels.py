@@ -705,3 +705,29 @@ def test_rnn_store_state_masks_and_packs(lib):
     assert torch.equal(slab[:, 3], want) and (slab[:, :3] == 9.0).all()
     lib.rnn_store_state(h, None, dones[:, 0], slab[:, 1, :H])
     assert torch.equal(slab[:, 1, :H], h * (~dones[:, 0]).float()[:, None]) and (slab[:, 1, H:] == 9.0).all()
+
+
+@pytest.mark.parametrize("n,D,H1,H2,act,norm", [(2048, 27, 64, 64, 2, True), (77, 8, 32, 32, 1, False), (300, 27, 64, 64, 3, True)])
+def test_fused_mlp_encoder_inference_kernel(lib, n, D, H1, H2, act, norm):
+    """sf_mlp2_fwd (normalisation + two encoder layers in one launch, rollout on vector observations) against the layer
+    kernels it replaces (sf_obsnorm_apply-style normalisation in torch + sf_linear_fwd twice) and float64"""
+    g = torch.Generator().manual_seed(n)
+    slab = torch.randn((n, 3, D), generator=g).cuda() * 3.0          # strided rows as in slab obs[:, t]
+    x = slab[:, 1]
+    w1, b1 = (torch.randn((D, H1), generator=g) / np.sqrt(D)).cuda(), (torch.randn(H1, generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn((H1, H2), generator=g) / np.sqrt(H1)).cuda(), (torch.randn(H2, generator=g) * 0.1).cuda()
+    mu = (torch.randn(D, generator=g) * 0.5).cuda() if norm else None
+    rstd = (torch.rand(D, generator=g) + 0.5).cuda() if norm else None
+    out = torch.full((n, H2), 7.0, device="cuda")
+    assert lib.mlp2_supported(D, H1, H2) and not lib.mlp2_supported(64, 512, 512)
+    lib.mlp2_fwd(x, x.stride(0), n, D, 0.0, 1.0, mu, rstd, w1, b1, w2, b2, act, out)
+    xn = x.contiguous()
+    if norm:
+        xn = ((xn - mu) * rstd).clamp(-5.0, 5.0)
+    h1, h2 = torch.empty((n, H1), device="cuda"), torch.empty((n, H2), device="cuda")
+    lib.linear_fwd(xn.contiguous(), w1, b1, h1, n, D, H1, act)
+    lib.linear_fwd(h1, w2, b2, h2, n, H1, H2, act)
+    fn = {1: torch.relu, 2: torch.tanh, 3: torch.nn.functional.elu}[act]
+    ref = fn(fn(xn.double() @ w1.double() + b1.double()) @ w2.double() + b2.double())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=3e-6, rtol=2e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), h2.cpu().numpy(), atol=1e-6, rtol=1e-6)
