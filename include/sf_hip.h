@@ -298,7 +298,7 @@ int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float 
  * (MlpEncoder with two layers).  x: f32 rows of D values, x_stride floats apart (e.g. slab obs[:, t]); w1 [D, H1], w2
  * [H1, H2] K-major; mu / rstd: [D] tables of the observation normaliser or both NULL; act: 0 none, 1 relu, 2 tanh, 3 elu;
  * out [n, H2].  Same arithmetic (fmaf chain, ascending k) as sf_conv_fwd on the two layers; needs H1, H2 % 8 == 0 and
- * (D*H1 + H1*H2 + 32*(D+H1)) * 4 <= 64 KiB, else returns an error (use the layer kernels). */
+ * (D*H1 + H1*H2 + 64*(D+H1)) * 4 <= 64 KiB, else returns an error (use the layer kernels). */
 int sf_mlp2_fwd(const float *x, int64_t x_stride, int64_t n, int D, float sub_mean, float inv_scale, const float *mu,
                 const float *rstd, const float *w1, const float *b1, int H1, const float *w2, const float *b2, int H2,
                 int act, float *out, void *stream);

@@ -1666,8 +1666,8 @@ extern "C" int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const
 // =========================================================================================== fused small MLP encoder
 // Inference on VECTOR observations (model/encoder.py:72-87 MlpEncoder behind utils/normalize.py:24-70): input
 // normalisation -> Linear(D, H1) + act -> Linear(H1, H2) + act in ONE launch.  At rollout sizes (2048 envs x 27 floats)
-// each of these layers is a 13 us MFMA-kernel launch doing 7 MFLOP; here a 256-thread block takes 32 samples, keeps both
-// weight matrices in LDS and each thread produces 8 columns of one row with an fmaf chain in ascending k — the same
+// each of these layers is a 13 us MFMA-kernel launch doing 7 MFLOP; here a 256-thread block takes 64 samples, keeps both
+// weight matrices in LDS and each thread produces 8 columns of two rows with fmaf chains in ascending k — the same
 // arithmetic (bit for bit) as the exact-f32 MFMA kernels, which the training pass keeps using (it needs the
 // intermediate activations).
 __device__ __forceinline__ float mlp_act(float x, int kind) {
@@ -1677,19 +1677,21 @@ __device__ __forceinline__ float mlp_act(float x, int kind) {
     return x;
 }
 
+constexpr int MLP2_ROWS = 64;  // samples per block; a thread owns 2 rows x 8 columns (weights read once per 16 fmaf)
+
 __global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, int64_t x_stride, int64_t n, int D,
                                                   float sub_mean, float inv_scale, const float *__restrict__ mu,
                                                   const float *__restrict__ rstd, const float *__restrict__ w1,
                                                   const float *__restrict__ b1, int H1, const float *__restrict__ w2,
                                                   const float *__restrict__ b2, int H2, int act,
                                                   float *__restrict__ out) {
-    extern __shared__ float sm[];
-    float *sw1 = sm, *sw2 = sw1 + D * H1, *sx = sw2 + H1 * H2, *sh = sx + 32 * D;  // sh: [32][H1]
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *sw1 = sm, *sw2 = sw1 + D * H1, *sx = sw2 + H1 * H2, *sh = sx + MLP2_ROWS * D;  // sh: [ROWS][H1]
     const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int64_t r0 = (int64_t)blockIdx.x * MLP2_ROWS;
     for (int i = tid; i < D * H1; i += 256) sw1[i] = w1[i];
     for (int i = tid; i < H1 * H2; i += 256) sw2[i] = w2[i];
-    for (int i = tid; i < 32 * D; i += 256) {
+    for (int i = tid; i < MLP2_ROWS * D; i += 256) {
         const int r = i / D, d = i - r * D;
         const int64_t row = r0 + r < n ? r0 + r : n - 1;
         float v = (x[row * x_stride + d] - sub_mean) * inv_scale;
@@ -1697,29 +1699,33 @@ __global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, i
         sx[i] = v;
     }
     __syncthreads();
-    const int r = tid >> 3, cg = tid & 7;
-    for (int c0 = cg * 8; c0 < H1; c0 += 64) {  // 8 consecutive columns per pass
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < D; ++k) {
-            const float a = sx[r * D + k];
+    const int ra = (tid >> 3) * 2, rb = ra + 1, cg = tid & 7;
+    auto layer = [&](const float *in, int K, const float *w, const float *bias, int N, float *dst, int64_t dst_ld,
+                     bool to_global) {
+        for (int c0 = cg * 8; c0 < N; c0 += 64) {  // 8 consecutive columns per pass
+            float accA[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, accB[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < K; ++k) {
+                const float a = in[ra * K + k], b = in[rb * K + k];
+                const float4 w0 = *reinterpret_cast<const float4 *>(w + k * N + c0);
+                const float4 w1v = *reinterpret_cast<const float4 *>(w + k * N + c0 + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1v.x, w1v.y, w1v.z, w1v.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(a, sw1[k * H1 + c0 + j], acc[j]);
+                for (int j = 0; j < 8; ++j) {
+                    accA[j] = fmaf(a, wv[j], accA[j]);
+                    accB[j] = fmaf(b, wv[j], accB[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float bj = bias[c0 + j];
+                if (!to_global || r0 + ra < n) dst[(to_global ? r0 + ra : ra) * dst_ld + c0 + j] = mlp_act(accA[j] + bj, act);
+                if (!to_global || r0 + rb < n) dst[(to_global ? r0 + rb : rb) * dst_ld + c0 + j] = mlp_act(accB[j] + bj, act);
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sh[r * H1 + c0 + j] = mlp_act(acc[j] + b1[c0 + j], act);
-    }
+    };
+    layer(sx, D, sw1, b1, H1, sh, H1, false);
     __syncthreads();
-    if (r0 + r >= n) return;
-    for (int c0 = cg * 8; c0 < H2; c0 += 64) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < H1; ++k) {
-            const float a = sh[r * H1 + k];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(a, sw2[k * H2 + c0 + j], acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[(r0 + r) * H2 + c0 + j] = mlp_act(acc[j] + b2[c0 + j], act);
-    }
+    layer(sh, H1, sw2, b2, H2, out, H2, true);
 }
 
 extern "C" int sf_mlp2_fwd(const float *x, int64_t x_stride, int64_t n, int D, float sub_mean, float inv_scale,
@@ -1728,9 +1734,9 @@ extern "C" int sf_mlp2_fwd(const float *x, int64_t x_stride, int64_t n, int D, f
     SF_REQUIRE(x && w1 && b1 && w2 && b2 && out && n > 0 && D > 0, "sf_mlp2_fwd: bad args");
     SF_REQUIRE(H1 > 0 && H2 > 0 && H1 % 8 == 0 && H2 % 8 == 0 && (mu == nullptr) == (rstd == nullptr),
                "sf_mlp2_fwd: layer widths must be multiples of 8 (H1=%d H2=%d)", H1, H2);
-    const size_t lds = sizeof(float) * ((size_t)D * H1 + (size_t)H1 * H2 + 32 * (size_t)(D + H1));
+    const size_t lds = sizeof(float) * ((size_t)D * H1 + (size_t)H1 * H2 + MLP2_ROWS * (size_t)(D + H1));
     SF_REQUIRE(lds <= 64 * 1024, "sf_mlp2_fwd: %zu bytes of LDS needed (D=%d H1=%d H2=%d): use the layer kernels", lds, D, H1, H2);
-    k_mlp2_fwd<<<dim3((unsigned)((n + 31) / 32)), dim3(256), lds, STREAM(stream)>>>(x, x_stride, n, D, sub_mean, inv_scale, mu,
+    k_mlp2_fwd<<<dim3((unsigned)((n + MLP2_ROWS - 1) / MLP2_ROWS)), dim3(256), lds, STREAM(stream)>>>(x, x_stride, n, D, sub_mean, inv_scale, mu,
                                                                                    rstd, w1, b1, H1, w2, b2, H2, act, out);
     return sf_launch_status("sf_mlp2_fwd");
 }

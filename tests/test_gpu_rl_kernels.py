@@ -724,9 +724,10 @@ def test_fused_mlp_encoder_inference_kernel(lib, n, D, H1, H2, act, norm):
     xn = x.contiguous()
     if norm:
         xn = ((xn - mu) * rstd).clamp(-5.0, 5.0)
+    from sample_factory_amd.model.actor_critic import _linear_desc
     h1, h2 = torch.empty((n, H1), device="cuda"), torch.empty((n, H2), device="cuda")
-    lib.linear_fwd(xn.contiguous(), w1, b1, h1, n, D, H1, act)
-    lib.linear_fwd(h1, w2, b2, h2, n, H1, H2, act)
+    lib.conv_fwd_raw(xn.contiguous(), D, None, 0, w1, b1, h1, n, _linear_desc(D, H1, act))   # the layer kernels (any act)
+    lib.conv_fwd_raw(h1, H1, None, 0, w2, b2, h2, n, _linear_desc(H1, H2, act))
     fn = {1: torch.relu, 2: torch.tanh, 3: torch.nn.functional.elu}[act]
     ref = fn(fn(xn.double() @ w1.double() + b1.double()) @ w2.double() + b2.double())
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=3e-6, rtol=2e-5)
