@@ -1704,7 +1704,8 @@ __global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, i
                      bool to_global) {
         for (int c0 = cg * 8; c0 < N; c0 += 64) {  // 8 consecutive columns per pass
             float accA[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, accB[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < K; ++k) {
+#pragma unroll 4
+            for (int k = 0; k < K; ++k) {  // (unrolled: the LDS reads of 4 k-steps are in flight together)
                 const float a = in[ra * K + k], b = in[rb * K + k];
                 const float4 w0 = *reinterpret_cast<const float4 *>(w + k * N + c0);
                 const float4 w1v = *reinterpret_cast<const float4 *>(w + k * N + c0 + 4);
