@@ -252,7 +252,8 @@ def rnn_cell_bwd(kind, dh, dc_in, gates, h_prev, ld_h, c_prev, ld_c, c_out, Cn, 
 
 
 def mlp2_supported(D, H1, H2) -> bool:
-    return H1 % 8 == 0 and H2 % 8 == 0 and (D * H1 + H1 * H2 + 64 * (D + H1)) * 4 <= 64 * 1024
+    return (H1 % 8 == 0 and H2 % 8 == 0 and (D * H1 + H1 * H2 + 64 * (D + H1)) * 4 <= 64 * 1024 and D <= 64 and
+            D * H1 <= 8192 and H1 * H2 <= 8192)
 
 
 def mlp2_fwd(x, x_stride, n, D, sub_mean, inv_scale, mu, rstd, w1, b1, w2, b2, act, out) -> None:
