@@ -16,7 +16,7 @@ def load(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].replace("void ", "").split("(")[0]
+        name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         b[name] += float(r["Counter_Value"]) * 1024.0
         t[name] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         n[name] += 1

@@ -18,7 +18,7 @@ import json
 import sys
 
 XCDS, CUS, SIMDS = 8, 256, 4
-KEEP = ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_dgrad_")
+KEEP = ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_dgrad_", "k_lstm_seq")
 
 
 def main(src, dst):
@@ -27,7 +27,7 @@ def main(src, dst):
     wall_ns = collections.defaultdict(float)
     seen = set()
     for r in csv.DictReader(open(src)):
-        name = r["Kernel_Name"].replace("void ", "").split("(")[0]
+        name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
