@@ -110,18 +110,18 @@ def workload_cfg(args, rank, world):
         return cfg, "synthetic_atari", make_synthetic_env, desc, "env-steps/sec (whole node), 4096 envs, 84x84x4 obs"
     if args.workload == "c5":  # sf_examples/mujoco/mujoco_params.py:1-38 + LSTM core + V-trace
         cfg = default_cfg(
-            env="synthetic_ant", use_rnn=True, rnn_type="lstm", rnn_size=512, recurrence=T, encoder_mlp_layers=[64, 64],
+            env="synthetic_ant", use_rnn=True, rnn_type=args.rnn_type, rnn_size=512, recurrence=T, encoder_mlp_layers=[64, 64],
             nonlinearity="tanh", normalize_input=True, normalize_returns=False, with_vtrace=True, kl_loss_coeff=0.1,
             adaptive_stddev=False, policy_initialization="torch_default", value_bootstrap=True, max_grad_norm=3.5,
             ppo_clip_ratio=0.2, value_loss_coeff=1.3, exploration_loss_coeff=0.0, learning_rate=0.00295, gamma=0.99,
             gae_lambda=0.95, **common)
         cfg.seed = rank  # torch-generator env: a different stream per replica
         desc = (f"BASELINE.json configs[4]: Ant-shaped synthetic continuous env {B} envs/GPU (obs f32[27], Box(8)), "
-                f"MLP[64,64] tanh + LSTM-512 core + learned stddev, V-trace + KL loss + value bootstrap, APPO {mode}, "
+                f"MLP[64,64] tanh + {args.rnn_type.upper()}-512 core + learned stddev, V-trace + KL loss + value bootstrap, APPO {mode}, "
                 f"rollout=recurrence={T}, batch_size={cfg.batch_size} x {args.num_batches} minibatches x "
                 f"{args.num_epochs} epoch(s)")
         return cfg, "synthetic_ant", make_synthetic_continuous_env, desc, \
-            "env-steps/sec (whole node), 2048 envs, obs f32[27], Box(8), LSTM-512 + V-trace"
+            f"env-steps/sec (whole node), 2048 envs, obs f32[27], Box(8), {args.rnn_type.upper()}-512 + V-trace"
     if args.workload == "c3":  # sf_examples/envpool/atari/envpool_atari_params.py:26-45 on a HOST vector env
         from sample_factory_amd.envs.synthetic import make_host_frame_env
         cfg = default_cfg(
@@ -143,6 +143,8 @@ def workload_cfg(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c3"])
+    ap.add_argument("--rnn_type", default="lstm", choices=["lstm", "gru"],
+                    help="c5: core type (BASELINE configs[4] names LSTM; gru = the reference's default core at the same width)")
     ap.add_argument("--host_env_sim_ms", type=float, default=0.0, help="c3: simulated emulator time per env step")
     ap.add_argument("--check_launch", action="store_true",
                     help="stop after the replica-group self-check (launcher / env plumbing test; needs no GPU with "

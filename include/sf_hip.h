@@ -327,6 +327,17 @@ int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const f
 int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout, const float *keep,
                     const float *whh, float *dgx, uint32_t *sync, int R, int Cn, int H, void *stream);
 
+/* the same two passes for a GRU-512 core (the reference's DEFAULT: cfg rnn_type=gru, rnn_size=512; model/core.py:19-64).
+ * gx [R][Cn][3H], whh [H][3H], bhh [3H] (torch gate order r,z,n); gates [R][Cn][4H] = {r, z, n, hn} with
+ * hn = h W_hn^T + b_hn (the recurrent part of the candidate gate, needed by the backward pass); hprev / hout as above.
+ * Backward: hprev = the forward pass's buffer; writes dgx [R][Cn][3H] = {dr, dz, dn} (gradient of gx: W_ih, encoder)
+ * and dgh [R][Cn][3H] = {dr, dz, dn * r} (gradient of h W_hh^T + b_hh: W_hh / b_hh, and the hand-off payload of the
+ * pass); the direct path dL/dh_prev += dh * z and the carry stay in registers.  Supported shapes: sf_lstm_seq_supported. */
+int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates, float *hprev,
+                   float *hout, uint32_t *sync, int R, int Cn, int H, void *stream);
+int sf_gru_seq_bwd(const float *dout, const float *gates, const float *hprev, const float *keep, const float *whh,
+                   float *dgx, float *dgh, uint32_t *sync, int R, int Cn, int H, void *stream);
+
 /* action means squashed to [-scale, scale] (continuous_tanh_scale > 0, model/action_parameterization.py:62-66), in
  * place on columns [col0, col0+ncols) of a row-major [n, ld] matrix: y = tanh(x/scale)*scale; backward: g *= 1-(y/scale)^2
  * with y the squashed output. */

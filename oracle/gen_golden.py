@@ -491,11 +491,13 @@ C5_ALGO_ARGS = ["--recurrence=32", "--with_vtrace=True", "--normalize_returns=Fa
                 "--exploration_loss_coeff=0.0", "--learning_rate=0.00295", "--gamma=0.99"]
 
 
-def gen_train_c5():
-    """BASELINE configs[4] as ONE Learner.train replay: Ant-shaped obs f32[27], Box(8) with the learned stddev,
+def gen_train_c5(rnn_type="lstm"):
+    """rnn_type="gru": the same replay with the reference's DEFAULT core type (cfg.py rnn_type=gru) at the same width.
+    BASELINE configs[4] as ONE Learner.train replay: Ant-shaped obs f32[27], Box(8) with the learned stddev,
     MLP[64,64] tanh encoder, LSTM-512 core (packed-sequence BPTT in the reference, rnn_utils.py:114-158), V-trace
     (learner.py:601-640) + KL loss + value bootstrap on time-outs, input normalisation, invalid rows."""
-    gen_train("c5", C5_OBS, C5_MODEL_ARGS, E=32, T=32, A=None, nb=2, epochs=1, subsample=37, use_rnn=True, box_dims=8,
+    model_args = [a.replace("--rnn_type=lstm", f"--rnn_type={rnn_type}") for a in C5_MODEL_ARGS]
+    gen_train("c5" if rnn_type == "lstm" else f"c5_{rnn_type}", C5_OBS, model_args, E=32, T=32, A=None, nb=2, epochs=1, subsample=37, use_rnn=True, box_dims=8,
               p_other_policy=0.04, extra=C5_ALGO_ARGS, fill_extra=dict(p_timeout=0.3), fp64_first_step=True)
 
 
@@ -678,6 +680,8 @@ def main():
         gen_train_cnn84()
     if "c5" in which:
         gen_train_c5()
+    if "c5_gru" in which:
+        gen_train_c5("gru")
     if "train" in which:
         gen_train("mlp", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2)
         gen_train("mlp_inv", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=4, epochs=1, extra=["--kl_loss_coeff=0.1"])

@@ -399,6 +399,322 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     }
 }
 
+
+// ================================================================================================ GRU (torch gate order r, z, n)
+// The reference's DEFAULT core (cfg rnn_type = gru, rnn_size = 512).  Same decomposition and hand-off protocol as the
+// LSTM passes; a work-group's 16 hidden units are 48 gate columns (r, z, n), the candidate gate needs the recurrent part
+// hn = h W_hn + b_hn separately (n = tanh(x_n + r * hn)), so the MFMA result is NOT pre-added to gx, and the backward
+// pass has two gate-gradient arrays: dgx (for W_ih and the encoder) and dgh = {dr, dz, dn * r} (for W_hh; it is the
+// hand-off payload), plus the direct path dL/dh_prev += dh * z.
+struct GruSeqFwd {
+    const float *gx, *whh, *bhh, *keep;
+    float *gates, *hprev, *hout;
+    unsigned *sync;
+    int R, Cn, ngroups, rows_per_group;
+};
+
+template <int JB, int NSUB>
+__global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
+    constexpr int H = 8192 / JB, G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
+    constexpr int KU = 8, NKB = H / 16 / KU;
+    constexpr int STG = 16 * JB;
+    static_assert(NKB * KU * 16 == H && NU >= 1, "shape");
+    __shared__ __attribute__((aligned(16))) float lds[NC * LDW + 4 * STG + 4];
+    float *wt = lds, *flag = lds + NC * LDW + 4 * STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    float *stg = lds + NC * LDW + wave * STG;
+    const int group = blockIdx.x % p.ngroups, j0 = (blockIdx.x / p.ngroups) * JB;
+    const unsigned ncol = H / JB;
+    const int Cn = p.Cn, R = p.R;
+    const int rot = (int)(blockIdx.x / p.ngroups) % NKB;
+    unsigned *counter = p.sync + group * SEQ_SYNC_STRIDE, *abort_flag = p.sync + SEQ_ABORT_SLOT;
+    for (int idx = tid; idx < NC * H; idx += 256) {  // wt[q*JB + u][k] = whh[k][q*H + j0 + u]
+        const int lc = idx % NC, k = idx / NC, q = lc / JB, u = lc % JB;
+        wt[lc * LDW + k] = p.whh[(int64_t)k * G3 + q * H + j0 + u];
+    }
+    float bias[3][NU];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) bias[q][u] = p.bhh[q * H + j0 + u * 16 + c];
+    __syncthreads();
+    const auto h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.hprev, 0, (int)((int64_t)(R + 1) * Cn * H * 4), 0x00020000);
+    const int g_row0 = group * p.rows_per_group;
+    const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
+    float hst[NSUB][4][NU];  // masked state entering the step, for this lane's (row, unit) elements
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int row0 = g_row0 + sub * 64 + wave * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) hst[sub][i][u] = p.hprev[(int64_t)r * H + j0 + u * 16 + c];
+        }
+    }
+    float xg[NSUB][4][3][NU], kp[NSUB][4];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
+                const int64_t tr = (int64_t)t * Cn + r;
+                kp[sub][i] = p.keep[tr];
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) xg[sub][i][q][u] = p.gx[tr * G3 + q * H + j0 + u * 16 + c];
+            }
+        }
+    };
+    prefetch(0);
+
+    for (int t = 0; t < R; ++t) {
+        if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
+        float sv[NSUB][4][NU][5];  // r, z, n, hn, h
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+            if (row0 >= g_rows_end) continue;
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int arow = row0 + c;
+            const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * H + 4 * g) * 4) : OOB;
+            i32x4 abuf[2][KU];
+            auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku)
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+            };
+            auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
+            load_block(kbe(0), abuf[0]);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb + 1 < NKB) load_block(kbe(kb + 1), abuf[(kb + 1) & 1]);
+                const float *bpk = wt + c * LDW + kbe(kb) * (KU * 16) + 4 * g;
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku) {
+                    const f32x4 a4 = __builtin_bit_cast(f32x4, abuf[kb & 1][ku]);
+                    const float *bp = bpk + ku * 16;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + nt * 16 * LDW);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b4[j], acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- GRU cell (k_rnn_cell_fwd's arithmetic)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const float r = sigm(xg[sub][i][0][u] + (acc[0 * NU + u][i] + bias[0][u]));
+                    const float z = sigm(xg[sub][i][1][u] + (acc[1 * NU + u][i] + bias[1][u]));
+                    const float hn = acc[2 * NU + u][i] + bias[2][u];
+                    const float n = tanhf(xg[sub][i][2][u] + r * hn);
+                    const float h = (1.0f - z) * n + z * hst[sub][i][u];
+                    hst[sub][i][u] = h * kp[sub][i];
+                    stg[(4 * g + i) * JB + u * 16 + c] = hst[sub][i][u];
+                    sv[sub][i][u][0] = r; sv[sub][i][u][1] = z; sv[sub][i][u][2] = n; sv[sub][i][u][3] = hn; sv[sub][i][u][4] = h;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int v = 0; v < NU; ++v) {
+                const int f = v * 64 + lane, r = f / (JB / 4), c4 = f % (JB / 4), row = row0 + r;
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + r * JB + c4 * 4);
+                const uint32_t off = row < g_rows_end ? (uint32_t)((((int64_t)(t + 1) * Cn + row) * H + j0 + c4 * 4) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), h_rsrc, off, 0, 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (t + 1 < R) {
+            seq_arrive(counter);
+            prefetch(t + 1);
+        }
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i;
+                if (row < g_rows_end) {
+                    const int64_t tr = (int64_t)t * Cn + row;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int j = j0 + u * 16 + c;
+                        float *go = p.gates + tr * G4 + j;
+                        go[0] = sv[sub][i][u][0]; go[H] = sv[sub][i][u][1]; go[2 * H] = sv[sub][i][u][2]; go[3 * H] = sv[sub][i][u][3];
+                        p.hout[tr * H + j] = sv[sub][i][u][4];
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct GruSeqBwd {
+    const float *dout, *gates, *hprev, *keep, *whh;
+    float *dgx, *dgh;
+    unsigned *sync;
+    int R, Cn, ngroups, rows_per_group;
+};
+
+template <int JB, int NSUB>
+__global__ __launch_bounds__(256, 1) void k_gru_seq_bwd(GruSeqBwd p) {
+    constexpr int H = 8192 / JB, G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NU = JB / 16, LDK = G3 + 4;
+    constexpr int KU = 8, NKB = G3 / 16 / KU;
+    constexpr int STG = 16 * NC;
+    static_assert(NKB * KU * 16 == G3 && NKB % 2 == 0, "shape");
+    __shared__ __attribute__((aligned(16))) float lds[JB * LDK + 4 * STG + 4];
+    float *wk = lds, *flag = lds + JB * LDK + 4 * STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    float *stg = lds + JB * LDK + wave * STG;
+    const int group = blockIdx.x % p.ngroups, j0 = (blockIdx.x / p.ngroups) * JB;
+    const unsigned ncol = H / JB;
+    const int Cn = p.Cn, R = p.R;
+    const int rot = (int)(blockIdx.x / p.ngroups) % NKB;
+    unsigned *counter = p.sync + group * SEQ_SYNC_STRIDE, *abort_flag = p.sync + SEQ_ABORT_SLOT;
+    for (int idx = tid; idx < JB * (G3 / 4); idx += 256) {  // wk[kk][n] = whh[j0 + kk][n]
+        const int kk = idx / (G3 / 4), n4 = idx % (G3 / 4);
+        *reinterpret_cast<f32x4 *>(wk + kk * LDK + n4 * 4) =
+            *reinterpret_cast<const f32x4 *>(p.whh + (int64_t)(j0 + kk) * G3 + n4 * 4);
+    }
+    __syncthreads();
+    const auto d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.dgh, 0, (int)((int64_t)R * Cn * G3 * 4), 0x00020000);
+    const int g_row0 = group * p.rows_per_group;
+    const int g_rows_end = min(Cn, g_row0 + p.rows_per_group);
+    float car_h[NSUB][4][NU];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) car_h[sub][i][u] = 0.0f;
+    float pg[NSUB][4][NU][4], pdo[NSUB][4][NU], php[NSUB][4][NU], pkp[NSUB][4];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
+                const int64_t tr = (int64_t)t * Cn + r;
+                pkp[sub][i] = t > 0 ? p.keep[tr - Cn] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int j = j0 + u * 16 + c;
+                    const float *go = p.gates + tr * G4 + j;
+                    pg[sub][i][u][0] = go[0]; pg[sub][i][u][1] = go[H]; pg[sub][i][u][2] = go[2 * H]; pg[sub][i][u][3] = go[3 * H];
+                    pdo[sub][i][u] = p.dout[tr * H + j];
+                    php[sub][i][u] = p.hprev[tr * H + j];
+                }
+            }
+        }
+    };
+    prefetch(R - 1);
+
+    for (int s = 0; s < R; ++s) {
+        const int t = R - 1 - s;
+        float dir[NSUB][4][NU];  // dL/dh_prev that does not go through W_hh: dh * z
+        // ---- phase A: GRU cell backward (k_rnn_cell_bwd's arithmetic); dgx plain, dgh = the hand-off payload
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+            if (row0 >= g_rows_end) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * g + i;
+                const bool ok = row < g_rows_end;
+                const int64_t tr = (int64_t)t * Cn + (ok ? row : g_rows_end - 1);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const float r = pg[sub][i][u][0], z = pg[sub][i][u][1], n = pg[sub][i][u][2], hn = pg[sub][i][u][3];
+                    float d = pdo[sub][i][u];
+                    if (s > 0) d = d + car_h[sub][i][u];
+                    const float dn_pre = (d * (1.0f - z)) * (1.0f - n * n);
+                    const float dz_pre = (d * (php[sub][i][u] - n)) * (z * (1.0f - z));
+                    const float dr_pre = (dn_pre * hn) * (r * (1.0f - r));
+                    float *sp = stg + (4 * g + i) * NC + u * 16 + c;
+                    sp[0] = dr_pre; sp[JB] = dz_pre; sp[2 * JB] = dn_pre * r;
+                    dir[sub][i][u] = d * z;
+                    if (ok) {
+                        float *x = p.dgx + tr * G3 + j0 + u * 16 + c;
+                        x[0] = dr_pre; x[H] = dz_pre; x[2 * H] = dn_pre;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int v = 0; v < STG / 4 / 64; ++v) {  // 16 rows x NC floats as 16-byte write-through stores
+                const int f = v * 64 + lane, r = f / (NC / 4), c4 = f % (NC / 4), row = row0 + r;
+                const int q = (c4 * 4) / JB, u4 = (c4 * 4) % JB;
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + r * NC + c4 * 4);
+                const uint32_t off = row < g_rows_end ? (uint32_t)((((int64_t)t * Cn + row) * G3 + q * H + j0 + u4) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, val), d_rsrc, off, 0, 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (t == 0) break;
+        seq_arrive(counter);
+        float kcur[NSUB][4];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kcur[sub][i] = pkp[sub][i];  // keep[t-1] of THIS step (prefetch overwrites pkp)
+        prefetch(t - 1);
+        if (!seq_wait(counter, ncol * (unsigned)(s + 1), abort_flag, flag)) return;
+        // ---- phase B: dL/dh_{t-1}[rows, own units] = (dgh_t[rows, :] W_hh[own units, :]^T + dh * z) * keep[t-1]
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row0 = g_row0 + sub * 64 + wave * 16;
+            if (row0 >= g_rows_end) continue;
+            f32x4 acc[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int arow = row0 + c;
+            const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * G3 + 4 * g) * 4) : OOB;
+            i32x4 abuf[2][KU];
+            auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku)
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+            };
+            auto mma_block = [&](int kb, const i32x4 (&src)[KU]) {
+#pragma unroll
+                for (int ku = 0; ku < KU; ++ku) {
+                    const f32x4 a4 = __builtin_bit_cast(f32x4, src[ku]);
+                    const float *bp = wk + c * LDK + (kb * KU + ku) * 16 + 4 * g;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + u * 16 * LDK);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b4[j], acc[u], 0, 0, 0);
+                    }
+                }
+            };
+            auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
+            load_block(kbe(0), abuf[0]);
+            for (int kb = 0; kb < NKB; kb += 2) {
+                load_block(kbe(kb + 1), abuf[1]);
+                mma_block(kbe(kb), abuf[0]);
+                if (kb + 2 < NKB) load_block(kbe(kb + 2), abuf[0]);
+                mma_block(kbe(kb + 1), abuf[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) car_h[sub][i][u] = (acc[u][i] + dir[sub][i][u]) * kcur[sub][i];
+        }
+    }
+}
+
 int seq_plan(int Cn, int H, int *ngroups, int *rows_per_group, int *jb) {
     if (H != 512) return 0;  // JB = 16; other widths take the per-step path (sf_rnn_cell_fwd/bwd)
     *jb = 8192 / H;
@@ -460,4 +776,39 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
     else if (nsub == 2) k_lstm_seq_bwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
     else k_lstm_seq_bwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
     return sf_launch_status("sf_lstm_seq_bwd");
+}
+
+extern "C" int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
+                              float *hprev, float *hout, uint32_t *sync, int R, int Cn, int H, void *stream) {
+    SF_REQUIRE(gx && whh && bhh && keep && gates && hprev && hout && sync && R > 0 && Cn > 0, "sf_gru_seq_fwd: bad args");
+    int ng, rpg, jb;
+    SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_gru_seq_fwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
+    SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_fwd: state buffer exceeds 2 GiB");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_fwd memset");
+    if (rc) return rc;
+    GruSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, ng, rpg};
+    const dim3 grid((unsigned)(ng * (H / jb))), block(256);
+    const int nsub = (rpg + 63) / 64;
+    if (nsub == 1) k_gru_seq_fwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
+    else if (nsub == 2) k_gru_seq_fwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
+    else k_gru_seq_fwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
+    return sf_launch_status("sf_gru_seq_fwd");
+}
+
+extern "C" int sf_gru_seq_bwd(const float *dout, const float *gates, const float *hprev, const float *keep,
+                              const float *whh, float *dgx, float *dgh, uint32_t *sync, int R, int Cn, int H,
+                              void *stream) {
+    SF_REQUIRE(dout && gates && hprev && keep && whh && dgx && dgh && sync && R > 0 && Cn > 0, "sf_gru_seq_bwd: bad args");
+    int ng, rpg, jb;
+    SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_gru_seq_bwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
+    SF_REQUIRE((int64_t)R * Cn * 3 * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_bwd: gate-gradient buffer exceeds 2 GiB");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_bwd memset");
+    if (rc) return rc;
+    GruSeqBwd p{dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, ng, rpg};
+    const dim3 grid((unsigned)(ng * (H / jb))), block(256);
+    const int nsub = (rpg + 63) / 64;
+    if (nsub == 1) k_gru_seq_bwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
+    else if (nsub == 2) k_gru_seq_bwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
+    else k_gru_seq_bwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
+    return sf_launch_status("sf_gru_seq_bwd");
 }

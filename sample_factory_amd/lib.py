@@ -38,7 +38,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
@@ -279,7 +279,7 @@ def lstm_seq_supported(Cn: int, H: int) -> bool:
     return bool(load().sf_lstm_seq_supported(int(Cn), int(H)))
 
 
-def _seq_key(op, R, Cn, H, steps):
+def _seq_key(op, R, Cn, H, steps, G=4):
     """profiling key of a fused LSTM pass in bench.py's layout: 2 * (steps*Cn) * 4H * H algorithmic FLOPs of the
     recurrent products (forward: R steps; backward: R-1, the first step has no state in front of it)"""
     if PROFILE is None:
@@ -287,7 +287,7 @@ def _seq_key(op, R, Cn, H, steps):
     ng = min(8, (Cn + 15) // 16)
     rpg = ((Cn + ng - 1) // ng + 15) // 16 * 16
     nsub = {1: 1, 2: 2}.get((rpg + 63) // 64, 4)
-    return (op, int(steps * Cn), int(H), 1, 1, int(4 * H), 1, 1, 1, 1, f"k_lstm_seq_{op[5:]}<16, {nsub}>")
+    return (op, int(steps * Cn), int(H), 1, 1, int(G * H), 1, 1, 1, 1, f"k_{op[:3]}_seq_{op[-3:]}<16, {nsub}>")
 
 
 def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H) -> None:
@@ -304,6 +304,22 @@ def lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, H) -> No
                                       ptr(cout, "f32", "cout"), ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"),
                                       ptr(dgx, "f32", "dgx"),
                                       ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_bwd")
+
+
+def gru_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H) -> None:
+    with _timed(_seq_key("gru_fwd", R, Cn, H, R, 3)):
+        _check(load().sf_gru_seq_fwd(ptr(gx, "f32", "gx"), ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"),
+                                     ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
+                                     ptr(hout, "f32", "hout"), ptr(sync, "i32", "sync"), int(R), int(Cn), int(H),
+                                     stream()), "sf_gru_seq_fwd")
+
+
+def gru_seq_bwd(dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, H) -> None:
+    with _timed(_seq_key("gru_bwd", R, Cn, H, R - 1, 3)):
+        _check(load().sf_gru_seq_bwd(ptr(dout, "f32", "dout"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
+                                     ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"), ptr(dgx, "f32", "dgx"),
+                                     ptr(dgh, "f32", "dgh"), ptr(sync, "i32", "sync"), int(R), int(Cn), int(H),
+                                     stream()), "sf_gru_seq_bwd")
 
 
 def rows_add_scale(a, b, keep, Cn, H, y) -> None:

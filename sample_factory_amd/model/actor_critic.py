@@ -11,7 +11,7 @@ with Sample Factory checkpoints; the compute is libsf_hip.so'
  * the u8 -> f32 observation normalisation (utils/normalize.py:51-70) is fused into the first layer's loader;
  * critic_linear and distribution_linear are one fused [F, 1+A] GEMM (column 0 = value).
 
-Native: conv or MLP encoder (relu/tanh/elu), optional one-layer GRU / LSTM core (per-step cell kernels; LSTM-512 BPTT
+Native: conv or MLP encoder (relu/tanh/elu), optional one-layer GRU / LSTM core (per-step cell kernels; width-512 BPTT
 passes as ONE persistent launch each, csrc/sf_rnn.hip), MLP decoder, input running-mean-std (normalize_input), Discrete /
 Tuple-of-Discrete / Box action heads.  Separate actor/critic weights and multi-layer RNNs raise; user-registered torch
 modules and multi-key observation dicts go through model/torch_policy.py (the network under autograd, everything around
@@ -580,10 +580,13 @@ class ActorCritic:
         if kind == 1:
             Cprev[0].copy_(h0[:, H:])
         GXv = GX.view(R, Cn, GH)
-        fused = kind == 1 and _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
+        fused = _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
         if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS
             sync = self._buf((tag, "seq_sync"), (192,), dtype=torch.int32)
-            lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, Hout, Cprev, Cout, sync, R, Cn, H)
+            if kind == 1:
+                lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, Hout, Cprev, Cout, sync, R, Cn, H)
+            else:
+                lib.gru_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, Hout, sync, R, Cn, H)
             self._seq_sync = sync
         gh = self._buf((tag, "gh_seq"), (Cn, GH)) if not fused else None
         for t in range(0 if fused else R):
@@ -607,10 +610,15 @@ class ActorCritic:
         dGX = self._buf(("g", "dGX"), (R, Cn, GH))
         if sv.get("fused"):  # the whole backward time loop in one persistent launch (cell backward + W_hh^T product + carries)
             sync = self._buf(("g", "seq_sync"), (192,), dtype=torch.int32)
-            lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, sync, R, Cn, H)
+            dGH = dGX
+            if kind == 1:
+                lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, sync, R, Cn, H)
+            else:  # GRU: the candidate gate's recurrent part is scaled by r -> W_hh sees its own gate gradients
+                dGH = self._buf(("g", "dGH"), (R, Cn, GH))
+                lib.gru_seq_bwd(dOut, sv["gates"], sv["Hprev"], keep, Lh.w, dGX, dGH, sync, R, Cn, H)
             self._seq_sync_bwd = sync
             ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
-            lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGX.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
+            lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
             return dGX.view(n, GH)
         dGH = self._buf(("g", "dGH"), (R, Cn, GH)) if kind == 0 else dGX
         dh = self._buf(("g", "dh"), (Cn, H))

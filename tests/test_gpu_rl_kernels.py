@@ -664,6 +664,64 @@ def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R):
     np.testing.assert_allclose(dgx.cpu().double().numpy(), want.numpy(), atol=2e-6 * scale, rtol=5e-5)
 
 
+@pytest.mark.parametrize("Cn,R", [(512, 6), (200, 4), (2048, 3), (16, 5)])
+def test_fused_gru_sequence_passes_vs_torch_fp64(lib, Cn, R):
+    """sf_gru_seq_fwd / sf_gru_seq_bwd (the reference's default core: GRU-512) against a float64 torch GRU loop with the
+    same masking; torch.nn.GRUCell's equations (r, z, n gate order, n = tanh(x_n + r * (h W_hn + b_hn))) are checked
+    against the loop first, so the reference here IS torch's GRU."""
+    H = 512
+    g = torch.Generator().manual_seed(3 * Cn + R)
+    gx = torch.randn((R, Cn, 3 * H), generator=g) * 0.7
+    whh = torch.randn((H, 3 * H), generator=g) / np.sqrt(H)
+    bhh = torch.randn((3 * H,), generator=g) * 0.1
+    keep = (torch.rand((R, Cn), generator=g) > 0.15).float()
+    h0 = torch.randn((Cn, H), generator=g) * 0.5
+    dout = torch.randn((R, Cn, H), generator=g)
+    gx64 = gx.double().requires_grad_(True)
+    W, b = whh.double(), bhh.double()
+    h = h0.double()
+    ref = dict(gates=[], hout=[], hprev=[h])
+    gh_probe = torch.zeros((R, Cn, 3 * H), dtype=torch.float64, requires_grad=True)  # its gradient = dL/d(h W_hh + b_hh)
+    for t in range(R):
+        gh = h @ W + b + gh_probe[t]
+        xr, xz, xn = gx64[t].split(H, dim=1)
+        hr, hz, hn = gh.split(H, dim=1)
+        r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+        n = torch.tanh(xn + r * hn)
+        hnew = (1 - z) * n + z * h
+        if t == 0:  # the loop is torch's GRUCell (weights: W_ih = I-free form -> compare through a cell with zero W_ih)
+            cell = torch.nn.GRUCell(1, H).double()
+            with torch.no_grad():
+                cell.weight_ih.zero_(); cell.bias_ih.zero_(); cell.weight_hh.copy_(W.t()); cell.bias_hh.copy_(b)
+                want0 = cell(torch.zeros((Cn, 1), dtype=torch.float64), h)
+                r0, z0 = torch.sigmoid(hr), torch.sigmoid(hz)
+                mine0 = (1 - z0) * torch.tanh(r0 * hn) + z0 * h
+            assert (want0 - mine0).abs().max().item() < 1e-12
+        ref["gates"].append(torch.cat([r, z, n, hn], 1)); ref["hout"].append(hnew)
+        h = hnew * keep[t].double()[:, None]
+        ref["hprev"].append(h)
+    (torch.stack(ref["hout"]) * dout.double()).sum().backward()
+    d = lambda x: x.cuda().contiguous()
+    gates, hout = torch.full((R, Cn, 4 * H), 7.0, device="cuda"), torch.full((R, Cn, H), 7.0, device="cuda")
+    hprev = torch.full((R + 1, Cn, H), 7.0, device="cuda")
+    hprev[0] = d(h0)
+    sync = torch.zeros(192, dtype=torch.int32, device="cuda")
+    lib.gru_seq_fwd(d(gx), d(whh), d(bhh), d(keep), gates, hprev, hout, sync, R, Cn, H)
+    torch.cuda.synchronize()
+    assert int(sync[128]) == 0, "forward pass aborted"
+    tol = dict(atol=3e-6, rtol=2e-5)
+    for name, got in [("gates", gates), ("hout", hout), ("hprev", hprev)]:
+        want = torch.stack([x.detach() for x in ref[name]])
+        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), err_msg=name, **tol)
+    dgx, dgh = torch.full((R, Cn, 3 * H), 7.0, device="cuda"), torch.full((R, Cn, 3 * H), 7.0, device="cuda")
+    lib.gru_seq_bwd(d(dout), gates, hprev, d(keep), d(whh), dgx, dgh, sync, R, Cn, H)
+    torch.cuda.synchronize()
+    assert int(sync[128]) == 0, "backward pass aborted"
+    for name, got, want in [("dgx", dgx, gx64.grad), ("dgh", dgh, gh_probe.grad)]:
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), atol=2e-6 * scale, rtol=5e-5, err_msg=name)
+
+
 def test_synthetic_continuous_env_kernel_rules(lib):
     """sf_synth_vec_step: reward / termination / dynamics rules of the Ant-shaped stand-in env, zero-copy into a strided
     slab slot, reproducible from (seed, global env id, step)"""

@@ -25,6 +25,10 @@ def one():
     sync = torch.zeros(192, dtype=torch.int32, device="cuda")
     fwd = lambda: lib.lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H)
     bwd = lambda: lib.lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, H)
+    if os.environ.get("RNN_KIND", "lstm") == "gru":
+        gx3, whh3, dgx3, dgh3 = gx[..., :3 * H].contiguous(), whh[:, :3 * H].contiguous(), torch.empty((R, Cn, 3 * H), device="cuda"), torch.empty((R, Cn, 3 * H), device="cuda")
+        fwd = lambda: lib.gru_seq_fwd(gx3, whh3, bhh, keep, gates, hprev, hout, sync, R, Cn, H)
+        bwd = lambda: lib.gru_seq_bwd(dout, gates, hprev, keep, whh3, dgx3, dgh3, sync, R, Cn, H)
     out = []
     for name, fn in [("fwd", fwd), ("bwd", bwd)]:
         for _ in range(3):
@@ -38,7 +42,7 @@ def one():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         out.append(f"{name} {ms * 1e3:7.1f} us = {ms * 1e3 / R:5.1f} us/step")
-    print(f"ablate={os.environ.get('SF_LSTM_ABLATE', '0'):>2}  " + "   ".join(out) + f"   aborted={int(sync[128])}")
+    print(f"{os.environ.get('RNN_KIND', 'lstm')} ablate={os.environ.get('SF_LSTM_ABLATE', '0'):>2}  " + "   ".join(out) + f"   aborted={int(sync[128])}")
 
 
 if __name__ == "__main__":
