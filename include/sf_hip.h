@@ -338,6 +338,25 @@ int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const fl
 int sf_gru_seq_bwd(const float *dout, const float *gates, const float *hprev, const float *keep, const float *whh,
                    float *dgx, float *dgh, uint32_t *sync, int R, int Cn, int H, void *stream);
 
+/* ---- data-parallel learner replicas (SURVEY.md §8(b) "DP -> sf_allreduce_grads", §8(e)) ----------------------------
+ * New capability: the reference runs ONE learner per policy (algo/utils/shared_buffers.py:26-32), so these replace no
+ * reference function; a host without torch.distributed binds them for the exchange algo/learning/learner.py performs
+ * per SGD step.  One RCCL communicator per rank, created once on the rank's current device: rank 0 calls
+ * sf_dp_unique_id and ships the SF_DP_UNIQUE_ID_BYTES bytes to the other ranks by any host channel; every rank then
+ * calls sf_dp_comm_create (a collective: returns when all nranks ranks joined).  sf_allreduce_grads: in-place SUM of n
+ * fp32 values over the ranks (each replica's gradient already carries the GLOBAL 1/n_valid), enqueued on `stream`;
+ * calls on one communicator must be issued in the same order on every rank.  sf_dp_allreduce_f64: the 3-double
+ * moment / loss-scalar exchanges (op 0 = sum, 1 = max).  sf_dp_broadcast: root's bytes to everyone (initial weights).
+ * librccl.so.1 is loaded on first use (dlopen), never at library load. */
+#define SF_DP_UNIQUE_ID_BYTES 128
+int sf_dp_unique_id(void *out_id);
+int sf_dp_comm_create(const void *id_bytes, int nranks, int rank, void **comm_out);
+int sf_dp_comm_destroy(void *comm);
+int sf_dp_comm_info(void *comm, int *nranks, int *rank);
+int sf_allreduce_grads(void *comm, float *grads, int64_t n, void *stream);
+int sf_dp_allreduce_f64(void *comm, double *buf, int64_t n, int op, void *stream);
+int sf_dp_broadcast(void *comm, void *buf, int64_t nbytes, int root, void *stream);
+
 /* action means squashed to [-scale, scale] (continuous_tanh_scale > 0, model/action_parameterization.py:62-66), in
  * place on columns [col0, col0+ncols) of a row-major [n, ld] matrix: y = tanh(x/scale)*scale; backward: g *= 1-(y/scale)^2
  * with y the squashed output. */

@@ -8,6 +8,12 @@ communication (recurrences run along T only).  Per SGD step the replicas exchang
 and once per dataset 3 doubles of return moments (returns normaliser) and the invalid count.  Adam then runs
 redundantly on identical inputs, so weights never need an all-gather.  `torch.distributed` backend "nccl" is RCCL on
 ROCm; the same code runs over gloo on CPU tensors (tests/test_dp_gloo.py).
+
+cfg.dp_native_rccl (opt-in): the GRADIENT buckets go through the C-ABI instead (`sf_allreduce_grads`, csrc/sf_dp.hip:
+one RCCL communicator per rank created from an id that rank 0 broadcasts over the torch process group, collectives
+enqueued on a dedicated exchange stream) — the path a host without torch.distributed binds.  The small
+scalar exchanges stay on torch.distributed.  Executed on hardware with ONE rank only so far (tests/test_gpu_dp.py), hence
+not the default.
 """
 from __future__ import annotations
 
@@ -22,8 +28,18 @@ class _Done:
         return None
 
 
+class _EventHandle:
+    """wait(): order the CURRENT stream behind a collective that was enqueued on the exchange stream"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class ReplicaGroup:
-    def __init__(self, process_group=None, force_collectives: bool = False):
+    def __init__(self, process_group=None, force_collectives: bool = False, native_rccl: bool = False):
         self.pg = process_group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.active else 1
@@ -35,6 +51,56 @@ class ReplicaGroup:
         # gloo (CPU collectives) with device tensors: stage through the host.  Only used to exercise the replica
         # protocol on boxes with fewer GPUs than ranks (tests); production runs use nccl (= RCCL over xGMI).
         self._stage = self.active and dist.get_backend(process_group) == "gloo"
+        self._comm = self._xstream = None
+        if native_rccl and self.on:
+            self._init_native()
+
+    # ---- gradient buckets through the C-ABI (sf_allreduce_grads)
+    def _init_native(self) -> None:
+        from sample_factory_amd import lib
+        dev = torch.device("cpu") if self._stage else torch.device("cuda", torch.cuda.current_device())
+        ident = torch.zeros(lib.DP_UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(lib.dp_unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+        self._comm = lib.dp_comm_create(bytes(ident.cpu().numpy().tobytes()), self.world, self.rank)
+        assert lib.dp_comm_info(self._comm) == (self.world, self.rank)
+        self._xstream = torch.cuda.Stream()
+        self._lib = lib
+
+    @property
+    def native(self) -> bool:
+        return self._comm is not None
+
+    def _native_reduce(self, t: torch.Tensor) -> _EventHandle:
+        """every gradient collective is enqueued on the ONE exchange stream, in program order (one communicator: same
+        order on every rank), behind what the current stream has produced so far"""
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self._xstream.wait_event(ready)
+        self._lib.allreduce_grads(self._comm, t, self._xstream)
+        done = torch.cuda.Event()
+        done.record(self._xstream)
+        return _EventHandle(done)
+
+    def all_reduce_grads(self, t: torch.Tensor) -> torch.Tensor:
+        """SUM of a slice of the flat fp32 gradient over the replicas; the current stream continues behind the result"""
+        if self.native:
+            self._native_reduce(t).wait()
+            return t
+        return self.all_reduce_sum(t)
+
+    def all_reduce_grads_async(self, t: torch.Tensor):
+        if self.native:
+            return self._native_reduce(t)
+        return self.all_reduce_sum_async(t)
+
+    def close(self) -> None:
+        if self._comm is not None:
+            torch.cuda.synchronize()
+            self._lib.dp_comm_destroy(self._comm)
+            self._comm = None
 
     def _collective(self, fn, t: torch.Tensor) -> torch.Tensor:
         if self.on:

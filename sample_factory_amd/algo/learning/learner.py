@@ -156,7 +156,8 @@ class Learner:
         # data-parallel replicas (C1): one rank per GPU; inactive group = single GPU
         self.pg = process_group
         dp_on = process_group is not None or (getattr(cfg, "data_parallel", False) and torch.distributed.is_initialized())
-        self.group = ReplicaGroup(process_group, bool(getattr(cfg, "dp_force_collectives", False))) if dp_on else None
+        self.group = ReplicaGroup(process_group, bool(getattr(cfg, "dp_force_collectives", False)),
+                                  bool(getattr(cfg, "dp_native_rccl", False))) if dp_on else None
         self.world = self.group.world if self.group is not None else 1
         self.dp = self.group is not None and self.group.on  # collectives are issued (world > 1, or forced for tests)
         self._grad_norms: List[float] = []
@@ -556,15 +557,16 @@ class Learner:
                     pending = []
                     ac.backward(acts, g_heads, buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
                                 traj_T=buff.T,
-                                on_layer_done=lambda li: pending.append(self.group.all_reduce_sum_async(
+                                on_layer_done=lambda li: pending.append(self.group.all_reduce_grads_async(
                                     ac.flat_grads[cut:])) if li == self._dp_split else None)
-                    self._all_reduce(ac.flat_grads[:cut])
+                    self.group.all_reduce_grads(ac.flat_grads[:cut])
                     for work in pending:
                         work.wait()
                 else:
                     ac.backward(acts, g_heads, buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
                                 traj_T=buff.T)
-                    self._all_reduce(ac.flat_grads)
+                    if self.dp:
+                        self.group.all_reduce_grads(ac.flat_grads)
                 actual_lr = self.curr_lr
                 if self._global_invalids > 0:  # learner.py:788-794
                     actual_lr = self.curr_lr * (global_size - self._global_invalids) / global_size

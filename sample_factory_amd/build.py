@@ -15,6 +15,7 @@ SOURCES = [
     ("sf_rl.hip", ["-ffp-contract=off"]),
     ("sf_nn.hip", []),
     ("sf_rnn.hip", ["-ffp-contract=off"]),  # the fused cell arithmetic must equal k_rnn_cell_* of sf_rl.hip
+    ("sf_dp.hip", []),                      # host code: RCCL gradient exchange (librccl resolved with dlopen at first use)
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
           f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
@@ -44,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

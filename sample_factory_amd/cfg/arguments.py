@@ -64,6 +64,18 @@ FLAGS = [
 ]
 
 
+# flags of THIS engine (no counterpart in the reference's cfg; everything above mirrors cfg/cfg.py)
+ENGINE_FLAGS = [
+    ("data_parallel", _bool, False),         # learner replicas over torch.distributed (set automatically when WORLD_SIZE > 1)
+    ("dp_overlap", _bool, True),             # all-reduce the fc/heads gradient bucket while the conv layers back-propagate
+    ("dp_native_rccl", _bool, False),        # gradient buckets through the C-ABI (sf_allreduce_grads) instead of torch.distributed
+    ("dp_force_collectives", _bool, False),  # issue the collectives in a group of one rank (tests)
+    ("device_shuffle", _bool, False),        # shuffle_minibatches with the stateless on-device permutation
+    ("sampler_thread", _bool, None),         # None: a sampler thread iff async_rl with a host env
+    ("record_grad_norm", _bool, False),
+]
+
+
 def parse_sf_args(argv: Optional[List[str]] = None, evaluation: bool = False) -> Tuple[argparse.ArgumentParser, argparse.Namespace]:
     """cfg/arguments.py:24-52 — returns (parser, partially parsed args); scripts may add args to the parser."""
     import sys
@@ -71,7 +83,7 @@ def parse_sf_args(argv: Optional[List[str]] = None, evaluation: bool = False) ->
     if argv is None:
         argv = sys.argv[1:]
     p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter, add_help=False)
-    for spec in FLAGS:
+    for spec in FLAGS + ENGINE_FLAGS:
         name, typ, default = spec[:3]
         kw = dict(type=typ, default=default)
         if len(spec) > 3:

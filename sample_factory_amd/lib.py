@@ -45,6 +45,8 @@ SYMBOLS = [
     "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
     "sf_tanh_scale_fwd", "sf_tanh_scale_bwd",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
+    "sf_dp_unique_id", "sf_dp_comm_create", "sf_dp_comm_destroy", "sf_dp_comm_info", "sf_allreduce_grads",
+    "sf_dp_allreduce_f64", "sf_dp_broadcast",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -583,3 +585,56 @@ def relu_mask(g, act) -> None:
 
 conv_fwd = conv_fwd_raw
 conv_wgrad = conv_wgrad_raw
+
+
+# ---- data-parallel replicas: the RCCL exchange behind the C-ABI (csrc/sf_dp.hip) ------------------------------------
+DP_UNIQUE_ID_BYTES = 128
+
+
+def dp_unique_id() -> bytes:
+    """rank 0: a fresh communicator id, to be shipped to the other ranks over any host channel"""
+    buf = C.create_string_buffer(DP_UNIQUE_ID_BYTES)
+    _check(load().sf_dp_unique_id(buf), "sf_dp_unique_id")
+    return buf.raw
+
+
+def dp_comm_create(unique_id: bytes, nranks: int, rank: int) -> C.c_void_p:
+    """collective over the ranks; the communicator lives on the CURRENT device of the calling rank"""
+    if len(unique_id) != DP_UNIQUE_ID_BYTES:
+        raise SfHipError(f"dp_comm_create: the id must be {DP_UNIQUE_ID_BYTES} bytes, got {len(unique_id)}")
+    comm = C.c_void_p()
+    _check(load().sf_dp_comm_create(C.c_char_p(unique_id), int(nranks), int(rank), C.byref(comm)), "sf_dp_comm_create")
+    return comm
+
+
+def dp_comm_destroy(comm) -> None:
+    _check(load().sf_dp_comm_destroy(comm), "sf_dp_comm_destroy")
+
+
+def dp_comm_info(comm):
+    n, r = C.c_int(), C.c_int()
+    _check(load().sf_dp_comm_info(comm, C.byref(n), C.byref(r)), "sf_dp_comm_info")
+    return n.value, r.value
+
+
+def _cur_or(stream_) -> C.c_void_p:
+    return stream() if stream_ is None else C.c_void_p(stream_.cuda_stream)
+
+
+def allreduce_grads(comm, grads: torch.Tensor, stream_=None) -> None:
+    """in-place SUM over the replicas of a contiguous fp32 device tensor (a slice of the flat gradient), enqueued on
+    `stream_` (default: the current stream)"""
+    _check(load().sf_allreduce_grads(comm, ptr(grads, "f32", "grads"), i64(grads.numel()), _cur_or(stream_)),
+           "sf_allreduce_grads")
+
+
+def dp_allreduce_f64(comm, buf: torch.Tensor, op: str = "sum", stream_=None) -> None:
+    _check(load().sf_dp_allreduce_f64(comm, ptr(buf, "f64", "buf"), i64(buf.numel()), {"sum": 0, "max": 1}[op],
+                                      _cur_or(stream_)), "sf_dp_allreduce_f64")
+
+
+def dp_broadcast(comm, buf: torch.Tensor, root: int = 0, stream_=None) -> None:
+    if not (buf.is_cuda and buf.is_contiguous()):
+        raise SfHipError("dp_broadcast: a contiguous device tensor is required")
+    _check(load().sf_dp_broadcast(comm, C.c_void_p(buf.data_ptr()), i64(buf.numel() * buf.element_size()), int(root),
+                                  _cur_or(stream_)), "sf_dp_broadcast")

@@ -38,6 +38,14 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc == -1 and b"sf_gae_returns" in L.sf_last_error()
     with pytest.raises(lib.SfHipError):      # CPU tensors are refused: there is no fallback path
         lib.grad_sumsq(torch.zeros(8), torch.zeros(1, dtype=torch.float64))
+    # the data-parallel exchange: argument checks come before librccl is even looked for
+    comm = ctypes.c_void_p()
+    assert L.sf_dp_comm_create(None, 2, 0, ctypes.byref(comm)) == -1 and b"sf_dp_comm_create" in L.sf_last_error()
+    assert L.sf_dp_comm_create(b"x" * 128, 2, 2, ctypes.byref(comm)) == -1 and b"rank=2" in L.sf_last_error()
+    assert L.sf_allreduce_grads(None, None, ctypes.c_int64(4), None) == -1 and b"sf_allreduce_grads" in L.sf_last_error()
+    assert L.sf_dp_allreduce_f64(ctypes.c_void_p(1), ctypes.c_void_p(1), ctypes.c_int64(4), 7, None) == -1
+    with pytest.raises(lib.SfHipError):
+        lib.dp_comm_create(b"short", 1, 0)
 
 
 def test_struct_layouts_match_header():
@@ -52,7 +60,9 @@ def test_cfg_defaults_equal_reference(golden_json):
     from sample_factory_amd.cfg.arguments import default_cfg, parse_full_cfg, parse_sf_args
     ref = golden_json("cfg_defaults")
     cfg = vars(default_cfg())
-    skip = {"train_dir", "command_line", "env", "experiment", "help"}
+    from sample_factory_amd.cfg.arguments import ENGINE_FLAGS
+    skip = {"train_dir", "command_line", "env", "experiment", "help"} | {f[0] for f in ENGINE_FLAGS}
+    assert not {f[0] for f in ENGINE_FLAGS} & set(ref), "an engine flag shadows a reference flag"
     for k, v in cfg.items():
         if k in skip:
             continue

@@ -98,7 +98,8 @@ from sample_factory_amd.cfg.arguments import default_cfg
 from sample_factory_amd.envs.env_utils import register_env
 from sample_factory_amd.envs.synthetic import make_synthetic_env
 from sample_factory_amd.train import make_runner
-force = os.environ.get("FORCE") == "1"
+force = os.environ.get("FORCE") in ("1", "2")
+native = os.environ.get("FORCE") == "2"
 if force:
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("nccl")
@@ -107,25 +108,62 @@ cfg = default_cfg(env="synthetic_atari", use_rnn=False, nonlinearity="relu", nor
                   encoder_conv_architecture="convnet_atari", rollout=8, batch_size=1024, num_batches_per_epoch=2,
                   num_epochs=2, num_workers=1, num_envs_per_worker=1, worker_num_splits=1, async_rl=False, seed=1,
                   serial_mode=True, synthetic_num_agents=256, train_dir=%r, experiment="rccl" + str(int(force)),
-                  data_parallel=force, dp_force_collectives=force, lr_schedule="kl_adaptive_epoch")
+                  data_parallel=force, dp_force_collectives=force, dp_native_rccl=native, lr_schedule="kl_adaptive_epoch")
 cfg, runner = make_runner(cfg)
 runner.init()
 assert runner.learner.dp == force and (not force or runner.learner._dp_split is not None)
+assert (runner.learner.group is not None and runner.learner.group.native) == native
 for _ in range(3):
     stats = runner.iteration()
 torch.cuda.synchronize()
 p = runner.learner.actor_critic.flat_params
 print("RESULT " + json.dumps(dict(sum=float(p.double().sum()), abs=float(p.double().abs().sum()), loss=stats["train"]["loss"],
                                   steps=runner.learner.train_step, backend=torch.distributed.get_backend() if force else None)))
+if native:
+    runner.learner.group.close()
 if force:
     torch.distributed.destroy_process_group()
 ''' % (root, str(tmp_path))
     out = {}
-    for force in ("0", "1"):
+    for force in ("0", "1", "2"):  # 2: the gradient buckets through the C-ABI (sf_allreduce_grads), the rest as in 1
         env = {k: v for k, v in os.environ.items() if k not in ("SF_DP_BACKEND",)}
         env.update(FORCE=force, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2500:]
         out[force] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert out["1"]["backend"] == "nccl" and out["1"]["steps"] == out["0"]["steps"] == 12
-    assert out["1"]["sum"] == out["0"]["sum"] and out["1"]["abs"] == out["0"]["abs"] and out["1"]["loss"] == out["0"]["loss"]
+    for k in ("1", "2"):
+        assert out[k]["sum"] == out["0"]["sum"] and out[k]["abs"] == out["0"]["abs"] and out[k]["loss"] == out["0"]["loss"], k
+    assert out["2"]["steps"] == 12
+
+
+def test_c_abi_rccl_exchange_single_rank():
+    """csrc/sf_dp.hip through ctypes on the one GPU of the box: id -> communicator of ONE rank -> in-place fp32 SUM on a
+    side stream (identity), f64 sum / max, byte broadcast, info, destroy.  (Two ranks need two devices: RCCL refuses
+    duplicate GPUs, so the multi-rank run belongs to the driver's 8-GPU node.)"""
+    from sample_factory_amd import lib
+    lib.load()
+    torch.cuda.set_device(0)
+    ident = lib.dp_unique_id()
+    assert len(ident) == 128 and ident != bytes(128)
+    comm = lib.dp_comm_create(ident, 1, 0)
+    assert lib.dp_comm_info(comm) == (1, 0)
+    g = torch.randn(1_687_744, device="cuda")
+    want = g.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    lib.allreduce_grads(comm, g, side)
+    lib.allreduce_grads(comm, g[1_000_000:], side)          # a tail slice of the flat buffer (the overlap bucket)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(g, want)
+    d = torch.tensor([1.5, -2.0, 3.0], dtype=torch.float64, device="cuda")
+    lib.dp_allreduce_f64(comm, d, "sum")
+    lib.dp_allreduce_f64(comm, d, "max")
+    assert d.tolist() == [1.5, -2.0, 3.0]
+    b = torch.arange(1000, dtype=torch.int32, device="cuda")
+    lib.dp_broadcast(comm, b, 0)
+    assert torch.equal(b, torch.arange(1000, dtype=torch.int32, device="cuda"))
+    with pytest.raises(lib.SfHipError):
+        lib.allreduce_grads(comm, torch.zeros(4))            # host tensor
+    torch.cuda.synchronize()
+    lib.dp_comm_destroy(comm)
