@@ -94,6 +94,7 @@ def parse_sf_args(argv: Optional[List[str]] = None, evaluation: bool = False) ->
         p.add_argument("--max_num_frames", type=int, default=int(1e9))
         p.add_argument("--eval_deterministic", type=_bool, default=False)
         p.add_argument("--no_render", type=_bool, default=True)
+        p.add_argument("--policy_index", type=int, default=0)
     args, _ = p.parse_known_args(argv)
     return p, args
 
@@ -106,6 +107,12 @@ def parse_full_cfg(parser: argparse.ArgumentParser, argv: Optional[List[str]] = 
         argv = sys.argv[1:]
     args = parser.parse_args(argv)
     args.command_line = " ".join(argv)
+    # the flags that were actually given (cfg/arguments.py:64-72): what load_from_checkpoint lets override a saved config
+    given = argparse.ArgumentParser(add_help=False, argument_default=argparse.SUPPRESS)
+    for a in parser._actions:
+        if a.option_strings:
+            given.add_argument(*a.option_strings, type=a.type, nargs=a.nargs, default=argparse.SUPPRESS)
+    args.cli_args = vars(given.parse_known_args(argv)[0])
     return args
 
 

@@ -160,6 +160,73 @@ def test_example_script_written_against_sample_factory_runs(tmp_path):
     assert "Collected {0: 4096}" in r.stdout
     d = os.path.join(str(tmp_path), "example_gym_cartpole-v1")
     assert os.path.exists(os.path.join(d, "config.json")) and glob.glob(os.path.join(d, "checkpoint_p0", "checkpoint_*.pth"))
+    # ... and the evaluation script of the same shape (sf_examples/enjoy_gym_env.py) reads it back: saved config.json as
+    # the base configuration, command-line flags on top
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "enjoy_gym_env.py"), "--env=CartPole-v1",
+                        f"--train_dir={tmp_path}", "--experiment=example_gym_cartpole-v1", "--max_num_episodes=40",
+                        "--eval_deterministic=True", "--env_agents=8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    avg = float(r.stdout.split("Avg episode reward:")[-1].split()[0])
+    assert 8.0 <= avg <= 500.0
+
+
+def test_enjoy_deterministic_equals_host_argmax_loop(tmp_path):
+    """enjoy(cfg) with --eval_deterministic (enjoy.py:170-172 argmax_actions) against an independent host loop over the
+    same checkpoint and the same seeded env: logits from ActorCritic.forward, torch.argmax, episode returns summed on
+    the host.  The average episode reward must be IDENTICAL (integer actions exact, same episode accounting), a
+    sampled evaluation of the same policy must differ from it, and a missing experiment is reported as in the reference."""
+    from sample_factory_amd.algo.learning.learner import Learner
+    from sample_factory_amd.cfg.arguments import default_cfg, parse_full_cfg, parse_sf_args
+    from sample_factory_amd.enjoy import enjoy
+    from sample_factory_amd.envs.cartpole import CartPoleVecEnv, make_cartpole_env
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.model.model_factory import create_actor_critic
+    from sample_factory_amd.train import make_runner
+    register_env("cartpole_vec", make_cartpole_env)
+    cfg = default_cfg(env="cartpole_vec", use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=16, rollout=16,
+                      encoder_mlp_layers=[32, 32], nonlinearity="tanh", normalize_input=True, batch_size=16 * 16,
+                      num_batches_per_epoch=1, num_epochs=2, num_workers=1, num_envs_per_worker=1, worker_num_splits=1,
+                      async_rl=False, serial_mode=True, seed=3, cartpole_num_agents=16, train_dir=str(tmp_path),
+                      experiment="enjoy_me", train_for_env_steps=16 * 16 * 12, save_every_sec=100000)
+    cfg, runner = make_runner(cfg)
+    assert runner.init() == 0 and runner.run() == 0
+    del runner
+    argv = ["--env=cartpole_vec", f"--train_dir={tmp_path}", "--experiment=enjoy_me", "--eval_deterministic=True",
+            "--max_num_frames=200", "--max_num_episodes=1000000", "--rollout=8"]
+    parser, _ = parse_sf_args(argv, evaluation=True)
+    parser.add_argument("--cartpole_num_agents", type=int, default=2)
+    ecfg = parse_full_cfg(parser, argv)
+    status, avg = enjoy(ecfg)
+    assert status == 0
+    # independent host loop: frames = 208 (the first multiple of rollout=8 past max_num_frames=200)
+    ac = create_actor_critic(cfg, CartPoleVecEnv().observation_space, CartPoleVecEnv().action_space, torch.device("cuda", 0))
+    ac.eval()
+    ck = Learner.load_checkpoint(Learner.get_checkpoints(Learner.checkpoint_dir(cfg, 0)), "cpu")
+    ac.load_state_dict(ck["model"])
+    env = CartPoleVecEnv(num_agents=16, seed=3)
+    o, _ = env.reset()
+    h = torch.zeros((16, 32), device="cuda")
+    ep_ret, total, episodes = np.zeros(16), 0.0, 0
+    for _ in range(208):
+        res = ac.forward({"obs": torch.from_numpy(o["obs"]).cuda()}, h)
+        a = res["action_logits"].argmax(dim=1)
+        h = res["new_rnn_states"].clone()
+        o, rew, term, trunc, _ = env.step(a)
+        ep_ret += rew
+        done = term | trunc
+        total += float(ep_ret[done].sum())
+        episodes += int(done.sum())
+        ep_ret[done] = 0.0
+        h[torch.from_numpy(done).cuda()] = 0.0
+    assert episodes > 0 and avg == total / episodes, (avg, total / episodes, episodes)
+    # sampling instead of arg-max: the saved config is the base, the flag given here overrides it
+    argv2 = [a for a in argv if not a.startswith("--eval_deterministic")] + ["--eval_deterministic=False"]
+    parser, _ = parse_sf_args(argv2, evaluation=True)
+    parser.add_argument("--cartpole_num_agents", type=int, default=2)
+    _, avg_sampled = enjoy(parse_full_cfg(parser, argv2))
+    assert avg_sampled != avg and avg_sampled > 0
+    with pytest.raises(FileNotFoundError, match="Could not load saved parameters"):
+        enjoy(default_cfg(env="cartpole_vec", train_dir=str(tmp_path), experiment="nope"))
 
 
 @pytest.mark.parametrize("use_rnn", [False, True])
