@@ -734,6 +734,7 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 
 #include "sf_nn_glds.h"
 #include "sf_nn_img.h"
+#include "sf_nn_u8.h"
 
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -767,6 +768,12 @@ static int pick_mode(const ConvG &g) {
 static bool conv1_img_ok(const ConvG &g, int mode, int64_t n) {
     return mode == MODE_U8 && n >= 256 && g.Cin == 4 && g.H == 84 && g.W == 84 && g.KH == 8 && g.KW == 8 && g.S == 4 &&
            g.Cout <= 32;
+}
+
+// k_conv1_u8_bf16: same geometry; the A operand must be exact in bf16: pixel - mean an integer of at most 8 bits
+static bool conv1_bf16_ok(const ConvG &g, int mode, int64_t n) {
+    static const int on = getenv("SF_CONV1_BF16") ? atoi(getenv("SF_CONV1_BF16")) : 1;
+    return on && conv1_img_ok(g, mode, n) && g.sub_mean == floorf(g.sub_mean) && g.sub_mean >= 0.f && g.sub_mean <= 255.f;
 }
 
 // forward launch plan: tile config + optional split-K when the natural grid cannot fill 256 CUs several times over
@@ -834,6 +841,19 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
     // Nature-CNN conv1 on raw frames: strip-image kernel (bytes converted once into an f32 LDS image, im2col read
     // out of LDS).  Geometry contract of the <2,4,5,16> instantiation: K = 256, 2*4*OW rows = 10 fragments.
     static const int img_on = getenv("SF_CONV1_IMG") ? atoi(getenv("SF_CONV1_IMG")) : 1;
+    // ... and on the bf16 matrix pipe with exact products (sf_nn_u8.h) when (pixel - mean) is an integer of <= 8 bits
+    if (conv1_bf16_ok(g, mode, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0) {
+        const unsigned lds_bytes = 2u * 4u * 20u * 88u * (unsigned)sizeof(uint16_t);  // [SMP][Cin][RS][WP] bf16
+        const int64_t npairs = cdiv64(n, 2), resident = (int64_t)num_cus() * 2;     // two work-groups per CU
+        const unsigned grid_q = (unsigned)(npairs < resident ? npairs : resident);
+        if (g.sub_mean != 0.f)
+            k_conv1_u8_bf16<true><<<dim3(grid_q), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
+        else
+            k_conv1_u8_bf16<false><<<dim3(grid_q), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
+        return sf_launch_status("sf_conv_fwd");
+    }
     if (img_on && conv1_img_ok(g, mode, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0) {
         const unsigned lds_bytes = (unsigned)(2 * 4 * 20 * 84 * sizeof(float));  // [SMP][Cin][RS][W] f32
         // persistent work-groups: as many as are resident at once (two per CU: 53.8 KB of LDS each), each walks the
@@ -1270,7 +1290,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
     const int64_t Mtot = n * g.OH * g.OW;
     const int mode = pick_mode(g);
     if (op == 0 && conv1_img_ok(g, mode, n)) {
-        snprintf(out, cap, g.sub_mean != 0.f ? "k_conv_u8_img<2, 4, 5, 16, true>" : "k_conv_u8_img<2, 4, 5, 16, false>");
+        if (conv1_bf16_ok(g, MODE_U8, n)) snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_u8_bf16<true>" : "k_conv1_u8_bf16<false>");
+        else snprintf(out, cap, g.sub_mean != 0.f ? "k_conv_u8_img<2, 4, 5, 16, true>" : "k_conv_u8_img<2, 4, 5, 16, false>");
     } else if (op == 0) {
         const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, split_k_allowed ? (int64_t)1 << 60 : 0);
         const bool big32 = p.splits == 1 && Mtot >= 256 * 2048;
