@@ -1168,6 +1168,24 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
     static const int glds_on = getenv("SF_WGRAD_GLDS") ? atoi(getenv("SF_WGRAD_GLDS")) : 1;
     int Zused = p.Z;
     static const int img_on = getenv("SF_CONV1_IMG") ? atoi(getenv("SF_CONV1_IMG")) : 1;
+    if (conv1_bf16_ok(g, mode, n) && N == 32 && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0 &&
+        ((uintptr_t)dout & 15) == 0) {
+        // exact products on the bf16 matrix pipe (sf_nn_u8.h): persistent blocks over sample pairs, one partial per block
+        const int npairs = (int)((n + 1) / 2);
+        int nb = npairs < 2 * num_cus() ? npairs : 2 * num_cus();
+        if (nb > Zws) nb = Zws;  // the workspace was sized for Zws partials
+        partial_b = partial_w + (int64_t)nb * K * N;
+        Zused = nb;
+        const unsigned lds_bytes = (unsigned)((2 * 4 * 20 * 4 * 36 + 3 * 32 * 168) * sizeof(uint16_t));
+        if (g.sub_mean != 0.f)
+            k_conv1_wgrad_bf16<true><<<dim3(nb), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
+                db ? partial_b : nullptr, (int)n, npairs);
+        else
+            k_conv1_wgrad_bf16<false><<<dim3(nb), dim3(256), lds_bytes, st>>>(
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
+                db ? partial_b : nullptr, (int)n, npairs);
+    } else
     if (img_on && conv1_img_ok(g, mode, n) && N == 32 && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0 &&
         ((uintptr_t)dout & 15) == 0) {
         // Nature-CNN conv1 on raw frames: strip-image kernel, persistent blocks, one partial per block
@@ -1301,7 +1319,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1, %d>", g.Cin, g.H, g.W, g.KH, g.S, g.OH);
         else snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
-        snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
+        if (conv1_bf16_ok(g, MODE_U8, n)) snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_bf16<true>" : "k_conv1_wgrad_bf16<false>");
+        else snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
     } else if (op == 1 && mode == MODE_F32 && wgrad_glds_wanted(Mtot, g.K, g.Cout) && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
         snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"

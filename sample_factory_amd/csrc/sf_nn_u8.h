@@ -203,3 +203,234 @@ void k_conv1_u8_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
                      float *__restrict__ out, int nsamples) {
     conv1_u8_bf16_body<SUB, 1>(g, in, in_stride, index, offset, w, bias, out, nsamples);
 }
+
+// ============================================================================================== WEIGHT GRADIENT, raw u8 frames
+// dW[(c, kh, kw)][n] = sum over output pixels m of x[m, (c, kh, kw)] * dY[m, n] with the same exact-product arithmetic:
+// x (pixel - integer mean) is a bf16 number, dY is split exactly into three bf16 terms, products are exact, accumulation
+// is f32 inside v_mfma_f32_16x16x32_bf16; 1/scale multiplies the finished sums.  The reduction index of the MFMA is the
+// output pixel: a lane's 8 reduction elements are two QUADS of 4 consecutive output pixels (ow0 = 0, 4, .., 16: five per
+// output row, nothing ragged), 8 quads = 32 pixels per instruction.
+//   * x along ow at fixed (c, kh, kw) is a stride-4 walk through the input row, so the strip image is stored
+//     DE-INTERLEAVED in LDS: img[smp][c][row][phase = x & 3][q = x >> 2] (bf16, line pitch 36): the 4 pixels of a quad for
+//     kw = phase are 4 contiguous elements at q = ow0 (one ds_read_b64), and for kw = 4 + phase the same line one
+//     element further (q = ow0 + 1): the 5th element is fetched with a ds_read_b32 and the fragment is formed with two
+//     v_alignbit — tiles are arranged so that the shift is uniform per tile (tile = (kh half, kw half), row i -> kh = 4*khalf
+//     + i/4, kw = 4*kwhalf + i%4).
+//   * dY is stored TRANSPOSED and split: dyT[term][n][pixel] (pitch 168), written as pixel PAIRS (one ds_write_b32); a
+//     lane's two quads are 8 consecutive pixel indices there: one ds_read_b128 per fragment.
+//   * wave w owns input channel c = w: 4 k-tiles x 2 n-tiles = 8 accumulator tiles, and walks ALL pixels of the strip
+//     (5 MFMA k-steps per strip of 2 samples x 80 pixels): no cross-wave reduction, one partial [256][32] per work-group
+//     (summed by k_reduce_partials in fixed order).  The bias gradient (column sums of dY) is taken from the f32 values
+//     on their way into LDS.
+template <bool SUB>
+__global__ __launch_bounds__(256, 2)
+void k_conv1_wgrad_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride, const int32_t *__restrict__ index,
+                        int64_t offset, const float *__restrict__ dy, float *__restrict__ partial,
+                        float *__restrict__ partial_b, int nsamples, int npairs) {
+    constexpr int SMP = 2, R = 4, H = 84, W = 84, Cin = 4, S = 4, OH = 20, OW = 20, OHOW = OH * OW, N = 32, K = 256;
+    constexpr int RS = (R - 1) * S + 8, W4 = W >> 2;
+    constexpr int WP2 = (W4 + 1) / 2, PAIRS = Cin * RS * WP2, NLD = (PAIRS + 255) / 256;  // word pairs (8 pixels) per thread
+    constexpr int QP = 36;                 // elements per (c, row, phase) line: 21 used; 18 dwords -> conflict-free b64 reads
+    constexpr int PIX = SMP * R * OW;      // 160 output pixels per strip
+    constexpr int DP = 168;                // dyT pitch (elements): 336 B, 16-byte aligned lines
+    constexpr int IMG_E = SMP * Cin * RS * 4 * QP;
+    constexpr int NDY = (PIX / 2 * (N / 4) + 255) / 256;  // (pixel pair, channel quad) items per thread: 3
+    constexpr int nstrips = OH / R;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem16[];
+    uint16_t *img = smem16;            // [SMP][Cin][RS][4][QP]
+    uint16_t *dyT = smem16 + IMG_E;    // [3][N][DP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kg = lane >> 4;
+    // ---- image word PAIRS of this thread: pair u -> (c, row, xp): words 2xp, 2xp+1 = pixels of phases 0..3 at q = 2xp,
+    // 2xp+1 (the 11th pair of a row has no second word: the first is used twice, q = 21 is never read)
+    int gofs[NLD], gofs2[NLD], lofs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        int u = tid + 256 * i;
+        const bool ok = u < PAIRS;
+        u = ok ? u : 0;
+        const int xp = u % WP2, t1 = u / WP2, row = t1 % RS, c = t1 / RS;
+        gofs[i] = (c * H + row) * W + xp * 8;
+        gofs2[i] = gofs[i] + (2 * xp + 1 < W4 ? 4 : 0);
+        lofs[i] = ok ? ((c * RS + row) * 4) * QP + 2 * xp : -1;
+    }
+    // ---- dY items of this thread: item e -> (pixel pair pp, channel quad n4); n4 = tid & 7 for every item
+    const int n4 = tid & 7;
+    // ---- fragment addressing, fixed per lane.  k-step s, half h: quad qd = 8*s + 2*kg + h -> pixel p0 = 4*qd
+    // A: lines of (khalf): kh = 4*khalf + (i16 >> 2), phase = i16 & 3
+    const int a_lane = ((wave * RS + (i16 >> 2)) * 4 + (i16 & 3)) * QP;  // + smp*Cin*RS*4*QP + (ohl*4 + 4*khalf)*4*QP + ow0
+    f32x4 acc[2][2][2];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+            for (int c_ = 0; c_ < 2; ++c_) acc[a_][b_][c_] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float colacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float sub = g.sub_mean;
+    // Operands are prefetched TWO strips ahead into two register sets (a strip's MFMA phase, ~1 us, is shorter than a
+    // loaded HBM round trip): unit u = (local pair, strip) uses set u & 1.
+    struct Regs { uint32_t pre[SMP][NLD][2]; f32x4 dpre[NDY][2]; };
+    const int my_pairs = (int)blockIdx.x < npairs ? (npairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total_units = my_pairs * nstrips;
+    auto load_strip = [&](int unit, Regs &rg) {
+        const int lp = unit / nstrips, st = unit - lp * nstrips;
+        const int pair = (int)blockIdx.x + lp * (int)gridDim.x;
+        const int rowoff = st * R * S * W;
+        bool sok[SMP];
+        int sidx[SMP];
+#pragma unroll
+        for (int z = 0; z < SMP; ++z) {
+            int sg = pair * SMP + z;
+            sok[z] = sg < nsamples;
+            sg = sok[z] ? sg : nsamples - 1;
+            sidx[z] = sg;
+            const uint8_t *sb = in + sample_base(g, index, offset, in_stride, (uint32_t)sg);  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                rg.pre[z][i][0] = *reinterpret_cast<const uint32_t *>(sb + rowoff + gofs[i]);
+                rg.pre[z][i][1] = *reinterpret_cast<const uint32_t *>(sb + rowoff + gofs2[i]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int e = it * 256 + tid, pp = e >> 3;           // pixel pair 0..79 (PIX/2), 40 per sample
+            const bool ok = pp < PIX / 2;
+            const int z = (ok && pp >= R * OW / 2) ? 1 : 0, pl = 2 * (pp - z * (R * OW / 2));
+            const bool live = ok && (z == 0 ? sok[0] : sok[1]);
+            const float *src = dy + ((int64_t)(z == 0 ? sidx[0] : sidx[1]) * OHOW + st * (R * OW) + pl) * N + n4 * 4;
+            rg.dpre[it][0] = live ? *reinterpret_cast<const f32x4 *>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rg.dpre[it][1] = live ? *reinterpret_cast<const f32x4 *>(src + N) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_strip = [&](const Regs &rg) {
+#pragma unroll
+        for (int z = 0; z < SMP; ++z)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                if (lofs[i] < 0) continue;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(img + z * Cin * RS * 4 * QP + lofs[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a8 = (float)((rg.pre[z][i][0] >> (8 * j)) & 0xFFu), b8 = (float)((rg.pre[z][i][1] >> (8 * j)) & 0xFFu);
+                    // integers of <= 8 significant bits: the upper halves of the f32 patterns ARE their bf16 forms
+                    dst[j * QP / 2] = __builtin_amdgcn_perm(__float_as_uint(SUB ? b8 - sub : b8),
+                                                            __float_as_uint(SUB ? a8 - sub : a8), 0x07060302u);
+                }
+            }
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int e = it * 256 + tid, pp = e >> 3;
+            if (pp >= PIX / 2) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v0 = rg.dpre[it][0][j], v1 = rg.dpre[it][1][j];
+                colacc[j] += v0 + v1;
+                // exact 3-way split of both values (see split3_bf16), the pair packed with one v_perm per term
+                const uint32_t b0 = __float_as_uint(v0), b1 = __float_as_uint(v1);
+                const float r0 = v0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = v1 - __uint_as_float(b1 & 0xFFFF0000u);
+                const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+                const float s0 = r0 - __uint_as_float(c0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(c1 & 0xFFFF0000u);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(dyT + (n4 * 4 + j) * DP + 2 * pp);
+                dst[0] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+                dst[N * DP / 2] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+                dst[2 * N * DP / 2] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+            }
+        }
+    };
+    auto mfma_phase = [&]() {
+#pragma unroll
+    for (int s = 0; s < PIX / 32; ++s) {
+        // this lane's two quads of the k-step
+        s16x8 afr[2][2], bfr[3][2];
+        uint32_t aw[2][2][3];  // [khalf][h][d0, d1, d2]
+        // B: the lane's two quads are 8 CONSECUTIVE pixel indices of dyT (it is indexed by the linear strip pixel)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                bfr[t][nt] = *reinterpret_cast<const s16x8 *>(
+                    __builtin_assume_aligned(dyT + (t * N + nt * 16 + i16) * DP + 8 * (4 * s + kg), 16));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p0 = 4 * (8 * s + 2 * kg + h);            // 0..156
+            const int smp = p0 / (R * OW), rem = p0 - smp * (R * OW), ohl = rem / OW, ow0 = rem - ohl * OW;
+            const uint16_t *ab = img + smp * Cin * RS * 4 * QP + a_lane + (ohl * S) * 4 * QP + ow0;
+#pragma unroll
+            for (int kh2 = 0; kh2 < 2; ++kh2) {
+                const uint16_t *ap = ab + kh2 * 4 * 4 * QP;
+                const uint2 d01 = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(ap, 8));
+                aw[kh2][h][0] = d01.x;
+                aw[kh2][h][1] = d01.y;
+                aw[kh2][h][2] = *reinterpret_cast<const uint32_t *>(__builtin_assume_aligned(ap + 4, 4));
+            }
+        }
+#pragma unroll
+        for (int kh2 = 0; kh2 < 2; ++kh2) {
+            uint32_t f0[4], f1[4];  // kw half 0: elements 0..3 of each quad; kw half 1: elements 1..4
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f0[2 * h] = aw[kh2][h][0];
+                f0[2 * h + 1] = aw[kh2][h][1];
+                f1[2 * h] = __builtin_amdgcn_alignbit(aw[kh2][h][1], aw[kh2][h][0], 16);
+                f1[2 * h + 1] = __builtin_amdgcn_alignbit(aw[kh2][h][2], aw[kh2][h][1], 16);
+            }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            afr[kh2][0] = __builtin_bit_cast(s16x8, (u32x4){f0[0], f0[1], f0[2], f0[3]});
+            afr[kh2][1] = __builtin_bit_cast(s16x8, (u32x4){f1[0], f1[1], f1[2], f1[3]});
+        }
+#pragma unroll
+        for (int t = 2; t >= 0; --t)
+#pragma unroll
+            for (int kh2 = 0; kh2 < 2; ++kh2)
+#pragma unroll
+                for (int kw2 = 0; kw2 < 2; ++kw2)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[kh2][kw2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, afr[kh2][kw2]), __builtin_bit_cast(bf16x8, bfr[t][nt]),
+                            acc[kh2][kw2][nt], 0, 0, 0);
+    }
+    };
+    Regs ra, rb;
+    if (total_units > 0) load_strip(0, ra);
+    if (total_units > 1) load_strip(1, rb);
+    auto step = [&](int unit, Regs &rg) {
+        store_strip(rg);
+        __syncthreads();
+        if (unit + 2 < total_units) load_strip(unit + 2, rg);
+        mfma_phase();
+        __syncthreads();  // img and dyT are free again
+    };
+    for (int unit = 0; unit < total_units; unit += 2) {
+        step(unit, ra);
+        if (unit + 1 < total_units) step(unit + 1, rb);
+    }
+    // ---- one partial per work-group: wave c writes its 64 weight rows.  C layout: col = lane & 15 -> n, row = 4*kg + r -> i
+    const float scl = g.inv_scale;
+    float *dst = partial + (int64_t)blockIdx.x * K * N;
+#pragma unroll
+    for (int kh2 = 0; kh2 < 2; ++kh2)
+#pragma unroll
+        for (int kw2 = 0; kw2 < 2; ++kw2)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = wave * 64 + (4 * kh2 + kg) * 8 + 4 * kw2 + r;  // i = 4*kg + r: kh = 4*khalf + i/4, kw = 4*kwhalf + i%4
+                    dst[k * N + nt * 16 + i16] = acc[kh2][kw2][nt][r] * scl;
+                }
+    if (partial_b) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem16);  // [256][4]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[tid * 4 + j] = colacc[j];
+        __syncthreads();
+        if (tid < N) {
+            float sum = 0.f;
+#pragma unroll 4
+            for (int part = 0; part < 32; ++part) sum += red[(part * 8 + (tid >> 2)) * 4 + (tid & 3)];
+            partial_b[(int64_t)blockIdx.x * N + tid] = sum;
+        }
+    }
+}

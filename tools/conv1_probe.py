@@ -47,6 +47,34 @@ def one():
         fl = 2.0 * n * 400 * 32 * K
         res.append(f"n={n}: {name} {ms * 1e3:8.1f} us = {fl / ms / 1e9:6.1f} TFLOP/s-equivalent, "
                    f"{(n * 28224 + n * 400 * 128) / ms / 1e6:6.0f} GB/s algorithmic, max err vs f64 {max(errs):.2e}")
+        # ---- weight / bias gradient of the same layer
+        nw = 512 if n == 4096 else n
+        dyv = (torch.randn((nw * 400, 32), generator=torch.Generator().manual_seed(n)) * 0.3).cuda()
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        ws = torch.empty(lib.conv_wgrad_workspace(nw, d), dtype=torch.uint8, device="cuda")
+        wname = lib.conv_kernel_name(1, nw, d)
+        gfn = lambda: lib.conv_wgrad(x[:nw], 4 * 84 * 84, None, 0, dyv, dw, db, nw, d, ws)
+        gfn()
+        torch.cuda.synchronize()
+        ns = min(nw, 512)   # float64 reference on a 512-sample launch of its own
+        dw2, db2 = torch.empty_like(w), torch.empty_like(b)
+        lib.conv_wgrad(x[:ns], 4 * 84 * 84, None, 0, dyv[:ns * 400], dw2, db2, ns, d, ws)
+        xin = ((x[:ns].double() - d.sub_mean) / 255.0).requires_grad_(False)
+        w64r = w64.clone().requires_grad_(True)
+        y = torch.nn.functional.conv2d(xin, w64r, None, stride=4)
+        gy = dyv[:ns * 400].double().view(ns, 400, 32).permute(0, 2, 1).reshape(ns, 32, 20, 20)
+        y.backward(gy)
+        want = w64r.grad.reshape(32, 256).t()
+        ew = float((dw2.double() - want).abs().max() / want.abs().max())
+        eb = float((db2.double() - gy.sum((0, 2, 3))).abs().max() / gy.sum((0, 2, 3)).abs().max())
+        e0.record()
+        for _ in range(reps):
+            gfn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res.append(f"   wgrad n={nw}: {wname} {ms * 1e3:8.1f} us = {2.0 * nw * 400 * 32 * K / ms / 1e9:6.1f} TFLOP/s-equivalent, "
+                   f"{(nw * 28224 + nw * 400 * 128) / ms / 1e6:6.0f} GB/s algorithmic, err vs f64 dW {ew:.2e} db {eb:.2e}")
     print("\n".join(res), flush=True)
 
 
