@@ -39,6 +39,22 @@ def kernel_flops(key):
     return 2.0 * n * OH * OW * Cout * (K * K * Cin)  # fwd, wgrad and (gather-form, no zero taps) dgrad are equal
 
 
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak
+
+
+def exact_bf16_kernel(name: str) -> bool:
+    """conv1 on raw u8 frames runs on the bf16 matrix pipe with EXACT products (csrc/sf_nn_u8.h): those launches are
+    bounded by HBM traffic, not by the f32-MFMA rate the other network kernels are priced against"""
+    return name.startswith("k_conv1_u8_bf16") or name.startswith("k_conv1_wgrad_bf16")
+
+
+def kernel_bytes(key):
+    """algorithmic HBM bytes of one launch of a conv1 kernel: the u8 frames once + the f32 output (forward) or output
+    gradient (weight gradient) once"""
+    op, n, Cin, H, W, Cout, K, S, OH, OW = key[:10]
+    return float(n) * (Cin * H * W + OH * OW * Cout * 4)
+
+
 def _free_port() -> int:
     import socket
     with socket.socket() as s_:
@@ -320,16 +336,29 @@ def main():
                 "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                 "gflop_per_launch": round(flops / launches / 1e9, 3),
                 "share_of_step_time": round(total_ms / (dt * 1e3), 4), "shapes": shapes}
+    if exact_bf16_kernel(dominant):  # HBM-bound kernel: algorithmic bytes per launch / launch duration against 8 TB/s
+        nbytes = sum(kernel_bytes(key) * len(evs) for key, evs in prof.items())
+        gbs = nbytes / (total_ms * 1e-3) / 1e9
+        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "gbytes_per_launch": round(nbytes / launches / 1e9, 4)})
+        roofline.pop("gflop_per_launch")
     net_ms = sum(k[0] for k in kern)
     net_flops = sum(kernel_flops(k[1]) * k[2] for k in kern)
     breakdown = [{"kernel": f"{k[1][0]}:{k[1][2]}x{k[1][3]}->{k[1][5]} n={k[1][1]}", "name": k[1][-1],
                   "ms_total": round(k[0], 2), "launches": k[2],
-                  "tflops": round(kernel_flops(k[1]) / (k[3] * 1e-3) / 1e12, 1)} for k in kern[:12]]
+                  "tflops": round(kernel_flops(k[1]) / (k[3] * 1e-3) / 1e12, 1),
+                  **({"arith": "exact products on the bf16 pipe (tflops = f32-equivalent)",
+                      "gbs": round(kernel_bytes(k[1]) / (k[3] * 1e-3) / 1e9, 0)} if exact_bf16_kernel(k[1][-1]) else {})}
+                 for k in kern[:14]]
 
     out = {
         "metric": metric, "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dtype_note": ("f32 storage, f32 accumulation everywhere; products: f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), "
+                       "except conv1 on raw u8 frames = v_mfma_f32_16x16x32_bf16 on operands that are EXACT in bf16 (u8 pixels; "
+                       "f32 weights / output gradients split exactly into 3 bf16 terms) - every product exact, no rounding of any "
+                       "operand (csrc/sf_nn_u8.h)") if args.workload != "c5" else "f32 (f32 MFMA, f32 accumulation)",
         "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
         "config": {"workload": workload_desc,
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,

@@ -348,3 +348,30 @@ def test_sample_factory_import_surface_resolves_to_this_engine():
                             "--async_rl=False", "--batch_size=512", f"--train_dir={ROOT}/gpurun_out/td_cpu"],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "no GPU visible" in r.stderr
+
+
+def test_three_term_bf16_split_is_exact():
+    """the operand split of csrc/sf_nn_u8.h (split3_bf16) restated in numpy: truncating an f32 to its upper 16 bits three
+    times (value, then the two residuals) yields three bf16 numbers whose sum IS the f32 — for every sign, exponent and
+    mantissa pattern; and every u8 value (and u8 - integer mean) is itself a bf16 number."""
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2 ** 32, size=200000, dtype=np.uint64).astype(np.uint32)
+    w = bits.view(np.float32)
+    w = w[np.isfinite(w) & (np.abs(w) > 1e-30) & (np.abs(w) < 1e30)]       # (terms below 2^-126 would be flushed by the MFMA)
+    w = np.concatenate([w, np.float32([1.0, -1.0, 1 / 255.0, 0.1, 3.1415927, 1e-8, 65504.0, 0.0])])
+
+    def trunc(v):
+        return (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    hi = trunc(w)
+    r1 = w - hi                      # exact: same exponent range, low 16 mantissa bits
+    mid = trunc(r1)
+    r2 = r1 - mid
+    lo = trunc(r2)
+    assert np.array_equal(r2, lo), "the third term is already a bf16 number"
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), w.astype(np.float64))
+    for t in (hi, mid, lo):          # bf16 = an f32 whose low 16 bits are zero
+        assert not np.any(t.view(np.uint32) & np.uint32(0xFFFF))
+    px = np.arange(256, dtype=np.float32)
+    for mean in (0.0, 128.0, 255.0):
+        assert np.array_equal(trunc(px - np.float32(mean)), px - np.float32(mean))

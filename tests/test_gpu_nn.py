@@ -296,6 +296,44 @@ def test_conv1_lds_image_kernel_vs_torch(lib, geom, n, mean):
     assert (db.cpu().double() - br.grad.double()).abs().max().item() < 3e-5 * max(1.0, br.grad.abs().max().item())
 
 
+def test_conv1_exact_product_kernels_on_integers(lib):
+    """csrc/sf_nn_u8.h: u8 pixels are bf16 numbers and f32 weights / output gradients are split EXACTLY into three bf16
+    terms, so every product is exact and only the f32 accumulation rounds.  With integer-valued weights (|w| <= 64, 1/scale
+    = 1, integer mean) every partial sum is an integer below 2^24: forward output, weight gradient and bias gradient must
+    then equal the integer convolution EXACTLY; with full-mantissa weights the error against float64 stays at the
+    accumulation level (a few 1e-7 of the largest value)."""
+    n, Cin, H, W, Cout, K, S = 260, 4, 84, 84, 32, 8, 4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (n, Cin, H, W), generator=g, dtype=torch.uint8)
+    d = desc(lib, Cin, H, W, Cout, K, S, in_u8=1, sub_mean=128.0, inv_scale=1.0, relu=0)
+    assert lib.conv_kernel_name(0, n, d).startswith("k_conv1_u8_bf16") and lib.conv_kernel_name(1, n, d).startswith("k_conv1_wgrad_bf16")
+    w_int = torch.randint(-64, 65, (Cout, Cin, K, K), generator=g).float()
+    b_int = torch.randint(-100, 101, (Cout,), generator=g).float()
+    out = torch.empty((n * 400, Cout), device="cuda")
+    lib.conv_fwd(x.cuda(), Cin * H * W, None, 0, to_kmajor(w_int, 1).cuda(), b_int.cuda(), out, n, d)
+    ref = F.conv2d(x.double() - 128.0, w_int.double(), b_int.double(), stride=S)     # |sum| <= 256*128*64 < 2^24: exact in f32
+    got = out.view(n, 20, 20, Cout).permute(0, 3, 1, 2).cpu().double()
+    assert torch.equal(got, ref)
+    dy_int = torch.randint(-3, 4, (n, Cout, 20, 20), generator=g).float()          # |dW| <= 260*400*128*3 < 2^27: sums of
+    dyd = dy_int.permute(0, 2, 3, 1).contiguous().cuda().view(n * 400, Cout)       # integers, exact while below 2^24 -> use 64 samples
+    m = 64
+    dw, db = torch.zeros((Cin * K * K, Cout), device="cuda"), torch.zeros(Cout, device="cuda")
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    xs = torch.cat([x[:m], torch.zeros((n - m, Cin, H, W), dtype=torch.uint8) + 128]).cuda()   # x - mean = 0 beyond the first m samples
+    lib.conv_wgrad(xs, Cin * H * W, None, 0, dyd, dw, db, n, d, ws)
+    wr = torch.zeros((Cout, Cin, K, K), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[:m].double() - 128.0, wr, None, stride=S).backward(dy_int[:m].double())
+    assert torch.equal(from_kmajor(dw.cpu().double(), Cout, Cin, K, K, 1), wr.grad)
+    assert torch.equal(db.cpu().double(), dy_int.double().sum((0, 2, 3)))
+    # full-mantissa weights, 1/255 scale: only the f32 accumulation (and the one multiplication by 1/scale) rounds
+    d2 = desc(lib, Cin, H, W, Cout, K, S, in_u8=1, sub_mean=0.0, inv_scale=float(np.float32(1 / 255.0)), relu=0)
+    w_f = torch.randn((Cout, Cin, K, K), generator=g) / 16
+    lib.conv_fwd(x.cuda(), Cin * H * W, None, 0, to_kmajor(w_f, 1).cuda(), b_int.cuda() * 0, out, n, d2)
+    ref = F.conv2d(x.double() * float(np.float32(1 / 255.0)), w_f.double(), None, stride=S)
+    got = out.view(n, 20, 20, Cout).permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref).abs().max().item() < 6e-7 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64)])
 def test_linear_fwd_bwd_vs_torch(lib, M, K, N):
     g = torch.Generator().manual_seed(M + K + N)
