@@ -319,7 +319,7 @@ def main():
     achieved = flops / (total_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (tools/profile_round.sh + tools/pmc_traffic.py), newest first
-    for tname in ("r02_traffic.json", "r01_traffic.json"):
+    for tname in ("r02_b_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         tj = os.path.join(ROOT, "profiles", tname)
         ent = json.load(open(tj)).get(dominant) if os.path.exists(tj) else None
         if ent:
