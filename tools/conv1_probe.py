@@ -21,7 +21,7 @@ def one():
     K = 256
     w = (torch.randn((K, 32), generator=g) / 16).cuda()
     b = (torch.randn(32, generator=g) * 0.1).cuda()
-    res = [f"SF_CONV1_BF16={os.environ.get('SF_CONV1_BF16', '1')} QUAD={os.environ.get('SF_CONV1_BF16_QUAD', '0')} sub={d.sub_mean}"]
+    res = [f"SF_CONV1_BF16={os.environ.get('SF_CONV1_BF16', '1')} sub={d.sub_mean}"]
     for n in (4096, 32768):
         x = torch.randint(0, 256, (n, 4, 84, 84), dtype=torch.uint8, generator=g).cuda()
         out = torch.empty((n * 400, 32), device="cuda")
@@ -82,7 +82,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         one()
     else:
-        for bf, quad in (("1", "0"), ("0", "0")):
+        for bf in ("1", "0"):
             for sub in ("0", "128"):
                 subprocess.run([sys.executable, os.path.abspath(__file__), "one"],
-                               env=dict(os.environ, SF_CONV1_BF16=bf, SF_CONV1_BF16_QUAD=quad, SUB=sub))
+                               env=dict(os.environ, SF_CONV1_BF16=bf, SUB=sub))
