@@ -277,7 +277,12 @@ typedef struct {
  * (index ? index[i] : offset+i) * in_sample_stride (elements).  out f32 NHWC [n,OH,OW,Cout].
  * workspace (optional, >= sf_conv_fwd_workspace bytes, 16-byte aligned): lets small launches (e.g. the 3136->512
  * layer at inference batch 4096: 256 tiles for 256 CUs) split the reduction over gridDim.z and finish with a
- * deterministic ordered sum (+bias, ReLU); NULL = never split. */
+ * deterministic ordered sum (+bias, ReLU); NULL = never split.
+ * Arithmetic: f32 operands, f32 accumulation on the f32 matrix instructions.  One dispatch differs: the Nature-CNN
+ * first layer on raw u8 frames (in_u8, 4x84x84, 8x8 stride 4, Cout <= 32, n >= 256, integer sub_mean in [0, 255]) runs
+ * sf_conv_fwd / sf_conv_wgrad on the bf16 matrix instruction with operands that are EXACT in bf16 (pixel - mean; the f32
+ * weights / output gradients split exactly into three bf16 terms): every product is exact, accumulation is f32, and
+ * inv_scale multiplies the accumulated sum (csrc/sf_nn_u8.h; SF_CONV1_BF16=0 selects the f32 kernels). */
 int64_t sf_conv_fwd_workspace(int64_t n, const sf_conv_desc *h_desc);
 int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *w,
                 const float *bias, float *out, int64_t n, const sf_conv_desc *h_desc, void *workspace,
