@@ -494,10 +494,10 @@ class Learner:
         rnn = None
         if cfg.use_rnn:  # learner.py:557-569: chunk-start states, done-or-invalid boundaries (masked-loop BPTT)
             R, Cn = cfg.recurrence, n // cfg.recurrence
-            rows = index.long() if index is not None else torch.arange(offset, offset + n, device=self.device)
-            doi = (buff.dones[rows] | ~buff.valids[rows]).view(Cn, R)
-            rnn = dict(R=R, h0=buff.rnn_states.index_select(0, rows.view(Cn, R)[:, 0]),
-                       keep_tm=(~doi).t().contiguous().float())
+            keep_tm = ac._buf(("rnn", "keep_tm"), (R, Cn))
+            h0 = ac._buf(("rnn", "h0"), (Cn, buff.rnn_states.shape[1]))
+            lib.rnn_chunk_setup(buff.dones, buff.valids, buff.rnn_states, index, offset, Cn, R, keep_tm, h0)
+            rnn = dict(R=R, h0=h0, keep_tm=keep_tm)
         acts = ac.forward_heads(buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
                                 traj_T=buff.T, tag="train", rnn=rnn)
         heads = acts[-1]

@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 8; }
+extern "C" int sf_abi_version(void) { return 9; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -1912,6 +1912,41 @@ extern "C" int sf_rnn_store_state(const float *h, const float *c, const uint8_t 
     k_rnn_store_state<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(h, c, dones, done_stride, out,
                                                                                              out_stride, B, H);
     return sf_launch_status("sf_rnn_store_state");
+}
+
+// training pass of a recurrent model over a minibatch of Cn chunks of R consecutive dataset rows (learner.py:557-569,
+// rnn_utils.py:59-105): chunk c starts at dataset row r0 = index ? index[c*R] : offset + c*R.  One launch instead of the
+// torch op sequence {arange, gathers, ~, |, transpose, float, index_select}:
+//   keep_tm[t][c] = !(dones[r0 + t] | !valids[r0 + t])      (state is zeroed AFTER a done / invalid step)
+//   h0[c][:]      = rnn_states[r0][:]                       (the state the chunk's first step was collected with)
+__global__ __launch_bounds__(256) void k_rnn_chunk_setup(const uint8_t *__restrict__ dones,
+                                                         const uint8_t *__restrict__ valids,
+                                                         const float *__restrict__ rnn_states,
+                                                         const int32_t *__restrict__ index, int64_t offset, int Cn,
+                                                         int R, int S, float *__restrict__ keep_tm,
+                                                         float *__restrict__ h0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nk = (int64_t)Cn * R;
+    if (i < nk) {  // i = t * Cn + c
+        const int t = (int)(i / Cn), c = (int)(i - (int64_t)t * Cn);
+        const int64_t row = index ? (int64_t)index[(int64_t)c * R + t] : offset + (int64_t)c * R + t;
+        keep_tm[i] = (dones[row] || !valids[row]) ? 0.0f : 1.0f;
+    } else if (i < nk + (int64_t)Cn * S) {
+        const int64_t j = i - nk;
+        const int c = (int)(j / S), e = (int)(j - (int64_t)c * S);
+        const int64_t row = index ? (int64_t)index[(int64_t)c * R] : offset + (int64_t)c * R;
+        h0[j] = rnn_states[row * S + e];
+    }
+}
+
+extern "C" int sf_rnn_chunk_setup(const uint8_t *dones, const uint8_t *valids, const float *rnn_states,
+                                  const int32_t *index, int64_t offset, int Cn, int R, int S, float *keep_tm, float *h0,
+                                  void *stream) {
+    SF_REQUIRE(dones && valids && rnn_states && keep_tm && h0 && Cn > 0 && R > 0 && S > 0, "sf_rnn_chunk_setup: bad args");
+    const int64_t tot = (int64_t)Cn * R + (int64_t)Cn * S;
+    k_rnn_chunk_setup<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
+        dones, valids, rnn_states, index, offset, Cn, R, S, keep_tm, h0);
+    return sf_launch_status("sf_rnn_chunk_setup");
 }
 
 // y[c, :] = (a[c, :] + b[c, :]) * keep[c]    (carry of dL/dh across a step boundary; b or keep may be NULL)

@@ -38,7 +38,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
@@ -275,6 +275,17 @@ def rnn_store_state(h, c, dones_col, out) -> None:
     _check(load().sf_rnn_store_state(ptr(h, "f32", "h"), ptr(c, "f32", "c"), C.c_void_p(dones_col.data_ptr()),
                                      i64(dones_col.stride(0)), _raw(out, "f32", "out"), i64(out.stride(0)), i64(B), int(H),
                                      stream()), "sf_rnn_store_state")
+
+
+def rnn_chunk_setup(dones, valids, rnn_states, index, offset, Cn, R, keep_tm, h0) -> None:
+    """chunk-start states and done-or-invalid boundaries of a recurrent minibatch in one launch (see sf_hip.h)"""
+    S = rnn_states.shape[1]
+    if not rnn_states.is_contiguous() or keep_tm.shape != (R, Cn) or h0.shape != (Cn, S):
+        raise SfHipError("rnn_chunk_setup: rnn_states must be contiguous [rows, S], keep_tm [R, Cn], h0 [Cn, S]")
+    _check(load().sf_rnn_chunk_setup(ptr(dones, "u8", "dones"), ptr(valids, "u8", "valids"),
+                                     ptr(rnn_states, "f32", "rnn_states"), ptr(index, "i32"), i64(offset), int(Cn),
+                                     int(R), int(S), ptr(keep_tm, "f32", "keep_tm"), ptr(h0, "f32", "h0"), stream()),
+           "sf_rnn_chunk_setup")
 
 
 def lstm_seq_supported(Cn: int, H: int) -> bool:
