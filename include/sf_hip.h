@@ -335,9 +335,13 @@ int sf_rnn_chunk_setup(const uint8_t *dones, const uint8_t *valids, const float 
  * both gx and h W_hh^T + b_hh); the carries of dL/dh and dL/dc live in registers.  Cn <= 8 * 256 rows. */
 int sf_lstm_seq_supported(int Cn, int H);
 int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates, float *hprev,
-                    float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H, void *stream);
+                    float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H, int env_major,
+                    void *stream);
 int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout, const float *keep,
-                    const float *whh, float *dgx, uint32_t *sync, int R, int Cn, int H, void *stream);
+                    const float *whh, float *dgx, uint32_t *sync, int R, int Cn, int H, int env_major, void *stream);
+/* env_major (all four passes): hout / dout are [Cn][R][H] — the row order of the minibatch (chunk c, step t = row c*R + t
+ * of the core's output and of its gradient) — instead of time-major [R][Cn][H]: the caller needs no transpose copies
+ * around the pass.  Everything else stays time-major. */
 
 /* the same two passes for a GRU-512 core (the reference's DEFAULT: cfg rnn_type=gru, rnn_size=512; model/core.py:19-64).
  * gx [R][Cn][3H], whh [H][3H], bhh [3H] (torch gate order r,z,n); gates [R][Cn][4H] = {r, z, n, hn} with
@@ -346,9 +350,9 @@ int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, c
  * and dgh [R][Cn][3H] = {dr, dz, dn * r} (gradient of h W_hh^T + b_hh: W_hh / b_hh, and the hand-off payload of the
  * pass); the direct path dL/dh_prev += dh * z and the carry stay in registers.  Supported shapes: sf_lstm_seq_supported. */
 int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates, float *hprev,
-                   float *hout, uint32_t *sync, int R, int Cn, int H, void *stream);
+                   float *hout, uint32_t *sync, int R, int Cn, int H, int env_major, void *stream);
 int sf_gru_seq_bwd(const float *dout, const float *gates, const float *hprev, const float *keep, const float *whh,
-                   float *dgx, float *dgh, uint32_t *sync, int R, int Cn, int H, void *stream);
+                   float *dgx, float *dgh, uint32_t *sync, int R, int Cn, int H, int env_major, void *stream);
 
 /* ---- data-parallel learner replicas (SURVEY.md §8(b) "DP -> sf_allreduce_grads", §8(e)) ----------------------------
  * New capability: the reference runs ONE learner per policy (algo/utils/shared_buffers.py:26-32), so these replace no

@@ -72,6 +72,7 @@ struct LstmSeqFwd {
     float *gates, *hprev, *hout, *cprev, *cout;
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
+    int64_t ho_rs, ho_ts;  // hout element (row, t) lives at row*ho_rs + t*ho_ts (+ unit): [R][Cn][H] or [Cn][R][H]
 };
 
 // JB hidden units per work-group, H = 8192 / JB (so that the W_hh slice fills ~129 KB of LDS): JB = 16 <-> H = 512.
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
                         const int j = j0 + u * 16 + c;
                         float *go = p.gates + tr * G4 + j;
                         go[0] = sv[sub][i][u][0]; go[H] = sv[sub][i][u][1]; go[2 * H] = sv[sub][i][u][2]; go[3 * H] = sv[sub][i][u][3];
-                        p.hout[tr * H + j] = sv[sub][i][u][4];
+                        p.hout[(int64_t)row * p.ho_rs + (int64_t)t * p.ho_ts + j] = sv[sub][i][u][4];
                         p.cout[tr * H + j] = sv[sub][i][u][5];
                         p.cprev[(tr + Cn) * H + j] = cst[sub][i][u];
                     }
@@ -241,6 +242,7 @@ struct LstmSeqBwd {
     float *dgx;
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
+    int64_t do_rs, do_ts;  // dout element (row, t) lives at row*do_rs + t*do_ts (+ unit)
     int ablate;  // timing experiments only (SF_LSTM_ABLATE, tools/lstm_bench.py): 1 no hand-off wait, 2 no phase-B loads,
                  // 4 no phase-B MFMAs, 8 no phase A — results are wrong with any bit set
 };
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
                     const int j = j0 + u * 16 + c;
                     const float *go = p.gates + tr * G4 + j;
                     pg[sub][i][u][0] = go[0]; pg[sub][i][u][1] = go[H]; pg[sub][i][u][2] = go[2 * H]; pg[sub][i][u][3] = go[3 * H];
-                    pdo[sub][i][u] = p.dout[tr * H + j];
+                    pdo[sub][i][u] = p.dout[(int64_t)r * p.do_rs + (int64_t)t * p.do_ts + j];
                     pco[sub][i][u] = p.cout[tr * H + j];
                     pcp[sub][i][u] = p.cprev[tr * H + j];
                 }
@@ -411,6 +413,7 @@ struct GruSeqFwd {
     float *gates, *hprev, *hout;
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
+    int64_t ho_rs, ho_ts;
 };
 
 template <int JB, int NSUB>
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
                         const int j = j0 + u * 16 + c;
                         float *go = p.gates + tr * G4 + j;
                         go[0] = sv[sub][i][u][0]; go[H] = sv[sub][i][u][1]; go[2 * H] = sv[sub][i][u][2]; go[3 * H] = sv[sub][i][u][3];
-                        p.hout[tr * H + j] = sv[sub][i][u][4];
+                        p.hout[(int64_t)row * p.ho_rs + (int64_t)t * p.ho_ts + j] = sv[sub][i][u][4];
                     }
                 }
             }
@@ -563,6 +566,7 @@ struct GruSeqBwd {
     float *dgx, *dgh;
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
+    int64_t do_rs, do_ts;
 };
 
 template <int JB, int NSUB>
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_bwd(GruSeqBwd p) {
                     const int j = j0 + u * 16 + c;
                     const float *go = p.gates + tr * G4 + j;
                     pg[sub][i][u][0] = go[0]; pg[sub][i][u][1] = go[H]; pg[sub][i][u][2] = go[2 * H]; pg[sub][i][u][3] = go[3 * H];
-                    pdo[sub][i][u] = p.dout[tr * H + j];
+                    pdo[sub][i][u] = p.dout[(int64_t)r * p.do_rs + (int64_t)t * p.do_ts + j];
                     php[sub][i][u] = p.hprev[tr * H + j];
                 }
             }
@@ -741,7 +745,7 @@ extern "C" int sf_lstm_seq_supported(int Cn, int H) {
 
 extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
                                float *hprev, float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H,
-                               void *stream) {
+                               int env_major, void *stream) {
     SF_REQUIRE(gx && whh && bhh && keep && gates && hprev && hout && cprev && cout && sync && R > 0 && Cn > 0,
                "sf_lstm_seq_fwd: bad args");
     int ng, rpg, jb;
@@ -749,7 +753,9 @@ extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *b
     SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_fwd: state buffer exceeds 2 GiB");
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_fwd memset");
     if (rc) return rc;
-    LstmSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, ng, rpg};
+    // hout [R][Cn][H] (time-major) or, env_major, [Cn][R][H] = the row order of the minibatch itself (no transpose copy)
+    LstmSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, ng, rpg,
+                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;  // 64-row sub-tiles per work-group, unrolled at compile time (register-resident state)
     if (nsub == 1) k_lstm_seq_fwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
@@ -760,7 +766,7 @@ extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *b
 
 extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout,
                                const float *keep, const float *whh, float *dgx, uint32_t *sync, int R, int Cn, int H,
-                               void *stream) {
+                               int env_major, void *stream) {
     SF_REQUIRE(dout && gates && cprev && cout && keep && whh && dgx && sync && R > 0 && Cn > 0,
                "sf_lstm_seq_bwd: bad args");
     int ng, rpg, jb;
@@ -769,7 +775,8 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_bwd memset");
     if (rc) return rc;
     static const int ablate = getenv("SF_LSTM_ABLATE") ? atoi(getenv("SF_LSTM_ABLATE")) : 0;
-    LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ng, rpg, ablate};
+    LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ng, rpg,
+                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H, ablate};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;
     if (nsub == 1) k_lstm_seq_bwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
@@ -779,14 +786,16 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
 }
 
 extern "C" int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
-                              float *hprev, float *hout, uint32_t *sync, int R, int Cn, int H, void *stream) {
+                              float *hprev, float *hout, uint32_t *sync, int R, int Cn, int H, int env_major,
+                              void *stream) {
     SF_REQUIRE(gx && whh && bhh && keep && gates && hprev && hout && sync && R > 0 && Cn > 0, "sf_gru_seq_fwd: bad args");
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_gru_seq_fwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_fwd: state buffer exceeds 2 GiB");
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_fwd memset");
     if (rc) return rc;
-    GruSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, ng, rpg};
+    GruSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, ng, rpg,
+                env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;
     if (nsub == 1) k_gru_seq_fwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
@@ -797,14 +806,15 @@ extern "C" int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bh
 
 extern "C" int sf_gru_seq_bwd(const float *dout, const float *gates, const float *hprev, const float *keep,
                               const float *whh, float *dgx, float *dgh, uint32_t *sync, int R, int Cn, int H,
-                              void *stream) {
+                              int env_major, void *stream) {
     SF_REQUIRE(dout && gates && hprev && keep && whh && dgx && dgh && sync && R > 0 && Cn > 0, "sf_gru_seq_bwd: bad args");
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_gru_seq_bwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)R * Cn * 3 * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_bwd: gate-gradient buffer exceeds 2 GiB");
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_bwd memset");
     if (rc) return rc;
-    GruSeqBwd p{dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, ng, rpg};
+    GruSeqBwd p{dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, ng, rpg,
+                env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;
     if (nsub == 1) k_gru_seq_bwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);

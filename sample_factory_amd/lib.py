@@ -303,36 +303,38 @@ def _seq_key(op, R, Cn, H, steps, G=4):
     return (op, int(steps * Cn), int(H), 1, 1, int(G * H), 1, 1, 1, 1, f"k_{op.split('_')[0]}_seq_{op.split('_')[1]}<16, {nsub}>")
 
 
-def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H) -> None:
+def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H, env_major=False) -> None:
     with _timed(_seq_key("lstm_fwd", R, Cn, H, R)):
         _check(load().sf_lstm_seq_fwd(ptr(gx, "f32", "gx"), ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"),
                                       ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
                                       ptr(hout, "f32", "hout"), ptr(cprev, "f32", "cprev"), ptr(cout, "f32", "cout"),
-                                      ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_fwd")
+                                      ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), int(bool(env_major)), stream()),
+               "sf_lstm_seq_fwd")
 
 
-def lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, H) -> None:
+def lstm_seq_bwd(dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, H, env_major=False) -> None:
     with _timed(_seq_key("lstm_bwd", R, Cn, H, R - 1)):
         _check(load().sf_lstm_seq_bwd(ptr(dout, "f32", "dout"), ptr(gates, "f32", "gates"), ptr(cprev, "f32", "cprev"),
                                       ptr(cout, "f32", "cout"), ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"),
                                       ptr(dgx, "f32", "dgx"),
-                                      ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), stream()), "sf_lstm_seq_bwd")
+                                      ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), int(bool(env_major)), stream()),
+               "sf_lstm_seq_bwd")
 
 
-def gru_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H) -> None:
+def gru_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H, env_major=False) -> None:
     with _timed(_seq_key("gru_fwd", R, Cn, H, R, 3)):
         _check(load().sf_gru_seq_fwd(ptr(gx, "f32", "gx"), ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"),
                                      ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
                                      ptr(hout, "f32", "hout"), ptr(sync, "i32", "sync"), int(R), int(Cn), int(H),
-                                     stream()), "sf_gru_seq_fwd")
+                                     int(bool(env_major)), stream()), "sf_gru_seq_fwd")
 
 
-def gru_seq_bwd(dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, H) -> None:
+def gru_seq_bwd(dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, H, env_major=False) -> None:
     with _timed(_seq_key("gru_bwd", R, Cn, H, R - 1, 3)):
         _check(load().sf_gru_seq_bwd(ptr(dout, "f32", "dout"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
                                      ptr(keep, "f32", "keep"), ptr(whh, "f32", "whh"), ptr(dgx, "f32", "dgx"),
                                      ptr(dgh, "f32", "dgh"), ptr(sync, "i32", "sync"), int(R), int(Cn), int(H),
-                                     stream()), "sf_gru_seq_bwd")
+                                     int(bool(env_major)), stream()), "sf_gru_seq_bwd")
 
 
 def rows_add_scale(a, b, keep, Cn, H, y) -> None:

@@ -573,30 +573,33 @@ class ActorCritic:
         GH = Lh.N
         gates = self._buf((tag, "gates"), (R, Cn, 4 * H))
         Hprev = self._buf((tag, "Hprev"), (R + 1, Cn, H))
-        Hout = self._buf((tag, "Hout"), (R, Cn, H))
         Cprev = self._buf((tag, "Cprev"), (R + 1, Cn, H)) if kind == 1 else None
         Cout = self._buf((tag, "Cout"), (R, Cn, H)) if kind == 1 else None
         Hprev[0].copy_(h0[:, :H])
         if kind == 1:
             Cprev[0].copy_(h0[:, H:])
         GXv = GX.view(R, Cn, GH)
+        out = self._buf((tag, "core_out"), (n, H))
         fused = _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
-        if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS
+        if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS; the
+            # core output is written in the minibatch's own row order (chunk-major), no transpose copy
             sync = self._buf((tag, "seq_sync"), (192,), dtype=torch.int32)
             if kind == 1:
-                lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, Hout, Cprev, Cout, sync, R, Cn, H)
+                lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, Cprev, Cout, sync, R, Cn, H, env_major=True)
             else:
-                lib.gru_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, Hout, sync, R, Cn, H)
+                lib.gru_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, sync, R, Cn, H, env_major=True)
             self._seq_sync = sync
-        gh = self._buf((tag, "gh_seq"), (Cn, GH)) if not fused else None
-        for t in range(0 if fused else R):
+            self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=True)
+            return out
+        Hout = self._buf((tag, "Hout"), (R, Cn, H))
+        gh = self._buf((tag, "gh_seq"), (Cn, GH))
+        for t in range(R):
             lib.conv_fwd_raw(Hprev[t], H, None, 0, Lh.w, Lh.b, gh, Cn, Lh.desc)
             lib.rnn_cell_fwd(kind, GXv[t], gh, Hprev[t], H, Cprev[t] if kind == 1 else None, H, keep[t], Cn, H,
                              gates[t], Hout[t], Cout[t] if kind == 1 else None, Hprev[t + 1],
                              Cprev[t + 1] if kind == 1 else None)
-        out = self._buf((tag, "core_out"), (n, H))
         out.view(Cn, R, H).copy_(Hout.transpose(0, 1))
-        self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=fused)
+        self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=False)
         return out
 
     def _rnn_sequence_bwd(self, li, d_core, n):
@@ -605,21 +608,22 @@ class ActorCritic:
         sv = self._rnn_saved
         R, Cn, keep = sv["R"], sv["Cn"], sv["keep"]
         GH = Lh.N
-        dOut = self._buf(("g", "dOut_tm"), (R, Cn, H))
-        dOut.copy_(d_core.view(Cn, R, H).transpose(0, 1))
         dGX = self._buf(("g", "dGX"), (R, Cn, GH))
         if sv.get("fused"):  # the whole backward time loop in one persistent launch (cell backward + W_hh^T product + carries)
             sync = self._buf(("g", "seq_sync"), (192,), dtype=torch.int32)
             dGH = dGX
+            dOut = d_core if d_core.is_contiguous() else d_core.contiguous()  # read in the minibatch's row order
             if kind == 1:
-                lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, sync, R, Cn, H)
+                lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, sync, R, Cn, H, env_major=True)
             else:  # GRU: the candidate gate's recurrent part is scaled by r -> W_hh sees its own gate gradients
                 dGH = self._buf(("g", "dGH"), (R, Cn, GH))
-                lib.gru_seq_bwd(dOut, sv["gates"], sv["Hprev"], keep, Lh.w, dGX, dGH, sync, R, Cn, H)
+                lib.gru_seq_bwd(dOut, sv["gates"], sv["Hprev"], keep, Lh.w, dGX, dGH, sync, R, Cn, H, env_major=True)
             self._seq_sync_bwd = sync
             ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
             lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
             return dGX.view(n, GH)
+        dOut = self._buf(("g", "dOut_tm"), (R, Cn, H))
+        dOut.copy_(d_core.view(Cn, R, H).transpose(0, 1))
         dGH = self._buf(("g", "dGH"), (R, Cn, GH)) if kind == 0 else dGX
         dh = self._buf(("g", "dh"), (Cn, H))
         dh_direct = self._buf(("g", "dh_direct"), (Cn, H)) if kind == 0 else None

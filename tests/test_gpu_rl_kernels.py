@@ -662,6 +662,14 @@ def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R):
     want = gx64.grad
     scale = float(want.abs().max())
     np.testing.assert_allclose(dgx.cpu().double().numpy(), want.numpy(), atol=2e-6 * scale, rtol=5e-5)
+    # env_major: hout / dout in the minibatch's own row order [Cn][R][H] — same numbers, no transpose copies around the pass
+    hout_em = torch.full((Cn, R, H), 7.0, device="cuda")
+    hprev2, cprev2 = hprev.clone(), cprev.clone()
+    lib.lstm_seq_fwd(d(gx), d(whh), d(bhh), d(keep), gates, hprev2, hout_em, cprev2, cout, sync, R, Cn, H, env_major=True)
+    assert torch.equal(hout_em, hout.transpose(0, 1).contiguous()) and torch.equal(hprev2, hprev)
+    dgx2 = torch.full_like(dgx, 7.0)
+    lib.lstm_seq_bwd(d(dout).transpose(0, 1).contiguous(), gates, cprev, cout, d(keep), d(whh), dgx2, sync, R, Cn, H, env_major=True)
+    assert torch.equal(dgx2, dgx)
 
 
 @pytest.mark.parametrize("Cn,R", [(512, 6), (200, 4), (2048, 3), (16, 5)])
@@ -720,6 +728,13 @@ def test_fused_gru_sequence_passes_vs_torch_fp64(lib, Cn, R):
     for name, got, want in [("dgx", dgx, gx64.grad), ("dgh", dgh, gh_probe.grad)]:
         scale = float(want.abs().max())
         np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), atol=2e-6 * scale, rtol=5e-5, err_msg=name)
+    hout_em = torch.full((Cn, R, H), 7.0, device="cuda")
+    hprev2 = hprev.clone()
+    lib.gru_seq_fwd(d(gx), d(whh), d(bhh), d(keep), gates, hprev2, hout_em, sync, R, Cn, H, env_major=True)
+    assert torch.equal(hout_em, hout.transpose(0, 1).contiguous()) and torch.equal(hprev2, hprev)
+    dgx2, dgh2 = torch.full_like(dgx, 7.0), torch.full_like(dgh, 7.0)
+    lib.gru_seq_bwd(d(dout).transpose(0, 1).contiguous(), gates, hprev, d(keep), d(whh), dgx2, dgh2, sync, R, Cn, H, env_major=True)
+    assert torch.equal(dgx2, dgx) and torch.equal(dgh2, dgh)
 
 
 def test_synthetic_continuous_env_kernel_rules(lib):
