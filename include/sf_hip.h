@@ -317,9 +317,10 @@ int sf_rnn_store_state(const float *h, const float *c, const uint8_t *dones, int
 /* training pass of a recurrent model (learner.py:557-569, rnn_utils.py:59-105): minibatch = Cn chunks of R consecutive
  * dataset rows, chunk c starting at row index[c*R] (index != NULL: a permuted minibatch, every chunk's R rows consecutive
  * in it) or offset + c*R.  keep_tm [R][Cn] f32 = 0 where the step is done or invalid (the state is zeroed after it), else
- * 1; h0 [Cn][S] = rnn_states[chunk start] (dones / valids: u8 per dataset row; rnn_states [rows][S] f32). */
+ * 1; h0 [Cn][S] = rnn_states[chunk start] (dones / valids: u8 per dataset row; rnn_states [rows][S] f32, or — traj_T > 0 —
+ * the slab itself, [E][traj_T + 1][S] read in place: dataset row e*T+t is slab row e*(T+1)+t, no compaction copy). */
 int sf_rnn_chunk_setup(const uint8_t *dones, const uint8_t *valids, const float *rnn_states, const int32_t *index,
-                       int64_t offset, int Cn, int R, int S, float *keep_tm, float *h0, void *stream);
+                       int64_t offset, int Cn, int R, int S, int traj_T, float *keep_tm, float *h0, void *stream);
 
 /* ---- fused LSTM sequence passes (config 5: LSTM-512 core, BPTT over recurrence-length chunks) -------------------
  * model/core.py:19-64 + algo/learning/rnn_utils.py:114-158 as ONE persistent launch per pass instead of

@@ -416,7 +416,7 @@ class Learner:
         buff.dones = batch["dones"].view(N)
         buff.policy_id, buff.policy_version = batch["policy_id"].view(N), batch["policy_version"].view(N)
         if cfg.use_rnn:
-            buff.rnn_states = batch["rnn_states"][:, :T].reshape(N, -1)
+            buff.rnn_states = batch["rnn_states"]  # the slab [E, T+1, S], read in place by sf_rnn_chunk_setup
         buff["values"] = batch["values"][:, :T].reshape(N)  # NB: item access, AttrDict.values is dict.values
         buff.valids = batch["valids"][:, :T].reshape(N)
         buff.E, buff.T = E, T
@@ -495,8 +495,8 @@ class Learner:
         if cfg.use_rnn:  # learner.py:557-569: chunk-start states, done-or-invalid boundaries (masked-loop BPTT)
             R, Cn = cfg.recurrence, n // cfg.recurrence
             keep_tm = ac._buf(("rnn", "keep_tm"), (R, Cn))
-            h0 = ac._buf(("rnn", "h0"), (Cn, buff.rnn_states.shape[1]))
-            lib.rnn_chunk_setup(buff.dones, buff.valids, buff.rnn_states, index, offset, Cn, R, keep_tm, h0)
+            h0 = ac._buf(("rnn", "h0"), (Cn, buff.rnn_states.shape[-1]))
+            lib.rnn_chunk_setup(buff.dones, buff.valids, buff.rnn_states, index, offset, Cn, R, keep_tm, h0, traj_T=buff.T)
             rnn = dict(R=R, h0=h0, keep_tm=keep_tm)
         acts = ac.forward_heads(buff.obs, n, sample_stride=ac.obs_elems, index=index, offset=offset,
                                 traj_T=buff.T, tag="train", rnn=rnn)

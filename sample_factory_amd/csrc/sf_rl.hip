@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 10; }
+extern "C" int sf_abi_version(void) { return 11; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -1923,7 +1923,7 @@ __global__ __launch_bounds__(256) void k_rnn_chunk_setup(const uint8_t *__restri
                                                          const uint8_t *__restrict__ valids,
                                                          const float *__restrict__ rnn_states,
                                                          const int32_t *__restrict__ index, int64_t offset, int Cn,
-                                                         int R, int S, float *__restrict__ keep_tm,
+                                                         int R, int S, int traj_T, float *__restrict__ keep_tm,
                                                          float *__restrict__ h0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nk = (int64_t)Cn * R;
@@ -1934,18 +1934,19 @@ __global__ __launch_bounds__(256) void k_rnn_chunk_setup(const uint8_t *__restri
     } else if (i < nk + (int64_t)Cn * S) {
         const int64_t j = i - nk;
         const int c = (int)(j / S), e = (int)(j - (int64_t)c * S);
-        const int64_t row = index ? (int64_t)index[(int64_t)c * R] : offset + (int64_t)c * R;
+        int64_t row = index ? (int64_t)index[(int64_t)c * R] : offset + (int64_t)c * R;
+        if (traj_T > 0) row = (row / traj_T) * (traj_T + 1) + row % traj_T;  // dataset row e*T+t -> slab row e*(T+1)+t
         h0[j] = rnn_states[row * S + e];
     }
 }
 
 extern "C" int sf_rnn_chunk_setup(const uint8_t *dones, const uint8_t *valids, const float *rnn_states,
-                                  const int32_t *index, int64_t offset, int Cn, int R, int S, float *keep_tm, float *h0,
-                                  void *stream) {
+                                  const int32_t *index, int64_t offset, int Cn, int R, int S, int traj_T, float *keep_tm,
+                                  float *h0, void *stream) {
     SF_REQUIRE(dones && valids && rnn_states && keep_tm && h0 && Cn > 0 && R > 0 && S > 0, "sf_rnn_chunk_setup: bad args");
     const int64_t tot = (int64_t)Cn * R + (int64_t)Cn * S;
     k_rnn_chunk_setup<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
-        dones, valids, rnn_states, index, offset, Cn, R, S, keep_tm, h0);
+        dones, valids, rnn_states, index, offset, Cn, R, S, traj_T, keep_tm, h0);
     return sf_launch_status("sf_rnn_chunk_setup");
 }
 

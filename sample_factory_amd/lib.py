@@ -277,14 +277,18 @@ def rnn_store_state(h, c, dones_col, out) -> None:
                                      stream()), "sf_rnn_store_state")
 
 
-def rnn_chunk_setup(dones, valids, rnn_states, index, offset, Cn, R, keep_tm, h0) -> None:
-    """chunk-start states and done-or-invalid boundaries of a recurrent minibatch in one launch (see sf_hip.h)"""
-    S = rnn_states.shape[1]
-    if not rnn_states.is_contiguous() or keep_tm.shape != (R, Cn) or h0.shape != (Cn, S):
-        raise SfHipError("rnn_chunk_setup: rnn_states must be contiguous [rows, S], keep_tm [R, Cn], h0 [Cn, S]")
+def rnn_chunk_setup(dones, valids, rnn_states, index, offset, Cn, R, keep_tm, h0, traj_T=0) -> None:
+    """chunk-start states and done-or-invalid boundaries of a recurrent minibatch in one launch (see sf_hip.h);
+    traj_T > 0: rnn_states is the slab [E, traj_T + 1, S], read in place"""
+    S = rnn_states.shape[-1]
+    if not rnn_states.is_contiguous() or keep_tm.shape != (R, Cn) or h0.shape != (Cn, S) or \
+            (traj_T > 0 and (rnn_states.dim() != 3 or rnn_states.shape[1] != traj_T + 1)):
+        raise SfHipError("rnn_chunk_setup: rnn_states must be contiguous [rows, S] (or the slab [E, T+1, S] with traj_T), "
+                         "keep_tm [R, Cn], h0 [Cn, S]")
     _check(load().sf_rnn_chunk_setup(ptr(dones, "u8", "dones"), ptr(valids, "u8", "valids"),
                                      ptr(rnn_states, "f32", "rnn_states"), ptr(index, "i32"), i64(offset), int(Cn),
-                                     int(R), int(S), ptr(keep_tm, "f32", "keep_tm"), ptr(h0, "f32", "h0"), stream()),
+                                     int(R), int(S), int(traj_T), ptr(keep_tm, "f32", "keep_tm"), ptr(h0, "f32", "h0"),
+                                     stream()),
            "sf_rnn_chunk_setup")
 
 
