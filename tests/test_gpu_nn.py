@@ -338,9 +338,18 @@ def test_conv1_exact_product_kernels_on_integers(lib):
     d2 = desc(lib, Cin, H, W, Cout, K, S, in_u8=1, sub_mean=0.0, inv_scale=float(np.float32(1 / 255.0)), relu=0)
     w_f = torch.randn((Cout, Cin, K, K), generator=g) / 16
     lib.conv_fwd(x.cuda(), Cin * H * W, None, 0, to_kmajor(w_f, 1).cuda(), b_int.cuda() * 0, out, n, d2)
-    ref = F.conv2d(x.double() * float(np.float32(1 / 255.0)), w_f.double(), None, stride=S)
+    inv = float(np.float32(1 / 255.0))
+    ref = F.conv2d(x.double() * inv, w_f.double(), None, stride=S)
     got = out.view(n, 20, 20, Cout).permute(0, 3, 1, 2).cpu().double()
     assert (got - ref).abs().max().item() < 6e-7 * ref.abs().max().item()
+    # ... and, because the products are exact, the error obeys the A-PRIORI bound of a pure f32 summation in ANY order:
+    # |fl(sum) - sum| <= (m - 1) u / (1 - (m - 1) u) * sum |terms| with m = 3 * 256 exact terms and u = 2^-24, plus one
+    # rounding each for the multiplication by 1/scale and for that constant itself — element by element, not just on the
+    # largest value (a kernel that rounded an operand, e.g. x/255 in f32, would add K u sum|x w| on top of it)
+    u = 2.0 ** -24
+    mag = F.conv2d(x.double() * inv, w_f.double().abs(), None, stride=S)          # sum_k |x_k w_k| / 255
+    bound = ((3 * 256 - 1) * u / (1 - 3 * 256 * u) + 2 * u) * mag + 1e-30
+    assert ((got - ref).abs() <= bound).all(), float(((got - ref).abs() / bound).max())
 
 
 @pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64)])
