@@ -167,3 +167,24 @@ def test_c_abi_rccl_exchange_single_rank():
         lib.allreduce_grads(comm, torch.zeros(4))            # host tensor
     torch.cuda.synchronize()
     lib.dp_comm_destroy(comm)
+
+
+def test_bench_contract_with_two_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` as the driver invokes it (self-launch under torch.distributed.run, one JSON line from
+    rank 0, whole-job aggregate, barrier + max-over-ranks timing) — over gloo with host staging, because the test box has
+    ONE GPU and RCCL refuses two ranks on it; everything but the collective backend is the production path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["SF_DP_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--envs", "256", "--no_cpu_baseline"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]          # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scaling"] == "weak" and j["steps"] == 2
+    assert j["config"]["parallelism"] == "dp2" and j["value"] > 0
+    assert abs(j["value"] - 2 * 256 * 32 * 2 / (j["ms_per_step"] * 2e-3)) < 0.02 * j["value"]   # aggregate over both ranks
