@@ -63,10 +63,18 @@ def _worker(rank, world, port, out_dir):
     # (2b) the learner's two-bucket form: the tail goes out asynchronously (while the backward pass would still be
     # producing the head), then the head, then wait — every element summed once, same result
     cut = bucket2.numel() // 3
+    bucket3 = bucket2.clone()
     work = grp.all_reduce_sum_async(bucket2[cut:])
     grp.all_reduce_sum(bucket2[:cut])
     work.wait()
     assert torch.equal(bucket2, bucket.reshape(-1))
+    # the entry points the learner actually calls (they route to sf_allreduce_grads under cfg.dp_native_rccl, to the
+    # torch.distributed collectives otherwise — this group is not native: no GPU here)
+    assert not grp.native
+    work = grp.all_reduce_grads_async(bucket3[cut:])
+    grp.all_reduce_grads(bucket3[:cut])
+    work.wait()
+    assert torch.equal(bucket3, bucket.reshape(-1))
     # (3) additive loss sums + max KL
     n_loc = float(va.sum())
     sums = torch.tensor([-out["policy_loss"] * mom[2].item(), 0.0, 0.0, 0.0, out["kl_max"], n_loc, 0.0, 0.0],
