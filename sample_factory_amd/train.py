@@ -321,7 +321,7 @@ class Runner:
         with self._cv:
             for sl in slices:
                 self._round_events[sl.start] = ev
-                self._ready += self.batcher.on_new_trajectories(sl)   # SliceMerger: adjacent slices -> datasets
+                self._ready += self.batcher.on_new_trajectories(sl)   # row ledger: adjacent slices -> datasets
             self.sampling_rounds += 1
             self._last_round_event = ev
             self._cv.notify_all()
@@ -338,7 +338,7 @@ class Runner:
     # ------------------------------------------------------------------------------------------ learning
     def _train_dataset(self, ds: slice):
         """Learner.train on slab rows [ds) IN PLACE (the reference copies them into a training batch first,
-        batcher.py:192-212), then hand the rows back: training slice -> SliceMerger -> free sampling slices"""
+        batcher.py:192-212), then hand the rows back: training slice -> row ledger -> free sampling slices"""
         main = torch.cuda.current_stream()
         unit = self.unit_rows
         with self._cv:

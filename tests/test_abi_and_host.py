@@ -185,21 +185,32 @@ def test_oracle_is_not_imported_by_the_product():
 
 def test_slice_merger_and_buffer_mgr_match_reference(golden_json):
     """host-side slab bookkeeping vs traces recorded from the reference's SliceMerger / BufferMgr"""
-    from sample_factory_amd.algo.learning.batcher import Batcher, SliceMerger
+    from sample_factory_amd.algo.learning.batcher import Batcher, RowLedger
     from sample_factory_amd.algo.utils.env_info import EnvInfo
     from sample_factory_amd.algo.utils.shared_buffers import BufferMgr
     from sample_factory_amd.cfg.arguments import default_cfg
     from sample_factory_amd.envs import spaces
     g = golden_json("host_logic")
+    # the occupancy-map ledger replays the op traces recorded from the reference's SliceMerger: same rows handed out in
+    # the same order, same number of rows held, same run starts after every operation (row granularity and, where the
+    # trace never splits a unit, the coarser granule the Batcher itself would use)
     for ops in g["slice_merger_traces"]:
-        sm = SliceMerger()
-        for op in ops:
-            if op[0] == "merge":
-                sm.merge_slices(slice(op[1], op[2]))
-                assert sm.total_num == op[3] and sorted(sm.slice_starts) == op[4]
-            else:
-                got = sm.get_exactly(op[1]) if op[0] == "exactly" else sm.get_at_most(op[1])
-                assert (None if got is None else [got.start, got.stop]) == op[2] and sm.total_num == op[3]
+        sizes = [op[2] - op[1] for op in ops if op[0] == "merge"] + [op[1] for op in ops if op[0] != "merge"]
+        for granule in {1, int(np.gcd.reduce(sizes))}:
+            led = RowLedger(256, granule)
+            for op in ops:
+                if op[0] == "merge":
+                    led.add(op[1], op[2])
+                    assert led.total_num == op[3] and led.run_starts == op[4]
+                else:
+                    got = led.take(op[1], exact=op[0] == "exactly")
+                    assert (None if got is None else [got.start, got.stop]) == op[2] and led.total_num == op[3]
+    led = RowLedger(64, 8)
+    led.add(8, 16)
+    with pytest.raises(AssertionError):
+        led.add(8, 16)      # rows cannot be handed in twice
+    with pytest.raises(AssertionError):
+        led.add(4, 12)      # nor in pieces that are not whole granules
     obs = spaces.Dict({"obs": spaces.Box(-1, 1, (4,), np.float32)})
     for m in g["buffer_mgr"]:
         kv = {}

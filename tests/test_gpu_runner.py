@@ -1,4 +1,4 @@
-"""Runner data plane and life-cycle on the GPU: the slab bookkeeping of BufferMgr / Batcher / SliceMerger wired into the
+"""Runner data plane and life-cycle on the GPU: the slab bookkeeping of BufferMgr / Batcher / RowLedger wired into the
 rollout -> train loop (shared_buffers.py:152-239, batcher.py:170-234, rollout_worker.py:108-126), and the checkpoint
 life-cycle of runner.py:170-176,207-230,685-698 + learner.py:300-386."""
 import glob
