@@ -166,20 +166,23 @@ int sf_minibatch_expand(const int32_t *chunk_starts, int32_t *out, int64_t exper
  * no weight decay/amsgrad; learner.py:228-243).  All parameters live in one flat fp32 buffer of P elements.
  * sf_grad_sumsq: sumsq (device double[1], zeroed by the call) = sum g^2.  sf_adam_step reads it: coef =
  * min(1, max_norm/(sqrt(sumsq)+1e-6)) (skipped when max_grad_norm <= 0 or sumsq == NULL), g scaled by
- * grad_scale*coef, then the Adam update in torch's op order.  `step` is the 1-based Adam step count. */
+ * grad_scale*coef, then the Adam update in torch's op order.  `step` is the 1-based Adam step count.
+ * skip_flag (device uint32, may be NULL): when the word is non-zero as the kernel starts, the launch is a no-op —
+ * weights and moments stay untouched (the sticky abort word of the fused recurrent passes, see sf_lstm_seq_fwd). */
 int sf_grad_sumsq(const float *g, int64_t P, double *sumsq, void *stream);
 int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
-                 float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale, void *stream);
+                 float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale,
+                 const uint32_t *skip_flag, void *stream);
 
 /* Lamb (cfg.optimizer = "lamb"; algo/utils/optimizers.py:14-189 as configured by learner.py:228-243: Adam direction
  * with bias correction + weight_decay * w, then per-TENSOR trust ratio min(||w||, 10)/||step|| clamped to
  * [min_trust, 1/min_trust]; the reference's `step` starts at 1).  seg_id[P] (u8): index of the reference tensor each
  * flat element belongs to, 255 = padding (skipped); scratch[P] f32; seg_sums: device double[128] (zeroed by the call).
- * Gradient clipping as in sf_adam_step. */
+ * Gradient clipping and skip_flag as in sf_adam_step. */
 int sf_lamb_step(float *p, const float *g, float *m, float *v, float *scratch, const uint8_t *seg_id, double *seg_sums,
                  int64_t P, int num_segments, int step, float lr, float beta1, float beta2, float eps,
                  float weight_decay, float min_trust, float max_grad_norm, const double *sumsq, float grad_scale,
-                 void *stream);
+                 const uint32_t *skip_flag, void *stream);
 
 /* ---- K4/K5: action sampling + policy outputs -> trajectory step ------------------------------------------------
  * action_distributions.py:110-148 (softmax, multinomial, log_softmax, gather), actor_critic.py:112-117,
@@ -329,8 +332,10 @@ int sf_rnn_chunk_setup(const uint8_t *dones, const uint8_t *valids, const float 
  * Layouts (all f32, row-major, time-major over the R steps of Cn chunks): gx [R][Cn][4H] = x W_ih^T + b_ih;
  * whh [H][4H] (K-major, torch gate order i,f,g,o); keep [R][Cn] = 1 - done_or_invalid; gates [R][Cn][4H] (post-
  * activation); hprev / cprev [R+1][Cn][H] with slot 0 = the chunk-start state on entry, slot t+1 = state_t * keep[t];
- * hout / cout [R][Cn][H] the unmasked new state.  sync: >= 129 device uint32 (zeroed by the call; word 128 != 0
- * afterwards = the pass was aborted because a work-group never arrived).  sf_lstm_seq_supported: 1 when (Cn, H) can
+ * hout / cout [R][Cn][H] the unmasked new state.  sync: >= 129 device uint32; words 0..127 are the hand-off counters
+ * (zeroed by the call), word 128 is the STICKY abort word: set by a pass that gave up waiting for a work-group, never
+ * cleared by the library (the caller zeroes it once, e.g. at the start of Learner.train, and hands the same word to
+ * sf_adam_step / sf_lamb_step as `skip_flag`, so that the garbage gradients of an aborted pass never reach the weights).  sf_lstm_seq_supported: 1 when (Cn, H) can
  * take this path on the current device (H == 512; grid <= #CUs), else use sf_rnn_cell_fwd/bwd per step.
  * sf_lstm_seq_bwd: dout [R][Cn][H] = dL/d hout; writes dgx [R][Cn][4H] = dL/d(gate pre-activations) (= the gradient of
  * both gx and h W_hh^T + b_hh); the carries of dL/dh and dL/dc live in registers.  Cn <= 8 * 256 rows. */

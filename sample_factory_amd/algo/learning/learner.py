@@ -545,6 +545,11 @@ class Learner:
         need_kl_each_mb = self.lr_scheduler.invoke_after_each_minibatch() and isinstance(self.lr_scheduler, KlAdaptiveScheduler)
         self._dp_reduce_each_mb = need_kl_each_mb
         self._grad_norms = []
+        # fused recurrent passes: sticky abort word, cleared once per call; the optimiser kernels skip their update
+        # while it is set, and it is read back with every epoch's scalars (before any further epoch is trained)
+        skip = ac.rnn_abort_word() if hasattr(ac, "rnn_abort_word") else None
+        if skip is not None:
+            ac.rnn_abort_clear()
         for epoch in range(cfg.num_epochs):
             minibatches = self._get_minibatches(batch_size, experience_size)
             for batch_num, mb in enumerate(minibatches):
@@ -584,11 +589,13 @@ class Learner:
                     seg, nseg, scratch, seg_sums = self._lamb
                     lib.lamb_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, scratch, seg, seg_sums,
                                   nseg, self.adam_step_count, actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
-                                  1e-4, 0.01, cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None)
+                                  1e-4, 0.01, cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None,
+                                  skip_flag=skip)
                 else:
                     lib.adam_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
                                   actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
-                                  cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None)
+                                  cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None,
+                                  skip_flag=skip)
                 ac.params_changed()
                 num_sgd_steps += 1
                 self.train_step += 1
@@ -612,6 +619,11 @@ class Learner:
                 self.group.all_reduce_max(mx)
                 blk[:, 5] = mx
             rows = blk.cpu()
+            if skip is not None and ac.rnn_pass_aborted():
+                raise lib.SfHipError(
+                    "a fused recurrent sequence pass was aborted (a work-group never arrived: is the GPU shared with "
+                    "another process?); the optimiser steps after it were skipped, the weights are those of the last "
+                    "good SGD step; set SF_LSTM_SEQ=0 to use the per-step kernels")
             actor_losses = (rows[:, 0] + rows[:, 1] + rows[:, 2]).double().numpy()
             if not need_kl_each_mb:
                 recent_kls.extend(rows[:, 4].double().tolist())
@@ -686,9 +698,6 @@ class Learner:
         if self._global_invalids >= experience_size * self.world:
             return None
         train_stats = self._train(buff, self.cfg.batch_size, experience_size, num_invalids)
-        if hasattr(self.actor_critic, "rnn_pass_aborted") and self.actor_critic.rnn_pass_aborted():
-            raise lib.SfHipError("a fused LSTM sequence pass was aborted (a work-group never arrived: is the GPU shared "
-                                 "with another process?); set SF_LSTM_SEQ=0 to use the per-step kernels")
         frameskip = self.env_info.frameskip if self.cfg.summaries_use_frameskip else 1
         self.env_steps += experience_size * self.world * frameskip
         stats = {LEARNER_ENV_STEPS: self.env_steps, POLICY_ID_KEY: self.policy_id}

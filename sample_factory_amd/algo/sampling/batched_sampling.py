@@ -204,12 +204,14 @@ class BatchedVectorEnvRunner:
                                 tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
                                 self.ep_len, self.ep_stats)
         if self.rnn:  # batched_sampling.py:332-335: next-step state = new_rnn_states * (1 - done)
-            parts = getattr(self.ac, "new_rnn_parts", None)
+            # the state THIS runner's forward produced (keyed by its tag: the learner thread may have run its bootstrap
+            # forward through the same model object since)
+            parts = self.ac.new_rnn_parts_of(self.tag)
             if parts is not None:  # native model: mask + store [h | c] in one launch
                 lib.rnn_store_state(parts[0], parts[1], tr["dones"][:, t], tr["rnn_states"][:, t + 1])
             else:                  # torch model path
                 keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
-                torch.mul(self.ac.new_rnn_states, keep, out=tr["rnn_states"][:, t + 1])
+                torch.mul(self.ac.new_rnn_states_of(self.tag), keep, out=tr["rnn_states"][:, t + 1])
         self.global_step += 1
 
     def set_slab(self, traj: TensorDict, carry_from: Optional[TensorDict] = None) -> None:

@@ -1004,7 +1004,8 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, con
 
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
                                               float *__restrict__ m, float *__restrict__ v, int64_t P, AdamC c,
-                                              const double *__restrict__ sumsq) {
+                                              const double *__restrict__ sumsq, const uint32_t *__restrict__ skip) {
+    if (skip && *skip) return;  // an aborted fused recurrent pass produced this gradient: leave weights and moments alone
     float coef = c.grad_scale;
     if (sumsq && c.max_norm > 0.f) {
         // clip_grad_norm_: total_norm of the (already grad_scale'd) gradient
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float
 
 extern "C" int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
                             float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale,
-                            void *stream) {
+                            const uint32_t *skip_flag, void *stream) {
     SF_REQUIRE(p && g && m && v && P > 0 && step >= 1, "sf_adam_step: bad args");
     SF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                "sf_adam_step: buffers must be 16-byte aligned");
@@ -1046,7 +1047,7 @@ extern "C" int sf_adam_step(float *p, const float *g, float *m, float *v, int64_
     c.grad_scale = grad_scale;
     const int64_t blocks = (P / 4 + 255) / 256;
     k_adam<<<dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, STREAM(stream)>>>(
-        p, g, m, v, P, c, sumsq);
+        p, g, m, v, P, c, sumsq, skip_flag);
     return sf_launch_status("sf_adam_step");
 }
 
@@ -1066,7 +1067,8 @@ __global__ __launch_bounds__(256) void k_lamb_dir(const float *__restrict__ p, c
                                                   float *__restrict__ m, float *__restrict__ v,
                                                   float *__restrict__ upd, const uint8_t *__restrict__ seg, int64_t P,
                                                   LambC c, const double *__restrict__ sumsq,
-                                                  double *__restrict__ seg_sums) {
+                                                  double *__restrict__ seg_sums, const uint32_t *__restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ double bins[2 * LAMB_MAX_SEG];
     for (int i = threadIdx.x; i < 2 * LAMB_MAX_SEG; i += blockDim.x) bins[i] = 0.0;
     __syncthreads();
@@ -1097,7 +1099,9 @@ __global__ __launch_bounds__(256) void k_lamb_dir(const float *__restrict__ p, c
 
 __global__ __launch_bounds__(256) void k_lamb_apply(float *__restrict__ p, const float *__restrict__ upd,
                                                     const uint8_t *__restrict__ seg, int64_t P, LambC c,
-                                                    const double *__restrict__ seg_sums) {
+                                                    const double *__restrict__ seg_sums,
+                                                    const uint32_t *__restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ float trust[LAMB_MAX_SEG];
     for (int i = threadIdx.x; i < LAMB_MAX_SEG; i += blockDim.x) {
         const float wn = (float)sqrt(seg_sums[2 * i]), sn = (float)sqrt(seg_sums[2 * i + 1]);
@@ -1119,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_lamb_apply(float *__restrict__ p, const
 extern "C" int sf_lamb_step(float *p, const float *g, float *m, float *v, float *scratch, const uint8_t *seg_id,
                             double *seg_sums, int64_t P, int num_segments, int step, float lr, float beta1, float beta2,
                             float eps, float weight_decay, float min_trust, float max_grad_norm, const double *sumsq,
-                            float grad_scale, void *stream) {
+                            float grad_scale, const uint32_t *skip_flag, void *stream) {
     SF_REQUIRE(p && g && m && v && scratch && seg_id && seg_sums && P > 0 && step >= 1, "sf_lamb_step: bad args");
     SF_REQUIRE(num_segments >= 1 && num_segments <= LAMB_MAX_SEG, "sf_lamb_step: 1..%d segments", LAMB_MAX_SEG);
     LambC c;
@@ -1133,8 +1137,8 @@ extern "C" int sf_lamb_step(float *p, const float *g, float *m, float *v, float 
     if (rc) return rc;
     const int64_t blocks = (P + 255) / 256;
     const dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024));
-    k_lamb_dir<<<grid, dim3(256), 0, STREAM(stream)>>>(p, g, m, v, scratch, seg_id, P, c, sumsq, seg_sums);
-    k_lamb_apply<<<grid, dim3(256), 0, STREAM(stream)>>>(p, scratch, seg_id, P, c, seg_sums);
+    k_lamb_dir<<<grid, dim3(256), 0, STREAM(stream)>>>(p, g, m, v, scratch, seg_id, P, c, sumsq, seg_sums, skip_flag);
+    k_lamb_apply<<<grid, dim3(256), 0, STREAM(stream)>>>(p, scratch, seg_id, P, c, seg_sums, skip_flag);
     return sf_launch_status("sf_lamb_step");
 }
 

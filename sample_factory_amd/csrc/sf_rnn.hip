@@ -751,7 +751,7 @@ extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *b
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_lstm_seq_fwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_fwd: state buffer exceeds 2 GiB");
-    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_fwd memset");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_fwd memset");
     if (rc) return rc;
     // hout [R][Cn][H] (time-major) or, env_major, [Cn][R][H] = the row order of the minibatch itself (no transpose copy)
     LstmSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, ng, rpg,
@@ -772,7 +772,7 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_lstm_seq_bwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)R * Cn * 4 * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_bwd: gate-gradient buffer exceeds 2 GiB");
-    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_bwd memset");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_bwd memset");
     if (rc) return rc;
     static const int ablate = getenv("SF_LSTM_ABLATE") ? atoi(getenv("SF_LSTM_ABLATE")) : 0;
     LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ng, rpg,
@@ -792,7 +792,7 @@ extern "C" int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bh
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_gru_seq_fwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_fwd: state buffer exceeds 2 GiB");
-    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_fwd memset");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_fwd memset");
     if (rc) return rc;
     GruSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, ng, rpg,
                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
@@ -811,7 +811,7 @@ extern "C" int sf_gru_seq_bwd(const float *dout, const float *gates, const float
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_gru_seq_bwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)R * Cn * 3 * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_bwd: gate-gradient buffer exceeds 2 GiB");
-    int rc = sf_hip_status(hipMemsetAsync(sync, 0, (SEQ_ABORT_SLOT + 1) * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_bwd memset");
+    int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_bwd memset");
     if (rc) return rc;
     GruSeqBwd p{dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, ng, rpg,
                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};

@@ -391,20 +391,22 @@ def grad_sumsq(g, sumsq) -> None:
            "sf_grad_sumsq")
 
 
-def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, max_grad_norm, sumsq, grad_scale=1.0) -> None:
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, max_grad_norm, sumsq, grad_scale=1.0, skip_flag=None) -> None:
+    """skip_flag: device int32 [1] view (the sticky abort word of the fused recurrent passes) or None"""
     _check(load().sf_adam_step(ptr(p, "f32", "params"), ptr(g, "f32", "grads"), ptr(m, "f32", "exp_avg"),
                                ptr(v, "f32", "exp_avg_sq"), i64(p.numel()), int(step), f(lr), f(beta1), f(beta2),
-                               f(eps), f(max_grad_norm), ptr(sumsq, "f64", "sumsq"), f(grad_scale), stream()),
+                               f(eps), f(max_grad_norm), ptr(sumsq, "f64", "sumsq"), f(grad_scale),
+                               ptr(skip_flag, "i32", "skip_flag"), stream()),
            "sf_adam_step")
 
 
 def lamb_step(p, g, m, v, scratch, seg_id, seg_sums, num_segments, step, lr, beta1, beta2, eps, weight_decay, min_trust,
-              max_grad_norm, sumsq, grad_scale=1.0) -> None:
+              max_grad_norm, sumsq, grad_scale=1.0, skip_flag=None) -> None:
     _check(load().sf_lamb_step(ptr(p, "f32", "p"), ptr(g, "f32", "g"), ptr(m, "f32", "m"), ptr(v, "f32", "v"),
                                ptr(scratch, "f32", "scratch"), ptr(seg_id, "u8", "seg_id"), ptr(seg_sums, "f64", "seg_sums"),
                                i64(p.numel()), int(num_segments), int(step), f(lr), f(beta1), f(beta2), f(eps),
                                f(weight_decay), f(min_trust), f(max_grad_norm), ptr(sumsq, "f64", "sumsq"),
-                               f(grad_scale), stream()), "sf_lamb_step")
+                               f(grad_scale), ptr(skip_flag, "i32", "skip_flag"), stream()), "sf_lamb_step")
 
 
 def sample_write_step(logits, ld_logits, values, ld_values, B, A, T, t, seed, step, row0, policy_version, deterministic,

@@ -249,6 +249,10 @@ class ActorCritic:
         self._wss: Dict = {}
         self._tls = threading.local()  # per-thread "which scratch am I using": a sampler thread may run beside the learner
         self._snap = None
+        # per-tag results of the last forward: a sampler thread ("inf*" tags) and the learner thread ("boot", "train")
+        # call forward_heads concurrently, so nothing a forward leaves behind may live in an untagged attribute
+        self._ctx: Dict = {}
+        self._rnn_out: Dict = {}   # tag -> (h_out, c_out | None) of the last ONE-STEP recurrent forward under that tag
         self.initialize_weights()
 
     # ------------------------------------------------------------------------------------------ reference surface
@@ -491,7 +495,7 @@ class ActorCritic:
 
         obs: any (possibly strided) view whose data_ptr is sample 0; logical sample i lives at row
         (index[i] | offset+i) [-> slab row if traj_T] * sample_stride elements.
-        rnn (recurrent models): {"states": [n, S] view} for one inference step (new state -> self.new_rnn_states) or
+        rnn (recurrent models): {"states": [n, S] view} for one inference step (new state -> new_rnn_parts_of(tag)) or
         {"R": recurrence, "h0": [n/R, S], "keep_tm": [R, n/R]} for a training pass over recurrence-length chunks.
         """
         acts: List[Optional[torch.Tensor]] = [None] * len(self.layers)
@@ -539,7 +543,6 @@ class ActorCritic:
             stride, idx, off, tT = x.numel() // n, None, 0, 0  # elements per sample of the activation just produced
         if self.tanh_scale > 0:  # action_parameterization.py:62-66 (col 0 = value, then the means)
             lib.tanh_scale_fwd(acts[-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
-        self._ctx = getattr(self, "_ctx", {})
         self._ctx[tag] = dict(acts=acts, inputs=inputs, first_in=first_in, rnn=rnn)
         return acts
 
@@ -560,8 +563,9 @@ class ActorCritic:
         c_out = self._buf((tag, "c_out"), (n, H)) if kind == 1 else None
         lib.rnn_cell_fwd(kind, gx, gh, st, st.stride(0), st[:, H:] if kind == 1 else None, st.stride(0), None, n, H,
                          None, h_out, c_out, None, None)
-        self.new_rnn_parts = (h_out, c_out)  # the rollout runner masks + stores them in one launch (sf_rnn_store_state)
-        self._new_rnn_cat = None
+        # keyed by tag: the rollout runner masks + stores ITS OWN step's state in one launch (sf_rnn_store_state) even
+        # while the learner thread runs the bootstrap forward (tag "boot") through the same model object
+        self._rnn_out[tag] = (h_out, c_out)
         return h_out
 
     def _rnn_sequence_fwd(self, li, GX, n, rnn, tag):
@@ -583,12 +587,11 @@ class ActorCritic:
         fused = _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
         if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS; the
             # core output is written in the minibatch's own row order (chunk-major), no transpose copy
-            sync = self._buf((tag, "seq_sync"), (192,), dtype=torch.int32)
+            sync = self._seq_sync_buf()
             if kind == 1:
                 lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, Cprev, Cout, sync, R, Cn, H, env_major=True)
             else:
                 lib.gru_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, sync, R, Cn, H, env_major=True)
-            self._seq_sync = sync
             self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=True)
             return out
         Hout = self._buf((tag, "Hout"), (R, Cn, H))
@@ -610,7 +613,7 @@ class ActorCritic:
         GH = Lh.N
         dGX = self._buf(("g", "dGX"), (R, Cn, GH))
         if sv.get("fused"):  # the whole backward time loop in one persistent launch (cell backward + W_hh^T product + carries)
-            sync = self._buf(("g", "seq_sync"), (192,), dtype=torch.int32)
+            sync = self._seq_sync_buf()
             dGH = dGX
             dOut = d_core if d_core.is_contiguous() else d_core.contiguous()  # read in the minibatch's row order
             if kind == 1:
@@ -618,7 +621,6 @@ class ActorCritic:
             else:  # GRU: the candidate gate's recurrent part is scaled by r -> W_hh sees its own gate gradients
                 dGH = self._buf(("g", "dGH"), (R, Cn, GH))
                 lib.gru_seq_bwd(dOut, sv["gates"], sv["Hprev"], keep, Lh.w, dGX, dGH, sync, R, Cn, H, env_major=True)
-            self._seq_sync_bwd = sync
             ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
             lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
             return dGX.view(n, GH)
@@ -646,23 +648,43 @@ class ActorCritic:
         lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
         return dGX.view(n, GH)
 
+    def new_rnn_parts_of(self, tag: str = "inf"):
+        """(h, c | None) produced by the last one-step forward issued under `tag` (None if there was none)"""
+        return self._rnn_out.get(tag)
+
+    def new_rnn_states_of(self, tag: str = "inf") -> torch.Tensor:
+        """[B, S] state after the last one-step forward under `tag` (reference output key `new_rnn_states`)"""
+        h, c = self._rnn_out[tag]
+        return h if c is None else torch.cat([h, c], dim=1)
+
     @property
     def new_rnn_states(self) -> torch.Tensor:
-        """[B, S] state after the last one-step forward (reference output key `new_rnn_states`), built on demand"""
-        if self._new_rnn_cat is None:
-            h, c = self.new_rnn_parts
-            self._new_rnn_cat = h if c is None else torch.cat([h, c], dim=1)
-        return self._new_rnn_cat
+        """the default inference tag's state (ActorCritic.forward())"""
+        return self.new_rnn_states_of("inf")
+
+    def _seq_sync_buf(self) -> torch.Tensor:
+        """hand-off counters (words 0..127, zeroed by every launch) + the STICKY abort word (word 128) of the fused
+        sequence passes; one buffer for the forward and the backward pass (they run back to back on one stream)"""
+        t = self._bufs.get(("rnn", "seq_sync"))
+        if t is None:
+            t = self._bufs[("rnn", "seq_sync")] = torch.zeros(192, dtype=torch.int32, device=self.device)
+        return t
+
+    def rnn_abort_word(self) -> Optional[torch.Tensor]:
+        """int32 [1] view of the sticky abort word (None: this model has no fused recurrent passes).  The optimiser
+        kernels take it as their skip flag: once a pass has aborted, no later SGD step of the call touches the weights."""
+        return self._seq_sync_buf()[128:129] if (self.rnn_kind is not None and _LSTM_SEQ) else None
+
+    def rnn_abort_clear(self) -> None:
+        if self.rnn_kind is not None and _LSTM_SEQ:
+            self._seq_sync_buf()[128:129].zero_()
 
     def rnn_pass_aborted(self) -> bool:
-        """True if a fused LSTM pass gave up waiting for a work-group (GPU shared with another process): its results are
-        garbage and the caller must not use them.  One 4-byte readback; called once per Learner.train()."""
-        bad = False
-        for name in ("_seq_sync", "_seq_sync_bwd"):
-            t = getattr(self, name, None)
-            if t is not None:
-                bad = bad or bool(int(t[128].item()))
-        return bad
+        """True if a fused sequence pass gave up waiting for a work-group since the last rnn_abort_clear() (GPU shared
+        with another process): its results are garbage.  One 4-byte readback; the Learner calls it where it reads the
+        epoch's loss scalars back anyway."""
+        t = self._bufs.get(("rnn", "seq_sync"))
+        return t is not None and bool(int(t[128].item()))
 
     def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
         """Inference-style forward on a dense obs batch [B, ...]; returns dict(values, action_logits, new_rnn_states)

@@ -312,7 +312,7 @@ class TorchPolicyAdapter:
         self.num_action_params = int(calc_num_action_parameters(action_space))
         self.heads_ld = (1 + self.num_action_params + 3) // 4 * 4
         self.rnn_kind = (0 if cfg.rnn_type == "gru" else 1) if cfg.use_rnn else None  # the rollout runner's switch
-        self.new_rnn_states = None
+        self._rnn_out: Dict = {}  # tag -> new state of the last one-step forward under that tag (sampler || learner threads)
         self.training = True
         # ---- re-seat parameters / gradients as views into flat buffers (16-byte aligned segments)
         params = [p for p in self.module.parameters() if p.requires_grad]
@@ -415,7 +415,7 @@ class TorchPolicyAdapter:
             elif "R" not in rnn:  # one inference step on the stored state (rollout, bootstrap value)
                 x, new_states = self.module.forward_core(self.module.forward_head(xd), rnn["states"])
                 res = self.module.forward_tail(x, values_only=False)
-                self.new_rnn_states = new_states.detach()
+                self._rnn_out[tag] = new_states.detach()
             else:
                 # BPTT over recurrence-length chunks as a masked time loop: rows are chunk-major (Cn chunks x R steps),
                 # the state is zeroed after a done / invalid step — the loop form of rnn_utils.py:114-158 that the
@@ -433,6 +433,17 @@ class TorchPolicyAdapter:
         if train:
             self._train_heads = heads
         return [heads.detach()]
+
+    def new_rnn_parts_of(self, tag: str = "inf"):
+        """the native model hands (h, c) to sf_rnn_store_state; a torch module's state is one tensor -> None"""
+        return None
+
+    def new_rnn_states_of(self, tag: str = "inf") -> torch.Tensor:
+        return self._rnn_out[tag]
+
+    @property
+    def new_rnn_states(self):
+        return self._rnn_out.get("inf")
 
     def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
         if self.multi_key:

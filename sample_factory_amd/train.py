@@ -163,10 +163,8 @@ class Runner:
     def _read_ep_stats(self):
         """sum of {return, length, count} over the env instances since the last call, then reset — on the stream the
         rollout kernels add to them on (async: the rollout stream), so no episode is lost between read and reset"""
-        if self.cfg.async_rl and not self.threaded:
-            self.rollout_stream.synchronize()
-        st = self.rollout_stream if (self.cfg.async_rl and self.threaded) else torch.cuda.current_stream()
-        with torch.cuda.stream(st):
+        st = self.rollout_stream if self.cfg.async_rl else torch.cuda.current_stream()
+        with torch.cuda.stream(st):  # read AND reset in the rollout stream's order (.cpu() waits for that stream)
             tot = sum(sm.ep_stats.cpu() for sm in self.samplers)
             for sm in self.samplers:
                 sm.ep_stats.zero_()
@@ -258,6 +256,10 @@ class Runner:
         # for its env.  cfg.sampler_thread: None = automatic (async mode with a host env), True / False = forced.
         for sm in self.samplers:
             sm.reset()  # first observation into slab obs[:, 0]; tells us whether the env lives on the host
+        if cfg.async_rl:  # the resets (reset kernel / H2D into obs[:, 0]) ran on THIS stream; round 0 samples on another
+            ev_reset = torch.cuda.Event()
+            ev_reset.record()
+            self.rollout_stream.wait_event(ev_reset)
         want = getattr(cfg, "sampler_thread", None)
         self.threaded = bool(cfg.async_rl and (want if want is not None else any(sm.host_env for sm in self.samplers)))
         self._thread, self._stop, self._thread_error = None, False, None

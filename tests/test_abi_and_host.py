@@ -386,3 +386,21 @@ def test_three_term_bf16_split_is_exact():
     px = np.arange(256, dtype=np.float32)
     for mean in (0.0, 128.0, 255.0):
         assert np.array_equal(trunc(px - np.float32(mean)), px - np.float32(mean))
+
+
+def test_sample_factory_alias_keeps_the_real_module_specs():
+    """`import sample_factory.x` returns the sample_factory_amd.x module object; the import machinery must not leave
+    the alias spec on it (importlib.reload, __package__ == __spec__.parent), and `python -m sample_factory.<module>`
+    finds the real module's code"""
+    import importlib
+    import subprocess
+    import sys
+    import sample_factory.cfg.arguments as a
+    import sample_factory_amd.cfg.arguments as b
+    import sample_factory.algo.learning as pkg
+    assert a is b and a.__spec__.name == "sample_factory_amd.cfg.arguments" and a.__package__ == a.__spec__.parent
+    assert pkg.__spec__.name == "sample_factory_amd.algo.learning" and list(pkg.__path__)
+    assert importlib.reload(a) is a
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "sample_factory.cfg.arguments"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -805,3 +805,66 @@ def test_fused_mlp_encoder_inference_kernel(lib, n, D, H1, H2, act, norm):
     ref = fn(fn(xn.double() @ w1.double() + b1.double()) @ w2.double() + b2.double())
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=3e-6, rtol=2e-5)
     np.testing.assert_allclose(out.cpu().numpy(), h2.cpu().numpy(), atol=1e-6, rtol=1e-6)
+
+
+def test_optimizer_skip_flag_and_sticky_abort_word(lib):
+    """The abort word of the fused recurrent passes is STICKY (a launch clears its hand-off counters, never word 128),
+    and sf_adam_step / sf_lamb_step leave weights and moments untouched while the word they are handed is non-zero —
+    an aborted pass in minibatch k can neither be wiped by the launch of minibatch k+1 nor reach the weights."""
+    P = 4096
+    g = torch.Generator().manual_seed(3)
+    p, gr = torch.randn(P, generator=g).cuda(), torch.randn(P, generator=g).cuda()
+    m, v = torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+    sumsq = torch.zeros(1, dtype=torch.float64, device="cuda")
+    flag = torch.ones(1, dtype=torch.int32, device="cuda")
+    p0 = p.clone()
+    lib.grad_sumsq(gr, sumsq)
+    lib.adam_step(p, gr, m, v, 1, 1e-3, 0.9, 0.999, 1e-6, 4.0, sumsq, skip_flag=flag)
+    seg = torch.zeros(P, dtype=torch.uint8, device="cuda")
+    lib.lamb_step(p, gr, m, v, torch.empty_like(p), seg, torch.zeros(128, dtype=torch.float64, device="cuda"), 1, 1, 1e-3,
+                  0.9, 0.999, 1e-6, 1e-4, 0.01, 4.0, sumsq, skip_flag=flag)
+    assert torch.equal(p, p0) and not m.any() and not v.any()
+    flag.zero_()
+    lib.adam_step(p, gr, m, v, 1, 1e-3, 0.9, 0.999, 1e-6, 4.0, sumsq, skip_flag=flag)
+    assert not torch.equal(p, p0) and m.any() and v.any()
+    # the sequence passes reset counters only
+    H, Cn, R = 512, 64, 2
+    z = lambda *s: torch.zeros(s, device="cuda")
+    sync = torch.full((192,), 5, dtype=torch.int32, device="cuda")
+    sync[128] = 0
+    hprev, cprev = z(R + 1, Cn, H), z(R + 1, Cn, H)
+    lib.lstm_seq_fwd(z(R, Cn, 4 * H), z(H, 4 * H), z(4 * H), torch.ones(R, Cn, device="cuda"), z(R, Cn, 4 * H), hprev,
+                     z(R, Cn, H), cprev, z(R, Cn, H), sync, R, Cn, H)
+    torch.cuda.synchronize()
+    assert int(sync[128]) == 0 and int(sync[129]) == 5      # finished normally; words past the abort word untouched
+    sync[128] = 1                                            # "an earlier pass aborted"
+    lib.lstm_seq_fwd(z(R, Cn, 4 * H), z(H, 4 * H), z(4 * H), torch.ones(R, Cn, device="cuda"), z(R, Cn, 4 * H), hprev,
+                     z(R, Cn, H), cprev, z(R, Cn, H), sync, R, Cn, H)
+    torch.cuda.synchronize()
+    assert int(sync[128]) == 1                               # still set after the next launch
+
+
+def test_learner_raises_and_keeps_weights_after_an_aborted_recurrent_pass(lib):
+    """Learner.train with the abort word set in the FIRST minibatch's forward pass (simulated by patching the clear):
+    every optimiser step of the call is skipped, the epoch-end readback raises, the weights are the ones before."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+    cfg = default_cfg(env="synthetic_ant", use_rnn=True, rnn_type="lstm", rnn_size=512, nonlinearity="tanh",
+                      normalize_input=True, encoder_mlp_layers=[64, 64], rollout=8, recurrence=8, batch_size=512,
+                      num_batches_per_epoch=2, num_epochs=2, num_workers=1, num_envs_per_worker=1, async_rl=False, seed=2,
+                      serial_mode=True, synthetic_num_agents=128, with_vtrace=True, normalize_returns=False)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    assert runner.iteration() is not None                      # a clean iteration first
+    ac = runner.learner.actor_critic
+    assert ac.rnn_abort_word() is not None and not ac.rnn_pass_aborted()
+    p0, m0, step0 = ac.flat_params.clone(), runner.learner.exp_avg.clone(), runner.learner.train_step
+    ac.rnn_abort_clear = lambda: ac._seq_sync_buf()[128:129].fill_(1)   # the next call starts out "aborted"
+    with pytest.raises(lib.SfHipError, match="aborted"):
+        runner.iteration()
+    torch.cuda.synchronize()
+    assert torch.equal(ac.flat_params, p0) and torch.equal(runner.learner.exp_avg, m0)
+    assert runner.learner.train_step == step0 + 2               # one epoch of (skipped) steps was issued, then the raise

@@ -413,3 +413,44 @@ def test_host_env_async_with_sampler_thread_and_pitched_ingest():
     assert sum(sm.h2d_bytes for sm in runner.samplers) >= runner.sampling_rounds * 2 * 64 * 8 * 28224
     s = runner.episode_stats()
     assert s["episodes"] >= 0
+
+
+@pytest.mark.parametrize("rnn_type", ["gru", "lstm"])
+def test_host_env_async_sampler_thread_with_recurrent_core(rnn_type):
+    """The default configuration class of the reference — async_rl + use_rnn with a HOST env — samples on a thread of
+    its own while the learner thread runs `_prepare_batch`'s bootstrap forward through the SAME model object.  The
+    one-step recurrent state a forward leaves behind is keyed by the caller's tag (`new_rnn_parts_of(tag)`): the sampler
+    must store the state ITS forward produced, not the learner's bootstrap state ([128, H] here against the sampler's
+    [64, H]: a mix-up raises in sf_rnn_store_state and kills the sampler thread).  The stored states obey the
+    reference's carry rule (batched_sampling.py:332-335): zero after a done, |h| <= 1 otherwise."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_host_frame_env
+    from sample_factory_amd.train import make_runner
+    register_env("host_atari", make_host_frame_env)
+    cfg = default_cfg(env="host_atari", use_rnn=True, rnn_type=rnn_type, rnn_size=64, recurrence=8, nonlinearity="relu",
+                      normalize_input=False, obs_scale=255.0, encoder_conv_architecture="convnet_atari", rollout=8,
+                      batch_size=512, num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=2,
+                      worker_num_splits=2, async_rl=True, serial_mode=False, seed=5, synthetic_num_agents=64,
+                      env_gpu_observations=False, env_gpu_actions=False)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    assert runner.threaded and runner.learner.actor_critic.rnn_kind is not None
+    trained = 0
+    for _ in range(8):
+        trained += runner.iteration() is not None
+    runner.stop_sampler_thread()
+    torch.cuda.synchronize()
+    assert trained == 8 and runner._thread_error is None
+    ac = runner.learner.actor_critic
+    assert set(ac._rnn_out) >= {"inf", "inf1", "boot"}          # sampler tags and the learner's tag kept apart
+    assert ac._rnn_out["inf"][0].shape[0] == 64 and ac._rnn_out["boot"][0].shape[0] == 128
+    assert torch.isfinite(ac.flat_params).all()
+    H = 64
+    for e in range(2):
+        rows = runner._prev_rows[e]
+        st, dn = rows["rnn_states"], rows["dones"]
+        assert torch.isfinite(st).all() and float(st[:, :, :H].abs().max()) <= 1.0 + 1e-6
+        nxt = st[:, 1:]                                          # state INPUT of step t+1
+        assert float(nxt[dn].abs().max() if dn.any() else 0.0) == 0.0
+        assert float(nxt[~dn].abs().max()) > 0.0
