@@ -55,6 +55,69 @@ def kernel_bytes(key):
     return float(n) * (Cin * H * W + OH * OW * Cout * 4)
 
 
+def cpu_baseline_leg(args, T):
+    """AFTER the timed region, rank 0, N = 1: the reference's CPU path timed on this box's host cores.
+    kind "reference" = the reference's own ActorCritic.forward + Learner.train (SURVEY.md 8(d) Tier B) executed from the
+    archive `make -C oracle ref` staged (oracle/_ref/, or /root/reference where that exists), in a process of its own
+    (its `sample_factory` package must not meet this repo's alias package); kind "port" (torch-CPU network + C oracle,
+    oracle/cpu_baseline.py) only when no reference is available or the reference run fails."""
+    import subprocess
+    from oracle import ref_import_path  # checker/baseline leg only; never on the measured path
+    err = None
+    if ref_import_path.reference_available():
+        try:
+            r = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", str(args.cpu_reference_envs), "6"],
+                               cwd=ROOT, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and line:
+                return json.loads(line[-1])
+            err = f"rc {r.returncode}: {r.stderr[-300:]}"
+        except Exception as e:  # noqa: BLE001 - the baseline leg must never take the bench line down
+            err = repr(e)
+    from oracle import cpu_baseline
+    res = cpu_baseline.run(num_envs=args.cpu_baseline_envs, rollout=T, num_minibatches=args.num_batches)
+    res["value"] = round(res["value"], 1)
+    if err:
+        res["reference_run_failed"] = err
+    return res
+
+
+def secondary_lines(args):
+    """AFTER the C2 timed region (rank 0, N = 1): the other single-GPU BASELINE configurations this engine runs —
+    configs[4] (c5: LSTM-512 + V-trace + Box(8), 2048 envs) and the configs[2] stand-in (c3: 1024 HOST envs ingested over
+    PCIe, env side unpinned: envpool is not installable here) — each as a process of its own running this very script,
+    summarised into the headline JSON line so that the driver observes them too.  Same contract per entry: warm-up, K
+    timed steps bracketed by synchronize, whole-job env-steps/s, roofline of that run's dominant kernel."""
+    import subprocess
+    out = []
+    for wl, steps, warm in (("c5", 6, 2), ("c3", 4, 2)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(steps), "--warmup", str(warm),
+               "--no_cpu_baseline", "--no_secondary"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=150)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out.append({"workload": wl, "error": f"rc {r.returncode}: {r.stderr[-200:]}"})
+                continue
+            d = json.loads(line[-1])
+            rf = d.get("roofline", {})
+            ent = {"workload": wl, "metric": d["metric"], "value": d["value"], "unit": d["unit"],
+                   "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
+                   "data": "synthetic", "config": d["config"]["workload"],
+                   "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                       "avg_launch_ms", "launches", "share_of_step_time")},
+                   "wall_s": round(time.perf_counter() - t0, 1)}
+            if "ingest" in d:
+                ent["ingest"] = {k: d["ingest"].get(k) for k in ("h2d_bytes_per_env_step", "obs_dma_gbs", "sampler_thread",
+                                                                  "dma_share_of_wall_clock")}
+                ent["env_side"] = "unpinned (synthetic host frames; envpool/ALE not installable)"
+            out.append(ent)
+        except Exception as e:  # noqa: BLE001 - a secondary line must never take the headline line down
+            out.append({"workload": wl, "error": repr(e)})
+    return out
+
+
 def _free_port() -> int:
     import socket
     with socket.socket() as s_:
@@ -173,8 +236,12 @@ def main():
     ap.add_argument("--num_batches", type=int, default=4)
     ap.add_argument("--num_epochs", type=int, default=None, help="default: 1 for c2, 2 for c5 (mujoco preset)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_secondary", action="store_true",
+                    help="c2, one GPU: skip the secondary workload lines (c5, c3) measured after the timed region")
     ap.add_argument("--no_kernel_events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
+    ap.add_argument("--cpu_reference_envs", type=int, default=512,
+                    help="trajectories of the sample the REFERENCE's CPU path is timed on (cpu_baseline kind 'reference')")
     ap.add_argument("--env_instances", type=int, default=1,
                     help="split the envs of a GPU into this many vector-env instances (num_envs_per_worker = "
                          "worker_num_splits = this): their rollouts run on separate HIP streams")
@@ -318,13 +385,21 @@ def main():
     avg_ms = total_ms / launches
     achieved = flops / (total_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (tools/profile_round.sh + tools/pmc_traffic.py), newest first
-    for tname in ("r02_b_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        tj = os.path.join(ROOT, "profiles", tname)
-        ent = json.load(open(tj)).get(dominant) if os.path.exists(tj) else None
-        if ent:
-            traffic, traffic_src = ent["hbm_bytes"], f"profiles/{tname} (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (tools/profile_round.sh + tools/pmc_traffic.py).  A
+    # counter file is only valid for the kernels it was measured on: it carries the hash of the kernel sources, and the
+    # field stays null when no committed file matches the code that just ran (instead of quoting a stale number).
+    import glob
+    from sample_factory_amd.build import source_sha16
+    sha = source_sha16()
+    for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        doc = json.load(open(tj))
+        ent = doc.get(dominant)
+        if ent and doc.get("_kernel_source_sha16") == sha:
+            traffic = ent["hbm_bytes"]
+            traffic_src = f"profiles/{os.path.basename(tj)} (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes; kernel sources {sha})"
             break
+    if traffic is None:
+        traffic_src = f"no PMC pass committed for kernel sources {sha} (profiles/*traffic*.json are stamped with the hash)"
     kern = []  # ranking of all network kernels from the instrumented warm-up step (NOT the timed region)
     for k2, evs2 in warm_prof.items():
         m2 = sorted(s_.elapsed_time(e_) for s_, e_ in evs2)
@@ -369,10 +444,16 @@ def main():
                             "ms_per_step": round(net_ms, 2), "tflops_avg": round(net_flops / (net_ms * 1e-3) / 1e12, 2),
                             "top": breakdown},
     }
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_secondary and not args.async_rl \
+            and args.envs == 4096:
+        # release this run's slab and activations first: the secondary runs get the whole device
+        del runner
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["secondary"] = secondary_lines(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c2":
-        from oracle import cpu_baseline  # checker/baseline leg only; never on the measured path
-        out["cpu_baseline"] = cpu_baseline.run(num_envs=args.cpu_baseline_envs, rollout=T, num_minibatches=args.num_batches)
-        out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 1)
+        out["cpu_baseline"] = cpu_baseline_leg(args, T)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -22,6 +22,14 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def build_ref() -> str:
+    """stage the reference's own Python package for the cpu_baseline leg (`make -C oracle ref`); returns the archive path
+    ('' when neither /root/reference nor a prebuilt archive exists)"""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    z = os.path.join(_HERE, "_ref", "sample_factory_ref.zip")
+    return z if os.path.exists(z) else ""
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -1,11 +1,13 @@
 """SURVEY.md §8(d) "Tier B" CPU baseline: the REFERENCE's own code (real ActorCritic.forward through
 prepare_and_normalize_obs, real Learner.train) timed on host cores for the BASELINE configs[1] workload shape.
 
-TEST/BENCH INFRASTRUCTURE; runs only where /root/reference exists (the build container), under the import stubs of
-oracle/ref_import.py.  A bounded sample is timed and extrapolated linearly to one 4096-env x 32-step iteration:
+TEST/BENCH INFRASTRUCTURE; runs where the reference is importable — /root/reference in the build container, or the
+archive `make -C oracle ref` staged from it (oracle/_ref/, travels to the GPU box) — under the import stubs of
+oracle/ref_import.py, always as a process of its own (bench.py's cpu_baseline leg starts it AFTER the timed region).
+A bounded sample is timed and extrapolated linearly to one 4096-env x 32-step iteration:
 env-steps/s = dataset size / (T x t_inference(4096 obs) + t_train(dataset)).
 
-  python -m oracle.ref_cpu_tier_b [envs_sample] > profiles/r02_cpu_reference_tierB.json
+  python -m oracle.ref_cpu_tier_b [envs_sample] [inference_seconds]
 """
 from __future__ import annotations
 
@@ -29,6 +31,7 @@ def main():
     cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(cores)
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 128   # trajectories in the timed sample
+    t_budget = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
     T, nb, full_envs = 32, 4, 4096
     obs_space = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 84, 84), np.uint8)})
     cfg = make_cfg(C2_MODEL_ARGS + [f"--rollout={T}", f"--batch_size={E * T // nb}", f"--num_batches_per_epoch={nb}",
@@ -46,7 +49,7 @@ def main():
         ac(prepare_and_normalize_obs(ac, obs0), rnn0)  # warm-up
         t0 = time.perf_counter()
         reps = 0
-        while time.perf_counter() - t0 < 8.0:
+        while time.perf_counter() - t0 < t_budget:
             ac(prepare_and_normalize_obs(ac, obs0), rnn0)
             reps += 1
         t_inf = (time.perf_counter() - t0) / reps
@@ -62,7 +65,9 @@ def main():
         sample=f"reference ActorCritic.forward on {E} obs ({t_inf * 1e3:.1f} ms, {reps} reps) and Learner.train on a "
                f"{E}x{T} dataset in {nb} minibatches ({t_train:.2f} s), torch {torch.__version__} CPU fp32, "
                f"{cores} threads; extrapolated x{scale:.0f} to one {full_envs}x{T} iteration (env excluded)",
-        t_inference_ms_per_step_sample=round(t_inf * 1e3, 2), t_train_s_sample=round(t_train, 3), where="build container")))
+        t_inference_ms_per_step_sample=round(t_inf * 1e3, 2), t_train_s_sample=round(t_train, 3),
+        reference_from=ref_import.REFERENCE_ROOT,
+        where="build container" if os.path.isdir("/root/reference") else "GPU box host cores")))
 
 
 if __name__ == "__main__":

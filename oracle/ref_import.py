@@ -1,7 +1,9 @@
-"""Import shim for the *reference* (Sample Factory, /root/reference) inside the build container.
+"""Import shim for the *reference* (Sample Factory): /root/reference inside the build container, or — where that does
+not exist (the GPU box) — the archive `make -C oracle ref` staged from it under oracle/_ref/.
 
-TEST INFRASTRUCTURE ONLY.  This module is used by ``oracle/gen_golden.py`` (and nothing else) to import the
-reference's own Python modules so that golden vectors can be generated from the reference itself.  The
+TEST / BENCH INFRASTRUCTURE ONLY.  This module is used by ``oracle/gen_golden.py`` (golden vectors generated from the
+reference itself) and by ``oracle/ref_cpu_tier_b.py`` (bench.py's cpu_baseline leg, a subprocess of its own: the
+reference timed on the host cores) to import the reference's own Python modules.  The
 reference cannot be imported as-is here because six third-party packages it imports at module top are not
 installed (gymnasium, signal_slot/faster_fifo, colorlog, tensorboardX, cv2, wandb) and there is no network.
 We register minimal stand-ins for those names in ``sys.modules`` *before* importing ``sample_factory``.
@@ -19,7 +21,7 @@ import types
 
 import numpy as np
 
-REFERENCE_ROOT = "/root/reference"
+from oracle.ref_import_path import REFERENCE_ROOT, reference_available  # noqa: E402,F401
 
 
 def _mod(name: str) -> types.ModuleType:

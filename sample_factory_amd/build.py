@@ -21,6 +21,18 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
           f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
 
+def source_sha16() -> str:
+    """sha256[:16] over the kernel sources (csrc/*.hip, csrc/*.h, include/sf_hip.h, in name order): stamps measurements
+    that are only valid for the code they were taken on (profiles/*traffic*.json, read back by bench.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for path in files + [os.path.join(ROOT, "include", "sf_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True

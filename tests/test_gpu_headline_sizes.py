@@ -1,0 +1,405 @@
+"""Parity AT THE LAUNCH SIZES THE HEADLINE NUMBER IS MEASURED AT (bench.py --workload c2 = BASELINE.json configs[1]).
+
+The bench state is built for real: 4096 device-resident synthetic envs, rollout 32 -> a 4096 x 33 x 28224 B slab of u8
+frames written by sf_synth_obs (3.8 GB; row byte offsets past 2^31), seeded Nature-CNN (1 687 719 parameters), NS-2
+learner preset (4 minibatches of 32768).  Everything below runs on the LAST minibatch — dataset offset 3 * 32768, slab
+addressing through traj_T = 32 — with the kernels of the benchmark (names asserted against sf_conv_kernel_name):
+
+ (a) forward, n = 32768: every layer's output rows are BIT-equal to the same kernel run on a permuted, compacted copy of
+     its input (a row's result may not depend on where in the batch / slab it sits: persistent-grid trip counts, tile
+     tails, 64-bit addressing), 512 random rows within fp32 round-off of rollout-size compact launches, 64 rows within
+     1e-6 * max of torch float64 per layer (heads end-to-end: 3e-6);
+ (b) weight / data gradients, n = 32768: against the sum / concatenation of eight n = 4096 launches on the same operands
+     (2e-5 * max) and against float64 (im2col + matmul on the GPU) for every layer;
+ (c) the dataset path: valids / advantages / returns / invalid count of `_prepare_batch` at (4096, 32) against the CPU
+     oracle and against 64-env slices through the golden-pinned small path (bit-equal), loss scalars and loss-head
+     gradients of the 32768-sample minibatch against the oracle;
+ (d) conv1 reading the LAST rows of a 32768-env slab (31 GB; byte offsets past 2^34).
+
+Reference: sample_factory/algo/learning/learner.py:671-841 (`_train`), :943-1034 (`_prepare_batch`), :537-669.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+E, T, NMB = 4096, 32, 4
+N = E * T // NMB          # 32768 samples per minibatch
+OFF = (NMB - 1) * N       # the last minibatch: dataset rows [98304, 131072)
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sample_factory_amd import lib as L
+    L.load()
+    return L
+
+
+@pytest.fixture(scope="module")
+def st(lib):
+    """the bench's own state after one rollout, + forward / loss / backward of the last minibatch"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_atari", make_synthetic_env)
+    cfg = default_cfg(  # == bench.py workload_cfg("c2")
+        env="synthetic_atari", use_rnn=False, recurrence=1, encoder_conv_architecture="convnet_atari", nonlinearity="relu",
+        encoder_conv_mlp_layers=[512], obs_scale=255.0, normalize_input=False, normalize_returns=True, gamma=0.99,
+        gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0, value_loss_coeff=0.5, exploration_loss_coeff=0.01,
+        max_grad_norm=4.0, learning_rate=1e-4, adam_eps=1e-6, synthetic_env0=0, rollout=T, batch_size=N,
+        num_batches_per_epoch=NMB, num_epochs=1, async_rl=False, serial_mode=True, batched_sampling=True, num_workers=1,
+        num_envs_per_worker=1, worker_num_splits=1, env_gpu_observations=True, env_gpu_actions=True, seed=0,
+        synthetic_num_agents=E)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    ln, ac = runner.learner, runner.learner.actor_critic
+    assert ac.num_params() == 1687719
+    runner._rollout_all(float(ln.train_step))
+    ds = runner._ready.pop(0)
+    batch = runner.traj[ds]
+    assert batch["obs"]["obs"].shape == (E, T + 1, 4, 84, 84) and batch["obs"]["obs"].numel() > 2 ** 31
+    # a few rows of another policy / stale versions, so that valids, invalid counts and masked means are exercised
+    g = torch.Generator().manual_seed(1)
+    bad = torch.randperm(E * T, generator=g)[: E * T // 50].cuda()
+    batch["policy_id"].view(-1)[bad[: len(bad) // 2]] = 3
+    batch["policy_version"].view(-1)[bad[len(bad) // 2:]] = -5000.0
+    snap = {k: batch[k].clone() for k in ["rewards", "dones", "time_outs", "policy_id", "policy_version", "actions",
+                                          "log_prob_actions", "values"]}
+    rms0 = ac.returns_normalizer.stats.clone()
+    buff, size, ninv = ln._prepare_batch(batch)
+    assert size == E * T
+    mb = (None, OFF, N)
+    acts, g_heads, scalars = ln._losses_native(buff, mb, ninv)
+    acts = [a for a in acts]
+    ac.backward(acts, g_heads, buff.obs, N, sample_stride=ac.obs_elems, index=None, offset=OFF, traj_T=T)
+    torch.cuda.synchronize()
+    s = dict(runner=runner, ln=ln, ac=ac, batch=batch, buff=buff, ninv=ninv, acts=acts, g_heads=g_heads,
+             scalars=scalars.clone(), snap=snap, rms0=rms0, cfg=cfg, grads=ac.flat_grads.clone())
+    yield s
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        json.dump(REPORT, open(os.path.join(OUT, "headline_parity.json"), "w"), indent=1)
+    except OSError:
+        pass
+
+
+def _rows(batch, rows):
+    """u8 frames of dataset rows `rows` (flat e*T+t), gathered into a dense batch"""
+    return batch["obs"]["obs"][rows // T, rows % T].contiguous()
+
+
+def _name(lib, op, n, d):
+    return lib.conv_kernel_name({"fwd": 0, "wgrad": 1, "dgrad": 2, "fwd_t": 3}[op], n, d)
+
+
+def test_dispatch_is_the_benchmarks(lib, st):
+    """the launches below are the kernels of profiles/r0x_*_kernel_stats.csv"""
+    L = st["ac"].layers
+    d0 = lib.sf_conv_desc.from_buffer_copy(L[0].desc)
+    d0.traj_T = T
+    assert _name(lib, "fwd", N, d0) == "k_conv1_u8_bf16<false>"
+    assert _name(lib, "wgrad", N, d0) == "k_conv1_wgrad_bf16<false>"
+    assert _name(lib, "fwd_t", N, L[1].desc) == "k_fwd_glds<128, 64, 2, 2, 2>"
+    assert _name(lib, "fwd_t", N, L[2].desc).startswith("k_fwd_img<64, 9, 9, 3, 1")
+    assert _name(lib, "fwd_t", N, L[3].desc) == "k_fwd_glds<128, 128, 2, 2, 2>"
+    assert _name(lib, "wgrad", N, L[1].desc) == "k_wgrad_glds<256, 64, 4, 1>"
+    assert _name(lib, "wgrad", N, L[2].desc) == "k_wgrad_glds<128, 64, 2, 2>"
+    assert _name(lib, "wgrad", N, L[3].desc) == "k_wgrad_glds<128, 128, 2, 2>"
+    assert _name(lib, "dgrad", N, L[1].desc).startswith("k_dgrad_quadrow<128, 128")
+    assert _name(lib, "dgrad", N, L[2].desc).startswith("k_dgrad_pix<128, 64")
+    REPORT["kernels"] = {f"{op}:{i}": _name(lib, op, N, L[i].desc) for i in range(1, 5) for op in ("fwd_t", "wgrad", "dgrad")}
+
+
+def test_forward_rows_do_not_depend_on_batch_position(lib, st):
+    """(a) bit-equality under a permutation of the batch, layer by layer, at n = 32768"""
+    ac, batch, acts = st["ac"], st["batch"], st["acts"]
+    g = torch.Generator().manual_seed(7)
+    perm = torch.randperm(N, generator=g).cuda()
+    rows = OFF + perm
+    # conv1: slab addressing (offset 98304, traj_T 32) vs a dense copy in permuted order
+    dense = _rows(batch, rows)
+    L0 = ac.layers[0]
+    out = torch.empty_like(acts[0])
+    lib.conv_fwd_raw(dense, ac.obs_elems, None, 0, L0.w, L0.b, out, N, L0.desc)
+    assert torch.equal(out.view(N, -1), acts[0].view(N, -1)[perm]), "conv1"
+    del dense, out
+    # and through an explicit index into the slab (the shuffled-minibatch path)
+    idx = rows.to(torch.int32)
+    d0 = lib.sf_conv_desc.from_buffer_copy(L0.desc)
+    d0.traj_T = T
+    out = torch.empty_like(acts[0])
+    lib.conv_fwd_raw(batch["obs"]["obs"], ac.obs_elems, idx, 0, L0.w, L0.b, out, N, d0)
+    assert torch.equal(out.view(N, -1), acts[0].view(N, -1)[perm]), "conv1 through an index"
+    del out
+    for li in range(1, len(ac.layers)):
+        L = ac.layers[li]
+        x = acts[li - 1].view(N, -1)[perm].contiguous()
+        out = torch.empty_like(acts[li])
+        ac._gemm(li, x, x.shape[1], None, 0, 0, out, N, "probe")
+        assert torch.equal(out.view(N, -1), acts[li].view(N, -1)[perm]), f"layer {li} ({L.name})"
+        del x, out
+
+
+def test_forward_rows_vs_compact_launches_and_float64(lib, st):
+    """(a) 512 random rows against rollout-size compact launches (other tile / split-K plans: fp32 round-off, 2e-6 * max)
+    and 64 rows against torch float64, every layer fed with OUR input of that layer (1e-6 * max), heads end to end"""
+    ac, batch, acts = st["ac"], st["batch"], st["acts"]
+    g = torch.Generator().manual_seed(8)
+    pick = torch.randperm(N, generator=g)[:512].cuda()
+    rest = torch.randperm(N, generator=g)[:4096 - 512].cuda()
+    sel = torch.cat([pick, rest])                      # 4096 rows, the first 512 are the ones compared
+    x = _rows(batch, OFF + sel)
+    rep = {}
+    for li, L in enumerate(ac.layers):
+        out = torch.empty((4096 * L.out_pixels, L.N), device="cuda")
+        if li == 0:
+            lib.conv_fwd_raw(x, ac.obs_elems, None, 0, L.w, L.b, out, 4096, L.desc)
+        else:
+            ac._gemm(li, x, x.shape[1], None, 0, 0, out, 4096, "probe")
+        got, want = out.view(4096, -1)[:512], acts[li].view(N, -1)[pick]
+        err = float((got - want).abs().max() / want.abs().max())
+        rep[f"layer{li}"] = err
+        assert err < 2e-6, (li, err)
+        x = acts[li].view(N, -1)[sel].contiguous()     # next layer: the big launch's own activations
+    REPORT["fwd_n32768_vs_n4096_maxmax"] = rep
+    # ---- float64, 64 rows
+    r64 = pick[:64]
+    sd = {k: v.double().cuda() for k, v in ac.state_dict().items() if v.dtype == torch.float32}
+    p = "encoder.encoders.obs.enc."
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)
+    nchw = lambda a, C, H, W: a.view(-1, H, W, C).permute(0, 3, 1, 2).double()
+    frames = _rows(batch, OFF + r64).double() / 255.0
+    a0 = acts[0].view(N, -1)[r64]
+    a1 = acts[1].view(N, -1)[r64]
+    a2 = acts[2].view(N, -1)[r64]
+    a3 = acts[3].view(N, -1)[r64]
+    hd = acts[4].view(N, -1)[r64]
+    conv = lambda x_, i, s_: F.relu(F.conv2d(x_, sd[p + f"conv_head.{i}.weight"], sd[p + f"conv_head.{i}.bias"], stride=s_))
+    r0 = conv(frames, 0, 4)
+    r1 = conv(nchw(a0, 32, 20, 20), 2, 2)
+    r2 = conv(nchw(a1, 64, 9, 9), 4, 1)
+    # the fc layer of the reference flattens NCHW; ours NHWC with the weight permuted accordingly (state_dict converts)
+    r3 = F.relu(F.linear(nchw(a2, 64, 7, 7).flatten(1), sd[p + "mlp_layers.0.weight"], sd[p + "mlp_layers.0.bias"]))
+    head = lambda f_: torch.cat([F.linear(f_, sd["critic_linear.weight"], sd["critic_linear.bias"]),
+                                 F.linear(f_, sd["action_parameterization.distribution_linear.weight"],
+                                          sd["action_parameterization.distribution_linear.bias"])], dim=1)
+    r4 = head(a3.double())
+    e = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    errs = dict(conv1=e(a0, nhwc(r0)), conv2=e(a1, nhwc(r1)), conv3=e(a2, nhwc(r2)), fc=e(a3, r3), heads=e(hd[:, :7], r4))
+    # end to end: the float64 network from the frames
+    f1 = conv(conv(r0, 2, 2), 4, 1)
+    e2e = head(F.relu(F.linear(f1.flatten(1), sd[p + "mlp_layers.0.weight"], sd[p + "mlp_layers.0.bias"])))
+    errs["heads_end_to_end"] = e(hd[:, :7], e2e)
+    REPORT["fwd_n32768_vs_float64_maxmax"] = errs
+    for k, v in errs.items():
+        assert v < (3e-6 if k == "heads_end_to_end" else 1e-6), (k, v)
+
+
+def _unfold_wgrad64(x_nchw, dy, K, S, chunk):
+    """float64 weight gradient of a conv layer by im2col + matmul on the GPU: x [n,C,H,W] (any dtype), dy [n*OH*OW, Cout]
+    (our NHWC rows) -> (dW [Cout, C, K, K], db [Cout])"""
+    n, C = x_nchw.shape[:2]
+    Cout = dy.shape[1]
+    dw = torch.zeros((C * K * K, Cout), dtype=torch.float64, device="cuda")
+    dyv = dy.view(n, -1, Cout)
+    for i in range(0, n, chunk):
+        cols = F.unfold(x_nchw[i:i + chunk].double(), K, stride=S)             # [c, C*K*K, P]
+        dw += torch.einsum("nkp,npc->kc", cols, dyv[i:i + chunk].double())
+    return dw.t().reshape(Cout, C, K, K), dy.double().sum(0)
+
+
+def test_weight_gradients_vs_eight_launches_and_float64(lib, st):
+    """(b) every layer's weight / bias gradient at n = 32768 (the values Adam consumed in this very step: flat_grads of
+    the last minibatch) against the sum of eight n = 4096 launches on the same operands and against float64"""
+    ac, batch, acts, g_heads = st["ac"], st["batch"], st["acts"], st["g_heads"]
+    saved = st["grads"]
+    rep = {}
+    for li, L in enumerate(ac.layers):
+        d = L.desc
+        dy = g_heads if li == len(ac.layers) - 1 else ac._bufs[("g", li)]
+        dy = dy.view(N * L.out_pixels, L.N)
+        o, ob = ac._segs[li]
+        gw_full = saved[o:o + L.K * L.N].view(L.K, L.N)
+        gb_full = saved[ob:ob + L.N]
+        gw_sum, gb_sum = torch.zeros_like(gw_full, dtype=torch.float64), torch.zeros_like(gb_full, dtype=torch.float64)
+        tw, tb = torch.empty_like(gw_full), torch.empty_like(gb_full)
+        rows_per = 4096 * L.out_pixels
+        for k in range(8):
+            dyk = dy[k * rows_per:(k + 1) * rows_per]
+            if li == 0:
+                d0 = lib.sf_conv_desc.from_buffer_copy(d)
+                d0.traj_T = T
+                ws = ac._workspace(lib.conv_wgrad_workspace(4096, d0))
+                lib.conv_wgrad_raw(batch["obs"]["obs"], ac.obs_elems, None, OFF + k * 4096, dyk, tw, tb, 4096, d0, ws)
+            else:
+                xin = acts[li - 1].view(N, -1)[k * 4096:(k + 1) * 4096]
+                ws = ac._workspace(lib.conv_wgrad_workspace(4096, d))
+                lib.conv_wgrad_raw(xin, xin.shape[1], None, 0, dyk, tw, tb, 4096, d, ws)
+            gw_sum += tw.double()
+            gb_sum += tb.double()
+        sw, sb = float(gw_full.abs().max()), float(gb_full.abs().max())
+        e8w, e8b = float((gw_full.double() - gw_sum).abs().max()) / sw, float((gb_full.double() - gb_sum).abs().max()) / sb
+        # float64 from OUR operands of that layer
+        if li == 0:
+            x64 = _rows(batch, OFF + torch.arange(N, device="cuda"))
+            dw64, db64 = _unfold_wgrad64(x64, dy, 8, 4, 1024)
+            dw64 = dw64 / 255.0
+            ref = dw64.reshape(L.N, -1).t()                                   # k = (c*KH+kh)*KW+kw
+            del x64
+        elif L.kind == "conv":
+            x64 = acts[li - 1].view(N, d.H, d.W, d.Cin).permute(0, 3, 1, 2)
+            dw64, db64 = _unfold_wgrad64(x64, dy, d.KH, d.stride, 2048)
+            ref = dw64.permute(2, 3, 1, 0).reshape(L.K, L.N)                  # k = (kh*KW+kw)*Cin+c
+        else:
+            xin = acts[li - 1].view(N, -1)
+            ref = torch.zeros((L.K, L.N), dtype=torch.float64, device="cuda")
+            for i in range(0, N, 8192):
+                ref += xin[i:i + 8192].double().t() @ dy[i:i + 8192].double()
+            db64 = dy.double().sum(0)
+        e64w = float((gw_full.double() - ref).abs().max() / ref.abs().max())
+        e64b = float((gb_full.double() - db64).abs().max() / db64.abs().max())
+        rep[L.name] = dict(vs_8x4096_w=e8w, vs_8x4096_b=e8b, vs_float64_w=e64w, vs_float64_b=e64b)
+        assert e8w < 2e-5 and e8b < 2e-5, (L.name, e8w, e8b)
+        assert e64w < 3e-6 and e64b < 3e-6, (L.name, e64w, e64b)
+    REPORT["wgrad_n32768_maxmax"] = rep
+
+
+def test_data_gradients_vs_eight_launches_and_float64(lib, st):
+    """(b) conv2 / conv3 / fc / heads data gradients at n = 32768 (ReLU mask of the producer fused) against eight
+    n = 4096 launches on the same operands (row results are independent: 1e-6 * max) and against float64"""
+    ac, acts, g_heads = st["ac"], st["acts"], st["g_heads"]
+    rep = {}
+    nl = len(ac.layers)
+    for li in range(1, nl):
+        L = ac.layers[li]
+        d = lib.sf_conv_desc.from_buffer_copy(L.desc)
+        d.relu = L.in_act_kind
+        dy = (g_heads if li == nl - 1 else ac._bufs[("g", li)]).view(N * L.out_pixels, L.N)
+        full = ac._bufs[("g", li - 1)].view(N, -1)
+        x = acts[li - 1].view(N, -1)
+        part = torch.empty((4096, full.shape[1]), device="cuda")
+        worst = 0.0
+        rows_per = 4096 * L.out_pixels
+        for k in range(8):
+            lib.conv_dgrad(dy[k * rows_per:(k + 1) * rows_per], L.w, x[k * 4096:(k + 1) * 4096].contiguous(), part, 4096, d)
+            worst = max(worst, float((part - full[k * 4096:(k + 1) * 4096]).abs().max()))
+        s = float(full.abs().max())
+        # float64: dX = mask(x) * (dY @ W^T) folded back onto the input pixels
+        W64 = L.w.double()                                                     # [K, Cout], k = (kh*KW+kw)*Cin+c
+        e64 = 0.0
+        dd = L.desc
+        for i in range(0, N, 4096):
+            dyc = dy[i * L.out_pixels:(i + 4096) * L.out_pixels].double()
+            cols = dyc @ W64.t()                                               # [c*P, K]
+            if L.kind == "conv":
+                cols = cols.view(4096, L.out_pixels, dd.KH, dd.KW, dd.Cin).permute(0, 4, 2, 3, 1)
+                cols = cols.reshape(4096, dd.Cin * dd.KH * dd.KW, L.out_pixels)
+                dx = F.fold(cols, (dd.H, dd.W), dd.KH, stride=dd.stride).permute(0, 2, 3, 1).reshape(4096, -1)
+            else:
+                dx = cols
+            dx = dx * (x[i:i + 4096] > 0)
+            e64 = max(e64, float((full[i:i + 4096].double() - dx).abs().max() / dx.abs().max()))
+        rep[L.name] = dict(vs_8x4096=worst / s, vs_float64=e64)
+        assert worst / s < 1e-6, (L.name, worst / s)
+        assert e64 < 2e-6, (L.name, e64)
+    REPORT["dgrad_n32768_maxmax"] = rep
+
+
+def test_prepare_batch_and_loss_at_full_size_vs_oracle_and_slices(lib, st):
+    """(c) the dataset path at (4096, 32): valids, invalid count, advantages, returns against the CPU oracle (returns /
+    advantages <= 1e-5, the north star asks 1e-4) and, through the golden-pinned small path, 64 envs at a time (GAE is
+    per-env: bit-equal); loss scalars and loss-head gradients of the n = 32768 minibatch against the oracle"""
+    ln, ac, batch, buff, snap, cfg = st["ln"], st["ac"], st["batch"], st["buff"], st["snap"], st["cfg"]
+    c = lambda t: t.cpu().numpy()
+    values_in = c(batch["values"])            # [:, T] already holds the bootstrap value written by _prepare_batch
+    ref = oracle.prepare_batch(c(snap["rewards"]), c(snap["dones"]), c(snap["time_outs"]), values_in, c(snap["policy_id"]),
+                               c(snap["policy_version"]), c(snap["actions"]), c(snap["log_prob_actions"]), my_policy_id=0,
+                               train_step=0, max_policy_lag=cfg.max_policy_lag, normalize_returns=True,
+                               value_bootstrap=False, gamma=cfg.gamma, lam=cfg.gae_lambda, rms=c(st["rms0"]))
+    assert st["ninv"] == ref["num_invalids"] > 0
+    assert np.array_equal(c(batch["valids"]), ref["valids"])
+    np.testing.assert_allclose(c(buff.advantages).reshape(E, T), ref["advantages"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(c(buff.returns).reshape(E, T), ref["returns"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_array_equal(c(buff.actions).reshape(E, T), ref["actions"].reshape(E, T))
+    np.testing.assert_array_equal(c(buff.log_prob_actions).reshape(E, T), ref["log_prob_actions"])
+    # 64-env slices through the same kernel at the golden-pinned size: bit-equal advantages and (pre-normalisation) returns
+    adv_f, ret_f = torch.empty((E, T), device="cuda"), torch.empty((E, T), device="cuda")
+    lib.gae_returns(batch["rewards"], batch["dones"], batch["time_outs"], batch["values"], batch["valids"], st["rms0"],
+                    cfg.gamma, cfg.gae_lambda, False, adv_f, ret_f)
+    assert torch.equal(adv_f.view(-1), buff.advantages)
+    a64, r64 = torch.empty((64, T), device="cuda"), torch.empty((64, T), device="cuda")
+    for e0 in range(0, E, 64 * 8):  # every 8th slice keeps the test short
+        sl = slice(e0, e0 + 64)
+        lib.gae_returns(batch["rewards"][sl].contiguous(), batch["dones"][sl].contiguous(),
+                        batch["time_outs"][sl].contiguous(), batch["values"][sl].contiguous(),
+                        batch["valids"][sl].contiguous(), st["rms0"], cfg.gamma, cfg.gae_lambda, False, a64, r64)
+        assert torch.equal(a64, adv_f[sl]) and torch.equal(r64, ret_f[sl])
+    # ---- loss of the last minibatch (offset 98304, n 32768): scalars and loss-head gradients vs the oracle
+    sl = slice(OFF, OFF + N)
+    heads = st["acts"][-1]
+    A = ln.num_action_params
+    lo = oracle.ppo_loss(c(heads[:, 1:1 + A]), c(heads[:, 0]), c(buff.actions[sl]), c(buff.log_prob_actions[sl]),
+                         c(buff.action_logits[sl]), c(buff["values"][sl]), c(buff.advantages[sl]), c(buff.returns[sl]),
+                         c(buff.valids[sl]), action_kind=0, clip_ratio=cfg.ppo_clip_ratio, clip_value=cfg.ppo_clip_value,
+                         value_loss_coeff=cfg.value_loss_coeff, exploration_coeff=cfg.exploration_loss_coeff,
+                         exploration_kind=1, kl_coeff=0.0)
+    sc = c(st["scalars"])
+    names = ["policy_loss", "exploration_loss", "kl_loss", "value_loss", "kl_mean", "kl_max", "adv_mean", "adv_std",
+             "n_valid", "entropy_mean"]
+    got = dict(zip(names, sc[:10].tolist()))
+    assert got["n_valid"] == lo["n_valid"]
+    for k in ["policy_loss", "exploration_loss", "value_loss", "adv_mean", "adv_std", "entropy_mean"]:
+        assert abs(got[k] - lo[k]) < 1e-6 + 2e-5 * abs(lo[k]), (k, got[k], lo[k])
+    gh = c(st["g_heads"])
+    np.testing.assert_allclose(gh[:, 1:1 + A], lo["grad_params"], atol=1e-9, rtol=5e-4)
+    np.testing.assert_allclose(gh[:, 0], lo["grad_values"], atol=1e-9, rtol=5e-4)
+    REPORT["loss_scalars_n32768"] = {k: [got[k], lo[k]] for k in names}
+
+
+def test_conv1_reads_the_last_rows_of_a_32768_env_slab(lib):
+    """(d) BASELINE configs[3] per-GPU... as ONE slab: 32768 envs x 33 frames = 30.5 GB; forward and weight gradient of
+    the dataset's last 32768 rows (envs 31744..32767, byte offsets past 2^34) are bit-equal to a dense copy"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import ActorCritic
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 40 GB of free HBM")
+    Eb = 32768
+    torch.cuda.empty_cache()
+    slab = torch.empty((Eb, T + 1, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    e0 = Eb - N // T
+    lib.synth_obs(slab[e0:].data_ptr(), 28224, (Eb - e0) * (T + 1), 7, 28224, 5, 9)  # the last 1024 envs, all 33 slots
+    cfg = default_cfg(use_rnn=False, nonlinearity="relu", normalize_input=False, encoder_conv_architecture="convnet_atari",
+                      obs_scale=255.0, seed=0)
+    torch.manual_seed(0)
+    ac = ActorCritic(cfg, spaces.Dict({"obs": spaces.Box(0, 255, (4, 84, 84), np.uint8)}), spaces.Discrete(6), "cuda")
+    L0 = ac.layers[0]
+    d = lib.sf_conv_desc.from_buffer_copy(L0.desc)
+    d.traj_T = T
+    off = Eb * T - N
+    out1 = torch.empty((N * 400, 32), device="cuda")
+    lib.conv_fwd_raw(slab, 28224, None, off, L0.w, L0.b, out1, N, d)
+    rows = off + torch.arange(N, device="cuda")
+    dense = slab[rows // T, rows % T].contiguous()
+    out2 = torch.empty_like(out1)
+    lib.conv_fwd_raw(dense, 28224, None, 0, L0.w, L0.b, out2, N, L0.desc)
+    assert out1.abs().max() > 0 and torch.equal(out1, out2)
+    dy = torch.randn((N * 400, 32), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    ws = torch.empty(lib.conv_wgrad_workspace(N, d), dtype=torch.uint8, device="cuda")
+    dw1, db1, dw2, db2 = (torch.zeros_like(L0.gw), torch.zeros_like(L0.gb), torch.zeros_like(L0.gw), torch.zeros_like(L0.gb))
+    lib.conv_wgrad_raw(slab, 28224, None, off, dy, dw1, db1, N, d, ws)
+    lib.conv_wgrad_raw(dense, 28224, None, 0, dy, dw2, db2, N, L0.desc, ws)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    del slab, dense
+    torch.cuda.empty_cache()

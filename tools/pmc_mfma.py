@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY \
               SQ_WAVE_CYCLES SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/pmc -o p -- \
-              python bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_events
+              python bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_secondary --no_kernel_events
     python tools/pmc_mfma.py gpurun_out/pmc/p_counter_collection.csv profiles/rNN_mfma_util.json
 
 Units (checked against the instruction counts of the same pass):

@@ -5,11 +5,16 @@
 
 Units/corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the
 bytes of a wide coalesced read stream, so reads are doubled; WRITE_SIZE is taken as is (it matched the algorithmic output
-size of every kernel here to <0.1 %).  A kernel is matched to a bench label by (op, bytes written)."""
+size of every kernel here to <0.1 %).  A kernel is matched to a bench label by (op, bytes written).  The output carries
+the hash of the kernel sources it was measured on (`_kernel_source_sha16`)."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sample_factory_amd.build import source_sha16  # noqa: E402
 
 LAYERS = {  # label-stem -> (Cin, H, W, Cout, K, S, OH, OW)
     "4x84->32": (4, 84, 84, 32, 8, 4, 20, 20), "32x20->64": (32, 20, 20, 64, 4, 2, 9, 9),
@@ -61,6 +66,7 @@ def main():
     # wgrad: one launch per layer per minibatch, identified by the layer's K*N partial size pattern (largest fetch first)
     wg = sorted(((fetch.get(k, 0), k) for k in write if "k_conv_wgrad<" in k[0]), reverse=True)
     out["_wgrad_unmatched"] = [dict(kernel=k[0][:60], grid=k[1], fetch_kib=round(f, 1), write_kib=round(write[k], 1)) for f, k in wg]
+    out["_kernel_source_sha16"] = source_sha16()  # bench.py drops roofline.traffic when the kernels have changed since
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -9,8 +9,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-B="python bench.py --steps 6 --warmup 2 --no_cpu_baseline"
-B1="python bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_events"
+B="python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_secondary"
+B1="python bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_secondary --no_kernel_events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $B > $O/trace_bench.json 2> $O/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- $B1 > /dev/null 2> $O/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- $B1 > /dev/null 2> $O/write.err
