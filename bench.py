@@ -66,7 +66,7 @@ def cpu_baseline_leg(args, T):
     err = None
     if ref_import_path.reference_available():
         try:
-            r = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", str(args.cpu_reference_envs), "6"],
+            r = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", str(args.cpu_reference_envs), "5", "auto"],
                                cwd=ROOT, capture_output=True, text=True, timeout=240)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode == 0 and line:
@@ -174,7 +174,10 @@ def workload_cfg(args, rank, world):
                   num_epochs=args.num_epochs, async_rl=args.async_rl, serial_mode=not args.async_rl, batched_sampling=True,
                   num_workers=1, num_envs_per_worker=args.env_instances, worker_num_splits=args.env_instances,
                   env_gpu_observations=True, env_gpu_actions=True, actor_worker_gpus=[0], seed=0,
-                  synthetic_num_agents=B // args.env_instances, data_parallel=world > 1)
+                  synthetic_num_agents=B // args.env_instances, data_parallel=world > 1,
+                  # SF_DP_NATIVE=1: gradient buckets through the C-ABI (sf_allreduce_grads, one RCCL communicator per rank)
+                  # instead of torch.distributed — both exchange paths can be measured by the same --gpus N run
+                  dp_native_rccl=os.environ.get("SF_DP_NATIVE", "0") not in ("", "0"))
     mode = "async (rollout k+1 || train k)" if args.async_rl else "sync"
     if args.workload == "c2":
         cfg = default_cfg(
@@ -240,7 +243,7 @@ def main():
                     help="c2, one GPU: skip the secondary workload lines (c5, c3) measured after the timed region")
     ap.add_argument("--no_kernel_events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
-    ap.add_argument("--cpu_reference_envs", type=int, default=512,
+    ap.add_argument("--cpu_reference_envs", type=int, default=256,
                     help="trajectories of the sample the REFERENCE's CPU path is timed on (cpu_baseline kind 'reference')")
     ap.add_argument("--env_instances", type=int, default=1,
                     help="split the envs of a GPU into this many vector-env instances (num_envs_per_worker = "
@@ -323,6 +326,9 @@ def main():
         dominant = max(by_name, key=by_name.get)
         lib.PROFILE, lib.PROFILE_ONLY = {}, {key for key in warm_prof if key[-1] == dominant}
     env_steps0, rounds0 = runner.learner.env_steps, runner.sampling_rounds
+    grp = getattr(runner.learner, "group", None)
+    if world > 1 and grp is not None:
+        grp.enable_timing()  # HIP-event pairs around every collective of the timed region (algo/learning/dp.py)
     if args.workload == "c3":
         for sm in runner.samplers:
             sm.ingest_prof, sm.h2d_bytes = {}, 0
@@ -353,10 +359,28 @@ def main():
                   "sampler_thread": bool(runner.threaded),
                   "dma_share_of_wall_clock": round(dma_ms * 1e-3 / dt, 4)}
     prof, lib.PROFILE, lib.PROFILE_ONLY = lib.PROFILE, None, None
+    collectives = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        summ = grp.timing_summary() if grp is not None else None
+        if summ is not None:
+            # per rank: time the compute stream spent at collectives (exposed), duration of the gradient exchange on its
+            # own stream (native path only) and the number of collectives, per step
+            mine = torch.tensor([summ[0], -1.0 if summ[1] is None else summ[1], float(summ[2])], dtype=torch.float64,
+                                device="cuda")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+            collectives = {
+                "gradient_exchange": "sf_allreduce_grads (C-ABI, own RCCL communicator + exchange stream)"
+                if grp.native else "torch.distributed all_reduce (RCCL), async tail bucket",
+                "exposed_ms_per_step": [round(float(a[0]) / args.steps, 3) for a in allr],
+                "allreduce_ms_per_step": [None if float(a[1]) < 0 else round(float(a[1]) / args.steps, 3) for a in allr],
+                "collectives_per_step": [round(float(a[2]) / args.steps, 1) for a in allr],
+                "note": "exposed = HIP-event pairs on the compute stream around every collective / bucket wait; "
+                        "allreduce = pairs on the exchange stream (native path; torch's collectives run on a stream of "
+                        "its own that cannot be bracketed from outside)"}
     env_steps = (runner.learner.env_steps - env_steps0) if args.workload == "c3" else args.steps * B * T * world
     value = env_steps / dt
 
@@ -365,6 +389,7 @@ def main():
             print(json.dumps({"metric": metric, "value": round(value, 1), "unit": "env-steps/s",
                               "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": world, "rccl_ranks": rccl_ranks,
                               "rank_devices": rank_devices, "config": {"workload": workload_desc},
+                              **({"collectives": collectives} if collectives else {}),
                               **({"ingest": ingest} if ingest is not None else {})}))
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -439,6 +464,7 @@ def main():
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
                    "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},
         "roofline": roofline,
+        **({"collectives": collectives} if collectives else {}),
         **({"ingest": ingest} if ingest is not None else {}),
         "network_kernels": {"source": "instrumented warm-up step (every launch timed in isolation; not the timed region)",
                             "ms_per_step": round(net_ms, 2), "tflops_avg": round(net_flops / (net_ms * 1e-3) / 1e12, 2),

@@ -35,10 +35,12 @@ int sf_abi_version(void);
 /* ---- K13: validity mask ---------------------------------------------------------------------------------
  * learner.py:949-955 (valids = policy_id==pid & train_step-policy_version < max_policy_lag; last column copies
  * the previous one) and :1021-1032 (count invalids; actions=0, log_prob_actions=-1 at invalid rows).
- * valids [E,T+1] u8 out; num_invalid: device int32 (overwritten). actions [E*T*num_actions], logp [E*T] in/out. */
-int sf_valid_mask(const int32_t *policy_id, const float *policy_version, uint8_t *valids, float *actions,
-                  int num_actions, float *log_prob_actions, int E, int T, int my_policy_id, int train_step,
-                  int max_policy_lag, int32_t *num_invalid, void *stream);
+ * valids [E,T+1] u8 out; valids_flat (may be NULL): the same mask as the flat [E*T] dataset array the minibatch consumers
+ * index (the reference's `valids[:, :-1]` flatten, learner.py:1009-1012, without its copy); num_invalid: device int32
+ * (overwritten). actions [E*T*num_actions], logp [E*T] in/out. */
+int sf_valid_mask(const int32_t *policy_id, const float *policy_version, uint8_t *valids, uint8_t *valids_flat,
+                  float *actions, int num_actions, float *log_prob_actions, int E, int T, int my_policy_id,
+                  int train_step, int max_policy_lag, int32_t *num_invalid, void *stream);
 
 /* ---- K10+K11: value de-normalisation, value bootstrap, GAE, returns ---------------------------------------
  * learner.py:969-1003 + rl_utils.py:52-94 (gae_advantages / calculate_discounted_sum_torch).
@@ -52,12 +54,14 @@ int sf_gae_returns(float *rewards, const uint8_t *dones, const uint8_t *time_out
 
 /* ---- K12: RunningMeanStdInPlace (scalar statistics) -------------------------------------------------------
  * running_mean_std.py:51-110.  sf_moments accumulates {sum, sumsq, count} (double[3], zeroed by the call) over x[n]
- * restricted to valid entries (valids NULL = all; `index` NULL = identity else x[index[i]], valids[index[i]]).
+ * restricted to valid entries: element i of the minibatch is dataset row j = index[i] (index != NULL) or offset + i;
+ * valids NULL = all rows count, else valids[j]; the value is x[j], or x[i] when dense_x != 0 (x holds the minibatch's own
+ * n values, e.g. the V-trace advantages, while valids is still the dataset's array).
  * Between the two calls a data-parallel learner all-reduces the 3 doubles.
  * sf_rms_update merges the batch moments into stats (Chan merge, :51-62, unbiased batch variance) -> stats_out.
  * sf_rms_apply normalises ((x-mean)/sqrt(var+1e-5) clamp +-5) or de-normalises (clamp, *sigma, +mean) in place. */
-int sf_moments(const float *x, const uint8_t *valids, const int32_t *index, int64_t n, double *moments,
-               void *stream);
+int sf_moments(const float *x, const uint8_t *valids, const int32_t *index, int64_t offset, int64_t n, int dense_x,
+               double *moments, void *stream);
 int sf_rms_update(const double *stats_in, const double *moments, double *stats_out, void *stream);
 int sf_rms_apply(float *x, int64_t n, const double *stats, int denormalize, void *stream);
 
@@ -136,6 +140,10 @@ typedef struct {
      * holds num_heads floats per sample.  num_heads <= 1: one Discrete(A). */
     int32_t num_heads;
     int32_t head_n[8];
+    /* > 0: `old_values` is the trajectory slab's values array [E, old_values_T + 1] read IN PLACE — dataset row
+     * e*T + t lives at e*(T+1) + t (the reference drops the last column by `[:, :-1]` + flatten, learner.py:1009-1012:
+     * a copy); 0: old_values is the flat [N] array. */
+    int32_t old_values_T;
 } sf_loss_cfg;
 
 int sf_ppo_loss(const float *params, int ld_params, const float *values, int ld_values, const float *actions,
@@ -242,6 +250,11 @@ int sf_synth_vec_step(float *state, const float *actions, int64_t act_stride, fl
  * (hipMemcpy2DAsync) on `stream` — no contiguous device staging copy, no kernel.  Returns without synchronising. */
 int sf_h2d_rows(void *dst, int64_t dst_pitch, const void *src, int64_t src_pitch, int64_t row_bytes, int64_t rows,
                 void *stream);
+/* device -> device row copy with pitches (one launch): the column copies of the slab protocol — the next rollout's
+ * obs[:, 0] / rnn_states[:, 0] <- this rollout's [:, T] (batched_sampling.py:289-296, TensorDict `copy_` per leaf in the
+ * reference), the bootstrap value -> values[:, T] (learner.py:962-969). */
+int sf_copy_rows(void *dst, int64_t dst_pitch, const void *src, int64_t src_pitch, int64_t row_bytes, int64_t rows,
+                 void *stream);
 
 /* ---- synthetic vector env (SURVEY.md §8d "C2 synthetic inputs") ------------------------------------------------
  * Device-resident stand-in for a GPU env (the reference's pattern: sf_examples/brax/train_brax.py:160-204).

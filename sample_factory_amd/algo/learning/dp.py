@@ -5,7 +5,9 @@ One process per GPU, envs partitioned by rank; rollout, inference, bootstrap val
 communication (recurrences run along T only).  Per SGD step the replicas exchange:
   * 3 doubles  {sum(adv), sum(adv^2), n_valid}   before the loss  -> global per-minibatch advantage normalisation
   * 1 bucket   flat fp32 gradient (already scaled by the GLOBAL 1/n_valid) -> sum == gradient of the global mean loss
-and once per dataset 3 doubles of return moments (returns normaliser) and the invalid count.  Adam then runs
+and once per dataset 3 doubles of return moments (returns normaliser) and the invalid count; loss / KL / entropy sums and
+the max KL travel as ONE packed bucket (`reduce_sum_max`: gathered, summed locally, MAX for the max column) once per
+epoch — per SGD step only for the per-minibatch KL-adaptive learning-rate schedule.  Adam then runs
 redundantly on identical inputs, so weights never need an all-gather.  `torch.distributed` backend "nccl" is RCCL on
 ROCm; the same code runs over gloo on CPU tensors (tests/test_dp_gloo.py).
 
@@ -31,11 +33,44 @@ class _Done:
 class _EventHandle:
     """wait(): order the CURRENT stream behind a collective that was enqueued on the exchange stream"""
 
-    def __init__(self, event):
-        self.event = event
+    def __init__(self, event, group=None):
+        self.event, self.group = event, group
 
     def wait(self) -> None:
-        torch.cuda.current_stream().wait_event(self.event)
+        with _Exposed(self.group):
+            torch.cuda.current_stream().wait_event(self.event)
+
+
+class _TimedWork:
+    """torch.distributed Work whose wait() is bracketed by events on the compute stream (exposed wait time)"""
+
+    def __init__(self, work, group):
+        self.work, self.group = work, group
+
+    def wait(self) -> None:
+        with _Exposed(self.group):
+            self.work.wait()
+
+
+class _Exposed:
+    """event pair on the CURRENT (compute) stream around a point where it may have to wait for a collective: the elapsed
+    time between the two is what the exchange cost the compute stream (0 when the collective had already finished)"""
+
+    def __init__(self, group):
+        self.on = group is not None and group.timing is not None and torch.cuda.is_available()
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.group.timing["exposed"].append((self.e0, e1))
+        return False
 
 
 class ReplicaGroup:
@@ -52,8 +87,25 @@ class ReplicaGroup:
         # protocol on boxes with fewer GPUs than ranks (tests); production runs use nccl (= RCCL over xGMI).
         self._stage = self.active and dist.get_backend(process_group) == "gloo"
         self._comm = self._xstream = None
+        # optional measurement (bench.py --gpus N): {"exposed": [(e0, e1)], "xchg": [(e0, e1)], "count": n}
+        self.timing = None
         if native_rccl and self.on:
             self._init_native()
+
+    def enable_timing(self) -> None:
+        """bracket every collective with HIP events: `exposed` = pairs on the compute stream around each point where it
+        waits for (or runs) a collective; `xchg` = pairs on the exchange stream around the collective itself (native RCCL
+        path only: torch.distributed runs its collectives on a stream of its own that cannot be instrumented from here)"""
+        self.timing = dict(exposed=[], xchg=[], count=0)
+
+    def timing_summary(self):
+        """(exposed_ms, exchange_ms | None, collectives) accumulated since enable_timing(); synchronises"""
+        if self.timing is None:
+            return None
+        torch.cuda.synchronize()
+        ex = sum(a.elapsed_time(b) for a, b in self.timing["exposed"])
+        xc = sum(a.elapsed_time(b) for a, b in self.timing["xchg"]) if self.timing["xchg"] else None
+        return ex, xc, self.timing["count"]
 
     # ---- gradient buckets through the C-ABI (sf_allreduce_grads)
     def _init_native(self) -> None:
@@ -79,10 +131,17 @@ class ReplicaGroup:
         ready = torch.cuda.Event()
         ready.record(cur)
         self._xstream.wait_event(ready)
+        timed = self.timing is not None
+        if timed:
+            x0 = torch.cuda.Event(enable_timing=True)
+            x0.record(self._xstream)
         self._lib.allreduce_grads(self._comm, t, self._xstream)
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(enable_timing=timed)
         done.record(self._xstream)
-        return _EventHandle(done)
+        if timed:
+            self.timing["xchg"].append((x0, done))
+            self.timing["count"] += 1
+        return _EventHandle(done, self)
 
     def all_reduce_grads(self, t: torch.Tensor) -> torch.Tensor:
         """SUM of a slice of the flat fp32 gradient over the replicas; the current stream continues behind the result"""
@@ -104,12 +163,15 @@ class ReplicaGroup:
 
     def _collective(self, fn, t: torch.Tensor) -> torch.Tensor:
         if self.on:
-            if self._stage and t.is_cuda:
-                h = t.detach().cpu()
-                fn(h)
-                t.copy_(h)
-            else:
-                fn(t)
+            if self.timing is not None:
+                self.timing["count"] += 1
+            with _Exposed(self if t.is_cuda else None):
+                if self._stage and t.is_cuda:
+                    h = t.detach().cpu()
+                    fn(h)
+                    t.copy_(h)
+                else:
+                    fn(t)
         return t
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
@@ -122,7 +184,9 @@ class ReplicaGroup:
         if not self.on or (self._stage and t.is_cuda):
             self.all_reduce_sum(t)
             return _Done()
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if self.timing is not None:
+            self.timing["count"] += 1
+        return _TimedWork(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), self)
 
     def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
         return self._collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.pg), t)
@@ -134,11 +198,23 @@ class ReplicaGroup:
         """[first, last) global env ids owned by this rank (weak scaling: per-rank work is fixed)."""
         return self.rank * envs_per_rank, (self.rank + 1) * envs_per_rank
 
+    def reduce_sum_max(self, t: torch.Tensor, max_cols) -> torch.Tensor:
+        """ONE collective for a small packed bucket whose entries need different reductions: every rank's copy is
+        gathered ([world, ...] — a few hundred bytes), then summed locally, except the trailing-dimension columns in
+        `max_cols`, which take the maximum over the ranks.  In place; every rank ends with identical values."""
+        if not self.on:
+            return t
+
+        def fn(x):
+            parts = [torch.empty_like(x) for _ in range(self.world)]
+            dist.all_gather(parts, x.contiguous(), group=self.pg)
+            g = torch.stack(parts)
+            red = g.sum(0)
+            if len(max_cols):
+                red[..., list(max_cols)] = g[..., list(max_cols)].max(0).values
+            x.copy_(red)
+        return self._collective(fn, t)
+
     def loss_sums(self, sums: torch.Tensor) -> torch.Tensor:
-        """sums[0..3] additive loss sums, sums[4] = max KL (needs MAX), rest additive."""
-        if self.on:
-            mx = sums[4:5].clone()
-            self.all_reduce_sum(sums)
-            self.all_reduce_max(mx)
-            sums[4:5].copy_(mx)
-        return sums
+        """sums[0..3] additive loss sums, sums[4] = max KL (needs MAX), rest additive: one packed exchange."""
+        return self.reduce_sum_max(sums, (4,))

@@ -381,9 +381,12 @@ class Learner:
         obs = {k: batch["obs"][k] for k in ac.obs_keys} if multi else batch["obs"]["obs"]
         E, T = batch["rewards"].shape
         N = E * T
+        # valids [E, T+1] (the batch is mutated as the reference mutates it) and, from the same launch, the flat [E*T]
+        # dataset mask the minibatch consumers index (the reference's `[:, :-1]` + flatten is a copy)
+        valids_flat = ac._buf(("prep", "valids_flat"), (N,), dtype=torch.bool)
         lib.valid_mask(batch["policy_id"], batch["policy_version"], batch["valids"], batch["actions"],
                        self.num_actions, batch["log_prob_actions"], self.policy_id, self.train_step,
-                       cfg.max_policy_lag, self._num_invalid)
+                       cfg.max_policy_lag, self._num_invalid, valids_flat=valids_flat)
         if not ac.training:
             ac.train()
         if ac.obs_normalizer is not None:  # learner.py:957-961: statistics updated once per dataset, over all T+1 columns
@@ -392,7 +395,7 @@ class Learner:
         last = {k: v[:, T] for k, v in obs.items()} if multi else obs[:, T]
         rnn = dict(states=batch["rnn_states"][:, T]) if cfg.use_rnn else None
         heads = ac.forward_heads(last, E, sample_stride=0 if multi else obs.stride(0), tag="boot", rnn=rnn)[-1]  # learner weights
-        batch["values"][:, T].copy_(heads[:, 0])
+        lib.copy_rows(batch["values"][:, T], heads[:, 0])
         adv = torch.empty((E, T), dtype=torch.float32, device=self.device)
         ret = torch.empty((E, T), dtype=torch.float32, device=self.device)
         buff = AttrDict()
@@ -407,7 +410,8 @@ class Learner:
             # advantages per minibatch, so its adv/ret outputs are scratch here (normalize_returns is off with V-trace).
             lib.gae_returns(batch["rewards"], batch["dones"], batch["time_outs"], batch["values"], batch["valids"],
                             None, cfg.gamma, cfg.gae_lambda, True, adv, ret)
-        # flat dataset views (index e*T + t); [E,T+1] tensors lose their last column by a small compact copy
+        # flat dataset views (index e*T + t).  The two [E, T+1] arrays are NOT compacted: the flat mask came out of the
+        # sf_valid_mask launch, the old values are read in place through the loss kernel's row mapping (old_values_T)
         buff.obs = obs
         buff.actions = batch["actions"].view(N, self.num_actions)
         buff.action_logits = batch["action_logits"].view(N, self.num_action_params)
@@ -417,8 +421,8 @@ class Learner:
         buff.policy_id, buff.policy_version = batch["policy_id"].view(N), batch["policy_version"].view(N)
         if cfg.use_rnn:
             buff.rnn_states = batch["rnn_states"]  # the slab [E, T+1, S], read in place by sf_rnn_chunk_setup
-        buff["values"] = batch["values"][:, :T].reshape(N)  # NB: item access, AttrDict.values is dict.values
-        buff.valids = batch["valids"][:, :T].reshape(N)
+        buff["values"] = batch["values"]  # [E, T+1], row e*T+t at e*(T+1)+t; NB: item access, AttrDict.values is dict.values
+        buff.valids = valids_flat
         buff.E, buff.T = E, T
         if cfg.normalize_returns and not cfg.with_vtrace:
             ac.returns_normalizer(buff.returns)  # in place: update (all-reduced moments under DP) + normalise
@@ -510,17 +514,14 @@ class Learner:
             lib.vtrace(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.rewards, buff.dones, index,
                        offset, n, A, self.loss_cfg.action_kind, cfg.recurrence, cfg.gamma, cfg.vtrace_rho,
                        cfg.vtrace_c, vs, adv, head_sizes=self._head_sizes)
-            valid_dense = buff.valids[index.long()] if index is not None else buff.valids[offset:offset + n]
-            lib.moments(adv, valid_dense.contiguous(), None, n, self._moments)
+            lib.moments(adv, buff.valids, index, n, self._moments, offset=offset, dense_x=True)
             adv_arr, tgt_arr = adv, vs
         else:
-            if index is not None:
-                lib.moments(buff.advantages, buff.valids, index, n, self._moments)
-            else:
-                lib.moments(buff.advantages[offset:offset + n], buff.valids[offset:offset + n], None, n, self._moments)
+            lib.moments(buff.advantages, buff.valids, index, n, self._moments, offset=offset)
             adv_arr, tgt_arr = buff.advantages, buff.returns
         self._all_reduce(self._moments)  # global per-minibatch advantage statistics under DP
         self._ratio = ac._buf(("loss", "ratio"), (n,))
+        self.loss_cfg.old_values_T = buff.T  # buff["values"] is the slab's [E, T+1] array
         lib.ppo_loss(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.action_logits, buff["values"],
                      adv_arr, tgt_arr, buff.valids, index, offset, n, A, self.loss_cfg, self._moments, self._sums,
                      g_heads[:, 1:], g_heads[:, 0], ratio_out=self._ratio)
@@ -540,7 +541,7 @@ class Learner:
         recent_kls: List[float] = []
         num_sgd_steps = 0
         n_mb = cfg.num_batches_per_epoch
-        self._scalars = torch.zeros((cfg.num_epochs * n_mb, 16), dtype=torch.float32, device=self.device)
+        self._scalars = ac._buf(("loss", "scalars"), (cfg.num_epochs * n_mb, 16))  # every row used is written in full
         global_size = experience_size * self.world
         need_kl_each_mb = self.lr_scheduler.invoke_after_each_minibatch() and isinstance(self.lr_scheduler, KlAdaptiveScheduler)
         self._dp_reduce_each_mb = need_kl_each_mb
@@ -610,14 +611,11 @@ class Learner:
             blk = self._scalars[epoch * n_mb:(epoch + 1) * n_mb]
             if self.dp and not need_kl_each_mb:
                 # data-parallel: every replica divided its LOCAL sums by the GLOBAL n, so the loss / KL / entropy means
-                # add up across ranks; one all-reduce per epoch instead of two per SGD step (max KL: MAX)
-                cols = [0, 1, 2, 3, 4, 9]
-                add = blk[:, cols].contiguous()
-                self._all_reduce(add)
-                blk[:, cols] = add
-                mx = blk[:, 5].contiguous()
-                self.group.all_reduce_max(mx)
-                blk[:, 5] = mx
+                # add up across ranks (max KL: MAX) — ONE packed exchange per epoch (ReplicaGroup.reduce_sum_max)
+                # instead of two collectives per SGD step; the per-rank columns (adv mean / std, n) stay as they are
+                pack = blk[:, [0, 1, 2, 3, 4, 9, 5]].contiguous()
+                self.group.reduce_sum_max(pack, (6,))
+                blk[:, [0, 1, 2, 3, 4, 9, 5]] = pack
             rows = blk.cpu()
             if skip is not None and ac.rnn_pass_aborted():
                 raise lib.SfHipError(
@@ -669,7 +667,7 @@ class Learner:
         vr = ratio[valid]
         if vr.numel() == 0:
             vr = ratio.new_ones(1)
-        old_v = buff["values"][rows]
+        old_v = buff["values"].reshape(-1)[rows + rows // buff.T]  # [E, T+1] slab rows
         dv = (values - old_v).abs()
         acts = buff.actions[rows]
         adv = adv_arr[:n] if self.cfg.with_vtrace else adv_arr[rows]

@@ -218,25 +218,25 @@ class BatchedVectorEnvRunner:
         """async mode: switch to another slab; its step 0 continues from the last step of `carry_from`"""
         self.traj = traj
         self.obs = traj["obs"]["obs" if "obs" in traj["obs"] else self.obs_keys[0]]
-        if carry_from is not None:
+        if carry_from is not None:  # column copies through the library's own row-copy kernel (sf_copy_rows)
             for k in self.obs_keys:
-                traj["obs"][k][:, 0].copy_(carry_from["obs"][k][:, self.T])
+                lib.copy_rows(traj["obs"][k][:, 0], carry_from["obs"][k][:, self.T])
             if self.masked:
-                traj["obs"]["action_mask"][:, 0].copy_(carry_from["obs"]["action_mask"][:, self.T])
+                lib.copy_rows(traj["obs"]["action_mask"][:, 0], carry_from["obs"]["action_mask"][:, self.T])
             if self.rnn:
-                traj["rnn_states"][:, 0].copy_(carry_from["rnn_states"][:, self.T])
+                lib.copy_rows(traj["rnn_states"][:, 0], carry_from["rnn_states"][:, self.T])
         elif self.rnn:
             traj["rnn_states"][:, 0].zero_()
 
     def carry_over(self) -> None:
         """The next rollout starts from the last observation: slab obs[:, 0] <- obs[:, T] (one frame per agent)."""
         for k in self.obs_keys:
-            self.traj["obs"][k][:, 0].copy_(self.traj["obs"][k][:, self.T])
+            lib.copy_rows(self.traj["obs"][k][:, 0], self.traj["obs"][k][:, self.T])
         if self.masked:
             mk = self.traj["obs"]["action_mask"]
-            mk[:, 0].copy_(mk[:, self.T])
+            lib.copy_rows(mk[:, 0], mk[:, self.T])
         if self.rnn:
-            self.traj["rnn_states"][:, 0].copy_(self.traj["rnn_states"][:, self.T])
+            lib.copy_rows(self.traj["rnn_states"][:, 0], self.traj["rnn_states"][:, self.T])
 
     def episode_stats(self) -> Dict[str, float]:
         s = self.ep_stats.cpu()

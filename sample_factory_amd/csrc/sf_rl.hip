@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 11; }
+extern "C" int sf_abi_version(void) { return 12; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -19,7 +19,8 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 // =========================================================================================== K13 validity mask
 __global__ __launch_bounds__(256) void k_valid_mask(const int32_t *__restrict__ policy_id,
                                                     const float *__restrict__ policy_version,
-                                                    uint8_t *__restrict__ valids, float *__restrict__ actions,
+                                                    uint8_t *__restrict__ valids, uint8_t *__restrict__ valids_flat,
+                                                    float *__restrict__ actions,
                                                     int num_actions, float *__restrict__ logp, int E, int T,
                                                     int my_pid, int train_step, int max_lag,
                                                     int32_t *__restrict__ num_invalid) {
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void k_valid_mask(const int32_t *__restrict__ 
         const int t = (int)(i - e * T);
         valid = (policy_id[i] == my_pid) && (((float)train_step - policy_version[i]) < (float)max_lag);
         valids[e * (T + 1) + t] = (uint8_t)valid;
+        if (valids_flat) valids_flat[i] = (uint8_t)valid;  // the [E*T] dataset view (learner.py:1009-1012) without a compaction copy
         if (t == T - 1) valids[e * (T + 1) + T] = (uint8_t)valid;  // learner.py:955
         if (!valid) {
             for (int a = 0; a < num_actions; ++a) actions[i * num_actions + a] = 0.0f;
@@ -42,9 +44,9 @@ __global__ __launch_bounds__(256) void k_valid_mask(const int32_t *__restrict__ 
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(num_invalid, (int32_t)__popcll(b));
 }
 
-extern "C" int sf_valid_mask(const int32_t *policy_id, const float *policy_version, uint8_t *valids, float *actions,
-                             int num_actions, float *log_prob_actions, int E, int T, int my_policy_id, int train_step,
-                             int max_policy_lag, int32_t *num_invalid, void *stream) {
+extern "C" int sf_valid_mask(const int32_t *policy_id, const float *policy_version, uint8_t *valids,
+                             uint8_t *valids_flat, float *actions, int num_actions, float *log_prob_actions, int E, int T,
+                             int my_policy_id, int train_step, int max_policy_lag, int32_t *num_invalid, void *stream) {
     SF_REQUIRE(E > 0 && T > 0 && num_actions > 0, "sf_valid_mask: bad shape E=%d T=%d na=%d", E, T, num_actions);
     SF_REQUIRE(policy_id && policy_version && valids && actions && log_prob_actions && num_invalid,
                "sf_valid_mask: null pointer");
@@ -52,8 +54,8 @@ extern "C" int sf_valid_mask(const int32_t *policy_id, const float *policy_versi
     if (rc) return rc;
     const int64_t N = (int64_t)E * T;
     k_valid_mask<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(
-        policy_id, policy_version, valids, actions, num_actions, log_prob_actions, E, T, my_policy_id, train_step,
-        max_policy_lag, num_invalid);
+        policy_id, policy_version, valids, valids_flat, actions, num_actions, log_prob_actions, E, T, my_policy_id,
+        train_step, max_policy_lag, num_invalid);
     return sf_launch_status("sf_valid_mask");
 }
 
@@ -200,14 +202,14 @@ extern "C" int sf_gae_returns(float *rewards, const uint8_t *dones, const uint8_
 
 // =========================================================================================== K12 running mean/std
 __global__ __launch_bounds__(256) void k_moments(const float *__restrict__ x, const uint8_t *__restrict__ valids,
-                                                 const int32_t *__restrict__ index, int64_t n,
-                                                 double *__restrict__ moments) {
+                                                 const int32_t *__restrict__ index, int64_t offset, int64_t n,
+                                                 int dense_x, double *__restrict__ moments) {
     __shared__ double lds[4 * 3];
     double acc[3] = {0.0, 0.0, 0.0};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = index ? (int64_t)index[i] : i;
+        const int64_t j = index ? (int64_t)index[i] : offset + i;
         if (!valids || valids[j]) {
-            const double v = (double)x[j];
+            const double v = (double)x[dense_x ? i : j];
             acc[0] += v;
             acc[1] += v * v;
             acc[2] += 1.0;
@@ -221,16 +223,16 @@ __global__ __launch_bounds__(256) void k_moments(const float *__restrict__ x, co
     }
 }
 
-extern "C" int sf_moments(const float *x, const uint8_t *valids, const int32_t *index, int64_t n, double *moments,
-                          void *stream) {
-    SF_REQUIRE(x && moments && n >= 0, "sf_moments: bad args");
+extern "C" int sf_moments(const float *x, const uint8_t *valids, const int32_t *index, int64_t offset, int64_t n,
+                          int dense_x, double *moments, void *stream) {
+    SF_REQUIRE(x && moments && n >= 0 && offset >= 0, "sf_moments: bad args");
     int rc = sf_hip_status(hipMemsetAsync(moments, 0, 3 * sizeof(double), STREAM(stream)), "sf_moments memset");
     if (rc || n == 0) return rc;
     // latency-bound at minibatch sizes (32768 elements = 164 KB): one element per thread and one round trip, not an
     // 8-deep dependent loop on 16 CUs; large inputs grid-stride over 2048 blocks (8 per CU)
     const int64_t blocks = (n + 255) / 256;
-    k_moments<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, STREAM(stream)>>>(x, valids, index, n,
-                                                                                                   moments);
+    k_moments<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, STREAM(stream)>>>(
+        x, valids, index, offset, n, dense_x, moments);
     return sf_launch_status("sf_moments");
 }
 
@@ -423,7 +425,13 @@ struct LossDev {
     float clip_lo, clip_hi, clip_value, value_coeff, expl_coeff, kl_coeff;
     int expl_kind, action_kind, dense_adv;
     int num_heads, head_n[8];
+    int ov_T;  // > 0: old_values is the slab's [E, ov_T + 1] array read in place (dataset row e*T+t -> e*(T+1)+t)
 };
+__device__ __forceinline__ int64_t ov_row(const LossDev &h, int64_t d) {
+    if (h.ov_T <= 0) return d;
+    const int64_t e = d / h.ov_T;
+    return d + e;  // e*(T+1) + t = (e*T + t) + e
+}
 
 __device__ __forceinline__ void atomic_max_float(double *addr, float v) {
     // sums[4] holds the running max as a double; KL >= 0 up to rounding, compare on the bit pattern of (v+1) > 0
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss(const float *__restrict__ para
         const float clipped = clampf(ratio, h.clip_lo, h.clip_hi);
         const float lu_ = ratio * advn, lc_ = clipped * advn;
         const float pl = fminf(lu_, lc_);
-        const float v = values[i * ldv], vo = old_values[d], R = targets[da];
+        const float v = values[i * ldv], vo = old_values[ov_row(h, d)], R = targets[da];
         const float vclip = vo + clampf(v - vo, -h.clip_value, h.clip_value);
         const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
         const float vl = fmaxf(l1, l2);
@@ -682,7 +690,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_md(const float *__restrict__ p
             const float clipped = clampf(ratio, h.clip_lo, h.clip_hi);
             const float lu_ = ratio * advn, lc_ = clipped * advn;
             const float pl = fminf(lu_, lc_);
-            const float v = values[i * ldv], vo = old_values[d], R = targets[da];
+            const float v = values[i * ldv], vo = old_values[ov_row(h, d)], R = targets[da];
             const float vclip = vo + clampf(v - vo, -h.clip_value, h.clip_value);
             const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
             const float vl = fmaxf(l1, l2);
@@ -794,6 +802,7 @@ static LossDev make_loss_dev(const sf_loss_cfg *c) {
     h.dense_adv = c->dense_adv;
     h.num_heads = c->num_heads > 1 ? c->num_heads : 1;
     for (int i = 0; i < 8; ++i) h.head_n[i] = c->num_heads > 1 ? c->head_n[i] : 0;
+    h.ov_T = c->old_values_T > 0 ? c->old_values_T : 0;
     return h;
 }
 
@@ -875,6 +884,36 @@ extern "C" int sf_loss_scalars(const double *sums, const double *moments, const 
     SF_REQUIRE(sums && moments && h_cfg && out, "sf_loss_scalars: null pointer");
     k_loss_scalars<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(sums, moments, make_loss_dev(h_cfg), out);
     return sf_launch_status("sf_loss_scalars");
+}
+
+// =========================================================================================== device row copies
+// dst[r][0..row_bytes) = src[r][0..row_bytes) for r < rows, rows `pitch` bytes apart on either side: the slab's column
+// copies (next rollout's obs[:, 0] <- obs[:, T], rnn_states likewise, bootstrap value -> values[:, T]).  16-byte units
+// when every address allows it, 4-byte units otherwise, bytes as the last resort.
+template <typename V>
+__global__ __launch_bounds__(256) void k_copy_rows(char *__restrict__ dst, int64_t dst_pitch, const char *__restrict__ src,
+                                                   int64_t src_pitch, int64_t units_per_row, int64_t rows) {
+    const int64_t total = units_per_row * rows;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / units_per_row, u = i - r * units_per_row;
+        *reinterpret_cast<V *>(dst + r * dst_pitch + u * (int64_t)sizeof(V)) =
+            *reinterpret_cast<const V *>(src + r * src_pitch + u * (int64_t)sizeof(V));
+    }
+}
+extern "C" int sf_copy_rows(void *dst, int64_t dst_pitch, const void *src, int64_t src_pitch, int64_t row_bytes,
+                            int64_t rows, void *stream) {
+    SF_REQUIRE(dst && src && row_bytes > 0 && rows > 0 && (rows == 1 || (llabs(dst_pitch) >= row_bytes && llabs(src_pitch) >= row_bytes)),
+               "sf_copy_rows: bad args (row_bytes=%lld rows=%lld)", (long long)row_bytes, (long long)rows);
+    const uintptr_t all = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)dst_pitch | (uintptr_t)src_pitch | (uintptr_t)row_bytes;
+    const int unit = (all & 15) == 0 ? 16 : (all & 3) == 0 ? 4 : 1;
+    const int64_t upr = row_bytes / unit, total = upr * rows;
+    const dim3 grid((unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536)), block(256);
+    char *d = reinterpret_cast<char *>(dst);
+    const char *s = reinterpret_cast<const char *>(src);
+    if (unit == 16) k_copy_rows<uint4><<<grid, block, 0, STREAM(stream)>>>(d, dst_pitch, s, src_pitch, upr, rows);
+    else if (unit == 4) k_copy_rows<uint32_t><<<grid, block, 0, STREAM(stream)>>>(d, dst_pitch, s, src_pitch, upr, rows);
+    else k_copy_rows<uint8_t><<<grid, block, 0, STREAM(stream)>>>(d, dst_pitch, s, src_pitch, upr, rows);
+    return sf_launch_status("sf_copy_rows");
 }
 
 // =========================================================================================== host-env ingest

@@ -24,7 +24,7 @@ class sf_loss_cfg(C.Structure):
     _fields_ = [("clip_ratio", C.c_float), ("clip_value", C.c_float), ("value_loss_coeff", C.c_float),
                 ("exploration_coeff", C.c_float), ("kl_coeff", C.c_float), ("exploration_kind", C.c_int32),
                 ("action_kind", C.c_int32), ("dense_adv", C.c_int32), ("num_heads", C.c_int32),
-                ("head_n", C.c_int32 * 8)]
+                ("head_n", C.c_int32 * 8), ("old_values_T", C.c_int32)]
 
 
 class sf_conv_desc(C.Structure):
@@ -41,7 +41,7 @@ SYMBOLS = [
     "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
-    "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
+    "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_copy_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
     "sf_conv_dgrad", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
     "sf_tanh_scale_fwd", "sf_tanh_scale_bwd",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
@@ -171,10 +171,13 @@ def u32(x) -> C.c_uint32:
 
 # ------------------------------------------------------------------------------------------------ thin wrappers
 def valid_mask(policy_id, policy_version, valids, actions, num_actions, log_prob_actions, my_policy_id, train_step,
-               max_policy_lag, num_invalid) -> None:
+               max_policy_lag, num_invalid, valids_flat=None) -> None:
     E, T = policy_id.shape
+    if valids_flat is not None and valids_flat.numel() != E * T:
+        raise SfHipError(f"valid_mask: valids_flat must hold E*T = {E * T} elements, got {valids_flat.numel()}")
     _check(load().sf_valid_mask(ptr(policy_id, "i32", "policy_id"), ptr(policy_version, "f32", "policy_version"),
-                                ptr(valids, "u8", "valids"), ptr(actions, "f32", "actions"), int(num_actions),
+                                ptr(valids, "u8", "valids"), ptr(valids_flat, "u8", "valids_flat"),
+                                ptr(actions, "f32", "actions"), int(num_actions),
                                 ptr(log_prob_actions, "f32", "log_prob_actions"), E, T, int(my_policy_id),
                                 int(train_step), int(max_policy_lag), ptr(num_invalid, "i32", "num_invalid"),
                                 stream()), "sf_valid_mask")
@@ -191,9 +194,10 @@ def gae_returns(rewards, dones, time_outs, values, valids, rms_stats, gamma, gae
                                  ptr(returns, "f32", "returns"), stream()), "sf_gae_returns")
 
 
-def moments(x, valids, index, n, out) -> None:
-    _check(load().sf_moments(ptr(x, "f32", "x"), ptr(valids, "u8", "valids"), ptr(index, "i32", "index"), i64(n),
-                             ptr(out, "f64", "moments"), stream()), "sf_moments")
+def moments(x, valids, index, n, out, offset=0, dense_x=False) -> None:
+    """{sum, sumsq, count} of the minibatch rows j = index[i] | offset + i that are valid; x[j], or x[i] if dense_x"""
+    _check(load().sf_moments(ptr(x, "f32", "x"), ptr(valids, "u8", "valids"), ptr(index, "i32", "index"), i64(offset),
+                             i64(n), int(bool(dense_x)), ptr(out, "f64", "moments"), stream()), "sf_moments")
 
 
 def rms_update(stats_in, mom, stats_out) -> None:
@@ -491,6 +495,33 @@ def h2d_rows(dst: torch.Tensor, src_pinned: torch.Tensor) -> None:
         pitch = dst.stride(0) * dst.element_size()
     _check(load().sf_h2d_rows(C.c_void_p(dst.data_ptr()), i64(pitch), C.c_void_p(src_pinned.data_ptr()), i64(row_bytes),
                               i64(row_bytes), i64(rows), stream()), "sf_h2d_rows")
+
+
+def copy_rows(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """dst <- src for two device views of equal shape / dtype whose rows (dim 0) are contiguous blocks, any row pitch on
+    either side (slab[:, t] columns, a column of a matrix): ONE launch of the library's own row-copy kernel"""
+    if not (dst.is_cuda and src.is_cuda) or dst.shape != src.shape or dst.dtype != src.dtype:
+        raise SfHipError(f"copy_rows: device views of equal shape/dtype required, got {tuple(dst.shape)} {dst.dtype} on "
+                         f"{dst.device} <- {tuple(src.shape)} {src.dtype} on {src.device}")
+    if dst.numel() == 0:
+        return
+    es = dst.element_size()
+
+    def rows_of(t):
+        if t.is_contiguous():
+            return 1, t.numel() * es, t.numel() * es
+        if t.dim() >= 1 and (t.dim() == 1 or t[0].is_contiguous()):
+            return t.shape[0], (t[0].numel() if t.dim() > 1 else 1) * es, t.stride(0) * es
+        raise SfHipError(f"copy_rows: rows must be contiguous blocks (shape {tuple(t.shape)}, strides {t.stride()})")
+    rd, bd, pd = rows_of(dst)
+    rs, bs, ps = rows_of(src)
+    if (rd, bd) != (rs, bs):  # one side is fully contiguous: express it in the other side's row structure
+        if rd == 1 and rs > 1:
+            rd, bd, pd = rs, bs, bs
+        elif rs == 1 and rd > 1:
+            rs, bs, ps = rd, bd, bd
+    _check(load().sf_copy_rows(C.c_void_p(dst.data_ptr()), i64(pd), C.c_void_p(src.data_ptr()), i64(ps), i64(bd),
+                               i64(rd), stream()), "sf_copy_rows")
 
 
 def synth_obs(obs_slot_ptr: int, env_stride, B, env0, obs_bytes, seed, step) -> None:

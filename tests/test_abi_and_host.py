@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(lib.SYMBOLS) == syms, "sample_factory_amd.lib.SYMBOLS out of date with include/sf_hip.h"
     for s in syms:
         assert hasattr(L, s), f"libsf_hip.so does not export {s}"
-    assert L.sf_abi_version() == 11
+    assert L.sf_abi_version() == 12
     assert L.sf_selftest_host() == 0          # exact integer division used by every im2col address
     assert isinstance(L.sf_last_error(), bytes)
 
@@ -50,7 +50,7 @@ def test_argument_errors_are_reported_not_thrown():
 
 def test_struct_layouts_match_header():
     from sample_factory_amd import lib
-    assert ctypes.sizeof(lib.sf_loss_cfg) == (8 + 1 + 8) * 4   # ... dense_adv, num_heads, head_n[8]
+    assert ctypes.sizeof(lib.sf_loss_cfg) == (8 + 1 + 8 + 1) * 4   # ... dense_adv, num_heads, head_n[8], old_values_T
     assert ctypes.sizeof(lib.sf_conv_desc) == 14 * 4
     assert [f[0] for f in lib.sf_conv_desc._fields_] == ["Cin", "H", "W", "Cout", "KH", "KW", "stride", "OH", "OW",
                                                           "in_u8", "relu", "traj_T", "sub_mean", "inv_scale"]

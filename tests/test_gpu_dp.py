@@ -188,3 +188,8 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scaling"] == "weak" and j["steps"] == 2
     assert j["config"]["parallelism"] == "dp2" and j["value"] > 0
     assert abs(j["value"] - 2 * 256 * 32 * 2 / (j["ms_per_step"] * 2e-3)) < 0.02 * j["value"]   # aggregate over both ranks
+    # every collective of the timed region was bracketed with HIP events, per rank (algo/learning/dp.py)
+    c = j["collectives"]
+    assert len(c["exposed_ms_per_step"]) == 2 and all(x > 0 for x in c["exposed_ms_per_step"])
+    assert all(x >= 10 for x in c["collectives_per_step"])      # 4 minibatches x (moments + gradient buckets) + per-dataset
+    assert c["allreduce_ms_per_step"] == [None, None]           # only the native path has an exchange stream to bracket

@@ -868,3 +868,84 @@ def test_learner_raises_and_keeps_weights_after_an_aborted_recurrent_pass(lib):
     torch.cuda.synchronize()
     assert torch.equal(ac.flat_params, p0) and torch.equal(runner.learner.exp_avg, m0)
     assert runner.learner.train_step == step0 + 2               # one epoch of (skipped) steps was issued, then the raise
+
+
+def test_slab_views_without_compaction_copies(lib):
+    """The [E, T+1] arrays of the slab are consumed IN PLACE: sf_valid_mask emits the flat [E*T] mask next to the
+    [E, T+1] one, sf_ppo_loss reads old values through `old_values_T`, sf_moments takes (index | offset) with dense or
+    dataset-indexed values — each bit-equal to the path through compacted copies (integer indexing: exact)."""
+    rng = np.random.default_rng(17)
+    E, T, A, n = 96, 32, 6, 1024
+    N = E * T
+    pid = dev(np.where(rng.random((E, T)) < 0.1, 3, 0).astype(np.int32))
+    pver = dev(rng.integers(-2000, 5, (E, T)).astype(np.float32))
+    mk = lambda: (torch.zeros((E, T + 1), dtype=torch.bool, device="cuda"), dev(rng.integers(0, A, (E, T, 1)).astype(np.float32)),
+                  dev(-rng.random((E, T)).astype(np.float32)), torch.zeros(1, dtype=torch.int32, device="cuda"))
+    v1, a1, l1, c1 = mk()
+    v2, a2, l2, c2 = v1.clone(), a1.clone(), l1.clone(), c1.clone()
+    flat = torch.zeros(N, dtype=torch.bool, device="cuda")
+    lib.valid_mask(pid, pver, v1, a1, 1, l1, 0, 7, 1000, c1)
+    lib.valid_mask(pid, pver, v2, a2, 1, l2, 0, 7, 1000, c2, valids_flat=flat)
+    assert torch.equal(v1, v2) and torch.equal(a1, a2) and torch.equal(l1, l2) and int(c1) == int(c2) > 0
+    assert torch.equal(flat, v1[:, :T].reshape(N))
+    with pytest.raises(lib.SfHipError):
+        lib.valid_mask(pid, pver, v2, a2, 1, l2, 0, 7, 1000, c2, valids_flat=flat[:-1])
+    # ---- loss: old values as the slab's [E, T+1] array vs its compacted copy
+    slab_values = dev(rng.standard_normal((E, T + 1)).astype(np.float32))
+    old_params = rng.standard_normal((N, A)).astype(np.float32)
+    index = rng.permutation(N)[:n].astype(np.int32)
+    params = (old_params[index] + 0.3 * rng.standard_normal((n, A))).astype(np.float32)
+    values = rng.standard_normal(n).astype(np.float32)
+    adv, tgt = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    old_logp = (-rng.random(N) - 0.3).astype(np.float32)
+    actions = rng.integers(0, A, (N, 1)).astype(np.float32)
+
+    def loss(old_values, ov_T, idx, off):
+        cfg = lib.sf_loss_cfg(clip_ratio=0.1, clip_value=0.5, value_loss_coeff=0.5, exploration_coeff=0.01, kl_coeff=0.2,
+                              exploration_kind=1, action_kind=0, dense_adv=0, old_values_T=ov_T)
+        mom = torch.zeros(3, dtype=torch.float64, device="cuda")
+        sums = torch.zeros(8, dtype=torch.float64, device="cuda")
+        gp, gv = torch.zeros((n, A), device="cuda"), torch.zeros(n, device="cuda")
+        lib.moments(dev(adv), flat, idx, n, mom, offset=off)
+        lib.ppo_loss(dev(params), A, dev(values), 1, dev(actions), dev(old_logp), dev(old_params), old_values, dev(adv),
+                     dev(tgt), flat, idx, off, n, A, cfg, mom, sums, gp, gv)
+        return mom.clone(), sums.clone(), gp, gv
+    compact = slab_values[:, :T].reshape(N).contiguous()
+    for idx, off in ((dev(index), 0), (None, 2048)):
+        m1, s1, gp1, gv1 = loss(compact, 0, idx, off)
+        m2, s2, gp2, gv2 = loss(slab_values, T, idx, off)
+        assert torch.equal(gp1, gp2) and torch.equal(gv1, gv2) and torch.equal(m1, m2) and torch.equal(s1, s2)
+        assert gv1.abs().max() > 0
+    # ---- moments: offset == slice views, dense values with a dataset-indexed mask == gathered mask
+    mom_a, mom_b = torch.zeros(3, dtype=torch.float64, device="cuda"), torch.zeros(3, dtype=torch.float64, device="cuda")
+    lib.moments(dev(adv), flat, None, n, mom_a, offset=2048)
+    lib.moments(dev(adv)[2048:2048 + n], flat[2048:2048 + n], None, n, mom_b)
+    assert torch.equal(mom_a, mom_b)
+    dense = dev(rng.standard_normal(n).astype(np.float32))
+    lib.moments(dense, flat, dev(index), n, mom_a, dense_x=True)
+    lib.moments(dense, flat[dev(index).long()].contiguous(), None, n, mom_b)
+    assert torch.equal(mom_a, mom_b) and float(mom_a[2]) < n
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 9, 4, 84, 84), torch.uint8), ((300, 33), torch.float32),
+                                         ((50, 5, 7), torch.uint8), ((128, 33, 1024), torch.float32),
+                                         ((17, 3, 6), torch.bool)])
+def test_copy_rows_equals_torch_copy(lib, shape, dtype):
+    """sf_copy_rows (the slab's column copies) against torch's strided copy_: 16-byte, 4-byte and byte units"""
+    g = torch.Generator().manual_seed(len(shape))
+    mk = lambda: (torch.randint(0, 255, shape, generator=g).to(dtype) if dtype != torch.float32
+                  else torch.randn(shape, generator=g)).cuda()
+    a, b = mk(), mk()
+    want = a.clone()
+    want[:, 0].copy_(b[:, shape[1] - 1])
+    lib.copy_rows(a[:, 0], b[:, shape[1] - 1])           # strided <- strided
+    assert torch.equal(a, want)
+    col = mk()[:, 1].contiguous()
+    want[:, 2].copy_(col)
+    lib.copy_rows(a[:, 2], col)                           # strided <- contiguous
+    assert torch.equal(a, want)
+    out = torch.empty_like(col)
+    lib.copy_rows(out, a[:, 2])                           # contiguous <- strided
+    assert torch.equal(out, col)
+    with pytest.raises(lib.SfHipError):
+        lib.copy_rows(a[:, 0], b[:, 0].float() if dtype != torch.float32 else b[:, 0].double())
