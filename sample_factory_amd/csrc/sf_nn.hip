@@ -735,6 +735,7 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 #include "sf_nn_glds.h"
 #include "sf_nn_img.h"
 #include "sf_nn_u8.h"
+#include "sf_nn_wimg.h"
 
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -1113,12 +1114,25 @@ static bool wgrad_glds_wanted(int64_t Mtot, int K, int N) {
     return Mtot >= 65536 || (Mtot >= 16384 && N >= 64 && (K >= 1024 || (int64_t)K * N >= 512 * 1024));
 }
 
+// LDS-image weight gradient (sf_nn_wimg.h): Nature-CNN conv3 geometry, launches that give every persistent work-group
+// at least a few samples.  SF_WGRAD_IMG=0: back on k_wgrad_glds (A/B switch).
+static bool wgrad_img_ok(const sf_conv_desc *d, int64_t n) {
+    static const int on = getenv("SF_WGRAD_IMG") ? atoi(getenv("SF_WGRAD_IMG")) : 1;
+    return on && !d->in_u8 && d->traj_T == 0 && d->Cin == 64 && d->Cout == 64 && d->H == 9 && d->W == 9 && d->KH == 3 &&
+           d->KW == 3 && d->stride == 1 && n >= 512;
+}
+static int wgrad_img_blocks(int64_t n) {
+    const int64_t nb = 2 * (int64_t)num_cus();
+    return (int)(n < nb ? n : nb);
+}
+
 extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc) {
     if (!h_desc || n <= 0) return 0;
     const int K = h_desc->KH * h_desc->KW * h_desc->Cin, N = h_desc->Cout;
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
     const SplitPlan p = plan_splits(Mtot, K, N, 128, wgrad_bn(N));
     int Z = p.Z;
+    if (wgrad_img_ok(h_desc, n) && wgrad_img_blocks(n) > Z) Z = wgrad_img_blocks(n);  // one partial per work-group
     if (!h_desc->in_u8) {  // the LDS-DMA kernel may pick other tiles (hence another split count)
         const WgradGlds q = plan_wgrad_glds(Mtot, K, N);
         if (q.Z > Z) Z = q.Z;
@@ -1203,6 +1217,14 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
             k_conv1_wgrad_img<2, 4, false><<<dim3(nb), dim3(256), lds_bytes, st>>>(
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
                 db ? partial_b : nullptr, (int)n, npairs);
+    } else
+    if (mode == MODE_F32 && !index && wgrad_img_ok(h_desc, n)) {
+        // conv3: persistent LDS-image kernel, every operand byte fetched once, one partial per work-group
+        const int nb = wgrad_img_blocks(n);
+        partial_b = partial_w + (int64_t)nb * K * N;
+        Zused = nb;
+        k_wgrad_img<64, 9, 9, 3><<<dim3(nb), dim3(256), 0, st>>>(reinterpret_cast<const float *>(in), in_sample_stride,
+                                                                  dout, partial_w, db ? partial_b : nullptr, (int)n);
     } else
     if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && wgrad_glds_wanted(Mtot, K, N) &&
         n * max(in_sample_stride, (int64_t)g.H * g.W * g.Cin) < ((int64_t)1 << 30)) {  // 32-bit byte offsets in the kernel
@@ -1321,6 +1343,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         if (conv1_bf16_ok(g, MODE_U8, n)) snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_bf16<true>" : "k_conv1_wgrad_bf16<false>");
         else snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
+    } else if (op == 1 && mode == MODE_F32 && wgrad_img_ok(h_desc, n)) {
+        snprintf(out, cap, "k_wgrad_img<64, 9, 9, 3>");
     } else if (op == 1 && mode == MODE_F32 && wgrad_glds_wanted(Mtot, g.K, g.Cout) && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
         snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"
