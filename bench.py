@@ -369,7 +369,7 @@ def main():
             # per rank: time the compute stream spent at collectives (exposed), duration of the gradient exchange on its
             # own stream (native path only) and the number of collectives, per step
             mine = torch.tensor([summ[0], -1.0 if summ[1] is None else summ[1], float(summ[2])], dtype=torch.float64,
-                                device="cuda")
+                                device="cuda" if backend == "nccl" else "cpu")  # (gloo gathers host tensors only)
             allr = [torch.zeros_like(mine) for _ in range(world)]
             torch.distributed.all_gather(allr, mine)
             collectives = {

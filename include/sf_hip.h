@@ -349,7 +349,8 @@ int sf_rnn_chunk_setup(const uint8_t *dones, const uint8_t *valids, const float 
  * (zeroed by the call), word 128 is the STICKY abort word: set by a pass that gave up waiting for a work-group, never
  * cleared by the library (the caller zeroes it once, e.g. at the start of Learner.train, and hands the same word to
  * sf_adam_step / sf_lamb_step as `skip_flag`, so that the garbage gradients of an aborted pass never reach the weights).  sf_lstm_seq_supported: 1 when (Cn, H) can
- * take this path on the current device (H == 512; grid <= #CUs), else use sf_rnn_cell_fwd/bwd per step.
+ * take this path on the current device (H in {256, 512}: 16 hidden units per work-group with their W_hh slice resident in
+ * LDS; grid <= #CUs), else use sf_rnn_cell_fwd/bwd per step.
  * sf_lstm_seq_bwd: dout [R][Cn][H] = dL/d hout; writes dgx [R][Cn][4H] = dL/d(gate pre-activations) (= the gradient of
  * both gx and h W_hh^T + b_hh); the carries of dL/dh and dL/dc live in registers.  Cn <= 8 * 256 rows. */
 int sf_lstm_seq_supported(int Cn, int H);

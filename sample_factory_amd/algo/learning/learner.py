@@ -474,19 +474,27 @@ class Learner:
         `(action_distribution, policy_loss, exploration_loss, kl_old, kl_loss, value_loss, loss_summaries)` for the
         minibatch `mb` — a dataset as returned by `_prepare_batch` (the whole of it is the minibatch, as in
         tests/algo/test_learner.py:21-39 of the reference) or `(dataset, (index|None, offset, n))` for a part of it.
-        The losses are 0-dim device tensors produced by the fused HIP loss kernel; `kl_old` is the mean KL(old || new)
-        over the valid samples (the reference returns the per-sample tensor whose mean that is); `action_distribution`
-        exposes the raw action parameters (`.raw_logits`), which is all the reference's callers read.  The training
-        loop itself uses `_losses_native` (same kernels, no tensor unpacking, gradient at the loss heads kept)."""
+        The losses are 0-dim device tensors produced by the fused HIP loss kernel.  `action_distribution` is the
+        reference's object type for the action space (algo/utils/action_distributions.py: Categorical / Tuple /
+        Continuous over the network's action parameters, + `.values`), `kl_old` the per-sample KL(new || old) over the
+        VALID samples (learner.py:460-470: `masked_select`), whose mean the kernel's `kl` scalar is.  The training loop
+        itself uses `_losses_native` (same kernels, no tensor unpacking, gradient at the loss heads kept)."""
+        from sample_factory_amd.algo.utils.action_distributions import get_action_distribution
         buff, part = (mb if isinstance(mb, tuple) else (mb, None))
         if part is None:
             part = (None, 0, buff.E * buff.T)
         acts, g_heads, sc = self._losses_native(buff, part, num_invalids)
+        index, offset, n = part
         heads = acts[-1]
-        dist = AttrDict(raw_logits=heads[:part[2], 1:1 + self.num_action_params], values=heads[:part[2], 0])
+        A = self.num_action_params
+        space = self.env_info.action_space
+        dist = get_action_distribution(space, heads[:n, 1:1 + A])
+        dist.raw_logits, dist.values = heads[:n, 1:1 + A], heads[:n, 0]
+        rows = index.long() if index is not None else torch.arange(offset, offset + n, device=self.device)
+        kl_old = dist.kl_divergence(get_action_distribution(space, buff.action_logits[rows]))[buff.valids[rows]]
         summaries = AttrDict(adv_mean=sc[6], adv_std=sc[7], num_valid=sc[8], entropy=sc[9], kl_divergence_max=sc[5],
-                             ratio=self._ratio[:part[2]], values=heads[:part[2], 0], g_heads=g_heads)
-        return dist, sc[0].clone(), sc[1].clone(), sc[4].clone(), sc[2].clone(), sc[3].clone(), summaries
+                             kl_old_mean=sc[4].clone(), ratio=self._ratio[:n], values=heads[:n, 0], g_heads=g_heads)
+        return dist, sc[0].clone(), sc[1].clone(), kl_old, sc[2].clone(), sc[3].clone(), summaries
 
     def _losses_native(self, buff: AttrDict, mb, num_invalids: int, scalars_out: Optional[torch.Tensor] = None):
         """learner.py:537-669 for one minibatch mb=(index, offset, n): forward, (v-trace), advantage moments,

@@ -75,10 +75,11 @@ struct LstmSeqFwd {
     int64_t ho_rs, ho_ts;  // hout element (row, t) lives at row*ho_rs + t*ho_ts (+ unit): [R][Cn][H] or [Cn][R][H]
 };
 
-// JB hidden units per work-group, H = 8192 / JB (so that the W_hh slice fills ~129 KB of LDS): JB = 16 <-> H = 512.
-template <int JB, int NSUB>
+// H hidden units, JB of them per work-group (JB = 16: the W_hh slice is 64 x (H + 4) floats of LDS — 129 KB at H = 512,
+// 66.5 KB at H = 256; H = 1024 would need 263 KB, i.e. JB = 8 and a different accumulator-to-lane mapping: not built).
+template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
-    constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
+    constexpr int G4 = 4 * H, NC = 4 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
     constexpr int KU = 8, NKB = H / 16 / KU;
     constexpr int STG = 16 * JB;  // floats of one wave's staging tile
     static_assert(NKB * KU * 16 == H && NU >= 1, "shape");
@@ -247,9 +248,9 @@ struct LstmSeqBwd {
                  // 4 no phase-B MFMAs, 8 no phase A — results are wrong with any bit set
 };
 
-template <int JB, int NSUB>
+template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
-    constexpr int H = 8192 / JB, G4 = 4 * H, NC = 4 * JB, NU = JB / 16, LDK = G4 + 4;
+    constexpr int G4 = 4 * H, NC = 4 * JB, NU = JB / 16, LDK = G4 + 4;
     constexpr int KU = 8, NKB = G4 / 16 / KU;  // 2 x 8 loads of 16 B in flight per lane (16 measured the same)
     constexpr int STG = 16 * NC;
     static_assert(NKB * KU * 16 == G4 && NKB % 2 == 0, "shape");
@@ -416,9 +417,9 @@ struct GruSeqFwd {
     int64_t ho_rs, ho_ts;
 };
 
-template <int JB, int NSUB>
+template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
-    constexpr int H = 8192 / JB, G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
+    constexpr int G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
     constexpr int KU = 8, NKB = H / 16 / KU;
     constexpr int STG = 16 * JB;
     static_assert(NKB * KU * 16 == H && NU >= 1, "shape");
@@ -569,9 +570,9 @@ struct GruSeqBwd {
     int64_t do_rs, do_ts;
 };
 
-template <int JB, int NSUB>
+template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_gru_seq_bwd(GruSeqBwd p) {
-    constexpr int H = 8192 / JB, G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NU = JB / 16, LDK = G3 + 4;
+    constexpr int G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NU = JB / 16, LDK = G3 + 4;
     constexpr int KU = 8, NKB = G3 / 16 / KU;
     constexpr int STG = 16 * NC;
     static_assert(NKB * KU * 16 == G3 && NKB % 2 == 0, "shape");
@@ -720,8 +721,10 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_bwd(GruSeqBwd p) {
 }
 
 int seq_plan(int Cn, int H, int *ngroups, int *rows_per_group, int *jb) {
-    if (H != 512) return 0;  // JB = 16; other widths take the per-step path (sf_rnn_cell_fwd/bwd)
-    *jb = 8192 / H;
+    // widths with a compiled instantiation (JB = 16; the k-blocking needs H % 128 == 0 forward, an even number of
+    // 128-column blocks backward: 256 and 512 satisfy both for LSTM and GRU); other widths take the per-step path
+    if (H != 512 && H != 256) return 0;
+    *jb = 16;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
@@ -737,6 +740,20 @@ int seq_plan(int Cn, int H, int *ngroups, int *rows_per_group, int *jb) {
 }
 
 }  // namespace
+
+// one instantiation per (width, sub-tiles per work-group)
+#define SEQ_DISPATCH(KERN)                                                              \
+    do {                                                                                \
+        if (H == 512) {                                                                 \
+            if (nsub == 1) KERN<512, 16, 1><<<grid, block, 0, STREAM(stream)>>>(p);     \
+            else if (nsub == 2) KERN<512, 16, 2><<<grid, block, 0, STREAM(stream)>>>(p); \
+            else KERN<512, 16, 4><<<grid, block, 0, STREAM(stream)>>>(p);               \
+        } else {                                                                        \
+            if (nsub == 1) KERN<256, 16, 1><<<grid, block, 0, STREAM(stream)>>>(p);     \
+            else if (nsub == 2) KERN<256, 16, 2><<<grid, block, 0, STREAM(stream)>>>(p); \
+            else KERN<256, 16, 4><<<grid, block, 0, STREAM(stream)>>>(p);               \
+        }                                                                               \
+    } while (0)
 
 extern "C" int sf_lstm_seq_supported(int Cn, int H) {
     int a, b, c;
@@ -758,9 +775,7 @@ extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *b
                  env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;  // 64-row sub-tiles per work-group, unrolled at compile time (register-resident state)
-    if (nsub == 1) k_lstm_seq_fwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
-    else if (nsub == 2) k_lstm_seq_fwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
-    else k_lstm_seq_fwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
+    SEQ_DISPATCH(k_lstm_seq_fwd);
     return sf_launch_status("sf_lstm_seq_fwd");
 }
 
@@ -779,9 +794,7 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
                  env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H, ablate};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;
-    if (nsub == 1) k_lstm_seq_bwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
-    else if (nsub == 2) k_lstm_seq_bwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
-    else k_lstm_seq_bwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
+    SEQ_DISPATCH(k_lstm_seq_bwd);
     return sf_launch_status("sf_lstm_seq_bwd");
 }
 
@@ -798,9 +811,7 @@ extern "C" int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bh
                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;
-    if (nsub == 1) k_gru_seq_fwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
-    else if (nsub == 2) k_gru_seq_fwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
-    else k_gru_seq_fwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
+    SEQ_DISPATCH(k_gru_seq_fwd);
     return sf_launch_status("sf_gru_seq_fwd");
 }
 
@@ -817,8 +828,6 @@ extern "C" int sf_gru_seq_bwd(const float *dout, const float *gates, const float
                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
     const int nsub = (rpg + 63) / 64;
-    if (nsub == 1) k_gru_seq_bwd<16, 1><<<grid, block, 0, STREAM(stream)>>>(p);
-    else if (nsub == 2) k_gru_seq_bwd<16, 2><<<grid, block, 0, STREAM(stream)>>>(p);
-    else k_gru_seq_bwd<16, 4><<<grid, block, 0, STREAM(stream)>>>(p);
+    SEQ_DISPATCH(k_gru_seq_bwd);
     return sf_launch_status("sf_gru_seq_bwd");
 }

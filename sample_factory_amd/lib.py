@@ -308,7 +308,7 @@ def _seq_key(op, R, Cn, H, steps, G=4):
     ng = min(8, (Cn + 15) // 16)
     rpg = ((Cn + ng - 1) // ng + 15) // 16 * 16
     nsub = {1: 1, 2: 2}.get((rpg + 63) // 64, 4)
-    return (op, int(steps * Cn), int(H), 1, 1, int(G * H), 1, 1, 1, 1, f"k_{op.split('_')[0]}_seq_{op.split('_')[1]}<16, {nsub}>")
+    return (op, int(steps * Cn), int(H), 1, 1, int(G * H), 1, 1, 1, 1, f"k_{op.split('_')[0]}_seq_{op.split('_')[1]}<{int(H)}, 16, {nsub}>")
 
 
 def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H, env_major=False) -> None:

@@ -1550,3 +1550,42 @@ def test_normalize_input_keys_subset_on_the_native_model(lib):
         ac = ActorCritic(cfg, obs_space, spaces.Discrete(4), "cuda")
         assert (ac.obs_normalizer is not None) == expect, keys
         assert ("obs_normalizer.running_mean_std.running_mean_std.obs.running_mean" in ac.state_dict()) == expect
+
+
+@pytest.mark.parametrize("rnn_type", ["lstm", "gru"])
+def test_fused_sequence_passes_at_width_256_equal_the_per_step_path(lib, rnn_type, monkeypatch):
+    """rnn_size = 256 takes the fused persistent BPTT passes (sf_*_seq_fwd/bwd, instantiated for H in {256, 512}); the
+    same run on the per-step cell kernels (the path every other width takes) must give the same weights."""
+    import sample_factory_amd.model.actor_critic as acm
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+
+    def run(fused):
+        monkeypatch.setattr(acm, "_LSTM_SEQ", fused)
+        cfg = default_cfg(env="synthetic_ant", use_rnn=True, rnn_type=rnn_type, rnn_size=256, nonlinearity="tanh",
+                          normalize_input=True, encoder_mlp_layers=[64, 64], rollout=8, recurrence=8, batch_size=1024,
+                          num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=False,
+                          seed=3, serial_mode=True, synthetic_num_agents=256, with_vtrace=True, normalize_returns=False,
+                          kl_loss_coeff=0.1)
+        cfg, runner = make_runner(cfg)
+        runner.init()
+        lib.PROFILE = {}
+        try:
+            for _ in range(2):
+                runner.iteration()
+            torch.cuda.synchronize()
+            names = {k[-1] for k in lib.PROFILE}
+        finally:
+            lib.PROFILE = None
+        return runner.learner.actor_critic.flat_params.clone(), names
+
+    p_fused, names = run(True)
+    assert any(f"k_{rnn_type}_seq_fwd" in n for n in names) and any(f"k_{rnn_type}_seq_bwd" in n for n in names), names
+    p_step, names2 = run(False)
+    assert not any("_seq_" in n for n in names2)
+    assert torch.isfinite(p_fused).all()
+    scale = float((p_step).abs().max())
+    assert float((p_fused - p_step).abs().max()) < 2e-5 * scale

@@ -299,6 +299,14 @@ def test_losses_invariant_to_spliced_invalid_data(use_rnn):
     inv = losses(inv_dataset, invalids2)
     for k in ("policy_loss", "exploration_loss", "kl_loss", "value_loss"):
         assert torch.allclose(res[k], inv[k], atol=0.02, rtol=0.02), (k, float(res[k]), float(inv[k]))
+    # reference-typed returns (learner.py:586-669): a distribution OBJECT over the action parameters and the per-sample
+    # KL(new || old) of the VALID samples, whose mean is the fused kernel's kl scalar
+    dist, _pl, _el, kl_old, _kl, _vl, summ = learner._calculate_losses(dataset, invalids)
+    assert dist.raw_logits.shape[0] == experience_size and dist.entropy().shape == (experience_size,)
+    assert torch.isfinite(dist.log_prob(dataset.actions)).all() and dist.values.shape == (experience_size,)
+    assert kl_old.shape == (experience_size,) and inv["kl_old"].shape == (experience_size,)   # invalid rows dropped
+    assert abs(float(kl_old.mean()) - float(summ.kl_old_mean)) < 1e-6 + 1e-4 * abs(float(summ.kl_old_mean))
+    assert abs(float(dist.entropy().mean()) - float(summ.entropy)) < 1e-5
 
 
 def _mlp_ckpt_setup(tmp_path, golden):

@@ -165,3 +165,45 @@ def test_reference_loads_a_checkpoint_written_here():
     r = subprocess.run([sys.executable, "-m", "oracle.check_our_checkpoint"], cwd=root, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "INTEROP OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_action_distribution_objects_match_reference_known_answers(golden):
+    """sample_factory_amd.algo.utils.action_distributions (the object API of action_distributions.py:99-323) against the
+    vectors the reference's own classes produced: probabilities, log-probs, entropy, KL(new || old), symmetric KL with the
+    uniform prior, arg-max, masked soft-max — categorical, diagonal normal and tuple-of-heads."""
+    import torch
+    from sample_factory_amd.algo.utils.action_distributions import (CategoricalActionDistribution, ContinuousActionDistribution,
+                                                                     TupleActionDistribution, argmax_actions,
+                                                                     get_action_distribution, sample_actions_log_probs)
+    from sample_factory_amd.envs import spaces
+    g = golden("action_dist")
+    t = lambda k: torch.from_numpy(np.asarray(g[k]))
+    close = lambda a, k, tol=2e-6: np.testing.assert_allclose(a.numpy(), g[k], atol=tol, rtol=2e-6, err_msg=k)
+    d = CategoricalActionDistribution(t("ka_logits"))
+    close(d.probs, "ka_probs"); close(d.entropy(), "ka_entropy")
+    for i in range(int(g["num_cat"])):
+        d, do = CategoricalActionDistribution(t(f"cat{i}_logits")), CategoricalActionDistribution(t(f"cat{i}_old_logits"))
+        close(d.probs, f"cat{i}_probs"); close(d.log_probs, f"cat{i}_log_probs", 1e-5); close(d.entropy(), f"cat{i}_entropy")
+        close(d.log_prob(t(f"cat{i}_actions")), f"cat{i}_log_prob_actions", 1e-5)
+        close(d.kl_divergence(do), f"cat{i}_kl", 1e-5); close(d.symmetric_kl_with_uniform_prior(), f"cat{i}_symkl_uniform", 1e-5)
+        assert np.array_equal(argmax_actions(d).reshape(-1).numpy(), g[f"cat{i}_argmax"])
+        a, lp = sample_actions_log_probs(d)
+        assert a.shape == (d.probs.shape[0], 1) and torch.equal(lp, d.log_prob(a))
+    for i in range(int(g["num_con"])):
+        d, do = ContinuousActionDistribution(t(f"con{i}_params")), ContinuousActionDistribution(t(f"con{i}_old_params"))
+        close(d.log_prob(t(f"con{i}_actions")), f"con{i}_log_prob_actions", 1e-5)
+        close(d.entropy(), f"con{i}_entropy", 1e-5); close(d.kl_divergence(do), f"con{i}_kl", 2e-5)
+        assert torch.equal(argmax_actions(d), d.means)
+    for i in range(int(g["num_tup"])):
+        space = spaces.Tuple([spaces.Discrete(int(n)) for n in g[f"tup{i}_heads"]])
+        d, do = get_action_distribution(space, t(f"tup{i}_logits")), TupleActionDistribution(space, t(f"tup{i}_old_logits"))
+        assert isinstance(d, TupleActionDistribution)
+        close(d.log_prob(t(f"tup{i}_actions")), f"tup{i}_log_prob_actions", 1e-5); close(d.entropy(), f"tup{i}_entropy", 1e-5)
+        close(d.kl_divergence(do), f"tup{i}_kl", 1e-5); close(d.symmetric_kl_with_uniform_prior(), f"tup{i}_symkl_uniform", 1e-5)
+        a, lp = sample_actions_log_probs(d)
+        assert a.shape == (45, len(g[f"tup{i}_heads"])) and torch.allclose(lp, d.log_prob(a))
+        assert d.argmax().shape == a.shape
+    d = CategoricalActionDistribution(t("mask_logits"), t("mask_mask").float())
+    close(d.probs, "mask_probs"); close(d.log_probs, "mask_log_probs", 1e-5)
+    assert d.sample().shape == (300, 1)            # rows with every action masked out still draw
+    assert isinstance(get_action_distribution(spaces.Box(-1, 1, (3,), np.float32), torch.zeros(5, 6)), ContinuousActionDistribution)
