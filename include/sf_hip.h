@@ -313,6 +313,21 @@ int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index
  * i.e. the previous layer's post-activation output, kind = h_desc->relu; NULL = no activation derivative). */
 int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                   const sf_conv_desc *h_desc, void *stream);
+/* ReLU SIGN-BIT MASKS between a layer's forward and its weight gradient (model/encoder.py:90-119 under autograd keeps
+ * the whole activation for ReLU's backward; here 1 bit per element).  sf_conv_fwd_relu_mask = sf_conv_fwd that also
+ * records relu_mask[n*OH*OW] (u32 per output pixel, bit c = channel c of that pixel is > 0; Cout = 32);
+ * sf_conv_wgrad_relu_mask = sf_conv_wgrad whose `dout` is the gradient wrt the layer's ReLU OUTPUT, NOT yet masked: the
+ * kernel applies the recorded bits on the way in (weight AND bias gradient).  The data-gradient launch that produced
+ * `dout` is then called with in_act = NULL and never re-reads this layer's activation (1.68 GB per C2 minibatch).
+ * sf_conv_relu_mask_supported: 1 for the launches both kernels take (first layer on raw u8 frames on the exact-product
+ * bf16 kernels, Cout == 32, ReLU); otherwise use the plain entry points with in_act. */
+int sf_conv_relu_mask_supported(int64_t n, const sf_conv_desc *h_desc);
+int sf_conv_fwd_relu_mask(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *w,
+                          const float *bias, float *out, uint32_t *relu_mask, int64_t n, const sf_conv_desc *h_desc,
+                          void *stream);
+int sf_conv_wgrad_relu_mask(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                            const float *dout, const uint32_t *relu_mask, float *dw, float *db, int64_t n,
+                            const sf_conv_desc *h_desc, void *workspace, void *stream);
 
 /* Inference on vector observations in one launch: [(x - sub_mean) * inv_scale -> (optional) running mean/std
  * normalisation with clamp +-5] -> act(x W1 + b1) -> act(. W2 + b2); utils/normalize.py:24-70 + model/encoder.py:72-87

@@ -822,9 +822,22 @@ extern "C" int64_t sf_conv_fwd_workspace(int64_t n, const sf_conv_desc *h_desc) 
         else FWD_LAUNCH(BM, BN, WM, WN, MODE_GENERIC);                 \
     } while (0)
 
-extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
-                           const float *w, const float *bias, float *out, int64_t n, const sf_conv_desc *h_desc,
-                           void *workspace, int64_t workspace_bytes, void *stream) {
+// ReLU sign-bit masks (sf_conv_fwd_relu_mask / sf_conv_wgrad_relu_mask): the layers whose forward AND weight-gradient
+// kernels can record / consume them — conv1 on raw u8 frames on the exact-product bf16 kernels, 32 output channels, ReLU.
+// SF_RELU_MASK=0 switches the path off (A/B: the data gradient below reads the activation again).
+static bool relu_mask_ok(const sf_conv_desc *d, int64_t n) {
+    static const int on = getenv("SF_RELU_MASK") ? atoi(getenv("SF_RELU_MASK")) : 1;
+    if (!on || !d->in_u8 || d->relu != 1 || d->Cout != 32) return false;
+    const ConvG g = make_geom(d);
+    return conv1_bf16_ok(g, pick_mode(g), n);
+}
+extern "C" int sf_conv_relu_mask_supported(int64_t n, const sf_conv_desc *h_desc) {
+    return h_desc && n > 0 && check_desc(h_desc, "sf_conv_relu_mask_supported") == 0 && relu_mask_ok(h_desc, n) ? 1 : 0;
+}
+
+static int conv_fwd_impl(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *w,
+                         const float *bias, float *out, uint32_t *relu_mask, int64_t n, const sf_conv_desc *h_desc,
+                         void *workspace, int64_t workspace_bytes, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_fwd");
     if (rc) return rc;
     SF_REQUIRE(in && w && out && n > 0, "sf_conv_fwd: bad args");
@@ -849,10 +862,10 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
         const unsigned grid_q = (unsigned)(npairs < resident ? npairs : resident);
         if (g.sub_mean != 0.f)
             k_conv1_u8_bf16<true><<<dim3(grid_q), dim3(256), lds_bytes, st>>>(
-                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, relu_mask, (int)n);
         else
             k_conv1_u8_bf16<false><<<dim3(grid_q), dim3(256), lds_bytes, st>>>(
-                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, relu_mask, (int)n);
         return sf_launch_status("sf_conv_fwd");
     }
     if (img_on && conv1_img_ok(g, mode, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0) {
@@ -890,6 +903,21 @@ extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32
             partial, bias, out, MN, g.Cout, p.splits, g.relu);
     }
     return sf_launch_status("sf_conv_fwd");
+}
+
+extern "C" int sf_conv_fwd(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                           const float *w, const float *bias, float *out, int64_t n, const sf_conv_desc *h_desc,
+                           void *workspace, int64_t workspace_bytes, void *stream) {
+    return conv_fwd_impl(in, in_sample_stride, index, offset, w, bias, out, nullptr, n, h_desc, workspace, workspace_bytes,
+                         stream);
+}
+extern "C" int sf_conv_fwd_relu_mask(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                                     const float *w, const float *bias, float *out, uint32_t *relu_mask, int64_t n,
+                                     const sf_conv_desc *h_desc, void *stream) {
+    SF_REQUIRE(relu_mask && ((uintptr_t)relu_mask & 3) == 0, "sf_conv_fwd_relu_mask: relu_mask must be a 4-byte aligned device buffer");
+    SF_REQUIRE(h_desc && n > 0 && relu_mask_ok(h_desc, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0,
+               "sf_conv_fwd_relu_mask: unsupported layer / launch (see sf_conv_relu_mask_supported)");
+    return conv_fwd_impl(in, in_sample_stride, index, offset, w, bias, out, relu_mask, n, h_desc, nullptr, 0, stream);
 }
 
 // ---- LDS-image forward (sf_nn_img.h): compile-time geometries (Cin, H, W, K, S, fragments per step, wave sets, output
@@ -1151,9 +1179,9 @@ extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc
         else WGRAD_LAUNCH(BN, WM, WN, MODE_GENERIC);                 \
     } while (0)
 
-extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
-                             const float *dout, float *dw, float *db, int64_t n, const sf_conv_desc *h_desc,
-                             void *workspace, void *stream) {
+static int conv_wgrad_impl(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                           const float *dout, const uint32_t *dmask, float *dw, float *db, int64_t n,
+                           const sf_conv_desc *h_desc, void *workspace, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_wgrad");
     if (rc) return rc;
     SF_REQUIRE(in && dout && dw && workspace && n > 0, "sf_conv_wgrad: bad args");
@@ -1193,12 +1221,15 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
         const unsigned lds_bytes = (unsigned)((2 * 4 * 20 * 4 * 36 + 3 * 32 * 168) * sizeof(uint16_t));
         if (g.sub_mean != 0.f)
             k_conv1_wgrad_bf16<true><<<dim3(nb), dim3(256), lds_bytes, st>>>(
-                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, dmask, partial_w,
                 db ? partial_b : nullptr, (int)n, npairs);
         else
             k_conv1_wgrad_bf16<false><<<dim3(nb), dim3(256), lds_bytes, st>>>(
-                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
+                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, dmask, partial_w,
                 db ? partial_b : nullptr, (int)n, npairs);
+    } else
+    if (dmask) {
+        SF_REQUIRE(false, "sf_conv_wgrad_relu_mask: this launch does not resolve to the mask-consuming kernel");
     } else
     if (img_on && conv1_img_ok(g, mode, n) && N == 32 && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0 &&
         ((uintptr_t)dout & 15) == 0) {
@@ -1250,6 +1281,21 @@ extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int
                                                                                                     Zused);
     if (db) k_reduce_partials<<<dim3(cdiv64(N, 256)), dim3(256), 0, st>>>(partial_b, db, N, Zused);
     return sf_launch_status("sf_conv_wgrad");
+}
+
+extern "C" int sf_conv_wgrad(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                             const float *dout, float *dw, float *db, int64_t n, const sf_conv_desc *h_desc,
+                             void *workspace, void *stream) {
+    return conv_wgrad_impl(in, in_sample_stride, index, offset, dout, nullptr, dw, db, n, h_desc, workspace, stream);
+}
+extern "C" int sf_conv_wgrad_relu_mask(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                                       const float *dout, const uint32_t *relu_mask, float *dw, float *db, int64_t n,
+                                       const sf_conv_desc *h_desc, void *workspace, void *stream) {
+    SF_REQUIRE(relu_mask && ((uintptr_t)relu_mask & 7) == 0, "sf_conv_wgrad_relu_mask: relu_mask must be an 8-byte aligned device buffer");
+    SF_REQUIRE(h_desc && n > 0 && relu_mask_ok(h_desc, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0 &&
+                   ((uintptr_t)dout & 15) == 0,
+               "sf_conv_wgrad_relu_mask: unsupported layer / launch (see sf_conv_relu_mask_supported)");
+    return conv_wgrad_impl(in, in_sample_stride, index, offset, dout, relu_mask, dw, db, n, h_desc, workspace, stream);
 }
 
 #define DGRAD_LAUNCH(BM, BN, WM, WN)                                                                          \

@@ -43,7 +43,8 @@ template <bool SUB, int NCT>
 __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
                                                    const int32_t *__restrict__ index, int64_t offset,
                                                    const float *__restrict__ w, const float *__restrict__ bias,
-                                                   float *__restrict__ out, int nsamples) {
+                                                   float *__restrict__ out, uint32_t *__restrict__ mask_out,
+                                                   int nsamples) {
     constexpr int SMP = 2 * NCT, R = 4, TMF = 5, KB = 8;
     constexpr int H = 84, W = 84, WP = 88, Cin = 4, KH = 8, S = 4, OH = 20, OW = 20, OHOW = OH * OW;
     constexpr int RS = (R - 1) * S + KH;  // 20 input rows per strip
@@ -178,6 +179,11 @@ __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__res
             constexpr int KIND = decltype(kc)::value;
             const bool sok = s0 + wsmp < nsamples;
             float *ob = out + ((int64_t)(s0 + wsmp) * OHOW + st * (R * OW)) * N;
+            // ReLU sign bits for the backward pass (mask_out != NULL, N == 32): one u32 per output pixel, bit c = channel c
+            // is positive.  This wave owns 16 channels = one u16 half of each word: a wave ballot of (v > 0) is 4 pixels
+            // (kg) x 16 channels (col); lane (kg, col 0) stores its pixel's half.
+            uint16_t *mb = mask_out ? reinterpret_cast<uint16_t *>(mask_out) +
+                                          ((int64_t)(s0 + wsmp) * OHOW + st * (R * OW)) * 2 + ct0 : nullptr;
 #pragma unroll
             for (int t = 0; t < TMF; ++t)
 #pragma unroll
@@ -187,6 +193,10 @@ __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__res
                     for (int r = 0; r < 4; ++r) {
                         const float v = act_fwd_c<KIND>(acc[t][ct][r] * scl + bv[ct], g.relu);
                         if (sok && cc < N) ob[(int64_t)(t * 16 + 4 * kg + r) * N + cc] = v;
+                        if (KIND == 1 && NCT == 1 && mb) {  // (wave-uniform)
+                            const unsigned long long bits = __ballot(v > 0.f);
+                            if (col == 0 && sok) mb[(t * 16 + 4 * kg + r) * 2] = (uint16_t)(bits >> (16 * kg));
+                        }
                     }
                 }
         };
@@ -200,8 +210,8 @@ template <bool SUB>
 __global__ __launch_bounds__(256, 2)
 void k_conv1_u8_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride, const int32_t *__restrict__ index,
                      int64_t offset, const float *__restrict__ w, const float *__restrict__ bias,
-                     float *__restrict__ out, int nsamples) {
-    conv1_u8_bf16_body<SUB, 1>(g, in, in_stride, index, offset, w, bias, out, nsamples);
+                     float *__restrict__ out, uint32_t *__restrict__ mask_out, int nsamples) {
+    conv1_u8_bf16_body<SUB, 1>(g, in, in_stride, index, offset, w, bias, out, mask_out, nsamples);
 }
 
 // ============================================================================================== WEIGHT GRADIENT, raw u8 frames
@@ -225,8 +235,11 @@ void k_conv1_u8_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
 template <bool SUB>
 __global__ __launch_bounds__(256, 2)
 void k_conv1_wgrad_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride, const int32_t *__restrict__ index,
-                        int64_t offset, const float *__restrict__ dy, float *__restrict__ partial,
-                        float *__restrict__ partial_b, int nsamples, int npairs) {
+                        int64_t offset, const float *__restrict__ dy, const uint32_t *__restrict__ dmask,
+                        float *__restrict__ partial, float *__restrict__ partial_b, int nsamples, int npairs) {
+    // dmask != NULL: dy is the gradient wrt this layer's ReLU OUTPUT, not yet masked; dmask[sample*400 + pixel] holds the
+    // sign bits the forward kernel recorded (bit c: channel c was positive) and the mask is applied on the way into LDS —
+    // the producing data-gradient kernel then never reads the 1.68 GB activation (n = 32768) to mask its output.
     constexpr int SMP = 2, R = 4, H = 84, W = 84, Cin = 4, S = 4, OH = 20, OW = 20, OHOW = OH * OW, N = 32, K = 256;
     constexpr int RS = (R - 1) * S + 8, W4 = W >> 2;
     constexpr int WP2 = (W4 + 1) / 2, PAIRS = Cin * RS * WP2, NLD = (PAIRS + 255) / 256;  // word pairs (8 pixels) per thread
@@ -270,7 +283,7 @@ void k_conv1_wgrad_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stri
     const float sub = g.sub_mean;
     // Operands are prefetched TWO strips ahead into two register sets (a strip's MFMA phase, ~1 us, is shorter than a
     // loaded HBM round trip): unit u = (local pair, strip) uses set u & 1.
-    struct Regs { uint32_t pre[SMP][NLD][2]; f32x4 dpre[NDY][2]; };
+    struct Regs { uint32_t pre[SMP][NLD][2]; f32x4 dpre[NDY][2]; uint2 mpre[NDY]; };
     const int my_pairs = (int)blockIdx.x < npairs ? (npairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int total_units = my_pairs * nstrips;
     auto load_strip = [&](int unit, Regs &rg) {
@@ -301,6 +314,10 @@ void k_conv1_wgrad_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stri
             const float *src = dy + ((int64_t)(z == 0 ? sidx[0] : sidx[1]) * OHOW + st * (R * OW) + pl) * N + n4 * 4;
             rg.dpre[it][0] = live ? *reinterpret_cast<const f32x4 *>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
             rg.dpre[it][1] = live ? *reinterpret_cast<const f32x4 *>(src + N) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dmask)  // the two pixels' sign words (pl is even: one aligned 8-byte load)
+                rg.mpre[it] = live ? *reinterpret_cast<const uint2 *>(dmask + (int64_t)(z == 0 ? sidx[0] : sidx[1]) * OHOW +
+                                                                      st * (R * OW) + pl)
+                                   : uint2{0u, 0u};
         }
     };
     auto store_strip = [&](const Regs &rg) {
@@ -324,7 +341,11 @@ void k_conv1_wgrad_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stri
             if (pp >= PIX / 2) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float v0 = rg.dpre[it][0][j], v1 = rg.dpre[it][1][j];
+                float v0 = rg.dpre[it][0][j], v1 = rg.dpre[it][1][j];
+                if (dmask) {  // (uniform) ReLU derivative from the recorded sign bit of channel 4*n4 + j
+                    v0 = ((rg.mpre[it].x >> (4 * n4 + j)) & 1u) ? v0 : 0.f;
+                    v1 = ((rg.mpre[it].y >> (4 * n4 + j)) & 1u) ? v1 : 0.f;
+                }
                 colacc[j] += v0 + v1;
                 // exact 3-way split of both values (see split3_bf16), the pair packed with one v_perm per term
                 const uint32_t b0 = __float_as_uint(v0), b1 = __float_as_uint(v1);

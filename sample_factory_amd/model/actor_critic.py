@@ -535,7 +535,23 @@ class ActorCritic:
                 x = xt
             inputs[li] = x
             out = self._buf((tag, li), (n * L.out_pixels, L.N))
-            self._gemm(li, x, stride, idx, off, tT, out, n, tag)
+            mask = None
+            if tag == "train" and li == 0 and li + 1 < len(self.layers) and self.layers[1].role == "chain":
+                d0 = L.desc
+                if tT:
+                    d0 = lib.sf_conv_desc.from_buffer_copy(L.desc)
+                    d0.traj_T = int(tT)
+                if lib.conv_relu_mask_supported(n, d0):
+                    # conv1 on raw frames: the forward also records ONE sign bit per output element; the backward pass
+                    # masks with these bits inside conv1's weight-gradient kernel, so conv2's data gradient never
+                    # re-reads this activation
+                    mask = self._buf((tag, "relu_mask0"), (n * L.out_pixels,), dtype=torch.int32)
+                    w_, b_, _ = self._wb(li, tag)
+                    lib.conv_fwd_relu_mask(x, stride, idx, off, w_, b_, out, mask, n, d0)
+            if mask is None:
+                self._gemm(li, x, stride, idx, off, tT, out, n, tag)
+            if li == 0:
+                self._relu_mask0 = mask if tag == "train" else getattr(self, "_relu_mask0", None)
             acts[li] = out
             x = out
             if L.role == "rnn_ih":
@@ -715,6 +731,7 @@ class ActorCritic:
         if self.tanh_scale > 0:  # d tanh(x/s)*s / dx = 1 - (y/s)^2 on the mean columns
             lib.tanh_scale_bwd(g_heads, ctx["acts"][-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
         chain = [li for li, L in enumerate(self.layers) if L.role != "rnn_hh"]
+        mask0 = getattr(self, "_relu_mask0", None)
         for pos in range(len(chain) - 1, -1, -1):
             li = chain[pos]
             L = self.layers[li]
@@ -725,7 +742,10 @@ class ActorCritic:
                 d0 = lib.sf_conv_desc.from_buffer_copy(d)
                 d0.traj_T = int(tT0)
                 ws = self._workspace(lib.conv_wgrad_workspace(n, d0))
-                lib.conv_wgrad_raw(x0, stride0, idx0, off0, g, L.gw, L.gb, n, d0, ws)
+                if mask0 is not None:  # g is the gradient wrt conv1's ReLU output, unmasked: the kernel applies the bits
+                    lib.conv_wgrad_relu_mask(x0, stride0, idx0, off0, g, mask0, L.gw, L.gb, n, d0, ws)
+                else:
+                    lib.conv_wgrad_raw(x0, stride0, idx0, off0, g, L.gw, L.gb, n, d0, ws)
             else:
                 x = inputs[li]
                 ws = self._workspace(lib.conv_wgrad_workspace(n, d))
@@ -733,7 +753,11 @@ class ActorCritic:
                 gin = self._buf(("g", li - 1), tuple(x.shape))
                 dd = lib.sf_conv_desc.from_buffer_copy(d)
                 dd.relu = L.in_act_kind  # derivative of the activation that produced x, fused into the epilogue
-                lib.conv_dgrad(g, L.w, x if L.in_act_kind else None, gin, n, dd)
+                if pos == 1 and mask0 is not None:  # conv1's sign bits are applied by its weight-gradient kernel instead
+                    dd.relu = 0
+                    lib.conv_dgrad(g, L.w, None, gin, n, dd)
+                else:
+                    lib.conv_dgrad(g, L.w, x if L.in_act_kind else None, gin, n, dd)
                 g = gin
                 if L.role == "rnn_ih":  # back to sample-major for the encoder
                     R, Cn = self._rnn_saved["R"], self._rnn_saved["Cn"]

@@ -228,6 +228,12 @@ def test_weight_gradients_vs_eight_launches_and_float64(lib, st):
     ac, batch, acts, g_heads = st["ac"], st["batch"], st["acts"], st["g_heads"]
     saved = st["grads"]
     rep = {}
+    mask0 = getattr(ac, "_relu_mask0", None)
+    assert mask0 is not None, "the bench's conv1 records ReLU sign bits (sf_conv_fwd_relu_mask)"
+    # the recorded bits ARE the sign pattern of conv1's output, bit c of word [sample*400 + pixel] = channel c
+    a0 = acts[0].view(N * 400, 32)
+    bits = ((mask0.view(-1, 1) >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1).bool()
+    assert torch.equal(bits, a0 > 0)
     for li, L in enumerate(ac.layers):
         d = L.desc
         dy = g_heads if li == len(ac.layers) - 1 else ac._bufs[("g", li)]
@@ -244,7 +250,11 @@ def test_weight_gradients_vs_eight_launches_and_float64(lib, st):
                 d0 = lib.sf_conv_desc.from_buffer_copy(d)
                 d0.traj_T = T
                 ws = ac._workspace(lib.conv_wgrad_workspace(4096, d0))
-                lib.conv_wgrad_raw(batch["obs"]["obs"], ac.obs_elems, None, OFF + k * 4096, dyk, tw, tb, 4096, d0, ws)
+                if mask0 is not None:  # dY of conv1 is unmasked; the kernel applies the recorded sign bits
+                    lib.conv_wgrad_relu_mask(batch["obs"]["obs"], ac.obs_elems, None, OFF + k * 4096, dyk,
+                                             mask0[k * rows_per:(k + 1) * rows_per], tw, tb, 4096, d0, ws)
+                else:
+                    lib.conv_wgrad_raw(batch["obs"]["obs"], ac.obs_elems, None, OFF + k * 4096, dyk, tw, tb, 4096, d0, ws)
             else:
                 xin = acts[li - 1].view(N, -1)[k * 4096:(k + 1) * 4096]
                 ws = ac._workspace(lib.conv_wgrad_workspace(4096, d))
@@ -256,6 +266,7 @@ def test_weight_gradients_vs_eight_launches_and_float64(lib, st):
         # float64 from OUR operands of that layer
         if li == 0:
             x64 = _rows(batch, OFF + torch.arange(N, device="cuda"))
+            dy = dy * (a0 > 0)  # float64 reference on the masked gradient (what the kernel forms internally)
             dw64, db64 = _unfold_wgrad64(x64, dy, 8, 4, 1024)
             dw64 = dw64 / 255.0
             ref = dw64.reshape(L.N, -1).t()                                   # k = (c*KH+kh)*KW+kw
@@ -293,6 +304,9 @@ def test_data_gradients_vs_eight_launches_and_float64(lib, st):
         L = ac.layers[li]
         d = lib.sf_conv_desc.from_buffer_copy(L.desc)
         d.relu = L.in_act_kind
+        unmasked = li == 1 and getattr(ac, "_relu_mask0", None) is not None  # conv1's mask is applied in ITS wgrad kernel
+        if unmasked:
+            d.relu = 0
         dy = (g_heads if li == nl - 1 else ac._bufs[("g", li)]).view(N * L.out_pixels, L.N)
         full = ac._bufs[("g", li - 1)].view(N, -1)
         x = acts[li - 1].view(N, -1)
@@ -300,7 +314,8 @@ def test_data_gradients_vs_eight_launches_and_float64(lib, st):
         worst = 0.0
         rows_per = 4096 * L.out_pixels
         for k in range(8):
-            lib.conv_dgrad(dy[k * rows_per:(k + 1) * rows_per], L.w, x[k * 4096:(k + 1) * 4096].contiguous(), part, 4096, d)
+            lib.conv_dgrad(dy[k * rows_per:(k + 1) * rows_per], L.w,
+                           None if unmasked else x[k * 4096:(k + 1) * 4096].contiguous(), part, 4096, d)
             worst = max(worst, float((part - full[k * 4096:(k + 1) * 4096]).abs().max()))
         s = float(full.abs().max())
         # float64: dX = mask(x) * (dY @ W^T) folded back onto the input pixels
@@ -316,7 +331,8 @@ def test_data_gradients_vs_eight_launches_and_float64(lib, st):
                 dx = F.fold(cols, (dd.H, dd.W), dd.KH, stride=dd.stride).permute(0, 2, 3, 1).reshape(4096, -1)
             else:
                 dx = cols
-            dx = dx * (x[i:i + 4096] > 0)
+            if not unmasked:
+                dx = dx * (x[i:i + 4096] > 0)
             e64 = max(e64, float((full[i:i + 4096].double() - dx).abs().max() / dx.abs().max()))
         rep[L.name] = dict(vs_8x4096=worst / s, vs_float64=e64)
         assert worst / s < 1e-6, (L.name, worst / s)

@@ -1589,3 +1589,35 @@ def test_fused_sequence_passes_at_width_256_equal_the_per_step_path(lib, rnn_typ
     assert torch.isfinite(p_fused).all()
     scale = float((p_step).abs().max())
     assert float((p_fused - p_step).abs().max()) < 2e-5 * scale
+
+
+def test_conv1_relu_sign_bits_between_forward_and_weight_gradient(lib):
+    """sf_conv_fwd_relu_mask records one sign bit per output element (u32 per pixel, bit c = channel c > 0) next to the
+    activations; sf_conv_wgrad_relu_mask applies them to an UNMASKED output gradient inside the kernel: bit-equal to the
+    plain kernels on the same frames / a pre-masked gradient (slab addressing through an index included)."""
+    E, T, n = 40, 8, 300
+    g = torch.Generator().manual_seed(21)
+    slab = torch.randint(0, 256, (E, T + 1, 4, 84, 84), generator=g, dtype=torch.uint8).cuda()
+    idx = torch.randperm(E * T, generator=g)[:n].to(torch.int32).cuda()
+    inv = float(np.float32(1 / 255.0))
+    d = desc(lib, 4, 84, 84, 32, 8, 4, in_u8=1, inv_scale=inv, traj_T=T)
+    assert lib.conv_relu_mask_supported(n, d) and not lib.conv_relu_mask_supported(100, d)
+    assert not lib.conv_relu_mask_supported(n, desc(lib, 4, 84, 84, 32, 8, 4, in_u8=1, inv_scale=inv, relu=2))
+    w = (torch.randn((256, 32), generator=g) / 16).cuda()
+    b = (torch.randn(32, generator=g) * 0.3).cuda()
+    S = 4 * 84 * 84
+    out1, out2 = torch.empty((n * 400, 32), device="cuda"), torch.empty((n * 400, 32), device="cuda")
+    mask = torch.full((n * 400,), -1, dtype=torch.int32, device="cuda")
+    lib.conv_fwd(slab, S, idx, 0, w, b, out1, n, d)
+    lib.conv_fwd_relu_mask(slab, S, idx, 0, w, b, out2, mask, n, d)
+    assert torch.equal(out1, out2)
+    bits = ((mask.view(-1, 1) >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1).bool()
+    assert torch.equal(bits, out1 > 0) and 0.2 < float(bits.float().mean()) < 0.8
+    dy = torch.randn((n * 400, 32), generator=g).cuda()
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    dw1, db1, dw2, db2 = torch.zeros_like(w), torch.zeros(32, device="cuda"), torch.zeros_like(w), torch.zeros(32, device="cuda")
+    lib.conv_wgrad(slab, S, idx, 0, (dy * (out1 > 0)).contiguous(), dw1, db1, n, d, ws)
+    lib.conv_wgrad_relu_mask(slab, S, idx, 0, dy, mask, dw2, db2, n, d, ws)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2) and dw1.abs().max() > 0
+    with pytest.raises(lib.SfHipError):   # a launch the mask kernels do not take
+        lib.conv_fwd_relu_mask(slab, S, idx[:64].contiguous(), 0, w, b, out2, mask, 64, d)
