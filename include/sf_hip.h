@@ -155,6 +155,20 @@ int sf_ppo_loss(const float *params, int ld_params, const float *values, int ld_
 /* out[0..3] = policy, exploration, kl, value losses; [4] kl mean; [5] kl max; [6] adv mean; [7] adv std;
  * [8] n_valid; [9] entropy (or symkl) mean — device float[16]. */
 int sf_loss_scalars(const double *sums, const double *moments, const sf_loss_cfg *h_cfg, float *out, void *stream);
+/* learner.py:843-923 (`_record_summaries`: ~25 torch reductions with an `.item()` each) for one minibatch in ONE pass:
+ * rows i < n are dataset rows index[i] | offset + i; ratio [n] (sf_ppo_loss's ratio_out), values (new, stride ld_values),
+ * old_values (flat [N], or the slab's [E, old_values_T + 1]), actions [N, num_actions], adv ([n] if dense_adv else [N]),
+ * policy_id / policy_version / valids [N], action_logits [N, A]; exp_avg_sq [P] (may be NULL).  out: device double[24]:
+ * [0] rows [1] valid [2] same-policy [3] sum value [4] sum |1 - ratio| over valid [5] clipped ratios (valid, outside
+ * [1/(1+clip_ratio), 1+clip_ratio]) [6] sum |v - v_old| [7] sum (train_step - policy_version) over same-policy rows;
+ * [8]/[9] ratio min / max (valid) [10] max |v - v_old| [11]/[12] action min / max [13]/[14] adv min / max
+ * [15] max |old action parameter| [16]/[17] version_diff min / max [18] max exp_avg_sq (minima +inf / maxima -inf when
+ * no row qualified). */
+int sf_train_summaries(const uint8_t *valids, const float *ratio, const float *values, int ld_values,
+                       const float *old_values, int old_values_T, const float *actions, int num_actions, const float *adv,
+                       int dense_adv, const int32_t *policy_id, const float *policy_version, const float *action_logits,
+                       int A, const int32_t *index, int64_t offset, int64_t n, int my_policy_id, int train_step,
+                       float clip_ratio, const float *exp_avg_sq, int64_t P, double *out, void *stream);
 
 /* ---- K14: minibatch index sets ------------------------------------------------------------------------------
  * learner.py:498-526.  Writes experience_size int32 indices: a pseudo-random permutation (stateless 4-round

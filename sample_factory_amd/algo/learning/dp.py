@@ -57,6 +57,7 @@ class _Exposed:
     time between the two is what the exchange cost the compute stream (0 when the collective had already finished)"""
 
     def __init__(self, group):
+        self.group = group
         self.on = group is not None and group.timing is not None and torch.cuda.is_available()
 
     def __enter__(self):

@@ -667,34 +667,27 @@ class Learner:
     def _record_summaries(self, buff: AttrDict) -> Dict[str, float]:
         """The rest of learner.py:843-923 for the LAST minibatch of the call: ratio / clipping / value-delta statistics,
         action / advantage / logit ranges, policy-lag (version_diff_*), gradient norm and Adam's largest second moment —
-        reduced on the device, ONE readback of 20 floats (the reference does ~25 `.item()` calls)."""
+        ONE pass over the minibatch on the device (sf_train_summaries) and ONE readback of 24 doubles (the reference
+        does ~25 torch reductions with an `.item()` each)."""
         index, offset, n, values, adv_arr = self._last_mb
-        rows = index.long() if index is not None else torch.arange(offset, offset + n, device=self.device)
-        valid = buff.valids[rows]
-        ratio = self._ratio[:n]
-        vr = ratio[valid]
-        if vr.numel() == 0:
-            vr = ratio.new_ones(1)
-        old_v = buff["values"].reshape(-1)[rows + rows // buff.T]  # [E, T+1] slab rows
-        dv = (values - old_v).abs()
-        acts = buff.actions[rows]
-        adv = adv_arr[:n] if self.cfg.with_vtrace else adv_arr[rows]
-        same = buff.policy_id[rows] == self.policy_id
-        vd = (float(self.train_step) - buff.policy_version[rows])[same]
-        if vd.numel() == 0:
-            vd = ratio.new_zeros(1)
-        lo, hi = self.loss_cfg.clip_ratio, self.loss_cfg.clip_ratio
-        clip_lo, clip_hi = 1.0 / (1.0 + lo), 1.0 + hi
-        t = torch.stack([
-            valid.float().mean(), same.float().mean(), values.mean(), (1.0 - vr).abs().mean(), vr.min(), vr.max(),
-            ((vr < clip_lo).float() + (vr > clip_hi).float()).mean(), dv.mean(), dv.max(), acts.min(), acts.max(),
-            adv.min(), adv.max(), buff.action_logits[rows].abs().max(), vd.mean(), vd.min(), vd.max(),
-            self._sumsq.sqrt().float().reshape(()), self.exp_avg_sq.max()]).cpu().tolist()
-        names = ["valids_fraction", "same_policy_fraction", "value", "ratio_mean", "ratio_min", "ratio_max",
-                 "fraction_clipped", "value_delta", "value_delta_max", "act_min", "act_max", "adv_min", "adv_max",
-                 "max_abs_logprob", "version_diff_avg", "version_diff_min", "version_diff_max", "grad_norm",
-                 "adam_max_second_moment"]
-        return dict(zip(names, t))
+        if not hasattr(self, "_summ"):
+            self._summ = torch.empty(24, dtype=torch.float64, device=self.device)
+        ld = values.stride(0) if values.dim() == 1 else 1
+        lib.train_summaries(buff.valids, self._ratio, values, ld, buff["values"], buff.T, buff.actions, self.num_actions,
+                            adv_arr, bool(self.cfg.with_vtrace), buff.policy_id, buff.policy_version, buff.action_logits,
+                            self.num_action_params, index, offset, n, self.policy_id, self.train_step,
+                            self.loss_cfg.clip_ratio, self.exp_avg_sq, self._summ)
+        o = self._summ.cpu().tolist()
+        rows, nv, ns = o[0], o[1], o[2]
+        has_v, has_s = nv > 0, ns > 0
+        return dict(
+            valids_fraction=nv / rows, same_policy_fraction=ns / rows, value=o[3] / rows,
+            ratio_mean=o[4] / nv if has_v else 0.0, ratio_min=o[8] if has_v else 1.0, ratio_max=o[9] if has_v else 1.0,
+            fraction_clipped=o[5] / nv if has_v else 0.0, value_delta=o[6] / rows, value_delta_max=o[10],
+            act_min=o[11], act_max=o[12], adv_min=o[13], adv_max=o[14], max_abs_logprob=o[15],
+            version_diff_avg=o[7] / ns if has_s else 0.0, version_diff_min=o[16] if has_s else 0.0,
+            version_diff_max=o[17] if has_s else 0.0, grad_norm=float(self._sumsq.sqrt().item()),
+            adam_max_second_moment=o[18])
 
     def train(self, batch: TensorDict) -> Optional[Dict]:
         """learner.py:1036-1067"""

@@ -886,6 +886,164 @@ extern "C" int sf_loss_scalars(const double *sums, const double *moments, const 
     return sf_launch_status("sf_loss_scalars");
 }
 
+// =========================================================================================== train summaries
+// learner.py:843-923 (_record_summaries) for the last minibatch of a training call: the reference evaluates ~25 small
+// torch reductions with one .item() each; here ONE pass over the minibatch's rows accumulates every statistic
+// (block reduction -> one atomic per block and quantity), a second small launch takes the maximum of Adam's second
+// moments, and the caller reads 24 doubles back.  out layout (device double[24], initialised by the call):
+//   [0] n rows  [1] n valid  [2] n same-policy  [3] sum value  [4] sum |1 - ratio| (valid)  [5] n clipped (valid)
+//   [6] sum |v - v_old|  [7] sum version_diff (same policy)
+//   [8] ratio min (valid)  [9] ratio max (valid)  [10] max |v - v_old|  [11] act min  [12] act max  [13] adv min
+//   [14] adv max  [15] max |old action parameter|  [16] version_diff min  [17] version_diff max  [18] max exp_avg_sq
+constexpr int SUMM_NS = 8, SUMM_NM = 11, SUMM_OUT = 24;
+struct SummArgs {
+    const uint8_t *valids;
+    const float *ratio, *values, *old_values, *actions, *adv, *policy_version, *action_logits;
+    const int32_t *policy_id, *index;
+    int64_t offset, n;
+    int ld_values, old_values_T, num_actions, A, dense_adv, my_pid;
+    float train_step, clip_lo, clip_hi;
+};
+__device__ __forceinline__ void atomic_minmax_d(double *addr, double v, bool is_max) {
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        const double cur = __longlong_as_double((long long)assumed);
+        if (is_max ? cur >= v : cur <= v) break;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    } while (assumed != old);
+}
+__global__ void k_summ_init(double *out) {
+    const int i = threadIdx.x;
+    if (i >= SUMM_OUT) return;
+    // sums 0; minima +inf; maxima -inf
+    const bool is_min = i == 8 || i == 11 || i == 13 || i == 16;
+    const bool is_max = i == 9 || i == 10 || i == 12 || i == 14 || i == 15 || i == 17 || i == 18;
+    out[i] = is_min ? (double)INFINITY : is_max ? -(double)INFINITY : 0.0;
+}
+__global__ __launch_bounds__(256) void k_train_summaries(SummArgs p, double *__restrict__ out) {
+    __shared__ double lds[4 * SUMM_NS];
+    __shared__ float ldm[4 * SUMM_NM];
+    double s[SUMM_NS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // minima: r_min, act_min, adv_min, vd_min;  maxima: r_max, dv_max, act_max, adv_max, logit_absmax, vd_max (+1 spare)
+    float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    float mx[7] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = p.index ? (int64_t)p.index[i] : p.offset + i;
+        const bool valid = p.valids[d] != 0, same = p.policy_id[d] == p.my_pid;
+        const float v = p.values[i * p.ld_values];
+        const int64_t dv_row = p.old_values_T > 0 ? d + d / p.old_values_T : d;
+        const float dv = fabsf(v - p.old_values[dv_row]);
+        s[0] += 1.0;
+        s[1] += valid ? 1.0 : 0.0;
+        s[2] += same ? 1.0 : 0.0;
+        s[3] += (double)v;
+        s[6] += (double)dv;
+        mx[1] = fmaxf(mx[1], dv);
+        if (valid) {
+            const float r = p.ratio[i];
+            s[4] += (double)fabsf(1.0f - r);
+            s[5] += (r < p.clip_lo ? 1.0 : 0.0) + (r > p.clip_hi ? 1.0 : 0.0);
+            mn[0] = fminf(mn[0], r);
+            mx[0] = fmaxf(mx[0], r);
+        }
+        for (int a = 0; a < p.num_actions; ++a) {
+            const float x = p.actions[d * p.num_actions + a];
+            mn[1] = fminf(mn[1], x);
+            mx[2] = fmaxf(mx[2], x);
+        }
+        const float ad = p.adv[p.dense_adv ? i : d];
+        mn[2] = fminf(mn[2], ad);
+        mx[3] = fmaxf(mx[3], ad);
+        for (int a = 0; a < p.A; ++a) mx[4] = fmaxf(mx[4], fabsf(p.action_logits[d * p.A + a]));
+        if (same) {
+            const float vd = p.train_step - p.policy_version[d];
+            s[7] += (double)vd;
+            mn[3] = fminf(mn[3], vd);
+            mx[5] = fmaxf(mx[5], vd);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < SUMM_NS; ++k) s[k] = sf_wave_sum(s[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
+#pragma unroll
+    for (int k = 0; k < 7; ++k) mx[k] = sf_wave_max(mx[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < SUMM_NS; ++k) lds[wave * SUMM_NS + k] = s[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ldm[wave * SUMM_NM + k] = mn[k];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) ldm[wave * SUMM_NM + 4 + k] = mx[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int k = 0; k < SUMM_NS; ++k) {
+            double t = 0.0;
+            for (int w = 0; w < nw; ++w) t += lds[w * SUMM_NS + k];
+            if (t != 0.0) atomicAdd(&out[k], t);
+        }
+        float m4[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, x7[7];
+        for (int k = 0; k < 7; ++k) x7[k] = -INFINITY;
+        for (int w = 0; w < nw; ++w) {
+            for (int k = 0; k < 4; ++k) m4[k] = fminf(m4[k], ldm[w * SUMM_NM + k]);
+            for (int k = 0; k < 7; ++k) x7[k] = fmaxf(x7[k], ldm[w * SUMM_NM + 4 + k]);
+        }
+        // out slots: 8 r_min, 9 r_max, 10 dv_max, 11 act_min, 12 act_max, 13 adv_min, 14 adv_max, 15 logit, 16 vd_min, 17 vd_max
+        atomic_minmax_d(&out[8], (double)m4[0], false);
+        atomic_minmax_d(&out[9], (double)x7[0], true);
+        atomic_minmax_d(&out[10], (double)x7[1], true);
+        atomic_minmax_d(&out[11], (double)m4[1], false);
+        atomic_minmax_d(&out[12], (double)x7[2], true);
+        atomic_minmax_d(&out[13], (double)m4[2], false);
+        atomic_minmax_d(&out[14], (double)x7[3], true);
+        atomic_minmax_d(&out[15], (double)x7[4], true);
+        atomic_minmax_d(&out[16], (double)m4[3], false);
+        atomic_minmax_d(&out[17], (double)x7[5], true);
+    }
+}
+__global__ __launch_bounds__(256) void k_max_f32(const float *__restrict__ x, int64_t n, double *__restrict__ out) {
+    __shared__ float ldm[4];
+    float m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, x[i]);
+    m = sf_wave_max(m);
+    if ((threadIdx.x & 63) == 0) ldm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) m = fmaxf(m, ldm[w]);
+        atomic_minmax_d(out, (double)m, true);
+    }
+}
+
+extern "C" int sf_train_summaries(const uint8_t *valids, const float *ratio, const float *values, int ld_values,
+                                  const float *old_values, int old_values_T, const float *actions, int num_actions,
+                                  const float *adv, int dense_adv, const int32_t *policy_id, const float *policy_version,
+                                  const float *action_logits, int A, const int32_t *index, int64_t offset, int64_t n,
+                                  int my_policy_id, int train_step, float clip_ratio, const float *exp_avg_sq, int64_t P,
+                                  double *out, void *stream) {
+    SF_REQUIRE(valids && ratio && values && old_values && actions && adv && policy_id && policy_version && action_logits &&
+                   out && n > 0 && num_actions > 0 && A > 0 && ld_values >= 1,
+               "sf_train_summaries: bad args");
+    SummArgs p{valids, ratio, values, old_values, actions, adv, policy_version, action_logits, policy_id, index, offset, n,
+               ld_values, old_values_T, num_actions, A, dense_adv, my_policy_id, (float)train_step,
+               (float)(1.0 / (1.0 + (double)clip_ratio)), (float)(1.0 + (double)clip_ratio)};
+    k_summ_init<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(out);
+    const int64_t blocks = (n + 255) / 256;
+    k_train_summaries<<<dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, STREAM(stream)>>>(p, out);
+    if (exp_avg_sq && P > 0) {
+        const int64_t b2 = (P + 1023) / 1024;
+        k_max_f32<<<dim3((unsigned)(b2 < 1024 ? b2 : 1024)), dim3(256), 0, STREAM(stream)>>>(exp_avg_sq, P, out + 18);
+    }
+    return sf_launch_status("sf_train_summaries");
+}
+
 // =========================================================================================== device row copies
 // dst[r][0..row_bytes) = src[r][0..row_bytes) for r < rows, rows `pitch` bytes apart on either side: the slab's column
 // copies (next rollout's obs[:, 0] <- obs[:, T], rnn_states likewise, bootstrap value -> values[:, T]).  16-byte units

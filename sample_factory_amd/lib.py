@@ -37,7 +37,7 @@ class sf_conv_desc(C.Structure):
 # every symbol include/sf_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
-    "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
+    "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_train_summaries", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
     "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
@@ -378,6 +378,21 @@ def ppo_loss(params, ld_params, values, ld_values, actions, old_logp, old_params
 def loss_scalars(sums, mom, cfg: sf_loss_cfg, out) -> None:
     _check(load().sf_loss_scalars(ptr(sums, "f64"), ptr(mom, "f64"), C.byref(cfg), ptr(out, "f32"), stream()),
            "sf_loss_scalars")
+
+
+def train_summaries(valids, ratio, values, ld_values, old_values, old_values_T, actions, num_actions, adv, dense_adv,
+                    policy_id, policy_version, action_logits, A, index, offset, n, my_policy_id, train_step, clip_ratio,
+                    exp_avg_sq, out) -> None:
+    """learner.py:843-923 for one minibatch in one pass; out: device double[24] (layout: include/sf_hip.h)"""
+    _check(load().sf_train_summaries(ptr(valids, "u8", "valids"), ptr(ratio, "f32", "ratio"), _raw(values, "f32", "values"),
+                                     int(ld_values), ptr(old_values, "f32", "old_values"), int(old_values_T),
+                                     ptr(actions, "f32", "actions"), int(num_actions), ptr(adv, "f32", "adv"),
+                                     int(bool(dense_adv)), ptr(policy_id, "i32", "policy_id"),
+                                     ptr(policy_version, "f32", "policy_version"), ptr(action_logits, "f32", "action_logits"),
+                                     int(A), ptr(index, "i32", "index"), i64(offset), i64(n), int(my_policy_id),
+                                     int(train_step), f(clip_ratio), ptr(exp_avg_sq, "f32", "exp_avg_sq"),
+                                     i64(exp_avg_sq.numel() if exp_avg_sq is not None else 0), ptr(out, "f64", "out"),
+                                     stream()), "sf_train_summaries")
 
 
 def minibatch_indices(out, experience_size, recurrence, shuffle, seed, epoch) -> None:

@@ -148,3 +148,17 @@ def test_bench_rccl_launch_without_enough_devices_fails_in_rank_code():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "need 2 devices on this node" in (r.stderr + r.stdout)
+
+
+def test_collective_timing_hooks_without_a_gpu():
+    """ReplicaGroup.enable_timing() on a box without a GPU: the event brackets are inert (no CUDA), the counters run, and
+    the packed sum/max exchange of a single-rank forced group is the identity"""
+    from sample_factory_amd.algo.learning import dp
+    grp = dp.ReplicaGroup()                      # no process group: inactive
+    grp.enable_timing()
+    t = torch.arange(6, dtype=torch.float64)
+    assert grp.reduce_sum_max(t.clone(), (2,)).equal(t) and grp.all_reduce_sum(t.clone()).equal(t)
+    with dp._Exposed(grp) as e:                  # bracket object keeps its group (regression: AttributeError on exit)
+        assert e.group is grp
+    if not torch.cuda.is_available():
+        assert grp.timing["exposed"] == [] and grp.timing["count"] == 0   # inactive group: nothing was issued

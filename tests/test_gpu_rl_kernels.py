@@ -951,3 +951,45 @@ def test_copy_rows_equals_torch_copy(lib, shape, dtype):
     assert torch.equal(out, col)
     with pytest.raises(lib.SfHipError):
         lib.copy_rows(a[:, 0], b[:, 0].float() if dtype != torch.float32 else b[:, 0].double())
+
+
+@pytest.mark.parametrize("vtrace,use_index", [(False, True), (False, False), (True, True)])
+def test_train_summaries_kernel_vs_torch(lib, vtrace, use_index):
+    """sf_train_summaries (learner.py:843-923 in one pass) against the torch expressions it replaces"""
+    rng = np.random.default_rng(33)
+    E, T, A, n = 64, 16, 6, 512
+    N = E * T
+    valids = dev(rng.random(N) > 0.2, torch.bool)
+    pid = dev(np.where(rng.random(N) < 0.15, 2, 0).astype(np.int32))
+    pver = dev(rng.integers(0, 9, N).astype(np.float32))
+    ratio = dev((rng.random(n) * 1.5 + 0.3).astype(np.float32))
+    heads = dev(rng.standard_normal((n, 8)).astype(np.float32))
+    values = heads[:, 0]
+    slab_values = dev(rng.standard_normal((E, T + 1)).astype(np.float32))
+    actions = dev(rng.integers(0, A, (N, 1)).astype(np.float32))
+    adv = dev(rng.standard_normal(n if vtrace else N).astype(np.float32))
+    logits = dev((rng.standard_normal((N, A)) * 3).astype(np.float32))
+    m2 = dev(rng.random(5000).astype(np.float32))
+    index = dev(rng.permutation(N)[:n].astype(np.int32)) if use_index else None
+    off = 0 if use_index else 256
+    out = torch.empty(24, dtype=torch.float64, device="cuda")
+    lib.train_summaries(valids, ratio, values, 8, slab_values, T, actions, 1, adv, vtrace, pid, pver, logits, A, index, off,
+                        n, 0, 11, 0.1, m2, out)
+    o = out.cpu().numpy()
+    rows = index.long() if use_index else torch.arange(off, off + n, device="cuda")
+    v, same = valids[rows], pid[rows] == 0
+    vr = ratio[v]
+    old_v = slab_values[:, :T].reshape(-1)[rows]
+    dv = (values - old_v).abs()
+    vd = (11.0 - pver[rows])[same]
+    ad = adv if vtrace else adv[rows]
+    want = [n, v.sum(), same.sum(), values.double().sum(), (1 - vr).abs().double().sum(),
+            ((vr < 1 / 1.1).sum() + (vr > 1.1).sum()), dv.double().sum(), vd.double().sum(), vr.min(), vr.max(), dv.max(),
+            actions[rows].min(), actions[rows].max(), ad.min(), ad.max(), logits[rows].abs().max(), vd.min(), vd.max(),
+            m2.max()]
+    np.testing.assert_allclose(o[:19], [float(x) for x in want], rtol=1e-6, atol=1e-6)
+    # no valid / no same-policy row: the minima / maxima stay at +-inf (the Learner substitutes the reference's defaults)
+    lib.train_summaries(torch.zeros_like(valids), ratio, values, 8, slab_values, T, actions, 1, adv, vtrace, pid + 5, pver,
+                        logits, A, index, off, n, 0, 11, 0.1, None, out)
+    o = out.cpu().numpy()
+    assert o[1] == 0 and o[2] == 0 and np.isposinf(o[8]) and np.isneginf(o[9]) and np.isposinf(o[16]) and np.isneginf(o[18])
