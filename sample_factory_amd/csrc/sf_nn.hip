@@ -1142,15 +1142,18 @@ static bool wgrad_glds_wanted(int64_t Mtot, int K, int N) {
     return Mtot >= 65536 || (Mtot >= 16384 && N >= 64 && (K >= 1024 || (int64_t)K * N >= 512 * 1024));
 }
 
-// LDS-image weight gradient (sf_nn_wimg.h): Nature-CNN conv3 geometry, launches that give every persistent work-group
-// at least a few samples.  SF_WGRAD_IMG=0: back on k_wgrad_glds (A/B switch).
-static bool wgrad_img_ok(const sf_conv_desc *d, int64_t n) {
-    static const int on = getenv("SF_WGRAD_IMG") ? atoi(getenv("SF_WGRAD_IMG")) : 1;
-    return on && !d->in_u8 && d->traj_T == 0 && d->Cin == 64 && d->Cout == 64 && d->H == 9 && d->W == 9 && d->KH == 3 &&
-           d->KW == 3 && d->stride == 1 && n >= 512;
+// LDS-image weight gradient (sf_nn_wimg.h): Nature-CNN conv3 (variant 1: 4 waves, two work-groups per CU) and conv2
+// (variant 2: 8 waves, one work-group per CU) geometries, launches that give every persistent work-group a few samples.
+// SF_WGRAD_IMG=0: back on k_wgrad_glds; =1: conv3 only; default 3: both (A/B switch).
+static int wgrad_img_variant(const sf_conv_desc *d, int64_t n) {
+    static const int on = getenv("SF_WGRAD_IMG") ? atoi(getenv("SF_WGRAD_IMG")) : 3;
+    if (!on || d->in_u8 || d->traj_T != 0 || d->Cout != 64 || n < 512) return 0;
+    if ((on & 1) && d->Cin == 64 && d->H == 9 && d->W == 9 && d->KH == 3 && d->KW == 3 && d->stride == 1) return 1;
+    if ((on & 2) && d->Cin == 32 && d->H == 20 && d->W == 20 && d->KH == 4 && d->KW == 4 && d->stride == 2) return 2;
+    return 0;
 }
-static int wgrad_img_blocks(int64_t n) {
-    const int64_t nb = 2 * (int64_t)num_cus();
+static int wgrad_img_blocks(const sf_conv_desc *d, int64_t n) {
+    const int64_t nb = (wgrad_img_variant(d, n) == 1 ? 2 : 1) * (int64_t)num_cus();
     return (int)(n < nb ? n : nb);
 }
 
@@ -1160,7 +1163,7 @@ extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
     const SplitPlan p = plan_splits(Mtot, K, N, 128, wgrad_bn(N));
     int Z = p.Z;
-    if (wgrad_img_ok(h_desc, n) && wgrad_img_blocks(n) > Z) Z = wgrad_img_blocks(n);  // one partial per work-group
+    if (wgrad_img_variant(h_desc, n) && wgrad_img_blocks(h_desc, n) > Z) Z = wgrad_img_blocks(h_desc, n);  // one partial per work-group
     if (!h_desc->in_u8) {  // the LDS-DMA kernel may pick other tiles (hence another split count)
         const WgradGlds q = plan_wgrad_glds(Mtot, K, N);
         if (q.Z > Z) Z = q.Z;
@@ -1249,13 +1252,18 @@ static int conv_wgrad_impl(const void *in, int64_t in_sample_stride, const int32
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
                 db ? partial_b : nullptr, (int)n, npairs);
     } else
-    if (mode == MODE_F32 && !index && wgrad_img_ok(h_desc, n)) {
-        // conv3: persistent LDS-image kernel, every operand byte fetched once, one partial per work-group
-        const int nb = wgrad_img_blocks(n);
+    if (mode == MODE_F32 && !index && wgrad_img_variant(h_desc, n)) {
+        // conv2 / conv3: persistent LDS-image kernel, every operand byte fetched once, one partial per work-group
+        const int nb = wgrad_img_blocks(h_desc, n);
         partial_b = partial_w + (int64_t)nb * K * N;
         Zused = nb;
-        k_wgrad_img<64, 9, 9, 3><<<dim3(nb), dim3(256), 0, st>>>(reinterpret_cast<const float *>(in), in_sample_stride,
-                                                                  dout, partial_w, db ? partial_b : nullptr, (int)n);
+        const float *inf = reinterpret_cast<const float *>(in);
+        if (wgrad_img_variant(h_desc, n) == 1)
+            k_wgrad_img<64, 9, 9, 3, 1, 1><<<dim3(nb), dim3(256), 0, st>>>(inf, in_sample_stride, dout, partial_w,
+                                                                            db ? partial_b : nullptr, (int)n);
+        else
+            k_wgrad_img<32, 20, 20, 4, 2, 2><<<dim3(nb), dim3(512), 0, st>>>(inf, in_sample_stride, dout, partial_w,
+                                                                              db ? partial_b : nullptr, (int)n);
     } else
     if (glds_on && mode == MODE_F32 && !index && g.traj_T == 0 && wgrad_glds_wanted(Mtot, K, N) &&
         n * max(in_sample_stride, (int64_t)g.H * g.W * g.Cin) < ((int64_t)1 << 30)) {  // 32-bit byte offsets in the kernel
@@ -1389,8 +1397,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         if (conv1_bf16_ok(g, MODE_U8, n)) snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_bf16<true>" : "k_conv1_wgrad_bf16<false>");
         else snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");
-    } else if (op == 1 && mode == MODE_F32 && wgrad_img_ok(h_desc, n)) {
-        snprintf(out, cap, "k_wgrad_img<64, 9, 9, 3>");
+    } else if (op == 1 && mode == MODE_F32 && wgrad_img_variant(h_desc, n)) {
+        snprintf(out, cap, wgrad_img_variant(h_desc, n) == 1 ? "k_wgrad_img<64, 9, 9, 3, 1, 1>" : "k_wgrad_img<32, 20, 20, 4, 2, 2>");
     } else if (op == 1 && mode == MODE_F32 && wgrad_glds_wanted(Mtot, g.K, g.Cout) && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
         snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"

@@ -112,8 +112,8 @@ def test_dispatch_is_the_benchmarks(lib, st):
     assert _name(lib, "fwd_t", N, L[1].desc) == "k_fwd_glds<128, 64, 2, 2, 2>"
     assert _name(lib, "fwd_t", N, L[2].desc).startswith("k_fwd_img<64, 9, 9, 3, 1")
     assert _name(lib, "fwd_t", N, L[3].desc) == "k_fwd_glds<128, 128, 2, 2, 2>"
-    assert _name(lib, "wgrad", N, L[1].desc) == "k_wgrad_glds<256, 64, 4, 1>"
-    assert _name(lib, "wgrad", N, L[2].desc) == "k_wgrad_img<64, 9, 9, 3>"
+    assert _name(lib, "wgrad", N, L[1].desc) == "k_wgrad_img<32, 20, 20, 4, 2, 2>"
+    assert _name(lib, "wgrad", N, L[2].desc) == "k_wgrad_img<64, 9, 9, 3, 1, 1>"
     assert _name(lib, "wgrad", N, L[3].desc) == "k_wgrad_glds<128, 128, 2, 2>"
     assert _name(lib, "dgrad", N, L[1].desc).startswith("k_dgrad_quadrow<128, 128")
     assert _name(lib, "dgrad", N, L[2].desc).startswith("k_dgrad_pix<128, 64")
