@@ -736,7 +736,6 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 #include "sf_nn_img.h"
 #include "sf_nn_u8.h"
 #include "sf_nn_wimg.h"
-#include "sf_nn_dimg.h"
 
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -1319,13 +1318,6 @@ static bool linear_dgrad_glds_ok(const ConvG &g, int64_t n) {
     return g.H == 1 && g.W == 1 && g.KH == 1 && g.KW == 1 && g.Cout % 32 == 0 && g.Cin >= 128 &&
            cdiv64(n, 128) * (int64_t)cdiv64(g.Cin, 128) >= 512;
 }
-// scatter-form LDS-image data gradient (sf_nn_dimg.h): Nature-CNN conv3 geometry; SF_DGRAD_IMG=0 keeps k_dgrad_pix
-static bool dgrad_img_ok(const sf_conv_desc *d, int64_t n, bool with_act) {
-    static const int on = getenv("SF_DGRAD_IMG") ? atoi(getenv("SF_DGRAD_IMG")) : 1;
-    return on && !d->in_u8 && d->Cin == 64 && d->Cout == 64 && d->H == 9 && d->W == 9 && d->KH == 3 && d->KW == 3 &&
-           d->stride == 1 && n >= 512 && (d->relu == 1 || d->relu == 0 || !with_act);
-}
-
 extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                              const sf_conv_desc *h_desc, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_dgrad");
@@ -1352,15 +1344,6 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
         const ConvG g2 = make_geom(&d2);
         k_fwd_glds<128, 128, 2, 2, 2><<<dim3(cdiv64(n, 128), cdiv64(g.Cin, 128), 1), dim3(256), 0, st>>>(
             g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1);
-        return sf_launch_status("sf_conv_dgrad");
-    }
-    // conv3: scatter-form LDS-image kernel (sf_nn_dimg.h); activation kinds: none, or ReLU with the activation given
-    if (dgrad_img_ok(h_desc, n, in_act != nullptr) && vec && ((uintptr_t)din & 15) == 0 &&
-        (!in_act || ((uintptr_t)in_act & 15) == 0)) {
-        const int64_t npairs = (n + 1) / 2, nbm = 2 * (int64_t)num_cus();
-        const unsigned nb = (unsigned)(npairs < nbm ? npairs : nbm);
-        if (in_act) k_dgrad_img<9, 9, 3, true><<<dim3(nb), dim3(256), 0, st>>>(dout, w, in_act, din, (int)n);
-        else k_dgrad_img<9, 9, 3, false><<<dim3(nb), dim3(256), 0, st>>>(dout, w, nullptr, din, (int)n);
         return sf_launch_status("sf_conv_dgrad");
     }
     // pixel-major LDS-DMA kernel: needs enough samples to fill BM-sample row tiles and Cout % 32 == 0
@@ -1428,8 +1411,6 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         const int64_t Mc = n * Hc * Wc;
         const char *v = g.vecB ? "true" : "false";
         if (g.vecB && linear_dgrad_glds_ok(g, n)) snprintf(out, cap, "k_fwd_glds<128, 128, 2, 2, 2>");
-        else if (g.vecB && dgrad_img_ok(h_desc, n, h_desc->relu != 0))
-            snprintf(out, cap, h_desc->relu ? "k_dgrad_img<9, 9, 3, true>" : "k_dgrad_img<9, 9, 3, false>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
             snprintf(out, cap, "k_dgrad_quadrow<128, 128, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024)

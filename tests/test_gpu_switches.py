@@ -1,4 +1,4 @@
-"""Every A/B switch of the network kernels (SF_CONV1_BF16, SF_CONV1_IMG, SF_DGRAD_PIX, SF_WGRAD_GLDS, SF_WGRAD_IMG, SF_DGRAD_IMG, SF_RELU_MASK, SF_GLDS_CFG,
+"""Every A/B switch of the network kernels (SF_CONV1_BF16, SF_CONV1_IMG, SF_DGRAD_PIX, SF_WGRAD_GLDS, SF_WGRAD_IMG, SF_RELU_MASK, SF_GLDS_CFG,
 SF_FWD_IMG, SF_GLDS_SPLITK — read once per process) selects a different kernel for the same operation; each must pass
 the same kernel-vs-torch tests as the default dispatch.  One pytest subprocess per group of independent (different
 operation) non-default settings; the two tests that assert which kernel / plan the DEFAULT dispatch picks are left out
@@ -15,11 +15,11 @@ SELECT = "(vs_torch or fuzz or in_place)"  # the kernel-level numerics tests of 
 
 GROUPS = [
     # the register-staged / im2col generation for every operation
-    ("SF_CONV1_BF16=0 SF_CONV1_IMG=0 SF_DGRAD_PIX=0 SF_DGRAD_IMG=0 SF_WGRAD_GLDS=0 SF_WGRAD_IMG=0 SF_FWD_IMG=0", " and not lds_image_forward_conv3"),
+    ("SF_CONV1_BF16=0 SF_CONV1_IMG=0 SF_DGRAD_PIX=0 SF_WGRAD_GLDS=0 SF_WGRAD_IMG=0 SF_FWD_IMG=0", " and not lds_image_forward_conv3"),
     # alternative tilings of the LDS-DMA kernels
     # ... and conv1 on the f32 strip-image kernels instead of the exact-product bf16 ones
-    ("SF_CONV1_BF16=0 SF_DGRAD_PIX=2 SF_DGRAD_IMG=0 SF_WGRAD_GLDS=2 SF_WGRAD_IMG=0 SF_GLDS_CFG=2", ""),
-    ("SF_DGRAD_PIX=3 SF_DGRAD_IMG=0 SF_WGRAD_GLDS=3 SF_WGRAD_IMG=1 SF_RELU_MASK=0 SF_GLDS_SPLITK=0", " and not splitk_small_grids and not relu_sign_bits"),
+    ("SF_CONV1_BF16=0 SF_DGRAD_PIX=2 SF_WGRAD_GLDS=2 SF_WGRAD_IMG=0 SF_GLDS_CFG=2", ""),
+    ("SF_DGRAD_PIX=3 SF_WGRAD_GLDS=3 SF_WGRAD_IMG=1 SF_RELU_MASK=0 SF_GLDS_SPLITK=0", " and not splitk_small_grids and not relu_sign_bits"),
 ]
 
 
