@@ -10,7 +10,7 @@ addressing through traj_T = 32 — with the kernels of the benchmark (names asse
      tails, 64-bit addressing), 512 random rows within fp32 round-off of rollout-size compact launches, 64 rows within
      1e-6 * max of torch float64 per layer (heads end-to-end: 3e-6);
  (b) weight / data gradients, n = 32768: against the sum / concatenation of eight n = 4096 launches on the same operands
-     (2e-5 * max) and against float64 (im2col + matmul on the GPU) for every layer;
+     (1e-5 * max; data gradients: bit-equal) and against float64 (im2col + matmul on the GPU) for every layer;
  (c) the dataset path: valids / advantages / returns / invalid count of `_prepare_batch` at (4096, 32) against the CPU
      oracle and against 64-env slices through the golden-pinned small path (bit-equal), loss scalars and loss-head
      gradients of the 32768-sample minibatch against the oracle;
@@ -287,11 +287,11 @@ def test_weight_gradients_vs_eight_launches_and_float64(lib, st):
                            terms_per_element=N * L.out_pixels)
     REPORT["wgrad_n32768_maxmax"] = rep
     # every element is an fp32 sum of n * OH * OW terms (conv1: 13.1 M, conv2: 2.65 M, conv3: 1.6 M, fc / heads: 32768)
-    # accumulated in blocked partials: 2e-5 * max against the eight-launch sum (a different blocking of the same sum) and
-    # against float64 (measured: conv1 6.9e-6, the others below 2e-6)
+    # accumulated in blocked partials: 1e-5 * max against the eight-launch sum (a different blocking of the same sum) and
+    # against float64 (measured: conv1 6.7e-6, conv2 4.3e-6, fc 3.4e-6, conv3 1.8e-6; profiles/r03_*_headline_parity.json)
     for name, r in rep.items():
-        assert r["vs_8x4096_w"] < 2e-5 and r["vs_8x4096_b"] < 2e-5, (name, r)
-        assert r["vs_float64_w"] < 2e-5 and r["vs_float64_b"] < 2e-5, (name, r)
+        assert r["vs_8x4096_w"] < 1e-5 and r["vs_8x4096_b"] < 1e-5, (name, r)
+        assert r["vs_float64_w"] < 1e-5 and r["vs_float64_b"] < 1e-5, (name, r)
 
 
 def test_data_gradients_vs_eight_launches_and_float64(lib, st):
