@@ -112,6 +112,8 @@ def secondary_lines(args):
                 ent["ingest"] = {k: d["ingest"].get(k) for k in ("h2d_bytes_per_env_step", "obs_dma_gbs", "sampler_thread",
                                                                   "dma_share_of_wall_clock")}
                 ent["env_side"] = "unpinned (synthetic host frames; envpool/ALE not installable)"
+            if wl == "c5":
+                ent["env_side"] = "unpinned (Ant-shaped synthetic env; envpool/mujoco not installable)"
             out.append(ent)
         except Exception as e:  # noqa: BLE001 - a secondary line must never take the headline line down
             out.append({"workload": wl, "error": repr(e)})

@@ -1623,3 +1623,44 @@ def test_conv1_relu_sign_bits_between_forward_and_weight_gradient(lib):
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2) and dw1.abs().max() > 0
     with pytest.raises(lib.SfHipError):   # a launch the mask kernels do not take
         lib.conv_fwd_relu_mask(slab, S, idx[:64].contiguous(), 0, w, b, out2, mask, 64, d)
+
+
+def test_conv1_exact_product_kernels_on_tiny_gradients(lib):
+    """Domain of the "every product exact" statement, MEASURED on the matrix pipe (it was asserted before): an f32 splits
+    exactly into three bf16 terms while all 24 bits sit above bf16's smallest normal, i.e. for |v| >= 2^-102
+    (tests/test_abi_and_host.py restricts its proof to |v| > 1e-30 for that reason).  Output gradients of 2^-95 (every term
+    normal): weight gradient exact to accumulation level.  Output gradients of 2^-118 .. 2^-114 (mid / lo terms are bf16
+    denormals or below the format): the result must degrade no further than to the hi term alone — relative error of the
+    sums <= 2^-7 — whatever the pipe does with denormal operands; the observed figure is written to
+    gpurun_out/conv1_tiny_gradients.json."""
+    import json
+    import os
+    n, Cin, H, W, Cout, K, S = 256, 4, 84, 84, 32, 8, 4
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(0, 256, (n, Cin, H, W), generator=g, dtype=torch.uint8)
+    d = desc(lib, Cin, H, W, Cout, K, S, in_u8=1, sub_mean=0.0, inv_scale=1.0, relu=0)
+    assert lib.conv_kernel_name(1, n, d).startswith("k_conv1_wgrad_bf16")
+    mant = 1.0 + torch.rand((n, Cout, 20, 20), generator=g)                      # full 24-bit mantissas in [1, 2)
+    sign = torch.where(torch.rand((n, Cout, 20, 20), generator=g) < 0.5, -1.0, 1.0)
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    rep = {}
+    for tag, e_lo, e_hi, tol in (("normal_terms_2^-95", -95, -95, 2e-6), ("denormal_terms_2^-118..-114", -118, -114, 2.0 ** -7)):
+        expo = torch.randint(e_lo, e_hi + 1, (n, Cout, 20, 20), generator=g).double()
+        dy64 = mant.double() * sign.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), expo)
+        dy = dy64.float()
+        assert torch.equal(dy.double(), dy64)                                    # representable: normal f32 values
+        dyd = dy.permute(0, 2, 3, 1).contiguous().cuda().view(n * 400, Cout)
+        dw, db = torch.zeros((Cin * K * K, Cout), device="cuda"), torch.zeros(Cout, device="cuda")
+        lib.conv_wgrad(x.cuda(), Cin * H * W, None, 0, dyd, dw, db, n, d, ws)
+        cols = F.unfold(x.double(), K, stride=S)                                 # [n, 256, 400]
+        ref = torch.einsum("nkp,npc->kc", cols, dy64.permute(0, 2, 3, 1).reshape(n, 400, Cout))
+        mag = torch.einsum("nkp,npc->kc", cols, dy64.abs().permute(0, 2, 3, 1).reshape(n, 400, Cout))
+        err = float(((dw.cpu().double() - ref).abs() / mag).max())              # relative to sum |x dy| of the element
+        rep[tag] = err
+        assert torch.isfinite(dw).all() and err <= tol, (tag, err)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        json.dump(rep, open(os.path.join(out, "conv1_tiny_gradients.json"), "w"), indent=1)
+    except OSError:
+        pass
