@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-SKIP = ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_dgrad_", "Cijk", "k_reduce_partials", "k_splitk_finish")
+SKIP = ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_wgrad_img", "k_dgrad_", "Cijk", "k_reduce_partials", "k_splitk_finish")
 
 
 def load(path, counter):

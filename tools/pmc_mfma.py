@@ -18,7 +18,7 @@ import json
 import sys
 
 XCDS, CUS, SIMDS = 8, 256, 4
-KEEP = ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_dgrad_", "k_lstm_seq", "k_gru_seq")
+KEEP = ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_wgrad_img", "k_dgrad_", "k_lstm_seq", "k_gru_seq")
 
 
 def main(src, dst):

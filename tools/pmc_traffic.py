@@ -58,7 +58,7 @@ def main():
         if r["Counter_Name"] == "WRITE_SIZE":
             w_all[r["Kernel_Name"]] += float(r["Counter_Value"])
     for name, nl in n_all.items():
-        if not any(t in name for t in ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_dgrad_")):
+        if not any(t in name for t in ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_wgrad_img", "k_dgrad_")):
             continue
         short = name.replace("void ", "").split("(")[0]
         out[short] = dict(fetch_kib_per_launch=round(f_all[name] / nl, 1), write_kib_per_launch=round(w_all[name] / nl, 1),
