@@ -682,6 +682,12 @@ def main():
         gen_train_c5()
     if "c5_gru" in which:
         gen_train_c5("gru")
+    if "rnn2" in which or "train" in which:  # two stacked recurrent layers (model/core.py:19-64 with rnn_num_layers = 2): state [B, 2, H(*2)]
+        rnn2 = ["--encoder_mlp_layers", "32", "--nonlinearity=relu", "--normalize_input=False", "--use_rnn=True",
+                "--rnn_size=32", "--rnn_num_layers=2", "--recurrence=8"]
+        gen_train("gru2", MLP_OBS, rnn2 + ["--rnn_type=gru"], E=16, T=8, A=6, nb=2, epochs=1, use_rnn=True)
+        gen_train("lstm2", MLP_OBS, rnn2 + ["--rnn_type=lstm", "--kl_loss_coeff=0.1"], E=16, T=16, A=6, nb=2, epochs=2,
+                  use_rnn=True, extra=["--recurrence=8"])
     if "train" in which:
         gen_train("mlp", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2)
         gen_train("mlp_inv", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=4, epochs=1, extra=["--kl_loss_coeff=0.1"])

@@ -195,24 +195,28 @@ class _TorchMultiInputEncoder(nn.Module):
 
 
 class _TorchRnnCore(nn.Module):
-    """model/core.py:19-64 (ModelCoreRNN), one layer: x [n, F], rnn_states [n, S] -> (out [n, H], new_states [n, S]);
-    LSTM state = [h | c].  Parameter names core.core.weight_ih_l0 ... as in the reference."""
+    """model/core.py:19-64 (ModelCoreRNN) with cfg.rnn_num_layers stacked layers: x [n, F], rnn_states [n, S] ->
+    (out [n, H], new_states [n, S]).  State layout as the reference keeps it in the trajectory buffer: per sample
+    [layer 0 | layer 1 | ...], a layer's block being h (GRU) or [h | c] (LSTM).  Parameter names
+    core.core.weight_ih_l<k> ... are torch's own, i.e. the reference's."""
 
     def __init__(self, cfg, input_size):
         super().__init__()
-        if cfg.rnn_num_layers != 1 or cfg.rnn_type not in ("gru", "lstm"):
-            raise NotImplementedError("recurrent core: one-layer GRU or LSTM only")
-        self.is_gru, self.H = cfg.rnn_type == "gru", int(cfg.rnn_size)
-        self.core = (nn.GRU if self.is_gru else nn.LSTM)(input_size, self.H, 1)
+        if cfg.rnn_type not in ("gru", "lstm"):
+            raise RuntimeError(f"Unknown RNN type {cfg.rnn_type}")
+        self.is_gru, self.H, self.L = cfg.rnn_type == "gru", int(cfg.rnn_size), int(cfg.rnn_num_layers)
+        self.core = (nn.GRU if self.is_gru else nn.LSTM)(input_size, self.H, self.L)
 
     def forward(self, x, rnn_states):
-        x = x.unsqueeze(0)
+        n = x.shape[0]
+        per_layer = rnn_states.reshape(n, self.L, -1).transpose(0, 1)          # [L, n, H] or [L, n, 2H]
         if self.is_gru:
-            out, h = self.core(x, rnn_states.unsqueeze(0).contiguous())
-            return out.squeeze(0), h.squeeze(0)
-        h, c = torch.split(rnn_states.unsqueeze(0), self.H, dim=2)
-        out, (h, c) = self.core(x, (h.contiguous(), c.contiguous()))
-        return out.squeeze(0), torch.cat((h, c), dim=2).squeeze(0)
+            out, new = self.core(x.unsqueeze(0), per_layer.contiguous())
+        else:
+            h, c = per_layer[..., :self.H], per_layer[..., self.H:]
+            out, (h, c) = self.core(x.unsqueeze(0), (h.contiguous(), c.contiguous()))
+            new = torch.cat((h, c), dim=2)
+        return out.squeeze(0), new.transpose(0, 1).reshape(n, -1)
 
     def get_out_size(self) -> int:
         return self.H

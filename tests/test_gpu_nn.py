@@ -708,11 +708,13 @@ def test_learner_train_matches_reference_rnn(lib, golden, tmp_path, name):
     from sample_factory_amd.model.actor_critic import get_rnn_size
     g = golden("train_" + name)
     E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
-    rnn_type = "gru" if name == "gru" else "lstm"
-    cfg = default_cfg(use_rnn=True, rnn_type=rnn_type, rnn_size=32, recurrence=8, nonlinearity="relu", normalize_input=False,
-                      encoder_mlp_layers=[32], rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb,
-                      num_epochs=int(g["num_epochs"]), kl_loss_coeff=0.1 if name == "lstm_inv" else 0.0, seed=0,
-                      serial_mode=True, train_dir=str(tmp_path), experiment="t", record_grad_norm=True)
+    rnn_type = "gru" if name.startswith("gru") else "lstm"
+    layers = 2 if name.endswith("2") else 1
+    cfg = default_cfg(use_rnn=True, rnn_type=rnn_type, rnn_size=32, rnn_num_layers=layers, recurrence=8, nonlinearity="relu",
+                      normalize_input=False, encoder_mlp_layers=[32], rollout=T, batch_size=E * T // nb,
+                      num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]),
+                      kl_loss_coeff=0.1 if rnn_type == "lstm" else 0.0, seed=0, serial_mode=True, train_dir=str(tmp_path),
+                      experiment="t", record_grad_norm=True)
     obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
     env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
     pv = torch.zeros(1, dtype=torch.int32)
@@ -1461,12 +1463,13 @@ def test_multi_input_model_forward_matches_reference(lib, golden):
     np.testing.assert_allclose(res["values"].cpu().numpy(), g["values"], atol=2e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["gru", "lstm_inv"])
+@pytest.mark.parametrize("name", ["gru", "lstm_inv", "gru2", "lstm2"])
 def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden, tmp_path, name):
     """The recurrent goldens once more, through the TORCH model path (a registered encoder, here the default
     architecture itself; also what observation dicts with several keys use): default one-layer GRU / LSTM core with
     the reference's parameter names, BPTT as a masked time loop under autograd, everything around the network native —
-    against the reference's Learner.train (PackedSequence BPTT)."""
+    against the reference's Learner.train (PackedSequence BPTT).  gru2 / lstm2: TWO stacked recurrent layers
+    (cfg.rnn_num_layers = 2, model/core.py:19-64) — create_actor_critic routes them to this path by itself."""
     from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
     from sample_factory_amd.algo.utils.env_info import EnvInfo
     from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
@@ -1477,15 +1480,18 @@ def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden
     from sample_factory_amd.model.torch_policy import TorchPolicyAdapter, _TorchMultiInputEncoder
     g = golden("train_" + name)
     E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
-    rnn_type = "gru" if name == "gru" else "lstm"
-    cfg = default_cfg(use_rnn=True, rnn_type=rnn_type, rnn_size=32, recurrence=8, nonlinearity="relu", normalize_input=False,
-                      encoder_mlp_layers=[32], rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb,
-                      num_epochs=int(g["num_epochs"]), kl_loss_coeff=0.1 if name == "lstm_inv" else 0.0, seed=0,
-                      serial_mode=True, train_dir=str(tmp_path), experiment="t", record_grad_norm=True)
+    rnn_type = "gru" if name.startswith("gru") else "lstm"
+    layers = 2 if name.endswith("2") else 1
+    cfg = default_cfg(use_rnn=True, rnn_type=rnn_type, rnn_size=32, rnn_num_layers=layers, recurrence=8, nonlinearity="relu",
+                      normalize_input=False, encoder_mlp_layers=[32], rollout=T, batch_size=E * T // nb,
+                      num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]),
+                      kl_loss_coeff=0.1 if rnn_type == "lstm" else 0.0, seed=0, serial_mode=True, train_dir=str(tmp_path),
+                      experiment="t", record_grad_norm=True)
     obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
     env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
     pv = torch.zeros(1, dtype=torch.int32)
-    global_model_factory().register_encoder_factory(lambda c, o: _TorchMultiInputEncoder(c, o))
+    if layers == 1:  # (stacked layers take the torch path without anything registered)
+        global_model_factory().register_encoder_factory(lambda c, o: _TorchMultiInputEncoder(c, o))
     try:
         learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
         learner.init()
@@ -1493,6 +1499,7 @@ def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden
         global_model_factory().reset()
     ac = learner.actor_critic
     assert isinstance(ac, TorchPolicyAdapter) and ac.rnn_kind == (0 if rnn_type == "gru" else 1)
+    assert get_rnn_size(cfg) == 32 * layers * (2 if rnn_type == "lstm" else 1) == int(g["in_rnn_states"].shape[-1])
     assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
     load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
     batch = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cuda")
