@@ -291,10 +291,11 @@ def obs_keys_of(obs_space) -> List[str]:
 
 
 def build_torch_actor_critic(cfg, obs_space, action_space, factory) -> nn.Module:
-    """the default actor-critic in torch around whatever the user registered; with nothing registered (observation
-    dicts of several keys land here) the reference's MultiInputEncoder"""
+    """the default actor-critic in torch around whatever the user registered; with no encoder registered (observation
+    dicts of several keys and stacked recurrent layers land here) the reference's MultiInputEncoder (model/encoder.py:33-69:
+    it is the default encoder for one key as well)"""
     enc = None
-    if factory.make_model_encoder_func is None and len(obs_keys_of(obs_space)) > 1:
+    if factory.make_model_encoder_func is None:
         enc = _TorchMultiInputEncoder(cfg, obs_space)
     return _DefaultTorchTail(cfg, obs_space, action_space, factory, encoder=enc)
 
