@@ -35,6 +35,12 @@ constexpr int SEQ_SYNC_STRIDE = 16;       // one counter per 64-byte line
 constexpr int SEQ_ABORT_SLOT = 8 * SEQ_SYNC_STRIDE;
 constexpr uint32_t SEQ_SPIN_LIMIT = 1u << 22;
 constexpr int SEQ_MAX_SUB = 4;             // 64-row sub-tiles per work-group (register-resident state): Cn <= ngroups * 256
+#ifndef SF_SEQ_NBUF
+#define SF_SEQ_NBUF 2
+#endif
+#ifndef SF_SEQ_LOAD_AUX
+#define SF_SEQ_LOAD_AUX 16  // cache policy of the hand-off payload loads: 16 = sc1 (served by L2), 0 = through the CU's L1
+#endif
 constexpr uint32_t OOB = 0x7FFFFFF0u;     // byte offset past every buffer: loads return 0, stores are dropped
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -62,6 +68,7 @@ __device__ __forceinline__ bool seq_wait(unsigned *counter, unsigned target, uns
         *lds_flag = ok ? 1.0f : 0.0f;
     }
     __syncthreads();
+    if (SF_SEQ_LOAD_AUX == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop the CU's L1 copies of older payload lines
     const bool ok = *lds_flag != 0.0f;
     __syncthreads();  // the flag word may be rewritten by the next wait
     return ok;
@@ -81,6 +88,7 @@ template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
     constexpr int G4 = 4 * H, NC = 4 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
     constexpr int KU = 8, NKB = H / 16 / KU;
+    constexpr int NBUF = NKB < SF_SEQ_NBUF ? NKB : SF_SEQ_NBUF;  // k-blocks of 8 x 16-byte loads per lane in flight (+ the one in the matrix pipe)
     constexpr int STG = 16 * JB;  // floats of one wave's staging tile
     static_assert(NKB * KU * 16 == H && NU >= 1, "shape");
     __shared__ __attribute__((aligned(16))) float lds[NC * LDW + 4 * STG + 4];
@@ -155,23 +163,24 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
             for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int arow = row0 + c;
             const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * H + 4 * g) * 4) : OOB;
-            i32x4 abuf[2][KU];
+            i32x4 abuf[NBUF][KU];
             auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku)
-                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, SF_SEQ_LOAD_AUX);
             };
             // every work-group of the row group reads the SAME h rows: each starts its reduction at a different k-block
             // so that at any moment they pull different lines (different L2 channels) instead of all the same one
             auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
-            load_block(kbe(0), abuf[0]);
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b) load_block(kbe(b), abuf[b]);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                if (kb + 1 < NKB) load_block(kbe(kb + 1), abuf[(kb + 1) & 1]);
+                if (kb + NBUF - 1 < NKB) load_block(kbe(kb + NBUF - 1), abuf[(kb + NBUF - 1) % NBUF]);
                 const float *bpk = wt + c * LDW + kbe(kb) * (KU * 16) + 4 * g;
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku) {
-                    const f32x4 a4 = __builtin_bit_cast(f32x4, abuf[kb & 1][ku]);
+                    const f32x4 a4 = __builtin_bit_cast(f32x4, abuf[kb % NBUF][ku]);
                     const float *bp = bpk + ku * 16;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -251,9 +260,10 @@ struct LstmSeqBwd {
 template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
     constexpr int G4 = 4 * H, NC = 4 * JB, NU = JB / 16, LDK = G4 + 4;
-    constexpr int KU = 8, NKB = G4 / 16 / KU;  // 2 x 8 loads of 16 B in flight per lane (16 measured the same)
+    constexpr int KU = 8, NKB = G4 / 16 / KU;
+    constexpr int NBUF = SF_SEQ_NBUF;  // k-blocks of 8 x 16-byte loads per lane: NBUF - 1 in flight behind the one in the matrix pipe
     constexpr int STG = 16 * NC;
-    static_assert(NKB * KU * 16 == G4 && NKB % 2 == 0, "shape");
+    static_assert(NKB * KU * 16 == G4 && NKB >= NBUF - 1, "shape");
     __shared__ __attribute__((aligned(16))) float lds[JB * LDK + 4 * STG + 4];
     float *wk = lds, *flag = lds + JB * LDK + 4 * STG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
@@ -362,11 +372,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
             for (int u = 0; u < NU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int arow = row0 + c;
             const uint32_t abase = (arow < g_rows_end && !(p.ablate & 2)) ? (uint32_t)((((int64_t)t * Cn + arow) * G4 + 4 * g) * 4) : OOB;
-            i32x4 abuf[2][KU];
+            i32x4 abuf[NBUF][KU];
             auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku)
-                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, SF_SEQ_LOAD_AUX);
             };
             auto mma_block = [&](int kb, const i32x4 (&src)[KU]) {
                 if (p.ablate & 4) return;
@@ -384,12 +394,15 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
                 }
             };
             auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
-            load_block(kbe(0), abuf[0]);
-            for (int kb = 0; kb < NKB; kb += 2) {
-                load_block(kbe(kb + 1), abuf[1]);
-                mma_block(kbe(kb), abuf[0]);
-                if (kb + 2 < NKB) load_block(kbe(kb + 2), abuf[0]);
-                mma_block(kbe(kb + 1), abuf[1]);
+            // block n lives in slot n % NBUF; NBUF - 1 blocks are in flight behind the one in the matrix pipe
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b) load_block(kbe(b), abuf[b]);
+            for (int kb = 0; kb < NKB; kb += NBUF) {
+#pragma unroll
+                for (int b = 0; b < NBUF; ++b) {
+                    if (kb + b + NBUF - 1 < NKB) load_block(kbe(kb + b + NBUF - 1), abuf[(b + NBUF - 1) % NBUF]);
+                    if (kb + b < NKB) mma_block(kbe(kb + b), abuf[b]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -421,6 +434,7 @@ template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
     constexpr int G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
     constexpr int KU = 8, NKB = H / 16 / KU;
+    constexpr int NBUF = NKB < SF_SEQ_NBUF ? NKB : SF_SEQ_NBUF;  // k-blocks of 8 x 16-byte loads per lane in flight (+ the one in the matrix pipe)
     constexpr int STG = 16 * JB;
     static_assert(NKB * KU * 16 == H && NU >= 1, "shape");
     __shared__ __attribute__((aligned(16))) float lds[NC * LDW + 4 * STG + 4];
@@ -487,21 +501,22 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
             for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int arow = row0 + c;
             const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * H + 4 * g) * 4) : OOB;
-            i32x4 abuf[2][KU];
+            i32x4 abuf[NBUF][KU];
             auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku)
-                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, SF_SEQ_LOAD_AUX);
             };
             auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
-            load_block(kbe(0), abuf[0]);
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b) load_block(kbe(b), abuf[b]);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                if (kb + 1 < NKB) load_block(kbe(kb + 1), abuf[(kb + 1) & 1]);
+                if (kb + NBUF - 1 < NKB) load_block(kbe(kb + NBUF - 1), abuf[(kb + NBUF - 1) % NBUF]);
                 const float *bpk = wt + c * LDW + kbe(kb) * (KU * 16) + 4 * g;
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku) {
-                    const f32x4 a4 = __builtin_bit_cast(f32x4, abuf[kb & 1][ku]);
+                    const f32x4 a4 = __builtin_bit_cast(f32x4, abuf[kb % NBUF][ku]);
                     const float *bp = bpk + ku * 16;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -574,8 +589,9 @@ template <int H, int JB, int NSUB>
 __global__ __launch_bounds__(256, 1) void k_gru_seq_bwd(GruSeqBwd p) {
     constexpr int G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NU = JB / 16, LDK = G3 + 4;
     constexpr int KU = 8, NKB = G3 / 16 / KU;
+    constexpr int NBUF = SF_SEQ_NBUF;
     constexpr int STG = 16 * NC;
-    static_assert(NKB * KU * 16 == G3 && NKB % 2 == 0, "shape");
+    static_assert(NKB * KU * 16 == G3 && NKB >= NBUF - 1, "shape");
     __shared__ __attribute__((aligned(16))) float lds[JB * LDK + 4 * STG + 4];
     float *wk = lds, *flag = lds + JB * LDK + 4 * STG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
@@ -684,11 +700,11 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_bwd(GruSeqBwd p) {
             for (int u = 0; u < NU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int arow = row0 + c;
             const uint32_t abase = arow < g_rows_end ? (uint32_t)((((int64_t)t * Cn + arow) * G3 + 4 * g) * 4) : OOB;
-            i32x4 abuf[2][KU];
+            i32x4 abuf[NBUF][KU];
             auto load_block = [&](int kb, i32x4 (&dst)[KU]) {
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku)
-                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, 16);
+                    dst[ku] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, abase + (uint32_t)((kb * KU + ku) * 64), 0, SF_SEQ_LOAD_AUX);
             };
             auto mma_block = [&](int kb, const i32x4 (&src)[KU]) {
 #pragma unroll
@@ -705,12 +721,15 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_bwd(GruSeqBwd p) {
                 }
             };
             auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
-            load_block(kbe(0), abuf[0]);
-            for (int kb = 0; kb < NKB; kb += 2) {
-                load_block(kbe(kb + 1), abuf[1]);
-                mma_block(kbe(kb), abuf[0]);
-                if (kb + 2 < NKB) load_block(kbe(kb + 2), abuf[0]);
-                mma_block(kbe(kb + 1), abuf[1]);
+            // block n lives in slot n % NBUF; NBUF - 1 blocks are in flight behind the one in the matrix pipe
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b) load_block(kbe(b), abuf[b]);
+            for (int kb = 0; kb < NKB; kb += NBUF) {
+#pragma unroll
+                for (int b = 0; b < NBUF; ++b) {
+                    if (kb + b + NBUF - 1 < NKB) load_block(kbe(kb + b + NBUF - 1), abuf[(b + NBUF - 1) % NBUF]);
+                    if (kb + b < NKB) mma_block(kbe(kb + b), abuf[b]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -739,7 +758,21 @@ int seq_plan(int Cn, int H, int *ngroups, int *rows_per_group, int *jb) {
     return *rows_per_group <= 64 * SEQ_MAX_SUB;
 }
 
+#include "sf_rnn_regw.h"
+
 }  // namespace
+
+// backward passes with the weights in registers (sf_rnn_regw.h): one instantiation per (width, row tiles per group)
+#define SEQ_DISPATCH_R(KERN)                                                         \
+    do {                                                                             \
+        if (H == 512) {                                                              \
+            if (rpg == 32) KERN<512, 2><<<grid, block, 0, STREAM(stream)>>>(p);      \
+            else KERN<512, 4><<<grid, block, 0, STREAM(stream)>>>(p);                \
+        } else {                                                                     \
+            if (rpg == 32) KERN<256, 2><<<grid, block, 0, STREAM(stream)>>>(p);      \
+            else KERN<256, 4><<<grid, block, 0, STREAM(stream)>>>(p);                \
+        }                                                                            \
+    } while (0)
 
 // one instantiation per (width, sub-tiles per work-group)
 #define SEQ_DISPATCH(KERN)                                                              \
@@ -790,6 +823,15 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_bwd memset");
     if (rc) return rc;
     static const int ablate = getenv("SF_LSTM_ABLATE") ? atoi(getenv("SF_LSTM_ABLATE")) : 0;
+    int ngr, rpgr;
+    if (seq_plan_r(Cn, H, &ngr, &rpgr)) {  // 32 hidden units per work-group, W_hh slice in registers
+        const int rpg = rpgr;
+        LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ngr, rpg,
+                     env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H, ablate};
+        const dim3 grid((unsigned)(ngr * (H / 32))), block(256);
+        SEQ_DISPATCH_R(k_lstm_seq_bwd_r);
+        return sf_launch_status("sf_lstm_seq_bwd");
+    }
     LstmSeqBwd p{dout, gates, cprev, cout, keep, whh, dgx, sync, R, Cn, ng, rpg,
                  env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H, ablate};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
@@ -824,6 +866,15 @@ extern "C" int sf_gru_seq_bwd(const float *dout, const float *gates, const float
     SF_REQUIRE((int64_t)R * Cn * 3 * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_bwd: gate-gradient buffer exceeds 2 GiB");
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_bwd memset");
     if (rc) return rc;
+    int ngr, rpgr;
+    if (seq_plan_r(Cn, H, &ngr, &rpgr)) {
+        const int rpg = rpgr;
+        GruSeqBwd p{dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, ngr, rpg,
+                    env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
+        const dim3 grid((unsigned)(ngr * (H / 32))), block(256);
+        SEQ_DISPATCH_R(k_gru_seq_bwd_r);
+        return sf_launch_status("sf_gru_seq_bwd");
+    }
     GruSeqBwd p{dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, ng, rpg,
                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);

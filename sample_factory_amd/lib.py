@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsf_hip.so")
+# SF_HIP_LIB: load another build of the same sources (kernel experiments: tools/build_variant.sh)
+LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libsf_hip.so")
 
 
 class SfHipError(RuntimeError):
@@ -305,10 +306,21 @@ def _seq_key(op, R, Cn, H, steps, G=4):
     recurrent products (forward: R steps; backward: R-1, the first step has no state in front of it)"""
     if PROFILE is None:
         return None
-    ng = min(8, (Cn + 15) // 16)
-    rpg = ((Cn + ng - 1) // ng + 15) // 16 * 16
-    nsub = {1: 1, 2: 2}.get((rpg + 63) // 64, 4)
-    return (op, int(steps * Cn), int(H), 1, 1, int(G * H), 1, 1, 1, 1, f"k_{op.split('_')[0]}_seq_{op.split('_')[1]}<{int(H)}, 16, {nsub}>")
+    kind, direction = op.split("_")
+    name = None
+    if direction == "bwd" and int(os.environ.get("SF_SEQ_BWD_REGW", "1")) and H in (256, 512):
+        # csrc/sf_rnn_regw.h seq_plan_r: 32 hidden units per work-group, row groups of 32 / 64 rows
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        ng = max(1, min(cus // (H // 32), 16, (Cn + 31) // 32))
+        rpg = ((Cn + ng - 1) // ng + 31) // 32 * 32
+        if rpg <= 64:
+            name = f"k_{kind}_seq_bwd_r<{int(H)}, {rpg // 16}>"
+    if name is None:
+        ng = min(8, (Cn + 15) // 16)
+        rpg = ((Cn + ng - 1) // ng + 15) // 16 * 16
+        nsub = {1: 1, 2: 2}.get((rpg + 63) // 64, 4)
+        name = f"k_{kind}_seq_{direction}<{int(H)}, 16, {nsub}>"
+    return (op, int(steps * Cn), int(H), 1, 1, int(G * H), 1, 1, 1, 1, name)
 
 
 def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H, env_major=False) -> None:
