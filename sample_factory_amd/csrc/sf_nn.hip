@@ -736,6 +736,7 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
 #include "sf_nn_img.h"
 #include "sf_nn_u8.h"
 #include "sf_nn_wimg.h"
+#include "sf_nn_narrow.h"
 
 // ============================================================================================== host launchers
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -1006,7 +1007,14 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     }
     return p;
 }
+// narrow linear layers (the heads): one wave per 16 rows, operands straight from memory (sf_nn_narrow.h)
+static bool narrow_fwd_ok(const sf_conv_desc *d, int64_t n) {
+    static const int on = getenv("SF_LINEAR_NARROW") ? atoi(getenv("SF_LINEAR_NARROW")) : 1;
+    return on && !d->in_u8 && d->traj_T == 0 && d->KH == 1 && d->KW == 1 && d->H == 1 && d->W == 1 && d->Cout <= 32 &&
+           d->Cin % 16 == 0 && n < (1 << 30);
+}
 extern "C" int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *h_desc) {
+    if (h_desc && n > 0 && narrow_fwd_ok(h_desc, n)) return 1;
     if (!h_desc || n <= 0 || !glds_fwd_ok(h_desc)) return 0;
     // small grids keep the split-K register-staged kernel (a 128-row tile grid must fill 256 CUs a few times over)
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
@@ -1014,7 +1022,7 @@ extern "C" int sf_conv_fwd_t_supported(int64_t n, const sf_conv_desc *h_desc) {
     return plan_fwd_t(Mtot, h_desc->Cout, h_desc->KH * h_desc->KW * h_desc->Cin).ok ? 1 : 0;
 }
 extern "C" int64_t sf_conv_fwd_t_workspace(int64_t n, const sf_conv_desc *h_desc) {
-    if (!h_desc || n <= 0 || !glds_fwd_ok(h_desc)) return 0;
+    if (!h_desc || n <= 0 || narrow_fwd_ok(h_desc, n) || !glds_fwd_ok(h_desc)) return 0;
     const int64_t Mtot = n * h_desc->OH * h_desc->OW;
     if (img_fwd_index(make_geom(h_desc), n) >= 0) return 0;
     const GldsFwdPlan p = plan_fwd_t(Mtot, h_desc->Cout, h_desc->KH * h_desc->KW * h_desc->Cin);
@@ -1029,9 +1037,19 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     int rc = check_desc(h_desc, "sf_conv_fwd_t");
     if (rc) return rc;
     SF_REQUIRE(in && wt && out && n > 0, "sf_conv_fwd_t: bad args");
-    SF_REQUIRE(glds_fwd_ok(h_desc), "sf_conv_fwd_t: needs f32 NHWC input with Cin %% 32 == 0 (use sf_conv_fwd)");
     SF_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)wt & 15) == 0 && in_sample_stride % 4 == 0,
                "sf_conv_fwd_t: operands must be 16-byte aligned");
+    if (narrow_fwd_ok(h_desc, n)) {
+        const dim3 grid((unsigned)cdiv64(n, 16)), block(64);
+        if (h_desc->Cout <= 16)
+            k_linear_narrow<1><<<grid, block, 0, STREAM(stream)>>>(in, in_sample_stride, wt, bias, out, (int)n, h_desc->Cout,
+                                                                    h_desc->Cin, h_desc->relu);
+        else
+            k_linear_narrow<2><<<grid, block, 0, STREAM(stream)>>>(in, in_sample_stride, wt, bias, out, (int)n, h_desc->Cout,
+                                                                    h_desc->Cin, h_desc->relu);
+        return sf_launch_status("sf_conv_fwd_t");
+    }
+    SF_REQUIRE(glds_fwd_ok(h_desc), "sf_conv_fwd_t: needs f32 NHWC input with Cin %% 32 == 0 (use sf_conv_fwd)");
     const ConvG g = make_geom(h_desc);
     const int64_t Mtot = n * g.OH * g.OW;
     SF_REQUIRE(Mtot < (1LL << 31), "sf_conv_fwd_t: M=%lld exceeds 2^31 rows; split the batch", (long long)Mtot);
@@ -1392,7 +1410,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         if (p.cfg == 0) snprintf(out, cap, "k_conv_fwd<%d, 32, 4, 1, %d>", big32 ? 256 : 128, mode);
         else snprintf(out, cap, "k_conv_fwd<%d, 64, 2, 2, %d>", p.cfg == 1 ? 128 : 64, mode);
     } else if (op == 3) {
-        if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1, %d>", g.Cin, g.H, g.W, g.KH, g.S, g.OH);
+        if (narrow_fwd_ok(h_desc, n)) snprintf(out, cap, "k_linear_narrow<%d>", g.Cout <= 16 ? 1 : 2);
+        else if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1, %d>", g.Cin, g.H, g.W, g.KH, g.S, g.OH);
         else snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         if (conv1_bf16_ok(g, MODE_U8, n)) snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_bf16<true>" : "k_conv1_wgrad_bf16<false>");

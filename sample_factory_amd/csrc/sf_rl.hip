@@ -1867,8 +1867,8 @@ extern "C" int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const
 // =========================================================================================== fused small MLP encoder
 // Inference on VECTOR observations (model/encoder.py:72-87 MlpEncoder behind utils/normalize.py:24-70): input
 // normalisation -> Linear(D, H1) + act -> Linear(H1, H2) + act in ONE launch.  At rollout sizes (2048 envs x 27 floats)
-// each of these layers is a 13 us MFMA-kernel launch doing 7 MFLOP; here a 256-thread block takes 64 samples, keeps both
-// weight matrices in LDS and each thread produces 8 columns of two rows with fmaf chains in ascending k — the same
+// each of these layers is a 13 us MFMA-kernel launch doing 7 MFLOP; here a 256-thread block takes 16 samples, keeps both
+// weight matrices in LDS and each thread produces 4 columns of one row with fmaf chains in ascending k — the same
 // arithmetic (bit for bit) as the exact-f32 MFMA kernels, which the training pass keeps using (it needs the
 // intermediate activations).
 __device__ __forceinline__ float mlp_act(float x, int kind) {
@@ -1878,7 +1878,7 @@ __device__ __forceinline__ float mlp_act(float x, int kind) {
     return x;
 }
 
-constexpr int MLP2_ROWS = 64;  // samples per block; a thread owns 2 rows x 8 columns (weights read once per 16 fmaf)
+constexpr int MLP2_ROWS = 16;  // samples per block (2048 envs: 128 blocks); a thread owns 1 row x 4 columns
 
 __global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, int64_t x_stride, int64_t n, int D,
                                                   float sub_mean, float inv_scale, const float *__restrict__ mu,
@@ -1891,7 +1891,7 @@ __global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, i
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * MLP2_ROWS;
     // every global load of the prologue is issued before the first LDS store (a load -> store loop waits for each load
-    // in turn: 30 serialised round trips were 14 of this kernel's 18 us)
+    // in turn: 30 serialised round trips were 14 of the first version's 18 us)
     {
         constexpr int NV = 8;  // float4s per thread and matrix: up to 8192 weights each (checked by the launcher)
         float4 v1[NV], v2[NV];
@@ -1902,7 +1902,7 @@ __global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, i
             v1[i] = reinterpret_cast<const float4 *>(w1)[q1 < n1 ? q1 : 0];
             v2[i] = reinterpret_cast<const float4 *>(w2)[q2 < n2 ? q2 : 0];
         }
-        constexpr int NX = 16;  // observation words per thread: up to 64 rows x 64 values
+        constexpr int NX = 4;  // observation words per thread: up to 16 rows x 64 values
         float xv[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -1927,28 +1927,27 @@ __global__ __launch_bounds__(256) void k_mlp2_fwd(const float *__restrict__ x, i
         }
     }
     __syncthreads();
-    const int ra = (tid >> 3) * 2, rb = ra + 1, cg = tid & 7;
+    const int ra = tid >> 4, cg = tid & 15;
     auto layer = [&](const float *in, int K, const float *w, const float *bias, int N, float *dst, int64_t dst_ld,
                      bool to_global) {
-        for (int c0 = cg * 8; c0 < N; c0 += 64) {  // 8 consecutive columns per pass
-            float accA[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, accB[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int k = 0; k < K; ++k) {  // (unrolled: the LDS reads of 4 k-steps are in flight together)
-                const float a = in[ra * K + k], b = in[rb * K + k];
-                const float4 w0 = *reinterpret_cast<const float4 *>(w + k * N + c0);
-                const float4 w1v = *reinterpret_cast<const float4 *>(w + k * N + c0 + 4);
-                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1v.x, w1v.y, w1v.z, w1v.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    accA[j] = fmaf(a, wv[j], accA[j]);
-                    accB[j] = fmaf(b, wv[j], accB[j]);
-                }
+        for (int c0 = cg * 4; c0 < N; c0 += 64) {  // 4 consecutive columns per pass
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int k = 0; k < K; ++k) {  // ascending k, one fmaf chain per output element (= the MFMA kernels' sums)
+                const float a = in[ra * K + k];
+                const float4 wv = *reinterpret_cast<const float4 *>(w + k * N + c0);
+                acc[0] = fmaf(a, wv.x, acc[0]);
+                acc[1] = fmaf(a, wv.y, acc[1]);
+                acc[2] = fmaf(a, wv.z, acc[2]);
+                acc[3] = fmaf(a, wv.w, acc[3]);
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float bj = bias[c0 + j];
-                if (!to_global || r0 + ra < n) dst[(to_global ? r0 + ra : ra) * dst_ld + c0 + j] = mlp_act(accA[j] + bj, act);
-                if (!to_global || r0 + rb < n) dst[(to_global ? r0 + rb : rb) * dst_ld + c0 + j] = mlp_act(accB[j] + bj, act);
+            if (!to_global || r0 + ra < n) {
+                float4 o;
+                o.x = mlp_act(acc[0] + bias[c0], act);
+                o.y = mlp_act(acc[1] + bias[c0 + 1], act);
+                o.z = mlp_act(acc[2] + bias[c0 + 2], act);
+                o.w = mlp_act(acc[3] + bias[c0 + 3], act);
+                *reinterpret_cast<float4 *>(dst + (to_global ? r0 + ra : ra) * dst_ld + c0) = o;
             }
         }
     };
@@ -1964,7 +1963,8 @@ extern "C" int sf_mlp2_fwd(const float *x, int64_t x_stride, int64_t n, int D, f
     SF_REQUIRE(H1 > 0 && H2 > 0 && H1 % 8 == 0 && H2 % 8 == 0 && (mu == nullptr) == (rstd == nullptr),
                "sf_mlp2_fwd: layer widths must be multiples of 8 (H1=%d H2=%d)", H1, H2);
     const size_t lds = sizeof(float) * ((size_t)D * H1 + (size_t)H1 * H2 + MLP2_ROWS * (size_t)(D + H1));
-    SF_REQUIRE(lds <= 64 * 1024 && D <= 64 && D * H1 <= 8192 && H1 * H2 <= 8192 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0,
+    SF_REQUIRE(lds <= 64 * 1024 && D <= 64 && D * H1 <= 8192 && H1 * H2 <= 8192 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0 &&
+                   ((uintptr_t)out & 15) == 0,
                "sf_mlp2_fwd: D=%d H1=%d H2=%d exceed the fused kernel (use the layer kernels)", D, H1, H2);
     k_mlp2_fwd<<<dim3((unsigned)((n + MLP2_ROWS - 1) / MLP2_ROWS)), dim3(256), lds, STREAM(stream)>>>(x, x_stride, n, D, sub_mean, inv_scale, mu,
                                                                                    rstd, w1, b1, H1, w2, b2, H2, act, out);

@@ -234,7 +234,8 @@ class ActorCritic:
         # refreshed by params_changed() after every parameter update
         self.flat_params_t = torch.zeros_like(self.flat_params)
         for L, (o, ob) in zip(self.layers, self._segs):
-            ok = not L.desc.in_u8 and L.desc.Cin % 32 == 0 and L.N >= 32  # (incl. the recurrent projections W_ih / W_hh)
+            # (incl. the recurrent projections W_ih / W_hh; the narrow heads matrix takes sf_conv_fwd_t's one-wave-per-16-rows kernel)
+            ok = not L.desc.in_u8 and ((L.desc.Cin % 32 == 0 and L.N >= 32) or (L.kind == "heads" and L.K % 16 == 0))
             L.wt = self.flat_params_t[o:o + L.K * L.N].view(L.N, L.K) if ok else None
         self.obs_normalizer = None
         if norm_input:

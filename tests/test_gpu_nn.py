@@ -1671,3 +1671,34 @@ def test_conv1_exact_product_kernels_on_tiny_gradients(lib):
         json.dump(rep, open(os.path.join(out, "conv1_tiny_gradients.json"), "w"), indent=1)
     except OSError:
         pass
+
+
+@pytest.mark.parametrize("n,K,N,act", [(4096, 512, 8, 0), (2048, 512, 20, 0), (77, 512, 20, 1), (1000, 64, 32, 2),
+                                       (33, 272, 5, 0), (5, 1024, 17, 1), (16, 16, 1, 0)])
+def test_narrow_linear_forward_vs_torch(lib, n, K, N, act):
+    """sf_nn_narrow.h (Cout <= 32: the fused heads matrix; one wave per 16 rows, both operands straight from memory into
+    MFMA fragments, 256-deep chunks double-buffered in registers) through sf_conv_fwd_t: ragged last row tile, column
+    tiles with missing columns, K not a multiple of the chunk, strided rows, no bias, every activation kind; rows past
+    the end are not written; result equal (to rounding) to the tiled kernel's."""
+    g = torch.Generator().manual_seed(n + K + N)
+    d = desc(lib, K, 1, 1, N, 1, 1, relu=act)
+    assert lib.conv_fwd_t_supported(n, d) and lib.conv_fwd_t_workspace(n, d) == 0
+    assert lib.conv_kernel_name(3, n, d) == f"k_linear_narrow<{1 if N <= 16 else 2}>"
+    x, w, b = torch.randn((n, K), generator=g), torch.randn((K, N), generator=g) / np.sqrt(K), torch.randn(N, generator=g) * 0.1
+    f = lambda p: F.relu(p) if act == 1 else torch.tanh(p) if act == 2 else p
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    wt = wd.t().contiguous()
+    out = torch.full((n + 3, N), 7.0, device="cuda")
+    lib.conv_fwd_t(xd, K, wt, bd, out, n, d)
+    ref = f(x.double() @ w.double() + b.double())
+    tol = 2e-6 * max(1.0, ref.abs().max().item()) * np.sqrt(K / 64)
+    assert (out[:n].cpu().double() - ref).abs().max().item() < tol
+    assert (out[n:] == 7.0).all(), "rows past the end must not be written"
+    old = torch.empty((n, N), device="cuda")
+    lib.conv_fwd(xd, K, None, 0, wd, bd, old, n, d)
+    assert (out[:n] - old).abs().max().item() < tol
+    big = torch.randn((n, 2, K), generator=g).cuda()  # strided rows (a view into a larger buffer), no bias
+    out2 = torch.empty((n, N), device="cuda")
+    lib.conv_fwd_t(big[:, 1], 2 * K, wt, None, out2, n, d)
+    ref2 = f(big[:, 1].cpu().double() @ w.double())
+    assert (out2.cpu().double() - ref2).abs().max().item() < tol

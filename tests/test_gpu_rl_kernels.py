@@ -614,7 +614,7 @@ def test_tanh_scale_fwd_bwd_vs_torch(lib):
 
 
 @pytest.mark.parametrize("Cn,R,H", [(512, 6, 512), (200, 4, 512), (2048, 3, 512), (16, 5, 512), (512, 5, 256),
-                                    (200, 3, 256), (2048, 2, 256)])
+                                    (200, 3, 256), (2048, 2, 256), (1024, 3, 512), (1000, 3, 256)])
 def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R, H):
     """sf_lstm_seq_fwd / sf_lstm_seq_bwd (ONE persistent launch per BPTT pass, W_hh slices resident in LDS, per-step
     write-through hand-offs between the work-groups of a row group) against a float64 torch LSTM loop with the same
@@ -674,7 +674,7 @@ def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R, H):
 
 
 @pytest.mark.parametrize("Cn,R,H", [(512, 6, 512), (200, 4, 512), (2048, 3, 512), (16, 5, 512), (512, 5, 256),
-                                    (200, 3, 256), (2048, 2, 256)])
+                                    (200, 3, 256), (2048, 2, 256), (1024, 3, 512), (1000, 3, 256)])
 def test_fused_gru_sequence_passes_vs_torch_fp64(lib, Cn, R, H):
     """sf_gru_seq_fwd / sf_gru_seq_bwd (the reference's default core: GRU-512) against a float64 torch GRU loop with the
     same masking; torch.nn.GRUCell's equations (r, z, n gate order, n = tanh(x_n + r * (h W_hn + b_hn))) are checked

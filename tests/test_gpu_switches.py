@@ -31,3 +31,14 @@ def test_kernel_numerics_under_non_default_switches(switches, minus):
                        timeout=900)
     tail = r.stdout[-1500:]
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, f"{switches}:\n{tail}\n{r.stderr[-500:]}"
+
+
+def test_rnn_sequence_passes_with_lds_weight_backward():
+    """SF_SEQ_BWD_REGW=0: the backward sequence passes with the W_hh slice in LDS (16 hidden units per work-group; the
+    dispatch for row groups of more than 64 rows) must pass the same fused-sequence tests as the register-weight ones"""
+    env = dict(os.environ, SF_SEQ_BWD_REGW="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rl_kernels.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "fused_lstm_sequence or fused_gru_sequence", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, f"{tail}\n{r.stderr[-500:]}"
