@@ -610,6 +610,38 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
     }
 }
 
+// Many partials, few outputs (persistent weight-gradient kernels write one partial per work-group: 256 - 512 of them for
+// a 27 x 64 ... 256 x 32 result): the loop above is then a handful of work-groups walking Z dependent rounds.  Here a
+// work-group takes 32 outputs x 8 groups of consecutive partials; every thread sums its group as above (ascending z,
+// eight interleaved accumulators), the eight group sums meet in LDS and are added in a fixed tree.  Deterministic.
+__global__ __launch_bounds__(256) void k_reduce_partials_tree(const float *__restrict__ partial, float *__restrict__ out,
+                                                              int64_t n, int Z) {
+    __shared__ float sm[8][33];
+    const int li = threadIdx.x & 31, zg = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + li;
+    const int zper = (Z + 7) / 8, z0 = zg * zper, z1 = z0 + zper < Z ? z0 + zper : Z;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += partial[(int64_t)(z + j) * n + i];
+        }
+        for (int j = 0; z < z1; ++z, ++j) s[j] += partial[(int64_t)z * n + i];
+    }
+    sm[zg][li] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (zg == 0 && i < n)
+        out[i] = ((sm[0][li] + sm[1][li]) + (sm[2][li] + sm[3][li])) + ((sm[4][li] + sm[5][li]) + (sm[6][li] + sm[7][li]));
+}
+static void launch_reduce_partials(const float *partial, float *out, int64_t n, int Z, hipStream_t st) {
+    static const int tree_on = getenv("SF_REDUCE_TREE") ? atoi(getenv("SF_REDUCE_TREE")) : 1;
+    if (tree_on && Z >= 64 && cdiv64(n, 256) < 256)  // fewer loop work-groups than CUs and a long walk each
+        k_reduce_partials_tree<<<dim3(cdiv64(n, 32)), dim3(256), 0, st>>>(partial, out, n, Z);
+    else
+        k_reduce_partials<<<dim3(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048), dim3(256), 0, st>>>(partial, out, n, Z);
+}
+
 // ============================================================================================== DATA GRADIENT
 // din[sample, ih, iw, c] = mask * sum_{kh,kw,n} dY[sample, (ih-kh)/S, (iw-kw)/S, n] * W[(kh,kw,c), n], only taps with
 // kh = ih mod S (+ a*S), kw = iw mod S (+ b*S) contribute -> one GEMM per parity class (ph, pw) = blockIdx.z:
@@ -1007,6 +1039,11 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     }
     return p;
 }
+static bool small_linear_wgrad_ok(const sf_conv_desc *d) {
+    static const int on = getenv("SF_LINEAR_NARROW") ? atoi(getenv("SF_LINEAR_NARROW")) : 1;
+    return on && !d->in_u8 && d->traj_T == 0 && d->KH == 1 && d->KW == 1 && d->H == 1 && d->W == 1 && d->Cout <= 64 &&
+           d->Cin <= 64;
+}
 // narrow linear layers (the heads): one wave per 16 rows, operands straight from memory (sf_nn_narrow.h)
 static bool narrow_fwd_ok(const sf_conv_desc *d, int64_t n) {
     static const int on = getenv("SF_LINEAR_NARROW") ? atoi(getenv("SF_LINEAR_NARROW")) : 1;
@@ -1182,6 +1219,10 @@ extern "C" int64_t sf_conv_wgrad_workspace(int64_t n, const sf_conv_desc *h_desc
     const SplitPlan p = plan_splits(Mtot, K, N, 128, wgrad_bn(N));
     int Z = p.Z;
     if (wgrad_img_variant(h_desc, n) && wgrad_img_blocks(h_desc, n) > Z) Z = wgrad_img_blocks(h_desc, n);  // one partial per work-group
+    if (small_linear_wgrad_ok(h_desc)) {  // one partial per 64-row tile, at most 1024
+        const int64_t zs = cdiv64(Mtot, 64) < 1024 ? cdiv64(Mtot, 64) : 1024;
+        if (zs > Z) Z = (int)zs;
+    }
     if (!h_desc->in_u8) {  // the LDS-DMA kernel may pick other tiles (hence another split count)
         const WgradGlds q = plan_wgrad_glds(Mtot, K, N);
         if (q.Z > Z) Z = q.Z;
@@ -1270,6 +1311,16 @@ static int conv_wgrad_impl(const void *in, int64_t in_sample_stride, const int32
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w,
                 db ? partial_b : nullptr, (int)n, npairs);
     } else
+    if (small_linear_wgrad_ok(h_desc) && !index) {
+        // 27 -> 64 -> 64 encoder layers: 64-row tiles through LDS, fmaf (sf_nn_narrow.h); one partial per work-group
+        int nb = (int)(cdiv64(Mtot, 64) < 256 ? cdiv64(Mtot, 64) : 256);  // (<= what sf_conv_wgrad_workspace sized for)
+        const int64_t mps = cdiv64(cdiv64(Mtot, nb), 64) * 64;
+        nb = (int)cdiv64(Mtot, mps);
+        partial_b = partial_w + (int64_t)nb * K * N;
+        Zused = nb;
+        k_linear_wgrad_small<<<dim3(nb), dim3(256), 0, st>>>(reinterpret_cast<const float *>(in), in_sample_stride, dout,
+                                                             partial_w, db ? partial_b : nullptr, Mtot, mps, K, N);
+    } else
     if (mode == MODE_F32 && !index && wgrad_img_variant(h_desc, n)) {
         // conv2 / conv3: persistent LDS-image kernel, every operand byte fetched once, one partial per work-group
         const int nb = wgrad_img_blocks(h_desc, n);
@@ -1303,9 +1354,8 @@ static int conv_wgrad_impl(const void *in, int64_t in_sample_stride, const int32
         else WGRAD_BY_MODE(64, 2, 2);
     }
     const int64_t KN = (int64_t)K * N;
-    k_reduce_partials<<<dim3(cdiv64(KN, 256) < 2048 ? cdiv64(KN, 256) : 2048), dim3(256), 0, st>>>(partial_w, dw, KN,
-                                                                                                    Zused);
-    if (db) k_reduce_partials<<<dim3(cdiv64(N, 256)), dim3(256), 0, st>>>(partial_b, db, N, Zused);
+    launch_reduce_partials(partial_w, dw, KN, Zused, st);
+    if (db) launch_reduce_partials(partial_b, db, N, Zused, st);
     return sf_launch_status("sf_conv_wgrad");
 }
 
@@ -1413,6 +1463,8 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         if (narrow_fwd_ok(h_desc, n)) snprintf(out, cap, "k_linear_narrow<%d>", g.Cout <= 16 ? 1 : 2);
         else if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1, %d>", g.Cin, g.H, g.W, g.KH, g.S, g.OH);
         else snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
+    } else if (op == 1 && small_linear_wgrad_ok(h_desc)) {
+        snprintf(out, cap, "k_linear_wgrad_small");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {
         if (conv1_bf16_ok(g, MODE_U8, n)) snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_bf16<true>" : "k_conv1_wgrad_bf16<false>");
         else snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_wgrad_img<2, 4, true>" : "k_conv1_wgrad_img<2, 4, false>");

@@ -354,7 +354,8 @@ def test_conv1_exact_product_kernels_on_integers(lib):
     assert ((got - ref).abs() <= bound).all(), float(((got - ref).abs() / bound).max())
 
 
-@pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64)])
+@pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64),
+                                   (16384, 27, 64), (70001, 64, 17)])  # (K, N <= 64: k_linear_wgrad_small)
 def test_linear_fwd_bwd_vs_torch(lib, M, K, N):
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn((M, K), generator=g)
