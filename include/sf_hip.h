@@ -403,6 +403,21 @@ int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const fl
 int sf_gru_seq_bwd(const float *dout, const float *gates, const float *hprev, const float *keep, const float *whh,
                    float *dgx, float *dgh, uint32_t *sync, int R, int Cn, int H, int env_major, void *stream);
 
+/* Forward sequence passes WITH the input projection (model/core.py:37-64: nn.LSTM / nn.GRU compute x W_ih^T + b_ih
+ * themselves): instead of gx [R][Cn][G*H] — written by a GEMM launch and read back by the pass — the pass takes
+ * x [R][Cn][Kx] (time-major core input), wih_t [G*H][Kx] (W_ih in torch's own [gate column][input] layout) and
+ * bih [G*H]; every work-group multiplies its own gate columns, the products of step t+1 run while it waits for the
+ * other work-groups' h_t.  gx_t = x_t W_ih^T + b_ih is formed in f32 exactly as the GEMM's epilogue does (MFMA sum, then
+ * + b_ih), then used as in sf_lstm_seq_fwd / sf_gru_seq_fwd.  sf_seq_fwd_x_supported: Kx == 64 and row groups of at
+ * most 128 rows (Cn <= 1024 on 256 CUs), else project with sf_conv_fwd_t and call the gx form. */
+int sf_seq_fwd_x_supported(int Cn, int H, int Kx);
+int sf_lstm_seq_fwd_x(const float *x, const float *wih_t, const float *bih, int Kx, const float *whh, const float *bhh,
+                      const float *keep, float *gates, float *hprev, float *hout, float *cprev, float *cout,
+                      uint32_t *sync, int R, int Cn, int H, int env_major, void *stream);
+int sf_gru_seq_fwd_x(const float *x, const float *wih_t, const float *bih, int Kx, const float *whh, const float *bhh,
+                     const float *keep, float *gates, float *hprev, float *hout, uint32_t *sync, int R, int Cn, int H,
+                     int env_major, void *stream);
+
 /* ---- data-parallel learner replicas (SURVEY.md §8(b) "DP -> sf_allreduce_grads", §8(e)) ----------------------------
  * New capability: the reference runs ONE learner per policy (algo/utils/shared_buffers.py:26-32), so these replace no
  * reference function; a host without torch.distributed binds them for the exchange algo/learning/learner.py performs

@@ -636,10 +636,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials_tree(const float *__res
 }
 static void launch_reduce_partials(const float *partial, float *out, int64_t n, int Z, hipStream_t st) {
     static const int tree_on = getenv("SF_REDUCE_TREE") ? atoi(getenv("SF_REDUCE_TREE")) : 1;
-    if (tree_on && Z >= 64 && cdiv64(n, 256) < 256)  // fewer loop work-groups than CUs and a long walk each
-        k_reduce_partials_tree<<<dim3(cdiv64(n, 32)), dim3(256), 0, st>>>(partial, out, n, Z);
+    if (tree_on && Z >= 64 && (n + 255) / 256 < 256)  // fewer loop work-groups than CUs and a long walk each
+        k_reduce_partials_tree<<<dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st>>>(partial, out, n, Z);
     else
-        k_reduce_partials<<<dim3(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048), dim3(256), 0, st>>>(partial, out, n, Z);
+        k_reduce_partials<<<dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st>>>(partial, out, n, Z);
 }
 
 // ============================================================================================== DATA GRADIENT
@@ -1012,8 +1012,10 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     p.ok = false; p.wide = false; p.Z = 1; p.k_per_split = (K + 31) / 32 * 32;
     const int64_t t64 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 64), t128 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 128);
     // (wide outputs of moderate height — the recurrent projection of one rollout step, 2048 x 512 x 2048: 512 tiles,
-    //  two per CU — also beat the register-staged kernel: 75 -> measured in profiles/r02_c5_*)
-    if (t64 >= 768 || (t64 >= 448 && N >= 512 && K >= 256)) {
+    //  two per CU — also beat the register-staged kernel: 75 -> measured in profiles/r02_c5_*; the GRU's 2048 x 512 x
+    //  1536 is 384 tiles)
+    static const int wide_min = getenv("SF_GLDS_WIDE_MIN") ? atoi(getenv("SF_GLDS_WIDE_MIN")) : 384;
+    if (t64 >= 768 || (t64 >= wide_min && N >= 512 && K >= 256)) {
         p.ok = true;
         if (N >= 128 && cfg == 0) {  // efficiency = rounds / ceil(rounds) with the kernel's own occupancy
             const double u64 = (double)t64 / (256.0 * occ64), u128 = (double)t128 / (256.0 * occ128);

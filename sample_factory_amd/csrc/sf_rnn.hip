@@ -80,13 +80,21 @@ struct LstmSeqFwd {
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
     int64_t ho_rs, ho_ts;  // hout element (row, t) lives at row*ho_rs + t*ho_ts (+ unit): [R][Cn][H] or [Cn][R][H]
+    // KXB > 0 (sf_lstm_seq_fwd_x): gx is not given but computed here, x [R][Cn][16*KXB] (time-major), wih_t [4H][16*KXB]
+    // (gate-column-major copy of W_ih), bih [4H]
+    const float *x, *wih_t, *bih;
 };
 
 // H hidden units, JB of them per work-group (JB = 16: the W_hh slice is 64 x (H + 4) floats of LDS — 129 KB at H = 512,
 // 66.5 KB at H = 256; H = 1024 would need 263 KB, i.e. JB = 8 and a different accumulator-to-lane mapping: not built).
-template <int H, int JB, int NSUB>
+// KXB > 0: the input projection gx_t = x_t W_ih^T + b_ih (KXB 16-column blocks of x) is computed HERE instead of by a GEMM
+// launch that writes [R][Cn][4H] floats for this kernel to read back: the W_ih fragments of the work-group's 64 gate
+// columns live in registers, the x fragments of step t+1 are fetched behind step t's hand-off, and the 16*KXB MFMAs run
+// while the first h rows of the step are on their way from L2 (placed between the hand-off and the wait they delayed
+// every work-group alike: +1.8 us per step, measured).
+template <int H, int JB, int NSUB, int KXB>
 __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
-    constexpr int G4 = 4 * H, NC = 4 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
+    constexpr int G4 = 4 * H, NC = 4 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4, KX = 16 * KXB;
     constexpr int KU = 8, NKB = H / 16 / KU;
     constexpr int NBUF = NKB < SF_SEQ_NBUF ? NKB : SF_SEQ_NBUF;  // k-blocks of 8 x 16-byte loads per lane in flight (+ the one in the matrix pipe)
     constexpr int STG = 16 * JB;  // floats of one wave's staging tile
@@ -105,11 +113,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
         const int lc = idx % NC, k = idx / NC, q = lc / JB, u = lc % JB;
         wt[lc * LDW + k] = p.whh[(int64_t)k * G4 + q * H + j0 + u];
     }
-    float bias[4][NU];
+    float bias[4][NU], bih[4][NU];
+    f32x4 bx[KXB > 0 ? KXB : 1][NT];  // lane (c, g): W_ih^T[gate column of tile nt, lane c][16*blk + 4*g ..]
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) bias[q][u] = p.bhh[q * H + j0 + u * 16 + c];
+        for (int u = 0; u < NU; ++u) {
+            bias[q][u] = p.bhh[q * H + j0 + u * 16 + c];
+            bih[q][u] = KXB > 0 ? p.bih[q * H + j0 + u * 16 + c] : 0.0f;
+            if (KXB > 0) {
+#pragma unroll
+                for (int blk = 0; blk < KXB; ++blk)
+                    bx[blk][q * NU + u] = *reinterpret_cast<const f32x4 *>(p.wih_t + (int64_t)(q * H + j0 + u * 16 + c) * KX + 16 * blk + 4 * g);
+            }
+        }
     __syncthreads();
     const auto h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.hprev, 0, (int)((int64_t)(R + 1) * Cn * H * 4), 0x00020000);
     const int g_row0 = group * p.rows_per_group;
@@ -131,7 +148,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
 
     // operands of the cell epilogue for the next step: issued right after this step's hand-off, so they fly during the
     // wait for the other work-groups and the MFMA phase
-    float xg[NSUB][4][4][NU], kp[NSUB][4];
+    float xg[KXB > 0 ? 1 : NSUB][4][4][NU], kp[NSUB][4];
+    f32x4 xa[NSUB][KXB > 0 ? KXB : 1];   // KXB > 0: x fragments of the NEXT projection (lane (c, g): row c, k = 16*blk + 4*g ..)
+    f32x4 xacc[NSUB][KXB > 0 ? NT : 1];  // KXB > 0: x_t W_ih^T of the step about to run
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
@@ -141,14 +160,37 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
                 const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
                 const int64_t tr = (int64_t)t * Cn + r;
                 kp[sub][i] = p.keep[tr];
+                if constexpr (KXB == 0) {
 #pragma unroll
-                for (int u = 0; u < NU; ++u)
+                    for (int u = 0; u < NU; ++u)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xg[sub][i][q][u] = p.gx[tr * G4 + q * H + j0 + u * 16 + c];
+                        for (int q = 0; q < 4; ++q) xg[sub][i][q][u] = p.gx[tr * G4 + q * H + j0 + u * 16 + c];
+                }
             }
         }
     };
+    auto load_x = [&](int t) {  // fragments of x_t
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row = g_row0 + sub * 64 + wave * 16 + c, r = row < g_rows_end ? row : g_rows_end - 1;
+#pragma unroll
+            for (int blk = 0; blk < KXB; ++blk)
+                xa[sub][blk] = *reinterpret_cast<const f32x4 *>(p.x + ((int64_t)t * Cn + r) * KX + 16 * blk + 4 * g);
+        }
+    };
+    auto project_x = [&](int sub) {  // xacc = xa W_ih^T (this work-group's gate columns)
+#pragma unroll
+        for (int nt = 0; nt < (KXB > 0 ? NT : 1); ++nt) xacc[sub][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < KXB; ++blk)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xacc[sub][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[sub][blk][j], bx[blk][nt][j], xacc[sub][nt], 0, 0, 0);
+    };
     prefetch(0);
+    if (KXB > 0) load_x(0);
 
     for (int t = 0; t < R; ++t) {
         if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
@@ -174,9 +216,15 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
             auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
 #pragma unroll
             for (int b = 0; b < NBUF - 1; ++b) load_block(kbe(b), abuf[b]);
+            if constexpr (KXB > 0) {  // x_t W_ih^T while the first h rows are on their way from L2
+                __builtin_amdgcn_sched_barrier(0);
+                project_x(sub);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 if (kb + NBUF - 1 < NKB) load_block(kbe(kb + NBUF - 1), abuf[(kb + NBUF - 1) % NBUF]);
+                if constexpr (KXB > 0) __builtin_amdgcn_sched_barrier(0);  // (with the projection's registers live hipcc sinks these loads to their use)
                 const float *bpk = wt + c * LDW + kbe(kb) * (KU * 16) + 4 * g;
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku) {
@@ -196,10 +244,14 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const float ig = sigm(xg[sub][i][0][u] + (acc[0 * NU + u][i] + bias[0][u]));
-                    const float fg = sigm(xg[sub][i][1][u] + (acc[1 * NU + u][i] + bias[1][u]));
-                    const float gg = tanhf(xg[sub][i][2][u] + (acc[2 * NU + u][i] + bias[2][u]));
-                    const float og = sigm(xg[sub][i][3][u] + (acc[3 * NU + u][i] + bias[3][u]));
+                    float gxv[4];  // gx of this (row, unit): given, or the projection computed behind the last hand-off
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        gxv[q] = KXB > 0 ? xacc[sub][KXB > 0 ? q * NU + u : 0][i] + bih[q][u] : xg[KXB > 0 ? 0 : sub][i][q][u];
+                    const float ig = sigm(gxv[0] + (acc[0 * NU + u][i] + bias[0][u]));
+                    const float fg = sigm(gxv[1] + (acc[1 * NU + u][i] + bias[1][u]));
+                    const float gg = tanhf(gxv[2] + (acc[2 * NU + u][i] + bias[2][u]));
+                    const float og = sigm(gxv[3] + (acc[3 * NU + u][i] + bias[3][u]));
                     const float cn = fg * cst[sub][i][u] + ig * gg;
                     const float h = og * tanhf(cn);
                     cst[sub][i][u] = cn * kp[sub][i];
@@ -222,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
         if (t + 1 < R) {
             seq_arrive(counter);
             prefetch(t + 1);
+            if (KXB > 0) load_x(t + 1);  // fragments of the next step's input
         }
         // ---- saves for the backward pass (plain stores: they drain while this work-group waits for the others)
 #pragma unroll
@@ -428,11 +481,12 @@ struct GruSeqFwd {
     unsigned *sync;
     int R, Cn, ngroups, rows_per_group;
     int64_t ho_rs, ho_ts;
+    const float *x, *wih_t, *bih;  // KXB > 0 (sf_gru_seq_fwd_x): see LstmSeqFwd
 };
 
-template <int H, int JB, int NSUB>
+template <int H, int JB, int NSUB, int KXB>
 __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
-    constexpr int G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4;
+    constexpr int G3 = 3 * H, G4 = 4 * H, NC = 3 * JB, NT = NC / 16, NU = JB / 16, LDW = H + 4, KX = 16 * KXB;
     constexpr int KU = 8, NKB = H / 16 / KU;
     constexpr int NBUF = NKB < SF_SEQ_NBUF ? NKB : SF_SEQ_NBUF;  // k-blocks of 8 x 16-byte loads per lane in flight (+ the one in the matrix pipe)
     constexpr int STG = 16 * JB;
@@ -450,11 +504,20 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
         const int lc = idx % NC, k = idx / NC, q = lc / JB, u = lc % JB;
         wt[lc * LDW + k] = p.whh[(int64_t)k * G3 + q * H + j0 + u];
     }
-    float bias[3][NU];
+    float bias[3][NU], bih[3][NU];
+    f32x4 bx[KXB > 0 ? KXB : 1][NT];
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) bias[q][u] = p.bhh[q * H + j0 + u * 16 + c];
+        for (int u = 0; u < NU; ++u) {
+            bias[q][u] = p.bhh[q * H + j0 + u * 16 + c];
+            bih[q][u] = KXB > 0 ? p.bih[q * H + j0 + u * 16 + c] : 0.0f;
+            if (KXB > 0) {
+#pragma unroll
+                for (int blk = 0; blk < KXB; ++blk)
+                    bx[blk][q * NU + u] = *reinterpret_cast<const f32x4 *>(p.wih_t + (int64_t)(q * H + j0 + u * 16 + c) * KX + 16 * blk + 4 * g);
+            }
+        }
     __syncthreads();
     const auto h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.hprev, 0, (int)((int64_t)(R + 1) * Cn * H * 4), 0x00020000);
     const int g_row0 = group * p.rows_per_group;
@@ -470,7 +533,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
             for (int u = 0; u < NU; ++u) hst[sub][i][u] = p.hprev[(int64_t)r * H + j0 + u * 16 + c];
         }
     }
-    float xg[NSUB][4][3][NU], kp[NSUB][4];
+    float xg[KXB > 0 ? 1 : NSUB][4][3][NU], kp[NSUB][4];
+    f32x4 xa[NSUB][KXB > 0 ? KXB : 1], xacc[NSUB][KXB > 0 ? NT : 1];  // (see k_lstm_seq_fwd)
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
@@ -480,14 +544,37 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
                 const int row = row0 + 4 * g + i, r = row < g_rows_end ? row : g_rows_end - 1;
                 const int64_t tr = (int64_t)t * Cn + r;
                 kp[sub][i] = p.keep[tr];
+                if constexpr (KXB == 0) {
 #pragma unroll
-                for (int u = 0; u < NU; ++u)
+                    for (int u = 0; u < NU; ++u)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) xg[sub][i][q][u] = p.gx[tr * G3 + q * H + j0 + u * 16 + c];
+                        for (int q = 0; q < 3; ++q) xg[sub][i][q][u] = p.gx[tr * G3 + q * H + j0 + u * 16 + c];
+                }
             }
         }
     };
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int row = g_row0 + sub * 64 + wave * 16 + c, r = row < g_rows_end ? row : g_rows_end - 1;
+#pragma unroll
+            for (int blk = 0; blk < KXB; ++blk)
+                xa[sub][blk] = *reinterpret_cast<const f32x4 *>(p.x + ((int64_t)t * Cn + r) * KX + 16 * blk + 4 * g);
+        }
+    };
+    auto project_x = [&](int sub) {
+#pragma unroll
+        for (int nt = 0; nt < (KXB > 0 ? NT : 1); ++nt) xacc[sub][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < KXB; ++blk)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xacc[sub][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[sub][blk][j], bx[blk][nt][j], xacc[sub][nt], 0, 0, 0);
+    };
     prefetch(0);
+    if (KXB > 0) load_x(0);
 
     for (int t = 0; t < R; ++t) {
         if (t > 0 && !seq_wait(counter, ncol * (unsigned)t, abort_flag, flag)) return;
@@ -510,9 +597,15 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
             auto kbe = [&](int kb) { const int k = kb + rot; return k >= NKB ? k - NKB : k; };
 #pragma unroll
             for (int b = 0; b < NBUF - 1; ++b) load_block(kbe(b), abuf[b]);
+            if constexpr (KXB > 0) {  // x_t W_ih^T while the first h rows are on their way from L2
+                __builtin_amdgcn_sched_barrier(0);
+                project_x(sub);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 if (kb + NBUF - 1 < NKB) load_block(kbe(kb + NBUF - 1), abuf[(kb + NBUF - 1) % NBUF]);
+                if constexpr (KXB > 0) __builtin_amdgcn_sched_barrier(0);  // (with the projection's registers live hipcc sinks these loads to their use)
                 const float *bpk = wt + c * LDW + kbe(kb) * (KU * 16) + 4 * g;
 #pragma unroll
                 for (int ku = 0; ku < KU; ++ku) {
@@ -532,10 +625,14 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const float r = sigm(xg[sub][i][0][u] + (acc[0 * NU + u][i] + bias[0][u]));
-                    const float z = sigm(xg[sub][i][1][u] + (acc[1 * NU + u][i] + bias[1][u]));
+                    float gxv[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        gxv[q] = KXB > 0 ? xacc[sub][KXB > 0 ? q * NU + u : 0][i] + bih[q][u] : xg[KXB > 0 ? 0 : sub][i][q][u];
+                    const float r = sigm(gxv[0] + (acc[0 * NU + u][i] + bias[0][u]));
+                    const float z = sigm(gxv[1] + (acc[1 * NU + u][i] + bias[1][u]));
                     const float hn = acc[2 * NU + u][i] + bias[2][u];
-                    const float n = tanhf(xg[sub][i][2][u] + r * hn);
+                    const float n = tanhf(gxv[2] + r * hn);
                     const float h = (1.0f - z) * n + z * hst[sub][i][u];
                     hst[sub][i][u] = h * kp[sub][i];
                     stg[(4 * g + i) * JB + u * 16 + c] = hst[sub][i][u];
@@ -555,6 +652,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
         if (t + 1 < R) {
             seq_arrive(counter);
             prefetch(t + 1);
+            if (KXB > 0) load_x(t + 1);  // fragments of the next step's input
         }
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
@@ -775,17 +873,28 @@ int seq_plan(int Cn, int H, int *ngroups, int *rows_per_group, int *jb) {
     } while (0)
 
 // one instantiation per (width, sub-tiles per work-group)
-#define SEQ_DISPATCH(KERN)                                                              \
-    do {                                                                                \
-        if (H == 512) {                                                                 \
-            if (nsub == 1) KERN<512, 16, 1><<<grid, block, 0, STREAM(stream)>>>(p);     \
-            else if (nsub == 2) KERN<512, 16, 2><<<grid, block, 0, STREAM(stream)>>>(p); \
-            else KERN<512, 16, 4><<<grid, block, 0, STREAM(stream)>>>(p);               \
-        } else {                                                                        \
-            if (nsub == 1) KERN<256, 16, 1><<<grid, block, 0, STREAM(stream)>>>(p);     \
-            else if (nsub == 2) KERN<256, 16, 2><<<grid, block, 0, STREAM(stream)>>>(p); \
-            else KERN<256, 16, 4><<<grid, block, 0, STREAM(stream)>>>(p);               \
-        }                                                                               \
+#define SEQ_DISPATCH(KERN, ...)                                                                       \
+    do {                                                                                              \
+        if (H == 512) {                                                                               \
+            if (nsub == 1) KERN<512, 16, 1 __VA_ARGS__><<<grid, block, 0, STREAM(stream)>>>(p);       \
+            else if (nsub == 2) KERN<512, 16, 2 __VA_ARGS__><<<grid, block, 0, STREAM(stream)>>>(p);  \
+            else KERN<512, 16, 4 __VA_ARGS__><<<grid, block, 0, STREAM(stream)>>>(p);                 \
+        } else {                                                                                      \
+            if (nsub == 1) KERN<256, 16, 1 __VA_ARGS__><<<grid, block, 0, STREAM(stream)>>>(p);       \
+            else if (nsub == 2) KERN<256, 16, 2 __VA_ARGS__><<<grid, block, 0, STREAM(stream)>>>(p);  \
+            else KERN<256, 16, 4 __VA_ARGS__><<<grid, block, 0, STREAM(stream)>>>(p);                 \
+        }                                                                                             \
+    } while (0)
+// forward passes with the input projection fused in (x has 64 columns; register budget: one or two sub-tiles)
+#define SEQ_DISPATCH_X(KERN)                                                                  \
+    do {                                                                                      \
+        if (H == 512) {                                                                       \
+            if (nsub == 1) KERN<512, 16, 1, 4><<<grid, block, 0, STREAM(stream)>>>(p);        \
+            else KERN<512, 16, 2, 4><<<grid, block, 0, STREAM(stream)>>>(p);                  \
+        } else {                                                                              \
+            if (nsub == 1) KERN<256, 16, 1, 4><<<grid, block, 0, STREAM(stream)>>>(p);        \
+            else KERN<256, 16, 2, 4><<<grid, block, 0, STREAM(stream)>>>(p);                  \
+        }                                                                                     \
     } while (0)
 
 extern "C" int sf_lstm_seq_supported(int Cn, int H) {
@@ -793,23 +902,46 @@ extern "C" int sf_lstm_seq_supported(int Cn, int H) {
     return Cn > 0 && seq_plan(Cn, H, &a, &b, &c);
 }
 
-extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
-                               float *hprev, float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H,
-                               int env_major, void *stream) {
-    SF_REQUIRE(gx && whh && bhh && keep && gates && hprev && hout && cprev && cout && sync && R > 0 && Cn > 0,
+static int lstm_seq_fwd_impl(const float *gx, const float *x, const float *wih_t, const float *bih, int Kx,
+                             const float *whh, const float *bhh, const float *keep, float *gates, float *hprev, float *hout,
+                             float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H, int env_major, void *stream) {
+    SF_REQUIRE((gx || (x && wih_t && bih)) && whh && bhh && keep && gates && hprev && hout && cprev && cout && sync && R > 0 && Cn > 0,
                "sf_lstm_seq_fwd: bad args");
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_lstm_seq_fwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_lstm_seq_fwd: state buffer exceeds 2 GiB");
+    const int nsub = (rpg + 63) / 64;  // 64-row sub-tiles per work-group, unrolled at compile time (register-resident state)
+    if (!gx)
+        SF_REQUIRE(Kx == 64 && nsub <= 2 && (((uintptr_t)x | (uintptr_t)wih_t) & 15) == 0,
+                   "sf_lstm_seq_fwd_x: unsupported shape Cn=%d H=%d Kx=%d (see sf_seq_fwd_x_supported)", Cn, H, Kx);
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_lstm_seq_fwd memset");
     if (rc) return rc;
     // hout [R][Cn][H] (time-major) or, env_major, [Cn][R][H] = the row order of the minibatch itself (no transpose copy)
     LstmSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, ng, rpg,
-                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
+                 env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H, x, wih_t, bih};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
-    const int nsub = (rpg + 63) / 64;  // 64-row sub-tiles per work-group, unrolled at compile time (register-resident state)
-    SEQ_DISPATCH(k_lstm_seq_fwd);
+    if (gx) SEQ_DISPATCH(k_lstm_seq_fwd, , 0);
+    else SEQ_DISPATCH_X(k_lstm_seq_fwd);
     return sf_launch_status("sf_lstm_seq_fwd");
+}
+extern "C" int sf_lstm_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
+                               float *hprev, float *hout, float *cprev, float *cout, uint32_t *sync, int R, int Cn, int H,
+                               int env_major, void *stream) {
+    SF_REQUIRE(gx, "sf_lstm_seq_fwd: bad args");
+    return lstm_seq_fwd_impl(gx, nullptr, nullptr, nullptr, 0, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H,
+                             env_major, stream);
+}
+extern "C" int sf_seq_fwd_x_supported(int Cn, int H, int Kx) {
+    static const int on = getenv("SF_SEQ_FWD_X") ? atoi(getenv("SF_SEQ_FWD_X")) : 1;
+    int ng, rpg, jb;
+    return on && Cn > 0 && Kx == 64 && seq_plan(Cn, H, &ng, &rpg, &jb) && (rpg + 63) / 64 <= 2;
+}
+extern "C" int sf_lstm_seq_fwd_x(const float *x, const float *wih_t, const float *bih, int Kx, const float *whh,
+                                 const float *bhh, const float *keep, float *gates, float *hprev, float *hout, float *cprev,
+                                 float *cout, uint32_t *sync, int R, int Cn, int H, int env_major, void *stream) {
+    SF_REQUIRE(x && wih_t && bih, "sf_lstm_seq_fwd_x: bad args");
+    return lstm_seq_fwd_impl(nullptr, x, wih_t, bih, Kx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H,
+                             env_major, stream);
 }
 
 extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const float *cprev, const float *cout,
@@ -840,21 +972,39 @@ extern "C" int sf_lstm_seq_bwd(const float *dout, const float *gates, const floa
     return sf_launch_status("sf_lstm_seq_bwd");
 }
 
-extern "C" int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
-                              float *hprev, float *hout, uint32_t *sync, int R, int Cn, int H, int env_major,
-                              void *stream) {
-    SF_REQUIRE(gx && whh && bhh && keep && gates && hprev && hout && sync && R > 0 && Cn > 0, "sf_gru_seq_fwd: bad args");
+static int gru_seq_fwd_impl(const float *gx, const float *x, const float *wih_t, const float *bih, int Kx, const float *whh,
+                            const float *bhh, const float *keep, float *gates, float *hprev, float *hout, uint32_t *sync,
+                            int R, int Cn, int H, int env_major, void *stream) {
+    SF_REQUIRE((gx || (x && wih_t && bih)) && whh && bhh && keep && gates && hprev && hout && sync && R > 0 && Cn > 0,
+               "sf_gru_seq_fwd: bad args");
     int ng, rpg, jb;
     SF_REQUIRE(seq_plan(Cn, H, &ng, &rpg, &jb), "sf_gru_seq_fwd: unsupported shape Cn=%d H=%d (see sf_lstm_seq_supported)", Cn, H);
     SF_REQUIRE((int64_t)(R + 1) * Cn * H * 4 < 0x7FFFFFF0LL, "sf_gru_seq_fwd: state buffer exceeds 2 GiB");
+    const int nsub = (rpg + 63) / 64;
+    if (!gx)
+        SF_REQUIRE(Kx == 64 && nsub <= 2 && (((uintptr_t)x | (uintptr_t)wih_t) & 15) == 0,
+                   "sf_gru_seq_fwd_x: unsupported shape Cn=%d H=%d Kx=%d (see sf_seq_fwd_x_supported)", Cn, H, Kx);
     int rc = sf_hip_status(hipMemsetAsync(sync, 0, SEQ_ABORT_SLOT * sizeof(uint32_t), STREAM(stream)), "sf_gru_seq_fwd memset");
     if (rc) return rc;
     GruSeqFwd p{gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, ng, rpg,
-                env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H};
+                env_major ? (int64_t)R * H : (int64_t)H, env_major ? (int64_t)H : (int64_t)Cn * H, x, wih_t, bih};
     const dim3 grid((unsigned)(ng * (H / jb))), block(256);
-    const int nsub = (rpg + 63) / 64;
-    SEQ_DISPATCH(k_gru_seq_fwd);
+    if (gx) SEQ_DISPATCH(k_gru_seq_fwd, , 0);
+    else SEQ_DISPATCH_X(k_gru_seq_fwd);
     return sf_launch_status("sf_gru_seq_fwd");
+}
+extern "C" int sf_gru_seq_fwd(const float *gx, const float *whh, const float *bhh, const float *keep, float *gates,
+                              float *hprev, float *hout, uint32_t *sync, int R, int Cn, int H, int env_major,
+                              void *stream) {
+    SF_REQUIRE(gx, "sf_gru_seq_fwd: bad args");
+    return gru_seq_fwd_impl(gx, nullptr, nullptr, nullptr, 0, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H, env_major,
+                            stream);
+}
+extern "C" int sf_gru_seq_fwd_x(const float *x, const float *wih_t, const float *bih, int Kx, const float *whh,
+                                const float *bhh, const float *keep, float *gates, float *hprev, float *hout, uint32_t *sync,
+                                int R, int Cn, int H, int env_major, void *stream) {
+    SF_REQUIRE(x && wih_t && bih, "sf_gru_seq_fwd_x: bad args");
+    return gru_seq_fwd_impl(nullptr, x, wih_t, bih, Kx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H, env_major, stream);
 }
 
 extern "C" int sf_gru_seq_bwd(const float *dout, const float *gates, const float *hprev, const float *keep,

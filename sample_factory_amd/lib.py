@@ -39,7 +39,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_train_summaries", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd", "sf_seq_fwd_x_supported", "sf_lstm_seq_fwd_x", "sf_gru_seq_fwd_x",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_copy_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
@@ -301,7 +301,7 @@ def lstm_seq_supported(Cn: int, H: int) -> bool:
     return bool(load().sf_lstm_seq_supported(int(Cn), int(H)))
 
 
-def _seq_key(op, R, Cn, H, steps, G=4):
+def _seq_key(op, R, Cn, H, steps, G=4, x_cols=0):
     """profiling key of a fused LSTM pass in bench.py's layout: 2 * (steps*Cn) * 4H * H algorithmic FLOPs of the
     recurrent products (forward: R steps; backward: R-1, the first step has no state in front of it)"""
     if PROFILE is None:
@@ -319,8 +319,9 @@ def _seq_key(op, R, Cn, H, steps, G=4):
         ng = min(8, (Cn + 15) // 16)
         rpg = ((Cn + ng - 1) // ng + 15) // 16 * 16
         nsub = {1: 1, 2: 2}.get((rpg + 63) // 64, 4)
-        name = f"k_{kind}_seq_{direction}<{int(H)}, 16, {nsub}>"
-    return (op, int(steps * Cn), int(H), 1, 1, int(G * H), 1, 1, 1, 1, name)
+        name = f"k_{kind}_seq_{direction}<{int(H)}, 16, {nsub}" + (f", {x_cols // 16}>" if direction == "fwd" else ">")
+    # (K = H + x_cols: the fused input projection's FLOPs count as the pass's own)
+    return (op, int(steps * Cn), int(H + x_cols), 1, 1, int(G * H), 1, 1, 1, 1, name)
 
 
 def lstm_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H, env_major=False) -> None:
@@ -347,6 +348,31 @@ def gru_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H, env_majo
                                      ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
                                      ptr(hout, "f32", "hout"), ptr(sync, "i32", "sync"), int(R), int(Cn), int(H),
                                      int(bool(env_major)), stream()), "sf_gru_seq_fwd")
+
+
+def seq_fwd_x_supported(Cn: int, H: int, Kx: int) -> bool:
+    return bool(load().sf_seq_fwd_x_supported(int(Cn), int(H), int(Kx)))
+
+
+def lstm_seq_fwd_x(x, wih_t, bih, whh, bhh, keep, gates, hprev, hout, cprev, cout, sync, R, Cn, H, env_major=False) -> None:
+    """sf_lstm_seq_fwd with the input projection fused in: x [R*Cn, Kx] time-major, wih_t [4H, Kx], bih [4H]"""
+    Kx = int(wih_t.shape[1])
+    with _timed(_seq_key("lstm_fwd", R, Cn, H, R, x_cols=Kx)):
+        _check(load().sf_lstm_seq_fwd_x(ptr(x, "f32", "x"), ptr(wih_t, "f32", "wih_t"), ptr(bih, "f32", "bih"), Kx,
+                                        ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"), ptr(keep, "f32", "keep"),
+                                        ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"), ptr(hout, "f32", "hout"),
+                                        ptr(cprev, "f32", "cprev"), ptr(cout, "f32", "cout"), ptr(sync, "i32", "sync"),
+                                        int(R), int(Cn), int(H), int(bool(env_major)), stream()), "sf_lstm_seq_fwd_x")
+
+
+def gru_seq_fwd_x(x, wih_t, bih, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H, env_major=False) -> None:
+    Kx = int(wih_t.shape[1])
+    with _timed(_seq_key("gru_fwd", R, Cn, H, R, 3, x_cols=Kx)):
+        _check(load().sf_gru_seq_fwd_x(ptr(x, "f32", "x"), ptr(wih_t, "f32", "wih_t"), ptr(bih, "f32", "bih"), Kx,
+                                       ptr(whh, "f32", "whh"), ptr(bhh, "f32", "bhh"), ptr(keep, "f32", "keep"),
+                                       ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"), ptr(hout, "f32", "hout"),
+                                       ptr(sync, "i32", "sync"), int(R), int(Cn), int(H), int(bool(env_major)), stream()),
+               "sf_gru_seq_fwd_x")
 
 
 def gru_seq_bwd(dout, gates, hprev, keep, whh, dgx, dgh, sync, R, Cn, H, env_major=False) -> None:

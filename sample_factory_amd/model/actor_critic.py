@@ -549,14 +549,23 @@ class ActorCritic:
                     mask = self._buf((tag, "relu_mask0"), (n * L.out_pixels,), dtype=torch.int32)
                     w_, b_, _ = self._wb(li, tag)
                     lib.conv_fwd_relu_mask(x, stride, idx, off, w_, b_, out, mask, n, d0)
-            if mask is None:
+            fuse_x = False
+            if L.role == "rnn_ih" and seq and _LSTM_SEQ and L.wt is not None and idx is None and not tT:
+                # BPTT pass whose fused sequence kernel can also do the input projection (sf_*_seq_fwd_x): no GEMM launch,
+                # no [n, G*H] round trip through memory for gx
+                fuse_x = lib.lstm_seq_supported(n // rnn["R"], self.rnn_H) and lib.seq_fwd_x_supported(n // rnn["R"], self.rnn_H, L.K)
+            if mask is None and not fuse_x:
                 self._gemm(li, x, stride, idx, off, tT, out, n, tag)
             if li == 0:
                 self._relu_mask0 = mask if tag == "train" else getattr(self, "_relu_mask0", None)
             acts[li] = out
             x = out
             if L.role == "rnn_ih":
-                x = self._rnn_sequence_fwd(li, out, n, rnn, tag) if seq else self._rnn_step(li, out, n, rnn, tag)
+                if fuse_x:
+                    acts[li] = None  # gx is never materialised
+                    x = self._rnn_sequence_fwd(li, None, n, rnn, tag, x_tm=inputs[li])
+                else:
+                    x = self._rnn_sequence_fwd(li, out, n, rnn, tag) if seq else self._rnn_step(li, out, n, rnn, tag)
             stride, idx, off, tT = x.numel() // n, None, 0, 0  # elements per sample of the activation just produced
         if self.tanh_scale > 0:  # action_parameterization.py:62-66 (col 0 = value, then the means)
             lib.tanh_scale_fwd(acts[-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
@@ -585,7 +594,7 @@ class ActorCritic:
         self._rnn_out[tag] = (h_out, c_out)
         return h_out
 
-    def _rnn_sequence_fwd(self, li, GX, n, rnn, tag):
+    def _rnn_sequence_fwd(self, li, GX, n, rnn, tag, x_tm=None):
         """training pass: masked time loop over recurrence-length chunks (state zeroed after done/invalid steps —
         the loop form of rnn_utils.py:114-158, see tests/algo/test_rnn.py in the reference)"""
         Lh, H, kind = self.layers[li + 1], self.rnn_H, self.rnn_kind
@@ -599,13 +608,17 @@ class ActorCritic:
         Hprev[0].copy_(h0[:, :H])
         if kind == 1:
             Cprev[0].copy_(h0[:, H:])
-        GXv = GX.view(R, Cn, GH)
         out = self._buf((tag, "core_out"), (n, H))
         fused = _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
         if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS; the
             # core output is written in the minibatch's own row order (chunk-major), no transpose copy
             sync = self._seq_sync_buf()
-            if kind == 1:
+            Li = self.layers[li]
+            if x_tm is not None and kind == 1:   # ... and the input projection x W_ih^T + b_ih inside the same launch
+                lib.lstm_seq_fwd_x(x_tm, Li.wt, Li.b, Lh.w, Lh.b, keep, gates, Hprev, out, Cprev, Cout, sync, R, Cn, H, env_major=True)
+            elif x_tm is not None:
+                lib.gru_seq_fwd_x(x_tm, Li.wt, Li.b, Lh.w, Lh.b, keep, gates, Hprev, out, sync, R, Cn, H, env_major=True)
+            elif kind == 1:
                 lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, Cprev, Cout, sync, R, Cn, H, env_major=True)
             else:
                 lib.gru_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, sync, R, Cn, H, env_major=True)
@@ -613,6 +626,7 @@ class ActorCritic:
             return out
         Hout = self._buf((tag, "Hout"), (R, Cn, H))
         gh = self._buf((tag, "gh_seq"), (Cn, GH))
+        GXv = GX.view(R, Cn, GH)
         for t in range(R):
             lib.conv_fwd_raw(Hprev[t], H, None, 0, Lh.w, Lh.b, gh, Cn, Lh.desc)
             lib.rnn_cell_fwd(kind, GXv[t], gh, Hprev[t], H, Cprev[t] if kind == 1 else None, H, keep[t], Cn, H,

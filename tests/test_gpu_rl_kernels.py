@@ -993,3 +993,48 @@ def test_train_summaries_kernel_vs_torch(lib, vtrace, use_index):
                         logits, A, index, off, n, 0, 11, 0.1, None, out)
     o = out.cpu().numpy()
     assert o[1] == 0 and o[2] == 0 and np.isposinf(o[8]) and np.isneginf(o[9]) and np.isposinf(o[16]) and np.isneginf(o[18])
+
+
+@pytest.mark.parametrize("kind", ["lstm", "gru"])
+@pytest.mark.parametrize("Cn,R,H", [(512, 6, 512), (200, 4, 512), (1024, 3, 512), (16, 5, 256), (1000, 2, 256)])
+def test_fused_sequence_forward_with_input_projection(lib, kind, Cn, R, H):
+    """sf_lstm_seq_fwd_x / sf_gru_seq_fwd_x: the pass computes gx_t = x_t W_ih^T + b_ih itself (W_ih fragments of the
+    work-group's gate columns in registers, the products of step t+1 behind step t's hand-off).  Every output equals the
+    gx form's, fed with the float64 projection rounded to f32, to a few f32 ulps of the pre-activation."""
+    G, Kx = (4 if kind == "lstm" else 3), 64
+    assert lib.seq_fwd_x_supported(Cn, H, Kx) and not lib.seq_fwd_x_supported(Cn, H, 48) and not lib.seq_fwd_x_supported(2048, H, Kx)
+    g = torch.Generator().manual_seed(Cn + R + G)
+    x = torch.randn((R, Cn, Kx), generator=g)
+    wih = torch.randn((G * H, Kx), generator=g) / np.sqrt(Kx)
+    bih = torch.randn((G * H,), generator=g) * 0.1
+    whh = torch.randn((H, G * H), generator=g) / np.sqrt(H)
+    bhh = torch.randn((G * H,), generator=g) * 0.1
+    keep = (torch.rand((R, Cn), generator=g) > 0.15).float()
+    h0, c0 = torch.randn((Cn, H), generator=g) * 0.5, torch.randn((Cn, H), generator=g) * 0.5
+    gx = (x.double() @ wih.double().t() + bih.double()).float()
+    d = lambda t: t.cuda().contiguous()
+    sync = torch.zeros(192, dtype=torch.int32, device="cuda")
+
+    def run(fused):
+        gates, hout, cout = (torch.full(s_, 7.0, device="cuda") for s_ in [(R, Cn, 4 * H), (R, Cn, H), (R, Cn, H)])
+        hprev, cprev = torch.full((R + 1, Cn, H), 7.0, device="cuda"), torch.full((R + 1, Cn, H), 7.0, device="cuda")
+        hprev[0], cprev[0] = d(h0), d(c0)
+        if kind == "lstm":
+            if fused:
+                lib.lstm_seq_fwd_x(d(x), d(wih), d(bih), d(whh), d(bhh), d(keep), gates, hprev, hout, cprev, cout, sync, R, Cn, H)
+            else:
+                lib.lstm_seq_fwd(d(gx), d(whh), d(bhh), d(keep), gates, hprev, hout, cprev, cout, sync, R, Cn, H)
+            outs = dict(gates=gates, hout=hout, cout=cout, hprev=hprev, cprev=cprev)
+        else:
+            if fused:
+                lib.gru_seq_fwd_x(d(x), d(wih), d(bih), d(whh), d(bhh), d(keep), gates, hprev, hout, sync, R, Cn, H)
+            else:
+                lib.gru_seq_fwd(d(gx), d(whh), d(bhh), d(keep), gates, hprev, hout, sync, R, Cn, H)
+            outs = dict(gates=gates, hout=hout, hprev=hprev)
+        torch.cuda.synchronize()
+        assert int(sync[128]) == 0, "pass aborted"
+        return outs
+
+    a, b = run(True), run(False)
+    for k in b:
+        np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), atol=4e-6, rtol=2e-5, err_msg=k)
