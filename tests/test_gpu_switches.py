@@ -1,5 +1,5 @@
 """Every A/B switch of the network kernels (SF_CONV1_BF16, SF_CONV1_IMG, SF_DGRAD_PIX, SF_WGRAD_GLDS, SF_WGRAD_IMG, SF_RELU_MASK, SF_GLDS_CFG,
-SF_FWD_IMG, SF_GLDS_SPLITK — read once per process) selects a different kernel for the same operation; each must pass
+SF_FWD_IMG, SF_GLDS_SPLITK, SF_LINEAR_NARROW, SF_REDUCE_TREE; recurrent passes: SF_SEQ_BWD_REGW, SF_SEQ_FWD_X — read once per process) selects a different kernel for the same operation; each must pass
 the same kernel-vs-torch tests as the default dispatch.  One pytest subprocess per group of independent (different
 operation) non-default settings; the two tests that assert which kernel / plan the DEFAULT dispatch picks are left out
 where the switch under test changes exactly that."""
@@ -20,6 +20,8 @@ GROUPS = [
     # ... and conv1 on the f32 strip-image kernels instead of the exact-product bf16 ones
     ("SF_CONV1_BF16=0 SF_DGRAD_PIX=2 SF_WGRAD_GLDS=2 SF_WGRAD_IMG=0 SF_GLDS_CFG=2", ""),
     ("SF_DGRAD_PIX=3 SF_WGRAD_GLDS=3 SF_WGRAD_IMG=1 SF_RELU_MASK=0 SF_GLDS_SPLITK=0", " and not splitk_small_grids and not relu_sign_bits"),
+    # the tiled kernels for the narrow / small linear layers, the serial reduction of partials
+    ("SF_LINEAR_NARROW=0 SF_REDUCE_TREE=0", " and not narrow_linear"),
 ]
 
 
@@ -34,11 +36,13 @@ def test_kernel_numerics_under_non_default_switches(switches, minus):
 
 
 def test_rnn_sequence_passes_with_lds_weight_backward():
-    """SF_SEQ_BWD_REGW=0: the backward sequence passes with the W_hh slice in LDS (16 hidden units per work-group; the
-    dispatch for row groups of more than 64 rows) must pass the same fused-sequence tests as the register-weight ones"""
-    env = dict(os.environ, SF_SEQ_BWD_REGW="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rl_kernels.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "fused_lstm_sequence or fused_gru_sequence", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
+    """SF_SEQ_BWD_REGW=0 SF_SEQ_FWD_X=0: the backward sequence passes with the W_hh slice in LDS (16 hidden units per
+    work-group; the dispatch for row groups of more than 64 rows) and the forward passes fed by a separate gx GEMM must pass
+    the same fused-sequence tests and the config-5 reference replays as the default kernels"""
+    env = dict(os.environ, SF_SEQ_BWD_REGW="0", SF_SEQ_FWD_X="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rl_kernels.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_parity_c2_c5.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "fused_lstm_sequence or fused_gru_sequence or config5", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     tail = r.stdout[-1500:]
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, f"{tail}\n{r.stderr[-500:]}"
