@@ -1166,7 +1166,7 @@ static int occ_wgrad_glds() {
 }
 static inline int wgrad_bn(int N) { return N <= 32 ? 32 : 64; }
 struct WgradGlds {
-    int cfg;  // 0: 256x64 (waves 4x1), 1: 128x128 (2x2), 2: 128x64 (2x2)
+    int cfg;  // 0: 256x64 (waves 4x1), 1: 128x128 (2x2), 2: 128x64 (2x2), 3: 64x128 (2x2; K = 64: the recurrent input projection)
     int BK, BN, Z;
     int64_t m_per_split;
 };
@@ -1177,12 +1177,13 @@ static WgradGlds plan_wgrad_glds(int64_t Mtot, int K, int N, bool query_occupanc
     const bool k256 = K >= 256 && (K + 255) / 256 * 256 <= (K + 127) / 128 * 128;
     q.cfg = N >= 128 ? 1 : (k256 ? 0 : 2);
     if (force >= 2) q.cfg = force - 2;
-    q.BK = q.cfg == 0 ? 256 : 128;
-    q.BN = q.cfg == 1 ? 128 : 64;
+    if (K == 64 && N >= 128) q.cfg = 3;  // a 128-row weight tile would be half padding
+    q.BK = q.cfg == 0 ? 256 : q.cfg == 3 ? 64 : 128;
+    q.BN = (q.cfg == 1 || q.cfg == 3) ? 128 : 64;
     int bpc = 0;
     if (query_occupancy)
         bpc = q.cfg == 0 ? occ_wgrad_glds<256, 64, 4, 1>() : q.cfg == 1 ? occ_wgrad_glds<128, 128, 2, 2>()
-                                                                        : occ_wgrad_glds<128, 64, 2, 2>();
+              : q.cfg == 3 ? occ_wgrad_glds<64, 128, 2, 2>() : occ_wgrad_glds<128, 64, 2, 2>();
     const SplitPlan p = plan_splits(Mtot, K, N, q.BK, q.BN, bpc);
     q.Z = p.Z;
     q.m_per_split = p.m_per_split;
@@ -1196,6 +1197,8 @@ static WgradGlds plan_wgrad_glds(int64_t Mtot, int K, int N, bool query_occupanc
 static bool wgrad_glds_wanted(int64_t Mtot, int K, int N) {
     static const int64_t v = getenv("SF_WGRAD_GLDS_MIN") ? atoll(getenv("SF_WGRAD_GLDS_MIN")) : -1;
     if (v >= 0) return Mtot >= v;
+    static const int k64 = getenv("SF_WGRAD_GLDS_K64") ? atoi(getenv("SF_WGRAD_GLDS_K64")) : 1;
+    if (k64 && Mtot >= 16384 && K == 64 && N >= 512) return true;  // W_ih of a recurrent core behind a 64-wide encoder
     return Mtot >= 65536 || (Mtot >= 16384 && N >= 64 && (K >= 1024 || (int64_t)K * N >= 512 * 1024));
 }
 
@@ -1347,7 +1350,8 @@ static int conv_wgrad_impl(const void *in, int64_t in_sample_stride, const int32
 #define WGRAD_GLDS(BK_, BN_, WM_, WN_)                                                                      \
     k_wgrad_glds<BK_, BN_, WM_, WN_><<<gq, dim3(256), 0, st>>>(g, inf, in_sample_stride, dout, partial_w,   \
                                                               db ? partial_b : nullptr, Mtot, q.m_per_split)
-        if (q.cfg == 0) WGRAD_GLDS(256, 64, 4, 1);
+        if (q.cfg == 3) WGRAD_GLDS(64, 128, 2, 2);
+        else if (q.cfg == 0) WGRAD_GLDS(256, 64, 4, 1);
         else if (q.cfg == 1) WGRAD_GLDS(128, 128, 2, 2);
         else WGRAD_GLDS(128, 64, 2, 2);
     } else {
@@ -1388,6 +1392,13 @@ static bool linear_dgrad_glds_ok(const ConvG &g, int64_t n) {
     return g.H == 1 && g.W == 1 && g.KH == 1 && g.KW == 1 && g.Cout % 32 == 0 && g.Cin >= 128 &&
            cdiv64(n, 128) * (int64_t)cdiv64(g.Cin, 128) >= 512;
 }
+// ... and narrow ones (Cin == 64 behind a deep reduction: the data gradient of a recurrent core's input projection,
+// 16384 x 2048 -> 64): 128-row tiles are 128 work-groups, half the chip; 64 x 64 tiles fill it
+static bool linear_dgrad_glds64_ok(const ConvG &g, int64_t n) {
+    static const int on = getenv("SF_DGRAD_LINEAR64") ? atoi(getenv("SF_DGRAD_LINEAR64")) : 1;
+    return on && g.H == 1 && g.W == 1 && g.KH == 1 && g.KW == 1 && g.Cout % 32 == 0 && g.Cout >= 512 && g.Cin == 64 &&
+           n >= 8192;
+}
 extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                              const sf_conv_desc *h_desc, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_dgrad");
@@ -1413,6 +1424,13 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
         sf_conv_desc d2 = linear_desc(g.Cout, g.Cin, g.relu);  // reduction = Cout, columns = Cin, relu = kind of in_act
         const ConvG g2 = make_geom(&d2);
         k_fwd_glds<128, 128, 2, 2, 2><<<dim3(cdiv64(n, 128), cdiv64(g.Cin, 128), 1), dim3(256), 0, st>>>(
+            g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1);
+        return sf_launch_status("sf_conv_dgrad");
+    }
+    if (lin_on && linear_dgrad_glds64_ok(g, n) && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+        sf_conv_desc d2 = linear_desc(g.Cout, g.Cin, g.relu);
+        const ConvG g2 = make_geom(&d2);
+        k_fwd_glds<64, 64, 2, 2, 2><<<dim3(cdiv64(n, 64), 1, 1), dim3(256), 0, st>>>(
             g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1);
         return sf_launch_status("sf_conv_dgrad");
     }
@@ -1474,7 +1492,7 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         snprintf(out, cap, wgrad_img_variant(h_desc, n) == 1 ? "k_wgrad_img<64, 9, 9, 3, 1, 1>" : "k_wgrad_img<32, 20, 20, 4, 2, 2>");
     } else if (op == 1 && mode == MODE_F32 && wgrad_glds_wanted(Mtot, g.K, g.Cout) && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
-        snprintf(out, cap, q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"
+        snprintf(out, cap, q.cfg == 3 ? "k_wgrad_glds<64, 128, 2, 2>" : q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"
                                                                                   : "k_wgrad_glds<128, 64, 2, 2>");
     } else if (op == 1) {
         if (wgrad_bn(g.Cout) == 32) snprintf(out, cap, "k_conv_wgrad<32, 4, 1, %d>", mode);
@@ -1484,6 +1502,7 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         const int64_t Mc = n * Hc * Wc;
         const char *v = g.vecB ? "true" : "false";
         if (g.vecB && linear_dgrad_glds_ok(g, n)) snprintf(out, cap, "k_fwd_glds<128, 128, 2, 2, 2>");
+        else if (g.vecB && linear_dgrad_glds64_ok(g, n)) snprintf(out, cap, "k_fwd_glds<64, 64, 2, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
             snprintf(out, cap, "k_dgrad_quadrow<128, 128, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024)

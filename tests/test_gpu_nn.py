@@ -355,7 +355,8 @@ def test_conv1_exact_product_kernels_on_integers(lib):
 
 
 @pytest.mark.parametrize("M,K,N", [(4096, 3136, 512), (257, 512, 7), (64, 8, 32), (33, 27, 5), (1000, 64, 64),
-                                   (16384, 27, 64), (70001, 64, 17)])  # (K, N <= 64: k_linear_wgrad_small)
+                                   (16384, 27, 64), (70001, 64, 17),   # (K, N <= 64: k_linear_wgrad_small)
+                                   (16384, 64, 2048), (16399, 64, 1536)])  # (W_ih of a recurrent core: 64-row weight tiles / 64-row dgrad tiles)
 def test_linear_fwd_bwd_vs_torch(lib, M, K, N):
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn((M, K), generator=g)
