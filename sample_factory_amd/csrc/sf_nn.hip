@@ -1116,6 +1116,24 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     }
     return sf_launch_status("sf_conv_fwd_t");
 }
+// two linear layers into one accumulator (k_fwd_glds2): out = a1 w1t^T + a2 w2t^T + bias1 + bias2
+extern "C" int sf_linear_fwd_dual_supported(int64_t n, int N, int K1, int K2) {
+    static const int on = getenv("SF_LINEAR_DUAL") ? atoi(getenv("SF_LINEAR_DUAL")) : 1;
+    return on && n > 0 && N >= 64 && K1 > 0 && K2 > 0 && K1 % 32 == 0 && K2 % 32 == 0 && n < (1LL << 31) &&
+           cdiv64(n, 128) * (int64_t)cdiv64(N, 64) >= 256;
+}
+extern "C" int sf_linear_fwd_dual(const float *a1, int64_t lda1, const float *w1t, const float *bias1, int K1,
+                                  const float *a2, int64_t lda2, const float *w2t, const float *bias2, int K2, float *out,
+                                  int64_t n, int N, void *stream) {
+    SF_REQUIRE(a1 && w1t && a2 && w2t && out && n > 0 && N > 0, "sf_linear_fwd_dual: bad args");
+    SF_REQUIRE(K1 > 0 && K2 > 0 && K1 % 32 == 0 && K2 % 32 == 0 && lda1 % 4 == 0 && lda2 % 4 == 0 && n < (1LL << 31),
+               "sf_linear_fwd_dual: K1, K2 must be multiples of 32 and the row strides multiples of 4 (K1=%d K2=%d)", K1, K2);
+    SF_REQUIRE((((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)w1t | (uintptr_t)w2t) & 15) == 0,
+               "sf_linear_fwd_dual: operands must be 16-byte aligned");
+    k_fwd_glds2<128, 64, 2, 2><<<dim3(cdiv64(n, 128), cdiv64(N, 64)), dim3(256), 0, STREAM(stream)>>>(
+        a1, lda1, w1t, bias1, K1, a2, lda2, w2t, bias2, K2, out, n, N);
+    return sf_launch_status("sf_linear_fwd_dual");
+}
 extern "C" int sf_transpose(const float *w, float *wt, int K, int N, void *stream) {
     SF_REQUIRE(w && wt && K > 0 && N > 0, "sf_transpose: bad args");
     k_transpose<<<dim3(cdiv64(K, 32), cdiv64(N, 32)), dim3(256), 0, STREAM(stream)>>>(w, wt, K, N);

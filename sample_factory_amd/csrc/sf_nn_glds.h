@@ -237,6 +237,94 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     }
 }
 
+// out[m][n] = sum_k A1[m][k] W1t[n][k] + sum_k A2[m][k] W2t[n][k] + bias1[n] + bias2[n]: TWO linear layers into one
+// accumulator (one inference step of an LSTM: x W_ih^T + h W_hh^T + b_ih + b_hh; sf_linear_fwd_dual).  The k_fwd_glds
+// pipeline with a segment switch per 32-chunk: chunks below K1 stream (A1, W1t), the rest (A2, W2t) — the short first
+// product (K1 = 64: two chunks) rides in the long one's pipeline instead of being a launch of its own that is all fill
+// and drain.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_fwd_glds2(const float *__restrict__ a1, int64_t lda1, const float *__restrict__ w1t,
+                                                   const float *__restrict__ bias1, int K1, const float *__restrict__ a2,
+                                                   int64_t lda2, const float *__restrict__ w2t,
+                                                   const float *__restrict__ bias2, int K2, float *__restrict__ out,
+                                                   int64_t Mtot, int N) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int STAGE = (BM + BN) * 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per block");
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int K = K1 + K2;
+    const int lrow = lane >> 3, lpos = lane & 7;
+    const float *as1[AI], *as2[AI], *bs1[BI], *bs2[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int64_t m = m0 + row;
+        m = m < Mtot ? m : Mtot - 1;
+        const int sw = (lpos ^ ((row >> 1) & 7)) << 2;
+        as1[i] = a1 + m * lda1 + sw;
+        as2[i] = a2 + m * lda2 + sw - K1;  // indexed with the global k
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int row = (i * 4 + wave) * 8 + lrow;
+        int n = n0 + row;
+        n = n < N ? n : N - 1;
+        const int sw = (lpos ^ ((row >> 1) & 7)) << 2;
+        bs1[i] = w1t + (int64_t)n * K1 + sw;
+        bs2[i] = w2t + (int64_t)n * K2 + sw - K1;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < TN; ++b_)
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+    auto issue = [&](int k0, int stage) {
+        float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
+        const bool first = k0 < K1;  // (uniform)
+#pragma unroll
+        for (int i = 0; i < AI; ++i) GLDS16((first ? as1[i] : as2[i]) + k0, sa + (i * 4 + wave) * 256);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16((first ? bs1[i] : bs2[i]) + k0, sb + (i * 4 + wave) * 256);
+    };
+    issue(0, 0);
+    int stage = 0, k0 = 0;
+    for (; k0 + 32 < K; k0 += 32, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BARRIER_NOFENCE();
+        issue(k0 + 32, stage ^ 1);
+        const float *sa = lds + stage * STAGE;
+        mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BARRIER_NOFENCE();
+    {
+        const float *sa = lds + stage * STAGE;
+        mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
+    }
+    // epilogue: (acc + bias1) + bias2, the order of "x W_ih^T + b_ih" + "h W_hh^T + b_hh" up to the product sums
+    const int lcol = lane & 31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + lcol;
+        if (col >= N) continue;
+        const float b1 = bias1 ? bias1[col] : 0.f, b2 = bias2 ? bias2[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * TM * 32 + tm * 32 + FRAG_ROW(r, lane);
+                if (row < Mtot) out[row * N + col] = (acc[tm][tn][r] + b1) + b2;
+            }
+    }
+}
+
 // wt[n][k] = w[k][n]  (weights are kept K-major for the data-gradient; the glds forward wants them Cout-major)
 __global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ w, float *__restrict__ wt, int K, int N) {
     __shared__ float t[32][33];

@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 13; }
+extern "C" int sf_abi_version(void) { return 14; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -2008,12 +2008,21 @@ __global__ __launch_bounds__(256) void k_rnn_cell_fwd(int kind, const float *__r
         h_out[i] = h;
         if (h_next) h_next[i] = h * k;
     } else {
-        const float *x = gx + c * 4 * H, *g = gh + c * 4 * H;
+        const float *x = gx + c * 4 * H;
         const float cp = c_prev[c * ld_c + j];
-        const float ig = sigmoidf_(x[j] + g[j]);
-        const float fg = sigmoidf_(x[H + j] + g[H + j]);
-        const float gg = tanhf(x[2 * H + j] + g[2 * H + j]);
-        const float og = sigmoidf_(x[3 * H + j] + g[3 * H + j]);
+        float ig, fg, gg, og;
+        if (gh) {
+            const float *g = gh + c * 4 * H;
+            ig = sigmoidf_(x[j] + g[j]);
+            fg = sigmoidf_(x[H + j] + g[H + j]);
+            gg = tanhf(x[2 * H + j] + g[2 * H + j]);
+            og = sigmoidf_(x[3 * H + j] + g[3 * H + j]);
+        } else {  // gx already holds x W_ih^T + b_ih + h W_hh^T + b_hh (sf_linear_fwd_dual)
+            ig = sigmoidf_(x[j]);
+            fg = sigmoidf_(x[H + j]);
+            gg = tanhf(x[2 * H + j]);
+            og = sigmoidf_(x[3 * H + j]);
+        }
         const float cn = fg * cp + ig * gg;
         const float h = og * tanhf(cn);
         if (gates_out) {
@@ -2030,7 +2039,7 @@ __global__ __launch_bounds__(256) void k_rnn_cell_fwd(int kind, const float *__r
 extern "C" int sf_rnn_cell_fwd(int kind, const float *gx, const float *gh, const float *h_prev, int64_t ld_h,
                                const float *c_prev, int64_t ld_c, const float *keep, int C, int H, float *gates_out,
                                float *h_out, float *c_out, float *h_next, float *c_next, void *stream) {
-    SF_REQUIRE((kind == 0 || kind == 1) && gx && gh && h_prev && h_out && C > 0 && H > 0, "sf_rnn_cell_fwd: bad args");
+    SF_REQUIRE((kind == 0 || kind == 1) && gx && (gh || kind == 1) && h_prev && h_out && C > 0 && H > 0, "sf_rnn_cell_fwd: bad args");
     SF_REQUIRE(kind == 0 || (c_prev && c_out), "sf_rnn_cell_fwd: LSTM needs c_prev and c_out");
     const int64_t n = (int64_t)C * H;
     k_rnn_cell_fwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(

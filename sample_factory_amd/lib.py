@@ -39,7 +39,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_train_summaries", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd", "sf_seq_fwd_x_supported", "sf_lstm_seq_fwd_x", "sf_gru_seq_fwd_x",
+    "sf_adam_step", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd", "sf_seq_fwd_x_supported", "sf_lstm_seq_fwd_x", "sf_gru_seq_fwd_x", "sf_linear_fwd_dual_supported", "sf_linear_fwd_dual",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_copy_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
@@ -348,6 +348,20 @@ def gru_seq_fwd(gx, whh, bhh, keep, gates, hprev, hout, sync, R, Cn, H, env_majo
                                      ptr(keep, "f32", "keep"), ptr(gates, "f32", "gates"), ptr(hprev, "f32", "hprev"),
                                      ptr(hout, "f32", "hout"), ptr(sync, "i32", "sync"), int(R), int(Cn), int(H),
                                      int(bool(env_major)), stream()), "sf_gru_seq_fwd")
+
+
+def linear_fwd_dual_supported(n: int, N: int, K1: int, K2: int) -> bool:
+    return bool(load().sf_linear_fwd_dual_supported(i64(n), int(N), int(K1), int(K2)))
+
+
+def linear_fwd_dual(a1, lda1, w1t, bias1, a2, lda2, w2t, bias2, out, n) -> None:
+    """out [n, N] = a1 w1t^T + a2 w2t^T + bias1 + bias2 (a_i: row-strided views, w_it: [N, K_i])"""
+    N, K1, K2 = int(w1t.shape[0]), int(w1t.shape[1]), int(w2t.shape[1])
+    key = None if PROFILE is None else ("fwd_dual", int(n), K1 + K2, 1, 1, N, 1, 1, 1, 1, "k_fwd_glds2<128, 64, 2, 2>")
+    with _timed(key):
+        _check(load().sf_linear_fwd_dual(_raw(a1, "f32", "a1"), i64(lda1), ptr(w1t, "f32", "w1t"), ptr(bias1, "f32", "bias1"), K1,
+                                         _raw(a2, "f32", "a2"), i64(lda2), ptr(w2t, "f32", "w2t"), ptr(bias2, "f32", "bias2"), K2,
+                                         ptr(out, "f32", "out"), i64(n), N, stream()), "sf_linear_fwd_dual")
 
 
 def seq_fwd_x_supported(Cn: int, H: int, Kx: int) -> bool:

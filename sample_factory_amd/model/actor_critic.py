@@ -554,7 +554,13 @@ class ActorCritic:
                 # BPTT pass whose fused sequence kernel can also do the input projection (sf_*_seq_fwd_x): no GEMM launch,
                 # no [n, G*H] round trip through memory for gx
                 fuse_x = lib.lstm_seq_supported(n // rnn["R"], self.rnn_H) and lib.seq_fwd_x_supported(n // rnn["R"], self.rnn_H, L.K)
-            if mask is None and not fuse_x:
+            fuse_dual = False
+            if L.role == "rnn_ih" and rnn is not None and not seq and self.rnn_kind == 1 and idx is None and not tT:
+                # one LSTM inference step: x W_ih^T and h W_hh^T into ONE accumulator (sf_linear_fwd_dual) — the 64-deep
+                # input projection was a launch of its own that is all fill and drain
+                fuse_dual = (self._wb(li, tag)[2] is not None and self._wb(li + 1, tag)[2] is not None and
+                             lib.linear_fwd_dual_supported(n, L.N, L.K, self.rnn_H))
+            if mask is None and not fuse_x and not fuse_dual:
                 self._gemm(li, x, stride, idx, off, tT, out, n, tag)
             if li == 0:
                 self._relu_mask0 = mask if tag == "train" else getattr(self, "_relu_mask0", None)
@@ -564,6 +570,9 @@ class ActorCritic:
                 if fuse_x:
                     acts[li] = None  # gx is never materialised
                     x = self._rnn_sequence_fwd(li, None, n, rnn, tag, x_tm=inputs[li])
+                elif fuse_dual:
+                    acts[li] = None
+                    x = self._rnn_step(li, None, n, rnn, tag, x_in=inputs[li], x_stride=stride)
                 else:
                     x = self._rnn_sequence_fwd(li, out, n, rnn, tag) if seq else self._rnn_step(li, out, n, rnn, tag)
             stride, idx, off, tT = x.numel() // n, None, 0, 0  # elements per sample of the activation just produced
@@ -573,14 +582,18 @@ class ActorCritic:
         return acts
 
     # ------------------------------------------------------------------------------------------ recurrent core
-    def _rnn_step(self, li, gx, n, rnn, tag):
+    def _rnn_step(self, li, gx, n, rnn, tag, x_in=None, x_stride=0):
         """one inference step: (gx, h W_hh^T + b_hh) -> cell -> new state (model/core.py:37-64)"""
         Lh, H, S, kind = self.layers[li + 1], self.rnn_H, self.rnn_S, self.rnn_kind
         st = rnn["states"]
         assert st.shape == (n, S) and st.stride(1) == 1
         gh = self._buf((tag, "gh"), (n, Lh.N))
         w_hh, b_hh, wt_hh = self._wb(li + 1, tag)
-        if wt_hh is not None and lib.conv_fwd_t_supported(n, Lh.desc):  # LDS-DMA GEMM (2048 envs x 512 x 2048 fills the chip)
+        if x_in is not None:  # LSTM: both projections and both biases in one launch, gh (the buffer) = the full pre-activation
+            _, b_ih, wt_ih = self._wb(li, tag)
+            lib.linear_fwd_dual(x_in, x_stride, wt_ih, b_ih, st, st.stride(0), wt_hh, b_hh, gh, n)
+            gx, gh = gh, None
+        elif wt_hh is not None and lib.conv_fwd_t_supported(n, Lh.desc):  # LDS-DMA GEMM (2048 envs x 512 x 2048 fills the chip)
             wsb = lib.conv_fwd_t_workspace(n, Lh.desc)
             lib.conv_fwd_t(st, st.stride(0), wt_hh, b_hh, gh, n, Lh.desc, self._workspace(wsb) if wsb else None)
         else:

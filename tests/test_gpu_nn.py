@@ -1704,3 +1704,27 @@ def test_narrow_linear_forward_vs_torch(lib, n, K, N, act):
     lib.conv_fwd_t(big[:, 1], 2 * K, wt, None, out2, n, d)
     ref2 = f(big[:, 1].cpu().double() @ w.double())
     assert (out2.cpu().double() - ref2).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("n,N,K1,K2", [(2048, 2048, 64, 512), (4096, 1024, 32, 256), (2050, 2000, 64, 512), (32768, 64, 96, 32)])
+def test_dual_linear_forward_vs_torch(lib, n, N, K1, K2):
+    """sf_linear_fwd_dual (k_fwd_glds2: two linear layers into one accumulator, the segment switched per 32-chunk of the
+    LDS-DMA pipeline; one LSTM inference step's x W_ih^T + h W_hh^T + b_ih + b_hh): against float64, row-strided second
+    operand (a slab column), ragged row / column tiles, NULL biases; rows past the end are not written."""
+    g = torch.Generator().manual_seed(n + N + K1)
+    a1 = torch.randn((n, K1), generator=g)
+    big = torch.randn((n, 3, K2 + 8), generator=g)  # a2 = big[:, 1, :K2]: row stride 3 * (K2 + 8)
+    w1, w2 = torch.randn((N, K1), generator=g) / np.sqrt(K1), torch.randn((N, K2), generator=g) / np.sqrt(K2)
+    b1, b2 = torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g) * 0.1
+    assert lib.linear_fwd_dual_supported(n, N, K1, K2) and not lib.linear_fwd_dual_supported(n, N, K1 + 8, K2)
+    bigd = big.cuda()
+    a2v = bigd[:, 1, :K2]
+    out = torch.full((n + 2, N), 7.0, device="cuda")
+    lib.linear_fwd_dual(a1.cuda(), K1, w1.cuda(), b1.cuda(), a2v, a2v.stride(0), w2.cuda(), b2.cuda(), out, n)
+    ref = a1.double() @ w1.double().t() + big[:, 1, :K2].double() @ w2.double().t() + b1.double() + b2.double()
+    tol = 3e-6 * max(1.0, ref.abs().max().item())
+    assert (out[:n].cpu().double() - ref).abs().max().item() < tol
+    assert (out[n:] == 7.0).all(), "rows past the end must not be written"
+    out2 = torch.empty((n, N), device="cuda")
+    lib.linear_fwd_dual(a1.cuda(), K1, w1.cuda(), None, a2v, a2v.stride(0), w2.cuda(), None, out2, n)
+    assert (out2.cpu().double() - (ref - b1.double() - b2.double())).abs().max().item() < tol

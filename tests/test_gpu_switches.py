@@ -36,10 +36,11 @@ def test_kernel_numerics_under_non_default_switches(switches, minus):
 
 
 def test_rnn_sequence_passes_with_lds_weight_backward():
-    """SF_SEQ_BWD_REGW=0 SF_SEQ_FWD_X=0: the backward sequence passes with the W_hh slice in LDS (16 hidden units per
-    work-group; the dispatch for row groups of more than 64 rows) and the forward passes fed by a separate gx GEMM must pass
-    the same fused-sequence tests and the config-5 reference replays as the default kernels"""
-    env = dict(os.environ, SF_SEQ_BWD_REGW="0", SF_SEQ_FWD_X="0")
+    """SF_SEQ_BWD_REGW=0 SF_SEQ_FWD_X=0 SF_LINEAR_DUAL=0 SF_WGRAD_GLDS_K64=0 SF_DGRAD_LINEAR64=0: the backward sequence
+    passes with the W_hh slice in LDS (16 hidden units per work-group; the dispatch for row groups of more than 64 rows), the
+    forward passes fed by a separate gx GEMM, the inference step as two projections and the input projection's gradients on
+    the general kernels must pass the same fused-sequence tests and the config-5 reference replays as the default kernels"""
+    env = dict(os.environ, SF_SEQ_BWD_REGW="0", SF_SEQ_FWD_X="0", SF_LINEAR_DUAL="0", SF_WGRAD_GLDS_K64="0", SF_DGRAD_LINEAR64="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rl_kernels.py"),
                         os.path.join(ROOT, "tests", "test_gpu_parity_c2_c5.py"), "-q", "-x", "-m", "gpu",
                         "-k", "fused_lstm_sequence or fused_gru_sequence or config5", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
