@@ -37,6 +37,17 @@ def main():
         ws = torch.empty(nb, dtype=torch.uint8, device="cuda") if nb else None
         f = lambda i: lib.conv_fwd_t(xs[i], stride, wt, b, outs[i % 2], n, d, ws)
         hot, cold = bench(lambda i: f(0), 1), bench(f, NB)
+        # ... and right behind a kernel that has just WRITTEN the input (dirty lines in L2 / Infinity Cache, write-backs in
+        # flight), as in the step where the previous layer produced it: events around the consumer only
+        evs = []
+        for i in range(12):
+            xs[i % NB].mul_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(i % NB); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        fresh = sum(a.elapsed_time(b) for a, b in evs[2:]) / len(evs[2:]) * 1e3
+        print(f"{name:6s} behind a producer of its input: {fresh:8.1f} us", flush=True)
         print(f"{name:6s} fwd_t  n={n}: hot {hot:8.1f} us   cold (rotating {NB} x {xs[0].numel() * 4 / 1e6:.0f} MB inputs) {cold:8.1f} us   {lib.conv_kernel_name(3, n, d)}", flush=True)
 
 
