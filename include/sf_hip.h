@@ -87,8 +87,9 @@ int sf_obsnorm_apply(const void *in, int in_u8, int64_t stride, const int32_t *i
  * model/core.py:19-64 (ModelCoreRNN over torch.nn.GRU / nn.LSTM, one layer); learner.py:557-581 +
  * rnn_utils.py:114-158 (BPTT over recurrence-length chunks; PackedSequence there, a masked time loop here — the
  * equivalence is the reference's own tests/algo/test_rnn.py).  kind 0 = GRU (gate order r,z,n), 1 = LSTM (i,f,g,o),
- * torch's parameter layout.  gx = x W_ih^T + b_ih, gh = h W_hh^T + b_hh come from sf_conv_fwd (1x1) launches; LSTM only:
- * gh == NULL means gx already is the complete pre-activation gx + gh (one sf_linear_fwd_dual launch).
+ * torch's parameter layout.  gx = x W_ih^T + b_ih, gh = h W_hh^T + b_hh come from sf_conv_fwd (1x1) launches; gh == NULL:
+ * gx is the output of ONE sf_linear_fwd_dual launch — LSTM: the complete pre-activation gx + gh [C,4H]; GRU (gru_H = H):
+ * [C,4H] = {r and z pre-activations with both parts summed, x W_in^T + b_in, h W_hn^T + b_hn}.
  * fwd: gates_out [C,4H] (GRU {r,z,n,W_hn h + b_hn}; LSTM {i,f,g,o}; NULL at inference), h_out/c_out = new state,
  *      h_next/c_next = new state * keep[c] (keep = 1 - done_or_invalid, learner.py:561; NULL = keep everything).
  * bwd: dh = dL/dh_out of this step (output gradient + masked carry), dc_in = carry into c_out (LSTM); writes dgx, dgh
@@ -448,12 +449,14 @@ int sf_tanh_scale_bwd(float *g, const float *y, int ld, int64_t n, int col0, int
  * floats apart; w_it: [N][K_i], i.e. torch's own Linear / LSTM weight layout; biases may be NULL).  One inference step
  * of model/core.py:37-64's nn.LSTM is this launch on (x, weight_ih_l0, bias_ih_l0) and (h, weight_hh_l0, bias_hh_l0)
  * followed by sf_rnn_cell_fwd(gh = NULL): the short first product (K1 = 64) rides in the pipeline of the long one instead
- * of being a launch of its own.  K1, K2 multiples of 32; sf_linear_fwd_dual_supported: the launch fills the chip (else
- * use two sf_conv_fwd launches). */
+ * of being a launch of its own.  gru_H > 0 (nn.GRU, N = 4 * gru_H, w_it = weight_{ih,hh}_l0 [3H][K_i]): the candidate
+ * gate's two parts stay apart — columns [0,2H) both products + both biases, [2H,3H) the first layer's rows 2H.. only,
+ * [3H,4H) the second layer's rows 2H.. only — which is what sf_rnn_cell_fwd(kind 0, gh = NULL) reads.  K1, K2 multiples of
+ * 32; sf_linear_fwd_dual_supported: the launch fills the chip (else use two sf_conv_fwd launches). */
 int sf_linear_fwd_dual_supported(int64_t n, int N, int K1, int K2);
 int sf_linear_fwd_dual(const float *a1, int64_t lda1, const float *w1t, const float *bias1, int K1, const float *a2,
                        int64_t lda2, const float *w2t, const float *bias2, int K2, float *out, int64_t n, int N,
-                       void *stream);
+                       int gru_H, void *stream);
 
 /* Forward for the dense hot layers through the gfx950 LDS-DMA path: same result contract as sf_conv_fwd, but the
  * weights are given Cout-major, wt[Cout, K] (sf_transpose of the canonical [K, Cout] array), the input must be f32

@@ -1124,14 +1124,16 @@ extern "C" int sf_linear_fwd_dual_supported(int64_t n, int N, int K1, int K2) {
 }
 extern "C" int sf_linear_fwd_dual(const float *a1, int64_t lda1, const float *w1t, const float *bias1, int K1,
                                   const float *a2, int64_t lda2, const float *w2t, const float *bias2, int K2, float *out,
-                                  int64_t n, int N, void *stream) {
+                                  int64_t n, int N, int gru_H, void *stream) {
     SF_REQUIRE(a1 && w1t && a2 && w2t && out && n > 0 && N > 0, "sf_linear_fwd_dual: bad args");
     SF_REQUIRE(K1 > 0 && K2 > 0 && K1 % 32 == 0 && K2 % 32 == 0 && lda1 % 4 == 0 && lda2 % 4 == 0 && n < (1LL << 31),
                "sf_linear_fwd_dual: K1, K2 must be multiples of 32 and the row strides multiples of 4 (K1=%d K2=%d)", K1, K2);
     SF_REQUIRE((((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)w1t | (uintptr_t)w2t) & 15) == 0,
                "sf_linear_fwd_dual: operands must be 16-byte aligned");
+    SF_REQUIRE(gru_H == 0 || (gru_H > 0 && gru_H % 64 == 0 && N == 4 * gru_H),
+               "sf_linear_fwd_dual: the GRU column layout needs N == 4 * gru_H and gru_H %% 64 == 0 (N=%d gru_H=%d)", N, gru_H);
     k_fwd_glds2<128, 64, 2, 2><<<dim3(cdiv64(n, 128), cdiv64(N, 64)), dim3(256), 0, STREAM(stream)>>>(
-        a1, lda1, w1t, bias1, K1, a2, lda2, w2t, bias2, K2, out, n, N);
+        a1, lda1, w1t, bias1, K1, a2, lda2, w2t, bias2, K2, out, n, N, gru_H);
     return sf_launch_status("sf_linear_fwd_dual");
 }
 extern "C" int sf_transpose(const float *w, float *wt, int K, int N, void *stream) {

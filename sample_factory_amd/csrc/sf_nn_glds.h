@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds2(const float *__restrict__ a1,
                                                    const float *__restrict__ bias1, int K1, const float *__restrict__ a2,
                                                    int64_t lda2, const float *__restrict__ w2t,
                                                    const float *__restrict__ bias2, int K2, float *__restrict__ out,
-                                                   int64_t Mtot, int N) {
+                                                   int64_t Mtot, int N, int gru_H) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;
@@ -257,7 +257,12 @@ __global__ __launch_bounds__(256) void k_fwd_glds2(const float *__restrict__ a1,
     const int wm = wave / WN, wn = wave % WN;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int K = K1 + K2;
+    // gru_H > 0 (one GRU inference step, N = 4*gru_H, BN divides gru_H): columns [0, 2H) = x W_i{r,z}^T + h W_h{r,z}^T + both
+    // biases; [2H, 3H) = x W_in^T + b_in only; [3H, 4H) = h W_hn^T + b_hn only (weight / bias row n - H of the second layer):
+    // the candidate gate needs its recurrent part separately, n = tanh(x_n + r * h_n).  Uniform per work-group.
+    const bool use1 = gru_H == 0 || n0 < 3 * gru_H, use2 = gru_H == 0 || n0 < 2 * gru_H || n0 >= 3 * gru_H;
+    const int row2_off = (gru_H > 0 && n0 >= 3 * gru_H) ? -gru_H : 0;
+    const int kbeg = use1 ? 0 : K1, K = use2 ? K1 + K2 : K1;
     const int lrow = lane >> 3, lpos = lane & 7;
     const float *as1[AI], *as2[AI], *bs1[BI], *bs2[BI];
 #pragma unroll
@@ -275,8 +280,8 @@ __global__ __launch_bounds__(256) void k_fwd_glds2(const float *__restrict__ a1,
         int n = n0 + row;
         n = n < N ? n : N - 1;
         const int sw = (lpos ^ ((row >> 1) & 7)) << 2;
-        bs1[i] = w1t + (int64_t)n * K1 + sw;
-        bs2[i] = w2t + (int64_t)n * K2 + sw - K1;
+        bs1[i] = w1t + (int64_t)(use1 ? n : 0) * K1 + sw;
+        bs2[i] = w2t + (int64_t)(use2 ? n + row2_off : 0) * K2 + sw - K1;
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -293,8 +298,8 @@ __global__ __launch_bounds__(256) void k_fwd_glds2(const float *__restrict__ a1,
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16((first ? bs1[i] : bs2[i]) + k0, sb + (i * 4 + wave) * 256);
     };
-    issue(0, 0);
-    int stage = 0, k0 = 0;
+    issue(kbeg, 0);
+    int stage = 0, k0 = kbeg;
     for (; k0 + 32 < K; k0 += 32, stage ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BARRIER_NOFENCE();
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds2(const float *__restrict__ a1,
     for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + wn * TN * 32 + tn * 32 + lcol;
         if (col >= N) continue;
-        const float b1 = bias1 ? bias1[col] : 0.f, b2 = bias2 ? bias2[col] : 0.f;
+        const float b1 = (bias1 && use1) ? bias1[col] : 0.f, b2 = (bias2 && use2) ? bias2[col + row2_off] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 14; }
+extern "C" int sf_abi_version(void) { return 15; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -1994,12 +1994,22 @@ __global__ __launch_bounds__(256) void k_rnn_cell_fwd(int kind, const float *__r
     const int j = (int)(i - c * H);
     const float k = keep ? keep[c] : 1.0f;
     if (kind == 0) {
-        const float *x = gx + c * 3 * H, *g = gh + c * 3 * H;
         const float hp = h_prev[c * ld_h + j];
-        const float r = sigmoidf_(x[j] + g[j]);
-        const float z = sigmoidf_(x[H + j] + g[H + j]);
-        const float hn = g[2 * H + j];
-        const float n = tanhf(x[2 * H + j] + r * hn);
+        float r, z, hn, xn;
+        if (gh) {
+            const float *x = gx + c * 3 * H, *g = gh + c * 3 * H;
+            r = sigmoidf_(x[j] + g[j]);
+            z = sigmoidf_(x[H + j] + g[H + j]);
+            hn = g[2 * H + j];
+            xn = x[2 * H + j];
+        } else {  // gx [C, 4H] = {r_pre, z_pre (x and h parts summed), x W_in^T + b_in, h W_hn^T + b_hn} (sf_linear_fwd_dual)
+            const float *x = gx + c * 4 * H;
+            r = sigmoidf_(x[j]);
+            z = sigmoidf_(x[H + j]);
+            xn = x[2 * H + j];
+            hn = x[3 * H + j];
+        }
+        const float n = tanhf(xn + r * hn);
         const float h = (1.0f - z) * n + z * hp;
         if (gates_out) {
             float *go = gates_out + c * 4 * H;
@@ -2039,7 +2049,7 @@ __global__ __launch_bounds__(256) void k_rnn_cell_fwd(int kind, const float *__r
 extern "C" int sf_rnn_cell_fwd(int kind, const float *gx, const float *gh, const float *h_prev, int64_t ld_h,
                                const float *c_prev, int64_t ld_c, const float *keep, int C, int H, float *gates_out,
                                float *h_out, float *c_out, float *h_next, float *c_next, void *stream) {
-    SF_REQUIRE((kind == 0 || kind == 1) && gx && (gh || kind == 1) && h_prev && h_out && C > 0 && H > 0, "sf_rnn_cell_fwd: bad args");
+    SF_REQUIRE((kind == 0 || kind == 1) && gx && h_prev && h_out && C > 0 && H > 0, "sf_rnn_cell_fwd: bad args");
     SF_REQUIRE(kind == 0 || (c_prev && c_out), "sf_rnn_cell_fwd: LSTM needs c_prev and c_out");
     const int64_t n = (int64_t)C * H;
     k_rnn_cell_fwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(

@@ -354,14 +354,16 @@ def linear_fwd_dual_supported(n: int, N: int, K1: int, K2: int) -> bool:
     return bool(load().sf_linear_fwd_dual_supported(i64(n), int(N), int(K1), int(K2)))
 
 
-def linear_fwd_dual(a1, lda1, w1t, bias1, a2, lda2, w2t, bias2, out, n) -> None:
-    """out [n, N] = a1 w1t^T + a2 w2t^T + bias1 + bias2 (a_i: row-strided views, w_it: [N, K_i])"""
-    N, K1, K2 = int(w1t.shape[0]), int(w1t.shape[1]), int(w2t.shape[1])
-    key = None if PROFILE is None else ("fwd_dual", int(n), K1 + K2, 1, 1, N, 1, 1, 1, 1, "k_fwd_glds2<128, 64, 2, 2>")
+def linear_fwd_dual(a1, lda1, w1t, bias1, a2, lda2, w2t, bias2, out, n, gru_H=0) -> None:
+    """out [n, N] = a1 w1t^T + a2 w2t^T + bias1 + bias2 (a_i: row-strided views, w_it: [N, K_i]); gru_H > 0: the GRU layout
+    (w_it [3H, K_i], out [n, 4H], see sf_hip.h)"""
+    N, K1, K2 = int(out.shape[1]), int(w1t.shape[1]), int(w2t.shape[1])
+    # (GRU layout: 3H columns' worth of products spread over 4H output columns)
+    key = None if PROFILE is None else ("fwd_dual", int(n), K1 + K2, 1, 1, 3 * int(gru_H) if gru_H else N, 1, 1, 1, 1, "k_fwd_glds2<128, 64, 2, 2>")
     with _timed(key):
         _check(load().sf_linear_fwd_dual(_raw(a1, "f32", "a1"), i64(lda1), ptr(w1t, "f32", "w1t"), ptr(bias1, "f32", "bias1"), K1,
                                          _raw(a2, "f32", "a2"), i64(lda2), ptr(w2t, "f32", "w2t"), ptr(bias2, "f32", "bias2"), K2,
-                                         ptr(out, "f32", "out"), i64(n), N, stream()), "sf_linear_fwd_dual")
+                                         ptr(out, "f32", "out"), i64(n), N, int(gru_H), stream()), "sf_linear_fwd_dual")
 
 
 def seq_fwd_x_supported(Cn: int, H: int, Kx: int) -> bool:

@@ -555,11 +555,11 @@ class ActorCritic:
                 # no [n, G*H] round trip through memory for gx
                 fuse_x = lib.lstm_seq_supported(n // rnn["R"], self.rnn_H) and lib.seq_fwd_x_supported(n // rnn["R"], self.rnn_H, L.K)
             fuse_dual = False
-            if L.role == "rnn_ih" and rnn is not None and not seq and self.rnn_kind == 1 and idx is None and not tT:
-                # one LSTM inference step: x W_ih^T and h W_hh^T into ONE accumulator (sf_linear_fwd_dual) — the 64-deep
-                # input projection was a launch of its own that is all fill and drain
+            if L.role == "rnn_ih" and rnn is not None and not seq and idx is None and not tT:
+                # one recurrent inference step: x W_ih^T and h W_hh^T in ONE launch (sf_linear_fwd_dual) — the 64-deep input
+                # projection was a launch of its own that is all fill and drain (GRU: the candidate gate's parts stay apart)
                 fuse_dual = (self._wb(li, tag)[2] is not None and self._wb(li + 1, tag)[2] is not None and
-                             lib.linear_fwd_dual_supported(n, L.N, L.K, self.rnn_H))
+                             self.rnn_H % 64 == 0 and lib.linear_fwd_dual_supported(n, 4 * self.rnn_H, L.K, self.rnn_H))
             if mask is None and not fuse_x and not fuse_dual:
                 self._gemm(li, x, stride, idx, off, tT, out, n, tag)
             if li == 0:
@@ -589,10 +589,11 @@ class ActorCritic:
         assert st.shape == (n, S) and st.stride(1) == 1
         gh = self._buf((tag, "gh"), (n, Lh.N))
         w_hh, b_hh, wt_hh = self._wb(li + 1, tag)
-        if x_in is not None:  # LSTM: both projections and both biases in one launch, gh (the buffer) = the full pre-activation
+        if x_in is not None:  # both projections and both biases in one launch; the cell reads the [n, 4H] pre-activations
             _, b_ih, wt_ih = self._wb(li, tag)
-            lib.linear_fwd_dual(x_in, x_stride, wt_ih, b_ih, st, st.stride(0), wt_hh, b_hh, gh, n)
-            gx, gh = gh, None
+            gpre = self._buf((tag, "gpre"), (n, 4 * H))
+            lib.linear_fwd_dual(x_in, x_stride, wt_ih, b_ih, st, st.stride(0), wt_hh, b_hh, gpre, n, gru_H=H if kind == 0 else 0)
+            gx, gh = gpre, None
         elif wt_hh is not None and lib.conv_fwd_t_supported(n, Lh.desc):  # LDS-DMA GEMM (2048 envs x 512 x 2048 fills the chip)
             wsb = lib.conv_fwd_t_workspace(n, Lh.desc)
             lib.conv_fwd_t(st, st.stride(0), wt_hh, b_hh, gh, n, Lh.desc, self._workspace(wsb) if wsb else None)

@@ -1728,3 +1728,27 @@ def test_dual_linear_forward_vs_torch(lib, n, N, K1, K2):
     out2 = torch.empty((n, N), device="cuda")
     lib.linear_fwd_dual(a1.cuda(), K1, w1.cuda(), None, a2v, a2v.stride(0), w2.cuda(), None, out2, n)
     assert (out2.cpu().double() - (ref - b1.double() - b2.double())).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("n,H,K1", [(2048, 512, 64), (2050, 256, 32)])
+def test_dual_linear_gru_layout_and_cell(lib, n, H, K1):
+    """sf_linear_fwd_dual with gru_H = H: [n, 4H] = {r, z pre-activations (x and h parts + both biases), x W_in^T + b_in,
+    h W_hn^T + b_hn}, and sf_rnn_cell_fwd(kind 0, gh = NULL) on it equals torch.nn.GRUCell in float64"""
+    g = torch.Generator().manual_seed(n + H)
+    x, h = torch.randn((n, K1), generator=g), torch.randn((n, H), generator=g) * 0.5
+    wih, whh = torch.randn((3 * H, K1), generator=g) / np.sqrt(K1), torch.randn((3 * H, H), generator=g) / np.sqrt(H)
+    bih, bhh = torch.randn(3 * H, generator=g) * 0.1, torch.randn(3 * H, generator=g) * 0.1
+    assert lib.linear_fwd_dual_supported(n, 4 * H, K1, H)
+    pre = torch.full((n, 4 * H), 7.0, device="cuda")
+    hd = h.cuda()
+    lib.linear_fwd_dual(x.cuda(), K1, wih.cuda(), bih.cuda(), hd, H, whh.cuda(), bhh.cuda(), pre, n, gru_H=H)
+    gx, gh = x.double() @ wih.double().t() + bih.double(), h.double() @ whh.double().t() + bhh.double()
+    ref = torch.cat([gx[:, :2 * H] + gh[:, :2 * H], gx[:, 2 * H:], gh[:, 2 * H:]], dim=1)
+    assert (pre.cpu().double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+    h_out = torch.empty((n, H), device="cuda")
+    lib.rnn_cell_fwd(0, pre, None, hd, H, None, 0, None, n, H, None, h_out, None, None, None)
+    cell = torch.nn.GRUCell(K1, H).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(wih.double()); cell.weight_hh.copy_(whh.double()); cell.bias_ih.copy_(bih.double()); cell.bias_hh.copy_(bhh.double())
+        want = cell(x.double(), h.double())
+    assert (h_out.cpu().double() - want).abs().max().item() < 3e-6
