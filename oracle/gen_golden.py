@@ -385,6 +385,55 @@ def first_step_grads_fp64(learner, b, cfg, names, subsample):
     return out
 
 
+def full_train_fp64(l64, b, cfg, names, subsample):
+    # NB: `l64` is consumed (its model is converted to double)
+    """The WHOLE Learner.train replay once more with the reference's own `_train` loop (losses, autograd, clip_grad_norm_,
+    torch.optim.Adam, LR schedule) executed in float64: `_prepare_batch` in fp32 as the replay does, then model.double()
+    and every minibatch cast to double on its way out of `_get_minibatch`.  delta64_<param> = the weight change both fp32
+    implementations approximate: the GPU test states how far EACH of them is from it (tests/test_gpu_parity_c2_c5.py)
+    instead of bounding their mutual distance with a wide floor."""
+    buff, experience_size, num_invalids = l64._prepare_batch(clone_tensordict(b))
+    l64.actor_critic.double()
+    sd0 = {k: v.clone() for k, v in l64.actor_critic.state_dict().items()}
+    # how many outputs of every ReLU are positive, per SGD step: a ReLU network's gradient is discontinuous where a
+    # pre-activation crosses zero, so an fp32 implementation that lands on the other side of ONE of these ~1e7 activations
+    # than float64 does moves the weight gradients below it by ~1e-3 of their largest element — the replay test counts such
+    # flips instead of hiding them in a wide tolerance.  (The conv encoder is a torch.jit.script module: no forward hooks;
+    # the counts come from the same layers evaluated functionally on the minibatch with the current float64 weights.)
+    relu_pos = []
+    conv_arch = getattr(cfg, "encoder_conv_architecture", None)
+    count_relu = cfg.nonlinearity == "relu" and conv_arch == "convnet_atari" and "obs" in b["obs"] and b["obs"]["obs"].dim() == 5
+    orig = l64._get_minibatch
+
+    def get_minibatch64(gpu_buffer, indices):
+        mb = AttrDict(_to_double(dict(orig(gpu_buffer, indices))))
+        if count_relu:
+            import torch.nn.functional as F
+            sd_ = l64.actor_critic.state_dict()
+            pfx = "encoder.encoders.obs.enc."
+            with torch.no_grad():
+                x, row = mb["normalized_obs"]["obs"], []
+                for i, stride in ((0, 4), (2, 2), (4, 1)):
+                    x = F.relu(F.conv2d(x, sd_[pfx + f"conv_head.{i}.weight"], sd_[pfx + f"conv_head.{i}.bias"], stride=stride))
+                    row.append(int((x > 0).sum()))
+                x = F.relu(F.linear(x.reshape(x.shape[0], -1), sd_[pfx + "mlp_layers.0.weight"], sd_[pfx + "mlp_layers.0.bias"]))
+                row.append(int((x > 0).sum()))
+            relu_pos.append(row)
+        return mb
+
+    l64._get_minibatch = get_minibatch64
+    l64._train(buff, cfg.batch_size, experience_size, num_invalids)
+    sd = l64.actor_critic.state_dict()
+    out = {}
+    if relu_pos:
+        out["relu_pos64"] = np.array(relu_pos, dtype=np.int64)
+        print("  fp64 ReLU positives per SGD step:", out["relu_pos64"].tolist())
+    for k in names:
+        assert sd[k].dtype == torch.float64
+        out["delta64_" + k] = (sd[k] - sd0[k]).numpy().reshape(-1)[::subsample].copy()
+    return out
+
+
 def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_seed=3, subsample=1, use_rnn=False,
               box_dims=0, obs_seed=None, p_other_policy=None, fill_extra=None, fp64_first_step=False):
     cfg = make_cfg(list(model_args) + [f"--rollout={T}", f"--batch_size={E * T // nb}",
@@ -414,6 +463,9 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
         l64, _ = make_learner(cfg, obs_space, action_space, E)
         load_seeded(l64.actor_critic, seed=param_seed)
         arrays.update(first_step_grads_fp64(l64, b, cfg, [k for k, _ in shapes], subsample))
+        l64b, _ = make_learner(cfg, obs_space, action_space, E)
+        load_seeded(l64b.actor_critic, seed=param_seed)
+        arrays.update(full_train_fp64(l64b, b, cfg, [k for k, _ in shapes], subsample))
     # record per-SGD-step grad norms by wrapping clip_grad_norm_
     norms = []
     orig_clip = torch.nn.utils.clip_grad_norm_
