@@ -207,3 +207,27 @@ def test_action_distribution_objects_match_reference_known_answers(golden):
     close(d.probs, "mask_probs"); close(d.log_probs, "mask_log_probs", 1e-5)
     assert d.sample().shape == (300, 1)            # rows with every action masked out still draw
     assert isinstance(get_action_distribution(spaces.Box(-1, 1, (3,), np.float32), torch.zeros(5, 6)), ContinuousActionDistribution)
+
+
+@pytest.mark.parametrize("name,ref_bound", [("train_cnn84", 1e-4), ("train_c5", 1e-4), ("train_c5_gru", 1e-4)])
+def test_float64_anchor_of_the_train_replays(golden, name, ref_bound):
+    """The replays of the two BASELINE configurations carry the reference's own training loop run in float64 (delta64_*;
+    oracle/gen_golden.py full_train_fp64).  The reference's fp32 run sits within 1e-4 of it on every tensor (max|d32 - d64| /
+    max|d64|): that is the yardstick the GPU test holds the HIP path to (tests/test_gpu_parity_c2_c5.py); for the ReLU
+    network the golden also counts the positive outputs of every ReLU layer per SGD step (relu_pos64)."""
+    g = golden(name)
+    worst = 0.0
+    for k in g["param_names"]:
+        k = str(k)
+        d32, d64 = g["delta_" + k].astype(np.float64), g["delta64_" + k]
+        assert d64.dtype == np.float64 and d64.shape == d32.shape
+        worst = max(worst, float(np.abs(d32 - d64).max() / np.abs(d64).max()))
+    assert worst <= ref_bound, worst
+    steps = int(g["num_batches"]) * int(g["num_epochs"])
+    if name == "train_cnn84":
+        rp = g["relu_pos64"]
+        assert rp.shape == (steps, 4) and (rp > 0).all()
+        # conv1 32 x 20 x 20, conv2 64 x 9 x 9, conv3 64 x 7 x 7, fc 512 outputs per sample, 1024 samples per minibatch
+        assert (rp <= np.array([12800, 5184, 3136, 512]) * 1024).all()
+    else:
+        assert "relu_pos64" not in g.files  # tanh network: no kinks to count
