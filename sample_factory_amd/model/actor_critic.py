@@ -619,9 +619,9 @@ class ActorCritic:
         Hprev = self._buf((tag, "Hprev"), (R + 1, Cn, H))
         Cprev = self._buf((tag, "Cprev"), (R + 1, Cn, H)) if kind == 1 else None
         Cout = self._buf((tag, "Cout"), (R, Cn, H)) if kind == 1 else None
-        Hprev[0].copy_(h0[:, :H])
+        lib.copy_rows(Hprev[0], h0[:, :H])  # (the library's own row-copy kernel: [h | c] columns of the chunk-start states)
         if kind == 1:
-            Cprev[0].copy_(h0[:, H:])
+            lib.copy_rows(Cprev[0], h0[:, H:])
         out = self._buf((tag, "core_out"), (n, H))
         fused = _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
         if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS; the
