@@ -404,3 +404,43 @@ def test_sample_factory_alias_keeps_the_real_module_specs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "sample_factory.cfg.arguments"], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_row_ledger_conserves_rows_under_random_traffic():
+    """RowLedger against a brute-force model (a set of held rows) under random add / take traffic: no row is handed out
+    twice or lost, a take stays inside ONE maximal run and prefers the oldest one that fits, runs() are maximal and
+    disjoint, total_num is the model's size"""
+    from hypothesis import given, settings, strategies as st
+    from sample_factory_amd.algo.learning.batcher import RowLedger
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.integers(1, 4), st.lists(st.tuples(st.booleans(), st.integers(0, 63), st.integers(1, 16), st.booleans()), max_size=60))
+    def run(granule, ops):
+        rows = 64 * granule
+        led, held = RowLedger(rows, granule), set()
+        for is_add, a, n, exact in ops:
+            if is_add:
+                start, stop = a * granule, min(rows, (a + n) * granule)
+                if any(r in held for r in range(start, stop)):
+                    continue  # (the ledger asserts on double adds; the callers never do that)
+                led.add(start, stop)
+                held.update(range(start, stop))
+            else:
+                before = led.runs()
+                got = led.take(n * granule, exact=exact)
+                fits = [r for r in before if (r[1] - r[0] >= n * granule) or not exact]
+                if not fits:
+                    assert got is None
+                    continue
+                oldest = min(fits, key=lambda r: r[2])
+                assert got is not None and got.start == oldest[0] and got.stop == min(oldest[1], oldest[0] + n * granule)
+                taken = set(range(got.start, got.stop))
+                assert taken <= held
+                held -= taken
+            runs = led.runs()
+            assert led.total_num == len(held) == sum(b - a for a, b, _ in runs)
+            for (a0, b0, _), (a1, b1, _) in zip(runs, runs[1:]):
+                assert b0 < a1, "runs must be maximal (no two touching) and in row order"
+            assert all(set(range(a, b)) <= held for a, b, _ in runs)
+
+    run()
