@@ -241,3 +241,38 @@ def sample_normal(params, seed, step, row0=0):
     lib().sfo_sample_normal(_p(params, C.c_float), C.c_long(N), D, C.c_uint32(seed), C.c_uint32(step),
                             C.c_uint32(row0), _p(act, C.c_float), _p(lp, C.c_float))
     return act, lp
+
+
+def rollout_replay(rew, term, trunc, new_rnn, obs, *, T, reward_scale, reward_clip):
+    """numpy restatement of the per-step bookkeeping of BatchedVectorEnvRunner (batched_sampling.py): reward scale + clamp
+    (:208-213), dones = terminated | truncated and time_outs = truncated (:317,:325-329), recurrent state zeroed AFTER
+    production and stored as the input of the next step (:332-335,:383-385), obs / state at [:, T] and their carry-over
+    into step 0 of the next rollout (:289-296), episode statistics on RAW rewards (:215-287).
+    rew/term/trunc [steps, B], new_rnn [steps, B, R], obs [steps + 1, B, ...] -> list of per-rollout dicts + stats."""
+    steps, B = rew.shape
+    assert steps % T == 0
+    scale, clip = np.float32(reward_scale), np.float32(reward_clip)
+    last_rnn = np.zeros_like(new_rnn[0])
+    ep_ret, ep_len = np.zeros(B, np.float32), np.zeros(B, np.int32)
+    ep_rewards, ep_lens, out = [], [], []
+    for r in range(steps // T):
+        cur = dict(rewards=np.empty((B, T), np.float32), dones=np.empty((B, T), bool), time_outs=np.empty((B, T), bool),
+                   rnn_states=np.empty((B, T + 1) + new_rnn.shape[2:], np.float32),
+                   obs=np.empty((B, T + 1) + obs.shape[2:], obs.dtype))
+        for t in range(T):
+            k = r * T + t
+            cur["obs"][:, t], cur["rnn_states"][:, t] = obs[k], last_rnn
+            done = term[k] | trunc[k]
+            cur["rewards"][:, t] = np.clip(rew[k] * scale, -clip, clip)
+            cur["dones"][:, t], cur["time_outs"][:, t] = done, trunc[k]
+            last_rnn = new_rnn[k] * (np.float32(1.0) - done.astype(np.float32))[:, None]
+            ep_ret = ep_ret + rew[k]
+            ep_len = ep_len + 1
+            fin = np.flatnonzero(done)
+            ep_rewards.append(ep_ret[fin].copy())
+            ep_lens.append(ep_len[fin].copy())
+            ep_ret[fin], ep_len[fin] = 0, 0
+        cur["obs"][:, T], cur["rnn_states"][:, T] = obs[(r + 1) * T], last_rnn
+        out.append(cur)
+    return out, dict(ep_reward=np.concatenate(ep_rewards), ep_len=np.concatenate(ep_lens), final_ep_reward=ep_ret,
+                     final_ep_len=ep_len, final_last_rnn=last_rnn)

@@ -713,9 +713,198 @@ def gen_host_logic():
     print("  wrote host_logic.json")
 
 
+# ------------------------------------------------------------------------------------------------- rollout half
+class ScriptedBatchedEnv(gym.Env):
+    """A batched env (num_agents = B) that replays pre-generated per-step outputs: obs (dict of arrays), rewards,
+    terminated, truncated — as torch tensors, the way a GPU/vector env hands them to BatchedVecEnv (make_env.py:147-237).
+    It records the actions it was stepped with (what preprocess_actions produced, batched_sampling.py:30-82)."""
+
+    def __init__(self, script, obs_space, action_space):
+        self.s, self.k = script, 0
+        self.num_agents = script["rew"].shape[1]
+        self.is_multiagent = True
+        self.observation_space, self.action_space = obs_space, action_space
+        self.seen_actions = []
+
+    def _obs(self):
+        return {key: torch.from_numpy(v[self.k].copy()) for key, v in self.s["obs"].items()}
+
+    def reset(self, **kwargs):
+        self.k = 0
+        return self._obs(), [dict() for _ in range(self.num_agents)]
+
+    def step(self, actions):
+        a = actions if isinstance(actions, (list, tuple)) else [actions]
+        self.seen_actions.append([np.asarray(x).copy() for x in a])
+        k = self.k
+        self.k += 1
+        return (self._obs(), torch.from_numpy(self.s["rew"][k].copy()), torch.from_numpy(self.s["term"][k].copy()),
+                torch.from_numpy(self.s["trunc"][k].copy()), [dict() for _ in range(self.num_agents)])
+
+
+def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, reward_clip, async_rl, seed,
+                     num_policies=1, worker_idx=0, gpu_actions=False):
+    """Drive the reference's BatchedVectorEnvRunner (batched_sampling.py:85-392: init, update_trajectory_buffers,
+    generate_policy_request, advance_rollouts, _process_rewards, _process_env_step, _finalize_trajectories) for
+    n_rollouts consecutive rollouts with a scripted env and scripted policy outputs; dump the slab rows it wrote."""
+    from sample_factory.algo.sampling.batched_sampling import BatchedVectorEnvRunner
+    from sample_factory.algo.utils.env_info import extract_env_info
+    from sample_factory.algo.utils.make_env import BatchedVecEnv
+    from sample_factory.algo.utils.shared_buffers import BufferMgr
+    from sample_factory.envs.env_utils import register_env
+    from sample_factory.utils.timing import Timing
+
+    rng = np.random.default_rng(seed)
+    steps = n_rollouts * T
+    script = dict(obs={})
+    spaces_ = {}
+    for key, (shape, dtype) in obs_spec.items():
+        if dtype == np.uint8:
+            script["obs"][key] = rng.integers(0, 256, (steps + 1, B) + shape, dtype=np.uint8)
+            spaces_[key] = gym.spaces.Box(0, 255, shape, np.uint8)
+        else:
+            script["obs"][key] = rng.standard_normal((steps + 1, B) + shape).astype(np.float32)
+            spaces_[key] = gym.spaces.Box(-10, 10, shape, np.float32)
+    # rewards: heavy-tailed so that clipping is active on both sides; a few exact zeros
+    rew = (rng.standard_normal((steps, B)) * 4.0).astype(np.float32)
+    rew[rng.random((steps, B)) < 0.1] = 0.0
+    term = rng.random((steps, B)) < 0.12
+    trunc = rng.random((steps, B)) < 0.06           # some rows are terminated AND truncated
+    term[T - 1, : max(1, B // 4)] = True            # done at t = T-1 of the first rollout: reset hits rnn_states[:, T]
+    trunc[T - 1, B // 4: B // 2] = True
+    if n_rollouts > 1:
+        term[T, -1] = True                          # and at t = 0 of the second
+    script.update(rew=rew, term=term, trunc=trunc)
+    obs_space = gym.spaces.Dict(spaces_)
+    action_space = gym.spaces.Discrete(A)
+
+    rnn_args = ["--use_rnn=False"] if rnn is None else ["--use_rnn=True", f"--rnn_type={rnn[0]}", f"--rnn_size={rnn[1]}"]
+    argv = ["--algo=APPO", f"--env=scripted_{name}", "--experiment=golden", "--train_dir=/tmp/sf_golden", "--device=cpu",
+            "--serial_mode=True", "--seed=0", f"--rollout={T}", f"--recurrence={T if rnn else 1}",
+            f"--batch_size={B * T}", "--num_batches_per_epoch=1", f"--num_workers={max(1, worker_idx + 1)}",
+            "--num_envs_per_worker=1", "--worker_num_splits=1", "--batched_sampling=True",
+            f"--async_rl={async_rl}", f"--reward_scale={reward_scale}", f"--reward_clip={reward_clip}",
+            f"--num_policies={num_policies}", "--encoder_mlp_layers", "16", "--env_gpu_observations=False",
+            f"--env_gpu_actions={gpu_actions}"] + rnn_args
+    parser, _ = parse_sf_args(argv)
+    cfg = parse_full_cfg(parser, argv)
+    env_box = {}
+
+    def make_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+        env_box["env"] = ScriptedBatchedEnv(script, obs_space, action_space)
+        env_box["env_config"] = dict(env_config)
+        return env_box["env"]
+
+    register_env(cfg.env, make_env)
+    env_info = extract_env_info(BatchedVecEnv(ScriptedBatchedEnv(script, obs_space, action_space)), cfg)
+    bm = BufferMgr(cfg, env_info)
+    (dev,) = bm.traj_tensors_torch.keys()
+    slab = bm.traj_tensors_torch[dev]
+    R = slab["rnn_states"].shape[-1]
+    runner = BatchedVectorEnvRunner(cfg, env_info, 1, worker_idx, 0, bm, dev, [None] * num_policies)
+    timing = Timing()
+    runner.init(timing)
+
+    # scripted policy outputs (what InferenceWorker._prepare_policy_outputs_batched scatters into policy_output_tensors,
+    # inference_worker.py:235-269): deterministic actions = argmax of the logits (action_distributions.py:73-81)
+    logits = (rng.standard_normal((steps, B, A)) * 1.5).astype(np.float32)
+    tl = torch.from_numpy(logits)
+    dist = CategoricalActionDistribution(tl.reshape(-1, A))
+    acts = torch.argmax(tl, dim=-1)
+    logp = dist.log_prob(acts.reshape(-1, 1)).reshape(steps, B).numpy()
+    values = rng.standard_normal((steps, B)).astype(np.float32)
+    new_rnn = (rng.standard_normal((steps, B, R)) * 0.7).astype(np.float32)
+    if rnn is None:  # ModelCoreIdentity hands the (zero) width-1 dummy state through (model/core.py:67-77)
+        new_rnn[:] = 0.0
+    versions = (3 + np.arange(steps) // 5).astype(np.float32)  # the policy version advances inside a rollout
+
+    po = runner.policy_output_tensors
+    out_rollouts, slices, reports_all, seen_obs, seen_rnn = [], [], [], [], []
+    k = 0
+    for r in range(n_rollouts):
+        assert runner.update_trajectory_buffers(timing), "no free trajectory slice"
+        sl = runner.curr_traj_slice
+        complete = []
+        for t in range(T):
+            req = runner.generate_policy_request()
+            assert req == {runner.policy_id: (sl, t)}
+            # what the inference worker would read for this request (inference_worker.py:183-205)
+            seen_obs.append({key: v[sl, t].numpy().copy() for key, v in slab["obs"].items()})
+            seen_rnn.append(slab["rnn_states"][sl, t].numpy().copy())
+            po["actions"].copy_(acts[k].float().unsqueeze(-1))
+            po["action_logits"].copy_(tl[k])
+            po["log_prob_actions"].copy_(torch.from_numpy(logp[k]))
+            po["values"].copy_(torch.from_numpy(values[k]))
+            po["policy_version"].fill_(float(versions[k]))
+            po["new_rnn_states"].copy_(torch.from_numpy(new_rnn[k]))
+            complete, reports = runner.advance_rollouts(runner.policy_id, timing)
+            reports_all.extend(reports)
+            k += 1
+        assert complete == [dict(policy_id=runner.policy_id, traj_buffer_idx=sl)]
+        slices.append([sl.start, sl.stop])
+        out_rollouts.append({kk: (vv[sl].numpy().copy() if not isinstance(vv, dict) else
+                                  {k2: v2[sl].numpy().copy() for k2, v2 in vv.items()}) for kk, vv in slab.items()})
+        # the batcher releases the slice: after training in sync mode (batcher.py:224-226), right after the copy into a
+        # training batch in async mode (batcher.py:214-218) -> the queue hands the slices out round-robin
+        bm.traj_buffer_queues[dev].put(sl)
+
+    arrays = dict(ref="sample_factory/algo/sampling/batched_sampling.py:85-392 BatchedVectorEnvRunner "
+                      "(init / generate_policy_request / advance_rollouts / _process_rewards / _process_env_step / "
+                      "_finalize_trajectories), preprocess_actions :30-82",
+                  B=B, T=T, A=A, n_rollouts=n_rollouts, rnn_type="" if rnn is None else rnn[0],
+                  rnn_size=0 if rnn is None else rnn[1], rnn_state_width=R, reward_scale=reward_scale,
+                  reward_clip=reward_clip, async_rl=async_rl, policy_id=runner.policy_id, seed=seed,
+                  gpu_actions=gpu_actions,
+                  slab_rows=slab["rewards"].shape[0], slices=np.asarray(slices),
+                  obs_keys=np.asarray(sorted(obs_spec.keys())),
+                  env_config=np.asarray([env_box["env_config"][q] for q in ("worker_index", "vector_index", "env_id")]),
+                  in_rew=rew, in_term=term, in_trunc=trunc, in_logits=logits, in_values=values, in_new_rnn=new_rnn,
+                  in_versions=versions, ref_logp=logp, ref_actions=acts.numpy(),
+                  env_seen_actions=np.stack([a[0] for a in env_box["env"].seen_actions]),
+                  env_seen_actions_dtype=str(env_box["env"].seen_actions[0][0].dtype),
+                  final_ep_reward=runner.curr_episode_reward.numpy(), final_ep_len=runner.curr_episode_len.numpy(),
+                  final_last_rnn=runner.last_rnn_state.numpy())
+    for key, v in script["obs"].items():
+        arrays[f"in_obs_{key}"] = v
+    for k_, (so, sr) in enumerate(zip(seen_obs, seen_rnn)):
+        arrays[f"seen_rnn_{k_}"] = sr
+        for key, v in so.items():
+            arrays[f"seen_obs_{key}_{k_}"] = v
+    for r, out in enumerate(out_rollouts):
+        for kk, vv in out.items():
+            if isinstance(vv, dict):
+                for k2, v2 in vv.items():
+                    arrays[f"out{r}_obs_{k2}"] = v2
+            else:
+                arrays[f"out{r}_{kk}"] = vv
+    ep_rew = np.concatenate([rp["episodic"]["reward"] for rp in reports_all]) if reports_all else np.zeros(0, np.float32)
+    ep_len = np.concatenate([rp["episodic"]["len"] for rp in reports_all]) if reports_all else np.zeros(0, np.int32)
+    arrays.update(ep_reward=ep_rew, ep_len=ep_len,
+                  ep_min_raw=np.concatenate([rp["episodic"]["min_raw_reward"] for rp in reports_all]),
+                  ep_max_raw=np.concatenate([rp["episodic"]["max_raw_reward"] for rp in reports_all]),
+                  report_policy_ids=np.asarray([rp["policy_id"] for rp in reports_all]))
+    assert int((term | trunc).sum()) == len(ep_rew)
+    save("rollout_" + name, **arrays)
+
+
+def gen_rollout():
+    vec = {"obs": ((11,), np.float32)}
+    gen_rollout_case("ff_sync", B=24, T=8, n_rollouts=3, obs_spec=vec, A=6, rnn=None, reward_scale=1.0, reward_clip=1000.0,
+                     async_rl=False, seed=501)
+    gen_rollout_case("gru_scale_clip", B=16, T=8, n_rollouts=2, obs_spec=vec, A=5, rnn=("gru", 24), reward_scale=0.3,
+                     reward_clip=1.5, async_rl=False, seed=502)
+    gen_rollout_case("lstm_async", B=16, T=6, n_rollouts=3, obs_spec=vec, A=4, rnn=("lstm", 16), reward_scale=2.5,
+                     reward_clip=5.0, async_rl=True, seed=503, gpu_actions=True)
+    gen_rollout_case("u8_image", B=8, T=4, n_rollouts=2, obs_spec={"obs": ((4, 12, 12), np.uint8)}, A=6, rnn=None,
+                     reward_scale=0.01, reward_clip=0.02, async_rl=True, seed=504)
+    gen_rollout_case("multikey_policy1", B=8, T=5, n_rollouts=2,
+                     obs_spec={"obs": ((7,), np.float32), "aux": ((2, 3, 3), np.uint8)}, A=3, rnn=("gru", 8),
+                     reward_scale=1.0, reward_clip=1.0, async_rl=False, seed=505, num_policies=2, worker_idx=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb", "cfg", "ckpt", "host"]
+    which = sys.argv[1:] or ["gae", "rms", "dist", "learner", "train", "model", "mb", "cfg", "ckpt", "host", "rollout"]
     if "gae" in which:
         gen_gae()
     if "rms" in which:
@@ -772,6 +961,8 @@ def main():
         gen_model_fwd_multi()
     if "host" in which:
         gen_host_logic()
+    if "rollout" in which:
+        gen_rollout()
     if "cfg" in which:
         import json
         p, a = parse_sf_args(["--algo=APPO", "--env=x", "--experiment=e"])

@@ -621,11 +621,19 @@ class Learner:
                 # data-parallel: every replica divided its LOCAL sums by the GLOBAL n, so the loss / KL / entropy means
                 # add up across ranks (max KL: MAX) — ONE packed exchange per epoch (ReplicaGroup.reduce_sum_max)
                 # instead of two collectives per SGD step; the per-rank columns (adv mean / std, n) stay as they are
-                pack = blk[:, [0, 1, 2, 3, 4, 9, 5]].contiguous()
-                self.group.reduce_sum_max(pack, (6,))
-                blk[:, [0, 1, 2, 3, 4, 9, 5]] = pack
+                # the abort word of the fused recurrent passes is rank-local: it rides along as a MAX column so that
+                # every replica raises in the same epoch (one rank raising alone would leave the others in a collective)
+                flag = (skip.to(torch.float32) if skip is not None else blk.new_zeros(1)).expand(blk.shape[0], 1)
+                pack = torch.cat([blk[:, [0, 1, 2, 3, 4, 9, 5]], flag], dim=1).contiguous()
+                self.group.reduce_sum_max(pack, (6, 7))
+                blk[:, [0, 1, 2, 3, 4, 9, 5]] = pack[:, :7]
+                aborted = skip is not None and bool(pack[0, 7].item() != 0)
+            elif self.dp and skip is not None:
+                aborted = bool(self.group.all_reduce_max(skip.to(torch.float32)).item() != 0)
+            else:
+                aborted = skip is not None and ac.rnn_pass_aborted()
             rows = blk.cpu()
-            if skip is not None and ac.rnn_pass_aborted():
+            if aborted:
                 raise lib.SfHipError(
                     "a fused recurrent sequence pass was aborted (a work-group never arrived: is the GPU shared with "
                     "another process?); the optimiser steps after it were skipped, the weights are those of the last "

@@ -52,6 +52,7 @@ class BatchedVectorEnvRunner:
         self.obs = traj["obs"]["obs" if "obs" in traj["obs"] else self.obs_keys[0]]
         self.rnn = actor_critic.rnn_kind is not None
         traj["rnn_states"].zero_()
+        self._dummy_state_rows = {traj["rnn_states"].data_ptr()}
         self._started = False
         self.A = actor_critic.num_action_params
         self.ld = actor_critic.heads_ld
@@ -218,6 +219,11 @@ class BatchedVectorEnvRunner:
         """async mode: switch to another slab; its step 0 continues from the last step of `carry_from`"""
         self.traj = traj
         self.obs = traj["obs"]["obs" if "obs" in traj["obs"] else self.obs_keys[0]]
+        if not self.rnn and traj["rnn_states"].data_ptr() not in self._dummy_state_rows:
+            # feed-forward policies carry a width-1 dummy state that is always zero and that the reference still writes
+            # at every step (parity trap 13, model_utils.py:11-24): zero the rows ONCE, nothing overwrites them later
+            traj["rnn_states"].zero_()
+            self._dummy_state_rows.add(traj["rnn_states"].data_ptr())
         if carry_from is not None:  # column copies through the library's own row-copy kernel (sf_copy_rows)
             for k in self.obs_keys:
                 lib.copy_rows(traj["obs"][k][:, 0], carry_from["obs"][k][:, self.T])

@@ -91,9 +91,6 @@ class CategoricalActionDistribution:
             noisy = noisy * self.action_mask
         return noisy.argmax(dim=-1)
 
-    def argmax(self) -> torch.Tensor:
-        return self.probs.argmax(dim=-1, keepdim=True)
-
     def log_prob(self, value: torch.Tensor) -> torch.Tensor:
         idx = value.long().reshape(self.log_probs.shape[:-1] + (1,))
         return self.log_probs.gather(-1, idx).reshape(-1)
@@ -178,41 +175,30 @@ def _as_columns(a: torch.Tensor) -> torch.Tensor:
     return a.reshape(a.shape[0], -1) if a.dim() > 1 else a.reshape(-1, 1)
 
 
-class ContinuousActionDistribution:
-    """diagonal normal over Box(D) actions from `params` = [mean (D) | log_std (D)]"""
+class ContinuousActionDistribution(torch.distributions.Independent):
+    """diagonal normal over Box(D) actions from `params` = [mean (D) | log_std (D)] — an `Independent(Normal, 1)` exactly
+    as the reference builds it (:290-323, validate_args=False: NaN parameters do not raise here either), so `.stddev`,
+    `.base_dist`, `.rsample`, `.entropy` and `torch.distributions.kl_divergence` behave as they do there"""
+    stddev_min: float = _STD_MIN
+    stddev_max: float = _STD_MAX
 
     def __init__(self, params: torch.Tensor):
-        self.means, self.log_std = params.chunk(2, dim=-1)
-        self.stddevs = self.log_std.exp().clamp(_STD_MIN, _STD_MAX)
-        self._normal = torch.distributions.Normal(self.means, self.stddevs)
-
-    @property
-    def mean(self) -> torch.Tensor:
-        return self.means
-
-    def sample(self) -> torch.Tensor:
-        return self._normal.sample()
-
-    def rsample(self) -> torch.Tensor:
-        return self._normal.rsample()
+        self.means, self.log_std = torch.chunk(params, 2, dim=-1)
+        self.stddevs = self.log_std.exp().clamp(self.stddev_min, self.stddev_max)
+        super().__init__(torch.distributions.Normal(self.means, self.stddevs, validate_args=False), 1, validate_args=False)
 
     def log_prob(self, value: torch.Tensor) -> torch.Tensor:
-        return self._normal.log_prob(value.reshape(self.means.shape)).sum(dim=-1)
-
-    def entropy(self) -> torch.Tensor:
-        return self._normal.entropy().sum(dim=-1)
+        return super().log_prob(value.reshape(self.means.shape))
 
     def kl_divergence(self, other: "ContinuousActionDistribution") -> torch.Tensor:
         """KL(self || other) = sum_d log(s_o / s) + (s^2 + (m - m_o)^2) / (2 s_o^2) - 1/2"""
-        var_ratio = (self.stddevs / other.stddevs) ** 2
-        shift = ((self.means - other.means) / other.stddevs) ** 2
-        return (0.5 * (var_ratio + shift - 1.0 - var_ratio.log())).sum(dim=-1)
+        return torch.distributions.kl.kl_divergence(self, other)
 
     def summaries(self) -> dict:
         return dict(action_mean=self.means.mean(), action_mean_min=self.means.min(), action_mean_max=self.means.max(),
                     action_log_std_mean=self.log_std.mean(), action_log_std_min=self.log_std.min(),
-                    action_log_std_max=self.log_std.max(), action_stddev_mean=self.stddevs.mean(),
-                    action_stddev_min=self.stddevs.min(), action_stddev_max=self.stddevs.max())
+                    action_log_std_max=self.log_std.max(), action_stddev_mean=self.stddev.mean(),
+                    action_stddev_min=self.stddev.min(), action_stddev_max=self.stddev.max())
 
 
 def get_action_distribution(action_space, raw_logits: torch.Tensor, action_mask: Optional[torch.Tensor] = None):
@@ -242,4 +228,6 @@ def argmax_actions(distribution) -> torch.Tensor:
         return distribution.argmax()
     if isinstance(distribution, ContinuousActionDistribution):
         return distribution.means
-    return distribution.probs.argmax(dim=-1, keepdim=True) if hasattr(distribution, "probs") else distribution.argmax()
+    if hasattr(distribution, "probs"):
+        return torch.argmax(distribution.probs, dim=-1)  # [N] (no trailing axis), as the reference returns it
+    raise NotImplementedError(f"Action distribution type {type(distribution)} does not support argmax!")

@@ -901,6 +901,11 @@ static int conv_fwd_impl(const void *in, int64_t in_sample_stride, const int32_t
                 g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, relu_mask, (int)n);
         return sf_launch_status("sf_conv_fwd");
     }
+    // only the kernel above records ReLU sign bits: every other path would leave the mask unwritten for the
+    // weight-gradient kernel to consume (misaligned operands drop to MODE_GENERIC without it)
+    SF_REQUIRE(relu_mask == nullptr,
+               "sf_conv_fwd_relu_mask: operands not eligible for the sign-bit kernel (sf_conv_relu_mask_supported, 4-byte "
+               "aligned frames and sample stride, 16-byte aligned weights)");
     if (img_on && conv1_img_ok(g, mode, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0) {
         const unsigned lds_bytes = (unsigned)(2 * 4 * 20 * 84 * sizeof(float));  // [SMP][Cin][RS][W] f32
         // persistent work-groups: as many as are resident at once (two per CU: 53.8 KB of LDS each), each walks the

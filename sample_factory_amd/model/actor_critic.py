@@ -501,6 +501,7 @@ class ActorCritic:
         """
         acts: List[Optional[torch.Tensor]] = [None] * len(self.layers)
         inputs: List[Optional[torch.Tensor]] = [None] * len(self.layers)
+        relu_mask0 = None
         self._tls.role = "rollout" + tag[3:] if tag.startswith("inf") else "learner"  # "inf", "inf1", ...: env groups
         x, stride, idx, off, tT = obs, sample_stride, index, offset, traj_T
         first_layer = 0
@@ -542,12 +543,13 @@ class ActorCritic:
                 if tT:
                     d0 = lib.sf_conv_desc.from_buffer_copy(L.desc)
                     d0.traj_T = int(tT)
-                if lib.conv_relu_mask_supported(n, d0):
+                w_, b_, _ = self._wb(li, tag)
+                aligned = x.data_ptr() % 4 == 0 and stride % 4 == 0 and w_.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
+                if aligned and lib.conv_relu_mask_supported(n, d0):  # (the launch fails hard on operands it cannot take)
                     # conv1 on raw frames: the forward also records ONE sign bit per output element; the backward pass
                     # masks with these bits inside conv1's weight-gradient kernel, so conv2's data gradient never
                     # re-reads this activation
                     mask = self._buf((tag, "relu_mask0"), (n * L.out_pixels,), dtype=torch.int32)
-                    w_, b_, _ = self._wb(li, tag)
                     lib.conv_fwd_relu_mask(x, stride, idx, off, w_, b_, out, mask, n, d0)
             fuse_x = False
             if L.role == "rnn_ih" and seq and _LSTM_SEQ and L.wt is not None and idx is None and not tT:
@@ -563,7 +565,7 @@ class ActorCritic:
             if mask is None and not fuse_x and not fuse_dual:
                 self._gemm(li, x, stride, idx, off, tT, out, n, tag)
             if li == 0:
-                self._relu_mask0 = mask if tag == "train" else getattr(self, "_relu_mask0", None)
+                relu_mask0 = mask  # kept in this forward's OWN context (below): nothing a forward leaves behind is untagged
             acts[li] = out
             x = out
             if L.role == "rnn_ih":
@@ -578,7 +580,7 @@ class ActorCritic:
             stride, idx, off, tT = x.numel() // n, None, 0, 0  # elements per sample of the activation just produced
         if self.tanh_scale > 0:  # action_parameterization.py:62-66 (col 0 = value, then the means)
             lib.tanh_scale_fwd(acts[-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
-        self._ctx[tag] = dict(acts=acts, inputs=inputs, first_in=first_in, rnn=rnn)
+        self._ctx[tag] = dict(acts=acts, inputs=inputs, first_in=first_in, rnn=rnn, relu_mask0=relu_mask0)
         return acts
 
     # ------------------------------------------------------------------------------------------ recurrent core
@@ -760,7 +762,7 @@ class ActorCritic:
         if self.tanh_scale > 0:  # d tanh(x/s)*s / dx = 1 - (y/s)^2 on the mean columns
             lib.tanh_scale_bwd(g_heads, ctx["acts"][-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
         chain = [li for li, L in enumerate(self.layers) if L.role != "rnn_hh"]
-        mask0 = getattr(self, "_relu_mask0", None)
+        mask0 = ctx.get("relu_mask0")  # sign bits recorded by THIS train forward (None: conv2's dgrad reads the activation)
         for pos in range(len(chain) - 1, -1, -1):
             li = chain[pos]
             L = self.layers[li]

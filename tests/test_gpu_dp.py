@@ -80,7 +80,97 @@ def _free_port():
         return s_.getsockname()[1]
 
 
-def test_rccl_branch_executes_with_one_rank(tmp_path):
+# ------------------------------------------------------------------------------------------ BASELINE configs[4] shape
+def _cfg_c5(num_agents, rnn_type, nb=1, **kw):
+    """BASELINE.json configs[4] ("Mujoco Ant-v4 continuous-action, LSTM core + V-trace, 2xMI355X") at test size: Box(8)
+    actions with learned stddev, MLP[64,64] tanh encoder, 256-wide recurrent core on the fused sequence kernels, V-trace,
+    KL loss, value bootstrap, normalize_input=True (the obs normaliser's moments are a per-dataset all-reduce under DP).
+    nb = 1: the dataset is ONE minibatch, so the global minibatch of G replicas is the single replica's minibatch (with
+    nb > 1 every replica cuts its own shard into nb pieces: an equally valid but different partition)"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    T = 8
+    return default_cfg(env="synthetic_ant", use_rnn=True, rnn_type=rnn_type, rnn_size=256, recurrence=T, rollout=T,
+                       encoder_mlp_layers=[64, 64], nonlinearity="tanh", normalize_input=True, normalize_returns=False,
+                       with_vtrace=True, kl_loss_coeff=0.1, adaptive_stddev=False, policy_initialization="torch_default",
+                       value_bootstrap=True, max_grad_norm=3.5, ppo_clip_ratio=0.2, value_loss_coeff=1.3,
+                       exploration_loss_coeff=0.0, learning_rate=1e-4, gamma=0.99, gae_lambda=0.95,
+                       batch_size=num_agents * T // nb, num_batches_per_epoch=nb, num_epochs=2, num_workers=1,
+                       num_envs_per_worker=1, async_rl=False, seed=7, serial_mode=True, synthetic_num_agents=num_agents, **kw)
+
+
+def _run_c5(num_agents, iters, rnn_type, **kw):
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+    cfg, runner = make_runner(_cfg_c5(num_agents, rnn_type, **kw))
+    runner.init()
+    ac = runner.learner.actor_critic
+    out = {}
+    for it in range(iters):
+        stats = runner.iteration()
+        torch.cuda.synchronize()
+        if it == 0:  # after ONE dataset: same rollout up to fp32 round-off of the first forward, 4 Adam steps
+            out.update(params1=ac.flat_params.cpu().numpy(), obs1=runner.traj["obs"]["obs"].cpu().numpy(),
+                       acts1=runner.traj["actions"].cpu().numpy(), loss1=stats["train"]["loss"])
+            sd1 = ac.state_dict()
+    sd = ac.state_dict()
+    pfx = "obs_normalizer.running_mean_std.running_mean_std.obs."
+    out.update(params=ac.flat_params.cpu().numpy(), loss=stats["train"]["loss"], env_steps=stats["learner_env_steps"],
+               fused=bool(ac._rnn_saved["fused"]), train_step=runner.learner.train_step,
+               **{f"obsn_{k}": sd[pfx + k].double().numpy() for k in ("running_mean", "running_var", "count")},
+               **{f"obsn1_{k}": sd1[pfx + k].double().numpy() for k in ("running_mean", "running_var", "count")})
+    return out
+
+
+def _worker_c5(rank, world, port, out_dir, rnn_type):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", SF_DP_BACKEND="gloo")
+    r = _run_c5(32, 3, rnn_type)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **r)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("rnn_type", ["lstm", "gru"])
+def test_two_replicas_equal_one_recurrent_vtrace_normalized_input(tmp_path, rnn_type):
+    """2 replicas x 32 envs == 1 replica x 64 envs on the configs[4] shape: the replicas' weights and observation-normaliser
+    statistics are IDENTICAL bit for bit (every collective hands every rank the same bytes), and equal to the single
+    replica up to fp32 summation order."""
+    mp.spawn(_worker_c5, args=(2, _free_port(), str(tmp_path), rnn_type), nprocs=2, join=True)
+    for k in ("WORLD_SIZE", "RANK"):
+        os.environ.pop(k, None)
+    single = _run_c5(64, 3, rnn_type)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(2)]
+    assert single["fused"] and bool(r[0]["fused"]) and bool(r[1]["fused"]), "BPTT must run as the persistent sequence kernels"
+    assert int(r[0]["env_steps"]) == single["env_steps"] == 3 * 64 * 8 and int(r[0]["train_step"]) == single["train_step"] == 6
+    # ---- replicas in lock-step, bit for bit
+    for k in ("params", "params1", "obsn_running_mean", "obsn_running_var", "obsn_count", "obsn1_running_mean", "obsn1_running_var"):
+        np.testing.assert_array_equal(r[0][k], r[1][k], err_msg=k)
+    assert float(r[0]["loss"]) == float(r[1]["loss"]) and float(r[0]["loss1"]) == float(r[1]["loss1"])
+    # ---- first dataset: the shards' rollout is the single replica's rollout (same env streams, same sampler keys; the
+    # forward of 32 vs 64 rows may pick another tile shape: fp32 round-off in the continuous actions)
+    obs = np.concatenate([r[0]["obs1"], r[1]["obs1"]])
+    acts = np.concatenate([r[0]["acts1"], r[1]["acts1"]])
+    np.testing.assert_allclose(acts, single["acts1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(obs, single["obs1"], rtol=0, atol=2e-5)
+    # GLOBAL observation-normaliser moments (running_mean_std.py:51-62 over both shards' rows): f64 statistics
+    assert float(r[0]["obsn1_count"].item()) == float(single["obsn1_count"].item()) == 1.0 + 64 * 9
+    np.testing.assert_allclose(r[0]["obsn1_running_mean"], single["obsn1_running_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r[0]["obsn1_running_var"], single["obsn1_running_var"], rtol=1e-5, atol=1e-6)
+    assert abs(float(r[0]["loss1"]) - single["loss1"]) < 1e-3 * max(1.0, abs(single["loss1"]))
+    # 2 Adam steps at lr 1e-4: a summation-order sign flip of a ~0 gradient is a full +-lr step per SGD step
+    d1 = np.abs(r[0]["params1"] - single["params1"])
+    assert d1.max() <= 2.1e-4 and (d1 > 2e-5).mean() < 2e-3, (d1.max(), (d1 > 2e-5).mean())
+    # ---- three datasets (6 Adam steps through a recurrent core): still the same run
+    d = np.abs(r[0]["params"] - single["params"])
+    assert d.max() <= 6.5e-4 and (d > 5e-5).mean() < 5e-3, (d.max(), (d > 5e-5).mean())
+    np.testing.assert_allclose(r[0]["obsn_running_mean"], single["obsn_running_mean"], rtol=1e-3, atol=1e-4)
+    assert abs(float(r[0]["loss"]) - single["loss"]) < 5e-3 * max(1.0, abs(single["loss"]))
+
+
+@pytest.mark.parametrize("kind", ["c2", "c5"])
+def test_rccl_branch_executes_with_one_rank(tmp_path, kind):
     """The production backend (nccl = RCCL) on the ONE GPU of the test box: a single-rank process group with
     cfg.dp_force_collectives issues every collective of the data-parallel learner for real — broadcast of the initial
     weights, the per-minibatch 3-double moment all-reduce, the two-bucket gradient all-reduce (async_op on a slice of
@@ -104,14 +194,22 @@ if force:
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("nccl")
 register_env("synthetic_atari", make_synthetic_env)
-cfg = default_cfg(env="synthetic_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
-                  encoder_conv_architecture="convnet_atari", rollout=8, batch_size=1024, num_batches_per_epoch=2,
-                  num_epochs=2, num_workers=1, num_envs_per_worker=1, worker_num_splits=1, async_rl=False, seed=1,
-                  serial_mode=True, synthetic_num_agents=256, train_dir=%r, experiment="rccl" + str(int(force)),
-                  data_parallel=force, dp_force_collectives=force, dp_native_rccl=native, lr_schedule="kl_adaptive_epoch")
+dp_kw = dict(train_dir=%r, experiment="rccl" + str(int(force)), data_parallel=force, dp_force_collectives=force,
+             dp_native_rccl=native, lr_schedule="kl_adaptive_epoch")
+if os.environ["KIND"] == "c5":   # BASELINE configs[4] shape: recurrent core + V-trace + global obs-normaliser moments
+    sys.path.insert(0, os.path.join(%r, "tests"))
+    from test_gpu_dp import _cfg_c5
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+    cfg = _cfg_c5(64, "lstm", nb=2, **dp_kw)
+else:
+    cfg = default_cfg(env="synthetic_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                      encoder_conv_architecture="convnet_atari", rollout=8, batch_size=1024, num_batches_per_epoch=2,
+                      num_epochs=2, num_workers=1, num_envs_per_worker=1, worker_num_splits=1, async_rl=False, seed=1,
+                      serial_mode=True, synthetic_num_agents=256, **dp_kw)
 cfg, runner = make_runner(cfg)
 runner.init()
-assert runner.learner.dp == force and (not force or runner.learner._dp_split is not None)
+assert runner.learner.dp == force and (not force or os.environ["KIND"] == "c5" or runner.learner._dp_split is not None)
 assert (runner.learner.group is not None and runner.learner.group.native) == native
 for _ in range(3):
     stats = runner.iteration()
@@ -123,11 +221,11 @@ if native:
     runner.learner.group.close()
 if force:
     torch.distributed.destroy_process_group()
-''' % (root, str(tmp_path))
+''' % (root, str(tmp_path), root)
     out = {}
     for force in ("0", "1", "2"):  # 2: the gradient buckets through the C-ABI (sf_allreduce_grads), the rest as in 1
         env = {k: v for k, v in os.environ.items() if k not in ("SF_DP_BACKEND",)}
-        env.update(FORCE=force, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        env.update(FORCE=force, KIND=kind, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2500:]
         out[force] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])

@@ -1,0 +1,194 @@
+"""Rollout half of the north star against fixtures recorded FROM THE REFERENCE.
+
+tests/golden/rollout_*.npz were written by oracle/gen_golden.py `gen_rollout_case`, which drives the reference's own
+`BatchedVectorEnvRunner` (sample_factory/algo/sampling/batched_sampling.py:85-392: init / update_trajectory_buffers /
+generate_policy_request / advance_rollouts / _process_rewards / _process_env_step / _finalize_trajectories) over the
+reference's `BufferMgr` free-slice queue with a scripted batched env and scripted policy outputs, for several consecutive
+rollouts, and dumps the slab rows it wrote.  Here the SAME env outputs and the same policy outputs (logits, values, new
+recurrent states, policy versions; deterministic actions = argmax as in action_distributions.py:73-81) go through this
+repo's `BatchedVectorEnvRunner` + `BufferMgr` and the kernels behind them — `sf_sample_write_step`,
+`sf_traj_write_env_step`, `sf_rnn_store_state`, `sf_copy_rows`, `sf_h2d_rows` — and every slab leaf the reference wrote
+must come out BIT-EQUAL (log-probabilities: 1e-6), including
+
+  * reward * reward_scale, clamp(+-reward_clip)                       batched_sampling.py:208-213
+  * dones = terminated | truncated, time_outs = truncated              :317, :325-329
+  * policy_id stamping                                                 :320, :329
+  * recurrent state zeroed AFTER production, stored as the INPUT of t+1  :332-335, :374-388
+  * obs / rnn_states at [:, T] and their carry-over into [:, 0] of the next slice  :289-296, :383-385
+  * what the policy is shown at step t (obs[:, t], rnn_states[:, t])   inference_worker.py:183-205
+  * int32 env actions, squeezed for a single Discrete head             :30-82
+  * episode return / length statistics (raw rewards)                   :215-287
+  * the order in which the free-slice queue hands out slab slices      shared_buffers.py:228-235, batcher.py:214-226
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1"]
+
+
+def _spaces(g):
+    from sample_factory_amd.envs import spaces
+    obs = {}
+    for key in [str(k) for k in g["obs_keys"]]:
+        a = g[f"in_obs_{key}"]
+        obs[key] = spaces.Box(0, 255, a.shape[2:], np.uint8) if a.dtype == np.uint8 else \
+            spaces.Box(-10, 10, a.shape[2:], np.float32)
+    return spaces.Dict(obs), spaces.Discrete(int(g["A"]))
+
+
+class ScriptedEnv:
+    """replays the fixture's env outputs: as CUDA tensors (a device vector env) or numpy arrays (a host vector env)"""
+
+    def __init__(self, g, obs_space, action_space, host: bool):
+        self.g, self.host, self.k = g, host, 0
+        self.num_agents = int(g["B"])
+        self.observation_space, self.action_space = obs_space, action_space
+        self.keys = [str(k) for k in g["obs_keys"]]
+        self.seen_actions = []
+
+    def _out(self, a):
+        return np.ascontiguousarray(a) if self.host else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def _obs(self):
+        return {k: self._out(self.g[f"in_obs_{k}"][self.k]) for k in self.keys}
+
+    def reset(self, **kw):
+        self.k = 0
+        return self._obs(), {}
+
+    def step(self, actions):
+        self.seen_actions.append(actions.copy() if isinstance(actions, np.ndarray) else actions.cpu().numpy())
+        k = self.k
+        self.k += 1
+        return self._obs(), self._out(self.g["in_rew"][k]), self._out(self.g["in_term"][k]), \
+            self._out(self.g["in_trunc"][k]), {}
+
+
+class ScriptedPolicy:
+    """stands where the ActorCritic stands in BatchedVectorEnvRunner: returns the fixture's heads matrix for the current
+    step and records what it was shown"""
+
+    def __init__(self, g, native_state: bool):
+        self.g = g
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        kind = str(g["rnn_type"])
+        self.rnn_kind = kind or None
+        self.H = int(g["rnn_size"])
+        self.num_action_params = int(g["A"])
+        self.heads_ld = 8 * ((1 + self.num_action_params + 7) // 8)   # padded rows as the fused-heads GEMM writes them
+        self.native_state = native_state
+        self.k = 0
+        self.seen_obs, self.seen_rnn = [], []
+        self._new = None
+
+    def forward_heads(self, x, B, sample_stride=None, tag="inf", rnn=None):
+        g, k = self.g, self.k
+        self.seen_obs.append({kk: v.clone() for kk, v in x.items()} if isinstance(x, dict) else {"": x.clone()})
+        self.seen_rnn.append(None if rnn is None else rnn["states"].clone())
+        heads = torch.full((B, self.heads_ld), 123.0, device=self.device)
+        heads[:, 0] = torch.from_numpy(g["in_values"][k]).cuda()
+        heads[:, 1:1 + self.num_action_params] = torch.from_numpy(g["in_logits"][k]).cuda()
+        self._new = torch.from_numpy(g["in_new_rnn"][k]).cuda()
+        self.k += 1
+        return [heads]
+
+    def new_rnn_parts_of(self, tag):
+        if not self.native_state:
+            return None
+        n, H = self._new, self.H
+        return (n[:, :H].contiguous(), n[:, H:].contiguous() if self.rnn_kind == "lstm" else None)
+
+    def new_rnn_states_of(self, tag):
+        return self._new
+
+
+def _leaf(tr, name):
+    if name.startswith("obs_"):
+        return tr["obs"][name[4:]]
+    return tr[name]
+
+
+@pytest.mark.parametrize("host_env", [False, True], ids=["device_env", "host_env"])
+@pytest.mark.parametrize("native_state", [True, False], ids=["native_state", "torch_state"])
+@pytest.mark.parametrize("case", CASES)
+def test_rollout_slab_equals_the_reference(golden, case, host_env, native_state):
+    from sample_factory_amd import lib
+    from sample_factory_amd.algo.sampling.batched_sampling import BatchedVectorEnvRunner
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import BufferMgr
+    from sample_factory_amd.cfg.arguments import default_cfg
+
+    lib.load()
+    g = golden("rollout_" + case)
+    B, T, A, NR = int(g["B"]), int(g["T"]), int(g["A"]), int(g["n_rollouts"])
+    rnn_type = str(g["rnn_type"])
+    if not rnn_type and not native_state:
+        pytest.skip("no recurrent state in this case")
+    pid = int(g["policy_id"])
+    cfg = default_cfg(env="scripted", rollout=T, recurrence=T if rnn_type else 1, use_rnn=bool(rnn_type),
+                      rnn_type=rnn_type or "gru", rnn_size=int(g["rnn_size"]) or 512, batch_size=B * T,
+                      num_batches_per_epoch=1, num_workers=max(1, pid + 1), num_envs_per_worker=1, worker_num_splits=1,
+                      batched_sampling=True, async_rl=bool(g["async_rl"]), reward_scale=float(g["reward_scale"]),
+                      reward_clip=float(g["reward_clip"]), num_policies=max(1, pid + 1), serial_mode=True)
+    obs_space, action_space = _spaces(g)
+    env_info = EnvInfo(obs_space, action_space, B, not host_env, not host_env)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    bm = BufferMgr(cfg, env_info, dev)
+    slab = bm.traj_tensors
+    assert slab["rewards"].shape[0] == int(g["slab_rows"]), "slab rows (shared_buffers.py:184-211)"
+    assert slab["rnn_states"].shape[-1] == int(g["rnn_state_width"])
+
+    env = ScriptedEnv(g, obs_space, action_space, host_env)
+    policy = ScriptedPolicy(g, native_state)
+    versions = torch.zeros(max(1, pid + 1), dtype=torch.int32)
+    runner = BatchedVectorEnvRunner(cfg, env_info, env, policy, slab[0:B], policy_id=pid, policy_versions=versions)
+    prev, k = None, 0
+    for r in range(NR):
+        sl = bm.get_free_slice()
+        assert [sl.start, sl.stop] == g["slices"][r].tolist(), "hand-out order of the free-slice queue"
+        rows = slab[sl]
+        runner.set_slab(rows, carry_from=prev)      # what Runner._rollout_all does for every sampling round
+        prev = rows
+        for t in range(T):
+            runner.begin_rollout(float(g["in_versions"][k]), deterministic=True)
+            runner.rollout_step(t)
+            k += 1
+        torch.cuda.synchronize()
+        # ---- every leaf the reference wrote for this rollout, bit for bit
+        for name in [n[len(f"out{r}_"):] for n in g.files if n.startswith(f"out{r}_")]:
+            want = g[f"out{r}_{name}"]
+            got = _leaf(rows, name).cpu().numpy()
+            if name == "values":            # [:, T] is the learner's bootstrap slot, the sampler never writes it
+                want, got = want[:, :T], got[:, :T]
+            if name == "valids":            # written by the learner (learner.py:950-955)
+                continue
+            if name == "log_prob_actions":
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-6, err_msg=f"{case} rollout {r} {name}")
+            else:
+                assert got.dtype == want.dtype or name.startswith("obs_"), (name, got.dtype, want.dtype)
+                np.testing.assert_array_equal(got, want, err_msg=f"{case} rollout {r} {name}")
+        bm.release(sl)                              # the batcher hands the rows back (batcher.py:214-226)
+    # ---- what the policy was shown at every step == what the reference's inference worker would have read
+    for kk in range(NR * T):
+        for key, v in policy.seen_obs[kk].items():
+            key = key or "obs"
+            np.testing.assert_array_equal(v.cpu().numpy(), g[f"seen_obs_{key}_{kk}"], err_msg=f"policy input obs step {kk}")
+        if rnn_type:
+            np.testing.assert_array_equal(policy.seen_rnn[kk].cpu().numpy(), g[f"seen_rnn_{kk}"],
+                                          err_msg=f"policy input rnn state step {kk}")
+    # ---- the env was stepped with the reference's actions (int32, [B] for one Discrete head)
+    seen = np.stack(env.seen_actions)
+    assert seen.dtype == np.int32 and str(g["env_seen_actions_dtype"]) == "int32"
+    np.testing.assert_array_equal(seen, g["env_seen_actions"])
+    np.testing.assert_array_equal(seen, g["ref_actions"])
+    # ---- episode statistics (raw rewards, batched_sampling.py:215-287)
+    st = runner.ep_stats.cpu().numpy()
+    assert st[2] == len(g["ep_reward"]) and st[1] == g["ep_len"].astype(np.int64).sum()
+    np.testing.assert_allclose(st[0], g["ep_reward"].astype(np.float64).sum(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_array_equal(runner.ep_return.cpu().numpy(), g["final_ep_reward"])
+    np.testing.assert_array_equal(runner.ep_len.cpu().numpy(), g["final_ep_len"])
+    if rnn_type:  # the state the NEXT rollout would start from
+        np.testing.assert_array_equal(rows["rnn_states"][:, T].cpu().numpy(), g["final_last_rnn"])

@@ -231,3 +231,28 @@ def test_float64_anchor_of_the_train_replays(golden, name, ref_bound):
         assert (rp <= np.array([12800, 5184, 3136, 512]) * 1024).all()
     else:
         assert "relu_pos64" not in g.files  # tanh network: no kinks to count
+
+
+@pytest.mark.parametrize("case", ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1"])
+def test_rollout_restatement_equals_the_reference_runner(golden, case):
+    """oracle.rollout_replay (numpy) against slab rows written by the reference's BatchedVectorEnvRunner
+    (tests/golden/rollout_*.npz, oracle/gen_golden.py gen_rollout_case): bit-equal"""
+    import oracle
+    g = golden("rollout_" + case)
+    T = int(g["T"])
+    key = [str(k) for k in g["obs_keys"]][0]
+    outs, st = oracle.rollout_replay(g["in_rew"], g["in_term"], g["in_trunc"], g["in_new_rnn"], g[f"in_obs_{key}"], T=T,
+                                     reward_scale=float(g["reward_scale"]), reward_clip=float(g["reward_clip"]))
+    assert len(outs) == int(g["n_rollouts"])
+    for r, cur in enumerate(outs):
+        for name in ("rewards", "dones", "time_outs", "rnn_states"):
+            np.testing.assert_array_equal(cur[name], g[f"out{r}_{name}"], err_msg=f"rollout {r} {name}")
+        np.testing.assert_array_equal(cur["obs"], g[f"out{r}_obs_{key}"])
+        assert (g[f"out{r}_policy_id"] == int(g["policy_id"])).all()
+        np.testing.assert_array_equal(g[f"out{r}_actions"][..., 0], g["ref_actions"][r * T:(r + 1) * T].T.astype(np.float32))
+        np.testing.assert_array_equal(g[f"out{r}_action_logits"], g["in_logits"][r * T:(r + 1) * T].transpose(1, 0, 2))
+        np.testing.assert_array_equal(g[f"out{r}_policy_version"], np.broadcast_to(g["in_versions"][r * T:(r + 1) * T], g[f"out{r}_policy_version"].shape))
+    for k in ("ep_reward", "ep_len", "final_ep_reward", "final_ep_len", "final_last_rnn"):
+        np.testing.assert_array_equal(st[k], g[k], err_msg=k)
+    _, la, _ = oracle.categorical(g["in_logits"].reshape(-1, int(g["A"])), g["ref_actions"].reshape(-1))
+    np.testing.assert_allclose(la.reshape(g["ref_logp"].shape), g["ref_logp"], atol=1e-6)
