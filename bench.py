@@ -33,6 +33,63 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_m
 PEAK_HBM_GBS = 8000.0
 
 
+class ClockSampler:
+    """shader clock of GPU 0 during the timed region (a host thread, never on the measured path): the roofline peak is
+    priced at the 2.4 GHz maximum, the chip runs at its power budget (MI355X_MICROARCH.md, DVFS) — `roofline.clock_ghz` and
+    `frac_at_measured_clock` say how much of the gap is clock.  Source: amdgpu sysfs pp_dpm_sclk (the starred level), else
+    `rocm-smi --showclocks`; None when neither is readable."""
+
+    def __init__(self, period=0.05):
+        import glob
+        self.period, self.samples, self._stop, self._thr = period, [], False, None
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.source = None
+
+    def _read(self):
+        import re
+        for p_ in self.paths[:1]:
+            try:
+                txt = open(p_).read()
+                m = [ln for ln in txt.splitlines() if ln.strip().endswith("*")]
+                if m:
+                    self.source = "sysfs pp_dpm_sclk"
+                    return float(re.search(r"(\d+)\s*[Mm][Hh]z", m[0]).group(1))
+            except Exception:  # noqa: BLE001
+                pass
+        try:
+            import subprocess
+            r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks"], capture_output=True, text=True, timeout=5)
+            m = re.search(r"sclk clock level:?\s*\d+:?\s*\((\d+)\s*[Mm][Hh]z\)", r.stdout)
+            if m:
+                self.source = "rocm-smi --showclocks"
+                return float(m.group(1))
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+
+    def _loop(self):
+        while not self._stop:
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            time.sleep(self.period if self.source == "sysfs pp_dpm_sclk" else 0.5)
+
+    def start(self):
+        import threading
+        self._thr = threading.Thread(target=self._loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(timeout=8)
+        if not self.samples:
+            return None
+        s_ = sorted(self.samples)
+        return {"ghz": round(s_[len(s_) // 2] / 1e3, 3), "min_ghz": round(s_[0] / 1e3, 3), "max_ghz": round(s_[-1] / 1e3, 3),
+                "samples": len(s_), "source": self.source}
+
+
 def kernel_flops(key):
     """algorithmic FLOPs of one launch of a network kernel (2*M*N*K of the implicit GEMM)"""
     op, n, Cin, H, W, Cout, K, S, OH, OW = key[:10]
@@ -117,7 +174,30 @@ def secondary_lines(args):
             out.append(ent)
         except Exception as e:  # noqa: BLE001 - a secondary line must never take the headline line down
             out.append({"workload": wl, "error": repr(e)})
+    out.append(reference_on_this_gpu())
     return out
+
+
+def reference_on_this_gpu():
+    """CONTEXT, not credit: the reference's own ActorCritic.forward + Learner.train through stock PyTorch-ROCm / MIOpen on
+    the same MI355X (oracle/ref_cpu_tier_b.py --device cuda, a process of its own, after the timed region), full workload
+    size — says whether the hand-written path beats the stock stack on this box, next to the CPU baseline."""
+    import subprocess
+    from oracle import ref_import_path  # baseline leg only; never on the measured path
+    if not ref_import_path.reference_available():
+        return {"workload": "reference_torch_rocm", "error": "no reference archive (make -C oracle ref)"}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", "--device", "cuda", "4096", "2"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=240)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"workload": "reference_torch_rocm", "error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+        d = json.loads(line[-1])
+        d["wall_s"] = round(time.perf_counter() - t0, 1)
+        return d
+    except Exception as e:  # noqa: BLE001
+        return {"workload": "reference_torch_rocm", "error": repr(e)}
 
 
 def _free_port() -> int:
@@ -334,12 +414,16 @@ def main():
     if args.workload == "c3":
         for sm in runner.samplers:
             sm.ingest_prof, sm.h2d_bytes = {}, 0
+    clk = ClockSampler() if rank == 0 else None
     barrier()
+    if clk is not None:
+        clk.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.iteration()
     barrier()
     dt = time.perf_counter() - t0
+    clock = clk.stop() if clk is not None else None
     runner.stop_sampler_thread()  # (threaded async mode, host envs) no-op otherwise
     ingest = None
     if args.workload == "c3":
@@ -438,12 +522,20 @@ def main():
                 "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                 "gflop_per_launch": round(flops / launches / 1e9, 3),
                 "share_of_step_time": round(total_ms / (dt * 1e3), 4), "shapes": shapes}
+    if clock is not None:  # peak is priced at the 2.4 GHz maximum clock; the timed region ran at clock["ghz"] (median sample)
+        roofline["clock_ghz"] = clock["ghz"]
+        roofline["clock"] = clock
+        roofline["frac_at_measured_clock"] = round(achieved / (PEAK_F32_MFMA_TFLOPS * clock["ghz"] / 2.4), 4)
+    else:
+        roofline["clock_ghz"] = None
+        roofline["clock_note"] = "shader clock not readable on this box (no pp_dpm_sclk, no rocm-smi): frac is priced at 2.4 GHz"
     if exact_bf16_kernel(dominant):  # HBM-bound kernel: algorithmic bytes per launch / launch duration against 8 TB/s
         nbytes = sum(kernel_bytes(key) * len(evs) for key, evs in prof.items())
         gbs = nbytes / (total_ms * 1e-3) / 1e9
         roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(gbs / PEAK_HBM_GBS, 4), "gbytes_per_launch": round(nbytes / launches / 1e9, 4)})
         roofline.pop("gflop_per_launch")
+        roofline.pop("frac_at_measured_clock", None)  # (an HBM-bound kernel is not priced against the shader clock)
     net_ms = sum(k[0] for k in kern)
     net_flops = sum(kernel_flops(k[1]) * k[2] for k in kern)
     breakdown = [{"kernel": f"{k[1][0]}:{k[1][2]}x{k[1][3]}->{k[1][5]} n={k[1][1]}", "name": k[1][-1],

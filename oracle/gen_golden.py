@@ -534,6 +534,18 @@ def gen_train_cnn84():
               p_other_policy=0.05, extra=["--exploration_loss_coeff=0.01"], fp64_first_step=True)
 
 
+def gen_train_cnn84_32k():
+    """The reference's Learner.train at the LAUNCH SIZE of the headline number: Nature-CNN on 84x84x4 u8 frames, E = 1024
+    trajectories x T = 32 = ONE minibatch of 32768 samples (BASELINE configs[1] / NS-2's batch_size), two epochs = two SGD
+    steps on it (the second one sees the first one's Adam update), 2 % rows of another policy.  fp32 replay + the same
+    loop in float64 + ReLU-positive counts, as train_cnn84 (which has 2 minibatches x 1024)."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 84, 84), np.uint8)})
+    gen_train("cnn84_32k", obs, C2_MODEL_ARGS, E=1024, T=32, A=6, nb=1, epochs=2, subsample=37, obs_seed=32768,
+              p_other_policy=0.02, extra=["--exploration_loss_coeff=0.01"], fp64_first_step=True)
+    torch.set_num_threads(1)
+
+
 C5_OBS = gym.spaces.Dict({"obs": gym.spaces.Box(-10, 10, (27,), np.float32)})
 # sf_examples/mujoco/mujoco_params.py:1-38 + what BASELINE configs[4] adds (LSTM core, V-trace; SURVEY.md §8d "C5")
 C5_MODEL_ARGS = ["--encoder_mlp_layers", "64", "64", "--nonlinearity=tanh", "--normalize_input=True",
@@ -919,6 +931,8 @@ def main():
         gen_ref_checkpoint()
     if "cnn84" in which:
         gen_train_cnn84()
+    if "cnn84_32k" in which:
+        gen_train_cnn84_32k()
     if "c5" in which:
         gen_train_c5()
     if "c5_gru" in which:

@@ -7,7 +7,12 @@ oracle/ref_import.py, always as a process of its own (bench.py's cpu_baseline le
 A bounded sample is timed and extrapolated linearly to one 4096-env x 32-step iteration:
 env-steps/s = dataset size / (T x t_inference(4096 obs) + t_train(dataset)).
 
-  python -m oracle.ref_cpu_tier_b [envs_sample] [inference_seconds]
+  python -m oracle.ref_cpu_tier_b [envs_sample] [inference_seconds] [threads|auto]
+  python -m oracle.ref_cpu_tier_b --device cuda [envs] [inference_seconds]
+
+`--device cuda` (context only, reported by bench.py as secondary workload "reference_torch_rocm"): the SAME reference code
+with `--device=gpu`, i.e. its stock PyTorch-ROCm / MIOpen path on the MI355X of the box, at the FULL workload size
+(4096 trajectories x 32 steps, nothing extrapolated), after one untimed iteration that absorbs MIOpen's kernel search.
 """
 from __future__ import annotations
 
@@ -27,7 +32,85 @@ from sample_factory.algo.utils.shared_buffers import alloc_trajectory_tensors
 from sample_factory.model.model_utils import get_rnn_size
 
 
+def main_cuda(argv):
+    """the reference on the GPU of this box through stock PyTorch-ROCm (learner.py / actor_critic.py unchanged)"""
+    os.environ.setdefault("CUDA_VISIBLE_DEVICES", "0")  # gpu_utils.get_available_gpus reads it
+    E = int(argv[0]) if len(argv) > 0 else 4096
+    t_budget = float(argv[1]) if len(argv) > 1 else 3.0
+    T, nb = 32, 4
+    obs_space = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 84, 84), np.uint8)})
+    cfg = make_cfg(C2_MODEL_ARGS + [f"--rollout={T}", f"--batch_size={E * T // nb}", f"--num_batches_per_epoch={nb}",
+                                    "--num_epochs=1", "--exploration_loss_coeff=0.01", "--device=gpu"])
+    assert cfg.device == "gpu"
+    t_setup = time.perf_counter()
+    learner, env_info = make_learner(cfg, obs_space, gym.spaces.Discrete(6), E)
+    ac = learner.actor_critic
+    dev = learner.device
+    assert dev.type == "cuda", dev
+    g = torch.Generator().manual_seed(0)
+    b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
+    fill_batch(b, g, 6, p_done=0.01)
+    from sample_factory.algo.utils.tensor_dict import TensorDict
+
+    def to_dev(td):
+        return TensorDict({k: to_dev(v) if isinstance(v, dict) else v.to(dev) for k, v in td.items()})
+
+    b = to_dev(b)
+    obs0 = {"obs": b["obs"]["obs"][:, 0].clone()}
+    rnn0 = b["rnn_states"][:, 0].clone()
+    from sample_factory.algo.utils.tensor_dict import clone_tensordict
+
+    def infer():
+        with torch.no_grad():
+            ac(prepare_and_normalize_obs(ac, obs0), rnn0)
+
+    # ---- untimed: one inference step + one Learner.train at the full shapes (MIOpen find / hipBLASLt heuristics)
+    ac.eval()
+    infer()
+    ac.train()
+    learner.train(clone_tensordict(b))
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    # ---- timed
+    ac.eval()
+    infer()
+    torch.cuda.synchronize()
+    t0, reps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < t_budget:
+        infer()
+        torch.cuda.synchronize()  # the reference's inference worker synchronises every step (inference_worker.py:337)
+        reps += 1
+    t_inf = (time.perf_counter() - t0) / reps
+    ac.train()
+    trains = []
+    for _ in range(2):
+        bb = clone_tensordict(b)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        learner.train(bb)
+        torch.cuda.synchronize()
+        trains.append(time.perf_counter() - t1)
+    t_train = min(trains)
+    t_iter = T * t_inf + t_train
+    print(json.dumps(dict(
+        workload="reference_torch_rocm", value=round(E * T / t_iter, 1), unit="env-steps/s", kind="reference",
+        device=torch.cuda.get_device_name(0), ms_per_step=round(t_iter * 1e3, 2),
+        sample=f"the reference's ActorCritic.forward on {E} obs ({t_inf * 1e3:.2f} ms per step, {reps} reps) x {T} steps + "
+               f"Learner.train on the {E}x{T} dataset in {nb} minibatches ({t_train * 1e3:.1f} ms, best of 2), torch "
+               f"{torch.__version__} on {dev} (stock PyTorch-ROCm / MIOpen, fp32); env excluded; one untimed warm-up "
+               f"iteration ({t_setup:.1f} s incl. MIOpen search)",
+        t_inference_ms_per_step=round(t_inf * 1e3, 3), t_train_ms=round(t_train * 1e3, 2), warmup_s=round(t_setup, 1),
+        miopen_find_mode=os.environ.get("MIOPEN_FIND_MODE", "default"), reference_from=ref_import.REFERENCE_ROOT)))
+
+
 def main():
+    if "--device" in sys.argv:
+        i = sys.argv.index("--device")
+        dev = sys.argv[i + 1]
+        rest = sys.argv[1:i] + sys.argv[i + 2:]
+        if dev == "cuda":
+            return main_cuda(rest)
+        sys.argv = sys.argv[:1] + rest
     cores = len(os.sched_getaffinity(0))
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 128   # trajectories in the timed sample
     t_budget = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
