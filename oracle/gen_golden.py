@@ -471,10 +471,28 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
     orig_clip = torch.nn.utils.clip_grad_norm_
     first_grads = {}
 
+    relu_pos32 = []
+    count32 = (fp64_first_step and nb == 1 and cfg.nonlinearity == "relu" and
+               getattr(cfg, "encoder_conv_architecture", None) == "convnet_atari" and b["obs"]["obs"].dim() == 5)
+
     def spy_clip(params, max_norm, *a, **k):
         if not norms:  # gradient of the FIRST SGD step as the reference's fp32 autograd produced it (before clipping)
             for kname, p_ in learner.actor_critic.named_parameters():
                 first_grads[kname] = p_.grad.detach().clone()
+        if count32:  # positive ReLU outputs of the reference's OWN fp32 forward of this SGD step (one minibatch = the dataset):
+            # how many activations the reference itself puts on the other side of zero than float64 (relu_pos64)
+            import torch.nn.functional as F
+            sd_ = learner.actor_critic.state_dict()
+            pfx = "encoder.encoders.obs.enc."
+            with torch.no_grad():
+                row = []
+                x = b["obs"]["obs"][:, :-1].reshape(-1, *b["obs"]["obs"].shape[2:]).float().mul_(1.0 / cfg.obs_scale)
+                for i, stride in ((0, 4), (2, 2), (4, 1)):
+                    x = F.relu(F.conv2d(x, sd_[pfx + f"conv_head.{i}.weight"], sd_[pfx + f"conv_head.{i}.bias"], stride=stride))
+                    row.append(int((x > 0).sum()))
+                x = F.relu(F.linear(x.reshape(x.shape[0], -1), sd_[pfx + "mlp_layers.0.weight"], sd_[pfx + "mlp_layers.0.bias"]))
+                row.append(int((x > 0).sum()))
+            relu_pos32.append(row)
         n = orig_clip(params, max_norm, *a, **k)
         norms.append(float(n))
         return n
@@ -483,6 +501,9 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
     stats = learner.train(clone_tensordict(b))
     torch.nn.utils.clip_grad_norm_ = orig_clip
     arrays["grad_norms"] = np.array(norms)
+    if relu_pos32:
+        arrays["relu_pos32"] = np.array(relu_pos32, dtype=np.int64)
+        print("  fp32 (reference) ReLU positives per SGD step:", relu_pos32)
     for k, _ in shapes:
         arrays["g1_" + k] = first_grads[k].numpy().reshape(-1)[::subsample].copy()
     arrays["train_step"] = learner.train_step

@@ -1424,10 +1424,9 @@ static bool linear_dgrad_glds64_ok(const ConvG &g, int64_t n) {
     return on && g.H == 1 && g.W == 1 && g.KH == 1 && g.KW == 1 && g.Cout % 32 == 0 && g.Cout >= 512 && g.Cin == 64 &&
            n >= 8192;
 }
-// stride-1 convolutions with 3 filter columns take the tap-reuse kernel (k_dgrad_row); SF_DGRAD_ROW=0: k_dgrad_pix
-static bool dgrad_row_ok(const ConvG &g) {
-    static const int on = getenv("SF_DGRAD_ROW") ? atoi(getenv("SF_DGRAD_ROW")) : 1;
-    return on && g.S == 1 && g.KW == 3 && g.Cin > 32 && g.W == g.OW + 2 && g.H == g.OH + g.KH - 1 && g.Cout % 32 == 0;
+static int dgrad_lpt() {  // longest rows first (k_dgrad_pix block order, sf_nn_glds.h); SF_DGRAD_LPT=0: row-major block ids
+    static const int on = getenv("SF_DGRAD_LPT") ? atoi(getenv("SF_DGRAD_LPT")) : 1;
+    return on;
 }
 extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                              const sf_conv_desc *h_desc, void *stream) {
@@ -1471,7 +1470,7 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     do {                                                                                                   \
         const int ntiles = (int)((n + BM - 1) / BM), tiles8 = (ntiles + 7) / 8, ctiles = (g.Cin + BN - 1) / BN; \
         k_dgrad_pix<BM, BN, WM, WN><<<dim3((unsigned)(tiles8 * 8 * g.H * ctiles)), dim3(256), 0, st>>>(    \
-            g, dout, w, in_act, din, (int)n, ntiles, tiles8);                                              \
+            g, dout, w, in_act, din, (int)n, ntiles, tiles8, dgrad_lpt());                                 \
     } while (0)
         if (g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0 && pix_cfg != 3) {
             // strided conv, row-walking tiles of (sample, group-column) rows: contiguous activation / gradient rows
@@ -1479,12 +1478,6 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
             const int64_t Mrows = n * Wg;
             k_dgrad_quadrow<128, 128, 2, 2><<<dim3(cdiv64(Mrows, 128), cdiv64(g.S * g.S * g.Cin, 128)), dim3(256), 0,
                                               st>>>(g, dout, w, in_act, din, Mrows, make_fastdiv((uint32_t)Wg));
-            return sf_launch_status("sf_conv_dgrad");
-        }
-        if (dgrad_row_ok(g)) {  // stride 1, 3 filter columns (Nature-CNN conv3): dY chunks reused across the filter columns
-            const int ntiles = (int)((n + 127) / 128), tiles8 = (ntiles + 7) / 8, ctiles = (g.Cin + 63) / 64;
-            k_dgrad_row<128, 64, 4, 2, 3><<<dim3((unsigned)(tiles8 * 8 * g.H * ctiles)), dim3(512), 0, st>>>(
-                g, dout, w, in_act, din, (int)n, ntiles, tiles8);
             return sf_launch_status("sf_conv_dgrad");
         }
         if (g.Cin <= 32) { if (pix_cfg == 2) DGRAD_PIX(128, 32, 4, 1); else DGRAD_PIX(256, 32, 4, 1); }
@@ -1541,7 +1534,6 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         else if (g.vecB && linear_dgrad_glds64_ok(g, n)) snprintf(out, cap, "k_fwd_glds<64, 64, 2, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
             snprintf(out, cap, "k_dgrad_quadrow<128, 128, 2, 2>");
-        else if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && dgrad_row_ok(g)) snprintf(out, cap, "k_dgrad_row<128, 64, 4, 2, 3>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024)
             snprintf(out, cap, g.Cin <= 32 ? "k_dgrad_pix<256, 32, 4, 1>" : "k_dgrad_pix<128, 64, 2, 2>");
         else if (g.Cin <= 32) snprintf(out, cap, "k_conv_dgrad<128, 32, 4, 1, %s>", v);

@@ -11,8 +11,12 @@ import numpy as np
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
-def compare_post_train(learner, g, before, tag, *, m_rtol, v_rtol, d_rtol, gn_rtol, floor=2e-3):
-    """returns a report of the worst errors per quantity; asserts the tolerances of the module docstring"""
+def compare_post_train(learner, g, before, tag, *, m_rtol, v_rtol, d_rtol, gn_rtol, floor=2e-3, delta_outliers=0.0):
+    """returns a report of the worst errors per quantity; asserts the tolerances of the module docstring.
+    delta_outliers: fraction of a tensor's weight-delta elements that may miss the tolerance (32768-sample minibatches: a
+    handful of the 1.6 M fc weights have a gradient within round-off of ZERO — dead ReLU inputs — and Adam's g / (|g| + eps)
+    turns a 1e-9 difference there into a delta difference of a few percent of the largest delta; the float64 comparison of
+    tests/test_gpu_parity_c2_c5.py shows the reference's own fp32 run has the same outliers)."""
     ac = learner.actor_critic
     sub = int(g["subsample"])
     after, m, v = ac.state_dict(), ac.flat_to_ref(learner.exp_avg), ac.flat_to_ref(learner.exp_avg_sq)
@@ -49,5 +53,9 @@ def compare_post_train(learner, g, before, tag, *, m_rtol, v_rtol, d_rtol, gn_rt
     np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=gn_rtol)
     assert all(fr >= 0.9 for _, fr in fracs), fracs
     for a, b, rtol, atol, msg in checks:
+        if delta_outliers > 0 and msg.startswith("weight delta"):
+            bad = np.abs(a - b) > atol + rtol * np.abs(b)
+            assert bad.mean() <= delta_outliers, (msg, float(bad.mean()), int(bad.sum()))
+            continue
         np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
     return rep

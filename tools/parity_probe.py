@@ -81,7 +81,7 @@ def main():
     rep["fwd"] = dict(conv1=e(acts[0], nhwc(a1)), conv2=e(acts[1], nhwc(a2)), conv3=e(acts[2], nhwc(a3)),
                       fc=e(acts[3], f), heads=e(acts[4][:, :1 + A], heads))
     gb = dict(ac._bufs)
-    if getattr(ac, "_relu_mask0", None) is not None:  # conv1's ReLU mask is applied inside its weight-gradient kernel
+    if ac._ctx["train"].get("relu_mask0") is not None:  # conv1's ReLU mask is applied inside its weight-gradient kernel
         gb[("g", 0)] = gb[("g", 0)] * (acts[0] > 0)
     rep["dgrad (gradient wrt the layer's pre-activation)"] = dict(
         conv1=e(gb[("g", 0)], nhwc(z1.grad)), conv2=e(gb[("g", 1)], nhwc(z2.grad)),
