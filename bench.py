@@ -188,8 +188,20 @@ def reference_on_this_gpu():
         return {"workload": "reference_torch_rocm", "error": "no reference archive (make -C oracle ref)"}
     t0 = time.perf_counter()
     try:
+        # MIOpen's kernel search for the reference's 18 fp32 convolution problems takes ~3 minutes on a fresh box; its
+        # result (the user find-db written by such a run on an MI355X) is committed under oracle/miopen_db and handed to
+        # the subprocess through a scratch copy, so the reference runs on the kernels MIOpen itself picked, in seconds
+        import shutil
+        import tempfile
+        env = dict(os.environ)
+        src_db = os.path.join(ROOT, "oracle", "miopen_db")
+        if os.path.isdir(src_db) and "MIOPEN_USER_DB_PATH" not in env:
+            tmp_db = tempfile.mkdtemp(prefix="sf_miopen_db_")
+            for f in os.listdir(src_db):
+                shutil.copy(os.path.join(src_db, f), tmp_db)
+            env["MIOPEN_USER_DB_PATH"] = tmp_db
         r = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", "--device", "cuda", "4096", "2"], cwd=ROOT,
-                           capture_output=True, text=True, timeout=240)
+                           capture_output=True, text=True, timeout=300, env=env)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
             return {"workload": "reference_torch_rocm", "error": f"rc {r.returncode}: {r.stderr[-300:]}"}

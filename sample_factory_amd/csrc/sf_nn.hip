@@ -1072,9 +1072,19 @@ extern "C" int64_t sf_conv_fwd_t_workspace(int64_t n, const sf_conv_desc *h_desc
     const GldsFwdPlan p = plan_fwd_t(Mtot, h_desc->Cout, h_desc->KH * h_desc->KW * h_desc->Cin);
     return p.ok && p.Z > 1 ? (int64_t)sizeof(float) * p.Z * Mtot * h_desc->Cout + 256 : 0;
 }
+// (XCD-aware block order of the launches with more than one column tile: sf_nn_glds.h; SF_XCD_RASTER=0 switches it off)
+static int xcd_raster_on() {
+    static const int on = getenv("SF_XCD_RASTER") ? atoi(getenv("SF_XCD_RASTER")) : 1;
+    return on;
+}
 #define GLDS_FWD(BM, BN, WM, WN, NS)                                                                           \
-    k_fwd_glds<BM, BN, WM, WN, NS><<<dim3(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), p.Z), dim3(256), 0, st>>>(     \
-        g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial, nullptr, 0)
+    do {                                                                                                       \
+        dim3 gq(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), p.Z);                                                    \
+        const int rx = (int)gq.x, ry = (int)gq.y, rtot = (xcd_raster_on() && gq.y > 1) ? (int)(gq.x * gq.y * gq.z) : 0; \
+        if (rtot > 0) gq = dim3((unsigned)(8 * ((rtot + 7) / 8)), 1, 1);                                        \
+        k_fwd_glds<BM, BN, WM, WN, NS><<<gq, dim3(256), 0, st>>>(                                              \
+            g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial, nullptr, 0, rx, ry, rtot);   \
+    } while (0)
 extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
                              int64_t n, const sf_conv_desc *h_desc, void *workspace, int64_t workspace_bytes,
                              void *stream) {
@@ -1371,10 +1381,14 @@ static int conv_wgrad_impl(const void *in, int64_t in_sample_stride, const int32
         partial_b = partial_w + (int64_t)q.Z * K * N;
         Zused = q.Z;
         dim3 gq(cdiv64(K, q.BK), cdiv64(N, q.BN), (unsigned)q.Z);
+        // XCD-aware block order (sf_nn_glds.h): a 1-D launch whose ids are re-mapped so that every XCD owns a contiguous
+        // run of (row tile, column tile, slice) — only worth it when tiles share strips (more than one tile per slice)
+        const int rx = (int)gq.x, ry = (int)gq.y, rtot = (xcd_raster_on() && gq.x * gq.y > 1) ? (int)(gq.x * gq.y * gq.z) : 0;
+        if (rtot > 0) gq = dim3((unsigned)(8 * ((rtot + 7) / 8)), 1, 1);
         const float *inf = reinterpret_cast<const float *>(in);
 #define WGRAD_GLDS(BK_, BN_, WM_, WN_)                                                                      \
     k_wgrad_glds<BK_, BN_, WM_, WN_><<<gq, dim3(256), 0, st>>>(g, inf, in_sample_stride, dout, partial_w,   \
-                                                              db ? partial_b : nullptr, Mtot, q.m_per_split)
+                                                              db ? partial_b : nullptr, Mtot, q.m_per_split, rx, ry, rtot)
         if (q.cfg == 3) WGRAD_GLDS(64, 128, 2, 2);
         else if (q.cfg == 0) WGRAD_GLDS(256, 64, 4, 1);
         else if (q.cfg == 1) WGRAD_GLDS(128, 128, 2, 2);
@@ -1452,8 +1466,13 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     if (lin_on && linear_dgrad_glds_ok(g, n) && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0) {
         sf_conv_desc d2 = linear_desc(g.Cout, g.Cin, g.relu);  // reduction = Cout, columns = Cin, relu = kind of in_act
         const ConvG g2 = make_geom(&d2);
-        k_fwd_glds<128, 128, 2, 2, 2><<<dim3(cdiv64(n, 128), cdiv64(g.Cin, 128), 1), dim3(256), 0, st>>>(
-            g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1);
+        dim3 gq(cdiv64(n, 128), cdiv64(g.Cin, 128), 1);
+        // (measured slower for this launch — 950 vs 930 us at n = 32768: both orders re-read one operand from the Infinity
+        // Cache, and the row-strip order sweeps the 6.4 MB weight matrix per strip — so only SF_XCD_RASTER=2 enables it here)
+        const int rx = (int)gq.x, ry = (int)gq.y, rtot = (xcd_raster_on() >= 2 && gq.y > 1) ? (int)(gq.x * gq.y) : 0;
+        if (rtot > 0) gq = dim3((unsigned)(8 * ((rtot + 7) / 8)), 1, 1);
+        k_fwd_glds<128, 128, 2, 2, 2><<<gq, dim3(256), 0, st>>>(
+            g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1, rx, ry, rtot);
         return sf_launch_status("sf_conv_dgrad");
     }
     if (lin_on && linear_dgrad_glds64_ok(g, n) && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0) {

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
                                                   const float *__restrict__ wt, const float *__restrict__ bias,
                                                   float *__restrict__ out, int64_t Mtot, int k_per_split,
                                                   float *__restrict__ partial, const float *__restrict__ dmask,
-                                                  int dmask_on) {
+                                                  int dmask_on, int rx = 0, int ry = 0, int rtot = 0) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
@@ -118,12 +118,25 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware block order (rtot > 0: 1-D launch of 8 * ceil(rtot / 8) ids, see k_wgrad_glds): XCD c owns a contiguous
+    // run of the logical order COLUMN TILE FASTEST, then row tile, then slice — the ry column tiles of one activation row
+    // strip run next to each other on one XCD (fc layer, n = 32768: the 411 MB activation matrix was fetched once per
+    // column tile, 1.65 GB per launch); the weight strips they differ in are small and shared by every row strip anyway.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (rtot > 0) {
+        const int per = (rtot + 7) >> 3, L = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+        if (L >= rtot) return;
+        by = L % ry;
+        const int t = L / ry;
+        bx = t % rx;
+        bz = t / rx;
+    }
+    const int64_t m0 = (int64_t)bx * BM;
+    const int n0 = by * BN;
     const int N = g.Cout, K = g.K;
     // split-K (grids too small to fill the chip): slice z reduces k in [kbeg, kend) into partial[z], k_splitk_finish
     // adds the slices in ascending z, the bias and the activation
-    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    const int kbeg = bz * k_per_split, kend = min(K, kbeg + k_per_split);
 
     // per-lane DMA sources: lane = (row-in-group lrow, chunk position lpos); position p holds chunk p ^ swz(row)
     const int lrow = lane >> 3, lpos = lane & 7;
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     // epilogue: uniform base pointer + one 32-bit lane offset; the activation kind and the "tile is complete" test
     // are hoisted out of the 16*TM*TN element loop (per element: bias add, max, address add, store — the first
     // version re-derived a 64-bit m*N+n and branched on the kind per element: 13 VALU + 3 quarter-rate multiplies)
-    float *ob = (partial ? partial + (int64_t)blockIdx.z * Mtot * N : out) + (m0 + wm * TM * 32) * N + (n0 + wn * TN * 32);
+    float *ob = (partial ? partial + (int64_t)bz * Mtot * N : out) + (m0 + wm * TM * 32) * N + (n0 + wn * TN * 32);
     const int rows_left = (int)min((int64_t)(TM * 32), Mtot - m0 - wm * TM * 32) - 4 * (lane >> 5);
     const int cols_left = N - (n0 + wn * TN * 32) - (lane & 31);
     const uint32_t voff = (uint32_t)(4 * (lane >> 5)) * (uint32_t)N + (uint32_t)(lane & 31);
@@ -592,18 +605,34 @@ __device__ __forceinline__ float vec_elem(const typename VecW<W>::T &v, int i) {
 template <int BK, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                                     const float *__restrict__ dy, float *__restrict__ partial,
-                                                    float *__restrict__ partial_b, int64_t Mtot, int64_t m_per_split) {
+                                                    float *__restrict__ partial_b, int64_t Mtot, int64_t m_per_split,
+                                                    int rx, int ry, int rtot) {
     constexpr int TM = BK / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4 && (TM == 1 || TM == 2 || TM == 4) && (TN == 1 || TN == 2 || TN == 4), "tile");
+    // XCD-aware block order (rtot > 0: 1-D launch of 8 * ceil(rtot / 8) blocks).  The hardware deals consecutive block ids
+    // to the 8 XCDs round-robin, so in a plain 3-D launch the tiles that share an operand strip — the ry column tiles of a
+    // weight-row strip, the rx row tiles of a dY column strip, all of one reduction slice — land on 8 different L2s and
+    // every strip is fetched from memory by each of them (fc layer, n = 32768: 2.29 GB per launch against 0.48 GB of
+    // operands).  Here XCD c takes the CONTIGUOUS run [c * per, (c + 1) * per) of the logical order (x fastest, then y,
+    // then z): a slice's tiles sit on one or two XCDs and walk their shared rows through the same L2 together.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (rtot > 0) {
+        const int per = (rtot + 7) >> 3, L = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+        if (L >= rtot) return;
+        bx = L % rx;
+        const int t = L / rx;
+        by = t % ry;
+        bz = t / ry;
+    }
     constexpr int A_RPI = 256 / BK, B_RPI = 256 / BN;  // reduction rows per 1-KiB DMA instruction
     constexpr int AI = 32 / A_RPI / 4, BI = 32 / B_RPI / 4;  // DMA instructions per wave and chunk
     constexpr int STAGE = (BK + BN) * 32;
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
-    const int k0row = blockIdx.x * BK, n0 = blockIdx.y * BN;
+    const int k0row = bx * BK, n0 = by * BN;
     const int N = g.Cout, K = g.K;
-    const int64_t mbeg = (int64_t)blockIdx.z * m_per_split;
+    const int64_t mbeg = (int64_t)bz * m_per_split;
     const int64_t mend = (mbeg + m_per_split < Mtot) ? mbeg + m_per_split : Mtot;
 
     // DMA lanes: A instruction j covers reduction rows j*A_RPI.. ; lane -> (row-in-instr, 16-byte position).
@@ -665,7 +694,7 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
             GLDS16(src, sb + (i * 4 + wave) * 256);
         }
     };
-    const bool do_colsum = partial_b != nullptr && blockIdx.x == 0 && tid < BN;
+    const bool do_colsum = partial_b != nullptr && bx == 0 && tid < BN;
     float colacc = 0.f;
     if (mbeg < mend) issue(mbeg, 0);
     int stage = 0;
@@ -695,8 +724,8 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
                                                                        acc[tm][tn], 0, 0, 0);
         }
     }
-    if (do_colsum && n0 + tid < N) partial_b[(int64_t)blockIdx.z * N + n0 + tid] = colacc;
-    float *dst = partial + (int64_t)blockIdx.z * K * N;
+    if (do_colsum && n0 + tid < N) partial_b[(int64_t)bz * N + n0 + tid] = colacc;
+    float *dst = partial + (int64_t)bz * K * N;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
