@@ -671,6 +671,40 @@ def gen_model_fwd_multi():
          param_shapes=np.array([str(s) for _, s in shapes]))
 
 
+def gen_model_fwd_separate():
+    """ActorCriticSeparateWeights (model/actor_critic.py:198-334, --actor_critic_share_weights=False): an encoder, core
+    and decoder each for actor and critic; recurrent state = [actor | critic].  Feed-forward MLP, GRU and LSTM cores."""
+    for tag, extra, S in (("ff", ["--use_rnn=False"], 2),
+                          ("gru", ["--use_rnn=True", "--rnn_type=gru", "--rnn_size=12", "--recurrence=4"], 24),
+                          ("lstm", ["--use_rnn=True", "--rnn_type=lstm", "--rnn_size=10", "--recurrence=4",
+                                    "--decoder_mlp_layers", "14"], 40)):
+        argv = ["--algo=APPO", "--env=synthetic", "--experiment=golden", "--train_dir=/tmp/sf_golden", "--device=cpu",
+                "--serial_mode=True", "--seed=0", "--actor_critic_share_weights=False", "--encoder_mlp_layers", "16", "12",
+                "--nonlinearity=tanh", "--normalize_input=False", "--rollout=4", "--batch_size=8",
+                "--num_batches_per_epoch=1"] + extra
+        parser, _ = parse_sf_args(argv)
+        cfg = parse_full_cfg(parser, argv)
+        assert get_rnn_size(cfg) == S, (get_rnn_size(cfg), S)
+        learner, env_info = make_learner(cfg, MLP_OBS, gym.spaces.Discrete(5), 2)
+        ac = learner.actor_critic
+        assert type(ac).__name__ == "ActorCriticSeparateWeights"
+        shapes = load_seeded(ac, seed=21)
+        g = torch.Generator().manual_seed(79)
+        obs = torch.randn((6, 8), generator=g)
+        rnn = torch.randn((6, S), generator=g) * 0.5
+        ac.eval()
+        with torch.no_grad():
+            nobs = ac.normalize_obs({"obs": obs})
+            head = ac.forward_head(nobs)
+            core, new_rnn = ac.forward_core(head, rnn)
+            res = ac.forward_tail(core, values_only=False, sample_actions=False)
+        save("model_fwd_separate_" + tag, ref="model/actor_critic.py:198-334 ActorCriticSeparateWeights", param_seed=21,
+             argv=" ".join(extra), obs=obs.numpy(), rnn_states=rnn.numpy(), head=head.numpy(), core=core.numpy(),
+             new_rnn_states=new_rnn.numpy(), action_logits=res["action_logits"].numpy(),
+             values=res["values"].reshape(-1).numpy(), param_names=np.array([k for k, _ in shapes]),
+             param_shapes=np.array([str(s) for _, s in shapes]))
+
+
 def gen_minibatch_indices():
     """Learner._get_minibatches — learner.py:498-526: contiguous slices by default; shuffled = permutation of
     recurrence-aligned chunk starts expanded to full index runs, np.split into minibatches."""
@@ -994,6 +1028,15 @@ def main():
     if "model" in which:
         gen_model_fwd()
         gen_model_fwd_multi()
+        gen_model_fwd_separate()
+    if "separate" in which:
+        gen_model_fwd_separate()
+    if "separate" in which or "train" in which:  # ActorCriticSeparateWeights through the reference's Learner.train
+        sep = ["--encoder_mlp_layers", "32", "--nonlinearity=relu", "--normalize_input=False",
+               "--actor_critic_share_weights=False"]
+        gen_train("sep_gru", MLP_OBS, sep + ["--use_rnn=True", "--rnn_size=32", "--recurrence=8", "--rnn_type=gru"], E=16, T=8,
+                  A=6, nb=2, epochs=1, use_rnn=True)
+        gen_train("sep_mlp", MLP_OBS, sep, E=16, T=8, A=6, nb=2, epochs=2, extra=["--kl_loss_coeff=0.1"])
     if "host" in which:
         gen_host_logic()
     if "rollout" in which:

@@ -222,6 +222,105 @@ class _TorchRnnCore(nn.Module):
         return self.H
 
 
+class _TorchMlpDecoder(nn.Module):
+    """model/decoder.py:15-31 (MlpDecoder): Linear + activation per cfg.decoder_mlp_layers entry, parameters under .mlp"""
+
+    def __init__(self, cfg, size):
+        super().__init__()
+        layers = []
+        for h in list(getattr(cfg, "decoder_mlp_layers", []) or []):
+            layers += [nn.Linear(size, int(h)), _nonlinearity(cfg)]
+            size = int(h)
+        self.mlp = nn.Sequential(*layers)
+        self.out_size = size
+
+    def forward(self, x):
+        return self.mlp(x)
+
+    def get_out_size(self) -> int:
+        return self.out_size
+
+
+def _make_decoder(cfg, size, factory):
+    if factory.make_model_decoder_func is not None:
+        return factory.make_model_decoder_func(cfg, size)
+    return _TorchMlpDecoder(cfg, size)
+
+
+def _initialize_weights(module: nn.Module, cfg) -> None:
+    """model/actor_critic.py:73-96 (ActorCritic.initialize_weights applied to every layer)"""
+    gain = cfg.policy_init_gain
+    for m in module.modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            if cfg.policy_initialization == "orthogonal":
+                nn.init.orthogonal_(m.weight, gain=gain)
+            elif cfg.policy_initialization == "xavier_uniform":
+                nn.init.xavier_uniform_(m.weight, gain=gain)
+            if cfg.policy_initialization != "torch_default" and m.bias is not None:
+                m.bias.data.fill_(0)
+
+
+class _SeparateTorchActorCritic(nn.Module):
+    """model/actor_critic.py:198-334 (ActorCriticSeparateWeights, cfg.actor_critic_share_weights=False): the actor and the
+    critic own an encoder, a core and a decoder each.  forward_head concatenates the two encodings, the recurrent state is
+    [actor state | critic state] (model_utils.py:20-22 doubles its width), forward_tail reads the value from the critic's
+    half and the action parameters from the actor's.  Parameter paths equal the reference's (actor_encoder.*, actor_core.*,
+    critic_encoder.*, critic_core.*, actor_decoder.mlp.*, critic_decoder.mlp.*, critic_linear.*,
+    action_parameterization.distribution_linear.*)."""
+
+    def __init__(self, cfg, obs_space, action_space, factory):
+        super().__init__()
+
+        def make_encoder():
+            if factory.make_model_encoder_func is not None:
+                return factory.make_model_encoder_func(cfg, obs_space)
+            return _TorchMultiInputEncoder(cfg, obs_space)
+
+        def make_core(size):
+            if factory.make_model_core_func is not None:
+                return factory.make_model_core_func(cfg, size)
+            return _TorchRnnCore(cfg, size) if cfg.use_rnn else None
+
+        self.actor_encoder = make_encoder()
+        self.actor_core = make_core(int(self.actor_encoder.get_out_size()))
+        self.critic_encoder = make_encoder()
+        self.critic_core = make_core(int(self.critic_encoder.get_out_size()))
+        a_size = int(self.actor_core.get_out_size()) if self.actor_core is not None else int(self.actor_encoder.get_out_size())
+        c_size = int(self.critic_core.get_out_size()) if self.critic_core is not None else int(self.critic_encoder.get_out_size())
+        self.actor_decoder = _make_decoder(cfg, a_size, factory)
+        self.critic_decoder = _make_decoder(cfg, c_size, factory)
+        self.critic_linear = nn.Linear(int(self.critic_decoder.get_out_size()), 1)
+        self.action_parameterization = nn.Module()
+        # (the reference sizes the action head by the CRITIC decoder's width, actor_critic.py:222; the two are equal)
+        self.action_parameterization.distribution_linear = nn.Linear(int(self.critic_decoder.get_out_size()),
+                                                                     calc_num_action_parameters(action_space))
+        _initialize_weights(self, cfg)
+
+    def forward_head(self, normalized_obs_dict):
+        return torch.cat([self.actor_encoder(normalized_obs_dict), self.critic_encoder(normalized_obs_dict)], dim=1)
+
+    def forward_core(self, head_output, rnn_states):
+        if self.actor_core is None:
+            return head_output, rnn_states
+        heads, states = head_output.chunk(2, dim=1), rnn_states.chunk(2, dim=1)
+        a_out, a_new = self.actor_core(heads[0], states[0])
+        c_out, c_new = self.critic_core(heads[1], states[1])
+        return torch.cat([a_out, c_out], dim=1), torch.cat([a_new, c_new], dim=1)
+
+    def forward_tail(self, core_output, values_only: bool = False):
+        a_feat, c_feat = core_output.chunk(2, dim=1)
+        res = dict(values=self.critic_linear(self.critic_decoder(c_feat)).squeeze(-1))
+        if not values_only:
+            res["action_logits"] = self.action_parameterization.distribution_linear(self.actor_decoder(a_feat))
+        return res
+
+    def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False):
+        x, new_rnn = self.forward_core(self.forward_head(normalized_obs_dict), rnn_states)
+        res = self.forward_tail(x, values_only)
+        res["new_rnn_states"] = new_rnn
+        return res
+
+
 class _DefaultTorchTail(nn.Module):
     """encoder -> [core] -> [decoder] -> critic_linear / distribution_linear, for a user-registered ENCODER (or core /
     decoder) with the remaining parts in their default form (model/actor_critic.py:136-195, decoder.py:15-31)."""
@@ -239,28 +338,13 @@ class _DefaultTorchTail(nn.Module):
             self.core = _TorchRnnCore(cfg, size) if cfg.use_rnn else None
         if self.core is not None:
             size = int(self.core.get_out_size())
-        if factory.make_model_decoder_func is not None:
-            self.decoder = factory.make_model_decoder_func(cfg, size)
-            size = int(self.decoder.get_out_size())
-        else:
-            layers = []
-            for h in list(getattr(cfg, "decoder_mlp_layers", []) or []):
-                layers += [nn.Linear(size, int(h)), _nonlinearity(cfg)]
-                size = int(h)
-            self.decoder = nn.Sequential(*layers)
+        self.decoder = _make_decoder(cfg, size, factory)
+        size = int(self.decoder.get_out_size())
         self.critic_linear = nn.Linear(size, 1)
         # same parameter path as the reference (model/action_parameterization.py:20-37)
         self.action_parameterization = nn.Module()
         self.action_parameterization.distribution_linear = nn.Linear(size, calc_num_action_parameters(action_space))
-        gain = cfg.policy_init_gain
-        for m in self.modules():  # actor_critic.py:73-96
-            if isinstance(m, (nn.Linear, nn.Conv2d)):
-                if cfg.policy_initialization == "orthogonal":
-                    nn.init.orthogonal_(m.weight, gain=gain)
-                elif cfg.policy_initialization == "xavier_uniform":
-                    nn.init.xavier_uniform_(m.weight, gain=gain)
-                if cfg.policy_initialization != "torch_default" and m.bias is not None:
-                    m.bias.data.fill_(0)
+        _initialize_weights(self, cfg)
 
     # head / core / tail as in model/actor_critic.py:160-195 (the recurrent training pass runs the core step by step)
     def forward_head(self, normalized_obs_dict):
@@ -294,6 +378,8 @@ def build_torch_actor_critic(cfg, obs_space, action_space, factory) -> nn.Module
     """the default actor-critic in torch around whatever the user registered; with no encoder registered (observation
     dicts of several keys and stacked recurrent layers land here) the reference's MultiInputEncoder (model/encoder.py:33-69:
     it is the default encoder for one key as well)"""
+    if not cfg.actor_critic_share_weights:  # ActorCriticSeparateWeights (model/actor_critic.py:198-334)
+        return _SeparateTorchActorCritic(cfg, obs_space, action_space, factory)
     enc = None
     if factory.make_model_encoder_func is None:
         enc = _TorchMultiInputEncoder(cfg, obs_space)

@@ -324,6 +324,52 @@ def test_multi_input_architecture_matches_reference_on_cpu():
     assert n_meas.scale == 1.0 and n_meas.sub_mean == 0.0 and n_meas.running
 
 
+@pytest.mark.parametrize("tag", ["ff", "gru", "lstm"])
+def test_separate_weights_architecture_matches_reference_on_cpu(tag):
+    """cfg.actor_critic_share_weights=False (model/actor_critic.py:198-334, ActorCriticSeparateWeights): parameter names,
+    shapes and — with the same seeded weights — head / core / new state / logits / values of the REFERENCE model
+    (tests/golden/model_fwd_separate_*.npz).  This path's network is plain torch (model/torch_policy.py), so the check runs
+    without a GPU; the recurrent state is [actor | critic], twice the shared-weights width (model_utils.py:20-22)."""
+    import os
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import get_rnn_size
+    from sample_factory_amd.model.model_factory import create_actor_critic
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter
+    from oracle.weights import seeded_state
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"model_fwd_separate_{tag}.npz"), allow_pickle=True)
+    kw = dict(ff=dict(use_rnn=False), gru=dict(use_rnn=True, rnn_type="gru", rnn_size=12, recurrence=4),
+              lstm=dict(use_rnn=True, rnn_type="lstm", rnn_size=10, recurrence=4, decoder_mlp_layers=[14]))[tag]
+    cfg = default_cfg(actor_critic_share_weights=False, encoder_mlp_layers=[16, 12], nonlinearity="tanh",
+                      normalize_input=False, normalize_returns=False, **kw)
+    cfg.dp_world = 1
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    ac = create_actor_critic(cfg, obs_space, spaces.Discrete(5), torch.device("cpu"))
+    assert isinstance(ac, TorchPolicyAdapter)
+    assert [(n, tuple(s)) for n, s in ac.ref_param_shapes()] == \
+        [(str(n), tuple(eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])]
+    st = seeded_state([(str(n), eval(str(s))) for n, s in zip(g["param_names"], g["param_shapes"])], int(g["param_seed"]))
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    ac.eval()
+    rnn = torch.from_numpy(g["rnn_states"])
+    assert rnn.shape[1] == get_rnn_size(cfg)
+    m = ac.module
+    with torch.no_grad():
+        head = m.forward_head({"obs": torch.from_numpy(g["obs"])})
+        core, new_rnn = m.forward_core(head, rnn)
+        res = m.forward_tail(core)
+    np.testing.assert_allclose(head.numpy(), g["head"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(core.numpy(), g["core"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(new_rnn.numpy(), g["new_rnn_states"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(res["action_logits"].numpy(), g["action_logits"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(res["values"].numpy(), g["values"], atol=2e-6, rtol=1e-5)
+    # ... and through the adapter's interface (what the rollout runner / evaluation call)
+    out = ac.forward({"obs": torch.from_numpy(g["obs"])}, rnn if cfg.use_rnn else None)
+    np.testing.assert_allclose(out["action_logits"].numpy(), g["action_logits"], atol=2e-6, rtol=1e-5)
+    if cfg.use_rnn:
+        np.testing.assert_allclose(out["new_rnn_states"].numpy(), g["new_rnn_states"], atol=1e-6, rtol=1e-5)
+
+
 def test_every_module_imports_without_a_gpu():
     """the whole host package must import on a CPU-only box (the HIP library is only dlopen'ed on first use)"""
     import importlib

@@ -1465,6 +1465,47 @@ def test_multi_input_model_forward_matches_reference(lib, golden):
     np.testing.assert_allclose(res["values"].cpu().numpy(), g["values"], atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["sep_gru", "sep_mlp"])
+def test_learner_train_matches_reference_separate_actor_critic_weights(lib, golden, tmp_path, name):
+    """cfg.actor_critic_share_weights=False (ActorCriticSeparateWeights, model/actor_critic.py:198-334): the reference's
+    Learner.train replayed on the torch model path create_actor_critic picks for it — two encoders / cores, recurrent
+    state [actor | critic] carried and chunk-started through the native slab kernels, loss / clip / Adam native."""
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import get_rnn_size
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter
+    g = golden("train_" + name)
+    E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
+    rnn = name == "sep_gru"
+    cfg = default_cfg(actor_critic_share_weights=False, use_rnn=rnn, rnn_type="gru", rnn_size=32, recurrence=8 if rnn else 1,
+                      nonlinearity="relu", normalize_input=False, encoder_mlp_layers=[32], rollout=T, batch_size=E * T // nb,
+                      num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]), kl_loss_coeff=0.0 if rnn else 0.1, seed=0,
+                      serial_mode=True, train_dir=str(tmp_path), experiment="t", record_grad_norm=True)
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
+    pv = torch.zeros(1, dtype=torch.int32)
+    learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
+    learner.init()
+    ac = learner.actor_critic
+    assert isinstance(ac, TorchPolicyAdapter)
+    assert get_rnn_size(cfg) == (64 if rnn else 2) == int(g["in_rnn_states"].shape[-1])
+    assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
+    load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
+    batch = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cuda")
+    for k in ["rnn_states", "actions", "action_logits", "log_prob_actions", "values", "policy_version", "rewards",
+              "dones", "time_outs", "policy_id", "valids"]:
+        batch[k].copy_(torch.from_numpy(g["in_" + k]))
+    batch["obs"]["obs"].copy_(torch.from_numpy(g["in_obs_obs"]))
+    before = {k: v.clone() for k, v in ac.state_dict().items()}
+    stats = learner.train(batch)
+    assert stats["learner_env_steps"] == int(g["env_steps"]) and learner.train_step == int(g["train_step"])
+    np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=5e-4)
+    compare_post_train(learner, g, before, name, **TIGHT)
+
+
 @pytest.mark.parametrize("name", ["gru", "lstm_inv", "gru2", "lstm2"])
 def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden, tmp_path, name):
     """The recurrent goldens once more, through the TORCH model path (a registered encoder, here the default
