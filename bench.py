@@ -307,8 +307,17 @@ def workload_cfg(args, rank, world):
             max_grad_norm=0.5, learning_rate=0.00025, adam_eps=1e-5, host_env_sim_ms=args.host_env_sim_ms, **common)
         cfg.seed = rank
         cfg.env_gpu_observations = cfg.env_gpu_actions = False
-        desc = (f"BASELINE.json configs[2] stand-in: HOST vector env {B} envs/GPU in {args.env_instances} instance(s) "
-                f"(numpy u8 [4,84,84] frames as envpool returns them -> pinned staging -> pitched H2D into the slab, int32 "
+        if args.env_workers > 0:  # the reference's deployment for CPU envs: env worker processes, double-buffered sampling
+            cfg.env_workers_mode, cfg.num_workers, cfg.num_envs_per_worker, cfg.worker_num_splits = "process", args.env_workers, 2, 2
+            cfg.synthetic_num_agents = B // (args.env_workers * 2)
+            assert cfg.synthetic_num_agents * args.env_workers * 2 == B, "--envs must be a multiple of 2 * --env_workers"
+            how = (f"{args.env_workers} env worker processes x 2 instances x {cfg.synthetic_num_agents} agents, 2 sampling splits "
+                   f"pipelined against inference; frames DMA'd into the slab from the workers' shared pages in place")
+        else:
+            cfg.env_workers_mode = "inline"
+            how = f"{args.env_instances} instance(s) in the sampler thread -> pinned staging -> pitched H2D into the slab"
+        desc = (f"BASELINE.json configs[2] stand-in: HOST vector env {B} envs/GPU ({how}; numpy u8 [4,84,84] frames as "
+                f"envpool returns them, int32 "
                 f"actions D2H), Discrete(6), Nature-CNN, APPO {mode}, rollout={T}, batch_size={cfg.batch_size} x "
                 f"{args.num_batches} minibatches x {args.num_epochs} epoch(s) (envpool-Atari preset)")
         return cfg, "host_atari", make_host_frame_env, desc, \
@@ -339,6 +348,8 @@ def main():
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
     ap.add_argument("--cpu_reference_envs", type=int, default=256,
                     help="trajectories of the sample the REFERENCE's CPU path is timed on (cpu_baseline kind 'reference')")
+    ap.add_argument("--env_workers", type=int, default=4,
+                    help="c3: env worker PROCESSES (algo/sampling/parallel_env.py); 0 = envs inside this process (sampler thread)")
     ap.add_argument("--env_instances", type=int, default=1,
                     help="split the envs of a GPU into this many vector-env instances (num_envs_per_worker = "
                          "worker_num_splits = this): their rollouts run on separate HIP streams")
@@ -437,6 +448,8 @@ def main():
     dt = time.perf_counter() - t0
     clock = clk.stop() if clk is not None else None
     runner.stop_sampler_thread()  # (threaded async mode, host envs) no-op otherwise
+    direct_dma = [sm._direct_ok.get("obs") for sm in runner.samplers] if args.workload == "c3" else None
+    runner.close_envs()           # env worker processes (c3) — a no-op for in-process envs
     ingest = None
     if args.workload == "c3":
         tot = dict(act_wait_s=0.0, env_step_s=0.0, stage_s=0.0)
@@ -454,7 +467,8 @@ def main():
                   "obs_dma_gbs": round(dma_bytes / (dma_ms * 1e-3) / 1e9, 2) if dma_ms else None,
                   "obs_dma_ms_total": round(dma_ms, 1), "h2d_gbs_over_wall_clock": round(h2d / dt / 1e9, 2),
                   "host_s": {k: round(v, 3) for k, v in tot.items()}, "wall_s": round(dt, 3), "sampling_rounds": rounds,
-                  "sampler_thread": bool(runner.threaded),
+                  "sampler_thread": bool(runner.threaded), "env_worker_processes": int(getattr(cfg, "env_workers", 0) or 0),
+                  "obs_dma_from_worker_pages_in_place": direct_dma,
                   "dma_share_of_wall_clock": round(dma_ms * 1e-3 / dt, 4)}
     prof, lib.PROFILE, lib.PROFILE_ONLY = lib.PROFILE, None, None
     collectives = None

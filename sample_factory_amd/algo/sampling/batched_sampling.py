@@ -58,7 +58,8 @@ class BatchedVectorEnvRunner:
         self.ld = actor_critic.heads_ld
         self.continuous = is_box(self.env_info.action_space)  # Box(D): params = [means | log_std]
         self.host_env = None
-        self._pin, self._pin_flip = {}, {}
+        self.async_env = hasattr(env, "step_async") and hasattr(env, "step_wait")  # stepped by worker processes
+        self._pin, self._pin_flip, self._direct_ok = {}, {}, {}
         self._act_event = torch.cuda.Event()
         self.h2d_bytes = 0  # host-env ingest volume (bench --workload c3)
         # optional host-timeline probe of the ingest path (bench --workload c3): seconds spent waiting for the actions
@@ -103,8 +104,20 @@ class BatchedVectorEnvRunner:
         prof = self.ingest_prof
         t0 = time.perf_counter() if prof is not None else 0.0
         a = np.asarray(src.cpu() if isinstance(src, torch.Tensor) else src)
-        stage = self._pinned(key, dst.shape, dst.dtype, nbuf=2)  # two buffers: the previous H2D may still be in flight
-        np.copyto(stage.numpy(), a.reshape(stage.shape), casting="unsafe")
+        stage = None
+        if getattr(self.env, "pages_registered", False) and isinstance(src, np.ndarray) and src.flags.c_contiguous and \
+                src.dtype == torch.empty(0, dtype=dst.dtype).numpy().dtype and src.size == dst.numel():
+            # the env workers' shared pages are registered with the HIP runtime (parallel_env.register_with_device): the
+            # DMA engine reads them in place.  Safe without a second buffer: the workers only overwrite them after the
+            # NEXT actions were read back, which is stream-ordered behind this copy.
+            cand = torch.from_numpy(src).view(dst.shape)
+            ok = self._direct_ok.get(key)
+            if ok is None:  # (asked once per key: is_pinned() is a runtime query)
+                ok = self._direct_ok[key] = bool(cand.is_pinned())
+            stage = cand if ok else None
+        if stage is None:
+            stage = self._pinned(key, dst.shape, dst.dtype, nbuf=2)  # two buffers: the previous H2D may still be in flight
+            np.copyto(stage.numpy(), a.reshape(stage.shape), casting="unsafe")
         timed = prof is not None and key.startswith("obs")
         if prof is not None:
             prof["stage_s"] = prof.get("stage_s", 0.0) + time.perf_counter() - t0
@@ -159,6 +172,11 @@ class BatchedVectorEnvRunner:
     def rollout_step(self, t: int) -> None:
         """step t of the current rollout (the Runner interleaves the steps of several env groups, each on its own HIP
         stream: the reference's double-buffered sampling, worker_num_splits / batched_sampling.py:298-388)"""
+        self.rollout_step_begin(t)
+        self.rollout_step_finish(t)
+
+    def rollout_step_begin(self, t: int) -> None:
+        """policy forward + sampling of step t and, for in-process envs, the env step itself"""
         tr, T, B, A = self.traj, self.T, self.B, self.A
         ver, deterministic, cfg = self._ver, self._deterministic, self.cfg
         rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
@@ -181,14 +199,31 @@ class BatchedVectorEnvRunner:
                                   tr["action_logits"], tr["log_prob_actions"], tr["values"], tr["policy_version"],
                                   None if self.continuous else self.env_actions, action_kind=int(self.continuous))
         env_actions = tr["actions"][:, t] if self.continuous else self.env_actions  # Box: f32 [B, D] view
+        if self.async_env:  # worker processes step the envs from here on (parallel_env.py); rollout_step_finish collects
+            self.env.step_async(self._actions_to_host(env_actions))
+            return
+        self._env_step_and_record(t, env_actions)
+
+    def rollout_step_finish(self, t: int) -> None:
+        """second half of a step for envs that are stepped asynchronously by worker processes (`step_async` / `step_wait`):
+        wait for the env outputs, ingest them, record the step.  Between `rollout_step_begin(t)` and this call the Runner
+        runs the inference of the OTHER sampling split — the reference's double-buffered sampling (rollout_worker.py:96-117)."""
+        if self.async_env:
+            self._env_step_and_record(t, None)
+
+    def _env_step_and_record(self, t: int, env_actions) -> None:
+        tr, T, cfg = self.traj, self.T, self.cfg
         if self.zero_copy:
             rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])
         else:
             if self.host_env is None:  # decided by what reset() returned
                 self.host_env = False
-            acts_in = self._actions_to_host(env_actions) if self.host_env else env_actions
             t0 = time.perf_counter()
-            o, rew, term, trunc, _ = self.env.step(acts_in)
+            if self.async_env:
+                o, rew, term, trunc, _ = self.env.step_wait()
+            else:
+                acts_in = self._actions_to_host(env_actions) if self.host_env else env_actions
+                o, rew, term, trunc, _ = self.env.step(acts_in)
             if self.ingest_prof is not None:
                 self.ingest_prof["env_step_s"] = self.ingest_prof.get("env_step_s", 0.0) + time.perf_counter() - t0
             self._store_obs(o, t + 1)

@@ -1,0 +1,334 @@
+"""Multi-process HOST env stepping — what `RolloutWorker` processes are for in the reference
+(sample_factory/algo/sampling/rollout_worker.py:79-308, algo/runners/runner_parallel.py:15-65, the per-env wrappers of
+algo/utils/make_env.py:57-128,240-331): Python / C++ envs that live on the CPU are stepped by `num_workers` worker
+processes, `num_envs_per_worker` env instances each, in parallel with each other AND with the policy's inference.
+
+Design (one process per GPU owns everything that touches the device; workers never import torch.cuda):
+
+  * every worker process creates its env instances through the SAME factory the reference calls
+    (`make_env_func(full_env_name, cfg, env_config, render_mode)` with `env_config = AttrDict(worker_index, vector_index,
+    env_id)`, batched_sampling.py:160-170) and steps them sequentially (rollout_worker.py: one thread per worker);
+  * env outputs are written straight into SHARED MEMORY arrays laid out `[agents, ...]` in slab row order
+    (observations per key, rewards f32, terminated / truncated bool) — the reference's `traj_tensors` in shared memory
+    (shared_buffers.py:34-57) — and the main process registers those pages with the HIP runtime, so `sf_h2d_rows`
+    DMAs a step's observations from the workers' own pages into slab column t (no staging copy, no pickling);
+  * double-buffered sampling (`worker_num_splits = 2`, rollout_worker.py:96-117): the env instances of a worker are dealt
+    to the splits; each split is one `ParallelVecEnvView` (an env-like object with `step_async` / `step_wait`), and the
+    Runner pipelines them — while the workers step split A's envs the GPU runs split B's inference;
+  * single-agent gym envs are wrapped as in make_env.py:97-128 (1-agent lists, auto-reset on done); batched /
+    multi-agent envs (`num_agents` attribute) return per-agent vectors and reset themselves (make_env.py:147-237).
+
+Commands travel over one `multiprocessing.Pipe` per worker; completion is one semaphore per (worker, split).
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+import traceback
+from multiprocessing import shared_memory
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from sample_factory_amd.envs.spaces import action_head_sizes, is_box
+from sample_factory_amd.utils.attr_dict import AttrDict
+
+CMD_RESET, CMD_STEP, CMD_CLOSE = 0, 1, 2
+
+
+def _as_obs_dict(obs) -> Dict[str, Any]:
+    return obs if isinstance(obs, dict) else {"obs": obs}
+
+
+def env_is_batched(env) -> bool:
+    """make_env.py:30-39: `num_agents` > 1 or an explicit `is_multiagent` -> the env speaks per-agent vectors"""
+    n = getattr(env, "num_agents", 1)
+    return bool(getattr(env, "is_multiagent", n > 1))
+
+
+def obs_space_dict(space) -> Dict[str, Any]:
+    return dict(space.spaces) if hasattr(space, "spaces") else {"obs": space}
+
+
+class _Shm:
+    """a numpy array on a named shared-memory block (created by the main process, attached by the workers)"""
+
+    def __init__(self, shape, dtype, name: Optional[str] = None):
+        self.shape, self.dtype = tuple(int(s) for s in shape), np.dtype(dtype)
+        nbytes = max(1, int(np.prod(self.shape)) * self.dtype.itemsize)
+        self.owner = name is None
+        self.shm = shared_memory.SharedMemory(create=True, size=nbytes) if name is None else \
+            shared_memory.SharedMemory(name=name)
+        self.array = np.ndarray(self.shape, dtype=self.dtype, buffer=self.shm.buf)
+        if self.owner:
+            self.array.fill(0)
+
+    def spec(self):
+        return (self.shm.name, self.shape, self.dtype.str)
+
+    def close(self):
+        self.array = None
+        try:
+            self.shm.close()
+            if self.owner:
+                self.shm.unlink()
+        except Exception:  # noqa: BLE001 - best effort at shutdown
+            pass
+
+
+def _format_actions(act_rows: np.ndarray, heads: List[int], continuous: bool, batched: bool):
+    """what `preprocess_actions` hands the env (batched_sampling.py:30-82): int32, the action axis squeezed for ONE Discrete
+    head; Tuple spaces get a list of per-head arrays; a single-agent env gets its agent's action without the agent axis"""
+    if continuous:
+        a = act_rows.astype(np.float32, copy=False)
+        return a if batched else a[0]
+    if len(heads) > 1:
+        a = act_rows.reshape(act_rows.shape[0], len(heads))
+        return [a[:, h].copy() for h in range(len(heads))] if batched else [int(v) for v in a[0]]
+    a = act_rows.reshape(-1)
+    return a if batched else int(a[0])
+
+
+def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: str, cfg, instances, specs, heads,
+                 continuous: bool):
+    """instances: [(split, vector_index, env_id, row0, nrows)] of this worker; specs[split] = {name: shm spec}"""
+    arrays, shms, envs = {}, [], []
+    try:
+        for split, sp in specs.items():
+            arrays[split] = {}
+            for name, (shm_name, shape, dt) in sp.items():
+                s = _Shm(shape, dt, name=shm_name)
+                shms.append(s)
+                arrays[split][name] = s.array
+        for split, vidx, env_id, row0, nrows in instances:
+            env = make_env_func(env_name, cfg, AttrDict(worker_index=widx, vector_index=vidx, env_id=env_id), None)
+            envs.append((split, env, env_is_batched(env), row0, nrows, env_id))
+        conn.send(("ready", widx))
+
+        def put_obs(a, obs, row0, nrows, batched):
+            for k, v in _as_obs_dict(obs).items():
+                dst = a["obs." + k]
+                if batched:
+                    if isinstance(v, (list, tuple)):
+                        v = np.stack([np.asarray(x) for x in v])
+                    v = np.asarray(v.cpu() if hasattr(v, "cpu") else v)
+                    np.copyto(dst[row0:row0 + nrows], v.reshape(dst[row0:row0 + nrows].shape), casting="unsafe")
+                else:
+                    np.copyto(dst[row0], np.asarray(v).reshape(dst[row0].shape), casting="unsafe")
+
+        while True:
+            cmd, split = conn.recv()
+            if cmd == CMD_CLOSE:
+                break
+            a = arrays[split]
+            for sp_, env, batched, row0, nrows, env_id in envs:
+                if sp_ != split:
+                    continue
+                if cmd == CMD_RESET:
+                    try:
+                        obs, _info = env.reset(seed=env_id)  # gymnasium >= 0.26 seeds in reset (make_env.py:206-214)
+                    except TypeError:
+                        obs, _info = env.reset()
+                    put_obs(a, obs, row0, nrows, batched)
+                    continue
+                act = _format_actions(a["act"][row0:row0 + nrows], heads, continuous, batched)
+                obs, rew, term, trunc, _info = env.step(act)
+                if batched:
+                    a["rew"][row0:row0 + nrows] = np.asarray(rew.cpu() if hasattr(rew, "cpu") else rew, dtype=np.float32).reshape(-1)
+                    a["term"][row0:row0 + nrows] = np.asarray(term.cpu() if hasattr(term, "cpu") else term).reshape(-1)
+                    a["trunc"][row0:row0 + nrows] = np.asarray(trunc.cpu() if hasattr(trunc, "cpu") else trunc).reshape(-1)
+                else:
+                    if term or trunc:  # auto-reset (make_env.py:100-102); the terminal observation is dropped as there
+                        obs, _ = env.reset()
+                    a["rew"][row0], a["term"][row0], a["trunc"][row0] = rew, bool(term), bool(trunc)
+                put_obs(a, obs, row0, nrows, batched)
+            done_sems[split].release()
+    except BaseException:  # noqa: BLE001 - reported to the main process, which raises
+        try:
+            conn.send(("error", traceback.format_exc()))
+        except Exception:  # noqa: BLE001
+            pass
+        for s in done_sems:
+            s.release()
+    finally:
+        for _sp, env, *_ in envs:
+            try:
+                env.close()
+            except Exception:  # noqa: BLE001
+                pass
+        for s in shms:
+            s.close()
+
+
+class ParallelVecEnvView:
+    """One split's agents over all workers, presented as ONE batched host env (reset / step / step_async / step_wait)."""
+
+    def __init__(self, parent: "ParallelHostEnvs", split: int, num_agents: int):
+        self.parent, self.split, self.num_agents = parent, split, int(num_agents)
+        self.observation_space, self.action_space = parent.observation_space, parent.action_space
+        self.is_multiagent = True
+        self._pending = False
+        self.pages_registered = False  # set by ParallelHostEnvs.register_with_device()
+
+    def _arrays(self):
+        return self.parent.arrays[self.split]
+
+    def _obs(self):
+        a = self._arrays()
+        return {k: a["obs." + k] for k in self.parent.obs_keys}
+
+    def reset(self, **kwargs):
+        self.parent._command(self.split, CMD_RESET)
+        self.parent._wait(self.split)
+        return self._obs(), {}
+
+    def step_async(self, actions) -> None:
+        assert not self._pending, "step_async() twice without step_wait()"
+        act = self._arrays()["act"]
+        np.copyto(act, np.asarray(actions.cpu() if hasattr(actions, "cpu") else actions).reshape(act.shape), casting="unsafe")
+        self.parent._command(self.split, CMD_STEP)
+        self._pending = True
+
+    def step_wait(self):
+        assert self._pending
+        self.parent._wait(self.split)
+        self._pending = False
+        a = self._arrays()
+        return self._obs(), a["rew"], a["term"], a["trunc"], {}
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.parent.close()
+
+
+class ParallelHostEnvs:
+    def __init__(self, cfg, env_name: str, make_env_func: Callable, num_workers: int, envs_per_worker: int,
+                 num_splits: int = 1, start_method: Optional[str] = None):
+        assert envs_per_worker % num_splits == 0, f"{envs_per_worker=} must be a multiple of {num_splits=}"
+        self.cfg, self.num_workers, self.envs_per_worker, self.num_splits = cfg, num_workers, envs_per_worker, num_splits
+        self._closed, self._conns, self._procs, self._shms = False, [], [], []
+        # ---- probe ONE instance here for spaces / agents per instance (the reference spawns a process for this,
+        # env_info.py:81-127; the instance is closed again before the workers start)
+        probe = make_env_func(env_name, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0), None)
+        self.observation_space, self.action_space = probe.observation_space, probe.action_space
+        self.agents_per_instance = int(getattr(probe, "num_agents", 1)) if env_is_batched(probe) else 1
+        try:
+            probe.close()
+        except Exception:  # noqa: BLE001
+            pass
+        spaces_ = obs_space_dict(self.observation_space)
+        self.obs_keys = list(spaces_.keys())
+        self.heads = action_head_sizes(self.action_space)
+        self.continuous = is_box(self.action_space)
+        per_split = envs_per_worker // num_splits
+        self.agents_per_view = num_workers * per_split * self.agents_per_instance
+        # ---- shared-memory arrays per split, rows in (worker, instance-in-split, agent) order
+        self.arrays: List[Dict[str, np.ndarray]] = []
+        specs: List[Dict[str, Tuple]] = []
+        n = self.agents_per_view
+        for _ in range(num_splits):
+            arr, spec = {}, {}
+
+            def add(name, shape, dtype):
+                s = _Shm(shape, dtype)
+                self._shms.append(s)
+                arr[name], spec[name] = s.array, s.spec()
+
+            for k, sp in spaces_.items():
+                dt = np.float32 if np.dtype(sp.dtype) == np.float64 else sp.dtype
+                add("obs." + k, (n,) + tuple(sp.shape), dt)
+            add("rew", (n,), np.float32)
+            add("term", (n,), np.bool_)
+            add("trunc", (n,), np.bool_)
+            if self.continuous:
+                add("act", (n, int(self.action_space.shape[0])), np.float32)
+            else:
+                add("act", (n, len(self.heads)) if len(self.heads) > 1 else (n,), np.int32)
+            self.arrays.append(arr)
+            specs.append(spec)
+        # ---- workers
+        method = start_method or getattr(cfg, "env_worker_start_method", None) or "spawn"
+        ctx = mp.get_context(method)
+        self._done = [[ctx.Semaphore(0) for _ in range(num_splits)] for _ in range(num_workers)]
+        for w in range(num_workers):
+            inst = []
+            for v in range(envs_per_worker):  # vector_index -> split as rollout_worker.py:96-117 deals them: blocks per split
+                split, j = v // per_split, v % per_split
+                row0 = (w * per_split + j) * self.agents_per_instance
+                inst.append((split, v, w * envs_per_worker + v, row0, self.agents_per_instance))
+            parent_conn, child_conn = ctx.Pipe()
+            p = ctx.Process(target=_worker_main, name=f"sf-env-worker-{w}", daemon=True,
+                            args=(w, child_conn, self._done[w], make_env_func, env_name, cfg, inst,
+                                  {s: specs[s] for s in range(num_splits)}, self.heads, self.continuous))
+            p.start()
+            self._conns.append(parent_conn)
+            self._procs.append(p)
+        for w, c in enumerate(self._conns):
+            if not c.poll(float(getattr(cfg, "env_worker_start_timeout", 300.0))):
+                self.close()
+                raise RuntimeError(f"env worker {w} did not start")
+            msg = c.recv()
+            if msg[0] != "ready":
+                self.close()
+                raise RuntimeError(f"env worker {w} failed to create its envs:\n{msg[1]}")
+        self.views = [ParallelVecEnvView(self, s, n) for s in range(num_splits)]
+
+    # ---- pinned pages: let the DMA engine read the workers' pages directly
+    def register_with_device(self) -> bool:
+        """hipHostRegister the observation pages (main process only; a no-op without a GPU).  Returns True if the pages are
+        now page-locked: the rollout runner then hands them to sf_h2d_rows without a staging copy."""
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return False
+            rt = torch.cuda.cudart()
+            for arr in self.arrays:
+                for k, a in arr.items():
+                    if k.startswith("obs."):
+                        err = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
+                        if int(err) != 0:
+                            return False
+            for v in self.views:
+                v.pages_registered = True
+            return True
+        except Exception:  # noqa: BLE001 - registration is an optimisation only
+            return False
+
+    def _command(self, split: int, cmd: int) -> None:
+        for c in self._conns:
+            c.send((cmd, split))
+
+    def _wait(self, split: int) -> None:
+        timeout = float(getattr(self.cfg, "env_worker_step_timeout", 600.0))
+        for w in range(self.num_workers):
+            if not self._done[w][split].acquire(timeout=timeout):
+                raise RuntimeError(f"env worker {w} did not answer within {timeout} s")
+            if self._conns[w].poll(0):
+                msg = self._conns[w].recv()
+                if msg[0] == "error":
+                    self.close()
+                    raise RuntimeError(f"env worker {w} died:\n{msg[1]}")
+
+    def close(self) -> None:
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        for c in self._conns:
+            try:
+                c.send((CMD_CLOSE, 0))
+            except Exception:  # noqa: BLE001
+                pass
+        for p in self._procs:
+            p.join(timeout=5.0)
+            if p.is_alive():
+                p.terminate()
+        for s in self._shms:
+            s.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -73,6 +73,10 @@ ENGINE_FLAGS = [
     ("device_shuffle", _bool, False),        # shuffle_minibatches with the stateless on-device permutation
     ("sampler_thread", _bool, None),         # None: a sampler thread iff async_rl with a host env
     ("record_grad_norm", _bool, False),
+    ("env_workers_mode", str, "auto"),       # host envs: "process" = cfg.num_workers env worker processes (the reference's
+    #                                          rollout workers), "inline" = in this process, "auto" = processes iff
+    #                                          serial_mode=False and the env is a host env (algo/sampling/parallel_env.py)
+    ("env_worker_start_method", str, "spawn"),  # multiprocessing start method of the env workers
 ]
 
 

@@ -58,4 +58,5 @@ class CartPoleVecEnv:
 
 def make_cartpole_env(full_env_name, cfg=None, env_config=None, render_mode=None):
     n = getattr(cfg, "cartpole_num_agents", 2) if cfg is not None else 2
-    return CartPoleVecEnv(num_agents=n, seed=(getattr(cfg, "seed", None) or 0) if cfg is not None else 0)
+    seed = ((getattr(cfg, "seed", None) or 0) if cfg is not None else 0) + 1000 * int(getattr(env_config, "env_id", 0) or 0)
+    return CartPoleVecEnv(num_agents=n, seed=seed)

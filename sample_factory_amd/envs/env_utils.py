@@ -22,6 +22,13 @@ def create_env(full_env_name: str, cfg=None, env_config=None, render_mode=None):
     return _ENV_REGISTRY[full_env_name](full_env_name, cfg, env_config, render_mode)
 
 
+def registered_env_factory(full_env_name: str) -> Callable:
+    """the factory registered under this name (handed to env worker processes, which call it themselves)"""
+    if full_env_name not in _ENV_REGISTRY:
+        raise ValueError(f"Env name {full_env_name} is not registered. See register_env()!")
+    return _ENV_REGISTRY[full_env_name]
+
+
 # ---- optional env interfaces (envs/env_utils.py:60-133 of the reference): same names, same calling convention
 def find_wrapper_interface(env, interface_type):
     """Unwrap `env` (gym-style `.env` chain, ending at `.unwrapped` if the env has one) until a layer implements

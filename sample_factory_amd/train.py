@@ -190,9 +190,29 @@ class Runner:
         # slice of the slab per rollout and the units' rollouts run on worker_num_splits HIP streams, which fills the
         # tails of the small-batch kernels: measured in tools/split_probe.py and DESIGN.md §5.
         E = max(1, int(cfg.num_workers) * int(cfg.num_envs_per_worker))
-        self.envs = [create_env(cfg.env, cfg, AttrDict(worker_index=e // int(cfg.num_envs_per_worker),
-                                                       vector_index=e % int(cfg.num_envs_per_worker), env_id=e))
-                     for e in range(E)]
+        self.parallel_envs = None
+        if self._want_env_workers():
+            # HOST envs in worker PROCESSES (rollout_worker.py:79-308): cfg.num_workers processes x cfg.num_envs_per_worker
+            # instances, dealt to cfg.worker_num_splits splits; every split is one batched host env for the code below
+            from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
+            from sample_factory_amd.envs.env_utils import registered_env_factory
+            S = max(1, int(cfg.worker_num_splits))
+            if int(cfg.num_envs_per_worker) % S != 0:
+                S = 1
+            self.parallel_envs = ParallelHostEnvs(cfg, cfg.env, registered_env_factory(cfg.env), int(cfg.num_workers),
+                                                  int(cfg.num_envs_per_worker), num_splits=S)
+            self.parallel_envs.register_with_device()
+            self.envs = list(self.parallel_envs.views)
+            # from here on: one "worker" whose env instances are the splits (slab rows, sampling units, streams follow)
+            cfg.env_workers, cfg.env_instances_per_worker = int(cfg.num_workers), int(cfg.num_envs_per_worker)
+            cfg.num_workers, cfg.num_envs_per_worker, cfg.worker_num_splits = 1, S, S
+            E = S
+        else:
+            probe = getattr(self, "_probe_env", None)
+            self.envs = [probe if (e == 0 and probe is not None) else
+                         create_env(cfg.env, cfg, AttrDict(worker_index=e // int(cfg.num_envs_per_worker),
+                                                           vector_index=e % int(cfg.num_envs_per_worker), env_id=e))
+                         for e in range(E)]
         self.env = self.envs[0]
         self.env_info = extract_env_info(self.env, cfg)
         n = self.env_info.num_agents
@@ -268,6 +288,34 @@ class Runner:
         self._observers_call("on_connect_components", self)
         return ExperimentStatus.SUCCESS
 
+    def _want_env_workers(self) -> bool:
+        """cfg.env_workers_mode: "process" = env instances in worker processes, "inline" = in this process, None / "auto" =
+        processes iff the reference would use them (serial_mode=False, runner_parallel.py) AND the env is a host env that
+        cannot write into the slab itself (no `step_into`: device-resident vector envs always stay in-process)."""
+        cfg = self.cfg
+        mode = getattr(cfg, "env_workers_mode", None) or "auto"
+        if mode == "inline":
+            return False
+        if mode == "process":
+            return True
+        if bool(cfg.serial_mode):
+            return False
+        # ask instance 0 what kind of env this is (kept and reused as instance 0 when the answer is "in-process")
+        probe = create_env(cfg.env, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0))
+        device_env = hasattr(probe, "step_into")
+        if not device_env:
+            o, _ = probe.reset()
+            first = next(iter(o.values())) if isinstance(o, dict) else o
+            device_env = isinstance(first, torch.Tensor) and first.is_cuda
+        if device_env:
+            self._probe_env = probe
+            return False
+        try:
+            probe.close()
+        except Exception:  # noqa: BLE001
+            pass
+        return True
+
     @property
     def slabs(self):
         """the row blocks of the slab one sampling round fills (async mode: two of them in flight)"""
@@ -311,10 +359,23 @@ class Runner:
             self._ev_fork.record(base)
             for st in self.split_streams:
                 st.wait_event(self._ev_fork)
-            for t in range(self.cfg.rollout):  # steps of the groups interleaved on the host, concurrent on the device
+            if all(sm.async_env for sm in self.samplers):
+                # envs stepped by worker processes: software pipeline over the splits — while the workers step split A's
+                # envs (begin(t) sent the actions) the GPU runs split B's inference (rollout_worker.py:96-117)
                 for e, sm in enumerate(self.samplers):
                     with torch.cuda.stream(self.split_streams[e % S]):
-                        sm.rollout_step(t)
+                        sm.rollout_step_begin(0)
+                for t in range(self.cfg.rollout):
+                    for e, sm in enumerate(self.samplers):
+                        with torch.cuda.stream(self.split_streams[e % S]):
+                            sm.rollout_step_finish(t)
+                            if t + 1 < self.cfg.rollout:
+                                sm.rollout_step_begin(t + 1)
+            else:
+                for t in range(self.cfg.rollout):  # steps of the groups interleaved on the host, concurrent on the device
+                    for e, sm in enumerate(self.samplers):
+                        with torch.cuda.stream(self.split_streams[e % S]):
+                            sm.rollout_step(t)
             for i, st in enumerate(self.split_streams):
                 self._ev_join[i].record(st)
                 base.wait_event(self._ev_join[i])
@@ -460,6 +521,12 @@ class Runner:
             self._ep_stats_request = False
             self._cv.notify_all()
 
+    def close_envs(self) -> None:
+        """stop the env worker processes (a no-op for in-process envs)"""
+        if getattr(self, "parallel_envs", None) is not None:
+            self.parallel_envs.close()
+            self.parallel_envs = None
+
     def _start_sampler_thread(self) -> None:
         if self._thread is None:
             self._stop = False
@@ -570,6 +637,7 @@ class Runner:
         self._emit_episodic_stats()
         self.stop_sampler_thread()
         torch.cuda.synchronize()
+        self.close_envs()
         self.env_steps = self.learner.env_steps
         self.fps = (self.env_steps - self._env_steps0) / max(1e-9, time.time() - t0)
         self._write_summaries(self.fps)

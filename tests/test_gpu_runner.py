@@ -398,7 +398,8 @@ def test_host_env_async_with_sampler_thread_and_pitched_ingest():
     cfg = default_cfg(env="host_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
                       encoder_conv_architecture="convnet_atari", rollout=8, batch_size=512, num_batches_per_epoch=2,
                       num_epochs=1, num_workers=1, num_envs_per_worker=2, worker_num_splits=2, async_rl=True,
-                      serial_mode=False, seed=4, synthetic_num_agents=64, env_gpu_observations=False, env_gpu_actions=False)
+                      serial_mode=False, seed=4, synthetic_num_agents=64, env_gpu_observations=False, env_gpu_actions=False,
+                      env_workers_mode="inline")  # (this test: envs in this process, sampler THREAD; processes: below)
     cfg, runner = make_runner(cfg)
     runner.init()
     assert runner.threaded and all(sm.host_env for sm in runner.samplers) and len(runner.units) == 2
@@ -440,7 +441,7 @@ def test_host_env_async_sampler_thread_with_recurrent_core(rnn_type):
                       normalize_input=False, obs_scale=255.0, encoder_conv_architecture="convnet_atari", rollout=8,
                       batch_size=512, num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=2,
                       worker_num_splits=2, async_rl=True, serial_mode=False, seed=5, synthetic_num_agents=64,
-                      env_gpu_observations=False, env_gpu_actions=False)
+                      env_gpu_observations=False, env_gpu_actions=False, env_workers_mode="inline")
     cfg, runner = make_runner(cfg)
     runner.init()
     assert runner.threaded and runner.learner.actor_critic.rnn_kind is not None
@@ -462,3 +463,50 @@ def test_host_env_async_sampler_thread_with_recurrent_core(rnn_type):
         nxt = st[:, 1:]                                          # state INPUT of step t+1
         assert float(nxt[dn].abs().max() if dn.any() else 0.0) == 0.0
         assert float(nxt[~dn].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("async_rl", [False, True], ids=["sync", "async"])
+def test_host_envs_in_worker_processes_double_buffered(async_rl):
+    """The reference's default deployment for CPU envs (serial_mode=False): `num_workers` env worker PROCESSES x
+    `num_envs_per_worker` instances, dealt to `worker_num_splits` = 2 splits that the Runner pipelines (while the workers
+    step split A's envs the GPU runs split B's inference: rollout_worker.py:96-117).  The workers write their frames into
+    shared pages which sf_h2d_rows DMAs into the slab in place: every frame in the slab must be the frame the env instance
+    of that slab row produced at that step — rows ordered (split; worker, instance, agent)."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import HostFrameVecEnv, make_host_frame_env
+    from sample_factory_amd.train import make_runner
+    register_env("host_atari", make_host_frame_env)
+    W, K, n, T = 2, 4, 16, 8                                   # 2 workers x 4 instances x 16 agents = 128 envs, 2 splits of 64
+    cfg = default_cfg(env="host_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                      encoder_conv_architecture="convnet_atari", rollout=T, batch_size=512, num_batches_per_epoch=2,
+                      num_epochs=1, num_workers=W, num_envs_per_worker=K, worker_num_splits=2, async_rl=async_rl,
+                      serial_mode=False, seed=4, synthetic_num_agents=n, env_gpu_observations=False, env_gpu_actions=False)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    try:
+        assert runner.parallel_envs is not None and len(runner.envs) == 2 and runner.envs[0].num_agents == W * (K // 2) * n
+        assert all(sm.async_env and sm.host_env for sm in runner.samplers)
+        trained = 0
+        for _ in range(4):
+            trained += runner.iteration() is not None
+        runner.stop_sampler_thread()
+        torch.cuda.synchronize()
+        assert trained >= 3 and torch.isfinite(runner.learner.actor_critic.flat_params).all()
+        rounds = runner.sampling_rounds
+        for split in range(2):
+            rows = runner._prev_rows[split]["obs"]["obs"].cpu().numpy()   # [64, T+1, 4, 84, 84]: the split's last rollout
+            per = K // 2
+            for w in range(W):
+                for j in range(per):
+                    env_id = w * K + split * per + j
+                    ring = HostFrameVecEnv(num_agents=n, seed=4 + env_id).ring
+                    r0 = (w * per + j) * n
+                    last = rounds * T                                   # env steps taken by every instance so far
+                    for t in range(T + 1):
+                        np.testing.assert_array_equal(rows[r0:r0 + n, t], ring[(last - T + t) % len(ring)],
+                                                      err_msg=f"split {split} worker {w} instance {j} step {t}")
+        direct = [sm._direct_ok.get("obs") for sm in runner.samplers]
+        print("frames DMA'd from the workers' pages in place:", direct)
+    finally:
+        runner.close_envs()

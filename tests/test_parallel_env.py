@@ -1,0 +1,158 @@
+"""Multi-process host env stepping (sample_factory_amd/algo/sampling/parallel_env.py) — the reference's rollout-worker
+processes (rollout_worker.py:79-308) — on the CPU: worker processes must produce exactly what the same env instances
+produce when stepped in this process, in slab row order, for batched AND single-agent envs, one or two splits."""
+import numpy as np
+import pytest
+
+from sample_factory_amd.cfg.arguments import default_cfg
+from sample_factory_amd.envs import spaces
+from sample_factory_amd.envs.cartpole import make_cartpole_env
+from sample_factory_amd.utils.attr_dict import AttrDict
+
+
+class CountingEnv:
+    """single-agent gym-style env (no num_agents): obs = [env_id, episode, step, last action], reward = action, an episode
+    lasts 3 + env_id % 3 steps (terminated) — deterministic, so the auto-reset of the worker wrapper is checkable"""
+
+    def __init__(self, env_id):
+        self.env_id, self.episode, self.t, self.last = int(env_id), -1, 0, 0
+        self.observation_space = spaces.Box(-1e6, 1e6, (4,), np.float32)
+        self.action_space = spaces.Discrete(5)
+
+    def _obs(self):
+        return np.array([self.env_id, self.episode, self.t, self.last], np.float32)
+
+    def reset(self, **kw):
+        self.episode += 1
+        self.t, self.last = 0, 0
+        return self._obs(), {}
+
+    def step(self, action):
+        assert isinstance(action, int), type(action)  # the action axis is squeezed for a single-agent Discrete env
+        self.t += 1
+        self.last = action
+        term = self.t >= 3 + self.env_id % 3
+        return self._obs(), float(action), term, False, {}
+
+    def close(self):
+        pass
+
+
+def make_counting_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    return CountingEnv(env_config.env_id)
+
+
+def _serial_reference(make, cfg, W, K, S, steps, actions):
+    """the same instances stepped here, rows ordered (split; worker, instance-in-split, agent)"""
+    from sample_factory_amd.algo.sampling.parallel_env import env_is_batched
+    per = K // S
+    out = []
+    for split in range(S):
+        envs = []
+        for w in range(W):
+            for j in range(per):
+                v = split * per + j
+                envs.append(make("x", cfg, AttrDict(worker_index=w, vector_index=v, env_id=w * K + v), None))
+        batched = env_is_batched(envs[0])
+        n_inst = getattr(envs[0], "num_agents", 1) if batched else 1
+        rows = []
+
+        def obs_of(e, reset=False, a=None):
+            if reset:
+                try:
+                    o, _ = e.reset(seed=0)
+                except TypeError:
+                    o, _ = e.reset()
+                return o
+            return None
+
+        cur = []
+        for i, e in enumerate(envs):
+            try:
+                o, _ = e.reset(seed=i)
+            except TypeError:
+                o, _ = e.reset()
+            cur.append(o["obs"] if isinstance(o, dict) else o)
+        hist = [np.concatenate([np.asarray(c).reshape(n_inst, -1) for c in cur])]
+        rews, terms = [], []
+        for t in range(steps):
+            cur, rr, tt = [], [], []
+            for i, e in enumerate(envs):
+                a = actions[split][t][i * n_inst:(i + 1) * n_inst]
+                if batched:
+                    o, r, te, tr, _ = e.step(a)
+                else:
+                    o, r, te, tr, _ = e.step(int(a[0]))
+                    if te or tr:
+                        o, _ = e.reset()
+                cur.append(o["obs"] if isinstance(o, dict) else o)
+                rr.append(np.asarray(r, np.float32).reshape(-1))
+                tt.append(np.asarray(te).reshape(-1))
+            hist.append(np.concatenate([np.asarray(c).reshape(n_inst, -1) for c in cur]))
+            rews.append(np.concatenate(rr))
+            terms.append(np.concatenate(tt))
+        out.append((hist, rews, terms))
+    return out
+
+
+@pytest.mark.parametrize("kind,W,K,S", [("cartpole", 2, 2, 1), ("cartpole", 2, 4, 2), ("counting", 3, 2, 1), ("counting", 2, 2, 2)])
+def test_worker_processes_equal_in_process_stepping(kind, W, K, S):
+    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
+    cfg = default_cfg(env=kind, seed=3, cartpole_num_agents=3)
+    make = make_cartpole_env if kind == "cartpole" else make_counting_env
+    penv = ParallelHostEnvs(cfg, kind, make, W, K, num_splits=S)
+    try:
+        assert len(penv.views) == S
+        n = penv.views[0].num_agents
+        assert n == W * (K // S) * (3 if kind == "cartpole" else 1)
+        steps, A = 12, 2 if kind == "cartpole" else 5
+        rng = np.random.default_rng(0)
+        actions = [[rng.integers(0, A, n).astype(np.int32) for _ in range(steps)] for _ in range(S)]
+        want = _serial_reference(make, cfg, W, K, S, steps, actions)
+        got = [([], [], []) for _ in range(S)]
+        for s, v in enumerate(penv.views):
+            o, _ = v.reset()
+            got[s][0].append(o["obs"].reshape(n, -1).copy())
+        for t in range(steps):  # both splits in flight at once (double-buffered sampling)
+            for s, v in enumerate(penv.views):
+                v.step_async(actions[s][t])
+            for s, v in enumerate(penv.views):
+                o, r, te, tr, _ = v.step_wait()
+                got[s][0].append(o["obs"].reshape(n, -1).copy())
+                got[s][1].append(r.copy())
+                got[s][2].append(te.copy())
+        for s in range(S):
+            for t in range(steps + 1):
+                np.testing.assert_array_equal(got[s][0][t], want[s][0][t].astype(np.float32), err_msg=f"obs split {s} step {t}")
+            for t in range(steps):
+                np.testing.assert_array_equal(got[s][1][t], want[s][1][t])
+                np.testing.assert_array_equal(got[s][2][t], want[s][2][t])
+        if kind == "counting":  # auto-reset happened inside the workers: episode counters advanced
+            assert got[0][0][-1][:, 1].max() >= 2
+    finally:
+        penv.close()
+
+
+def test_worker_failure_is_reported():
+    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
+    cfg = default_cfg(env="boom", seed=0)
+    with pytest.raises(RuntimeError, match="failed to create|did not start"):
+        ParallelHostEnvs(cfg, "boom", make_failing_env, 1, 1)
+
+
+class _Probe:
+    observation_space = spaces.Box(-1, 1, (2,), np.float32)
+    action_space = spaces.Discrete(2)
+
+    def close(self):
+        pass
+
+
+_calls = {"n": 0}
+
+
+def make_failing_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    import multiprocessing
+    if multiprocessing.current_process().name.startswith("sf-env-worker"):
+        raise ValueError("no such simulator on this host")
+    return _Probe()
