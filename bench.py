@@ -167,7 +167,8 @@ def secondary_lines(args):
                    "wall_s": round(time.perf_counter() - t0, 1)}
             if "ingest" in d:
                 ent["ingest"] = {k: d["ingest"].get(k) for k in ("h2d_bytes_per_env_step", "obs_dma_gbs", "sampler_thread",
-                                                                  "dma_share_of_wall_clock")}
+                                                                  "dma_share_of_wall_clock", "env_worker_processes",
+                                                                  "obs_dma_from_worker_pages_in_place", "host_s")}
                 ent["env_side"] = "unpinned (synthetic host frames; envpool/ALE not installable)"
             if wl == "c5":
                 ent["env_side"] = "unpinned (Ant-shaped synthetic env; envpool/mujoco not installable)"

@@ -197,6 +197,16 @@ int sf_grad_sumsq(const float *g, int64_t P, double *sumsq, void *stream);
 int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
                  float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale,
                  const uint32_t *skip_flag, void *stream);
+/* sf_adam_step with the learning rate in DEVICE memory (lr = *lr_dev * lr_scale; lr_scale = the valid-sample fraction of
+ * learner.py:788-794), and the per-minibatch KL-adaptive schedule of learner.py:46-85 (lr_schedule=kl_adaptive_minibatch:
+ * lr /= 1.5 above 2 x threshold, *= 1.5 below threshold / 2, within [lr_min, lr_max]) as a one-thread launch on the
+ * minibatch's mean KL (sf_loss_scalars out[4]): the schedule no longer costs a host read-back per SGD step.
+ * lr_out (may be NULL) receives a copy of the new rate (read back once per epoch with the loss scalars). */
+int sf_adam_step_dlr(float *p, const float *g, float *m, float *v, int64_t P, int step, const float *lr_dev,
+                     float lr_scale, float beta1, float beta2, float eps, float max_grad_norm, const double *sumsq,
+                     float grad_scale, const uint32_t *skip_flag, void *stream);
+int sf_lr_kl_adaptive(const float *kl, float *lr_dev, float threshold, float lr_min, float lr_max, float *lr_out,
+                      void *stream);
 
 /* Lamb (cfg.optimizer = "lamb"; algo/utils/optimizers.py:14-189 as configured by learner.py:228-243: Adam direction
  * with bias correction + weight_decay * w, then per-TENSOR trust ratio min(||w||, 10)/||step|| clamped to

@@ -506,6 +506,7 @@ def gen_train(name, obs_space, model_args, E, T, A, nb, epochs, extra=(), param_
         print("  fp32 (reference) ReLU positives per SGD step:", relu_pos32)
     for k, _ in shapes:
         arrays["g1_" + k] = first_grads[k].numpy().reshape(-1)[::subsample].copy()
+    arrays["curr_lr"] = float(learner.curr_lr)
     arrays["train_step"] = learner.train_step
     arrays["env_steps"] = stats["learner_env_steps"]
     sd = learner.actor_critic.state_dict()
@@ -1029,6 +1030,11 @@ def main():
         gen_model_fwd()
         gen_model_fwd_multi()
         gen_model_fwd_separate()
+    if "klmb" in which or "train" in which:  # per-minibatch KL-adaptive learning rate (learner.py:46-85), both directions
+        gen_train("mlp_klmb_down", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2,
+                  extra=["--lr_schedule=kl_adaptive_minibatch", "--lr_schedule_kl_threshold=1e-7", "--learning_rate=1e-3"])
+        gen_train("mlp_klmb_up", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2,
+                  extra=["--lr_schedule=kl_adaptive_minibatch", "--lr_schedule_kl_threshold=10.0", "--learning_rate=1e-4"])
     if "separate" in which:
         gen_model_fwd_separate()
     if "separate" in which or "train" in which:  # ActorCriticSeparateWeights through the reference's Learner.train

@@ -553,6 +553,14 @@ class Learner:
         global_size = experience_size * self.world
         need_kl_each_mb = self.lr_scheduler.invoke_after_each_minibatch() and isinstance(self.lr_scheduler, KlAdaptiveScheduler)
         self._dp_reduce_each_mb = need_kl_each_mb
+        # per-minibatch KL-adaptive schedule (learner.py:46-85) WITHOUT a read-back per SGD step: the learning rate lives
+        # in device memory, sf_lr_kl_adaptive updates it from the step's mean KL (scalars row slot 4; slot 10 = new rate)
+        # and sf_adam_step_dlr reads it.  Lamb keeps the host form (its trust ratios need the rate on the host anyway).
+        lr_on_device = need_kl_each_mb and cfg.optimizer == "adam"
+        if lr_on_device:
+            if not hasattr(self, "_lr_dev"):
+                self._lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._lr_dev.fill_(float(self.curr_lr))
         self._grad_norms = []
         # fused recurrent passes: sticky abort word, cleared once per call; the optimiser kernels skip their update
         # while it is set, and it is read back with every epoch's scalars (before any further epoch is trained)
@@ -582,8 +590,10 @@ class Learner:
                     if self.dp:
                         self.group.all_reduce_grads(ac.flat_grads)
                 actual_lr = self.curr_lr
+                valid_frac = 1.0
                 if self._global_invalids > 0:  # learner.py:788-794
-                    actual_lr = self.curr_lr * (global_size - self._global_invalids) / global_size
+                    valid_frac = (global_size - self._global_invalids) / global_size
+                    actual_lr = self.curr_lr * valid_frac
                 self.adam_step_count += 1
                 use_clip = cfg.max_grad_norm > 0.0
                 if use_clip or getattr(cfg, "record_grad_norm", False):
@@ -600,6 +610,11 @@ class Learner:
                                   nseg, self.adam_step_count, actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
                                   1e-4, 0.01, cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None,
                                   skip_flag=skip)
+                elif lr_on_device:
+                    lib.adam_step_dlr(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
+                                      self._lr_dev, valid_frac, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
+                                      cfg.max_grad_norm if use_clip else 0.0, self._sumsq if use_clip else None,
+                                      skip_flag=skip)
                 else:
                     lib.adam_step(ac.flat_params, ac.flat_grads, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
                                   actual_lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps,
@@ -608,7 +623,10 @@ class Learner:
                 ac.params_changed()
                 num_sgd_steps += 1
                 self.train_step += 1
-                if need_kl_each_mb:
+                if lr_on_device:
+                    sch = self.lr_scheduler
+                    lib.lr_kl_adaptive(row[4:5], self._lr_dev, sch.threshold, sch.min_lr, sch.max_lr, lr_out=row[10:11])
+                elif need_kl_each_mb:
                     recent_kls.append(float(row[4].item()))
                     self.curr_lr = self.lr_scheduler.update(self.curr_lr, recent_kls)
                 elif self.lr_scheduler.invoke_after_each_minibatch():
@@ -639,7 +657,10 @@ class Learner:
                     "another process?); the optimiser steps after it were skipped, the weights are those of the last "
                     "good SGD step; set SF_LSTM_SEQ=0 to use the per-step kernels")
             actor_losses = (rows[:, 0] + rows[:, 1] + rows[:, 2]).double().numpy()
-            if not need_kl_each_mb:
+            if lr_on_device:  # the rate the device schedule arrived at, read back with the epoch's scalars
+                self.curr_lr = float(rows[-1, 10])
+                actual_lr = self.curr_lr * valid_frac
+            if not need_kl_each_mb or lr_on_device:
                 recent_kls.extend(rows[:, 4].double().tolist())
             if self.lr_scheduler.invoke_after_each_epoch():
                 self.curr_lr = self.lr_scheduler.update(self.curr_lr, recent_kls)

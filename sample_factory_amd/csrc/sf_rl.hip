@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 15; }
+extern "C" int sf_abi_version(void) { return 16; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -1201,8 +1201,10 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, con
 
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float *__restrict__ g,
                                               float *__restrict__ m, float *__restrict__ v, int64_t P, AdamC c,
-                                              const double *__restrict__ sumsq, const uint32_t *__restrict__ skip) {
+                                              const double *__restrict__ sumsq, const uint32_t *__restrict__ skip,
+                                              const float *__restrict__ lr_dev) {
     if (skip && *skip) return;  // an aborted fused recurrent pass produced this gradient: leave weights and moments alone
+    if (lr_dev) c.lr_step *= *lr_dev;  // sf_adam_step_dlr: the learning rate lives on the device (KL-adaptive schedule)
     float coef = c.grad_scale;
     if (sumsq && c.max_norm > 0.f) {
         // clip_grad_norm_: total_norm of the (already grad_scale'd) gradient
@@ -1226,12 +1228,12 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, const float
     for (int64_t i = nvec * 4 + tid; i < P; i += nt) adam1(p[i], g[i], m[i], v[i], c, coef);
 }
 
-extern "C" int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
-                            float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale,
-                            const uint32_t *skip_flag, void *stream) {
-    SF_REQUIRE(p && g && m && v && P > 0 && step >= 1, "sf_adam_step: bad args");
+static int adam_step_impl(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
+                          float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale,
+                          const uint32_t *skip_flag, const float *lr_dev, void *stream, const char *who) {
+    SF_REQUIRE(p && g && m && v && P > 0 && step >= 1, "%s: bad args", who);
     SF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
-               "sf_adam_step: buffers must be 16-byte aligned");
+               "%s: buffers must be 16-byte aligned", who);
     AdamC c;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     c.lr_step = (float)((double)lr / bc1);
@@ -1244,8 +1246,45 @@ extern "C" int sf_adam_step(float *p, const float *g, float *m, float *v, int64_
     c.grad_scale = grad_scale;
     const int64_t blocks = (P / 4 + 255) / 256;
     k_adam<<<dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, STREAM(stream)>>>(
-        p, g, m, v, P, c, sumsq, skip_flag);
-    return sf_launch_status("sf_adam_step");
+        p, g, m, v, P, c, sumsq, skip_flag, lr_dev);
+    return sf_launch_status(who);
+}
+
+extern "C" int sf_adam_step(float *p, const float *g, float *m, float *v, int64_t P, int step, float lr, float beta1,
+                            float beta2, float eps, float max_grad_norm, const double *sumsq, float grad_scale,
+                            const uint32_t *skip_flag, void *stream) {
+    return adam_step_impl(p, g, m, v, P, step, lr, beta1, beta2, eps, max_grad_norm, sumsq, grad_scale, skip_flag, nullptr,
+                          stream, "sf_adam_step");
+}
+// the same step with the learning rate read from DEVICE memory: lr = *lr_dev * lr_scale (lr_scale: the valid-sample
+// fraction of learner.py:788-794).  With sf_lr_kl_adaptive this keeps the per-minibatch KL-adaptive schedule
+// (learner.py:46-85, lr_schedule=kl_adaptive_minibatch) off the host: no read-back between SGD steps.
+extern "C" int sf_adam_step_dlr(float *p, const float *g, float *m, float *v, int64_t P, int step, const float *lr_dev,
+                                float lr_scale, float beta1, float beta2, float eps, float max_grad_norm,
+                                const double *sumsq, float grad_scale, const uint32_t *skip_flag, void *stream) {
+    SF_REQUIRE(lr_dev, "sf_adam_step_dlr: null lr_dev");
+    return adam_step_impl(p, g, m, v, P, step, lr_scale, beta1, beta2, eps, max_grad_norm, sumsq, grad_scale, skip_flag,
+                          lr_dev, stream, "sf_adam_step_dlr");
+}
+
+// learner.py:46-85 (KlAdaptiveScheduler.update): lr /= 1.5 (floor lr_min) when the KL of the step exceeds 2 x threshold,
+// lr *= 1.5 (cap lr_max) when it is below threshold / 2.  kl: device float (the minibatch's mean KL, sf_loss_scalars[4]);
+// lr_dev: device float, updated in place; lr_out (may be NULL): a copy of the new value for the epoch's read-back.
+__global__ void k_lr_kl_adaptive(const float *__restrict__ kl, float *__restrict__ lr_dev, float threshold, float lr_min,
+                                 float lr_max, float *__restrict__ lr_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    const double k = (double)*kl;
+    double lr = (double)*lr_dev;
+    if (k > 2.0 * (double)threshold) lr = fmax(lr / 1.5, (double)lr_min);
+    if (k < 0.5 * (double)threshold) lr = fmin(lr * 1.5, (double)lr_max);
+    *lr_dev = (float)lr;
+    if (lr_out) *lr_out = (float)lr;
+}
+extern "C" int sf_lr_kl_adaptive(const float *kl, float *lr_dev, float threshold, float lr_min, float lr_max,
+                                 float *lr_out, void *stream) {
+    SF_REQUIRE(kl && lr_dev, "sf_lr_kl_adaptive: null pointer");
+    k_lr_kl_adaptive<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(kl, lr_dev, threshold, lr_min, lr_max, lr_out);
+    return sf_launch_status("sf_lr_kl_adaptive");
 }
 
 // =========================================================================================== Lamb (cfg.optimizer=lamb)
