@@ -162,7 +162,8 @@ def secondary_lines(args):
             ent = {"workload": wl, "metric": d["metric"], "value": d["value"], "unit": d["unit"],
                    "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
                    "data": "synthetic", "config": d["config"]["workload"],
-                   "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                   "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                       "traffic_source", "clock_ghz", "frac_at_measured_clock",
                                                        "avg_launch_ms", "launches", "share_of_step_time")},
                    "wall_s": round(time.perf_counter() - t0, 1)}
             if "ingest" in d:

@@ -14,6 +14,19 @@ python bench.py $Q --steps 8 --async_rl > $O/${TAG}_bench_async.json 2> $O/async
 python bench.py $Q --steps 2 --warmup 1 --rollout 128 --num_batches 16 --num_epochs 4 > $O/${TAG}_bench_atari_preset.json 2> $O/atari.err
 python bench.py $Q --steps 600 --no_kernel_events > $O/${TAG}_bench_600steps.json 2> $O/long.err
 for E in 8192 32768; do python bench.py $Q --steps 4 --envs $E --no_kernel_events > $O/${TAG}_envs_$E.json 2> $O/envs_$E.err; done
+# config 5: counter passes first (HBM traffic + matrix-pipe busy of the fused sequence kernels), so that the c5 line below
+# carries roofline.traffic from kernel sources with the same hash
+C1="python bench.py --workload c5 --steps 1 --warmup 1 $Q --no_kernel_events"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c5fetch -o f -- $C1 > /dev/null 2> $O/c5fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c5write -o w -- $C1 > /dev/null 2> $O/c5write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS \
+  --kernel-trace --output-format csv -d $O/c5sq -o p -- $C1 > /dev/null 2> $O/c5sq.err
+F=$(find $O/c5fetch -name "*counter_collection.csv" | head -1); W=$(find $O/c5write -name "*counter_collection.csv" | head -1)
+S=$(find $O/c5sq -name "*counter_collection.csv" | head -1)
+[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_traffic.py $F $W > $O/${TAG}_c5_traffic.json 2> $O/c5_pmc_traffic.err && cp $O/${TAG}_c5_traffic.json profiles/${TAG}_c5_traffic.json
+[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_hbm.py $F $W $O/${TAG}_c5_hbm_kernels.json > /dev/null 2> $O/c5_pmc_hbm.err
+[ -n "$S" ] && python tools/pmc_mfma.py $S $O/${TAG}_c5_mfma_util.json > /dev/null 2> $O/c5_pmc_mfma.err
+find $O -name "*counter_collection.csv" -size +8M -delete
 python bench.py --workload c5 $Q --steps 8 > $O/${TAG}_c5_bench.json 2> $O/c5.err
 python bench.py --workload c5 --rnn_type gru $Q --steps 8 > $O/${TAG}_c5_gru_bench.json 2> $O/c5g.err
 python bench.py --workload c3 $Q --steps 4 > $O/${TAG}_c3_bench.json 2> $O/c3.err

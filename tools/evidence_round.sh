@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything a round commits as judged evidence, in ONE GPU-box call (run from the repo root):
 #   bash tools/evidence_round.sh <tag>        e.g. r03_d
-#   1. the whole GPU test-suite;  2. the driver's bench line (default flags);  3. rocprofv3 kernel trace + stats of the timed
+#   1. the whole GPU test-suite;  2. (dropped: the driver-like line is step 5);  3. rocprofv3 kernel trace + stats of the timed
 #   bench, the two TCC passes (HBM traffic) and one SQ pass (matrix-pipe busy) -- tools/profile_round.sh; counter passes never
 #   share a run with other trace domains;  4. the post-processed summaries (stamped with the kernel-source hash);  5. the
 #   bench line again, now with roofline.traffic from the pass just taken.
@@ -14,7 +14,6 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 python -m pytest tests -q -m gpu 2>&1 | tail -25 > $O/pytest.log
-python bench.py > $O/bench_driver_like.json 2> $O/bench_driver_like.err
 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/write -name "*counter_collection.csv" | head -1)

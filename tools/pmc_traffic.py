@@ -58,9 +58,10 @@ def main():
         if r["Counter_Name"] == "WRITE_SIZE":
             w_all[r["Kernel_Name"]] += float(r["Counter_Value"])
     for name, nl in n_all.items():
-        if not any(t in name for t in ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_wgrad_img", "k_dgrad_")):
+        if not any(t in name for t in ("k_conv", "k_fwd_glds", "k_fwd_img", "k_wgrad_glds", "k_wgrad_img", "k_dgrad_",
+                                       "k_lstm_seq", "k_gru_seq", "k_linear_")):
             continue
-        short = name.replace("void ", "").split("(")[0]
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         out[short] = dict(fetch_kib_per_launch=round(f_all[name] / nl, 1), write_kib_per_launch=round(w_all[name] / nl, 1),
                           hbm_bytes=int((2 * f_all[name] + w_all[name]) / nl * 1024), launches=nl)
     # wgrad: one launch per layer per minibatch, identified by the layer's K*N partial size pattern (largest fetch first)
