@@ -207,6 +207,10 @@ int sf_adam_step_dlr(float *p, const float *g, float *m, float *v, int64_t P, in
                      float grad_scale, const uint32_t *skip_flag, void *stream);
 int sf_lr_kl_adaptive(const float *kl, float *lr_dev, float threshold, float lr_min, float lr_max, float *lr_out,
                       void *stream);
+/* measurement helper: one wave spins for spin_cycles shader cycles; out[0] = shader cycles, out[1] = ticks of the constant
+ * 100 MHz wall clock elapsed meanwhile (device uint64[2]) -> shader clock [GHz] = 0.1 * out[0] / out[1].  bench.py launches
+ * it on a side stream during the timed region (roofline.clock_ghz). */
+int sf_clock_probe(unsigned long long *out, int spin_cycles, void *stream);
 
 /* Lamb (cfg.optimizer = "lamb"; algo/utils/optimizers.py:14-189 as configured by learner.py:228-243: Adam direction
  * with bias correction + weight_decay * w, then per-TENSOR trust ratio min(||w||, 10)/||step|| clamped to

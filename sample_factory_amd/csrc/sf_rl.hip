@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 16; }
+extern "C" int sf_abi_version(void) { return 17; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
@@ -1265,6 +1265,25 @@ extern "C" int sf_adam_step_dlr(float *p, const float *g, float *m, float *v, in
     SF_REQUIRE(lr_dev, "sf_adam_step_dlr: null lr_dev");
     return adam_step_impl(p, g, m, v, P, step, lr_scale, beta1, beta2, eps, max_grad_norm, sumsq, grad_scale, skip_flag,
                           lr_dev, stream, "sf_adam_step_dlr");
+}
+
+// Measurement helper (bench.py's roofline.clock_ghz): ONE wave spins for `spin_cycles` shader cycles and reports how many
+// ticks of the constant 100 MHz wall clock (s_memrealtime) went by meanwhile: shader clock [GHz] = 0.1 * out[0] / out[1].
+// Launched on a side stream during the timed region it reads the clock the chip actually runs at under that load (the
+// DVFS-governed clock is what the 2.4 GHz peak has to be scaled by; sysfs / smi values proved unreliable on the boxes).
+__global__ void k_clock_probe(unsigned long long *__restrict__ out, int spin_cycles) {
+    if (threadIdx.x || blockIdx.x) return;
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned long long c1 = c0;
+    while ((long long)(c1 - c0) < (long long)spin_cycles) c1 = clock64();
+    const unsigned long long w1 = wall_clock64();
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+}
+extern "C" int sf_clock_probe(unsigned long long *out, int spin_cycles, void *stream) {
+    SF_REQUIRE(out && spin_cycles > 0, "sf_clock_probe: bad args");
+    k_clock_probe<<<dim3(1), dim3(64), 0, STREAM(stream)>>>(out, spin_cycles);
+    return sf_launch_status("sf_clock_probe");
 }
 
 // learner.py:46-85 (KlAdaptiveScheduler.update): lr /= 1.5 (floor lr_min) when the KL of the step exceeds 2 x threshold,

@@ -39,7 +39,7 @@ class sf_conv_desc(C.Structure):
 SYMBOLS = [
     "sf_last_error", "sf_abi_version", "sf_valid_mask", "sf_gae_returns", "sf_moments", "sf_rms_update",
     "sf_rms_apply", "sf_vtrace", "sf_ppo_loss", "sf_loss_scalars", "sf_train_summaries", "sf_minibatch_indices", "sf_minibatch_expand", "sf_grad_sumsq",
-    "sf_adam_step", "sf_adam_step_dlr", "sf_lr_kl_adaptive", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd", "sf_seq_fwd_x_supported", "sf_lstm_seq_fwd_x", "sf_gru_seq_fwd_x", "sf_linear_fwd_dual_supported", "sf_linear_fwd_dual",
+    "sf_adam_step", "sf_adam_step_dlr", "sf_lr_kl_adaptive", "sf_clock_probe", "sf_lamb_step", "sf_rnn_cell_fwd", "sf_rnn_cell_bwd", "sf_rows_add_scale", "sf_mlp2_fwd", "sf_rnn_store_state", "sf_rnn_chunk_setup", "sf_lstm_seq_supported", "sf_lstm_seq_fwd", "sf_lstm_seq_bwd", "sf_gru_seq_fwd", "sf_gru_seq_bwd", "sf_seq_fwd_x_supported", "sf_lstm_seq_fwd_x", "sf_gru_seq_fwd_x", "sf_linear_fwd_dual_supported", "sf_linear_fwd_dual",
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_copy_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
@@ -486,6 +486,14 @@ def lr_kl_adaptive(kl, lr_dev, threshold, lr_min, lr_max, lr_out=None) -> None:
     """kl: device f32 [1] view (mean KL of the SGD step); lr_dev: device f32 [1], updated in place (learner.py:46-85)"""
     _check(load().sf_lr_kl_adaptive(ptr(kl, "f32", "kl"), ptr(lr_dev, "f32", "lr_dev"), f(threshold), f(lr_min), f(lr_max),
                                     ptr(lr_out, "f32", "lr_out"), stream()), "sf_lr_kl_adaptive")
+
+
+def clock_probe(out: torch.Tensor, spin_cycles: int = 200000, on_stream=None) -> None:
+    """out: device int64 [2] -> (shader cycles, 100 MHz wall-clock ticks) of a one-wave spin (bench.py roofline.clock_ghz)"""
+    if not out.is_cuda or out.dtype != torch.int64 or out.numel() < 2:
+        raise SfHipError("clock_probe: out must be a device int64 tensor of 2 elements")
+    st = C.c_void_p(on_stream.cuda_stream) if on_stream is not None else stream()
+    _check(load().sf_clock_probe(C.c_void_p(out.data_ptr()), int(spin_cycles), st), "sf_clock_probe")
 
 
 def lamb_step(p, g, m, v, scratch, seg_id, seg_sums, num_segments, step, lr, beta1, beta2, eps, weight_decay, min_trust,

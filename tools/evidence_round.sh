@@ -13,7 +13,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-python -m pytest tests -q -m gpu 2>&1 | tail -25 > $O/pytest.log
+python -m pytest tests -q -m gpu --durations=30 2>&1 | tail -60 > $O/pytest.log
 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/write -name "*counter_collection.csv" | head -1)
