@@ -34,43 +34,32 @@ PEAK_HBM_GBS = 8000.0
 
 
 class ClockSampler:
-    """Shader clock of this rank's GPU DURING the timed region (a host thread + a side stream, never on the measured
-    stream): the roofline peak is priced at the 2.4 GHz maximum, the chip runs at its power budget (MI355X_MICROARCH.md,
-    DVFS) — `roofline.clock_ghz` / `frac_at_measured_clock` say how much of the gap is clock.  Source: `sf_clock_probe`, a
-    one-wave kernel that spins for 200 k shader cycles (~85 us) and counts the ticks of the constant 100 MHz wall clock
-    meanwhile — the clock the chip actually runs at under this load (amdgpu's pp_dpm_sclk reported 95 MHz and 2.39 GHz for
-    the same workload on two boxes, rocm-smi needs 0.3 s per sample)."""
+    """Shader clock of this rank's GPU DURING the timed region: the roofline peak is priced at the 2.4 GHz maximum, the chip
+    runs at its power budget (MI355X_MICROARCH.md, DVFS) — `roofline.clock_ghz` / `frac_at_measured_clock` say how much of the
+    gap is clock.  Source: `sf_clock_probe`, a one-wave kernel that spins for 200 k shader cycles (~85 us) and counts the
+    ticks of the constant 100 MHz wall clock meanwhile.  The probes are ENQUEUED on a side stream from the timing loop
+    itself (one per step, at most 32; ~10 us of host time each, no thread: a sampling thread cost the launch-bound c5 loop
+    4 % through the GIL) and run beside whatever the measured stream is executing; read back after the region.
+    (amdgpu's pp_dpm_sclk reported 95 MHz and 2.39 GHz for the same workload on two boxes — not used.)"""
 
-    def __init__(self, period=0.04):
-        self.period, self.samples, self._stop, self._thr = period, [], False, None
+    MAX = 32
 
-    def _loop(self):
+    def __init__(self):
         import torch
-        from sample_factory_amd import lib
-        try:
-            side = torch.cuda.Stream()
-            out = torch.zeros(2, dtype=torch.int64, device="cuda")
-            with torch.cuda.stream(side):
-                while not self._stop:
-                    lib.clock_probe(out, 200000, on_stream=side)
-                    side.synchronize()
-                    c, w = (int(v) for v in out.tolist())
-                    if w > 0:
-                        self.samples.append(0.1 * c / w)
-                    time.sleep(self.period)
-        except Exception as e:  # noqa: BLE001 - a measurement helper must never take the bench line down
-            self.error = repr(e)
+        self.side = torch.cuda.Stream()
+        self.out = torch.zeros((self.MAX, 2), dtype=torch.int64, device="cuda")
+        self.n = 0
 
-    def start(self):
-        import threading
-        self._thr = threading.Thread(target=self._loop, daemon=True)
-        self._thr.start()
+    def probe(self):
+        if self.n < self.MAX:
+            from sample_factory_amd import lib
+            lib.clock_probe(self.out[self.n], 200000, on_stream=self.side)
+            self.n += 1
 
     def stop(self):
-        self._stop = True
-        if self._thr is not None:
-            self._thr.join(timeout=8)
-        good = sorted(v for v in self.samples if 0.3 < v < 3.5)
+        self.side.synchronize()
+        rows = self.out[:self.n].tolist()
+        good = sorted(0.1 * c / w for c, w in rows if w > 0 and 0.3 < 0.1 * c / w < 3.5)
         if not good:
             return None
         return {"ghz": round(good[len(good) // 2], 3), "min_ghz": round(good[0], 3), "max_ghz": round(good[-1], 3),
@@ -428,11 +417,11 @@ def main():
             sm.ingest_prof, sm.h2d_bytes = {}, 0
     clk = ClockSampler() if rank == 0 else None
     barrier()
-    if clk is not None:
-        clk.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.iteration()
+        if clk is not None:
+            clk.probe()  # lands beside the next step's kernels
     barrier()
     dt = time.perf_counter() - t0
     clock = clk.stop() if clk is not None else None
