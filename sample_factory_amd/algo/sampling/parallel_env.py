@@ -88,10 +88,64 @@ def _format_actions(act_rows: np.ndarray, heads: List[int], continuous: bool, ba
     return a if batched else int(a[0])
 
 
+class _InstanceStepper:
+    """the env instances of ONE worker (or, inline, of the whole runner) and the arrays they write into: reset / step of one
+    split, exactly what a rollout worker does per message (rollout_worker.py:201-259, make_env.py:97-128,147-237)"""
+
+    def __init__(self, make_env_func, env_name, cfg, widx, instances, arrays, heads, continuous):
+        self.arrays, self.heads, self.continuous, self.envs = arrays, heads, continuous, []
+        for split, vidx, env_id, row0, nrows in instances:
+            env = make_env_func(env_name, cfg, AttrDict(worker_index=widx, vector_index=vidx, env_id=env_id), None)
+            self.envs.append((split, env, env_is_batched(env), row0, nrows, env_id))
+
+    @staticmethod
+    def _put_obs(a, obs, row0, nrows, batched):
+        for k, v in _as_obs_dict(obs).items():
+            dst = a["obs." + k]
+            if batched:
+                if isinstance(v, (list, tuple)):
+                    v = np.stack([np.asarray(x) for x in v])
+                v = np.asarray(v.cpu() if hasattr(v, "cpu") else v)
+                np.copyto(dst[row0:row0 + nrows], v.reshape(dst[row0:row0 + nrows].shape), casting="unsafe")
+            else:
+                np.copyto(dst[row0], np.asarray(v).reshape(dst[row0].shape), casting="unsafe")
+
+    def run(self, cmd: int, split: int) -> None:
+        a = self.arrays[split]
+        for sp_, env, batched, row0, nrows, env_id in self.envs:
+            if sp_ != split:
+                continue
+            if cmd == CMD_RESET:
+                try:
+                    obs, _info = env.reset(seed=env_id)  # gymnasium >= 0.26 seeds in reset (make_env.py:206-214)
+                except TypeError:
+                    obs, _info = env.reset()
+                self._put_obs(a, obs, row0, nrows, batched)
+                continue
+            act = _format_actions(a["act"][row0:row0 + nrows], self.heads, self.continuous, batched)
+            obs, rew, term, trunc, _info = env.step(act)
+            if batched:
+                a["rew"][row0:row0 + nrows] = np.asarray(rew.cpu() if hasattr(rew, "cpu") else rew, dtype=np.float32).reshape(-1)
+                a["term"][row0:row0 + nrows] = np.asarray(term.cpu() if hasattr(term, "cpu") else term).reshape(-1)
+                a["trunc"][row0:row0 + nrows] = np.asarray(trunc.cpu() if hasattr(trunc, "cpu") else trunc).reshape(-1)
+            else:
+                if term or trunc:  # auto-reset (make_env.py:100-102); the terminal observation is dropped as there
+                    obs, _ = env.reset()
+                a["rew"][row0], a["term"][row0], a["trunc"][row0] = rew, bool(term), bool(trunc)
+            self._put_obs(a, obs, row0, nrows, batched)
+
+    def close(self) -> None:
+        for _sp, env, *_ in self.envs:
+            try:
+                env.close()
+            except Exception:  # noqa: BLE001
+                pass
+
+
 def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: str, cfg, instances, specs, heads,
                  continuous: bool):
     """instances: [(split, vector_index, env_id, row0, nrows)] of this worker; specs[split] = {name: shm spec}"""
-    arrays, shms, envs = {}, [], []
+    arrays, shms, stepper = {}, [], None
     try:
         for split, sp in specs.items():
             arrays[split] = {}
@@ -99,48 +153,13 @@ def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: 
                 s = _Shm(shape, dt, name=shm_name)
                 shms.append(s)
                 arrays[split][name] = s.array
-        for split, vidx, env_id, row0, nrows in instances:
-            env = make_env_func(env_name, cfg, AttrDict(worker_index=widx, vector_index=vidx, env_id=env_id), None)
-            envs.append((split, env, env_is_batched(env), row0, nrows, env_id))
+        stepper = _InstanceStepper(make_env_func, env_name, cfg, widx, instances, arrays, heads, continuous)
         conn.send(("ready", widx))
-
-        def put_obs(a, obs, row0, nrows, batched):
-            for k, v in _as_obs_dict(obs).items():
-                dst = a["obs." + k]
-                if batched:
-                    if isinstance(v, (list, tuple)):
-                        v = np.stack([np.asarray(x) for x in v])
-                    v = np.asarray(v.cpu() if hasattr(v, "cpu") else v)
-                    np.copyto(dst[row0:row0 + nrows], v.reshape(dst[row0:row0 + nrows].shape), casting="unsafe")
-                else:
-                    np.copyto(dst[row0], np.asarray(v).reshape(dst[row0].shape), casting="unsafe")
-
         while True:
             cmd, split = conn.recv()
             if cmd == CMD_CLOSE:
                 break
-            a = arrays[split]
-            for sp_, env, batched, row0, nrows, env_id in envs:
-                if sp_ != split:
-                    continue
-                if cmd == CMD_RESET:
-                    try:
-                        obs, _info = env.reset(seed=env_id)  # gymnasium >= 0.26 seeds in reset (make_env.py:206-214)
-                    except TypeError:
-                        obs, _info = env.reset()
-                    put_obs(a, obs, row0, nrows, batched)
-                    continue
-                act = _format_actions(a["act"][row0:row0 + nrows], heads, continuous, batched)
-                obs, rew, term, trunc, _info = env.step(act)
-                if batched:
-                    a["rew"][row0:row0 + nrows] = np.asarray(rew.cpu() if hasattr(rew, "cpu") else rew, dtype=np.float32).reshape(-1)
-                    a["term"][row0:row0 + nrows] = np.asarray(term.cpu() if hasattr(term, "cpu") else term).reshape(-1)
-                    a["trunc"][row0:row0 + nrows] = np.asarray(trunc.cpu() if hasattr(trunc, "cpu") else trunc).reshape(-1)
-                else:
-                    if term or trunc:  # auto-reset (make_env.py:100-102); the terminal observation is dropped as there
-                        obs, _ = env.reset()
-                    a["rew"][row0], a["term"][row0], a["trunc"][row0] = rew, bool(term), bool(trunc)
-                put_obs(a, obs, row0, nrows, batched)
+            stepper.run(cmd, split)
             done_sems[split].release()
     except BaseException:  # noqa: BLE001 - reported to the main process, which raises
         try:
@@ -150,11 +169,8 @@ def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: 
         for s in done_sems:
             s.release()
     finally:
-        for _sp, env, *_ in envs:
-            try:
-                env.close()
-            except Exception:  # noqa: BLE001
-                pass
+        if stepper is not None:
+            stepper.close()
         for s in shms:
             s.close()
 
@@ -205,7 +221,9 @@ class ParallelVecEnvView:
 
 class ParallelHostEnvs:
     def __init__(self, cfg, env_name: str, make_env_func: Callable, num_workers: int, envs_per_worker: int,
-                 num_splits: int = 1, start_method: Optional[str] = None):
+                 num_splits: int = 1, start_method: Optional[str] = None, inline: bool = False):
+        """inline=True: no processes — the same instances, wrappers and row layout stepped in THIS process (serial_mode:
+        single-agent gym envs such as BASELINE configs[0]'s two CartPole copies behind one batched view)."""
         assert envs_per_worker % num_splits == 0, f"{envs_per_worker=} must be a multiple of {num_splits=}"
         self.cfg, self.num_workers, self.envs_per_worker, self.num_splits = cfg, num_workers, envs_per_worker, num_splits
         self._closed, self._conns, self._procs, self._shms = False, [], [], []
@@ -232,6 +250,9 @@ class ParallelHostEnvs:
             arr, spec = {}, {}
 
             def add(name, shape, dtype):
+                if inline:
+                    arr[name], spec[name] = np.zeros(tuple(int(v) for v in shape), dtype=dtype), None
+                    return
                 s = _Shm(shape, dtype)
                 self._shms.append(s)
                 arr[name], spec[name] = s.array, s.spec()
@@ -248,6 +269,19 @@ class ParallelHostEnvs:
                 add("act", (n, len(self.heads)) if len(self.heads) > 1 else (n,), np.int32)
             self.arrays.append(arr)
             specs.append(spec)
+        self.inline, self._steppers = inline, []
+        if inline:
+            for w in range(num_workers):
+                inst = []
+                for v in range(envs_per_worker):
+                    split, j = v // per_split, v % per_split
+                    inst.append((split, v, w * envs_per_worker + v, (w * per_split + j) * self.agents_per_instance,
+                                 self.agents_per_instance))
+                self._steppers.append(_InstanceStepper(make_env_func, env_name, cfg, w, inst,
+                                                       {s_: self.arrays[s_] for s_ in range(num_splits)}, self.heads,
+                                                       self.continuous))
+            self.views = [ParallelVecEnvView(self, s_, n) for s_ in range(num_splits)]
+            return
         # ---- workers
         method = start_method or getattr(cfg, "env_worker_start_method", None) or "spawn"
         ctx = mp.get_context(method)
@@ -279,6 +313,8 @@ class ParallelHostEnvs:
     def register_with_device(self) -> bool:
         """hipHostRegister the observation pages (main process only; a no-op without a GPU).  Returns True if the pages are
         now page-locked: the rollout runner then hands them to sf_h2d_rows without a staging copy."""
+        if self.inline:
+            return False
         try:
             import torch
             if not torch.cuda.is_available():
@@ -297,10 +333,16 @@ class ParallelHostEnvs:
             return False
 
     def _command(self, split: int, cmd: int) -> None:
+        if self.inline:
+            for st in self._steppers:
+                st.run(cmd, split)
+            return
         for c in self._conns:
             c.send((cmd, split))
 
     def _wait(self, split: int) -> None:
+        if self.inline:
+            return
         timeout = float(getattr(self.cfg, "env_worker_step_timeout", 600.0))
         for w in range(self.num_workers):
             if not self._done[w][split].acquire(timeout=timeout):
@@ -315,6 +357,8 @@ class ParallelHostEnvs:
         if getattr(self, "_closed", True):
             return
         self._closed = True
+        for st in getattr(self, "_steppers", []):
+            st.close()
         for c in self._conns:
             try:
                 c.send((CMD_CLOSE, 0))

@@ -56,6 +56,46 @@ class CartPoleVecEnv:
         pass
 
 
+class CartPoleEnv:
+    """ONE cart-pole with the gymnasium single-env API (reset(seed=...) -> (obs, info); step(a) -> (obs, reward,
+    terminated, truncated, info); no auto-reset) — what `gym.make("CartPole-v1")` returns, for boxes without gymnasium.
+    The engine wraps such envs as the reference does (make_env.py:97-128): one agent each, auto-reset on done, stepped in
+    this process (serial_mode) or in env worker processes."""
+
+    def __init__(self, seed=0, max_steps=500, render_mode=None):
+        self._v = CartPoleVecEnv(num_agents=1, seed=seed, max_steps=max_steps)
+        self.observation_space = spaces.Box(-np.inf, np.inf, (4,), np.float32)
+        self.action_space = spaces.Discrete(2)
+        self.render_mode = render_mode
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self._v.rng = np.random.default_rng(seed)
+        o, info = self._v.reset()
+        return o["obs"][0], info
+
+    def step(self, action):
+        v = self._v
+        a = np.asarray([action]).reshape(-1).astype(np.int64)
+        x, x_dot, th, th_dot = v.state.T
+        force = np.where(a == 1, 10.0, -10.0)
+        g, mc, mp, length = 9.8, 1.0, 0.1, 0.5
+        total, pml = mc + mp, mp * length
+        cos, sin = np.cos(th), np.sin(th)
+        temp = (force + pml * th_dot ** 2 * sin) / total
+        th_acc = (g * sin - cos * temp) / (length * (4.0 / 3.0 - mp * cos ** 2 / total))
+        x_acc = temp - pml * th_acc * cos / total
+        tau = 0.02
+        v.state = np.stack([x + tau * x_dot, x_dot + tau * x_acc, th + tau * th_dot, th_dot + tau * th_acc], 1)
+        v.steps += 1
+        terminated = bool((np.abs(v.state[0, 0]) > 2.4) | (np.abs(v.state[0, 2]) > 12 * 2 * np.pi / 360))
+        truncated = bool(v.steps[0] >= v.max_steps) and not terminated
+        return v.state[0].astype(np.float32), 1.0, terminated, truncated, {}
+
+    def close(self):
+        pass
+
+
 def make_cartpole_env(full_env_name, cfg=None, env_config=None, render_mode=None):
     n = getattr(cfg, "cartpole_num_agents", 2) if cfg is not None else 2
     seed = ((getattr(cfg, "seed", None) or 0) if cfg is not None else 0) + 1000 * int(getattr(env_config, "env_id", 0) or 0)

@@ -191,7 +191,8 @@ class Runner:
         # tails of the small-batch kernels: measured in tools/split_probe.py and DESIGN.md §5.
         E = max(1, int(cfg.num_workers) * int(cfg.num_envs_per_worker))
         self.parallel_envs = None
-        if self._want_env_workers():
+        plan = self._env_plan()
+        if plan != "direct":
             # HOST envs in worker PROCESSES (rollout_worker.py:79-308): cfg.num_workers processes x cfg.num_envs_per_worker
             # instances, dealt to cfg.worker_num_splits splits; every split is one batched host env for the code below
             from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
@@ -200,7 +201,7 @@ class Runner:
             if int(cfg.num_envs_per_worker) % S != 0:
                 S = 1
             self.parallel_envs = ParallelHostEnvs(cfg, cfg.env, registered_env_factory(cfg.env), int(cfg.num_workers),
-                                                  int(cfg.num_envs_per_worker), num_splits=S)
+                                                  int(cfg.num_envs_per_worker), num_splits=S, inline=plan == "inline")
             self.parallel_envs.register_with_device()
             self.envs = list(self.parallel_envs.views)
             # from here on: one "worker" whose env instances are the splits (slab rows, sampling units, streams follow)
@@ -288,33 +289,33 @@ class Runner:
         self._observers_call("on_connect_components", self)
         return ExperimentStatus.SUCCESS
 
-    def _want_env_workers(self) -> bool:
-        """cfg.env_workers_mode: "process" = env instances in worker processes, "inline" = in this process, None / "auto" =
-        processes iff the reference would use them (serial_mode=False, runner_parallel.py) AND the env is a host env that
-        cannot write into the slab itself (no `step_into`: device-resident vector envs always stay in-process)."""
+    def _env_plan(self) -> str:
+        """"process": host envs in cfg.num_workers worker processes (the reference's deployment for serial_mode=False);
+        "inline": single-agent gym-style envs stepped in this process behind one batched view (serial_mode=True, e.g.
+        BASELINE configs[0]'s CartPole copies); "direct": the env instances are batched vector envs used as they are
+        (device-resident envs always; batched host envs in serial mode).  cfg.env_workers_mode = "process" | "inline"
+        overrides the serial_mode rule ("auto")."""
+        from sample_factory_amd.algo.sampling.parallel_env import env_is_batched
         cfg = self.cfg
         mode = getattr(cfg, "env_workers_mode", None) or "auto"
-        if mode == "inline":
-            return False
         if mode == "process":
-            return True
-        if bool(cfg.serial_mode):
-            return False
-        # ask instance 0 what kind of env this is (kept and reused as instance 0 when the answer is "in-process")
+            return "process"
+        # ask instance 0 what kind of env this is (kept and reused as instance 0 when the answer is "direct")
         probe = create_env(cfg.env, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0))
         device_env = hasattr(probe, "step_into")
-        if not device_env:
+        if not device_env and env_is_batched(probe):
             o, _ = probe.reset()
             first = next(iter(o.values())) if isinstance(o, dict) else o
             device_env = isinstance(first, torch.Tensor) and first.is_cuda
-        if device_env:
+        in_process = mode == "inline" or bool(cfg.serial_mode)
+        if device_env or (in_process and env_is_batched(probe)):
             self._probe_env = probe
-            return False
+            return "direct"
         try:
             probe.close()
         except Exception:  # noqa: BLE001
             pass
-        return True
+        return "inline" if in_process else "process"
 
     @property
     def slabs(self):

@@ -510,3 +510,23 @@ def test_host_envs_in_worker_processes_double_buffered(async_rl):
         print("frames DMA'd from the workers' pages in place:", direct)
     finally:
         runner.close_envs()
+
+
+def test_baseline_config0_two_single_agent_envs_serial_mode(tmp_path):
+    """BASELINE.json configs[0] as written — "sf_examples/train_gym_env.py CartPole-v1, serial mode, 2 envs" — through the
+    example script of the same shape: the env factory returns ONE gym-style env per instance (gym.make where gymnasium is
+    installed, the bundled CartPoleEnv with the same API otherwise), `--num_envs_per_worker=2`, `--serial_mode=True`; the
+    engine wraps the two single-agent envs as the reference does (one agent each, auto-reset on done).  The learner runs
+    on the GPU: this engine has no CPU execution mode."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "train_gym_env.py"), "--env=CartPole-v1",
+                        "--env_agents=0", "--use_rnn=False", "--serial_mode=True", "--async_rl=False", "--num_workers=1",
+                        "--num_envs_per_worker=2", "--worker_num_splits=1", "--batch_size=64", "--rollout=32",
+                        "--num_batches_per_epoch=1", "--train_for_env_steps=1280", f"--train_dir={tmp_path}",
+                        "--experiment=config0", "--seed=0", "--encoder_mlp_layers", "64", "64"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Collected {0: 1280}" in r.stdout
+    assert glob.glob(os.path.join(str(tmp_path), "config0", "checkpoint_p0", "checkpoint_*.pth"))

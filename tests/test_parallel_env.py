@@ -156,3 +156,36 @@ def make_failing_env(full_env_name, cfg=None, env_config=None, render_mode=None)
     if multiprocessing.current_process().name.startswith("sf-env-worker"):
         raise ValueError("no such simulator on this host")
     return _Probe()
+
+
+def make_single_cartpole(full_env_name, cfg=None, env_config=None, render_mode=None):
+    from sample_factory_amd.envs.cartpole import CartPoleEnv
+    return CartPoleEnv(seed=3 + env_config.env_id)
+
+
+def test_inline_mode_wraps_single_agent_gym_envs_like_the_reference():
+    """serial_mode: the same wrappers without processes — K single-agent gym-style envs (reset(seed) / step, no auto-reset,
+    what gym.make returns) behind one batched view with auto-reset on done (make_env.py:97-128); BASELINE configs[0] is two
+    CartPole copies of this kind"""
+    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
+    from sample_factory_amd.envs.cartpole import CartPoleEnv
+    cfg = default_cfg(env="c", seed=3)
+    penv = ParallelHostEnvs(cfg, "c", make_single_cartpole, 1, 2, num_splits=1, inline=True)
+    v = penv.views[0]
+    assert v.num_agents == 2 and not penv.register_with_device()
+    o, _ = v.reset()
+    envs = [CartPoleEnv(seed=3 + i) for i in range(2)]
+    np.testing.assert_array_equal(o["obs"], np.stack([e.reset(seed=i)[0] for i, e in enumerate(envs)]))
+    rng, resets = np.random.default_rng(0), 0
+    for t in range(300):
+        a = rng.integers(0, 2, 2).astype(np.int32)
+        o, r, te, tr, _ = v.step(a)
+        for i, e in enumerate(envs):
+            oo, rr, t1, t2, _ = e.step(int(a[i]))
+            if t1 or t2:
+                oo, _ = e.reset()
+                resets += 1
+            np.testing.assert_array_equal(o["obs"][i], oo)
+            assert te[i] == t1 and tr[i] == t2 and r[i] == rr
+    assert resets >= 5
+    penv.close()
