@@ -75,6 +75,13 @@ def enjoy(cfg) -> Tuple[int, float]:
         raise lib.SfHipError("enjoy(): no GPU visible. sample_factory_amd has no CPU path.")
     dev = torch.device("cuda", torch.cuda.current_device())
     env = create_env(cfg.env, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0))
+    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs, env_is_batched
+    if not hasattr(env, "step_into") and not env_is_batched(env):
+        # a single-agent gym-style env (what gym.make returns): evaluated behind the same one-agent view the training
+        # runner uses for it (make_env.py:97-128: auto-reset on done), in this process (enjoy.py:113-119 makes ONE env)
+        from sample_factory_amd.envs.env_utils import registered_env_factory
+        env.close()
+        env = ParallelHostEnvs(cfg, cfg.env, registered_env_factory(cfg.env), 1, 1, num_splits=1, inline=True).views[0]
     env_info = extract_env_info(env, cfg)
     if cfg.recurrence == -1:
         preprocess_cfg(cfg, env_info)

@@ -530,3 +530,8 @@ def test_baseline_config0_two_single_agent_envs_serial_mode(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Collected {0: 1280}" in r.stdout
     assert glob.glob(os.path.join(str(tmp_path), "config0", "checkpoint_p0", "checkpoint_*.pth"))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "enjoy_gym_env.py"), "--env=CartPole-v1",
+                        f"--train_dir={tmp_path}", "--experiment=config0", "--max_num_episodes=5", "--env_agents=0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 8.0 <= float(r.stdout.split("Avg episode reward:")[-1].split()[0]) <= 500.0
