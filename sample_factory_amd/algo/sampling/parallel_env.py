@@ -237,6 +237,9 @@ class ParallelHostEnvs:
         except Exception:  # noqa: BLE001
             pass
         spaces_ = obs_space_dict(self.observation_space)
+        if not hasattr(self.observation_space, "spaces"):  # make_env.py:46-66: a bare space becomes Dict(obs=space)
+            from sample_factory_amd.envs import spaces as _sp
+            self.observation_space = _sp.Dict(spaces_)
         self.obs_keys = list(spaces_.keys())
         self.heads = action_head_sizes(self.action_space)
         self.continuous = is_box(self.action_space)
