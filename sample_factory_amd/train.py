@@ -156,9 +156,12 @@ class Runner:
         """runner.py:497-501: config.json next to the checkpoints (what enjoy / resume read back)"""
         d = os.path.join(self.cfg.train_dir, self.cfg.experiment)
         os.makedirs(d, exist_ok=True)
+        out = {k: v for k, v in vars(self.cfg).items() if isinstance(v, (int, float, str, bool, list, type(None)))}
+        if getattr(self, "parallel_envs", None) is not None:  # the file keeps what the user asked for, not the internal
+            out["num_workers"], out["num_envs_per_worker"] = out.pop("env_workers"), out.pop("env_instances_per_worker")
+            out["worker_num_splits"] = int(getattr(self.cfg, "env_worker_splits_requested", out["worker_num_splits"]))
         with open(os.path.join(d, "config.json"), "w") as f:
-            json.dump({k: v for k, v in vars(self.cfg).items() if isinstance(v, (int, float, str, bool, list, type(None)))},
-                      f, indent=2)
+            json.dump(out, f, indent=2)
 
     def _read_ep_stats(self):
         """sum of {return, length, count} over the env instances since the last call, then reset — on the stream the
@@ -206,6 +209,7 @@ class Runner:
             self.envs = list(self.parallel_envs.views)
             # from here on: one "worker" whose env instances are the splits (slab rows, sampling units, streams follow)
             cfg.env_workers, cfg.env_instances_per_worker = int(cfg.num_workers), int(cfg.num_envs_per_worker)
+            cfg.env_worker_splits_requested = int(cfg.worker_num_splits)
             cfg.num_workers, cfg.num_envs_per_worker, cfg.worker_num_splits = 1, S, S
             E = S
         else:
