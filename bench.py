@@ -37,9 +37,9 @@ class ClockSampler:
     """Shader clock of this rank's GPU DURING the timed region: the roofline peak is priced at the 2.4 GHz maximum, the chip
     runs at its power budget (MI355X_MICROARCH.md, DVFS) — `roofline.clock_ghz` / `frac_at_measured_clock` say how much of the
     gap is clock.  Source: `sf_clock_probe`, a one-wave kernel that spins for 200 k shader cycles (~85 us) and counts the
-    ticks of the constant 100 MHz wall clock meanwhile.  The probes are ENQUEUED on a side stream from the timing loop
-    itself (one per step, at most 32; ~10 us of host time each, no thread: a sampling thread cost the launch-bound c5 loop
-    4 % through the GIL) and run beside whatever the measured stream is executing; read back after the region.
+    ticks of the constant 100 MHz wall clock meanwhile.  The probes are enqueued on a side stream during the plain warm-up
+    steps right before the timed region (same steady-state load; see the call site for why not inside it) and run beside
+    whatever the measured stream is executing; read back after the region.
     (amdgpu's pp_dpm_sclk reported 95 MHz and 2.39 GHz for the same workload on two boxes — not used.)"""
 
     MAX = 32
@@ -384,8 +384,17 @@ def main():
 
     # warm-up.  The last warm-up step is instrumented per launch (HIP events on the launch stream) to rank the network
     # kernels; inside the TIMED region only the dominant kernel keeps its events (timing every launch costs ~7 %).
+    # Shader-clock probes ride on the PLAIN warm-up steps (same steady-state load as the timed region, immediately before
+    # it): a probe is a kernel on another queue, and its launch / completion cache maintenance cost the L2-resident
+    # hand-offs of the recurrent c5 loop 5 % when probes ran inside the timed region (17.3 vs 16.4 ms per step, same box).
+    clk = ClockSampler() if (rank == 0 and os.environ.get("SF_CLOCK_PROBE", "1") != "0") else None
     for _ in range(max(0, args.warmup - 1)):
         runner.iteration()
+        if clk is not None:
+            for _p in range(4):
+                clk.probe()  # enqueued back to back on the side stream: they spread over the next step's kernels
+    if clk is not None and args.warmup < 2:
+        clk = None  # no plain warm-up step to probe in: roofline.clock_ghz stays null rather than perturbing the timed region
     warm_prof = None
     if args.warmup > 0:
         if not args.no_kernel_events:
@@ -415,13 +424,10 @@ def main():
     if args.workload == "c3":
         for sm in runner.samplers:
             sm.ingest_prof, sm.h2d_bytes = {}, 0
-    clk = ClockSampler() if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.iteration()
-        if clk is not None:
-            clk.probe()  # lands beside the next step's kernels
     barrier()
     dt = time.perf_counter() - t0
     clock = clk.stop() if clk is not None else None
