@@ -326,6 +326,11 @@ def main():
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
     ap.add_argument("--cpu_reference_envs", type=int, default=256,
                     help="trajectories of the sample the REFERENCE's CPU path is timed on (cpu_baseline kind 'reference')")
+    ap.add_argument("--event_stride", type=int, default=1,
+                    help="timed region: every k-th launch of the dominant kernel carries a HIP-event pair (1 = all of them, the "
+                         "default: a stride of 4 saved 0.2 ms per step but aliased with the 4 minibatches per step — every "
+                         "sample was the same minibatch, 1.44 vs 1.53 ms for the n = 32768 shape; use a stride coprime to 4 "
+                         "and 33 if at all)")
     ap.add_argument("--env_workers", type=int, default=4,
                     help="c3: env worker PROCESSES (algo/sampling/parallel_env.py); 0 = envs inside this process (sampler thread)")
     ap.add_argument("--env_instances", type=int, default=1,
@@ -417,6 +422,8 @@ def main():
             by_name[key[-1]] = by_name.get(key[-1], 0.0) + robust_total(evs)
         dominant = max(by_name, key=by_name.get)
         lib.PROFILE, lib.PROFILE_ONLY = {}, {key for key in warm_prof if key[-1] == dominant}
+        # optional subsampling of the event pairs (--event_stride k: every k-th launch of each shape; default 1 = all)
+        lib.PROFILE_STRIDE, lib.PROFILE_SEEN = max(1, int(args.event_stride)), {}
     env_steps0, rounds0 = runner.learner.env_steps, runner.sampling_rounds
     grp = getattr(runner.learner, "group", None)
     if world > 1 and grp is not None:
@@ -455,6 +462,7 @@ def main():
                   "obs_dma_from_worker_pages_in_place": direct_dma,
                   "dma_share_of_wall_clock": round(dma_ms * 1e-3 / dt, 4)}
     prof, lib.PROFILE, lib.PROFILE_ONLY = lib.PROFILE, None, None
+    seen, lib.PROFILE_STRIDE, lib.PROFILE_SEEN = dict(lib.PROFILE_SEEN), 1, {}
     collectives = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -493,15 +501,21 @@ def main():
     # ---- roofline of the dominant kernel instantiation (largest total time; HIP events over the timed region).
     # achieved = mean algorithmic FLOPs per launch / mean launch duration = sum(flops) / sum(duration) over its launches;
     # avg_launch_ms is directly comparable with AverageNs of the same name in profiles/r01_*_kernel_stats.csv
-    total_ms, launches, flops, shapes = 0.0, 0, 0.0, []
+    # per shape: mean duration of the TIMED launches (every event_stride-th) x ALL launches of that shape in the region
+    total_ms, launches, flops, shapes, timed = 0.0, 0, 0.0, [], 0
     for key, evs in prof.items():
         ms = [s_.elapsed_time(e_) for s_, e_ in evs]
-        total_ms += sum(ms)
-        launches += len(ms)
-        flops += kernel_flops(key) * len(ms)
-        shapes.append({"shape": f"{key[0]}:{key[2]}x{key[3]}->{key[5]} n={key[1]}", "launches": len(ms),
-                       "avg_ms": round(sum(ms) / len(ms), 4),
-                       "tflops": round(kernel_flops(key) / (sum(ms) / len(ms) * 1e-3) / 1e12, 1)})
+        n_all = int(seen.get(key, len(ms))) if len(ms) else 0
+        if not ms:
+            continue
+        avg = sum(ms) / len(ms)
+        total_ms += avg * n_all
+        launches += n_all
+        timed += len(ms)
+        flops += kernel_flops(key) * n_all
+        shapes.append({"shape": f"{key[0]}:{key[2]}x{key[3]}->{key[5]} n={key[1]}", "launches": n_all, "timed_launches": len(ms),
+                       "avg_ms": round(avg, 4),
+                       "tflops": round(kernel_flops(key) / (avg * 1e-3) / 1e12, 1)})
     shapes.sort(key=lambda d: -d["avg_ms"] * d["launches"])
     avg_ms = total_ms / launches
     achieved = flops / (total_ms * 1e-3) / 1e12
@@ -530,6 +544,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                "timed_launches": timed, "event_stride": int(args.event_stride),
                 "gflop_per_launch": round(flops / launches / 1e9, 3),
                 "share_of_step_time": round(total_ms / (dt * 1e3), 4), "shapes": shapes}
     if clock is not None:  # peak is priced at the 2.4 GHz maximum clock; the timed region ran at clock["ghz"] (median sample)
@@ -540,7 +555,7 @@ def main():
         roofline["clock_ghz"] = None
         roofline["clock_note"] = "no clock sample (sf_clock_probe): frac is priced at 2.4 GHz"
     if exact_bf16_kernel(dominant):  # HBM-bound kernel: algorithmic bytes per launch / launch duration against 8 TB/s
-        nbytes = sum(kernel_bytes(key) * len(evs) for key, evs in prof.items())
+        nbytes = sum(kernel_bytes(key) * int(seen.get(key, len(evs))) for key, evs in prof.items() if evs)
         gbs = nbytes / (total_ms * 1e-3) / 1e9
         roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(gbs / PEAK_HBM_GBS, 4), "gbytes_per_launch": round(nbytes / launches / 1e9, 4)})

@@ -61,10 +61,20 @@ PROFILE_SYNC = False  # ranking pass: drain the device before every timed launch
 #                       charged to whatever small kernel happens to be launched next)
 
 
+PROFILE_STRIDE = 1    # time every PROFILE_STRIDE-th launch of a key (bench.py's timed region: a HIP-event pair costs ~19 us of
+#                       step time per timed launch; the average over a regular subsample is the same measurement)
+PROFILE_SEEN: dict = {}  # key -> launches seen so far (timed or not)
+
+
 class _timed:
     def __init__(self, key):
         self.key = key if PROFILE is not None and key is not None and \
             (PROFILE_ONLY is None or key in PROFILE_ONLY) else None
+        if self.key is not None and PROFILE_STRIDE > 1:
+            seen = PROFILE_SEEN.get(self.key, 0)
+            PROFILE_SEEN[self.key] = seen + 1
+            if seen % PROFILE_STRIDE:
+                self.key = None
 
     def __enter__(self):
         if self.key is not None:
