@@ -490,7 +490,8 @@ def main():
 
     if not prof:
         if rank == 0:
-            print(json.dumps({"metric": metric, "value": round(value, 1), "unit": "env-steps/s",
+            print(json.dumps({"metric": metric, "value": round(value, 1), "unit": "env-steps/s", "steps": args.steps,
+                              "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "data": "synthetic",
                               "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": world, "rccl_ranks": rccl_ranks,
                               "rank_devices": rank_devices, "config": {"workload": workload_desc},
                               **({"collectives": collectives} if collectives else {}),
