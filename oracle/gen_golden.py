@@ -811,7 +811,8 @@ class ScriptedBatchedEnv(gym.Env):
 
 
 def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, reward_clip, async_rl, seed,
-                     num_policies=1, worker_idx=0, gpu_actions=False):
+                     num_policies=1, worker_idx=0, gpu_actions=False, action_kind="discrete"):
+    # action_kind: "discrete" = Discrete(A); "tuple" = Tuple(Discrete(n) for n in A); "box" = Box(A) (2*A action parameters)
     """Drive the reference's BatchedVectorEnvRunner (batched_sampling.py:85-392: init, update_trajectory_buffers,
     generate_policy_request, advance_rollouts, _process_rewards, _process_env_step, _finalize_trajectories) for
     n_rollouts consecutive rollouts with a scripted env and scripted policy outputs; dump the slab rows it wrote."""
@@ -844,7 +845,15 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
         term[T, -1] = True                          # and at t = 0 of the second
     script.update(rew=rew, term=term, trunc=trunc)
     obs_space = gym.spaces.Dict(spaces_)
-    action_space = gym.spaces.Discrete(A)
+    if action_kind == "tuple":
+        action_space = gym.spaces.Tuple([gym.spaces.Discrete(int(n_)) for n_ in A])
+        heads, A = [int(n_) for n_ in A], int(sum(A))
+    elif action_kind == "box":
+        action_space = gym.spaces.Box(-1.0, 1.0, (int(A),), np.float32)
+        heads, A = [], 2 * int(A)
+    else:
+        action_space = gym.spaces.Discrete(A)
+        heads = [int(A)]
 
     rnn_args = ["--use_rnn=False"] if rnn is None else ["--use_rnn=True", f"--rnn_type={rnn[0]}", f"--rnn_size={rnn[1]}"]
     argv = ["--algo=APPO", f"--env=scripted_{name}", "--experiment=golden", "--train_dir=/tmp/sf_golden", "--device=cpu",
@@ -876,10 +885,18 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
     # scripted policy outputs (what InferenceWorker._prepare_policy_outputs_batched scatters into policy_output_tensors,
     # inference_worker.py:235-269): deterministic actions = argmax of the logits (action_distributions.py:73-81)
     logits = (rng.standard_normal((steps, B, A)) * 1.5).astype(np.float32)
+    if action_kind == "box":
+        logits[..., A // 2:] = logits[..., A // 2:] * 0.3 - 0.5   # log-stddevs
     tl = torch.from_numpy(logits)
-    dist = CategoricalActionDistribution(tl.reshape(-1, A))
-    acts = torch.argmax(tl, dim=-1)
-    logp = dist.log_prob(acts.reshape(-1, 1)).reshape(steps, B).numpy()
+    from sample_factory.algo.utils.action_distributions import argmax_actions
+    dist = get_action_distribution(action_space, tl.reshape(-1, A))
+    if action_kind == "tuple":  # per-head arg-max (TupleActionDistribution.argmax is written for ONE sample: enjoy.py)
+        acts = torch.stack([argmax_actions(d_) for d_ in dist.distributions], dim=1)
+    else:
+        acts = argmax_actions(dist)                  # deterministic actions (action_distributions.py:73-81)
+    acts = acts.reshape(steps * B, -1)               # [N, num_actions] as the actor-critic stores them
+    logp = dist.log_prob(acts if action_kind != "discrete" else acts.reshape(-1, 1)).reshape(steps, B).numpy()
+    acts = acts.reshape(steps, B, -1)
     values = rng.standard_normal((steps, B)).astype(np.float32)
     new_rnn = (rng.standard_normal((steps, B, R)) * 0.7).astype(np.float32)
     if rnn is None:  # ModelCoreIdentity hands the (zero) width-1 dummy state through (model/core.py:67-77)
@@ -899,7 +916,7 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
             # what the inference worker would read for this request (inference_worker.py:183-205)
             seen_obs.append({key: v[sl, t].numpy().copy() for key, v in slab["obs"].items()})
             seen_rnn.append(slab["rnn_states"][sl, t].numpy().copy())
-            po["actions"].copy_(acts[k].float().unsqueeze(-1))
+            po["actions"].copy_(acts[k].float())
             po["action_logits"].copy_(tl[k])
             po["log_prob_actions"].copy_(torch.from_numpy(logp[k]))
             po["values"].copy_(torch.from_numpy(values[k]))
@@ -927,8 +944,13 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
                   obs_keys=np.asarray(sorted(obs_spec.keys())),
                   env_config=np.asarray([env_box["env_config"][q] for q in ("worker_index", "vector_index", "env_id")]),
                   in_rew=rew, in_term=term, in_trunc=trunc, in_logits=logits, in_values=values, in_new_rnn=new_rnn,
-                  in_versions=versions, ref_logp=logp, ref_actions=acts.numpy(),
-                  env_seen_actions=np.stack([a[0] for a in env_box["env"].seen_actions]),
+                  in_versions=versions, ref_logp=logp,
+                  ref_actions=acts.numpy() if action_kind != "discrete" else acts.numpy()[..., 0],
+                  action_kind=action_kind, head_sizes=np.asarray(heads, np.int64),
+                  # what env.step received (preprocess_actions): one array for Discrete / Box, a LIST of per-head arrays for
+                  # a Tuple space -> stacked here as [steps, heads, B]
+                  env_seen_actions=np.stack([np.stack(a) if len(a) > 1 else a[0] for a in env_box["env"].seen_actions]),
+                  env_seen_is_list=bool(len(env_box["env"].seen_actions[0]) > 1),
                   env_seen_actions_dtype=str(env_box["env"].seen_actions[0][0].dtype),
                   final_ep_reward=runner.curr_episode_reward.numpy(), final_ep_len=runner.curr_episode_len.numpy(),
                   final_last_rnn=runner.last_rnn_state.numpy())
@@ -965,6 +987,10 @@ def gen_rollout():
                      reward_clip=5.0, async_rl=True, seed=503, gpu_actions=True)
     gen_rollout_case("u8_image", B=8, T=4, n_rollouts=2, obs_spec={"obs": ((4, 12, 12), np.uint8)}, A=6, rnn=None,
                      reward_scale=0.01, reward_clip=0.02, async_rl=True, seed=504)
+    gen_rollout_case("tuple_heads", B=12, T=6, n_rollouts=2, obs_spec=vec, A=(3, 4), rnn=None, reward_scale=1.0,
+                     reward_clip=1000.0, async_rl=False, seed=506, action_kind="tuple")
+    gen_rollout_case("box_actions", B=12, T=6, n_rollouts=2, obs_spec=vec, A=3, rnn=("gru", 8), reward_scale=1.0,
+                     reward_clip=1000.0, async_rl=False, seed=507, action_kind="box", gpu_actions=True)
     gen_rollout_case("multikey_policy1", B=8, T=5, n_rollouts=2,
                      obs_spec={"obs": ((7,), np.float32), "aux": ((2, 3, 3), np.uint8)}, A=3, rnn=("gru", 8),
                      reward_scale=1.0, reward_clip=1.0, async_rl=False, seed=505, num_policies=2, worker_idx=1)

@@ -77,13 +77,15 @@ class _Shm:
 
 def _format_actions(act_rows: np.ndarray, heads: List[int], continuous: bool, batched: bool):
     """what `preprocess_actions` hands the env (batched_sampling.py:30-82): int32, the action axis squeezed for ONE Discrete
-    head; Tuple spaces get a list of per-head arrays; a single-agent env gets its agent's action without the agent axis"""
+    head; an all-Discrete Tuple space gets the [agents, heads] int32 array (the `all_discrete` branch — pinned by
+    tests/golden/rollout_tuple_heads.npz); a single-agent env gets its agent's row without the agent axis
+    (make_env.py:97-99)"""
     if continuous:
         a = act_rows.astype(np.float32, copy=False)
         return a if batched else a[0]
     if len(heads) > 1:
         a = act_rows.reshape(act_rows.shape[0], len(heads))
-        return [a[:, h].copy() for h in range(len(heads))] if batched else [int(v) for v in a[0]]
+        return a if batched else a[0]
     a = act_rows.reshape(-1)
     return a if batched else int(a[0])
 

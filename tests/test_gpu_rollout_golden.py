@@ -26,7 +26,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1"]
+CASES = ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1", "tuple_heads", "box_actions"]
 
 
 def _spaces(g):
@@ -36,7 +36,14 @@ def _spaces(g):
         a = g[f"in_obs_{key}"]
         obs[key] = spaces.Box(0, 255, a.shape[2:], np.uint8) if a.dtype == np.uint8 else \
             spaces.Box(-10, 10, a.shape[2:], np.float32)
-    return spaces.Dict(obs), spaces.Discrete(int(g["A"]))
+    kind = str(g["action_kind"]) if "action_kind" in g.files else "discrete"
+    if kind == "tuple":
+        act = spaces.Tuple([spaces.Discrete(int(n)) for n in g["head_sizes"]])
+    elif kind == "box":
+        act = spaces.Box(-1.0, 1.0, (int(g["A"]) // 2,), np.float32)
+    else:
+        act = spaces.Discrete(int(g["A"]))
+    return spaces.Dict(obs), act
 
 
 class ScriptedEnv:
@@ -165,8 +172,10 @@ def test_rollout_slab_equals_the_reference(golden, case, host_env, native_state)
                 want, got = want[:, :T], got[:, :T]
             if name == "valids":            # written by the learner (learner.py:950-955)
                 continue
-            if name == "log_prob_actions":
-                np.testing.assert_allclose(got, want, rtol=0, atol=1e-6, err_msg=f"{case} rollout {r} {name}")
+            if name == "log_prob_actions":  # log-softmax / Normal log-density: expf / logf vs torch's, summed over the heads
+                kind_ = str(g["action_kind"]) if "action_kind" in g.files else "discrete"
+                tol = dict(discrete=1e-6, tuple=2e-6, box=5e-6)[kind_]
+                np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=f"{case} rollout {r} {name}")
             else:
                 assert got.dtype == want.dtype or name.startswith("obs_"), (name, got.dtype, want.dtype)
                 np.testing.assert_array_equal(got, want, err_msg=f"{case} rollout {r} {name}")
@@ -179,11 +188,17 @@ def test_rollout_slab_equals_the_reference(golden, case, host_env, native_state)
         if rnn_type:
             np.testing.assert_array_equal(policy.seen_rnn[kk].cpu().numpy(), g[f"seen_rnn_{kk}"],
                                           err_msg=f"policy input rnn state step {kk}")
-    # ---- the env was stepped with the reference's actions (int32, [B] for one Discrete head)
+    # ---- the env was stepped with what the reference's preprocess_actions handed ITS env (batched_sampling.py:30-82):
+    # int32 [B] for one Discrete head, int32 [B, heads] for an all-Discrete Tuple, f32 [B, D] for a Box
     seen = np.stack(env.seen_actions)
-    assert seen.dtype == np.int32 and str(g["env_seen_actions_dtype"]) == "int32"
-    np.testing.assert_array_equal(seen, g["env_seen_actions"])
-    np.testing.assert_array_equal(seen, g["ref_actions"])
+    assert str(seen.dtype) == str(g["env_seen_actions_dtype"]) and seen.shape == g["env_seen_actions"].shape
+    kind = str(g["action_kind"]) if "action_kind" in g.files else "discrete"
+    if kind == "box":  # deterministic: the means, bit for bit
+        np.testing.assert_array_equal(seen, g["env_seen_actions"])
+        np.testing.assert_array_equal(seen, g["in_logits"][..., :seen.shape[-1]])
+    else:
+        np.testing.assert_array_equal(seen, g["env_seen_actions"])
+        np.testing.assert_array_equal(seen, g["ref_actions"])
     # ---- episode statistics (raw rewards, batched_sampling.py:215-287)
     st = runner.ep_stats.cpu().numpy()
     assert st[2] == len(g["ep_reward"]) and st[1] == g["ep_len"].astype(np.int64).sum()

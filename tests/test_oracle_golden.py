@@ -233,7 +233,8 @@ def test_float64_anchor_of_the_train_replays(golden, name, ref_bound):
         assert "relu_pos64" not in g.files  # tanh network: no kinks to count
 
 
-@pytest.mark.parametrize("case", ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1"])
+@pytest.mark.parametrize("case", ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1", "tuple_heads",
+                                  "box_actions"])
 def test_rollout_restatement_equals_the_reference_runner(golden, case):
     """oracle.rollout_replay (numpy) against slab rows written by the reference's BatchedVectorEnvRunner
     (tests/golden/rollout_*.npz, oracle/gen_golden.py gen_rollout_case): bit-equal"""
@@ -249,10 +250,29 @@ def test_rollout_restatement_equals_the_reference_runner(golden, case):
             np.testing.assert_array_equal(cur[name], g[f"out{r}_{name}"], err_msg=f"rollout {r} {name}")
         np.testing.assert_array_equal(cur["obs"], g[f"out{r}_obs_{key}"])
         assert (g[f"out{r}_policy_id"] == int(g["policy_id"])).all()
-        np.testing.assert_array_equal(g[f"out{r}_actions"][..., 0], g["ref_actions"][r * T:(r + 1) * T].T.astype(np.float32))
+        kind = str(g["action_kind"]) if "action_kind" in g.files else "discrete"
+        ra = g["ref_actions"][r * T:(r + 1) * T]                           # [T, B] or [T, B, num_actions]
+        if kind == "discrete":
+            np.testing.assert_array_equal(g[f"out{r}_actions"][..., 0], ra.T.astype(np.float32))
+        else:  # every policy output is stored as f32 [B, T, num_actions] (shared_buffers.py:100-103)
+            np.testing.assert_array_equal(g[f"out{r}_actions"], ra.transpose(1, 0, 2).astype(np.float32))
         np.testing.assert_array_equal(g[f"out{r}_action_logits"], g["in_logits"][r * T:(r + 1) * T].transpose(1, 0, 2))
         np.testing.assert_array_equal(g[f"out{r}_policy_version"], np.broadcast_to(g["in_versions"][r * T:(r + 1) * T], g[f"out{r}_policy_version"].shape))
     for k in ("ep_reward", "ep_len", "final_ep_reward", "final_ep_len", "final_last_rnn"):
         np.testing.assert_array_equal(st[k], g[k], err_msg=k)
-    _, la, _ = oracle.categorical(g["in_logits"].reshape(-1, int(g["A"])), g["ref_actions"].reshape(-1))
-    np.testing.assert_allclose(la.reshape(g["ref_logp"].shape), g["ref_logp"], atol=1e-6)
+    if kind == "discrete":
+        _, la, _ = oracle.categorical(g["in_logits"].reshape(-1, int(g["A"])), g["ref_actions"].reshape(-1))
+        np.testing.assert_allclose(la.reshape(g["ref_logp"].shape), g["ref_logp"], atol=1e-6)
+    elif kind == "tuple":  # independent heads: the log-probabilities add up (action_distributions.py:231-243)
+        la, o = 0.0, 0
+        for h, n in enumerate(int(v) for v in g["head_sizes"]):
+            la = la + oracle.categorical(g["in_logits"][..., o:o + n].reshape(-1, n), g["ref_actions"][..., h].reshape(-1))[1]
+            o += n
+        np.testing.assert_allclose(la.reshape(g["ref_logp"].shape), g["ref_logp"], atol=2e-6)
+        # what the env was handed: the [B, heads] int32 array itself (preprocess_actions' all_discrete branch)
+        assert not bool(g["env_seen_is_list"]) and g["env_seen_actions"].shape[1:] == g["ref_actions"].shape[1:]
+    else:  # Box: deterministic action = the mean, log-density of a diagonal normal at its mean
+        D = int(g["A"]) // 2
+        np.testing.assert_array_equal(g["ref_actions"], g["in_logits"][..., :D])
+        sd = np.clip(np.exp(g["in_logits"][..., D:].astype(np.float64)), 1e-4, 1e4)
+        np.testing.assert_allclose((-np.log(sd) - 0.5 * np.log(2 * np.pi)).sum(-1), g["ref_logp"], atol=1e-5)
