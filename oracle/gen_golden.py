@@ -1061,6 +1061,8 @@ def main():
                   extra=["--lr_schedule=kl_adaptive_minibatch", "--lr_schedule_kl_threshold=1e-7", "--learning_rate=1e-3"])
         gen_train("mlp_klmb_up", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=2,
                   extra=["--lr_schedule=kl_adaptive_minibatch", "--lr_schedule_kl_threshold=10.0", "--learning_rate=1e-4"])
+        gen_train("mlp_klep", MLP_OBS, MLP_ARGS, E=16, T=8, A=6, nb=2, epochs=3,   # per-EPOCH KL-adaptive schedule
+                  extra=["--lr_schedule=kl_adaptive_epoch", "--lr_schedule_kl_threshold=1e-7", "--learning_rate=1e-3"])
     if "separate" in which:
         gen_model_fwd_separate()
     if "separate" in which or "train" in which:  # ActorCriticSeparateWeights through the reference's Learner.train

@@ -557,7 +557,7 @@ def test_learner_train_matches_reference_cnn36(lib, golden, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["mlp", "mlp_inv", "mlp_lamb", "mlp_nonadaptive", "mlp_nonadaptive_tanh", "mlp_klmb_down",
-                                  "mlp_klmb_up"])
+                                  "mlp_klmb_up", "mlp_klep"])
 def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
     """vector-observation MLP encoder with tanh (the reference's Mujoco-style model), 2 epochs / KL loss / invalid rows:
     full Learner.train vs the reference's post-training state (train_mlp*.npz)."""
@@ -573,10 +573,11 @@ def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
                       rollout=T, batch_size=E * T // nb, num_batches_per_epoch=nb, num_epochs=int(g["num_epochs"]),
                       kl_loss_coeff=kl, seed=0, serial_mode=True, train_dir=str(tmp_path), experiment="t",
                       record_grad_norm=True, optimizer="lamb" if "optimizer=lamb" in str(g["argv"]) else "adam")
-    if "klmb" in name:  # lr_schedule=kl_adaptive_minibatch (learner.py:46-85): the rate changes after EVERY SGD step — here
-        # on the device (sf_lr_kl_adaptive + sf_adam_step_dlr), no read-back between the steps
+    if "klmb" in name or "klep" in name:  # KL-adaptive schedules (learner.py:46-85): per minibatch the rate changes after EVERY
+        # SGD step — here on the device (sf_lr_kl_adaptive + sf_adam_step_dlr), no read-back between the steps; per epoch it
+        # changes with the epoch's read-back
         argv = dict(a.lstrip("-").split("=") for a in str(g["argv"]).split() if "=" in a)
-        cfg.lr_schedule, cfg.lr_schedule_kl_threshold = "kl_adaptive_minibatch", float(argv["lr_schedule_kl_threshold"])
+        cfg.lr_schedule, cfg.lr_schedule_kl_threshold = argv["lr_schedule"], float(argv["lr_schedule_kl_threshold"])
         cfg.learning_rate = float(argv["learning_rate"])
     obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
     action_space = spaces.Discrete(A)
@@ -604,8 +605,8 @@ def test_learner_train_matches_reference_mlp(lib, golden, tmp_path, name):
     np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=3e-4)
     np.testing.assert_allclose(ac.returns_normalizer.stats.cpu().numpy(), g["out_rms"], rtol=1e-5)
     compare_post_train(learner, g, before, name, **TIGHT)
-    if "klmb" in name:
-        assert hasattr(learner, "_lr_dev"), "the schedule ran on the device"
+    if "klmb" in name or "klep" in name:
+        assert hasattr(learner, "_lr_dev") == ("klmb" in name), "the per-minibatch schedule (and only it) runs on the device"
         np.testing.assert_allclose(learner.curr_lr, float(g["curr_lr"]), rtol=1e-6)
         assert abs(learner.curr_lr / cfg.learning_rate - 1.0) > 0.5   # the schedule moved the rate (x 1.5^4 or / 1.5^4)
 
