@@ -58,6 +58,14 @@ class _Shm:
         self.owner = name is None
         self.shm = shared_memory.SharedMemory(create=True, size=nbytes) if name is None else \
             shared_memory.SharedMemory(name=name)
+        if not self.owner:
+            # Python < 3.13 registers ATTACHED segments with the resource tracker too, which then unlinks them when the
+            # attaching process exits (bpo-38119): the owner (main process) is the only one that may unlink
+            try:
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self.shm._name, "shared_memory")
+            except Exception:  # noqa: BLE001
+                pass
         self.array = np.ndarray(self.shape, dtype=self.dtype, buffer=self.shm.buf)
         if self.owner:
             self.array.fill(0)
@@ -350,8 +358,15 @@ class ParallelHostEnvs:
             return
         timeout = float(getattr(self.cfg, "env_worker_step_timeout", 600.0))
         for w in range(self.num_workers):
-            if not self._done[w][split].acquire(timeout=timeout):
-                raise RuntimeError(f"env worker {w} did not answer within {timeout} s")
+            waited = 0.0
+            while not self._done[w][split].acquire(timeout=1.0):  # short waits: notice a worker that died without a word
+                waited += 1.0
+                if not self._procs[w].is_alive():
+                    self.close()
+                    raise RuntimeError(f"env worker {w} exited (exit code {self._procs[w].exitcode}) while stepping")
+                if waited >= timeout:
+                    self.close()
+                    raise RuntimeError(f"env worker {w} did not answer within {timeout} s")
             if self._conns[w].poll(0):
                 msg = self._conns[w].recv()
                 if msg[0] == "error":

@@ -258,7 +258,11 @@ class Runner:
         self.sampler = self.samplers[0]
         self._prev_rows: List = [None] * E          # slab view each env instance wrote its previous rollout into
         S = max(1, min(int(cfg.worker_num_splits), E))
-        self.split_streams = [torch.cuda.Stream() for _ in range(S)] if E > 1 else None
+        # async mode: the sampling streams get the HIGH hardware-queue priority — a rollout step is a chain of small,
+        # latency-critical launches (the env waits for its actions) that otherwise queue behind the learner's chip-filling
+        # kernels (SF_ROLLOUT_PRIORITY=0: default priority)
+        prio = -1 if (cfg.async_rl and os.environ.get("SF_ROLLOUT_PRIORITY", "1") != "0") else 0
+        self.split_streams = [torch.cuda.Stream(priority=prio) for _ in range(S)] if E > 1 else None
         self._ev_fork = torch.cuda.Event()
         self._ev_join = [torch.cuda.Event() for _ in range(S)]
         self._training_info_ifaces = [find_training_info_interface(env) for env in self.envs]
@@ -268,7 +272,7 @@ class Runner:
         self._free_events: Dict[int, torch.cuda.Event] = {}    # sampling slice start -> "learner done with rows" event
         self.sampling_rounds = 0
         if cfg.async_rl:  # rollouts overlap Learner.train: second stream, published weight snapshots
-            self.rollout_stream = torch.cuda.Stream()
+            self.rollout_stream = torch.cuda.Stream(priority=prio)
             self.ev_publish = torch.cuda.Event()
             self.learner.actor_critic.enable_weight_snapshots()
             self._pub_slot = 0                      # snapshot slot holding the most recently published weights
