@@ -189,3 +189,30 @@ def test_inline_mode_wraps_single_agent_gym_envs_like_the_reference():
             assert te[i] == t1 and tr[i] == t2 and r[i] == rr
     assert resets >= 5
     penv.close()
+
+
+class _DyingEnv(CountingEnv):
+    def step(self, action):
+        if self.t >= 2:
+            import os
+            os._exit(7)  # the simulator takes the whole process down (no exception, no message)
+        return super().step(action)
+
+
+def make_dying_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    import multiprocessing
+    return _DyingEnv(env_config.env_id) if multiprocessing.current_process().name.startswith("sf-env-worker") \
+        else CountingEnv(env_config.env_id)
+
+
+def test_a_worker_that_dies_silently_is_noticed():
+    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
+    cfg = default_cfg(env="dying", seed=0)
+    penv = ParallelHostEnvs(cfg, "dying", make_dying_env, 1, 1)
+    v = penv.views[0]
+    v.reset()
+    a = np.zeros(1, np.int32)
+    v.step(a)
+    v.step(a)
+    with pytest.raises(RuntimeError, match="exited"):
+        v.step(a)
