@@ -258,10 +258,9 @@ class Runner:
         self.sampler = self.samplers[0]
         self._prev_rows: List = [None] * E          # slab view each env instance wrote its previous rollout into
         S = max(1, min(int(cfg.worker_num_splits), E))
-        # async mode: the sampling streams get the HIGH hardware-queue priority — a rollout step is a chain of small,
-        # latency-critical launches (the env waits for its actions) that otherwise queue behind the learner's chip-filling
-        # kernels (SF_ROLLOUT_PRIORITY=0: default priority)
-        prio = -1 if (cfg.async_rl and os.environ.get("SF_ROLLOUT_PRIORITY", "1") != "0") else 0
+        # SF_ROLLOUT_PRIORITY=1 (async mode): sampling streams on the HIGH hardware-queue priority.  Off by default: over
+        # 3 x 100-step alternations on the host-env line it measured 478 vs 488 k env-steps/s (profiles/r04_d_c3_priority_ab*).
+        prio = -1 if (cfg.async_rl and os.environ.get("SF_ROLLOUT_PRIORITY", "0") == "1") else 0
         self.split_streams = [torch.cuda.Stream(priority=prio) for _ in range(S)] if E > 1 else None
         self._ev_fork = torch.cuda.Event()
         self._ev_join = [torch.cuda.Event() for _ in range(S)]
