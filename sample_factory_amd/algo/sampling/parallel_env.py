@@ -237,6 +237,7 @@ class ParallelHostEnvs:
         assert envs_per_worker % num_splits == 0, f"{envs_per_worker=} must be a multiple of {num_splits=}"
         self.cfg, self.num_workers, self.envs_per_worker, self.num_splits = cfg, num_workers, envs_per_worker, num_splits
         self._closed, self._conns, self._procs, self._shms = False, [], [], []
+        self._registered: List[int] = []  # page-locked base addresses (register_with_device), unregistered in close()
         # ---- probe ONE instance here for spaces / agents per instance (the reference spawns a process for this,
         # env_info.py:81-127; the instance is closed again before the workers start)
         probe = make_env_func(env_name, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0), None)
@@ -339,6 +340,7 @@ class ParallelHostEnvs:
                         err = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
                         if int(err) != 0:
                             return False
+                        self._registered.append(int(a.ctypes.data))
             for v in self.views:
                 v.pages_registered = True
             return True
@@ -388,6 +390,17 @@ class ParallelHostEnvs:
             p.join(timeout=5.0)
             if p.is_alive():
                 p.terminate()
+        if self._registered:  # the pages must leave the HIP runtime's tables before they are unmapped
+            try:
+                import torch
+                rt = torch.cuda.cudart()
+                for ptr in self._registered:
+                    rt.cudaHostUnregister(ptr)
+            except Exception:  # noqa: BLE001 - best effort at shutdown
+                pass
+            self._registered = []
+        for v in getattr(self, "views", []):
+            v.pages_registered = False
         for s in self._shms:
             s.close()
 
