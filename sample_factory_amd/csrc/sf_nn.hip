@@ -1004,9 +1004,11 @@ static bool glds_fwd_ok(const sf_conv_desc *d) {
 // A wide layer with a long reduction and too few rows to fill the chip (the fc layer of a rollout step: 4096 x 512,
 // K = 3136 -> 128 tiles of 128x128) is split along K so that ~2 blocks land on every CU; the slices go through
 // k_splitk_finish (ascending z: deterministic).  Measured at n = 4096: register-staged split-K kernel 140 us, this
-// plan 4 x 128 blocks.
+// plan 4 x 128 blocks 127 + 10 us.  Where 64x64 tiles alone give two work-groups per CU (>= 512 tiles: exactly that fc
+// launch) the reduction runs unsplit on k_fwd_glds<64, 64>: 118-121 us and no partial sums (step -0.4 ms, three
+// alternations on one box, profiles/r04_d_fc64_ab.log; 128x64 tiles x 2 slices and a third pipeline stage: +-0).  SF_GLDS_FC64=0: the split plan.
 struct GldsFwdPlan {
-    bool ok, wide;
+    bool ok, wide, sq64;  // sq64: 64x64 tiles, unsplit
     int Z, k_per_split;
 };
 static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
@@ -1014,7 +1016,8 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     static const int split_on = getenv("SF_GLDS_SPLITK") ? atoi(getenv("SF_GLDS_SPLITK")) : 1;
     static const int occ64 = occupancy_of(k_fwd_glds<128, 64, 2, 2, 2>), occ128 = occupancy_of(k_fwd_glds<128, 128, 2, 2, 2>);
     GldsFwdPlan p;
-    p.ok = false; p.wide = false; p.Z = 1; p.k_per_split = (K + 31) / 32 * 32;
+    p.ok = false; p.wide = false; p.sq64 = false; p.Z = 1; p.k_per_split = (K + 31) / 32 * 32;
+    static const int fc64 = getenv("SF_GLDS_FC64") ? atoi(getenv("SF_GLDS_FC64")) : 1;
     const int64_t t64 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 64), t128 = cdiv64(Mtot, 128) * (int64_t)cdiv64(N, 128);
     // (wide outputs of moderate height — the recurrent projection of one rollout step, 2048 x 512 x 2048: 512 tiles,
     //  two per CU — also beat the register-staged kernel: 75 -> measured in profiles/r02_c5_*; the GRU's 2048 x 512 x
@@ -1028,6 +1031,10 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
             p.wide = e128 * 1.03 >= e64;  // 64x64 wave tiles: fewer LDS reads and DMA instructions per MFMA
         }
         if (cfg == 2) p.wide = true;
+        return p;
+    }
+    if (fc64 == 1 && N >= 128 && K >= 1024 && cdiv64(Mtot, 64) * (int64_t)cdiv64(N, 64) >= 512) {
+        p.ok = true; p.sq64 = true;  // two 64x64 work-groups per CU, the whole reduction in one pass, no partial sums
         return p;
     }
     if (split_on && N >= 128 && K >= 1024 && t128 >= 32) {
@@ -1122,7 +1129,8 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
         partial = reinterpret_cast<float *>(workspace);
     }
     hipStream_t st = STREAM(stream);
-    if (p.wide) GLDS_FWD(128, 128, 2, 2, 2);
+    if (p.sq64) GLDS_FWD(64, 64, 2, 2, 2);
+    else if (p.wide) GLDS_FWD(128, 128, 2, 2, 2);
     else GLDS_FWD(128, 64, 2, 2, 2);
     if (partial) {
         const int64_t MN = Mtot * g.Cout;
@@ -1530,7 +1538,10 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
     } else if (op == 3) {
         if (narrow_fwd_ok(h_desc, n)) snprintf(out, cap, "k_linear_narrow<%d>", g.Cout <= 16 ? 1 : 2);
         else if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1, %d>", g.Cin, g.H, g.W, g.KH, g.S, g.OH);
-        else snprintf(out, cap, plan_fwd_t(Mtot, g.Cout, g.K).wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
+        else {
+            const GldsFwdPlan q = plan_fwd_t(Mtot, g.Cout, g.K);
+            snprintf(out, cap, q.sq64 ? "k_fwd_glds<64, 64, 2, 2, 2>" : q.wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
+        }
     } else if (op == 1 && small_linear_wgrad_ok(h_desc)) {
         snprintf(out, cap, "k_linear_wgrad_small");
     } else if (op == 1 && conv1_img_ok(g, mode, n) && g.Cout == 32) {

@@ -116,12 +116,13 @@ def fwd_t_ws(lib, n, d):
     return torch.empty(nb, dtype=torch.uint8, device="cuda") if nb else None
 
 
-@pytest.mark.parametrize("geom,n,act", [((3136, 1, 1, 512, 1, 1), 4096, 1), ((1024, 1, 1, 200, 1, 1), 4001, 2),
+@pytest.mark.parametrize("geom,n,act", [((3136, 1, 1, 512, 1, 1), 2048, 1), ((1024, 1, 1, 200, 1, 1), 4001, 2),
                                         ((64, 5, 5, 136, 5, 1), 4500, 1), ((1056, 1, 1, 128, 1, 1), 8200, 0)])
 def test_glds_fwd_splitk_small_grids_vs_torch(lib, geom, n, act):
-    """wide layer, long reduction, too few rows to fill the chip (the fc layer of a rollout step): sf_conv_fwd_t splits
-    along K into workspace slices + k_splitk_finish.  Ragged row tile, Cout not a multiple of 128, K slices of unequal
-    length, ReLU / tanh / no activation in the finisher; missing workspace must fail loudly."""
+    """wide layer, long reduction, too few rows to fill the chip: sf_conv_fwd_t splits along K into workspace slices +
+    k_splitk_finish.  Ragged row tile, Cout not a multiple of 128, K slices of unequal length, ReLU / tanh / no activation
+    in the finisher; missing workspace must fail loudly.  (The fc layer of a 4096-env rollout step has >= 512 tiles of
+    64x64 and runs unsplit: next test.)"""
     Cin, H, W, Cout, K, S = geom
     g = torch.Generator().manual_seed(Cin + n)
     x = torch.randn((n, Cin, H, W), generator=g)
@@ -146,6 +147,30 @@ def test_glds_fwd_splitk_small_grids_vs_torch(lib, geom, n, act):
     out2 = torch.empty_like(out)
     lib.conv_fwd_t(x_dev, Cin * H * W, wt, b.cuda(), out2, n, d, fwd_t_ws(lib, n, d))
     assert torch.equal(out, out2), "slices are added in a fixed order: bit-reproducible"
+
+
+@pytest.mark.parametrize("n,cout,act", [(4096, 512, 1), (4100, 520, 2), (5000, 448, 0)])
+def test_glds_fwd_64x64_unsplit_fc_of_a_rollout_step_vs_torch(lib, n, cout, act):
+    """the fc layer of a rollout step (4096 x 3136 -> 512): 512 tiles of 64x64 = two work-groups per CU, whole reduction
+    in one pass on k_fwd_glds<64, 64> — no workspace, no partial sums; ragged row / column tiles"""
+    Cin = 3136
+    g = torch.Generator().manual_seed(n + cout)
+    x = torch.randn((n, Cin), generator=g)
+    d = desc(lib, Cin, 1, 1, cout, 1, 1)
+    d.relu = act
+    w_ref = torch.randn((cout, Cin), generator=g) / np.sqrt(Cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    assert lib.conv_fwd_t_supported(n, d)
+    assert lib.conv_kernel_name(3, n, d) == "k_fwd_glds<64, 64, 2, 2, 2>", lib.conv_kernel_name(3, n, d)
+    assert lib.conv_fwd_t_workspace(n, d) == 0
+    out = torch.full((n, cout), 7.0, device="cuda")
+    lib.conv_fwd_t(x.cuda(), Cin, w_ref.cuda().contiguous(), b.cuda(), out, n, d, None)
+    pre = x.double() @ w_ref.double().t() + b.double()
+    ref = torch.relu(pre) if act == 1 else torch.tanh(pre) if act == 2 else pre
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    out2 = torch.empty_like(out)
+    lib.conv_fwd_t(x.cuda(), Cin, w_ref.cuda().contiguous(), b.cuda(), out2, n, d, None)
+    assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("geom,n", [((32, 20, 20, 64, 4, 2), 2500), ((64, 9, 9, 64, 3, 1), 2500),
