@@ -614,7 +614,8 @@ def test_tanh_scale_fwd_bwd_vs_torch(lib):
 
 
 @pytest.mark.parametrize("Cn,R,H", [(512, 6, 512), (200, 4, 512), (2048, 3, 512), (16, 5, 512), (512, 5, 256),
-                                    (200, 3, 256), (2048, 2, 256), (1024, 3, 512), (1000, 3, 256)])
+                                    (200, 3, 256), (2048, 2, 256), (1024, 3, 512), (1000, 3, 256),
+                                    (256, 4, 512), (384, 33, 512)])  # (two-groups-per-work-group forward: 4 / 6 pairs)
 def test_fused_lstm_sequence_passes_vs_torch_fp64(lib, Cn, R, H):
     """sf_lstm_seq_fwd / sf_lstm_seq_bwd (ONE persistent launch per BPTT pass, W_hh slices resident in LDS, per-step
     write-through hand-offs between the work-groups of a row group) against a float64 torch LSTM loop with the same
@@ -996,7 +997,7 @@ def test_train_summaries_kernel_vs_torch(lib, vtrace, use_index):
 
 
 @pytest.mark.parametrize("kind", ["lstm", "gru"])
-@pytest.mark.parametrize("Cn,R,H", [(512, 6, 512), (200, 4, 512), (1024, 3, 512), (16, 5, 256), (1000, 2, 256)])
+@pytest.mark.parametrize("Cn,R,H", [(512, 6, 512), (200, 4, 512), (1024, 3, 512), (16, 5, 256), (1000, 2, 256), (320, 7, 512)])
 def test_fused_sequence_forward_with_input_projection(lib, kind, Cn, R, H):
     """sf_lstm_seq_fwd_x / sf_gru_seq_fwd_x: the pass computes gx_t = x_t W_ih^T + b_ih itself (W_ih fragments of the
     work-group's gate columns in registers, the products of step t+1 behind step t's hand-off).  Every output equals the
