@@ -1,5 +1,7 @@
-"""forward LSTM sequence pass at the configs[4] minibatch shape: k_lstm_seq_fwd (SF_SEQ_FWD2=0) against k_lstm_seq_fwd2
-with its ablation bits (SF_LSTM_ABLATE: 1 no wait, 2 no h loads, 4 no MFMAs, 8 no saves, 16 no arrivals)"""
+"""forward LSTM sequence pass at the configs[4] minibatch shape: k_lstm_seq_fwd (SF_SEQ_FWD2=0) against the PARKED
+k_lstm_seq_fwd2 (tools/experiments/sf_rnn_fwd2.h — paste it into csrc/sf_rnn.hip and dispatch it as its header says; the
+product library has neither the kernel nor the SF_SEQ_FWD2 switch) with its ablation bits (SF_LSTM_ABLATE: 1 no wait, 2 no h
+loads, 4 no MFMAs, 8 no saves, 16 no arrivals, 32 no matrix-phase token).  Results: profiles/r04_d_seq_fwd2_ablate.log"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def one():
