@@ -216,3 +216,30 @@ def test_a_worker_that_dies_silently_is_noticed():
     v.step(a)
     with pytest.raises(RuntimeError, match="exited"):
         v.step(a)
+
+
+@pytest.mark.parametrize("case", ["rollout_ff_sync", "rollout_tuple_heads", "rollout_box_actions"])
+def test_action_format_handed_to_the_env_equals_the_reference(case):
+    """`_format_actions` (what a worker hands `env.step`) against what the reference's `preprocess_actions`
+    (batched_sampling.py:30-82) handed the scripted env when the fixture was recorded: int32 with the action axis squeezed
+    for one Discrete head, the [agents, heads] int32 array for an all-Discrete Tuple, float32 rows for a Box."""
+    import os
+    from sample_factory_amd.algo.sampling.parallel_env import _format_actions
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", case + ".npz"), allow_pickle=True)
+    seen, ref = d["env_seen_actions"], d["ref_actions"]          # [steps, agents(, heads / dims)]
+    kind = str(d["action_kind"])
+    continuous = kind == "box"
+    heads = [7] * ref.shape[2] if (ref.ndim == 3 and not continuous) else [6]
+    for t in range(seen.shape[0]):
+        rows = ref[t].astype(np.float32 if continuous else np.int32)  # the worker's shared `act` array
+        got = _format_actions(rows, heads, continuous, batched=True)
+        assert got.dtype == seen.dtype and got.shape == seen[t].shape, (got.dtype, got.shape, seen.dtype, seen[t].shape)
+        assert np.array_equal(got, seen[t])
+    # a single-agent env gets its agent's row without the agent axis (make_env.py:97-99)
+    one = _format_actions(ref[0][:1].astype(np.float32 if continuous else np.int32), heads, continuous, batched=False)
+    if continuous:
+        assert one.shape == seen[0][0].shape and one.dtype == np.float32
+    elif len(heads) > 1:
+        assert one.shape == (len(heads),) and np.array_equal(one, seen[0][0])
+    else:
+        assert isinstance(one, int) and one == int(seen[0][0])
