@@ -243,3 +243,42 @@ def test_action_format_handed_to_the_env_equals_the_reference(case):
         assert one.shape == (len(heads),) and np.array_equal(one, seen[0][0])
     else:
         assert isinstance(one, int) and one == int(seen[0][0])
+
+
+class _HostVecEnv:
+    """batched HOST env (num_agents attribute, numpy observations): the reference steps such an env as it is"""
+    num_agents = 4
+
+    def __init__(self):
+        self.observation_space = spaces.Box(-1.0, 1.0, (3,), np.float32)
+        self.action_space = spaces.Discrete(2)
+
+    def reset(self, **kw):
+        return np.zeros((4, 3), np.float32), {}
+
+    def step(self, a):
+        return np.zeros((4, 3), np.float32), np.zeros(4, np.float32), np.zeros(4, bool), np.zeros(4, bool), {}
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("env,serial,mode,want", [
+    ("plan_single", True, "auto", "inline"),     # BASELINE configs[0]: single-agent gym envs, serial_mode -> this process
+    ("plan_single", False, "auto", "process"),   # ... parallel mode -> cfg.num_workers worker processes
+    ("plan_vec", True, "auto", "direct"),        # a batched host env in serial mode is stepped as it is
+    ("plan_vec", False, "auto", "process"),
+    ("plan_vec", False, "inline", "direct"),     # cfg.env_workers_mode overrides the serial_mode rule
+    ("plan_single", True, "process", "process"),
+])
+def test_env_deployment_plan_follows_serial_mode_and_env_kind(env, serial, mode, want):
+    """Runner._env_plan (train.py): which of the three deployments a (cfg, env) pair gets — decided from a probe instance,
+    on the host, before anything touches the GPU"""
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.train import Runner
+    register_env("plan_single", make_counting_env)
+    register_env("plan_vec", lambda name, cfg=None, env_config=None, render_mode=None: _HostVecEnv())
+    cfg = default_cfg(env=env, serial_mode=serial, env_workers_mode=mode, num_workers=2, num_envs_per_worker=2)
+    r = Runner(cfg)
+    assert r._env_plan() == want
+    assert (getattr(r, "_probe_env", None) is not None) == (want == "direct")  # the probe is reused only as instance 0
