@@ -80,6 +80,17 @@ def _worker(rank, world, port, out_dir):
     sums = torch.tensor([-out["policy_loss"] * mom[2].item(), 0.0, 0.0, 0.0, out["kl_max"], n_loc, 0.0, 0.0],
                         dtype=torch.float64)
     grp.loss_sums(sums)
+    # (3b) the learner's per-epoch pack [minibatches, 8]: additive loss columns, column 6 = max KL and column 7 = the
+    # abort word of the fused recurrent passes, both MAX — only rank 1 "aborted", every rank must see it (learner.py: one
+    # rank raising alone would leave the others waiting in the next collective)
+    pack = torch.arange(16, dtype=torch.float32).reshape(2, 8) * (rank + 1)
+    pack[:, 6] = torch.tensor([0.25, 0.5]) * (rank + 1)
+    pack[:, 7] = float(rank == 1)
+    grp.reduce_sum_max(pack, (6, 7))
+    want = torch.arange(16, dtype=torch.float32).reshape(2, 8) * 3.0   # ranks 0 and 1: factors 1 + 2
+    want[:, 6] = torch.tensor([0.5, 1.0])
+    want[:, 7] = 1.0
+    assert torch.equal(pack, want), pack
     # (4) returns normaliser: global batch moments -> identical statistics on every rank
     rmom = torch.tensor([s["returns"].astype(np.float64).sum(), (s["returns"].astype(np.float64) ** 2).sum(),
                          float(len(s["returns"]))], dtype=torch.float64)
