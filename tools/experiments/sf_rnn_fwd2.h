@@ -11,7 +11,7 @@
 // from lstm_seq_fwd_impl with p.ngroups = Cn / 32, grid (Cn / 64) * 32, block 512.
 // ---- forward pass with TWO row groups per work-group (H = 512, 256 <= Cn <= 512 rows in 64-row steps).
 // k_lstm_seq_fwd above has one wave per SIMD: while a work-group waits for its group's hand-off (write-through drain,
-// counter, poll, first h rows from L2: ~7 of the 13.7 us per step at configs[4]) its matrix pipes idle.  Here the row
+// counter, poll, first h rows from L2, lockstep skew of the 32 work-groups) its matrix pipes idle.  Here the row
 // groups are 32 rows (16 of them at Cn = 512) and a work-group of EIGHT waves serves the same 16 hidden units of two
 // groups: waves 0-3 group 2p, waves 4-7 group 2p + 1, so every SIMD holds one wave of each group and multiplies one
 // group's step while the other group's hand-off is in flight.  The waves never meet after the prologue: a wave owns 16
