@@ -1,5 +1,5 @@
-"""Evaluate what examples/train_gym_env.py trained — the shape of the reference's sf_examples/enjoy_gym_env.py:
-register the same components, parse the evaluation flags, call enjoy(cfg).
+"""Evaluate the policy examples/train_gym_env.py trained (the reference's counterpart: sf_examples/enjoy_gym_env.py): same
+component registration, the evaluation flag set of the argument parser, `sample_factory.enjoy.enjoy(cfg)`.
 
   python examples/enjoy_gym_env.py --env=CartPole-v1 --experiment=example_gym_cartpole-v1 --max_num_episodes=100 \
       --eval_deterministic=True
@@ -7,21 +7,14 @@ register the same components, parse the evaluation flags, call enjoy(cfg).
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), HERE]
 
+import train_gym_env as training_script  # noqa: E402
 from sample_factory.enjoy import enjoy  # noqa: E402
-from train_gym_env import parse_custom_args, register_custom_components  # noqa: E402
-
-
-def main():
-    """Script entry point."""
-    register_custom_components()
-    cfg = parse_custom_args(evaluation=True)
-    status, avg_reward = enjoy(cfg)
-    print(f"Avg episode reward: {avg_reward:.3f}")
-    return status
-
 
 if __name__ == "__main__":
-    sys.exit(main())
+    training_script.register_custom_components()
+    status, mean_return = enjoy(training_script.parse_custom_args(evaluation=True))
+    print(f"Avg episode reward: {mean_return:.3f}")
+    sys.exit(status)
