@@ -32,7 +32,7 @@ import numpy as np
 from sample_factory_amd.envs.spaces import action_head_sizes, is_box
 from sample_factory_amd.utils.attr_dict import AttrDict
 
-CMD_RESET, CMD_STEP, CMD_CLOSE = 0, 1, 2
+CMD_RESET, CMD_STEP, CMD_CLOSE, CMD_TRAINING_INFO = 0, 1, 2, 3
 
 
 def _as_obs_dict(obs) -> Dict[str, Any]:
@@ -43,6 +43,11 @@ def env_is_batched(env) -> bool:
     """make_env.py:30-39: `num_agents` > 1 or an explicit `is_multiagent` -> the env speaks per-agent vectors"""
     n = getattr(env, "num_agents", 1)
     return bool(getattr(env, "is_multiagent", n > 1))
+
+
+def probe_info(env):
+    """(observation_space, action_space, agents per instance) of one env instance"""
+    return env.observation_space, env.action_space, (int(getattr(env, "num_agents", 1)) if env_is_batched(env) else 1)
 
 
 def obs_space_dict(space) -> Dict[str, Any]:
@@ -58,14 +63,10 @@ class _Shm:
         self.owner = name is None
         self.shm = shared_memory.SharedMemory(create=True, size=nbytes) if name is None else \
             shared_memory.SharedMemory(name=name)
-        if not self.owner:
-            # Python < 3.13 registers ATTACHED segments with the resource tracker too, which then unlinks them when the
-            # attaching process exits (bpo-38119): the owner (main process) is the only one that may unlink
-            try:
-                from multiprocessing import resource_tracker
-                resource_tracker.unregister(self.shm._name, "shared_memory")
-            except Exception:  # noqa: BLE001
-                pass
+        # (Python < 3.13 registers ATTACHED segments with the resource tracker too, bpo-38119.  The env workers are spawn /
+        # fork children of the owner and therefore talk to the owner's tracker: the second registration is a no-op in its
+        # set, nothing is unlinked when a worker exits, and the owner's unlink() removes the one entry.  An attaching
+        # process must NOT unregister: that would delete the owner's registration as well.)
         self.array = np.ndarray(self.shape, dtype=self.dtype, buffer=self.shm.buf)
         if self.owner:
             self.array.fill(0)
@@ -102,11 +103,21 @@ class _InstanceStepper:
     """the env instances of ONE worker (or, inline, of the whole runner) and the arrays they write into: reset / step of one
     split, exactly what a rollout worker does per message (rollout_worker.py:201-259, make_env.py:97-128,147-237)"""
 
-    def __init__(self, make_env_func, env_name, cfg, widx, instances, arrays, heads, continuous):
+    def __init__(self, make_env_func, env_name, cfg, widx, instances, arrays, heads, continuous, render_mode=None):
+        from sample_factory_amd.envs.env_utils import find_training_info_interface
         self.arrays, self.heads, self.continuous, self.envs = arrays, heads, continuous, []
+        self.training_info_ifaces = []
         for split, vidx, env_id, row0, nrows in instances:
-            env = make_env_func(env_name, cfg, AttrDict(worker_index=widx, vector_index=vidx, env_id=env_id), None)
+            env = make_env_func(env_name, cfg, AttrDict(worker_index=widx, vector_index=vidx, env_id=env_id), render_mode)
             self.envs.append((split, env, env_is_batched(env), row0, nrows, env_id))
+            iface = find_training_info_interface(env)
+            if iface is not None:
+                self.training_info_ifaces.append(iface)
+
+    def set_training_info(self, training_info) -> None:
+        """curricula (batched_sampling.py:352-355): every instance that implements TrainingInfoInterface gets the dict"""
+        for iface in self.training_info_ifaces:
+            iface.set_training_info(training_info)
 
     @staticmethod
     def _put_obs(a, obs, row0, nrows, batched):
@@ -164,11 +175,14 @@ def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: 
                 shms.append(s)
                 arrays[split][name] = s.array
         stepper = _InstanceStepper(make_env_func, env_name, cfg, widx, instances, arrays, heads, continuous)
-        conn.send(("ready", widx))
+        conn.send(("ready", widx, len(stepper.training_info_ifaces)))
         while True:
             cmd, split = conn.recv()
             if cmd == CMD_CLOSE:
                 break
+            if cmd == CMD_TRAINING_INFO:  # payload in place of the split index; no completion signal
+                stepper.set_training_info(split)
+                continue
             stepper.run(cmd, split)
             done_sems[split].release()
     except BaseException:  # noqa: BLE001 - reported to the main process, which raises
@@ -225,28 +239,37 @@ class ParallelVecEnvView:
         self.step_async(actions)
         return self.step_wait()
 
+    def set_training_info(self, training_info) -> None:
+        """forwarded to every env instance that implements TrainingInfoInterface (in its worker process)"""
+        if self.split == 0:  # one message per worker and rollout covers all splits
+            self.parent.set_training_info(training_info)
+
     def close(self):
         self.parent.close()
 
 
 class ParallelHostEnvs:
     def __init__(self, cfg, env_name: str, make_env_func: Callable, num_workers: int, envs_per_worker: int,
-                 num_splits: int = 1, start_method: Optional[str] = None, inline: bool = False):
+                 num_splits: int = 1, start_method: Optional[str] = None, inline: bool = False, render_mode=None,
+                 probed=None):
         """inline=True: no processes — the same instances, wrappers and row layout stepped in THIS process (serial_mode:
-        single-agent gym envs such as BASELINE configs[0]'s two CartPole copies behind one batched view)."""
+        single-agent gym envs such as BASELINE configs[0]'s two CartPole copies behind one batched view).
+        probed = (observation_space, action_space, agents_per_instance) when the caller already looked at an instance."""
         assert envs_per_worker % num_splits == 0, f"{envs_per_worker=} must be a multiple of {num_splits=}"
         self.cfg, self.num_workers, self.envs_per_worker, self.num_splits = cfg, num_workers, envs_per_worker, num_splits
         self._closed, self._conns, self._procs, self._shms = False, [], [], []
         self._registered: List[int] = []  # page-locked base addresses (register_with_device), unregistered in close()
         # ---- probe ONE instance here for spaces / agents per instance (the reference spawns a process for this,
         # env_info.py:81-127; the instance is closed again before the workers start)
-        probe = make_env_func(env_name, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0), None)
-        self.observation_space, self.action_space = probe.observation_space, probe.action_space
-        self.agents_per_instance = int(getattr(probe, "num_agents", 1)) if env_is_batched(probe) else 1
-        try:
-            probe.close()
-        except Exception:  # noqa: BLE001
-            pass
+        if probed is None:
+            probe = make_env_func(env_name, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0), None)
+            probed = probe_info(probe)
+            try:
+                probe.close()
+            except Exception:  # noqa: BLE001
+                pass
+        self.observation_space, self.action_space, self.agents_per_instance = probed
+        self._training_info_instances = 0
         spaces_ = obs_space_dict(self.observation_space)
         if not hasattr(self.observation_space, "spaces"):  # make_env.py:46-66: a bare space becomes Dict(obs=space)
             from sample_factory_amd.envs import spaces as _sp
@@ -293,7 +316,8 @@ class ParallelHostEnvs:
                                  self.agents_per_instance))
                 self._steppers.append(_InstanceStepper(make_env_func, env_name, cfg, w, inst,
                                                        {s_: self.arrays[s_] for s_ in range(num_splits)}, self.heads,
-                                                       self.continuous))
+                                                       self.continuous, render_mode))
+                self._training_info_instances += len(self._steppers[-1].training_info_ifaces)
             self.views = [ParallelVecEnvView(self, s_, n) for s_ in range(num_splits)]
             return
         # ---- workers
@@ -321,6 +345,7 @@ class ParallelHostEnvs:
             if msg[0] != "ready":
                 self.close()
                 raise RuntimeError(f"env worker {w} failed to create its envs:\n{msg[1]}")
+            self._training_info_instances += int(msg[2])
         self.views = [ParallelVecEnvView(self, s, n) for s in range(num_splits)]
 
     # ---- pinned pages: let the DMA engine read the workers' pages directly
@@ -346,6 +371,18 @@ class ParallelHostEnvs:
             return True
         except Exception:  # noqa: BLE001 - registration is an optimisation only
             return False
+
+    def set_training_info(self, training_info) -> None:
+        """rollout_worker.py: the runner's training info reaches the envs where they live; a no-op (no messages) when no
+        instance implements TrainingInfoInterface"""
+        if not self._training_info_instances or self._closed:
+            return
+        if self.inline:
+            for st in self._steppers:
+                st.set_training_info(training_info)
+            return
+        for c in self._conns:
+            c.send((CMD_TRAINING_INFO, dict(training_info)))
 
     def _command(self, split: int, cmd: int) -> None:
         if self.inline:

@@ -169,3 +169,54 @@ def verify_cfg(cfg, env_info) -> bool:
         err(f"sync mode needs batch_size*num_batches_per_epoch ({per_iter}) to be a multiple of "
             f"agents*rollout ({per_rollout})")
     return ok
+
+
+def cfg_dict(cfg) -> dict:
+    return dict(cfg) if isinstance(cfg, dict) else dict(vars(cfg))
+
+
+def cfg_str(cfg) -> str:
+    return "\n".join(f"{k}={v}" for k, v in cfg_dict(cfg).items())
+
+
+def load_from_checkpoint(cfg):
+    """cfg/arguments.py:227-260: the experiment's saved config.json is the base configuration; flags given on the command
+    line (cfg.cli_args) override it; flags the file does not know are added"""
+    import json
+
+    from sample_factory_amd.utils.attr_dict import AttrDict
+    name = os.path.join(cfg.train_dir, cfg.experiment, "config.json")
+    if not os.path.isfile(name):
+        raise FileNotFoundError(f"Could not load saved parameters for experiment {cfg.experiment} (file {name} not found). "
+                                "Check that you have the correct experiment name and --train_dir is set correctly.")
+    with open(name) as f:
+        loaded = AttrDict(json.load(f))
+    for key, value in getattr(cfg, "cli_args", {}).items():
+        if key in loaded and loaded[key] != value:
+            loaded[key] = value
+    for key, value in cfg_dict(cfg).items():
+        if key not in loaded:
+            loaded[key] = value
+    return loaded
+
+
+def maybe_load_from_checkpoint(cfg):
+    """cfg/arguments.py:263-275: resume = saved configuration + command-line overrides; no saved configuration = a fresh
+    experiment with the given one (returned as a new AttrDict: the caller's object is never mutated)"""
+    from sample_factory_amd.utils.attr_dict import AttrDict
+    from sample_factory_amd.utils.utils import log
+    if not os.path.isfile(os.path.join(cfg.train_dir, cfg.experiment, "config.json")):
+        log.warning("Saved parameter configuration for experiment %s not found! Starting experiment from scratch!",
+                    cfg.experiment)
+        return AttrDict(cfg_dict(cfg))
+    return load_from_checkpoint(cfg)
+
+
+def checkpoint_override_defaults(cfg, parser) -> None:
+    """cfg/arguments.py:75-94 (used by enjoy-style scripts with their own parsers): the saved configuration becomes the
+    parser's defaults so that a second parse only overrides what the command line names"""
+    import json
+    name = os.path.join(cfg.train_dir, cfg.experiment, "config.json")
+    if os.path.isfile(name):
+        with open(name) as f:
+            parser.set_defaults(**json.load(f))

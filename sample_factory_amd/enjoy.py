@@ -25,26 +25,8 @@ import torch
 from sample_factory_amd.algo.utils.misc import ExperimentStatus
 
 
-def cfg_file(cfg) -> str:
-    return os.path.join(cfg.train_dir, cfg.experiment, "config.json")
-
-
-def load_from_checkpoint(cfg):
-    """cfg/arguments.py:227-260: saved experiment configuration + explicit command-line overrides + new flags"""
-    import argparse
-    name = cfg_file(cfg)
-    if not os.path.isfile(name):
-        raise FileNotFoundError(f"Could not load saved parameters for experiment {cfg.experiment} (file {name} not found). "
-                                "Check that you have the correct experiment name and --train_dir is set correctly.")
-    with open(name) as f:
-        loaded = json.load(f)
-    for key, value in getattr(cfg, "cli_args", {}).items():
-        if key in loaded and loaded[key] != value:
-            loaded[key] = value
-    for key, value in vars(cfg).items():
-        if key not in loaded:
-            loaded[key] = value
-    return argparse.Namespace(**loaded)
+from sample_factory_amd.cfg.arguments import load_from_checkpoint  # noqa: E402,F401  (cfg/arguments.py:227-260)
+from sample_factory_amd.utils.utils import cfg_file, log  # noqa: E402,F401
 
 
 def load_state_dict(cfg, actor_critic, device) -> dict:
@@ -71,8 +53,10 @@ def enjoy(cfg) -> Tuple[int, float]:
     from sample_factory_amd.utils.attr_dict import AttrDict
 
     cfg = load_from_checkpoint(cfg)
-    if not torch.cuda.is_available():
-        raise lib.SfHipError("enjoy(): no GPU visible. sample_factory_amd has no CPU path.")
+    if getattr(cfg, "device", "gpu") == "cpu" or not torch.cuda.is_available():
+        log.error("enjoy(): needs an MI355X (--device=gpu). sample_factory_amd has no CPU execution path.")
+        return ExperimentStatus.FAILURE, 0.0
+    lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     env = create_env(cfg.env, cfg, AttrDict(worker_index=0, vector_index=0, env_id=0))
     from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs, env_is_batched

@@ -22,6 +22,9 @@ from torch import nn
 
 from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
 from sample_factory_amd.envs.spaces import calc_num_action_parameters
+from sample_factory_amd.model.core import ModelCoreRNN
+from sample_factory_amd.model.decoder import default_make_decoder_func
+from sample_factory_amd.model.encoder import MultiInputEncoder, default_make_encoder_func
 
 
 class TorchObsNormalizer:
@@ -73,10 +76,12 @@ class TorchObsNormalizer:
         self.var = (m_a + m_b + delta * delta * self.count * bn / tot) / tot
         self.count = tot
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, stats=None) -> torch.Tensor:
+        """stats = (mean, var) of a published snapshot (async inference); None = the learner's current moments"""
         x = self._scale(x)
         if self.running:
-            x = ((x - self.mean.float()) / torch.sqrt(self.var.float() + 1e-5)).clamp(-5.0, 5.0)
+            mean, var = stats if stats is not None else (self.mean, self.var)
+            x = ((x - mean.float()) / torch.sqrt(var.float() + 1e-5)).clamp(-5.0, 5.0)
         return x
 
     def state_dict(self, prefix=None):
@@ -94,10 +99,6 @@ class TorchObsNormalizer:
             self.count.copy_(torch.as_tensor(sd[prefix + "count"], dtype=torch.float64).reshape(-1))
 
 
-def _nonlinearity(cfg) -> nn.Module:
-    return dict(elu=nn.ELU, relu=nn.ReLU, tanh=nn.Tanh)[cfg.nonlinearity]()
-
-
 class _DictObsNormalizer:
     """what the Learner updates once per dataset when the observation is a dict of several keys"""
 
@@ -109,155 +110,33 @@ class _DictObsNormalizer:
             nm.update(obs[k], 0, n)
 
 
-class _TorchMlpEncoder(nn.Module):
-    """model/encoder.py:72-87 (MlpEncoder): mlp_head = Linear + activation per cfg.encoder_mlp_layers entry"""
-
-    def __init__(self, cfg, space):
-        super().__init__()
-        size, layers = int(space.shape[0]), []
-        for h in list(cfg.encoder_mlp_layers):
-            layers += [nn.Linear(size, int(h)), _nonlinearity(cfg)]
-            size = int(h)
-        self.mlp_head = nn.Sequential(*layers)
-        self.out_size = size
-
-    def forward(self, x):
-        return self.mlp_head(x)
-
-    def get_out_size(self) -> int:
-        return self.out_size
-
-
-class _TorchConvImpl(nn.Module):
-    def __init__(self, cfg, space):
-        super().__init__()
-        from sample_factory_amd.model.actor_critic import CONV_ARCHS
-        c, h, w = (int(v) for v in space.shape)
-        layers = []
-        for cout, k, st in CONV_ARCHS[cfg.encoder_conv_architecture]:
-            layers += [nn.Conv2d(c, cout, k, stride=st), _nonlinearity(cfg)]
-            c, h, w = cout, (h - k) // st + 1, (w - k) // st + 1
-        self.conv_head = nn.Sequential(*layers)
-        size, mlp = c * h * w, []
-        self.conv_head_out_size = size
-        for hdim in list(cfg.encoder_conv_mlp_layers):
-            mlp += [nn.Linear(size, int(hdim)), _nonlinearity(cfg)]
-            size = int(hdim)
-        self.mlp_layers = nn.Sequential(*mlp)
-        self.out_size = size
-
-    def forward(self, x):
-        x = self.conv_head(x)
-        return self.mlp_layers(x.contiguous().view(-1, self.conv_head_out_size))
-
-
-class _TorchConvEncoder(nn.Module):
-    """model/encoder.py:90-150 (ConvEncoder wrapping ConvEncoderImpl as .enc)"""
-
-    def __init__(self, cfg, space):
-        super().__init__()
-        self.enc = _TorchConvImpl(cfg, space)
-
-    def forward(self, x):
-        return self.enc(x)
-
-    def get_out_size(self) -> int:
-        return self.enc.out_size
-
-
-class _TorchMultiInputEncoder(nn.Module):
-    """model/encoder.py:33-69 (MultiInputEncoder): one encoder per observation key (sorted; vectors -> MLP, images ->
-    conv), outputs concatenated.  Parameter names equal the reference's (encoders.<key>.mlp_head.* /
-    encoders.<key>.enc.conv_head.* / .enc.mlp_layers.*)."""
-
-    def __init__(self, cfg, obs_space):
-        super().__init__()
-        self.obs_keys = sorted(k for k in obs_space.spaces.keys() if k != "action_mask")
-        self.encoders = nn.ModuleDict()
-        self.out_size = 0
-        for k in self.obs_keys:
-            space = obs_space[k]
-            if len(space.shape) == 1:
-                self.encoders[k] = _TorchMlpEncoder(cfg, space)
-            elif len(space.shape) == 3:
-                if not cfg.encoder_conv_architecture.startswith("convnet"):
-                    raise NotImplementedError(f"{cfg.encoder_conv_architecture} encoders")
-                self.encoders[k] = _TorchConvEncoder(cfg, space)
-            else:
-                raise NotImplementedError(f"Unsupported observation space {space}")
-            self.out_size += self.encoders[k].get_out_size()
-
-    def forward(self, obs_dict):
-        return torch.cat([self.encoders[k](obs_dict[k]) for k in self.obs_keys], 1)
-
-    def get_out_size(self) -> int:
-        return self.out_size
-
-
-class _TorchRnnCore(nn.Module):
-    """model/core.py:19-64 (ModelCoreRNN) with cfg.rnn_num_layers stacked layers: x [n, F], rnn_states [n, S] ->
-    (out [n, H], new_states [n, S]).  State layout as the reference keeps it in the trajectory buffer: per sample
-    [layer 0 | layer 1 | ...], a layer's block being h (GRU) or [h | c] (LSTM).  Parameter names
-    core.core.weight_ih_l<k> ... are torch's own, i.e. the reference's."""
-
-    def __init__(self, cfg, input_size):
-        super().__init__()
-        if cfg.rnn_type not in ("gru", "lstm"):
-            raise RuntimeError(f"Unknown RNN type {cfg.rnn_type}")
-        self.is_gru, self.H, self.L = cfg.rnn_type == "gru", int(cfg.rnn_size), int(cfg.rnn_num_layers)
-        self.core = (nn.GRU if self.is_gru else nn.LSTM)(input_size, self.H, self.L)
-
-    def forward(self, x, rnn_states):
-        n = x.shape[0]
-        per_layer = rnn_states.reshape(n, self.L, -1).transpose(0, 1)          # [L, n, H] or [L, n, 2H]
-        if self.is_gru:
-            out, new = self.core(x.unsqueeze(0), per_layer.contiguous())
-        else:
-            h, c = per_layer[..., :self.H], per_layer[..., self.H:]
-            out, (h, c) = self.core(x.unsqueeze(0), (h.contiguous(), c.contiguous()))
-            new = torch.cat((h, c), dim=2)
-        return out.squeeze(0), new.transpose(0, 1).reshape(n, -1)
-
-    def get_out_size(self) -> int:
-        return self.H
-
-
-class _TorchMlpDecoder(nn.Module):
-    """model/decoder.py:15-31 (MlpDecoder): Linear + activation per cfg.decoder_mlp_layers entry, parameters under .mlp"""
-
-    def __init__(self, cfg, size):
-        super().__init__()
-        layers = []
-        for h in list(getattr(cfg, "decoder_mlp_layers", []) or []):
-            layers += [nn.Linear(size, int(h)), _nonlinearity(cfg)]
-            size = int(h)
-        self.mlp = nn.Sequential(*layers)
-        self.out_size = size
-
-    def forward(self, x):
-        return self.mlp(x)
-
-    def get_out_size(self) -> int:
-        return self.out_size
-
-
 def _make_decoder(cfg, size, factory):
     if factory.make_model_decoder_func is not None:
         return factory.make_model_decoder_func(cfg, size)
-    return _TorchMlpDecoder(cfg, size)
+    return default_make_decoder_func(cfg, size)
+
+
+def _make_core(cfg, size, factory):
+    """a registered core factory decides; otherwise the reference's default: ModelCoreRNN iff cfg.use_rnn (None = no core)"""
+    if factory.make_model_core_func is not None:
+        return factory.make_model_core_func(cfg, size)
+    return ModelCoreRNN(cfg, size) if cfg.use_rnn else None
 
 
 def _initialize_weights(module: nn.Module, cfg) -> None:
-    """model/actor_critic.py:73-96 (ActorCritic.initialize_weights applied to every layer)"""
+    """model/actor_critic.py:73-96 (ActorCritic.initialize_weights applied to every layer, user-registered ones included):
+    every `.bias` that is a Parameter is zeroed whatever the scheme (LayerNorm, user layers, ...; GRU / LSTM name theirs
+    bias_ih_l<k> and keep torch's own initialisation); orthogonal / xavier_uniform touch the weights of exactly
+    nn.Linear and nn.Conv2d (subclasses keep theirs, as `type(layer) is ...` in the reference)."""
     gain = cfg.policy_init_gain
     for m in module.modules():
-        if isinstance(m, (nn.Linear, nn.Conv2d)):
+        if isinstance(getattr(m, "bias", None), nn.Parameter):
+            m.bias.data.fill_(0)
+        if type(m) in (nn.Linear, nn.Conv2d):
             if cfg.policy_initialization == "orthogonal":
-                nn.init.orthogonal_(m.weight, gain=gain)
+                nn.init.orthogonal_(m.weight.data, gain=gain)
             elif cfg.policy_initialization == "xavier_uniform":
-                nn.init.xavier_uniform_(m.weight, gain=gain)
-            if cfg.policy_initialization != "torch_default" and m.bias is not None:
-                m.bias.data.fill_(0)
+                nn.init.xavier_uniform_(m.weight.data, gain=gain)
 
 
 class _SeparateTorchActorCritic(nn.Module):
@@ -274,12 +153,10 @@ class _SeparateTorchActorCritic(nn.Module):
         def make_encoder():
             if factory.make_model_encoder_func is not None:
                 return factory.make_model_encoder_func(cfg, obs_space)
-            return _TorchMultiInputEncoder(cfg, obs_space)
+            return default_make_encoder_func(cfg, obs_space)
 
         def make_core(size):
-            if factory.make_model_core_func is not None:
-                return factory.make_model_core_func(cfg, size)
-            return _TorchRnnCore(cfg, size) if cfg.use_rnn else None
+            return _make_core(cfg, size, factory)
 
         self.actor_encoder = make_encoder()
         self.actor_core = make_core(int(self.actor_encoder.get_out_size()))
@@ -332,10 +209,7 @@ class _DefaultTorchTail(nn.Module):
         if self.encoder is None:
             raise NotImplementedError("register an encoder (or a whole actor-critic) when customising core/decoder")
         size = int(self.encoder.get_out_size())
-        if factory.make_model_core_func is not None:
-            self.core = factory.make_model_core_func(cfg, size)
-        else:
-            self.core = _TorchRnnCore(cfg, size) if cfg.use_rnn else None
+        self.core = _make_core(cfg, size, factory)
         if self.core is not None:
             size = int(self.core.get_out_size())
         self.decoder = _make_decoder(cfg, size, factory)
@@ -382,7 +256,7 @@ def build_torch_actor_critic(cfg, obs_space, action_space, factory) -> nn.Module
         return _SeparateTorchActorCritic(cfg, obs_space, action_space, factory)
     enc = None
     if factory.make_model_encoder_func is None:
-        enc = _TorchMultiInputEncoder(cfg, obs_space)
+        enc = default_make_encoder_func(cfg, obs_space)
     return _DefaultTorchTail(cfg, obs_space, action_space, factory, encoder=enc)
 
 
@@ -435,6 +309,7 @@ class TorchPolicyAdapter:
             self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
         self._bufs: Dict = {}
         self._train_heads = None
+        self._snap = None
 
     def num_params(self) -> int:
         return sum(p.numel() for p in self._params)
@@ -455,9 +330,36 @@ class TorchPolicyAdapter:
     def params_changed(self) -> None:
         pass  # the module's parameters ARE views of flat_params
 
-    def enable_weight_snapshots(self):
-        raise NotImplementedError("async_rl=True is not available on the torch model path (user-registered models, "
-                                  "observation dicts with several keys): run with --async_rl=False")
+    def enable_weight_snapshots(self) -> None:
+        """async_rl=True (the reference's default): inference reads PUBLISHED weights while the learner updates its own.
+        Two snapshot slots, as on the native path (model/actor_critic.py): a slot is a deep copy of the module whose
+        parameters are re-seated as views into one flat snapshot buffer; `publish_weights(slot)` is one device copy of
+        the flat parameters (+ the module's buffers and the observation normaliser's moments); forwards tagged "inf*"
+        run the module of slot `snap_read`."""
+        import copy
+        self._snap, self._snap_modules, self._snap_norms = [], [], []
+        for _ in range(2):
+            buf = self.flat_params.clone()
+            m = copy.deepcopy(self.module)
+            mine = [p for p in m.parameters() if p.requires_grad]
+            assert len(mine) == len(self._params)
+            for p, o in zip(mine, self._offs):
+                p.grad = None
+                p.requires_grad_(False)
+                p.data = buf[o:o + p.numel()].view(p.shape)
+            m.eval()
+            self._snap.append(buf)
+            self._snap_modules.append(m)
+            self._snap_norms.append({k: (nm.mean, nm.var) for k, nm in self._norms.items()})
+        self.snap_read = 0
+
+    def publish_weights(self, slot: int) -> None:
+        self._snap[slot].copy_(self.flat_params)
+        with torch.no_grad():
+            for dst, src in zip(self._snap_modules[slot].buffers(), self.module.buffers()):
+                dst.copy_(src)
+        # TorchObsNormalizer.update REBINDS mean / var to new tensors, so holding the current ones is a snapshot
+        self._snap_norms[slot] = {k: (nm.mean, nm.var) for k, nm in self._norms.items()}
 
     def _buf(self, key, shape, dtype=torch.float32):
         t = self._bufs.get(key)
@@ -494,31 +396,35 @@ class TorchPolicyAdapter:
         return x[offset:offset + n]
 
     def forward_heads(self, obs, n, *, sample_stride, index=None, offset=0, traj_T=0, tag="inf", rnn=None) -> List[torch.Tensor]:
+        module, nstats = self.module, {}
+        if self._snap is not None and tag.startswith("inf"):  # published snapshot (async mode)
+            module, nstats = self._snap_modules[self.snap_read], self._snap_norms[self.snap_read]
         if isinstance(obs, dict):  # several observation keys: every key gathered / normalised on its own
-            xd = {k: self._norms[k](self._gather(obs[k], n, index, offset, traj_T, self.obs_shapes[k]))
+            xd = {k: self._norms[k](self._gather(obs[k], n, index, offset, traj_T, self.obs_shapes[k]), nstats.get(k))
                   for k in self.obs_keys}
         else:
-            xd = {"obs": self._norm(self._gather(obs, n, index, offset, traj_T))}
+            main = self._norm.key
+            xd = {"obs": self._norm(self._gather(obs, n, index, offset, traj_T), nstats.get(main))}
         train = tag == "train"
         with torch.set_grad_enabled(train):
             if rnn is None:
-                res = self.module(xd, None, values_only=False)
+                res = module(xd, None, values_only=False)
             elif "R" not in rnn:  # one inference step on the stored state (rollout, bootstrap value)
-                x, new_states = self.module.forward_core(self.module.forward_head(xd), rnn["states"])
-                res = self.module.forward_tail(x, values_only=False)
+                x, new_states = module.forward_core(module.forward_head(xd), rnn["states"])
+                res = module.forward_tail(x, values_only=False)
                 self._rnn_out[tag] = new_states.detach()
             else:
                 # BPTT over recurrence-length chunks as a masked time loop: rows are chunk-major (Cn chunks x R steps),
                 # the state is zeroed after a done / invalid step — the loop form of rnn_utils.py:114-158 that the
                 # reference's tests/algo/test_rnn.py proves equal to its PackedSequence path
                 R, Cn = rnn["R"], n // rnn["R"]
-                feats = self.module.forward_head(xd).reshape(Cn, R, -1)
+                feats = module.forward_head(xd).reshape(Cn, R, -1)
                 h, keep, outs = rnn["h0"], rnn["keep_tm"], []
                 for t in range(R):
-                    out, h = self.module.forward_core(feats[:, t], h)
+                    out, h = module.forward_core(feats[:, t], h)
                     outs.append(out)
                     h = h * keep[t].unsqueeze(1)
-                res = self.module.forward_tail(torch.stack(outs, 1).reshape(n, -1), values_only=False)
+                res = module.forward_tail(torch.stack(outs, 1).reshape(n, -1), values_only=False)
             heads = torch.cat([res["values"].reshape(n, 1), res["action_logits"].reshape(n, self.num_action_params),
                                torch.zeros((n, self.heads_ld - 1 - self.num_action_params), device=self.device)], dim=1)
         if train:

@@ -22,9 +22,11 @@ from sample_factory_amd.algo.sampling.batched_sampling import BatchedVectorEnvRu
 from sample_factory_amd.algo.utils.env_info import extract_env_info
 from sample_factory_amd.algo.learning.batcher import Batcher
 from sample_factory_amd.algo.utils.shared_buffers import BufferMgr
-from sample_factory_amd.cfg.arguments import preprocess_cfg
+from sample_factory_amd.cfg.arguments import cfg_dict, preprocess_cfg
 from sample_factory_amd.envs.env_utils import create_env, find_training_info_interface, set_training_info
+from sample_factory_amd.algo.sampling.parallel_env import ParallelVecEnvView
 from sample_factory_amd.utils.attr_dict import AttrDict
+from sample_factory_amd.utils.utils import init_file_logger, log
 
 
 from sample_factory_amd.algo.utils.misc import (EPISODIC, LEARNER_ENV_STEPS, POLICY_ID_KEY, TRAIN_STATS,  # noqa: F401
@@ -156,7 +158,7 @@ class Runner:
         """runner.py:497-501: config.json next to the checkpoints (what enjoy / resume read back)"""
         d = os.path.join(self.cfg.train_dir, self.cfg.experiment)
         os.makedirs(d, exist_ok=True)
-        out = {k: v for k, v in vars(self.cfg).items() if isinstance(v, (int, float, str, bool, list, type(None)))}
+        out = {k: v for k, v in cfg_dict(self.cfg).items() if isinstance(v, (int, float, str, bool, list, type(None)))}
         if getattr(self, "parallel_envs", None) is not None:  # the file keeps what the user asked for, not the internal
             out["num_workers"], out["num_envs_per_worker"] = out.pop("env_workers"), out.pop("env_instances_per_worker")
             out["worker_num_splits"] = int(getattr(self.cfg, "env_worker_splits_requested", out["worker_num_splits"]))
@@ -174,6 +176,28 @@ class Runner:
         return tot
 
     def init(self) -> int:
+        """runner.py:521-541: ExperimentStatus.SUCCESS, or FAILURE for a configuration this engine cannot run (reported
+        through the log, as the reference reports invalid configurations) — exceptions are for bugs, not for user input"""
+        import copy
+        # the internal env layout below (one "worker" whose instances are the splits) lives on a COPY: the object the
+        # user handed in keeps what they asked for (the reference's make_runner hands Runner a fresh AttrDict as well)
+        self.user_cfg, self.cfg = self.cfg, copy.copy(self.cfg)
+        if getattr(self.cfg, "device", "gpu") == "cpu":
+            log.error("--device=cpu: this engine has no CPU execution path (the hot path is HIP kernels for gfx950; there "
+                      "is deliberately no fallback).  Run with --device=gpu on an MI355X.")
+            return ExperimentStatus.FAILURE
+        if not torch.cuda.is_available():
+            log.error("Runner.init(): no GPU visible. sample_factory_amd has no CPU path.")
+            return ExperimentStatus.FAILURE
+        from sample_factory_amd import lib
+        lib.load()  # the HIP library itself: fails loudly (SfHipError) when it was not built
+        try:
+            return self._init()
+        except BaseException:
+            self.close_envs()  # env worker processes must not outlive a failed init
+            raise
+
+    def _init(self) -> int:
         cfg = self.cfg
         if self.world > 1:
             if not torch.distributed.is_initialized():
@@ -204,7 +228,8 @@ class Runner:
             if int(cfg.num_envs_per_worker) % S != 0:
                 S = 1
             self.parallel_envs = ParallelHostEnvs(cfg, cfg.env, registered_env_factory(cfg.env), int(cfg.num_workers),
-                                                  int(cfg.num_envs_per_worker), num_splits=S, inline=plan == "inline")
+                                                  int(cfg.num_envs_per_worker), num_splits=S, inline=plan == "inline",
+                                                  probed=getattr(self, "_probed", None))
             self.parallel_envs.register_with_device()
             self.envs = list(self.parallel_envs.views)
             # from here on: one "worker" whose env instances are the splits (slab rows, sampling units, streams follow)
@@ -226,12 +251,12 @@ class Runner:
         if int(cfg.num_envs_per_worker) % int(cfg.worker_num_splits) != 0:
             cfg.worker_num_splits = 1  # (the reference rejects this; one unit per worker is the natural reading)
         if not preprocess_cfg(cfg, self.env_info):
-            raise ValueError("Invalid config! See above for details.")
+            self.close_envs()
+            return ExperimentStatus.FAILURE
+        self.user_cfg.recurrence = cfg.recurrence  # (the reference resolves recurrence=-1 on the user's object too)
         if self.rank == 0:
             self._save_cfg()
-        if not torch.cuda.is_available():
-            from sample_factory_amd import lib
-            raise lib.SfHipError("Runner.init(): no GPU visible. sample_factory_amd has no CPU path.")
+            init_file_logger(cfg)
         dev = torch.device("cuda", torch.cuda.current_device())
         # Slab + free-slice queue + policy versions (shared_buffers.py:152-239).  Rows: agents x env instances, twice
         # that when rollouts overlap training (async), never fewer than the learner's dataset(s).
@@ -264,7 +289,10 @@ class Runner:
         self.split_streams = [torch.cuda.Stream(priority=prio) for _ in range(S)] if E > 1 else None
         self._ev_fork = torch.cuda.Event()
         self._ev_join = [torch.cuda.Event() for _ in range(S)]
-        self._training_info_ifaces = [find_training_info_interface(env) for env in self.envs]
+        # curricula: envs in this process through their TrainingInfoInterface layer, envs behind a ParallelVecEnvView
+        # through the view (which forwards the dict to the worker processes)
+        self._training_info_ifaces = [env if isinstance(env, ParallelVecEnvView) else find_training_info_interface(env)
+                                      for env in self.envs]
         self._cv = threading.Condition(threading.RLock())   # guards queue / merger / event maps / publish state
         self._ready: List[slice] = []               # complete datasets waiting for the learner
         self._round_events: Dict[int, torch.cuda.Event] = {}   # sampling slice start -> "rollout written" event
@@ -302,7 +330,7 @@ class Runner:
         BASELINE configs[0]'s CartPole copies); "direct": the env instances are batched vector envs used as they are
         (device-resident envs always; batched host envs in serial mode).  cfg.env_workers_mode = "process" | "inline"
         overrides the serial_mode rule ("auto")."""
-        from sample_factory_amd.algo.sampling.parallel_env import env_is_batched
+        from sample_factory_amd.algo.sampling.parallel_env import env_is_batched, probe_info
         cfg = self.cfg
         mode = getattr(cfg, "env_workers_mode", None) or "auto"
         if mode == "process":
@@ -318,6 +346,7 @@ class Runner:
         if device_env or (in_process and env_is_batched(probe)):
             self._probe_env = probe
             return "direct"
+        self._probed = probe_info(probe)  # ParallelHostEnvs does not have to build a second instance for the spaces
         try:
             probe.close()
         except Exception:  # noqa: BLE001
@@ -658,6 +687,12 @@ class Runner:
 
 
 def make_runner(cfg) -> Tuple[object, Runner]:
+    """train.py:12-30 of the reference: with restart_behavior=resume (the default) the configuration saved in the
+    experiment directory is the base and only flags given on the command line override it.  A cfg that did not come from
+    parse_full_cfg (no `cli_args`: tests, bench) is used as it is."""
+    if getattr(cfg, "restart_behavior", "resume") == "resume" and hasattr(cfg, "cli_args"):
+        from sample_factory_amd.cfg.arguments import maybe_load_from_checkpoint
+        cfg = maybe_load_from_checkpoint(cfg)
     return cfg, Runner(cfg)
 
 

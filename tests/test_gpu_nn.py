@@ -1556,7 +1556,8 @@ def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden
     from sample_factory_amd.envs import spaces
     from sample_factory_amd.model.actor_critic import get_rnn_size
     from sample_factory_amd.model.model_factory import global_model_factory
-    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter, _TorchMultiInputEncoder
+    from sample_factory_amd.model.encoder import MultiInputEncoder as _TorchMultiInputEncoder
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter
     g = golden("train_" + name)
     E, T, A, nb = int(g["E"]), int(g["T"]), int(g["A"]), int(g["num_batches"])
     rnn_type = "gru" if name.startswith("gru") else "lstm"
