@@ -8,6 +8,7 @@ A bounded sample is timed and extrapolated linearly to one 4096-env x 32-step it
 env-steps/s = dataset size / (T x t_inference(4096 obs) + t_train(dataset)).
 
   python -m oracle.ref_cpu_tier_b [envs_sample] [inference_seconds] [threads|auto]
+  python -m oracle.ref_cpu_tier_b --procs P [envs_sample] [inference_seconds] [threads]   # P concurrent copies, pinned
   python -m oracle.ref_cpu_tier_b --device cuda [envs] [inference_seconds]
 
 `--device cuda` (context only, reported by bench.py as secondary workload "reference_torch_rocm"): the SAME reference code
@@ -103,7 +104,44 @@ def main_cuda(argv):
         miopen_find_mode=os.environ.get("MIOPEN_FIND_MODE", "default"), reference_from=ref_import.REFERENCE_ROOT)))
 
 
+def main_procs(argv):
+    """P copies of the single-process leg at once, each pinned to its own 1/P of the host cores with a fixed intra-op pool
+    — closer to "the box's host cores" than one process at its best pool size (the reference's own CPU deployment is
+    many processes too: rollout / inference / learner workers).  Every copy times the same bounded sample under the
+    others' load; value = sum of the copies' rates, each extrapolated as in the single-process leg."""
+    import subprocess
+    P = int(argv[0])
+    E = int(argv[1]) if len(argv) > 1 else 128
+    secs = argv[2] if len(argv) > 2 else "5"
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // P)
+    threads = int(argv[3]) if len(argv) > 3 and argv[3] != "auto" else per
+    procs = []
+    for i in range(P):
+        env = dict(os.environ, SF_TIER_B_PIN=",".join(str(c) for c in cores[i * per:(i + 1) * per]))
+        procs.append(subprocess.Popen([sys.executable, "-m", "oracle.ref_cpu_tier_b", str(E), secs, str(threads)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=600)
+        line = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if pr.returncode != 0 or not line:
+            raise SystemExit(f"tier-B copy failed: rc {pr.returncode}: {se[-300:]}")
+        outs.append(json.loads(line[-1]))
+    print(json.dumps(dict(
+        value=round(sum(o["value"] for o in outs), 1), unit="env-steps/s", processes=P, threads_per_process=threads,
+        cores=min(P * threads, len(cores)), host_cores=len(cores), kind="reference",
+        per_process=[o["value"] for o in outs],
+        sample=f"{P} concurrent copies of the single-process sample ({E} trajectories each), each pinned to {per} cores "
+               f"with {threads} intra-op threads; value = sum of the copies' extrapolated rates")))
+
+
 def main():
+    if "--procs" in sys.argv:
+        i = sys.argv.index("--procs")
+        return main_procs(sys.argv[i + 1:])
+    if os.environ.get("SF_TIER_B_PIN"):
+        os.sched_setaffinity(0, [int(c) for c in os.environ["SF_TIER_B_PIN"].split(",")])
     if "--device" in sys.argv:
         i = sys.argv.index("--device")
         dev = sys.argv[i + 1]

@@ -67,9 +67,9 @@ def test_async_round_split_into_two_datasets():
     assert runner.training_iteration_since_resume == 2
     assert stats["train"]["version_diff_min"] == 4.0  # second dataset: sampled 4 SGD steps before its last update
     assert runner.batcher.in_flight == 2 and len(runner._ready) == 2  # round 1's two datasets wait for the learner
-    # sync mode rejects this shape, as the reference does
-    with pytest.raises(ValueError):
-        make_runner(_synthetic_cfg(synthetic_num_agents=128, batch_size=256, num_batches_per_epoch=2))[1].init()
+    # sync mode rejects this shape the way the reference does: Runner.init() reports the invalid configuration and
+    # returns ExperimentStatus.FAILURE (algo/runners/runner.py:527-528), it does not raise
+    assert make_runner(_synthetic_cfg(synthetic_num_agents=128, batch_size=256, num_batches_per_epoch=2))[1].init() == 1
 
 
 def test_async_accumulates_and_throttles():

@@ -13,39 +13,10 @@ import numpy as np
 import pytest
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STUBS = os.path.join(ROOT, "tests", "stubs")
-EX_ZIP = os.path.join(ROOT, "oracle", "_ref", "sf_examples_ref.zip")
+from conftest import EX_ZIP, staged_scripts
+
 SCRIPTS = ["sf_examples/train_gym_env.py", "sf_examples/enjoy_gym_env.py",
            "sf_examples/train_custom_env_custom_model.py", "sf_examples/enjoy_custom_env_custom_model.py"]
-
-
-def staged_scripts(tmp_path):
-    """the reference's example scripts, byte for byte: from the staged archive (built where /root/reference exists,
-    travels to the GPU box); returns the directory to put on sys.path"""
-    if not os.path.isfile(EX_ZIP):
-        pytest.skip("oracle/_ref/sf_examples_ref.zip not staged (make -C oracle ref needs /root/reference)")
-    with zipfile.ZipFile(EX_ZIP) as z:
-        z.extractall(tmp_path)
-    return str(tmp_path)
-
-
-@pytest.fixture
-def ref_scripts(tmp_path, monkeypatch):
-    d = staged_scripts(tmp_path / "ref_scripts")
-    import sample_factory  # noqa: F401  (installs the alias finder)
-    try:
-        import gymnasium  # noqa: F401
-        if "test-stub" not in getattr(gymnasium, "__version__", ""):
-            pass  # a real gymnasium: nothing to stub
-    except ImportError:
-        monkeypatch.syspath_prepend(STUBS)
-    monkeypatch.syspath_prepend(d)
-    from sample_factory.algo.utils.context import reset_global_context
-    yield d
-    reset_global_context()
-    for m in [m for m in sys.modules if m == "sf_examples" or m.startswith("sf_examples.")]:
-        del sys.modules[m]
 
 
 def test_staged_scripts_are_the_reference_bytes():
