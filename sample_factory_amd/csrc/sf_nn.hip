@@ -1023,7 +1023,19 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     //  two per CU — also beat the register-staged kernel: 75 -> measured in profiles/r02_c5_*; the GRU's 2048 x 512 x
     //  1536 is 384 tiles)
     static const int wide_min = getenv("SF_GLDS_WIDE_MIN") ? atoi(getenv("SF_GLDS_WIDE_MIN")) : 384;
-    if (t64 >= 768 || (t64 >= wide_min && N >= 512 && K >= 256)) {
+    // Launches of a few hundred tiles — the per-split inference launches of a host-env run: conv2 at n = 512 is 324 tiles
+    // of 128 x 64, the fc layer 4 x 8 tiles of 64 x 64 — used to fall to the register-staged kernel.  Measured at
+    // n = 512 / 1024 (profiles/r05_b_kbench_small_n.log): conv2 47.6 / 84.3 us there, 40.1 / 61.4 us on 128 x 64 LDS-DMA
+    // tiles, 34.4 / 61.7 us on 64 x 64 tiles (SF_GLDS_SMALL64 = rows/64 from which they are used; 0 = off); the fc layer
+    // 170 / 52 us -> 26 / 39 us on 64 x 64 tiles split along K (SF_GLDS_SPLIT64 below).  SF_GLDS_MIN_TILES: 128 x 64
+    // tiles from which the unsplit 128-row plan is used (unchanged: 768).
+    static const int min_tiles = getenv("SF_GLDS_MIN_TILES") ? atoi(getenv("SF_GLDS_MIN_TILES")) : 768;
+    static const int small64 = getenv("SF_GLDS_SMALL64") ? atoi(getenv("SF_GLDS_SMALL64")) : 256;
+    if (small64 && t64 < 768 && N == 64 && K >= 256 && cdiv64(Mtot, 64) >= small64) {
+        p.ok = true; p.sq64 = true;  // narrow layer, few rows: 64-row tiles double the work-groups on the chip
+        return p;
+    }
+    if (t64 >= min_tiles || (t64 >= wide_min && N >= 512 && K >= 256)) {
         p.ok = true;
         if (N >= 128 && cfg == 0) {  // efficiency = rounds / ceil(rounds) with the kernel's own occupancy
             const double u64 = (double)t64 / (256.0 * occ64), u128 = (double)t128 / (256.0 * occ128);
@@ -1036,6 +1048,26 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     if (fc64 == 1 && N >= 128 && K >= 1024 && cdiv64(Mtot, 64) * (int64_t)cdiv64(N, 64) >= 512) {
         p.ok = true; p.sq64 = true;  // two 64x64 work-groups per CU, the whole reduction in one pass, no partial sums
         return p;
+    }
+    // a wide layer on very few rows (the fc layer of a 512-sample inference launch: 4 x 8 tiles of 64 x 64): 64 x 64
+    // tiles split along K until ~2 work-groups per CU exist.  SF_GLDS_SPLIT64=<min 64x64 tiles> (0 = off)
+    static const int split64 = getenv("SF_GLDS_SPLIT64") ? atoi(getenv("SF_GLDS_SPLIT64")) : 32;
+    const int64_t t6464 = cdiv64(Mtot, 64) * (int64_t)cdiv64(N, 64);
+    if (split64 && split_on && N >= 128 && K >= 1024 && t6464 >= split64 && t6464 < 512) {
+        int z = (int)((512 + t6464 - 1) / t6464);
+        const int zmax = K / 256;
+        z = z > zmax ? zmax : z;
+        z = z > 16 ? 16 : z;
+        if (z > 1) {
+            const int chunks = (K + 31) / 32;
+            p.k_per_split = ((chunks + z - 1) / z) * 32;
+            p.Z = (K + p.k_per_split - 1) / p.k_per_split;
+            if (p.Z > 1) {
+                p.ok = true; p.sq64 = true;
+                return p;
+            }
+            p.Z = 1; p.k_per_split = (K + 31) / 32 * 32;
+        }
     }
     if (split_on && N >= 128 && K >= 1024 && t128 >= 32) {
         const int slots = 256 * occ128;

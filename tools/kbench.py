@@ -22,8 +22,11 @@ def timeit(fn, reps):
 
 def main():
     which = sys.argv[1:] or ["fwd", "wgrad", "dgrad"]
-    for n in (4096, 32768):
+    ns = [int(v) for v in os.environ["KBENCH_NS"].split(",")] if os.environ.get("KBENCH_NS") else [4096, 32768]
+    only = os.environ.get("KBENCH_LAYERS", "").split(",") if os.environ.get("KBENCH_LAYERS") else None
+    for n in ns:
         for name, d in LAYERS:
+            if only and name not in only: continue
             K = d.KH*d.KW*d.Cin
             M = n*d.OH*d.OW
             flops = 2.0*M*d.Cout*K
@@ -31,7 +34,7 @@ def main():
             else: x = torch.randn((n,d.H,d.W,d.Cin),device="cuda")
             w = torch.randn((K,d.Cout),device="cuda")/np.sqrt(K); b = torch.zeros(d.Cout,device="cuda")
             out = torch.empty((M,d.Cout),device="cuda"); dy = torch.randn((M,d.Cout),device="cuda")
-            reps = 20 if n == 4096 else 5
+            reps = 5 if n >= 32768 else (20 if n >= 4096 else 100)
             stride = d.Cin*d.H*d.W
             res = []
             if "fwd" in which:
