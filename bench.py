@@ -138,9 +138,9 @@ def secondary_lines(args):
     timed steps bracketed by synchronize, whole-job env-steps/s, roofline of that run's dominant kernel."""
     import subprocess
     out = []
-    for wl, steps, warm in (("c5", 6, 2), ("c3", 4, 2)):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(steps), "--warmup", str(warm),
-               "--no_cpu_baseline", "--no_secondary"]
+    for wl, steps, warm in (("c5", 6, 2), ("c3", 4, 2), ("c2_normalize_input", 4, 2)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl.split("_")[0], "--steps", str(steps), "--warmup",
+               str(warm), "--no_cpu_baseline", "--no_secondary"] + (["--normalize_input"] if wl.endswith("normalize_input") else [])
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=150)
@@ -269,13 +269,16 @@ def workload_cfg(args, rank, world):
     if args.workload == "c2":
         cfg = default_cfg(
             env="synthetic_atari", use_rnn=False, recurrence=1, encoder_conv_architecture="convnet_atari",
-            nonlinearity="relu", encoder_conv_mlp_layers=[512], obs_scale=255.0, normalize_input=False,
-            normalize_returns=True, gamma=0.99, gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0,
+            nonlinearity="relu", encoder_conv_mlp_layers=[512], obs_scale=255.0,
+            normalize_input=bool(args.normalize_input), normalize_returns=True, gamma=0.99, gae_lambda=0.95, ppo_clip_ratio=0.1, ppo_clip_value=1.0,
             value_loss_coeff=0.5, exploration_loss_coeff=0.01, max_grad_norm=4.0, learning_rate=1e-4, adam_eps=1e-6,
             synthetic_env0=rank * B, **common)
         desc = (f"BASELINE.json configs[1]: synthetic vector env {B} envs/GPU, 84x84x4 u8 obs, Discrete(6), Nature-CNN "
                 f"actor-critic (1,687,719 params), APPO {mode}, rollout={T}, batch_size={cfg.batch_size} x "
                 f"{args.num_batches} minibatches x {args.num_epochs} epoch(s)")
+        if args.normalize_input:
+            desc += (", normalize_input=True (the reference's default: per-pixel running mean / std of the frames, moments "
+                     "in one pass over the u8 slab, normalisation inside conv1's loader — no f32 copy of the frames)")
         return cfg, "synthetic_atari", make_synthetic_env, desc, "env-steps/sec (whole node), 4096 envs, 84x84x4 obs"
     if args.workload == "c5":  # sf_examples/mujoco/mujoco_params.py:1-38 + LSTM core + V-trace
         cfg = default_cfg(
@@ -354,6 +357,8 @@ def main():
     ap.add_argument("--sync_rl", action="store_true", help="c3: synchronous instead of the configuration's async mode")
     ap.add_argument("--one_instance", action="store_true", help="c3: a single env instance (no double-buffered sampling)")
     ap.add_argument("--async_rl", action="store_true", help="overlap rollout k+1 with train(k) (policy lag of one dataset)")
+    ap.add_argument("--normalize_input", action="store_true",
+                    help="c2 with cfg.normalize_input=True (the reference's default; BASELINE configs[1] / NS-2 runs with False)")
     args = ap.parse_args()
     if args.envs is None:
         args.envs = dict(c2=4096, c5=2048, c3=1024)[args.workload]

@@ -359,6 +359,25 @@ int sf_conv_wgrad_relu_mask(const void *in, int64_t in_sample_stride, const int3
                             const float *dout, const uint32_t *relu_mask, float *dw, float *db, int64_t n,
                             const sf_conv_desc *h_desc, void *workspace, void *stream);
 
+/* First conv layer on raw u8 frames WITH the observation normaliser applied in the loader — cfg.normalize_input=True on
+ * image observations (cfg/cfg.py:337-341: the default; sf_examples/atari/atari_params.py:39).  Replaces, for the launches
+ * it takes, the reference's f32 materialisation of every frame (utils/normalize.py:40-70: obs.float() clone, sub_, mul_;
+ * running_mean_std.py:79-110: x.sub_(mu).mul_(1/sigma).clamp_(-5, 5)) followed by conv1 (model/encoder.py:90-119):
+ * x' = clamp(((float(u8) - sub_mean) * inv_scale - mu[d]) * rstd[d], +-5) is formed where the byte enters LDS, d = the
+ * byte's offset inside the NCHW frame; mu / rstd = the f32 tables [Cin*H*W] sf_obsnorm_update maintains (16-byte
+ * aligned).  No normalised copy of the frames exists in HBM (28 KB instead of 28 + 2 x 113 KB per
+ * frame and pass).  sf_conv_wgrad_norm = the weight / bias gradient against the same normalised input (dout already
+ * masked by the activation derivative; workspace >= sf_conv_wgrad_workspace bytes).  sf_conv_norm_supported: 1 for the
+ * launches these take (Nature-CNN conv1 geometry 4x84x84 -> 32, 8x8 stride 4, any n); otherwise sf_obsnorm_apply +
+ * sf_conv_fwd on the f32 batch.  Sample addressing (index | offset, traj_T) as sf_conv_fwd. */
+int sf_conv_norm_supported(int64_t n, const sf_conv_desc *h_desc);
+int sf_conv_fwd_norm(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *mu,
+                     const float *rstd, const float *w, const float *bias, float *out, int64_t n,
+                     const sf_conv_desc *h_desc, void *stream);
+int sf_conv_wgrad_norm(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset, const float *mu,
+                       const float *rstd, const float *dout, float *dw, float *db, int64_t n, const sf_conv_desc *h_desc,
+                       void *workspace, void *stream);
+
 /* Inference on vector observations in one launch: [(x - sub_mean) * inv_scale -> (optional) running mean/std
  * normalisation with clamp +-5] -> act(x W1 + b1) -> act(. W2 + b2); utils/normalize.py:24-70 + model/encoder.py:72-87
  * (MlpEncoder with two layers).  x: f32 rows of D values, x_stride floats apart (e.g. slab obs[:, t]); w1 [D, H1], w2

@@ -556,6 +556,16 @@ def gen_train_cnn84():
               p_other_policy=0.05, extra=["--exploration_loss_coeff=0.01"], fp64_first_step=True)
 
 
+def gen_train_cnn84_norm():
+    """train_cnn84 with cfg.normalize_input=True (the reference's default, cfg/cfg.py:337-341): the observation normaliser's
+    per-pixel running statistics are updated on the dataset and applied to every frame in front of conv1
+    (utils/normalize.py:40-70, running_mean_std.py:64-110) — the replay the loader-fused conv1 (sf_conv_fwd_norm) is held to."""
+    obs = gym.spaces.Dict({"obs": gym.spaces.Box(0, 255, (4, 84, 84), np.uint8)})
+    args = [a for a in C2_MODEL_ARGS if not a.startswith("--normalize_input")] + ["--normalize_input=True"]
+    gen_train("cnn84_norm", obs, args, E=64, T=32, A=6, nb=2, epochs=1, subsample=37, obs_seed=8485,
+              p_other_policy=0.05, extra=["--exploration_loss_coeff=0.01"], fp64_first_step=True)
+
+
 def gen_train_cnn84_32k():
     """The reference's Learner.train at the LAUNCH SIZE of the headline number: Nature-CNN on 84x84x4 u8 frames, E = 1024
     trajectories x T = 32 = ONE minibatch of 32768 samples (BASELINE configs[1] / NS-2's batch_size), two epochs = two SGD
@@ -1013,6 +1023,8 @@ def main():
         gen_ref_checkpoint()
     if "cnn84" in which:
         gen_train_cnn84()
+    if "cnn84_norm" in which:
+        gen_train_cnn84_norm()
     if "cnn84_32k" in which:
         gen_train_cnn84_32k()
     if "c5" in which:

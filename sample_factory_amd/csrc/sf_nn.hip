@@ -65,6 +65,7 @@ struct ConvG {
     float sub_mean, inv_scale;
     int K;          // KH*KW*Cin
     int vecA, vecB; // vector (16-byte / 4-byte-of-u8) loads legal for the activation / [*,Cout] operands
+    const float *nmu, *nrstd;  // sf_conv_fwd_norm / sf_conv_wgrad_norm: the observation normaliser's f32 tables, else NULL
     FastDiv dOHOW, dOW, dCin, dKW, dKHKW, dT, dCout;
     FastDiv dHcWc[16], dWc[16], dKWs[16];  // data-gradient stride-parity classes (S*S <= 16)
 };
@@ -74,6 +75,7 @@ static ConvG make_geom(const sf_conv_desc *d) {
     g.Cin = d->Cin; g.H = d->H; g.W = d->W; g.Cout = d->Cout; g.KH = d->KH; g.KW = d->KW; g.S = d->stride;
     g.OH = d->OH; g.OW = d->OW; g.in_u8 = d->in_u8; g.relu = d->relu; g.traj_T = d->traj_T;
     g.sub_mean = d->sub_mean; g.inv_scale = d->inv_scale;
+    g.nmu = nullptr; g.nrstd = nullptr;
     g.K = d->KH * d->KW * d->Cin;
     g.vecA = d->in_u8 ? (d->KW % 4 == 0 && d->stride % 4 == 0 && d->W % 4 == 0) : (d->Cin % 4 == 0);
     g.vecB = d->Cout % 4 == 0;
@@ -764,6 +766,7 @@ __global__ __launch_bounds__(256) void k_relu_mask(float *__restrict__ gsrc, con
         if (!(act[i] > 0.f)) gsrc[i] = 0.f;
 }
 
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 #include "sf_nn_glds.h"
 #include "sf_nn_img.h"
 #include "sf_nn_u8.h"
@@ -775,9 +778,9 @@ static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b -
 
 // resident blocks per CU of a 256-thread kernel (registers + static LDS), for grid-quantisation decisions
 template <class KernelT>
-static int occupancy_of(KernelT kern, int threads = 256) {
+static int occupancy_of(KernelT kern, int threads = 256, size_t dyn_lds = 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, 0) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, dyn_lds) != hipSuccess || nb < 1) nb = 2;
     (void)hipGetLastError();
     return nb;
 }
@@ -1457,6 +1460,69 @@ extern "C" int sf_conv_wgrad_relu_mask(const void *in, int64_t in_sample_stride,
                    ((uintptr_t)dout & 15) == 0,
                "sf_conv_wgrad_relu_mask: unsupported layer / launch (see sf_conv_relu_mask_supported)");
     return conv_wgrad_impl(in, in_sample_stride, index, offset, dout, relu_mask, dw, db, n, h_desc, workspace, stream);
+}
+
+// ---- conv1 on raw u8 frames WITH the observation normaliser's running statistics applied in the loader (cfg.normalize_input
+// on image observations: utils/normalize.py:51-70, running_mean_std.py:79-110, cfg/cfg.py:337-341 default True): no
+// normalised f32 copy of the frames exists anywhere.  mu / rstd: the normaliser's f32 tables [Cin*H*W] in the frame's NCHW
+// order (sf_obsnorm_update writes them).  Launches sf_conv_norm_supported() accepts: the Nature-CNN conv1 geometry the
+// strip-image kernels are built for, n >= 256, 4-byte aligned frames; everything else goes through sf_obsnorm_apply.
+static bool conv_norm_ok(const sf_conv_desc *d, int64_t n) {
+    static const int on = getenv("SF_CONV1_NORM") ? atoi(getenv("SF_CONV1_NORM")) : 1;
+    if (!on || !d || n <= 0 || !d->in_u8 || d->Cout != 32) return false;
+    const ConvG g = make_geom(d);
+    // the strip kernels' compile-time geometry; ANY n (their n >= 256 dispatch threshold is a speed heuristic of the plain
+    // entry points, the kernels themselves are correct for every n >= 1 and there is no other kernel to fall back to)
+    return pick_mode(g) == MODE_U8 && g.Cin == 4 && g.H == 84 && g.W == 84 && g.KH == 8 && g.KW == 8 && g.S == 4;
+}
+extern "C" int sf_conv_norm_supported(int64_t n, const sf_conv_desc *h_desc) {
+    return h_desc && check_desc(h_desc, "sf_conv_norm_supported") == 0 && conv_norm_ok(h_desc, n) ? 1 : 0;
+}
+extern "C" int sf_conv_fwd_norm(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                                const float *mu, const float *rstd, const float *w, const float *bias, float *out,
+                                int64_t n, const sf_conv_desc *h_desc, void *stream) {
+    int rc = check_desc(h_desc, "sf_conv_fwd_norm");
+    if (rc) return rc;
+    SF_REQUIRE(in && mu && rstd && w && out && n > 0, "sf_conv_fwd_norm: bad args");
+    SF_REQUIRE(conv_norm_ok(h_desc, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0 &&
+                   ((uintptr_t)mu & 15) == 0 && ((uintptr_t)rstd & 15) == 0,
+               "sf_conv_fwd_norm: unsupported layer / launch (see sf_conv_norm_supported; frames 4-byte, tables 16-byte aligned)");
+    ConvG g = make_geom(h_desc);
+    g.nmu = mu; g.nrstd = rstd;
+    SF_REQUIRE(n * g.OH * g.OW < (1LL << 31), "sf_conv_fwd_norm: M exceeds 2^31 rows; split the batch");
+    const unsigned lds_bytes = (unsigned)(2 * 4 * 20 * 84 * sizeof(float));
+    static const int bpc = occupancy_of(k_conv_u8_img_norm<2, 4, 5, 16>, 256, lds_bytes);
+    const int64_t npairs = cdiv64(n, 2), resident = (int64_t)num_cus() * (bpc > 0 ? bpc : 1);
+    k_conv_u8_img_norm<2, 4, 5, 16><<<dim3((unsigned)(npairs < resident ? npairs : resident)), dim3(256), lds_bytes, STREAM(stream)>>>(
+        g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, (int)n);
+    return sf_launch_status("sf_conv_fwd_norm");
+}
+extern "C" int sf_conv_wgrad_norm(const void *in, int64_t in_sample_stride, const int32_t *index, int64_t offset,
+                                  const float *mu, const float *rstd, const float *dout, float *dw, float *db, int64_t n,
+                                  const sf_conv_desc *h_desc, void *workspace, void *stream) {
+    int rc = check_desc(h_desc, "sf_conv_wgrad_norm");
+    if (rc) return rc;
+    SF_REQUIRE(in && mu && rstd && dout && dw && workspace && n > 0, "sf_conv_wgrad_norm: bad args");
+    SF_REQUIRE(conv_norm_ok(h_desc, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0 &&
+                   ((uintptr_t)mu & 15) == 0 && ((uintptr_t)rstd & 15) == 0 && ((uintptr_t)dout & 15) == 0 &&
+                   ((uintptr_t)workspace & 15) == 0,
+               "sf_conv_wgrad_norm: unsupported layer / launch (see sf_conv_norm_supported)");
+    ConvG g = make_geom(h_desc);
+    g.nmu = mu; g.nrstd = rstd;
+    const int K = g.K, N = g.Cout;
+    const int Zws = plan_splits(n * g.OH * g.OW, K, N, 128, wgrad_bn(N)).Z;  // what sf_conv_wgrad_workspace promised room for
+    const int npairs = (int)((n + 1) / 2);
+    int nb = npairs < 512 ? npairs : 512;
+    if (nb > Zws) nb = Zws;
+    float *partial_w = reinterpret_cast<float *>(workspace), *partial_b = partial_w + (int64_t)nb * K * N;
+    const unsigned lds_bytes = (unsigned)((160 * 32 + 2 * 4 * 20 * 84) * sizeof(float));
+    hipStream_t st = STREAM(stream);
+    k_conv1_wgrad_img_norm<2, 4><<<dim3(nb), dim3(256), lds_bytes, st>>>(
+        g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, dout, partial_w, db ? partial_b : nullptr,
+        (int)n, npairs);
+    launch_reduce_partials(partial_w, dw, (int64_t)K * N, nb, st);
+    if (db) launch_reduce_partials(partial_b, db, N, nb, st);
+    return sf_launch_status("sf_conv_wgrad_norm");
 }
 
 #define DGRAD_LAUNCH(BM, BN, WM, WN)                                                                          \

@@ -758,11 +758,18 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
 // Reduction order inside a 16-group: MFMA j consumes k = 16g + 4*kg + j from lane group kg (A and B agree on it).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SMP, int R, int TMF, int KG, bool SUB>
-__global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
-                                                     const int32_t *__restrict__ index, int64_t offset,
-                                                     const float *__restrict__ w, const float *__restrict__ bias,
-                                                     float *__restrict__ out, int nsamples) {
+// NORM (sf_conv_fwd_norm): cfg.normalize_input=True on raw frames — the running-statistics normalisation of
+// utils/normalize.py:51-70 + running_mean_std.py:79-110, v = clamp(((x - sub) * 1/scale - mu[d]) * rstd[d], +-5), happens
+// HERE, where the byte becomes an f32 in LDS, instead of in a pass of its own that writes (and conv1 then re-reads) a
+// 113 KB f32 copy of every 28 KB frame.  d = the byte's NCHW offset inside the frame, mu / rstd = the normaliser's f32
+// tables [Cin*H*W] (g.nmu, g.nrstd).  The table words of a strip depend on the strip only, so with NORM the work-group
+// walks its units STRIP-major (all its sample pairs at strip 0, then strip 1, ...) and keeps the strip's table words
+// in registers: the tables are fetched 5 times per work-group and launch, not once per unit.
+template <int SMP, int R, int TMF, int KG, bool SUB, bool NORM>
+__device__ __forceinline__ void conv_u8_img_body(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                 const int32_t *__restrict__ index, int64_t offset,
+                                                 const float *__restrict__ w, const float *__restrict__ bias,
+                                                 float *__restrict__ out, int nsamples) {
     extern __shared__ __attribute__((aligned(16))) float strip[];  // [SMP][Cin][RS][W] f32
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave >> 1, wn = wave & 1;
@@ -798,8 +805,14 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
         lofs[i] = ok ? (c * RS + row) * W + x4 * 4 : -1;
     }
     uint32_t pre[SMP][NLD];
+    f32x4 tmu[NORM ? NLD : 1], trs[NORM ? NLD : 1];  // NORM: this strip's table words of the thread's NLD image words
+    auto decode = [&](int unit, int &lp, int &st) {  // unit -> (local pair, strip): pair-major, NORM strip-major
+        if (NORM) { st = unit / my_pairs; lp = unit - st * my_pairs; }
+        else { lp = unit / nstrips; st = unit - lp * nstrips; }
+    };
     auto load_strip = [&](int unit) {
-        const int lp = unit / nstrips, st = unit - lp * nstrips;
+        int lp, st;
+        decode(unit, lp, st);
         const int s0u = ((int)blockIdx.x + lp * (int)gridDim.x) * SMP;
         const int rowoff = st * R * S * W;
 #pragma unroll
@@ -809,6 +822,13 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
             const uint8_t *sb = in + sample_base(g, index, offset, in_stride, (uint32_t)sg);  // wave-uniform
 #pragma unroll
             for (int i = 0; i < NLD; ++i) pre[z][i] = *reinterpret_cast<const uint32_t *>(sb + rowoff + gofs[i]);
+        }
+        if (NORM && lp == 0) {  // first unit of a strip (the previous strip's last store_strip is over)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                tmu[i] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(g.nmu + rowoff + gofs[i], 16));
+                trs[i] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(g.nrstd + rowoff + gofs[i], 16));
+            }
         }
     };
     const float sub = g.sub_mean, scl = g.inv_scale;
@@ -822,6 +842,7 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
                 for (int j = 0; j < 4; ++j) {
                     const float b8 = (float)((pre[z][i] >> (8 * j)) & 0xFFu);
                     v[j] = (SUB ? b8 - sub : b8) * scl;  // SUB = false: mean == 0 (x - 0 is exact anyway)
+                    if (NORM) v[j] = clampf((v[j] - tmu[i][j]) * trs[i][j], -5.0f, 5.0f);  // k_obsnorm_apply's arithmetic
                 }
                 if (lofs[i] >= 0)
                     *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(strip + z * Cin * RS * W + lofs[i], 16)) = v;
@@ -853,7 +874,8 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
     }
     const uint32_t voff = (uint32_t)(4 * (lane >> 4)) * (uint32_t)N + (uint32_t)col;
     for (int unit = 0; unit < total_units; ++unit) {
-        const int lp = unit / nstrips, st = unit - lp * nstrips;
+        int lp, st;
+        decode(unit, lp, st);
         const int s0 = ((int)blockIdx.x + lp * (int)gridDim.x) * SMP;
         store_strip();  // first use of the prefetched bytes
         __syncthreads();
@@ -901,6 +923,21 @@ __global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__r
         else epilogue(std::integral_constant<int, -1>{});
         __syncthreads();  // everybody is done reading this strip before it is overwritten
     }
+}
+
+template <int SMP, int R, int TMF, int KG, bool SUB>
+__global__ __launch_bounds__(256) void k_conv_u8_img(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                     const int32_t *__restrict__ index, int64_t offset,
+                                                     const float *__restrict__ w, const float *__restrict__ bias,
+                                                     float *__restrict__ out, int nsamples) {
+    conv_u8_img_body<SMP, R, TMF, KG, SUB, false>(g, in, in_stride, index, offset, w, bias, out, nsamples);
+}
+template <int SMP, int R, int TMF, int KG>
+__global__ __launch_bounds__(256) void k_conv_u8_img_norm(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                          const int32_t *__restrict__ index, int64_t offset,
+                                                          const float *__restrict__ w, const float *__restrict__ bias,
+                                                          float *__restrict__ out, int nsamples) {
+    conv_u8_img_body<SMP, R, TMF, KG, true, true>(g, in, in_stride, index, offset, w, bias, out, nsamples);
 }
 
 // ============================================================================================== DATA GRADIENT, stride groups
@@ -1126,11 +1163,13 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
 // Blocks are persistent over sample pairs; the four waves' accumulators are summed through LDS at the end and written
 // as ONE partial per block (reduced by k_reduce_partials, deterministic).  The bias gradient (column sums of dY) rides
 // along from the LDS copy of dY.
-template <int SMP, int R, bool SUB>
-__global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
-                                                           const int32_t *__restrict__ index, int64_t offset,
-                                                           const float *__restrict__ dy, float *__restrict__ partial,
-                                                           float *__restrict__ partial_b, int nsamples, int npairs) {
+// NORM (sf_conv_wgrad_norm): x is the NORMALISED observation, formed from the byte and the normaliser's tables on the way
+// into LDS exactly as in the forward kernel above (same strip-major unit order, same table registers).
+template <int SMP, int R, bool SUB, bool NORM>
+__device__ __forceinline__ void conv1_wgrad_img_body(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                     const int32_t *__restrict__ index, int64_t offset,
+                                                     const float *__restrict__ dy, float *__restrict__ partial,
+                                                     float *__restrict__ partial_b, int nsamples, int npairs) {
     constexpr int H = 84, W = 84, Cin = 4, KH = 8, KW = 8, S = 4, OH = 20, OW = 20, OHOW = OH * OW, N = 32, K = 256;
     constexpr int RS = (R - 1) * S + KH, W4 = W >> 2, NLD = 7;
     constexpr int ROWS = SMP * R * OW;       // output pixels per strip (160)
@@ -1180,12 +1219,21 @@ __global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8
             sbase[z] = in + sample_base(g, index, offset, in_stride, (uint32_t)sg);
         }
     };
+    f32x4 tmu[NORM ? NLD : 1], trs[NORM ? NLD : 1];
     auto load_strip = [&](int st) {
         const int rowoff = st * R * S * W;
 #pragma unroll
         for (int z = 0; z < SMP; ++z)
 #pragma unroll
             for (int i = 0; i < NLD; ++i) pre[z][i] = *reinterpret_cast<const uint32_t *>(sbase[z] + rowoff + gofs[i]);
+    };
+    auto load_tables = [&](int st) {
+        const int rowoff = st * R * S * W;
+#pragma unroll
+        for (int i = 0; i < (NORM ? NLD : 0); ++i) {
+            tmu[i] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(g.nmu + rowoff + gofs[i], 16));
+            trs[i] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(g.nrstd + rowoff + gofs[i], 16));
+        }
     };
     auto store_strip = [&]() {
 #pragma unroll
@@ -1197,6 +1245,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8
                 for (int j = 0; j < 4; ++j) {
                     const float b8 = (float)((pre[z][i] >> (8 * j)) & 0xFFu);
                     v[j] = (SUB ? b8 - sub : b8) * scl;
+                    if (NORM) v[j] = clampf((v[j] - tmu[i][j]) * trs[i][j], -5.0f, 5.0f);
                 }
                 if (lofs[i] >= 0)
                     *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(strip + z * Cin * RS * W + lofs[i], 16)) = v;
@@ -1216,16 +1265,33 @@ __global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8
         }
     };
     constexpr int nstrips = OH / R;
-    int pair = blockIdx.x;
-    if (pair < npairs) { set_pair(pair); load_strip(0); dma_dy(pair, 0); }
-    for (; pair < npairs; pair += gridDim.x) {
-        for (int st = 0; st < nstrips; ++st) {
+    // unit = (pair of this work-group, strip): pair-major (strip fastest), NORM strip-major (the table registers change 5
+    // times per launch)
+    const int my_pairs = (int)blockIdx.x < npairs ? (npairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total_units = my_pairs * nstrips;
+    auto decode = [&](int unit, int &pr, int &st) {
+        int lp;
+        if (NORM) { st = unit / my_pairs; lp = unit - st * my_pairs; }
+        else { lp = unit / nstrips; st = unit - lp * nstrips; }
+        pr = (int)blockIdx.x + lp * (int)gridDim.x;
+    };
+    int pair = blockIdx.x, st = 0;
+    if (total_units > 0) { set_pair(pair); load_tables(0); load_strip(0); dma_dy(pair, 0); }
+    for (int unit = 0; unit < total_units; ++unit) {
+        {
+            decode(unit, pair, st);
+            int npair = pair, nst = st;
+            const bool more = unit + 1 < total_units;
+            if (more) decode(unit + 1, npair, nst);
             store_strip();  // VALU + ds_write: runs while this strip's dY DMA (issued one phase ago) is in flight
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // prefetch the next strip's bytes (next strip of this pair, or strip 0 of the block's next pair)
-            if (st + 1 < nstrips) load_strip(st + 1);
-            else if (pair + (int)gridDim.x < npairs) { set_pair(pair + gridDim.x); load_strip(0); }
+            // prefetch the next unit's bytes (and, NORM, the next strip's table words: this strip's last use is over)
+            if (more) {
+                if (npair != pair) set_pair(npair);
+                if (NORM && nst != st) load_tables(nst);
+                load_strip(nst);
+            }
             if (partial_b) {  // bias gradient: thread (n, part) sums every 8th row; parts are combined at the end
 #pragma unroll 4
                 for (int m = tid >> 5; m < ROWS; m += 8) colacc += dys[m * N + (tid & 31)];
@@ -1246,8 +1312,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8
                 }
             }
             __syncthreads();  // strip and dys are free again
-            if (st + 1 < nstrips) dma_dy(pair, st + 1);
-            else if (pair + (int)gridDim.x < npairs) dma_dy(pair + gridDim.x, 0);
+            if (more) dma_dy(npair, nst);
         }
     }
     // ---- block reduction of the four waves' accumulators (fixed order: wave 0 + 1 + 2 + 3), then one partial per block
@@ -1296,4 +1361,18 @@ __global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8
             partial_b[(int64_t)blockIdx.x * N + tid] = sum;
         }
     }
+}
+template <int SMP, int R, bool SUB>
+__global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                           const int32_t *__restrict__ index, int64_t offset,
+                                                           const float *__restrict__ dy, float *__restrict__ partial,
+                                                           float *__restrict__ partial_b, int nsamples, int npairs) {
+    conv1_wgrad_img_body<SMP, R, SUB, false>(g, in, in_stride, index, offset, dy, partial, partial_b, nsamples, npairs);
+}
+template <int SMP, int R>
+__global__ __launch_bounds__(256, 2) void k_conv1_wgrad_img_norm(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
+                                                                const int32_t *__restrict__ index, int64_t offset,
+                                                                const float *__restrict__ dy, float *__restrict__ partial,
+                                                                float *__restrict__ partial_b, int nsamples, int npairs) {
+    conv1_wgrad_img_body<SMP, R, true, true>(g, in, in_stride, index, offset, dy, partial, partial_b, nsamples, npairs);
 }

@@ -43,7 +43,7 @@ SYMBOLS = [
     "sf_obsnorm_moments", "sf_obsnorm_update", "sf_obsnorm_apply", "sf_sample_write_step",
     "sf_sample_write_step_tuple", "sf_sample_write_step_masked", "sf_traj_write_env_step", "sf_synth_obs",
     "sf_synth_step", "sf_synth_vec_step", "sf_h2d_rows", "sf_copy_rows", "sf_conv_fwd", "sf_conv_fwd_workspace", "sf_conv_wgrad_workspace", "sf_conv_wgrad",
-    "sf_conv_dgrad", "sf_conv_relu_mask_supported", "sf_conv_fwd_relu_mask", "sf_conv_wgrad_relu_mask", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
+    "sf_conv_dgrad", "sf_conv_norm_supported", "sf_conv_fwd_norm", "sf_conv_wgrad_norm", "sf_conv_relu_mask_supported", "sf_conv_fwd_relu_mask", "sf_conv_wgrad_relu_mask", "sf_conv_kernel_name", "sf_conv_fwd_t_supported", "sf_conv_fwd_t_workspace", "sf_conv_fwd_t", "sf_transpose",
     "sf_tanh_scale_fwd", "sf_tanh_scale_bwd",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
     "sf_dp_unique_id", "sf_dp_comm_create", "sf_dp_comm_destroy", "sf_dp_comm_info", "sf_allreduce_grads",
@@ -692,6 +692,32 @@ def conv_wgrad_relu_mask(inp, in_sample_stride, index, offset, dout, relu_mask, 
                                               i64(offset), ptr(dout, "f32", "dout"), ptr(relu_mask, "i32", "relu_mask"),
                                               ptr(dw, "f32", "dw"), ptr(db, "f32", "db"), i64(n), C.byref(desc),
                                               ptr(workspace, "u8", "workspace"), stream()), "sf_conv_wgrad_relu_mask")
+
+
+def conv_norm_supported(n, desc: sf_conv_desc) -> bool:
+    return bool(load().sf_conv_norm_supported(i64(n), C.byref(desc)))
+
+
+def _nkey(op, n, desc, name):
+    k = _dkey(op, n, desc)
+    return None if k is None else k[:-1] + (name,)
+
+
+def conv_fwd_norm(inp, in_sample_stride, index, offset, mu, rstd, w, bias, out, n, desc: sf_conv_desc) -> None:
+    """conv1 on raw u8 frames with the observation normaliser's tables applied in the loader (sf_conv_fwd_norm)"""
+    with _timed(_nkey("fwd", n, desc, "k_conv_u8_img_norm<2, 4, 5, 16>")):
+        _check(load().sf_conv_fwd_norm(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"), i64(offset),
+                                       ptr(mu, "f32", "mu"), ptr(rstd, "f32", "rstd"), ptr(w, "f32", "w"),
+                                       ptr(bias, "f32", "bias"), ptr(out, "f32", "out"), i64(n), C.byref(desc),
+                                       stream()), "sf_conv_fwd_norm")
+
+
+def conv_wgrad_norm(inp, in_sample_stride, index, offset, mu, rstd, dout, dw, db, n, desc: sf_conv_desc, workspace) -> None:
+    with _timed(_nkey("wgrad", n, desc, "k_conv1_wgrad_img_norm<2, 4>")):
+        _check(load().sf_conv_wgrad_norm(_raw_in(inp, desc), i64(in_sample_stride), ptr(index, "i32", "index"),
+                                         i64(offset), ptr(mu, "f32", "mu"), ptr(rstd, "f32", "rstd"),
+                                         ptr(dout, "f32", "dout"), ptr(dw, "f32", "dw"), ptr(db, "f32", "db"), i64(n),
+                                         C.byref(desc), ptr(workspace, "u8", "workspace"), stream()), "sf_conv_wgrad_norm")
 
 
 def conv_dgrad(dout, w, in_act, din, n, desc: sf_conv_desc) -> None:

@@ -33,6 +33,7 @@ from sample_factory_amd.envs.spaces import is_box, calc_num_action_parameters, i
 import os
 
 _LSTM_SEQ = os.environ.get("SF_LSTM_SEQ", "1") != "0"  # A/B switch: 0 = per-step launches instead of the fused passes
+_CONV1_NORM = os.environ.get("SF_CONV1_NORM", "1") != "0"  # A/B switch: 0 = normalised f32 copy of the frames + f32 conv1
 _MLP2 = os.environ.get("SF_MLP2", "1") != "0"          # A/B switch: 0 = layer-by-layer encoder in the rollout as well
 
 ACT_KIND = {"relu": 1, "tanh": 2, "elu": 3}  # model/model_utils.py:27-35; fused into the GEMM epilogues
@@ -150,6 +151,7 @@ class ActorCritic:
         if abs(sub_mean) <= 1e-5:
             sub_mean = 0.0
 
+        self._fused_norm = False
         if len(self.obs_shape) == 3:
             C, H, W = self.obs_shape
             if not self.obs_u8:
@@ -158,7 +160,14 @@ class ActorCritic:
             cin, h, w = C, H, W
             for i, (cout, k, s) in enumerate(CONV_ARCHS[cfg.encoder_conv_architecture]):
                 oh, ow = (h - k) // s + 1, (w - k) // s + 1
-                first = i == 0 and not norm_input  # normalised frames arrive as f32 NHWC (utils/normalize.py)
+                # normalize_input=True: the Nature-CNN conv1 geometry normalises INSIDE conv1's loader (sf_conv_fwd_norm /
+                # sf_conv_wgrad_norm: frames stay u8, first layer keeps its raw-frame form); any other first layer reads a
+                # materialised normalised f32 NHWC batch (utils/normalize.py)
+                if i == 0 and norm_input and _CONV1_NORM:
+                    probe = lib.sf_conv_desc(Cin=cin, H=h, W=w, Cout=cout, KH=k, KW=k, stride=s, OH=oh, OW=ow, in_u8=1,
+                                             relu=act, traj_T=0, sub_mean=sub_mean, inv_scale=inv_scale)
+                    self._fused_norm = bool(lib.conv_norm_supported(1, probe))
+                first = i == 0 and (not norm_input or self._fused_norm)
                 desc = lib.sf_conv_desc(Cin=cin, H=h, W=w, Cout=cout, KH=k, KW=k, stride=s, OH=oh, OW=ow,
                                         in_u8=int(first), relu=act, traj_T=0,
                                         sub_mean=sub_mean if first else 0.0, inv_scale=inv_scale if first else 1.0)
@@ -520,11 +529,18 @@ class ActorCritic:
             acts[1] = out
             x, stride, idx, off, tT = out, self.layers[1].N, None, 0, 0
             first_layer = 2
-        elif self.obs_normalizer is not None:  # normalize_input=True: materialise the normalised f32 batch (NHWC)
-            xn = self._buf((tag, "obsn"), (n, self.obs_elems))
+        norm_tabs = None
+        if self.obs_normalizer is not None and first_layer == 0:  # normalize_input=True
+            on = self.obs_normalizer
             tabs = self._snap_tabs[self.snap_read] if (tag.startswith("inf") and self._snap is not None) else None
-            self.obs_normalizer.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T, tabs=tabs)
-            x, stride, idx, off, tT = xn, self.obs_elems, None, 0, 0
+            if self._fused_norm:
+                # image frames: (x - mu) * rstd, clamped, happens in conv1's loader (sf_conv_fwd_norm) — the frames stay
+                # u8 in the slab and no normalised f32 copy is written or read
+                norm_tabs = tabs if tabs is not None else (on.mu_tab, on.rstd_tab)
+            else:  # any other shape: materialise the normalised f32 batch (NHWC), as the reference does
+                xn = self._buf((tag, "obsn"), (n, self.obs_elems))
+                on.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T, tabs=tabs)
+                x, stride, idx, off, tT = xn, self.obs_elems, None, 0, 0
         first_in = (x, stride, idx, off, tT)
         seq = rnn is not None and "R" in rnn
         for li, L in enumerate(self.layers):
@@ -538,7 +554,7 @@ class ActorCritic:
             inputs[li] = x
             out = self._buf((tag, li), (n * L.out_pixels, L.N))
             mask = None
-            if tag == "train" and li == 0 and li + 1 < len(self.layers) and self.layers[1].role == "chain":
+            if tag == "train" and li == 0 and norm_tabs is None and li + 1 < len(self.layers) and self.layers[1].role == "chain":
                 d0 = L.desc
                 if tT:
                     d0 = lib.sf_conv_desc.from_buffer_copy(L.desc)
@@ -562,7 +578,14 @@ class ActorCritic:
                 # projection was a launch of its own that is all fill and drain (GRU: the candidate gate's parts stay apart)
                 fuse_dual = (self._wb(li, tag)[2] is not None and self._wb(li + 1, tag)[2] is not None and
                              self.rnn_H % 64 == 0 and lib.linear_fwd_dual_supported(n, 4 * self.rnn_H, L.K, self.rnn_H))
-            if mask is None and not fuse_x and not fuse_dual:
+            if li == 0 and norm_tabs is not None:
+                w_, b_, _ = self._wb(li, tag)
+                dn = L.desc
+                if tT:
+                    dn = lib.sf_conv_desc.from_buffer_copy(L.desc)
+                    dn.traj_T = int(tT)
+                lib.conv_fwd_norm(x, stride, idx, off, norm_tabs[0], norm_tabs[1], w_, b_, out, n, dn)
+            elif mask is None and not fuse_x and not fuse_dual:
                 self._gemm(li, x, stride, idx, off, tT, out, n, tag)
             if li == 0:
                 relu_mask0 = mask  # kept in this forward's OWN context (below): nothing a forward leaves behind is untagged
@@ -580,7 +603,8 @@ class ActorCritic:
             stride, idx, off, tT = x.numel() // n, None, 0, 0  # elements per sample of the activation just produced
         if self.tanh_scale > 0:  # action_parameterization.py:62-66 (col 0 = value, then the means)
             lib.tanh_scale_fwd(acts[-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
-        self._ctx[tag] = dict(acts=acts, inputs=inputs, first_in=first_in, rnn=rnn, relu_mask0=relu_mask0)
+        self._ctx[tag] = dict(acts=acts, inputs=inputs, first_in=first_in, rnn=rnn, relu_mask0=relu_mask0,
+                              norm_tabs=norm_tabs)
         return acts
 
     # ------------------------------------------------------------------------------------------ recurrent core
@@ -773,7 +797,10 @@ class ActorCritic:
                 d0 = lib.sf_conv_desc.from_buffer_copy(d)
                 d0.traj_T = int(tT0)
                 ws = self._workspace(lib.conv_wgrad_workspace(n, d0))
-                if mask0 is not None:  # g is the gradient wrt conv1's ReLU output, unmasked: the kernel applies the bits
+                if ctx.get("norm_tabs") is not None:  # the forward normalised in conv1's loader: so does the gradient
+                    mu_, rstd_ = ctx["norm_tabs"]
+                    lib.conv_wgrad_norm(x0, stride0, idx0, off0, mu_, rstd_, g, L.gw, L.gb, n, d0, ws)
+                elif mask0 is not None:  # g is the gradient wrt conv1's ReLU output, unmasked: the kernel applies the bits
                     lib.conv_wgrad_relu_mask(x0, stride0, idx0, off0, g, mask0, L.gw, L.gb, n, d0, ws)
                 else:
                     lib.conv_wgrad_raw(x0, stride0, idx0, off0, g, L.gw, L.gb, n, d0, ws)

@@ -1830,3 +1830,56 @@ def test_dual_linear_gru_layout_and_cell(lib, n, H, K1):
         cell.weight_ih.copy_(wih.double()); cell.weight_hh.copy_(whh.double()); cell.bias_ih.copy_(bih.double()); cell.bias_hh.copy_(bhh.double())
         want = cell(x.double(), h.double())
     assert (h_out.cpu().double() - want).abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize("n,traj_T,use_index", [(1, 0, False), (3, 0, False), (64, 0, True), (255, 5, False), (1000, 8, True),
+                                                (2049, 0, False)])
+def test_conv1_loader_fused_normalisation_vs_float64(lib, n, traj_T, use_index):
+    """sf_conv_fwd_norm / sf_conv_wgrad_norm (cfg.normalize_input on raw u8 frames, normalisation inside conv1's loader)
+    against utils/normalize.py:40-70 + running_mean_std.py:79-110 + F.conv2d evaluated in float64: every launch size
+    (odd n, n < 256, one sample), dataset -> slab addressing (traj_T), index gather, obs_subtract_mean / obs_scale."""
+    import torch.nn.functional as F
+    assert lib.load().sf_abi_version() >= 18
+    g = torch.Generator().manual_seed(1000 + n)
+    C_, H, W, N, KH, S = 4, 84, 84, 32, 8, 4
+    d = lib.sf_conv_desc(Cin=C_, H=H, W=W, Cout=N, KH=KH, KW=KH, stride=S, OH=20, OW=20, in_u8=1, relu=1, traj_T=traj_T,
+                         sub_mean=3.0, inv_scale=float(np.float32(1.0 / 255.0)))
+    assert lib.conv_norm_supported(n, d)
+    rows = n + (n // traj_T + 2 if traj_T else 0) + 7
+    frames = torch.randint(0, 256, (rows, C_, H, W), dtype=torch.uint8, generator=g).cuda()
+    mu = (torch.rand(C_ * H * W, generator=g) * 0.6 + 0.2).cuda()
+    rstd = (1.0 / torch.sqrt(torch.rand(C_ * H * W, generator=g) * 0.2 + 1e-3)).cuda()   # some pixels clamp at +-5
+    w = (torch.randn(C_ * KH * KH, N, generator=g) / 16).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    index = torch.randperm(n, generator=g).int().cuda() if use_index else None
+    offset = 0 if use_index else 2
+    dsel = index.long() if use_index else torch.arange(offset, offset + n, device="cuda")
+    if traj_T:
+        dsel = dsel + dsel // traj_T
+    x = frames[dsel].double()
+    xn = (((x - 3.0) * float(np.float32(1.0 / 255.0)) - mu.double().view(1, C_, H, W)) * rstd.double().view(1, C_, H, W)).clamp(-5, 5)
+    assert float((xn.abs() == 5).double().mean()) > 1e-3        # the clamp is exercised
+    w4 = w.double().t().reshape(N, C_, KH, KH).clone().requires_grad_(True)     # k = (c*KH + kh)*KW + kw
+    b64 = b.double().clone().requires_grad_(True)
+    pre = F.conv2d(xn, w4, b64, stride=S)                       # [n, N, 20, 20], before the ReLU
+    out = torch.empty((n * 400, N), device="cuda")
+    stride = C_ * H * W
+    lib.conv_fwd_norm(frames, stride, index, offset, mu, rstd, w, b, out, n, d)
+    ref = F.relu(pre).detach().permute(0, 2, 3, 1).reshape(n * 400, N)
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    dy = torch.randn((n * 400, N), generator=g).cuda()
+    dy_masked = dy * (out > 0)   # the mask of OUR forward, applied by the caller (as sf_conv_dgrad's epilogue does): the
+    # float64 gradient below is that of the LINEAR layer against this very dout — no ReLU-flip ambiguity in the comparison
+    pre.backward(dy_masked.double().reshape(n, 20, 20, N).permute(0, 3, 1, 2))
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    ws = torch.empty(lib.conv_wgrad_workspace(n, d), dtype=torch.uint8, device="cuda")
+    lib.conv_wgrad_norm(frames, stride, index, offset, mu, rstd, dy_masked, dw, db, n, d, ws)
+    gw = w4.grad.reshape(N, -1).t()
+    e_w = (dw.double() - gw).abs().max().item() / gw.abs().max().item()
+    e_b = (db.double() - b64.grad).abs().max().item() / b64.grad.abs().max().item()
+    assert e_w < 5e-6 and e_b < 5e-6, (e_w, e_b)
+    # misuse is reported, not executed
+    bad = lib.sf_conv_desc.from_buffer_copy(d)
+    bad.H = 80
+    assert not lib.conv_norm_supported(n, bad)
