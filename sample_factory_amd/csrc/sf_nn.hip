@@ -1034,6 +1034,8 @@ static GldsFwdPlan plan_fwd_t(int64_t Mtot, int N, int K) {
     // tiles from which the unsplit 128-row plan is used (unchanged: 768).
     static const int min_tiles = getenv("SF_GLDS_MIN_TILES") ? atoi(getenv("SF_GLDS_MIN_TILES")) : 768;
     static const int small64 = getenv("SF_GLDS_SMALL64") ? atoi(getenv("SF_GLDS_SMALL64")) : 256;
+    static const int force64 = getenv("SF_GLDS_FORCE64") ? atoi(getenv("SF_GLDS_FORCE64")) : 0;  // experiment switch
+    if (force64 && N == 64 && t64 <= force64) { p.ok = true; p.sq64 = true; return p; }
     if (small64 && t64 < 768 && N == 64 && K >= 256 && cdiv64(Mtot, 64) >= small64) {
         p.ok = true; p.sq64 = true;  // narrow layer, few rows: 64-row tiles double the work-groups on the chip
         return p;
