@@ -1121,13 +1121,30 @@ static int xcd_raster_on() {
     static const int on = getenv("SF_XCD_RASTER") ? atoi(getenv("SF_XCD_RASTER")) : 1;
     return on;
 }
+// SF_XCD_ROWS=1: the same re-mapping for launches with ONE column tile (conv2's forward): XCD c then owns a contiguous run
+// of row tiles, so the image rows two neighbouring tiles share (a sample straddling a tile boundary, the 2-row halo of the
+// 4x4 stride-2 window) are fetched into one L2 instead of two
+static int xcd_rows_on() {
+    static const int on = getenv("SF_XCD_ROWS") ? atoi(getenv("SF_XCD_ROWS")) : 0;
+    return on;
+}
+// SF_TAP_PERM (default 1): conv2's forward visits its 16 filter taps in groups of the four taps that read the same input
+// elements (k_fwd_glds, sf_nn_glds.h).  Measured (profiles/r05_h_*): counter traffic of the dominant kernel 805.6 -> 544.1 MB
+// per launch (1.56 -> 1.05 x algorithmic), launch time 1573 / 1591 vs 1591 / 1597 us at n = 32768 — the re-reads were being
+// served by the Infinity Cache, so the time does not move; kept for the third of fabric traffic it removes.
+static int tap_perm_on() {
+    static const int on = getenv("SF_TAP_PERM") ? atoi(getenv("SF_TAP_PERM")) : 1;
+    return on;
+}
 #define GLDS_FWD(BM, BN, WM, WN, NS)                                                                           \
     do {                                                                                                       \
         dim3 gq(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), p.Z);                                                    \
-        const int rx = (int)gq.x, ry = (int)gq.y, rtot = (xcd_raster_on() && gq.y > 1) ? (int)(gq.x * gq.y * gq.z) : 0; \
+        const int rx = (int)gq.x, ry = (int)gq.y,                                                               \
+                  rtot = (xcd_raster_on() && (gq.y > 1 || (xcd_rows_on() && gq.x >= 64))) ? (int)(gq.x * gq.y * gq.z) : 0; \
         if (rtot > 0) gq = dim3((unsigned)(8 * ((rtot + 7) / 8)), 1, 1);                                        \
         k_fwd_glds<BM, BN, WM, WN, NS><<<gq, dim3(256), 0, st>>>(                                              \
-            g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial, nullptr, 0, rx, ry, rtot);   \
+            g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial, nullptr, 0, rx, ry, rtot,    \
+            tap_perm_on());                                                                                    \
     } while (0)
 extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const float *wt, const float *bias, float *out,
                              int64_t n, const sf_conv_desc *h_desc, void *workspace, int64_t workspace_bytes,

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
                                                   const float *__restrict__ wt, const float *__restrict__ bias,
                                                   float *__restrict__ out, int64_t Mtot, int k_per_split,
                                                   float *__restrict__ partial, const float *__restrict__ dmask,
-                                                  int dmask_on, int rx = 0, int ry = 0, int rtot = 0) {
+                                                  int dmask_on, int rx = 0, int ry = 0, int rtot = 0, int tap_perm = 0) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
@@ -179,7 +179,20 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     // "at most (NS-2) chunks' worth of DMA instructions outstanding" == "chunk t has landed" — never a vmcnt(0)
     // inside the loop for NS = 3.
     static_assert(NS == 2, "two LDS stages");
-    issue(kbeg, 0);
+    // Chunk ORDER of a 4x4 stride-2 window over 32 channels (conv2: a chunk = one filter tap).  An input element is read
+    // by the four taps (kh, kw), (kh, kw+2), (kh+2, kw), (kh+2, kw+2) of four different output pixels; in tap order those
+    // reads are up to 10 chunks (~25 us, ~20 MB streamed through the XCD's 4 MB L2) apart, and 74 % of the im2col
+    // re-reads leave the L2 (profiles/r05_g_traffic_xcd_rows_0.json: 642 MB fetched per launch against 368 MB read
+    // once).  tapperm != 0: visit the taps in groups of those four, so that an element's uses are at most 3 chunks
+    // apart.  The reduction is a sum over the same products in another order.
+    const bool tapperm = tap_perm && g.KH == 4 && g.KW == 4 && g.S == 2 && g.Cin == 32 && kbeg == 0 && kend == K;
+    auto kord = [&](int k0) {  // position in the visiting order -> first reduction index of the chunk visited there
+        if (!tapperm) return k0;
+        const int p = k0 >> 5, grp = p >> 2, e = p & 3;              // grp = (kh & 1) * 2 + (kw & 1) in visiting order
+        const int kh = ((grp >> 1) & 1) + 2 * (e >> 1), kw = (grp & 1) + 2 * (e & 1);
+        return (kh * 4 + kw) << 5;
+    };
+    issue(kord(kbeg), 0);
     int stage = 0, k0 = kbeg;
     if constexpr (TM * TN <= 2) {
         // chunk k0 is multiplied out of `stage` while chunk k0+32 streams into the other stage; its DMA instructions
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
         for (; k0 + 32 < kend; k0 += 32, stage ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             BARRIER_NOFENCE();  // chunk k0 is visible to all waves, the stage about to be refilled is no longer read
-            const int kn = k0 + 32;
+            const int kn = kord(k0 + 32);
             const uint32_t tap = fdiv((uint32_t)kn, g.dCin), c0 = (uint32_t)kn - tap * (uint32_t)g.Cin;
             const uint32_t kh = fdiv(tap, g.dKW), kw = tap - kh * (uint32_t)g.KW;
             const int aoff = (int)((kh * (uint32_t)g.W + kw) * (uint32_t)g.Cin + c0);

@@ -43,7 +43,25 @@ constexpr int SEQ_MAX_SUB = 4;             // 64-row sub-tiles per work-group (r
 #endif
 constexpr uint32_t OOB = 0x7FFFFFF0u;     // byte offset past every buffer: loads return 0, stores are dropped
 
+// Cell transcendentals of the fused sequence passes.  SF_FAST_CELL = 1 (default; -DSF_FAST_CELL=0 through
+// tools/build_variant.sh for the A/B): hardware v_exp_f32 / v_rcp_f32 forms — ~4 instructions instead of the ~15 (expf) /
+// ~25 (tanhf) of the accurate library code; absolute error <= 2e-7 (the relative error of tanh grows as 6e-8 / |x| near
+// 0).  Vector instructions do not overlap with MFMAs on a SIMD, so they are matrix-pipe time: forward
+// pass 0.440 -> 0.415 ms, configs[4] step 16.36 -> 16.09 ms over three alternations, the configs[4] LSTM / GRU replays
+// against the reference and its float64 loop unchanged within their bounds (profiles/r05_i_fastcell_ab.log).
+#ifndef SF_FAST_CELL
+#define SF_FAST_CELL 1
+#endif
+#if SF_FAST_CELL
+__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_c(float x) {
+    const float t = __expf(-2.0f * fabsf(x));
+    return copysignf((1.0f - t) * __frcp_rn(1.0f + t), x);
+}
+#else
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanh_c(float x) { return tanhf(x); }
+#endif
 
 // arrive: every wave has drained its write-through stores, then one relaxed agent-scope increment
 __device__ __forceinline__ void seq_arrive(unsigned *counter) {
@@ -250,10 +268,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_fwd(LstmSeqFwd p) {
                         gxv[q] = KXB > 0 ? xacc[sub][KXB > 0 ? q * NU + u : 0][i] + bih[q][u] : xg[KXB > 0 ? 0 : sub][i][q][u];
                     const float ig = sigm(gxv[0] + (acc[0 * NU + u][i] + bias[0][u]));
                     const float fg = sigm(gxv[1] + (acc[1 * NU + u][i] + bias[1][u]));
-                    const float gg = tanhf(gxv[2] + (acc[2 * NU + u][i] + bias[2][u]));
+                    const float gg = tanh_c(gxv[2] + (acc[2 * NU + u][i] + bias[2][u]));
                     const float og = sigm(gxv[3] + (acc[3 * NU + u][i] + bias[3][u]));
                     const float cn = fg * cst[sub][i][u] + ig * gg;
-                    const float h = og * tanhf(cn);
+                    const float h = og * tanh_c(cn);
                     cst[sub][i][u] = cn * kp[sub][i];
                     stg[(4 * g + i) * JB + u * 16 + c] = h * kp[sub][i];
                     sv[sub][i][u][0] = ig; sv[sub][i][u][1] = fg; sv[sub][i][u][2] = gg; sv[sub][i][u][3] = og;
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd(LstmSeqBwd p) {
                         d = d + car_h[sub][i][u];
                         dc_in = car_c[sub][i][u];
                     }
-                    const float tc = tanhf(pco[sub][i][u]);
+                    const float tc = tanh_c(pco[sub][i][u]);
                     const float dc = d * og * (1.0f - tc * tc) + dc_in;
                     const float di = (dc * gg) * (ig * (1.0f - ig)), df = (dc * pcp[sub][i][u]) * (fg * (1.0f - fg));
                     const float dg = (dc * ig) * (1.0f - gg * gg), dob = (d * tc) * (og * (1.0f - og));
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_seq_fwd(GruSeqFwd p) {
                     const float r = sigm(gxv[0] + (acc[0 * NU + u][i] + bias[0][u]));
                     const float z = sigm(gxv[1] + (acc[1 * NU + u][i] + bias[1][u]));
                     const float hn = acc[2 * NU + u][i] + bias[2][u];
-                    const float n = tanhf(gxv[2] + r * hn);
+                    const float n = tanh_c(gxv[2] + r * hn);
                     const float h = (1.0f - z) * n + z * hst[sub][i][u];
                     hst[sub][i][u] = h * kp[sub][i];
                     stg[(4 * g + i) * JB + u * 16 + c] = hst[sub][i][u];

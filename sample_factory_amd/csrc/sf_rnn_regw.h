@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_seq_bwd_r(LstmSeqBwd p) {
                     d = d + car_h[q][i];
                     dc_in = car_c[q][i];
                 }
-                const float tc = tanhf(pco[q][i]);
+                const float tc = tanh_c(pco[q][i]);
                 const float dc = d * og * (1.0f - tc * tc) + dc_in;
                 const float di = (dc * gg) * (ig * (1.0f - ig)), df = (dc * pcp[q][i]) * (fg * (1.0f - fg));
                 const float dg = (dc * ig) * (1.0f - gg * gg), dob = (d * tc) * (og * (1.0f - og));

@@ -2,6 +2,7 @@
 wrappers) and for the whole model/learner against golden vectors produced by the reference's own ActorCritic /
 Learner.train.  Floating-point kernels: the checker is plain torch fp32/fp64 math on the CPU (same op, different
 implementation); tolerances are fp32-accumulation class and written next to each assert."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -171,6 +172,51 @@ def test_glds_fwd_64x64_unsplit_fc_of_a_rollout_step_vs_torch(lib, n, cout, act)
     out2 = torch.empty_like(out)
     lib.conv_fwd_t(x.cuda(), Cin, w_ref.cuda().contiguous(), b.cuda(), out2, n, d, None)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("n", [512, 513, 1024, 2048])
+def test_glds_fwd_small_inference_launches_vs_torch(lib, n):
+    """the per-split inference launches of a host-env run (n = 512 .. 2048 samples; BASELINE configs[2]: 1024 envs in two
+    splits): conv2 on 64 x 64 LDS-DMA tiles, the fc layer on 64 x 64 tiles split along K with deterministic slice order —
+    both used to fall to the register-staged kernels (profiles/r05_b_kbench_small_n.log: fc at n = 512 170 -> 26 us)"""
+    import torch.nn.functional as F
+    default = not any(os.environ.get(k) for k in ("SF_GLDS_SMALL64", "SF_GLDS_SPLIT64", "SF_GLDS_MIN_TILES", "SF_GLDS_CFG"))
+    g = torch.Generator().manual_seed(n)
+    # conv2: 32 x 20 x 20 -> 64, 4 x 4 stride 2
+    d = desc(lib, 32, 20, 20, 64, 4, 2)
+    x = torch.randn((n, 32, 20, 20), generator=g)
+    w_ref = torch.randn((64, 32, 4, 4), generator=g) / np.sqrt(512)
+    b = torch.randn(64, generator=g) * 0.1
+    assert lib.conv_fwd_t_supported(n, d)
+    if default and n <= 1024:
+        assert lib.conv_kernel_name(3, n, d) == "k_fwd_glds<64, 64, 2, 2, 2>", lib.conv_kernel_name(3, n, d)
+    wk = to_kmajor(w_ref, 0).cuda()
+    wt = torch.empty((64, 512), device="cuda")
+    lib.transpose(wk, wt, 512, 64)
+    out = torch.full((n * 81, 64), 7.0, device="cuda")
+    nb = lib.conv_fwd_t_workspace(n, d)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda") if nb else None
+    lib.conv_fwd_t(x.permute(0, 2, 3, 1).contiguous().cuda(), 32 * 400, wt, b.cuda(), out, n, d, ws)
+    ref = F.relu(F.conv2d(x.double(), w_ref.double(), b.double(), stride=2)).permute(0, 2, 3, 1).reshape(n * 81, 64)
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    # fc: 3136 -> 512
+    Cin, cout = 3136, 512
+    d = desc(lib, Cin, 1, 1, cout, 1, 1)
+    x = torch.randn((n, Cin), generator=g)
+    w_ref = torch.randn((cout, Cin), generator=g) / np.sqrt(Cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    assert lib.conv_fwd_t_supported(n, d)
+    nb = lib.conv_fwd_t_workspace(n, d)
+    if default:
+        assert lib.conv_kernel_name(3, n, d) == "k_fwd_glds<64, 64, 2, 2, 2>" and nb > 0, (lib.conv_kernel_name(3, n, d), nb)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    out = torch.full((n, cout), 7.0, device="cuda")
+    lib.conv_fwd_t(x.cuda(), Cin, w_ref.cuda().contiguous(), b.cuda(), out, n, d, ws if nb else None)
+    ref = torch.relu(x.double() @ w_ref.double().t() + b.double())
+    assert (out.cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    out2 = torch.empty_like(out)
+    lib.conv_fwd_t(x.cuda(), Cin, w_ref.cuda().contiguous(), b.cuda(), out2, n, d, ws if nb else None)
+    assert torch.equal(out, out2)       # split-K slices are added in a fixed order
 
 
 @pytest.mark.parametrize("geom,n", [((32, 20, 20, 64, 4, 2), 2500), ((64, 9, 9, 64, 3, 1), 2500),
