@@ -21,6 +21,9 @@
 // chunk back-to-back and waits once (the first version branched per load and hipcc serialised them with vmcnt(0)).
 #include "sf_common.h"
 #include <stdlib.h>
+#ifndef SF_GLDS_ABLATE
+#define SF_GLDS_ABLATE 0  // timing experiments only (sf_nn_glds.h)
+#endif
 #include <type_traits>
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -303,7 +306,11 @@ __device__ __forceinline__ void store_fwd_tile(const f32x16 (&acc)[TM][TN], floa
                 const int rr = tm * 32 + (r & 3) + 8 * (r >> 2);
                 float *p = ob + (int64_t)rr * N + tn * 32;  // uniform
                 const float v = act_fwd_c<KIND>(acc[tm][tn][r] + bv, kind);
+#if SF_GLDS_ABLATE & 4
+                if (v == 1.2345e30f) p[voff] = v;  // timing experiment: the value is computed, the store never happens
+#else
                 if (FULL || (cok && rr < rows_left)) p[voff] = v;
+#endif
             }
     }
 }
@@ -1128,12 +1135,22 @@ static int xcd_rows_on() {
     static const int on = getenv("SF_XCD_ROWS") ? atoi(getenv("SF_XCD_ROWS")) : 0;
     return on;
 }
-// SF_TAP_PERM (default 1): conv2's forward visits its 16 filter taps in groups of the four taps that read the same input
+// SF_GLDS_ZL (default 2; 1 = wave tiles of at most two 32x32 blocks only, 0 = off): the LDS-DMA forward with no vector-ALU
+// instruction in its k-loop (k_fwd_glds_z, sf_nn_glds.h).  Measured (profiles/r05_k_zl_ab.log, r05_k_zl128_ab.log, same box,
+// alternating): conv2 forward 213 / 218 -> 192 / 195 us at n = 4096, 1491 / 1507 -> 1413 / 1406 us at n = 32768; fc forward
+// of a rollout step (64 x 64 tiles) 110 / 113 -> 105 / 104 us; fc forward at n = 32768 (128 x 128 tiles) 832 / 837 -> 802 / 811 us.
+static int glds_zl_on() {
+    static const int on = getenv("SF_GLDS_ZL") ? atoi(getenv("SF_GLDS_ZL")) : 2;
+    return on;
+}
+// SF_TAP_PERM=1 (default 0): conv2's forward visits its 16 filter taps in groups of the four taps that read the same input
 // elements (k_fwd_glds, sf_nn_glds.h).  Measured (profiles/r05_h_*): counter traffic of the dominant kernel 805.6 -> 544.1 MB
 // per launch (1.56 -> 1.05 x algorithmic), launch time 1573 / 1591 vs 1591 / 1597 us at n = 32768 — the re-reads were being
-// served by the Infinity Cache, so the time does not move; kept for the third of fabric traffic it removes.
+// served by the Infinity Cache, so the time does not move.  It is a different fp32 summation order, though, and the
+// normalised-input replay (train_cnn84_norm: inputs up to +-5, two SGD steps) lands on other ReLU flips with it and leaves the
+// tolerance the replays are held to (profiles/r05_m_norm_bisect.log); with no time to gain, the natural order stays.
 static int tap_perm_on() {
-    static const int on = getenv("SF_TAP_PERM") ? atoi(getenv("SF_TAP_PERM")) : 1;
+    static const int on = getenv("SF_TAP_PERM") ? atoi(getenv("SF_TAP_PERM")) : 0;
     return on;
 }
 #define GLDS_FWD(BM, BN, WM, WN, NS)                                                                           \
@@ -1142,6 +1159,16 @@ static int tap_perm_on() {
         const int rx = (int)gq.x, ry = (int)gq.y,                                                               \
                   rtot = (xcd_raster_on() && (gq.y > 1 || (xcd_rows_on() && gq.x >= 64))) ? (int)(gq.x * gq.y * gq.z) : 0; \
         if (rtot > 0) gq = dim3((unsigned)(8 * ((rtot + 7) / 8)), 1, 1);                                        \
+        bool launched_z = false;                                                                               \
+        {                                                                                                      \
+            if (zl_ok && ((BM / WM / 32) * (BN / WN / 32) <= 2 || glds_zl_on() >= 2)) {                        \
+                k_fwd_glds_z<BM, BN, WM, WN><<<gq, dim3(256), 0, st>>>(                                        \
+                    g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial, nullptr, 0, rx, ry,  \
+                    rtot, tap_perm_on());                                                                      \
+                launched_z = true;                                                                             \
+            }                                                                                                  \
+        }                                                                                                      \
+        if (!launched_z)                                                                                       \
         k_fwd_glds<BM, BN, WM, WN, NS><<<gq, dim3(256), 0, st>>>(                                              \
             g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, partial, nullptr, 0, rx, ry, rtot,    \
             tap_perm_on());                                                                                    \
@@ -1183,6 +1210,9 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
         partial = reinterpret_cast<float *>(workspace);
     }
     hipStream_t st = STREAM(stream);
+    // zero-VALU k-loop form (k_fwd_glds_z): every per-lane operand offset must fit 32 bits
+    const bool zl_ok = glds_zl_on() && (n - 1) * in_sample_stride + (int64_t)g.H * g.W * g.Cin < (1LL << 30) &&
+                       (int64_t)g.Cout * g.K < (1LL << 30);
     if (p.sq64) GLDS_FWD(64, 64, 2, 2, 2);
     else if (p.wide) GLDS_FWD(128, 128, 2, 2, 2);
     else GLDS_FWD(128, 64, 2, 2, 2);
@@ -1596,6 +1626,11 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
         // Cache, and the row-strip order sweeps the 6.4 MB weight matrix per strip — so only SF_XCD_RASTER=2 enables it here)
         const int rx = (int)gq.x, ry = (int)gq.y, rtot = (xcd_raster_on() >= 2 && gq.y > 1) ? (int)(gq.x * gq.y) : 0;
         if (rtot > 0) gq = dim3((unsigned)(8 * ((rtot + 7) / 8)), 1, 1);
+        const bool zl = glds_zl_on() >= 2 && n * (int64_t)g.Cout < (1LL << 30) && (int64_t)g.Cin * g.Cout < (1LL << 30);
+        if (zl)
+            k_fwd_glds_z<128, 128, 2, 2><<<gq, dim3(256), 0, st>>>(
+                g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1, rx, ry, rtot);
+        else
         k_fwd_glds<128, 128, 2, 2, 2><<<gq, dim3(256), 0, st>>>(
             g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1, rx, ry, rtot);
         return sf_launch_status("sf_conv_dgrad");
@@ -1603,6 +1638,11 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
     if (lin_on && linear_dgrad_glds64_ok(g, n) && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)w & 15) == 0) {
         sf_conv_desc d2 = linear_desc(g.Cout, g.Cin, g.relu);
         const ConvG g2 = make_geom(&d2);
+        const bool zl = glds_zl_on() && n * (int64_t)g.Cout < (1LL << 30) && (int64_t)g.Cin * g.Cout < (1LL << 30);
+        if (zl)
+            k_fwd_glds_z<64, 64, 2, 2><<<dim3(cdiv64(n, 64), 1, 1), dim3(256), 0, st>>>(
+                g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1);
+        else
         k_fwd_glds<64, 64, 2, 2, 2><<<dim3(cdiv64(n, 64), 1, 1), dim3(256), 0, st>>>(
             g2, dout, g.Cout, w, nullptr, din, n, (g.Cout + 31) / 32 * 32, nullptr, in_act, 1);
         return sf_launch_status("sf_conv_dgrad");
@@ -1613,13 +1653,28 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
 #define DGRAD_PIX(BM, BN, WM, WN)                                                                          \
     do {                                                                                                   \
         const int ntiles = (int)((n + BM - 1) / BM), tiles8 = (ntiles + 7) / 8, ctiles = (g.Cin + BN - 1) / BN; \
+        if (dgrad_zl && (dzl & 2))                                                                         \
+            k_dgrad_pix_z<BM, BN, WM, WN><<<dim3((unsigned)(tiles8 * 8 * g.H * ctiles)), dim3(256), 0, st>>>( \
+                g, dout, w, in_act, din, (int)n, ntiles, tiles8, dgrad_lpt());                              \
+        else                                                                                               \
         k_dgrad_pix<BM, BN, WM, WN><<<dim3((unsigned)(tiles8 * 8 * g.H * ctiles)), dim3(256), 0, st>>>(    \
             g, dout, w, in_act, din, (int)n, ntiles, tiles8, dgrad_lpt());                                 \
     } while (0)
+        // zero-VALU reduction loop (k_dgrad_pix_z / k_dgrad_quadrow_z): per-lane operand offsets must fit 32 bits
+        // SF_DGRAD_ZL (default 1): bit 0 = k_dgrad_quadrow_z (conv2: 1918 / 1921 -> 1877 / 1892 us at n = 32768), bit 1 =
+        // k_dgrad_pix_z (conv3: 1214 / 1234 -> 1316 / 1324 us — the form costs hipcc 256 + 168 registers against 173 + 32 and
+        // with them the second wave per SIMD: not used) — profiles/r05_k_dgrad_zl_ab.log
+        static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 1;
+        const bool dgrad_zl = dzl && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) &&
+                              (int64_t)g.K * g.Cout < (1LL << 30);
         if (g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0 && pix_cfg != 3) {
             // strided conv, row-walking tiles of (sample, group-column) rows: contiguous activation / gradient rows
             const int Wg = g.W / g.S;
             const int64_t Mrows = n * Wg;
+            if (dgrad_zl && (dzl & 1))
+                k_dgrad_quadrow_z<128, 128, 2, 2><<<dim3(cdiv64(Mrows, 128), cdiv64(g.S * g.S * g.Cin, 128)), dim3(256), 0,
+                                                    st>>>(g, dout, w, in_act, din, Mrows, make_fastdiv((uint32_t)Wg));
+            else
             k_dgrad_quadrow<128, 128, 2, 2><<<dim3(cdiv64(Mrows, 128), cdiv64(g.S * g.S * g.Cin, 128)), dim3(256), 0,
                                               st>>>(g, dout, w, in_act, din, Mrows, make_fastdiv((uint32_t)Wg));
             return sf_launch_status("sf_conv_dgrad");
@@ -1636,6 +1691,10 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
 
 // Name of the kernel instantiation a launch with these arguments resolves to (aligned operands assumed), spelled the
 // way rocprofv3 prints it, so that bench.py can group its HIP-event timings exactly like the rocprof kernel stats.
+static bool dgrad_quadrow_zl(const ConvG &g, int64_t n) {
+    static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 1;
+    return (dzl & 1) && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) && (int64_t)g.K * g.Cout < (1LL << 30);
+}
 extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc, int split_k_allowed, char *out,
                                    int cap) {
     int rc = check_desc(h_desc, "sf_conv_kernel_name");
@@ -1657,6 +1716,10 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         else if (img_fwd_index(g, n) >= 0) snprintf(out, cap, "k_fwd_img<%d, %d, %d, %d, %d, 2, 1, %d>", g.Cin, g.H, g.W, g.KH, g.S, g.OH);
         else {
             const GldsFwdPlan q = plan_fwd_t(Mtot, g.Cout, g.K);
+            const bool zl = glds_zl_on() && (!q.wide || glds_zl_on() >= 2) && (n - 1) * (int64_t)(g.H * g.W * g.Cin) + (int64_t)g.H * g.W * g.Cin < (1LL << 30) &&
+                            (int64_t)g.Cout * g.K < (1LL << 30);  // (dense samples: the stride the model launches with)
+            if (zl) snprintf(out, cap, q.sq64 ? "k_fwd_glds_z<64, 64, 2, 2>" : q.wide ? "k_fwd_glds_z<128, 128, 2, 2>" : "k_fwd_glds_z<128, 64, 2, 2>");
+            else
             snprintf(out, cap, q.sq64 ? "k_fwd_glds<64, 64, 2, 2, 2>" : q.wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
         }
     } else if (op == 1 && small_linear_wgrad_ok(h_desc)) {
@@ -1677,10 +1740,11 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         const int Hc = (g.H + g.S - 1) / g.S, Wc = (g.W + g.S - 1) / g.S;
         const int64_t Mc = n * Hc * Wc;
         const char *v = g.vecB ? "true" : "false";
-        if (g.vecB && linear_dgrad_glds_ok(g, n)) snprintf(out, cap, "k_fwd_glds<128, 128, 2, 2, 2>");
-        else if (g.vecB && linear_dgrad_glds64_ok(g, n)) snprintf(out, cap, "k_fwd_glds<64, 64, 2, 2, 2>");
+        const bool zlf = n * (int64_t)g.Cout < (1LL << 30) && (int64_t)g.Cin * g.Cout < (1LL << 30);
+        if (g.vecB && linear_dgrad_glds_ok(g, n)) snprintf(out, cap, glds_zl_on() >= 2 && zlf ? "k_fwd_glds_z<128, 128, 2, 2>" : "k_fwd_glds<128, 128, 2, 2, 2>");
+        else if (g.vecB && linear_dgrad_glds64_ok(g, n)) snprintf(out, cap, glds_zl_on() && zlf ? "k_fwd_glds_z<64, 64, 2, 2>" : "k_fwd_glds<64, 64, 2, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
-            snprintf(out, cap, "k_dgrad_quadrow<128, 128, 2, 2>");
+            snprintf(out, cap, dgrad_quadrow_zl(g, n) ? "k_dgrad_quadrow_z<128, 128, 2, 2>" : "k_dgrad_quadrow<128, 128, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024)
             snprintf(out, cap, g.Cin <= 32 ? "k_dgrad_pix<256, 32, 4, 1>" : "k_dgrad_pix<128, 64, 2, 2>");
         else if (g.Cin <= 32) snprintf(out, cap, "k_conv_dgrad<128, 32, 4, 1, %s>", v);

@@ -20,6 +20,12 @@
 // Cin % 32 == 0 (a 32-chunk never straddles a filter tap), dense samples (no index gather), 16-byte aligned bases.
 #pragma once
 
+// SF_GLDS_ABLATE (compile-time, tools/build_variant.sh; TIMING EXPERIMENTS ONLY — results are wrong with any bit set):
+// bit 0: k_fwd_glds issues no DMA inside its k-loop, bit 1: no wait / barrier per chunk, bit 2: no epilogue stores,
+// bit 3: one k-chunk per tile (prologue + epilogue only)
+#ifndef SF_GLDS_ABLATE
+#define SF_GLDS_ABLATE 0
+#endif
 #define GLDS16(gsrc, ldst)                                                                       \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),    \
                                      (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
@@ -103,14 +109,97 @@ __device__ __forceinline__ void mma_chunk_rows_mid(const float *__restrict__ As,
     }
 }
 
+// LDS-DMA with the address split the way the hardware wants it: 64-bit UNIFORM base in SGPRs + 32-bit per-lane byte
+// offset in ONE VGPR (hipcc's builtin only emits the "off" form: a 64-bit per-lane address, i.e. one v_lshl_add_u64 per
+// instruction and chunk to add the chunk's uniform offset).  M0 (LDS destination base) is set inside the same statement.
+__device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_byte_addr), "v"(voff), "s"(ubase) : "memory", "m0");
+}
+
+// mma_chunk_rows_mid with the fragment addresses as per-lane LDS POINTERS computed once per kernel (ap[c], bp[c]: group c of
+// stage 0) and the stage as a compile-time float offset: every ds_read_b128 is "VGPR + immediate", no address VALU at all.
+template <int TM, int TN, int OFF, typename F>
+__device__ __forceinline__ void mma_chunk_ptrs_mid(const float *const (&ap)[4], const float *const (&bp)[4],
+                                                   f32x16 (&acc)[TM][TN], F &&mid) {
+    float4 a[2][TM], b[2][TN];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[c & 1][i] = *reinterpret_cast<const float4 *>(ap[c] + OFF + i * 32 * 32);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) b[c & 1][i] = *reinterpret_cast<const float4 *>(bp[c] + OFF + i * 32 * 32);
+    };
+    auto mfmas = [&](int c, int j) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    j == 0 ? a[c & 1][tm].x : j == 1 ? a[c & 1][tm].y : j == 2 ? a[c & 1][tm].z : a[c & 1][tm].w,
+                    j == 0 ? b[c & 1][tn].x : j == 1 ? b[c & 1][tn].y : j == 2 ? b[c & 1][tn].z : b[c & 1][tn].w,
+                    acc[tm][tn], 0, 0, 0);
+    };
+    fetch(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mfmas(c, 0);
+        mfmas(c, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mid(c);
+        if (c + 1 < 4) fetch(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(c, 2);
+        mfmas(c, 3);
+    }
+}
+
+// mma_chunk_rows (fragments of a group fetched together, no scheduling fences: the form the 64x64 wave tiles want) with
+// pointer + compile-time-offset addressing
+template <int TM, int TN, int OFF>
+__device__ __forceinline__ void mma_chunk_ptrs(const float *const (&ap)[4], const float *const (&bp)[4],
+                                               f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(ap[c] + OFF + i * 32 * 32);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const float4 *>(bp[c] + OFF + i * 32 * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        j == 0 ? a[tm].x : j == 1 ? a[tm].y : j == 2 ? a[tm].z : a[tm].w,
+                        j == 0 ? b[tn].x : j == 1 ? b[tn].y : j == 2 ? b[tn].z : b[tn].w, acc[tm][tn], 0, 0, 0);
+    }
+}
+
+// the chunk out of stage `stage` (run-time, wave-uniform) of a two-stage pipeline: a scalar branch picks one of two copies of
+// the chunk whose stage offset is an immediate — the k-loops whose stage parity is not static (pipelines running across
+// pixel / step boundaries) get VALU-free fragment addressing this way
+template <int TM, int TN, int STAGE_F>
+__device__ __forceinline__ void mma_chunk_stage(const float *const (&ap)[4], const float *const (&bp)[4], int stage,
+                                                f32x16 (&acc)[TM][TN]) {
+    if (stage == 0) mma_chunk_ptrs<TM, TN, 0>(ap, bp, acc);
+    else mma_chunk_ptrs<TM, TN, STAGE_F>(ap, bp, acc);
+}
+
 // ============================================================================================== FORWARD (glds)
 // out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ),  A = im2col view of the NHWC input, Wt = weights [Cout, K].
-template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
-                                                  const float *__restrict__ wt, const float *__restrict__ bias,
-                                                  float *__restrict__ out, int64_t Mtot, int k_per_split,
-                                                  float *__restrict__ partial, const float *__restrict__ dmask,
-                                                  int dmask_on, int rx = 0, int ry = 0, int rtot = 0, int tap_perm = 0) {
+// ZL ("zero-VALU loop", TM*TN <= 2 tiles): the k-loop issues its DMA through glds16_s (uniform base + 32-bit lane offset)
+// and reads its fragments through mma_chunk_ptrs_mid — two chunks per loop trip, so the pipeline stage is a compile-time
+// constant.  The loop body is then MFMA + ds_read + DMA + scalar instructions only (the plain form spends 10 v_add_u32 and
+// 6 v_lshl_add_u64 per 32 MFMAs on addresses; vector ALU instructions do not overlap with MFMAs on a SIMD).  Needs
+// every per-lane operand offset < 4 GiB (the launcher checks).
+template <int BM, int BN, int WM, int WN, int NS, bool ZL>
+__device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                              const float *__restrict__ wt, const float *__restrict__ bias,
+                                              float *__restrict__ out, int64_t Mtot, int k_per_split,
+                                              float *__restrict__ partial, const float *__restrict__ dmask,
+                                              int dmask_on, int rx, int ry, int rtot, int tap_perm) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
@@ -192,16 +281,85 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
         const int kh = ((grp >> 1) & 1) + 2 * (e >> 1), kw = (grp & 1) + 2 * (e & 1);
         return (kh * 4 + kw) << 5;
     };
-    issue(kord(kbeg), 0);
     int stage = 0, k0 = kbeg;
+    if constexpr (ZL) {
+
+        // ---- per-lane 32-bit byte offsets of the DMA sources (relative to `in` / `wt`), LDS fragment pointers of stage 0
+        uint32_t avoff[AI], bvoff[BI];
+#pragma unroll
+        for (int i = 0; i < AI; ++i) avoff[i] = (uint32_t)((asrc[i] - in) * (int64_t)sizeof(float));
+#pragma unroll
+        for (int i = 0; i < BI; ++i) bvoff[i] = (uint32_t)((bsrc[i] - wt) * (int64_t)sizeof(float));
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+        const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+        const float *apl[4], *bpl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int pos = (((2 * c + h) ^ sw) << 2);
+            apl[c] = lds + (wm * TM * 32 + r) * 32 + pos;
+            bpl[c] = lds + BM * 32 + (wn * TN * 32 + r) * 32 + pos;
+        }
+        auto chunk_off = [&](int kn) {  // element offset of chunk kn inside an input patch (uniform)
+            const uint32_t tap = fdiv((uint32_t)kn, g.dCin), c0 = (uint32_t)kn - tap * (uint32_t)g.Cin;
+            const uint32_t kh = fdiv(tap, g.dKW), kw = tap - kh * (uint32_t)g.KW;
+            return (int)((kh * (uint32_t)g.W + kw) * (uint32_t)g.Cin + c0);
+        };
+        auto dma = [&](int q, const float *abase, const float *bbase, int st) {  // DMA instruction q of a chunk
+            if (q < AI) glds16_s(abase, avoff[q < AI ? q : 0], lds0 + (uint32_t)((st * STAGE + (q * 4 + wave) * 256) * 4));
+            else glds16_s(bbase, bvoff[q >= AI ? q - AI : 0], lds0 + (uint32_t)((st * STAGE + BM * 32 + ((q - AI) * 4 + wave) * 256) * 4));
+        };
+        {
+            const int kf = kord(kbeg);
+            const float *ab = in + chunk_off(kf), *bb = wt + kf;
+#pragma unroll
+            for (int q = 0; q < AI + BI; ++q) dma(q, ab, bb, 0);
+        }
+        auto step = [&](auto stc, bool prefetch) {  // multiply the chunk in stage ST; stream the next one into ST ^ 1
+            constexpr int ST = decltype(stc)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            BARRIER_NOFENCE();
+            const int kn = prefetch ? kord(k0 + 32) : 0;
+            const float *ab = in + chunk_off(kn), *bb = wt + kn;
+            if constexpr (TM * TN <= 2) {  // DMA instructions spread over the first three MFMA groups
+                mma_chunk_ptrs_mid<TM, TN, ST * STAGE>(apl, bpl, acc, [&](int c) {
+                    constexpr int TOT = AI + BI, PER = (TOT + 2) / 3;
+                    if (prefetch) {
+#pragma unroll
+                        for (int q = 0; q < TOT; ++q)
+                            if (q / PER == c) dma(q, ab, bb, ST ^ 1);
+                    }
+                });
+            } else {  // 64 x 64 wave tiles: burst in front of the chunk (see the plain form below)
+                if (prefetch) {
+#pragma unroll
+                    for (int q = 0; q < AI + BI; ++q) dma(q, ab, bb, ST ^ 1);
+                }
+                mma_chunk_ptrs<TM, TN, ST * STAGE>(apl, bpl, acc);
+            }
+            k0 += 32;
+        };
+        while (k0 + 64 < kend) {  // two chunks per trip: stages 0 and 1 as compile-time constants
+            step(std::integral_constant<int, 0>{}, true);
+            step(std::integral_constant<int, 1>{}, true);
+        }
+        if (k0 + 32 < kend) {
+            step(std::integral_constant<int, 0>{}, true);
+            step(std::integral_constant<int, 1>{}, false);
+        } else {
+            step(std::integral_constant<int, 0>{}, false);
+        }
+    } else {
+    issue(kord(kbeg), 0);
     if constexpr (TM * TN <= 2) {
         // chunk k0 is multiplied out of `stage` while chunk k0+32 streams into the other stage; its DMA instructions
         // are spread over the first three MFMA groups (mma_chunk_rows_mid).  Measured: +0..+3 % for the 64x32 wave
         // tile, -11 % for the 64x64 one (16 MFMAs per group: the fences cost more fragment-read overlap than the DMA
         // placement wins), which therefore keeps the burst form below.
-        for (; k0 + 32 < kend; k0 += 32, stage ^= 1) {
+        for (; k0 + 32 < ((SF_GLDS_ABLATE & 8) ? kbeg + 64 : kend); k0 += 32, stage ^= 1) {
+            if (!(SF_GLDS_ABLATE & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             BARRIER_NOFENCE();  // chunk k0 is visible to all waves, the stage about to be refilled is no longer read
+            }
             const int kn = kord(k0 + 32);
             const uint32_t tap = fdiv((uint32_t)kn, g.dCin), c0 = (uint32_t)kn - tap * (uint32_t)g.Cin;
             const uint32_t kh = fdiv(tap, g.dKW), kw = tap - kh * (uint32_t)g.KW;
@@ -212,7 +370,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
                 constexpr int TOT = AI + BI, PER = (TOT + 2) / 3;
 #pragma unroll
                 for (int q = 0; q < TOT; ++q) {
-                    if (q / PER != c) continue;
+                    if (q / PER != c || (SF_GLDS_ABLATE & 1)) continue;
                     if (q < AI) GLDS16(asrc[q < AI ? q : 0] + aoff, na + (q * 4 + wave) * 256);
                     else GLDS16(bsrc[q >= AI ? q - AI : 0] + kn, nb + ((q - AI) * 4 + wave) * 256);
                 }
@@ -233,6 +391,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
         const float *sa = lds + stage * STAGE;
         mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
     }
+    }  // !ZL
     // epilogue: uniform base pointer + one 32-bit lane offset; the activation kind and the "tile is complete" test
     // are hoisted out of the 16*TM*TN element loop (per element: bias add, max, address add, store — the first
     // version re-derived a 64-bit m*N+n and branched on the kind per element: 13 VALU + 3 quarter-rate multiplies)
@@ -261,6 +420,26 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
     } else {
         store_fwd_tile<TM, TN, -1, false>(acc, ob, voff, N, rows_left, cols_left, bias ? bias + n0 + wn * TN * 32 : nullptr, lane & 31, g.relu);
     }
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                  const float *__restrict__ wt, const float *__restrict__ bias,
+                                                  float *__restrict__ out, int64_t Mtot, int k_per_split,
+                                                  float *__restrict__ partial, const float *__restrict__ dmask,
+                                                  int dmask_on, int rx = 0, int ry = 0, int rtot = 0, int tap_perm = 0) {
+    fwd_glds_body<BM, BN, WM, WN, NS, false>(g, in, in_stride, wt, bias, out, Mtot, k_per_split, partial, dmask, dmask_on, rx,
+                                             ry, rtot, tap_perm);
+}
+// the same kernel with the zero-VALU k-loop (see fwd_glds_body, ZL)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_fwd_glds_z(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                    const float *__restrict__ wt, const float *__restrict__ bias,
+                                                    float *__restrict__ out, int64_t Mtot, int k_per_split,
+                                                    float *__restrict__ partial, const float *__restrict__ dmask,
+                                                    int dmask_on, int rx = 0, int ry = 0, int rtot = 0, int tap_perm = 0) {
+    fwd_glds_body<BM, BN, WM, WN, 2, true>(g, in, in_stride, wt, bias, out, Mtot, k_per_split, partial, dmask, dmask_on, rx, ry,
+                                           rtot, tap_perm);
 }
 
 // out[m][n] = sum_k A1[m][k] W1t[n][k] + sum_k A2[m][k] W2t[n][k] + bias1[n] + bias2[n]: TWO linear layers into one
@@ -387,10 +566,10 @@ __device__ __attribute__((aligned(128))) const float sf_zero_page[32] = {};
 //   B[c][co] = W[(kh*KW + kw)*Cin + c][co]
 // Work-group ids are dealt round-robin to the 8 XCDs; the ids are re-mapped so that all pixel rows of one sample tile
 // run on the same XCD and share its L2 copy of that tile's dY.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
-                                                   const float *__restrict__ in_act, float *__restrict__ din,
-                                                   int nsamples, int ntiles, int tiles8, int lpt) {
+template <int BM, int BN, int WM, int WN, bool ZL>
+__device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
+                                               const float *__restrict__ in_act, float *__restrict__ din,
+                                               int nsamples, int ntiles, int tiles8, int lpt) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;
@@ -560,12 +739,39 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
         p.total = 0;
         return p;
     };
+    // ZL (k_dgrad_pix_z): DMA as uniform base + 32-bit lane offset (glds16_s), fragments through per-lane LDS pointers with
+    // the stage as an immediate (mma_chunk_stage): no vector-ALU instruction in the reduction loop (see fwd_glds_body)
+    uint32_t avoff[AI], bvoff[BI];
+    const float *apl[4], *bpl[4];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+    if constexpr (ZL) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) avoff[i] = (uint32_t)((asrc[i] - dy) * (int64_t)sizeof(float));
+#pragma unroll
+        for (int i = 0; i < BI; ++i) bvoff[i] = (uint32_t)((bsrc[i] - w) * (int64_t)sizeof(float));
+        const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int pos = (((2 * c + h) ^ sw) << 2);
+            apl[c] = lds + (wm * TM * 32 + r) * 32 + pos;
+            bpl[c] = lds + BM * 32 + (wn * TN * 32 + r) * 32 + pos;
+        }
+    }
     auto issue = [&](const Px &p, int q, int stage) {
         const int tap = q / CC, cc = q - tap * CC;  // CC, nb: small wave-uniform divisors (scalar unit)
         const int a = a_lo + tap / p.nb, b = p.b_lo + tap % p.nb;
         const int oh = ihc - a, ow = p.iwc - b, kh = ph + a * S, kw = p.pw + b * S;
         const int64_t aoff = (int64_t)(oh * OW + ow) * Cout + cc * 32;
         const int64_t boff = (int64_t)((kh * g.KW + kw) * Cin) * Cout + cc * 32;
+        if constexpr (ZL) {
+            const float *ab = dy + aoff, *bb = w + boff;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) glds16_s(ab, avoff[i], lds0 + (uint32_t)((stage * STAGE + (i * 4 + wave) * 256) * 4));
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                glds16_s(bb, bvoff[i], lds0 + (uint32_t)((stage * STAGE + BM * 32 + (i * 4 + wave) * 256) * 4));
+            return;
+        }
         float *sa = lds + stage * STAGE, *sb = sa + BM * 32;
 #pragma unroll
         for (int i = 0; i < AI; ++i) GLDS16(asrc[i] + aoff, sa + (i * 4 + wave) * 256);
@@ -579,6 +785,24 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
     while (cur.iw < g.W) {
         const Px nx = pixel(cur.iw + 1);
         zero_acc();
+        if constexpr (ZL) {
+            // every tap is CC chunks and CC is even (the launcher's contract for this form: Cout % 64 == 0), so a pixel
+            // always starts in stage 0: two chunks per trip with the stage as a compile-time constant
+            auto chunk = [&](int q, auto stc) {
+                constexpr int ST = decltype(stc)::value;  // (only the even chunk of a pair can be a pixel's first)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (ST == 0 && q == 0 && parked >= 0) store_pixel(parked);
+                if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
+                else if (nx.iw < g.W) issue(nx, 0, ST ^ 1);
+                if (ST == 0 && q == 0) prefetch_act(cur.iw);
+                mma_chunk_ptrs<TM, TN, ST * STAGE>(apl, bpl, acc);
+            };
+            for (int q = 0; q < cur.total; q += 2) {
+                chunk(q, std::integral_constant<int, 0>{});
+                chunk(q + 1, std::integral_constant<int, 1>{});
+            }
+        } else
         for (int q = 0; q < cur.total; ++q, stage ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -595,6 +819,18 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
         cur = nx;
     }
     if (parked >= 0) store_pixel(parked);
+}
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
+                                                   const float *__restrict__ in_act, float *__restrict__ din,
+                                                   int nsamples, int ntiles, int tiles8, int lpt) {
+    dgrad_pix_body<BM, BN, WM, WN, false>(g, dy, w, in_act, din, nsamples, ntiles, tiles8, lpt);
+}
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_dgrad_pix_z(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
+                                                     const float *__restrict__ in_act, float *__restrict__ din,
+                                                     int nsamples, int ntiles, int tiles8, int lpt) {
+    dgrad_pix_body<BM, BN, WM, WN, true>(g, dy, w, in_act, din, nsamples, ntiles, tiles8, lpt);
 }
 
 // ============================================================================================== WEIGHT GRADIENT (glds)
@@ -973,10 +1209,10 @@ __global__ __launch_bounds__(256) void k_conv_u8_img_norm(ConvG g, const uint8_t
 // structural-zero work left).  Measured (n = 32768, conv2): class-decomposed im2col kernel 2.98 ms, pixel-major
 // 2.51 ms, this kernel 2.33 ms; with all memory traffic removed 1.65 ms — the epilogue's 64 loads + 64 stores per lane
 // and step, not the matrix pipe, are what is left.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *__restrict__ dy,
-                                                         const float *__restrict__ w, const float *__restrict__ in_act,
-                                                         float *__restrict__ din, int64_t Mrows, FastDiv dWg) {
+template <int BM, int BN, int WM, int WN, bool ZL>
+__device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restrict__ dy,
+                                                   const float *__restrict__ w, const float *__restrict__ in_act,
+                                                   float *__restrict__ din, int64_t Mrows, FastDiv dWg) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;
@@ -1119,6 +1355,23 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
         while (p.ihc < Hg && p.total == 0) p = step(p.ihc + 1);
         return p;
     };
+    // ZL (k_dgrad_quadrow_z): fragments through per-lane LDS pointers with the stage as an immediate, the weight operand's
+    // DMA as uniform base + 32-bit lane offset.  (The dY operand keeps 64-bit lane addresses: a lane whose tap column is
+    // outside dY reads the zero page, which no 32-bit offset from dY can name.)
+    uint32_t bvoff[BI];
+    const float *apl[4], *bpl[4];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+    if constexpr (ZL) {
+#pragma unroll
+        for (int i = 0; i < BI; ++i) bvoff[i] = (uint32_t)((bsrc[i] - w) * (int64_t)sizeof(float));
+        const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int pos = (((2 * c + h) ^ sw) << 2);
+            apl[c] = lds + (wm * TM * 32 + r) * 32 + pos;
+            bpl[c] = lds + BM * 32 + (wn * TN * 32 + r) * 32 + pos;
+        }
+    }
     auto issue = [&](const St &p, int q, int stage) {
         const int blk = q / CC, cc = q - blk * CC;
         const int a = p.a_lo + blk / KWs, b = blk % KWs;
@@ -1130,6 +1383,13 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
             const int ow = aiwc[i] - b;
             const float *src = (ow >= 0 && ow < OW) ? asrc[i] + aoff : sf_zero_page + zpos;
             GLDS16(src, sa + (i * 4 + wave) * 256);
+        }
+        if constexpr (ZL) {
+            const float *bb = w + boff;
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                glds16_s(bb, bvoff[i], lds0 + (uint32_t)((stage * STAGE + BM * 32 + (i * 4 + wave) * 256) * 4));
+            return;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + boff, sb + (i * 4 + wave) * 256);
@@ -1146,6 +1406,21 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
             for (int b_ = 0; b_ < TN; ++b_)
 #pragma unroll
                 for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+        if constexpr (ZL) {  // CC even (launcher contract): a step starts in stage 0, two chunks per trip, static stages
+            auto chunk = [&](int q, auto stc) {
+                constexpr int ST = decltype(stc)::value;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
+                else if (nx.ihc < Hg) issue(nx, 0, ST ^ 1);
+                if (ST == 0 && q == 0) prefetch_act(cur.ihc);
+                mma_chunk_ptrs<TM, TN, ST * STAGE>(apl, bpl, acc);
+            };
+            for (int q = 0; q < cur.total; q += 2) {
+                chunk(q, std::integral_constant<int, 0>{});
+                chunk(q + 1, std::integral_constant<int, 1>{});
+            }
+        } else
         for (int q = 0; q < cur.total; ++q, stage ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1159,6 +1434,18 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *
         for (int z = cur.ihc + 1; z < nx.ihc && z < Hg; ++z) store_step(z, true);
         cur = nx;
     }
+}
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_dgrad_quadrow(ConvG g, const float *__restrict__ dy,
+                                                         const float *__restrict__ w, const float *__restrict__ in_act,
+                                                         float *__restrict__ din, int64_t Mrows, FastDiv dWg) {
+    dgrad_quadrow_body<BM, BN, WM, WN, false>(g, dy, w, in_act, din, Mrows, dWg);
+}
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_dgrad_quadrow_z(ConvG g, const float *__restrict__ dy,
+                                                           const float *__restrict__ w, const float *__restrict__ in_act,
+                                                           float *__restrict__ din, int64_t Mrows, FastDiv dWg) {
+    dgrad_quadrow_body<BM, BN, WM, WN, true>(g, dy, w, in_act, din, Mrows, dWg);
 }
 
 // ============================================================================================== WEIGHT GRADIENT, raw u8 frames
