@@ -1478,9 +1478,19 @@ static int conv_wgrad_impl(const void *in, int64_t in_sample_stride, const int32
         const int rx = (int)gq.x, ry = (int)gq.y, rtot = (xcd_raster_on() && gq.x * gq.y > 1) ? (int)(gq.x * gq.y * gq.z) : 0;
         if (rtot > 0) gq = dim3((unsigned)(8 * ((rtot + 7) / 8)), 1, 1);
         const float *inf = reinterpret_cast<const float *>(in);
+        // linear layers: the zero-VALU reduction loop (k_wgrad_glds_z); SF_WGRAD_ZL=0 switches it off
+        static const int wzl = getenv("SF_WGRAD_ZL") ? atoi(getenv("SF_WGRAD_ZL")) : 1;
+        const bool wgrad_zl = wzl && g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && g.OH == 1 && g.OW == 1 &&
+                              n * in_sample_stride < (1LL << 30) && Mtot * N < (1LL << 30);
 #define WGRAD_GLDS(BK_, BN_, WM_, WN_)                                                                      \
+    do {                                                                                                    \
+        if (wgrad_zl)                                                                                       \
+            k_wgrad_glds_z<BK_, BN_, WM_, WN_><<<gq, dim3(256), 0, st>>>(g, inf, in_sample_stride, dout, partial_w, \
+                                                                        db ? partial_b : nullptr, Mtot, q.m_per_split, rx, ry, rtot); \
+        else                                                                                                \
     k_wgrad_glds<BK_, BN_, WM_, WN_><<<gq, dim3(256), 0, st>>>(g, inf, in_sample_stride, dout, partial_w,   \
-                                                              db ? partial_b : nullptr, Mtot, q.m_per_split, rx, ry, rtot)
+                                                              db ? partial_b : nullptr, Mtot, q.m_per_split, rx, ry, rtot); \
+    } while (0)
         if (q.cfg == 3) WGRAD_GLDS(64, 128, 2, 2);
         else if (q.cfg == 0) WGRAD_GLDS(256, 64, 4, 1);
         else if (q.cfg == 1) WGRAD_GLDS(128, 128, 2, 2);
@@ -1731,8 +1741,9 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         snprintf(out, cap, wgrad_img_variant(h_desc, n) == 1 ? "k_wgrad_img<64, 9, 9, 3, 1, 1>" : "k_wgrad_img<32, 20, 20, 4, 2, 2>");
     } else if (op == 1 && mode == MODE_F32 && wgrad_glds_wanted(Mtot, g.K, g.Cout) && (int64_t)n * g.H * g.W * g.Cin < ((int64_t)1 << 30)) {
         const WgradGlds q = plan_wgrad_glds(Mtot, g.K, g.Cout);
-        snprintf(out, cap, q.cfg == 3 ? "k_wgrad_glds<64, 128, 2, 2>" : q.cfg == 0 ? "k_wgrad_glds<256, 64, 4, 1>" : q.cfg == 1 ? "k_wgrad_glds<128, 128, 2, 2>"
-                                                                                  : "k_wgrad_glds<128, 64, 2, 2>");
+        static const int wzl = getenv("SF_WGRAD_ZL") ? atoi(getenv("SF_WGRAD_ZL")) : 1;
+        const bool z = wzl && g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && n * (int64_t)g.Cin < (1LL << 30) && Mtot * g.Cout < (1LL << 30);
+        snprintf(out, cap, "k_wgrad_glds%s<%s>", z ? "_z" : "", q.cfg == 3 ? "64, 128, 2, 2" : q.cfg == 0 ? "256, 64, 4, 1" : q.cfg == 1 ? "128, 128, 2, 2" : "128, 64, 2, 2");
     } else if (op == 1) {
         if (wgrad_bn(g.Cout) == 32) snprintf(out, cap, "k_conv_wgrad<32, 4, 1, %d>", mode);
         else snprintf(out, cap, "k_conv_wgrad<64, 2, 2, %d>", mode);

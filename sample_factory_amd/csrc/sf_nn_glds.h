@@ -851,11 +851,15 @@ __device__ __forceinline__ float vec_elem(const typename VecW<W>::T &v, int i) {
     else return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
 }
 
-template <int BK, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
-                                                    const float *__restrict__ dy, float *__restrict__ partial,
-                                                    float *__restrict__ partial_b, int64_t Mtot, int64_t m_per_split,
-                                                    int rx, int ry, int rtot) {
+// ZL (k_wgrad_glds_z, LINEAR layers only: 1x1 window on a 1x1 image, i.e. reduction row m = sample m): the row decode that
+// sits in the general kernel's k-loop (two fast divisions, the patch origin, one ds_bpermute per DMA instruction) collapses
+// to "uniform base + per-lane constant": both operands' DMA in SADDR form (glds16_s), fragment reads as VGPR + immediate
+// with two chunks per trip (static stages) — no vector-ALU instruction in the reduction loop besides the bias column sums.
+template <int BK, int BN, int WM, int WN, bool ZL>
+__device__ __forceinline__ void wgrad_glds_body(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                const float *__restrict__ dy, float *__restrict__ partial,
+                                                float *__restrict__ partial_b, int64_t Mtot, int64_t m_per_split,
+                                                int rx, int ry, int rtot) {
     constexpr int TM = BK / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4 && (TM == 1 || TM == 2 || TM == 4) && (TN == 1 || TN == 2 || TN == 4), "tile");
     // XCD-aware block order (rtot > 0: 1-D launch of 8 * ceil(rtot / 8) blocks).  The hardware deals consecutive block ids
@@ -945,9 +949,72 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
     };
     const bool do_colsum = partial_b != nullptr && bx == 0 && tid < BN;
     float colacc = 0.f;
-    if (mbeg < mend) issue(mbeg, 0);
     int stage = 0;
-    for (int64_t mc = mbeg; mc < mend; mc += 32, stage ^= 1) {
+    int64_t mc0 = mbeg;
+    if constexpr (ZL) {
+        // ---- full 32-row chunks of a linear layer; a ragged last chunk (and nothing else) takes the general loop below
+        const int64_t nfull = (mend - mbeg) / 32;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+        uint32_t avoff[AI], bvoff[BI];
+#pragma unroll
+        for (int i = 0; i < AI; ++i)  // row (inside a chunk) of instruction i = ((i*4 + wave)*A_RPI + a_r); linear layer: origin 0
+            avoff[i] = (uint32_t)(((i * 4 + wave) * A_RPI + a_r) * (int)in_stride * 4) + a_tapb;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) bvoff[i] = b_offb[i];
+        const int i_ = lane & 31, h_ = lane >> 5;
+        const int acol = ((((wm * TM * 32 + TM * i_) >> 2) ^ (h_ << 3)) << 2) | ((TM * i_) & 3);
+        const int bcol = ((((wn * TN * 32 + TN * i_) >> 2) ^ (h_ << 3)) << 2) | ((TN * i_) & 3);
+        const float *ap0 = lds + h_ * BK + acol, *bp0 = lds + BK * 32 + h_ * BN + bcol;  // stage 0
+        auto dma = [&](int64_t mc, int st) {
+            const char *ab = reinterpret_cast<const char *>(in) + mc * in_stride * 4;
+            const char *bb = reinterpret_cast<const char *>(dy + mc * N);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) glds16_s(ab, avoff[i], lds0 + (uint32_t)((st * STAGE + (i * 4 + wave) * 256) * 4));
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                glds16_s(bb, bvoff[i], lds0 + (uint32_t)((st * STAGE + BK * 32 + (i * 4 + wave) * 256) * 4));
+        };
+        auto chunk = [&](int64_t mc, int64_t mlast, auto stc) {  // multiply chunk mc out of stage ST, stream mc + 32 into ST ^ 1
+            constexpr int ST = decltype(stc)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (mc + 32 < mlast) dma(mc + 32, ST ^ 1);
+            if (do_colsum) {
+                const float *sb = lds + ST * STAGE + BK * 32;
+#pragma unroll 8
+                for (int kk = 0; kk < 32; ++kk) colacc += sb[kk * BN + ((((tid >> 2) ^ ((kk & 1) << 3)) << 2) | (tid & 3))];
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const typename VecW<TM>::T a = *reinterpret_cast<const typename VecW<TM>::T *>(ap0 + ST * STAGE + 2 * s_ * BK);
+                const typename VecW<TN>::T b = *reinterpret_cast<const typename VecW<TN>::T *>(bp0 + ST * STAGE + 2 * s_ * BN);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_elem<TM>(a, tm), vec_elem<TN>(b, tn),
+                                                                           acc[tm][tn], 0, 0, 0);
+            }
+        };
+        const int64_t mlast = mbeg + nfull * 32;  // end of the full chunks
+        if (nfull > 0) dma(mbeg, 0);
+        int64_t mc = mbeg;
+        for (; mc + 64 <= mlast; mc += 64) {
+            chunk(mc, mlast, std::integral_constant<int, 0>{});
+            chunk(mc + 32, mlast, std::integral_constant<int, 1>{});
+        }
+        if (mc < mlast) {
+            chunk(mc, mlast, std::integral_constant<int, 0>{});
+            mc += 32;
+        }
+        mc0 = mc;  // == mlast
+        if (mc0 < mend) {  // ragged tail: every wave is past its last read of both stages only after a barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (mc0 < mend) issue(mc0, 0);
+    for (int64_t mc = mc0; mc < mend; mc += 32, stage ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (mc + 32 < mend) issue(mc + 32, stage ^ 1);
@@ -986,6 +1053,21 @@ __global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__rest
                 if (k < K && n < N) dst[(int64_t)k * N + n] = acc[tm][tn][r];
             }
         }
+}
+
+template <int BK, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wgrad_glds(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                    const float *__restrict__ dy, float *__restrict__ partial,
+                                                    float *__restrict__ partial_b, int64_t Mtot, int64_t m_per_split,
+                                                    int rx, int ry, int rtot) {
+    wgrad_glds_body<BK, BN, WM, WN, false>(g, in, in_stride, dy, partial, partial_b, Mtot, m_per_split, rx, ry, rtot);
+}
+template <int BK, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wgrad_glds_z(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                      const float *__restrict__ dy, float *__restrict__ partial,
+                                                      float *__restrict__ partial_b, int64_t Mtot, int64_t m_per_split,
+                                                      int rx, int ry, int rtot) {
+    wgrad_glds_body<BK, BN, WM, WN, true>(g, in, in_stride, dy, partial, partial_b, Mtot, m_per_split, rx, ry, rtot);
 }
 
 // ============================================================================================== FORWARD, raw u8 frames

@@ -18,7 +18,7 @@ GROUPS = [
     ("SF_CONV1_BF16=0 SF_CONV1_IMG=0 SF_DGRAD_PIX=0 SF_WGRAD_GLDS=0 SF_WGRAD_IMG=0 SF_FWD_IMG=0", " and not lds_image_forward_conv3"),
     # alternative tilings of the LDS-DMA kernels
     # ... and conv1 on the f32 strip-image kernels instead of the exact-product bf16 ones
-    ("SF_CONV1_BF16=0 SF_DGRAD_PIX=2 SF_WGRAD_GLDS=2 SF_WGRAD_IMG=0 SF_GLDS_CFG=2 SF_GLDS_ZL=0 SF_DGRAD_ZL=2", ""),
+    ("SF_CONV1_BF16=0 SF_DGRAD_PIX=2 SF_WGRAD_GLDS=2 SF_WGRAD_IMG=0 SF_GLDS_CFG=2 SF_GLDS_ZL=0 SF_DGRAD_ZL=2 SF_WGRAD_ZL=0", ""),
     ("SF_DGRAD_PIX=3 SF_WGRAD_GLDS=3 SF_WGRAD_IMG=1 SF_RELU_MASK=0 SF_GLDS_SPLITK=0", " and not splitk_small_grids and not relu_sign_bits"),
     # the tiled kernels for the narrow / small linear layers, the serial reduction of partials
     ("SF_LINEAR_NARROW=0 SF_REDUCE_TREE=0", " and not narrow_linear"),
