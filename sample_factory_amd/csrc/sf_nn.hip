@@ -1671,10 +1671,11 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
             g, dout, w, in_act, din, (int)n, ntiles, tiles8, dgrad_lpt());                                 \
     } while (0)
         // zero-VALU reduction loop (k_dgrad_pix_z / k_dgrad_quadrow_z): per-lane operand offsets must fit 32 bits
-        // SF_DGRAD_ZL (default 1): bit 0 = k_dgrad_quadrow_z (conv2: 1918 / 1921 -> 1877 / 1892 us at n = 32768), bit 1 =
-        // k_dgrad_pix_z (conv3: 1214 / 1234 -> 1316 / 1324 us — the form costs hipcc 256 + 168 registers against 173 + 32 and
-        // with them the second wave per SIMD: not used) — profiles/r05_k_dgrad_zl_ab.log
-        static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 1;
+        // SF_DGRAD_ZL (default 3): bit 0 = k_dgrad_quadrow_z (conv2: 1918 / 1921 -> 1877 / 1892 us at n = 32768), bit 1 =
+        // k_dgrad_pix_z with SADDR-form DMA only (conv3: 1308 / 1316 -> 1277 / 1297 us; the full form — pointer fragment reads,
+        // two chunks per trip — costs hipcc 256 + 168 registers against 173 + 32 and the second wave per SIMD with them:
+        // 1214 -> 1316 us, compile-time switch SF_DGRAD_PIX_ZL_LITE=0) — profiles/r05_k_dgrad_zl_ab.log, r05_n_dgrad_pix_lite_ab.log
+        static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 3;
         const bool dgrad_zl = dzl && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) &&
                               (int64_t)g.K * g.Cout < (1LL << 30);
         if (g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0 && pix_cfg != 3) {
@@ -1702,7 +1703,7 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
 // Name of the kernel instantiation a launch with these arguments resolves to (aligned operands assumed), spelled the
 // way rocprofv3 prints it, so that bench.py can group its HIP-event timings exactly like the rocprof kernel stats.
 static bool dgrad_quadrow_zl(const ConvG &g, int64_t n) {
-    static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 1;
+    static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 3;
     return (dzl & 1) && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) && (int64_t)g.K * g.Cout < (1LL << 30);
 }
 extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc, int split_k_allowed, char *out,

@@ -177,6 +177,9 @@ __device__ __forceinline__ void mma_chunk_ptrs(const float *const (&ap)[4], cons
     }
 }
 
+#ifndef SF_DGRAD_PIX_ZL_LITE
+#define SF_DGRAD_PIX_ZL_LITE 1  // k_dgrad_pix_z: 1 = SADDR-form DMA only (fragment reads stay "runtime stage + VALU add")
+#endif
 // the chunk out of stage `stage` (run-time, wave-uniform) of a two-stage pipeline: a scalar branch picks one of two copies of
 // the chunk whose stage offset is an immediate — the k-loops whose stage parity is not static (pipelines running across
 // pixel / step boundaries) get VALU-free fragment addressing this way
@@ -282,6 +285,28 @@ __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__
         return (kh * 4 + kw) << 5;
     };
     int stage = 0, k0 = kbeg;
+    // data-gradient launches with a ReLU mask (dmask = the layer's input activation): the tile's 16*TM*TN mask words are
+    // fetched in front of the LAST chunk's MFMAs instead of in the epilogue (where every group of 16 loads was a bare
+    // round trip to memory with nothing of this wave to overlap it)
+    constexpr bool MASK_PRE = ZL && TM * TN == 4;
+    float mpre[MASK_PRE ? TM : 1][MASK_PRE ? TN : 1][16];
+    bool mask_pre = false;
+    auto prefetch_mask = [&]() {
+        if constexpr (MASK_PRE) {
+            if (dmask_on && dmask && g.relu == 1 && m0 + BM <= Mtot && n0 + BN <= N) {
+                const float *mk = dmask + (m0 + wm * TM * 32) * N + (n0 + wn * TN * 32);
+                const uint32_t vo = (uint32_t)(4 * (lane >> 5)) * (uint32_t)N + (uint32_t)(lane & 31);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            mpre[tm][tn][r] = (mk + (int64_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * N + tn * 32)[vo];
+                mask_pre = true;
+            }
+        }
+    };
     if constexpr (ZL) {
 
         // ---- per-lane 32-bit byte offsets of the DMA sources (relative to `in` / `wt`), LDS fragment pointers of stage 0
@@ -320,6 +345,7 @@ __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__
             BARRIER_NOFENCE();
             const int kn = prefetch ? kord(k0 + 32) : 0;
             const float *ab = in + chunk_off(kn), *bb = wt + kn;
+            if (!prefetch) prefetch_mask();  // (last chunk of the tile)
             if constexpr (TM * TN <= 2) {  // DMA instructions spread over the first three MFMA groups
                 mma_chunk_ptrs_mid<TM, TN, ST * STAGE>(apl, bpl, acc, [&](int c) {
                     constexpr int TOT = AI + BI, PER = (TOT + 2) / 3;
@@ -405,6 +431,16 @@ __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__
         if (!dmask) {
             if (full) store_dgrad_tile<TM, TN, 0, true>(acc, ob, mk, voff, N, rows_left, cols_left, 0);
             else store_dgrad_tile<TM, TN, 0, false>(acc, ob, mk, voff, N, rows_left, cols_left, 0);
+        } else if (MASK_PRE && mask_pre) {  // (complete tile, ReLU) mask words already in registers
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = tm * 32 + (r & 3) + 8 * (r >> 2);
+                        (ob + (int64_t)rr * N + tn * 32)[voff] = act_bwd_mul<1>(acc[tm][tn][r], mpre[MASK_PRE ? tm : 0][MASK_PRE ? tn : 0][r], 1);
+                    }
         } else if (g.relu == 1) {
             if (full) store_dgrad_tile<TM, TN, 1, true>(acc, ob, mk, voff, N, rows_left, cols_left, 1);
             else store_dgrad_tile<TM, TN, 1, false>(acc, ob, mk, voff, N, rows_left, cols_left, 1);
@@ -433,7 +469,7 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
 }
 // the same kernel with the zero-VALU k-loop (see fwd_glds_body, ZL)
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_fwd_glds_z(ConvG g, const float *__restrict__ in, int64_t in_stride,
+__global__ __launch_bounds__(256, 2) void k_fwd_glds_z(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                                     const float *__restrict__ wt, const float *__restrict__ bias,
                                                     float *__restrict__ out, int64_t Mtot, int k_per_split,
                                                     float *__restrict__ partial, const float *__restrict__ dmask,
@@ -785,7 +821,7 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
     while (cur.iw < g.W) {
         const Px nx = pixel(cur.iw + 1);
         zero_acc();
-        if constexpr (ZL) {
+        if constexpr (ZL && !SF_DGRAD_PIX_ZL_LITE) {
             // every tap is CC chunks and CC is even (the launcher's contract for this form: Cout % 64 == 0), so a pixel
             // always starts in stage 0: two chunks per trip with the stage as a compile-time constant
             auto chunk = [&](int q, auto stc) {
