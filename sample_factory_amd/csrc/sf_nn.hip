@@ -975,7 +975,10 @@ extern "C" int sf_conv_fwd_relu_mask(const void *in, int64_t in_sample_stride, c
 // work-group per CU whose 8 waves all stop at the same block barrier (110 vs 117 TFLOP/s); strips of 3 output rows —
 // X(32, 20, 20, 4, 2, 2, 1, 3), 20 KB per strip, two work-groups per CU — reach 115: a third more image bytes (strip
 // overlap), 2-way bank conflicts where a fragment wraps to the next output row, fewer MFMAs per block step.
-#define IMG_FWD_GEOMS(X) X(64, 9, 9, 3, 1, 2, 1, 7)
+#ifndef SF_IMG_TMF
+#define SF_IMG_TMF 2  // 16-row fragments per wave and block step of the conv3 LDS-image forward (experiment switch)
+#endif
+#define IMG_FWD_GEOMS(X) X(64, 9, 9, 3, 1, SF_IMG_TMF, 1, 7)
 static int img_fwd_index(const ConvG &g, int64_t n) {
     static const int on = getenv("SF_FWD_IMG") ? atoi(getenv("SF_FWD_IMG")) : 1;
     if (!on || g.Cout != 64 || g.KH != g.KW || n < 512) return -1;

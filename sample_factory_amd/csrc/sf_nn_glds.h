@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256) void k_dgrad_pix(ConvG g, const float *__restr
     dgrad_pix_body<BM, BN, WM, WN, false>(g, dy, w, in_act, din, nsamples, ntiles, tiles8, lpt);
 }
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_dgrad_pix_z(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void k_dgrad_pix_z(ConvG g, const float *__restrict__ dy, const float *__restrict__ w,
                                                      const float *__restrict__ in_act, float *__restrict__ din,
                                                      int nsamples, int ntiles, int tiles8, int lpt) {
     dgrad_pix_body<BM, BN, WM, WN, true>(g, dy, w, in_act, din, nsamples, ntiles, tiles8, lpt);
