@@ -180,13 +180,16 @@ def test_glds_fwd_small_inference_launches_vs_torch(lib, n):
     splits): conv2 on 64 x 64 LDS-DMA tiles, the fc layer on 64 x 64 tiles split along K with deterministic slice order —
     both used to fall to the register-staged kernels (profiles/r05_b_kbench_small_n.log: fc at n = 512 170 -> 26 us)"""
     import torch.nn.functional as F
-    default = not any(os.environ.get(k) for k in ("SF_GLDS_SMALL64", "SF_GLDS_SPLIT64", "SF_GLDS_MIN_TILES", "SF_GLDS_CFG"))
+    default = not any(os.environ.get(k) for k in ("SF_GLDS_SMALL64", "SF_GLDS_SPLIT64", "SF_GLDS_MIN_TILES", "SF_GLDS_CFG",
+                                                  "SF_GLDS_SPLITK", "SF_GLDS_ZL"))
     g = torch.Generator().manual_seed(n)
     # conv2: 32 x 20 x 20 -> 64, 4 x 4 stride 2
     d = desc(lib, 32, 20, 20, 64, 4, 2)
     x = torch.randn((n, 32, 20, 20), generator=g)
     w_ref = torch.randn((64, 32, 4, 4), generator=g) / np.sqrt(512)
     b = torch.randn(64, generator=g) * 0.1
+    if not default and not lib.conv_fwd_t_supported(n, d):
+        pytest.skip("the switch under test sends this launch back to the register-staged kernels")
     assert lib.conv_fwd_t_supported(n, d)
     if default and n <= 1024:
         assert lib.conv_kernel_name(3, n, d) in ("k_fwd_glds<64, 64, 2, 2, 2>", "k_fwd_glds_z<64, 64, 2, 2>"), lib.conv_kernel_name(3, n, d)
@@ -205,6 +208,8 @@ def test_glds_fwd_small_inference_launches_vs_torch(lib, n):
     x = torch.randn((n, Cin), generator=g)
     w_ref = torch.randn((cout, Cin), generator=g) / np.sqrt(Cin)
     b = torch.randn(cout, generator=g) * 0.1
+    if not default and not lib.conv_fwd_t_supported(n, d):
+        return
     assert lib.conv_fwd_t_supported(n, d)
     nb = lib.conv_fwd_t_workspace(n, d)
     if default:
