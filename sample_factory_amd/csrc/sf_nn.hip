@@ -1216,6 +1216,21 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     // zero-VALU k-loop form (k_fwd_glds_z): every per-lane operand offset must fit 32 bits
     const bool zl_ok = glds_zl_on() && (n - 1) * in_sample_stride + (int64_t)g.H * g.W * g.Cin < (1LL << 30) &&
                        (int64_t)g.Cout * g.K < (1LL << 30);
+    // SF_GLDS_TALL=<min 256-row tiles> (experiment): 256 x 64 tiles (waves 4 x 1, 64 x 64 wave tiles) for 64-column layers with
+    // many rows — half the per-tile fixed cost and a sixth less DMA per flop, at two work-groups per CU instead of three
+    static const int tall = getenv("SF_GLDS_TALL") ? atoi(getenv("SF_GLDS_TALL")) : 0;
+    static const int persist = getenv("SF_GLDS_PERSIST") ? atoi(getenv("SF_GLDS_PERSIST")) : 0;
+    if (persist && !p.sq64 && !p.wide && p.Z == 1 && g.Cout <= 64 && zl_ok) {  // experiment: persistent row-tile walk
+        static const int occp = occupancy_of(k_fwd_glds_zp<128, 64, 2, 2>);
+        const int64_t tiles = cdiv64(Mtot, 128), slots = (int64_t)num_cus() * occp;
+        k_fwd_glds_zp<128, 64, 2, 2><<<dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(256), 0, st>>>(
+            g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split);
+    } else
+    if (tall && !p.sq64 && !p.wide && p.Z == 1 && g.Cout <= 64 && cdiv64(Mtot, 256) >= tall && zl_ok) {
+        dim3 gq(cdiv64(Mtot, 256), 1, 1);
+        k_fwd_glds_z<256, 64, 4, 1><<<gq, dim3(256), 0, st>>>(g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split,
+                                                                nullptr, nullptr, 0, 0, 0, 0, tap_perm_on());
+    } else
     if (p.sq64) GLDS_FWD(64, 64, 2, 2, 2);
     else if (p.wide) GLDS_FWD(128, 128, 2, 2, 2);
     else GLDS_FWD(128, 64, 2, 2, 2);

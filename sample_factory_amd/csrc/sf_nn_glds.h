@@ -197,7 +197,7 @@ __device__ __forceinline__ void mma_chunk_stage(const float *const (&ap)[4], con
 // constant.  The loop body is then MFMA + ds_read + DMA + scalar instructions only (the plain form spends 10 v_add_u32 and
 // 6 v_lshl_add_u64 per 32 MFMAs on addresses; vector ALU instructions do not overlap with MFMAs on a SIMD).  Needs
 // every per-lane operand offset < 4 GiB (the launcher checks).
-template <int BM, int BN, int WM, int WN, int NS, bool ZL>
+template <int BM, int BN, int WM, int WN, int NS, bool ZL, bool PERSIST = false>
 __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                               const float *__restrict__ wt, const float *__restrict__ bias,
                                               float *__restrict__ out, int64_t Mtot, int k_per_split,
@@ -214,7 +214,10 @@ __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__
     // run of the logical order COLUMN TILE FASTEST, then row tile, then slice — the ry column tiles of one activation row
     // strip run next to each other on one XCD (fc layer, n = 32768: the 411 MB activation matrix was fetched once per
     // column tile, 1.65 GB per launch); the weight strips they differ in are small and shared by every row strip anyway.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    // PERSIST (k_fwd_glds_zp, single-column unsplit launches): the work-group walks the row tiles b, b + grid, ...
+    const int ptiles = PERSIST ? (int)((Mtot + BM - 1) / BM) : 1;
+    for (int ptile = PERSIST ? (int)blockIdx.x : 0; ptile < ptiles; ptile += PERSIST ? (int)gridDim.x : 1) {
+    int bx = PERSIST ? ptile : (int)blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (rtot > 0) {
         const int per = (rtot + 7) >> 3, L = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
         if (L >= rtot) return;
@@ -456,6 +459,8 @@ __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__
     } else {
         store_fwd_tile<TM, TN, -1, false>(acc, ob, voff, N, rows_left, cols_left, bias ? bias + n0 + wn * TN * 32 : nullptr, lane & 31, g.relu);
     }
+    if (PERSIST) BARRIER_NOFENCE();  // every wave is past its last fragment read before the next tile's DMA lands
+    }  // ptile
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
@@ -466,6 +471,13 @@ __global__ __launch_bounds__(256) void k_fwd_glds(ConvG g, const float *__restri
                                                   int dmask_on, int rx = 0, int ry = 0, int rtot = 0, int tap_perm = 0) {
     fwd_glds_body<BM, BN, WM, WN, NS, false>(g, in, in_stride, wt, bias, out, Mtot, k_per_split, partial, dmask, dmask_on, rx,
                                              ry, rtot, tap_perm);
+}
+// ... and persistent (experiment: SF_GLDS_PERSIST)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_fwd_glds_zp(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                       const float *__restrict__ wt, const float *__restrict__ bias,
+                                                       float *__restrict__ out, int64_t Mtot, int k_per_split) {
+    fwd_glds_body<BM, BN, WM, WN, 2, true, true>(g, in, in_stride, wt, bias, out, Mtot, k_per_split, nullptr, nullptr, 0, 0, 0, 0, 0);
 }
 // the same kernel with the zero-VALU k-loop (see fwd_glds_body, ZL)
 template <int BM, int BN, int WM, int WN>
