@@ -900,15 +900,32 @@ static int conv_fwd_impl(const void *in, int64_t in_sample_stride, const int32_t
     static const int img_on = getenv("SF_CONV1_IMG") ? atoi(getenv("SF_CONV1_IMG")) : 1;
     // ... and on the bf16 matrix pipe with exact products (sf_nn_u8.h) when (pixel - mean) is an integer of <= 8 bits
     if (conv1_bf16_ok(g, mode, n) && ((uintptr_t)in & 3) == 0 && in_sample_stride % 4 == 0) {
-        const unsigned lds_bytes = 2u * 4u * 20u * 88u * (unsigned)sizeof(uint16_t);  // [SMP][Cin][RS][WP] bf16
-        const int64_t npairs = cdiv64(n, 2), resident = (int64_t)num_cus() * 2;     // two work-groups per CU
+        // [SMP][Cin][RS][WP] bf16 strip image + (whole-line stores) the staging tile [SMP][80][36] f32
+        const unsigned img_bytes = 2u * 4u * 20u * (unsigned)SF_CONV1_WP * (unsigned)sizeof(uint16_t);
+        // persistent grid: SF_CONV1_WGS work-groups per CU (default 2 = what the register budget of __launch_bounds__(256, 2) admits)
+        static const int wgs_per_cu = getenv("SF_CONV1_WGS") ? atoi(getenv("SF_CONV1_WGS")) : 2;
+        static const int occ_dbg = getenv("SF_DEBUG_OCC") ? atoi(getenv("SF_DEBUG_OCC")) : 0;
+        if (occ_dbg)
+            fprintf(stderr, "k_conv1_u8_bf16 occupancy: %d (dword stores, %u B LDS) / %d (whole-line stores, %u B LDS) work-groups per CU\n",
+                    occupancy_of(k_conv1_u8_bf16<false>, 256, img_bytes), img_bytes,
+                    occupancy_of(k_conv1_u8_bf16_w<false>, 256, img_bytes + 2u * 80u * 36u * 4u), img_bytes + 2u * 80u * 36u * 4u);
+        const int64_t npairs = cdiv64(n, 2), resident = (int64_t)num_cus() * wgs_per_cu;
         const unsigned grid_q = (unsigned)(npairs < resident ? npairs : resident);
-        if (g.sub_mean != 0.f)
-            k_conv1_u8_bf16<true><<<dim3(grid_q), dim3(256), lds_bytes, st>>>(
-                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, relu_mask, (int)n);
-        else
-            k_conv1_u8_bf16<false><<<dim3(grid_q), dim3(256), lds_bytes, st>>>(
-                g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, offset, w, bias, out, relu_mask, (int)n);
+        // SF_CONV1_WIDE (default 1): whole-line output stores through an LDS staging tile (sf_nn_u8.h) — N == 32, aligned output
+        static const int wide_on = getenv("SF_CONV1_WIDE") ? atoi(getenv("SF_CONV1_WIDE")) : 1;
+        const bool wide = wide_on && g.Cout == 32 && ((uintptr_t)out & 15) == 0;
+        const unsigned lds_bytes = img_bytes + (wide ? 2u * 80u * 36u * (unsigned)sizeof(float) : 0u);
+#define CONV1_BF16_LAUNCH(KERN)                                                                                       \
+    KERN<<<dim3(grid_q), dim3(256), lds_bytes, st>>>(g, reinterpret_cast<const uint8_t *>(in), in_sample_stride, index, \
+                                                    offset, w, bias, out, relu_mask, (int)n)
+        if (g.sub_mean != 0.f) {
+            if (wide) CONV1_BF16_LAUNCH(k_conv1_u8_bf16_w<true>);
+            else CONV1_BF16_LAUNCH(k_conv1_u8_bf16<true>);
+        } else {
+            if (wide) CONV1_BF16_LAUNCH(k_conv1_u8_bf16_w<false>);
+            else CONV1_BF16_LAUNCH(k_conv1_u8_bf16<false>);
+        }
+#undef CONV1_BF16_LAUNCH
         return sf_launch_status("sf_conv_fwd");
     }
     // only the kernel above records ReLU sign bits: every other path would leave the mask unwritten for the
@@ -1625,6 +1642,13 @@ static int dgrad_lpt() {  // longest rows first (k_dgrad_pix block order, sf_nn_
     static const int on = getenv("SF_DGRAD_LPT") ? atoi(getenv("SF_DGRAD_LPT")) : 1;
     return on;
 }
+// k_dgrad_quadrow_z addresses dY / W lanes as 32-bit element offsets and the input-gradient / activation elements as
+// 32-bit BYTE offsets from a uniform base: both tensors must stay below 2^30 elements
+static bool dgrad_quadrow_zl(const ConvG &g, int64_t n) {
+    static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 3;
+    return (dzl & 1) && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) &&
+           (int64_t)g.K * g.Cout < (1LL << 30) && n * (int64_t)g.H * g.W * g.Cin < (1LL << 30);
+}
 extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_act, float *din, int64_t n,
                              const sf_conv_desc *h_desc, void *stream) {
     int rc = check_desc(h_desc, "sf_conv_dgrad");
@@ -1700,7 +1724,7 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
             // strided conv, row-walking tiles of (sample, group-column) rows: contiguous activation / gradient rows
             const int Wg = g.W / g.S;
             const int64_t Mrows = n * Wg;
-            if (dgrad_zl && (dzl & 1))
+            if (dgrad_quadrow_zl(g, n))
                 k_dgrad_quadrow_z<128, 128, 2, 2><<<dim3(cdiv64(Mrows, 128), cdiv64(g.S * g.S * g.Cin, 128)), dim3(256), 0,
                                                     st>>>(g, dout, w, in_act, din, Mrows, make_fastdiv((uint32_t)Wg));
             else
@@ -1720,10 +1744,15 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
 
 // Name of the kernel instantiation a launch with these arguments resolves to (aligned operands assumed), spelled the
 // way rocprofv3 prints it, so that bench.py can group its HIP-event timings exactly like the rocprof kernel stats.
-static bool dgrad_quadrow_zl(const ConvG &g, int64_t n) {
-    static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 3;
-    return (dzl & 1) && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) && (int64_t)g.K * g.Cout < (1LL << 30);
+#if SF_CONV1_TRACE
+// experiment builds only (tools/conv1_trace.py): read and clear the per-phase cycle sums of k_conv1_u8_bf16
+extern "C" int sf_debug_conv1_trace(unsigned long long *host_out12) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(host_out12, HIP_SYMBOL(sf_conv1_trace_acc), 12 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(sf_conv1_trace_acc), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
+#endif
 extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc, int split_k_allowed, char *out,
                                    int cap) {
     int rc = check_desc(h_desc, "sf_conv_kernel_name");
@@ -1733,7 +1762,9 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
     const int64_t Mtot = n * g.OH * g.OW;
     const int mode = pick_mode(g);
     if (op == 0 && conv1_img_ok(g, mode, n)) {
-        if (conv1_bf16_ok(g, MODE_U8, n)) snprintf(out, cap, g.sub_mean != 0.f ? "k_conv1_u8_bf16<true>" : "k_conv1_u8_bf16<false>");
+        static const int wide_on = getenv("SF_CONV1_WIDE") ? atoi(getenv("SF_CONV1_WIDE")) : 1;
+        if (conv1_bf16_ok(g, MODE_U8, n))
+            snprintf(out, cap, "k_conv1_u8_bf16%s<%s>", wide_on && g.Cout == 32 ? "_w" : "", g.sub_mean != 0.f ? "true" : "false");
         else snprintf(out, cap, g.sub_mean != 0.f ? "k_conv_u8_img<2, 4, 5, 16, true>" : "k_conv_u8_img<2, 4, 5, 16, false>");
     } else if (op == 0) {
         const FwdPlan p = plan_fwd(Mtot, g.Cout, g.K, split_k_allowed ? (int64_t)1 << 60 : 0);

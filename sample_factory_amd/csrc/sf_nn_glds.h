@@ -155,7 +155,9 @@ __device__ __forceinline__ void mma_chunk_ptrs_mid(const float *const (&ap)[4], 
 
 // mma_chunk_rows (fragments of a group fetched together, no scheduling fences: the form the 64x64 wave tiles want) with
 // pointer + compile-time-offset addressing
-template <int TM, int TN, int OFF>
+// ZEROC: the chunk STARTS an accumulation — the first MFMA of every accumulator takes the constant 0 as its C operand
+// (an inline constant of the instruction) instead of a register tile that 16 v_mov per tile would have to clear first
+template <int TM, int TN, int OFF, bool ZEROC = false>
 __device__ __forceinline__ void mma_chunk_ptrs(const float *const (&ap)[4], const float *const (&bp)[4],
                                                f32x16 (&acc)[TM][TN]) {
 #pragma unroll
@@ -170,10 +172,13 @@ __device__ __forceinline__ void mma_chunk_ptrs(const float *const (&ap)[4], cons
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < TN; ++tn) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                         j == 0 ? a[tm].x : j == 1 ? a[tm].y : j == 2 ? a[tm].z : a[tm].w,
-                        j == 0 ? b[tn].x : j == 1 ? b[tn].y : j == 2 ? b[tn].z : b[tn].w, acc[tm][tn], 0, 0, 0);
+                        j == 0 ? b[tn].x : j == 1 ? b[tn].y : j == 2 ? b[tn].z : b[tn].w,
+                        (ZEROC && c == 0 && j == 0) ? zero : acc[tm][tn], 0, 0, 0);
+                }
     }
 }
 
@@ -1361,7 +1366,9 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
         const int64_t m = m0 + tid;
         const uint32_t mm = m < Mrows ? (uint32_t)m : 0u;
         const uint32_t s = fdiv(mm, dWg), iwc = mm - s * (uint32_t)Wg;
-        rowoff[tid] = m < Mrows ? s * sstride + iwc * (uint32_t)(S * Cin) : 0xFFFFFFFFu;
+        // ZL: BYTE offsets (the launcher guarantees n*H*W*Cin*4 < 2^32), so that "uniform base + 32-bit lane offset" stores and
+        // loads need one v_add_u32 per element instead of a 64-bit address build-up
+        rowoff[tid] = m < Mrows ? (s * sstride + iwc * (uint32_t)(S * Cin)) * (ZL ? 4u : 1u) : 0xFFFFFFFFu;
     }
     const int lrow = lane >> 3, lpos = lane & 7;
     const float *asrc[AI], *bsrc[BI];
@@ -1397,7 +1404,7 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
         phv[tn] = pp / S;
         pwv[tn] = pp - phv[tn] * S;
         colok[tn] = n < N;
-        cbase[tn] = (uint32_t)((phv[tn] * W + pwv[tn]) * Cin + c);
+        cbase[tn] = (uint32_t)((phv[tn] * W + pwv[tn]) * Cin + c) * (ZL ? 4u : 1u);
     }
     const int rbase = wm * TM * 32 + 4 * (lane >> 5);
     float actv[TM][TN][16];
@@ -1405,9 +1412,17 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
     // Complete tiles (all rows real, all columns real, no group row hanging over the image) skip the per-element
     // predicates; the activation kind is hoisted out of the element loops.
     const bool full = m0 + BM <= Mrows && n0 + BN <= N && H % S == 0;
+    auto ld32 = [&](const float *base, uint32_t off) {  // ZL: off in bytes; else in elements
+        if constexpr (ZL) return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)off);
+        else return base[off];
+    };
+    auto st32 = [&](float *base, uint32_t off, float v) {
+        if constexpr (ZL) *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (size_t)off) = v;
+        else base[off] = v;
+    };
     auto prefetch_act = [&](int ihc) {
         if (!in_act) return;
-        const uint32_t gy = (uint32_t)(ihc * S * W * Cin);
+        const uint32_t gy = (uint32_t)(ihc * S * W * Cin) * (ZL ? 4u : 1u);
         if (full) {
             uint32_t cb[TN];
 #pragma unroll
@@ -1418,7 +1433,7 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t ro = rowoff[rbase + tm * 32 + (r & 3) + 8 * (r >> 2)];
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) actv[tm][tn][r] = in_act[ro + cb[tn]];
+                    for (int tn = 0; tn < TN; ++tn) actv[tm][tn][r] = ld32(in_act, ro + cb[tn]);
                 }
             return;
         }
@@ -1430,12 +1445,12 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const bool ok = ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H;
-                    actv[tm][tn][r] = in_act[ok ? ro + gy + cbase[tn] : 0u];
+                    actv[tm][tn][r] = ld32(in_act, ok ? ro + gy + cbase[tn] : 0u);
                 }
             }
     };
     auto store_step = [&](int ihc, bool zero) {
-        const uint32_t gy = (uint32_t)(ihc * S * W * Cin);
+        const uint32_t gy = (uint32_t)(ihc * S * W * Cin) * (ZL ? 4u : 1u);
         const int akind = g.relu;
         auto body = [&](auto kc, auto fc) {
             constexpr int KIND = decltype(kc)::value;
@@ -1453,7 +1468,7 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
                         if (FULL || (ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H)) {
                             float v = zero ? 0.f : acc[tm][tn][r];
                             if (!zero) v = act_bwd_mul<KIND>(v, actv[tm][tn][r], akind);
-                            din[ro + cb[tn]] = v;
+                            st32(din, ro + cb[tn], v);
                         }
                 }
         };
@@ -1530,25 +1545,30 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
     int stage = 0;
     while (cur.ihc < Hg) {
         const St nx = next_step(cur.ihc + 1);
+        if constexpr (!ZL) {
 #pragma unroll
-        for (int a_ = 0; a_ < TM; ++a_)
+            for (int a_ = 0; a_ < TM; ++a_)
 #pragma unroll
-            for (int b_ = 0; b_ < TN; ++b_)
+                for (int b_ = 0; b_ < TN; ++b_)
 #pragma unroll
-                for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+                    for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+        }
         if constexpr (ZL) {  // CC even (launcher contract): a step starts in stage 0, two chunks per trip, static stages
-            auto chunk = [&](int q, auto stc) {
+            auto chunk = [&](int q, auto stc, auto firstc) {
                 constexpr int ST = decltype(stc)::value;
+                constexpr bool FIRST = decltype(firstc)::value;  // first chunk of the step: accumulation starts from the constant 0
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
                 else if (nx.ihc < Hg) issue(nx, 0, ST ^ 1);
-                if (ST == 0 && q == 0) prefetch_act(cur.ihc);
-                mma_chunk_ptrs<TM, TN, ST * STAGE>(apl, bpl, acc);
+                if (FIRST) prefetch_act(cur.ihc);
+                mma_chunk_ptrs<TM, TN, ST * STAGE, FIRST>(apl, bpl, acc);
             };
-            for (int q = 0; q < cur.total; q += 2) {
-                chunk(q, std::integral_constant<int, 0>{});
-                chunk(q + 1, std::integral_constant<int, 1>{});
+            chunk(0, std::integral_constant<int, 0>{}, std::true_type{});
+            chunk(1, std::integral_constant<int, 1>{}, std::false_type{});
+            for (int q = 2; q < cur.total; q += 2) {
+                chunk(q, std::integral_constant<int, 0>{}, std::false_type{});
+                chunk(q + 1, std::integral_constant<int, 1>{}, std::false_type{});
             }
         } else
         for (int q = 0; q < cur.total; ++q, stage ^= 1) {

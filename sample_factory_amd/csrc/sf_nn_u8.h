@@ -19,6 +19,25 @@
 //     the whole kernel: one wave per SIMD, 512-register budget.
 // MFMA layout (v_mfma_f32_16x16x32_bf16): A lane l -> row l & 15, k = 8 * (l >> 4) + j; B lane l -> col l & 15, same
 // k; C/D col = l & 15, row = 4 * (l >> 4) + reg.
+#ifndef SF_CONV1_WP
+#define SF_CONV1_WP 84  // LDS row pitch of the forward strip image, bf16 elements: 168 B = the packed row — a fragment of 16
+                       // pixels that wraps into the next output row (4 image rows = 672 B further) continues the bank sequence
+                       // (88: rollout-size launch 110 -> 105 us, profiles/r05_s_conv1_trace_quadrow.log)
+#endif
+#ifndef SF_CONV1_TRACE
+#define SF_CONV1_TRACE 0  // experiment builds only: per-phase shader-cycle sums of k_conv1_u8_bf16 (tools/conv1_trace.py)
+#endif
+#if SF_CONV1_TRACE
+__device__ unsigned long long sf_conv1_trace_acc[12];
+#define SF_C1T(i)                                 \
+    do {                                          \
+        const unsigned long long tn_ = clock64(); \
+        tacc_[i] += tn_ - tprev_;                 \
+        tprev_ = tn_;                             \
+    } while (0)
+#else
+#define SF_C1T(i)
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -39,21 +58,37 @@ __device__ __forceinline__ void split3_bf16(float w, uint32_t &hi, uint32_t &mid
 // phases are serial and nothing else is resident to fill them).  NCT = 1 (the one that is launched): SMP = 2 samples,
 // waves = 2 samples x 2 column tiles (an A fragment is read by two waves), 96 weight registers -> two work-groups per
 // CU whose phases overlap: 718 us.
-template <bool SUB, int NCT>
+// WIDE (N == 32, 16-byte aligned output): whole-line output stores through an LDS staging tile.  The MFMA hands lane
+// (c, rg) the 4 pixels 4*rg + r of ONE channel and this wave owns 16 of the 32 channels, so its natural stores are 64-byte
+// HALVES of the 128-byte pixel lines, the sibling wave writing the other halves a little earlier or later.  Measured
+// (tools/ubench/stream_rw.hip, profiles/r05_u_stream_rw.log): conv1's traffic mix (28 KB read + 51 KB written per sample,
+// nothing else) streams at 5.2-5.9 TB/s with whole-line stores and at 3.9 TB/s — 665 us at n = 32768, exactly this
+// kernel's time — when two waves write the halves.  (16-byte stores of the halves after an in-register DPP
+// transposition cut the store instructions 4x and the epilogue's issue time from 30 % to 18 % of the strip loop, and the
+// waves waited that much longer for their bytes instead: -1 %, profiles/r05_t_conv1_wide_stores.log.)
+// So: the activated tile goes to LDS as stg[SMP][80 pixels][36 words] (20 ds_write_b32 per lane and strip, immediate
+// offsets, conflict-free with the 144-byte pixel pitch), and AFTER the strip's trailing barrier every thread reads 5 x
+// 16 bytes back in output order and stores them with global_store_dwordx4: a wave instruction is 1 KB of contiguous
+// output.  No extra barrier: the next strip's staging writes come after its leading barrier.  The ReLU sign bits are
+// taken there too (4 channels per lane, OR over the 8 lanes of a pixel by DPP): one u32 store per pixel.
+template <bool SUB, int NCT, bool WIDE>
 __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride,
                                                    const int32_t *__restrict__ index, int64_t offset,
                                                    const float *__restrict__ w, const float *__restrict__ bias,
                                                    float *__restrict__ out, uint32_t *__restrict__ mask_out,
                                                    int nsamples) {
     constexpr int SMP = 2 * NCT, R = 4, TMF = 5, KB = 8;
-    constexpr int H = 84, W = 84, WP = 88, Cin = 4, KH = 8, S = 4, OH = 20, OW = 20, OHOW = OH * OW;
+    constexpr int H = 84, W = 84, WP = SF_CONV1_WP, Cin = 4, KH = 8, S = 4, OH = 20, OW = 20, OHOW = OH * OW;
     constexpr int RS = (R - 1) * S + KH;  // 20 input rows per strip
     constexpr int W4 = W >> 2;            // 4-byte words per input row
     constexpr int WORDS = Cin * RS * W4;  // u32 words per strip and sample
     constexpr int NLD = (WORDS + 255) / 256;
     constexpr int nstrips = OH / R;
     static_assert(R * OW == TMF * 16 && KB * 32 == Cin * KH * 8, "Nature-CNN conv1 geometry");
-    extern __shared__ __attribute__((aligned(16))) uint16_t img[];  // [SMP][Cin][RS][WP] bf16
+    extern __shared__ __attribute__((aligned(16))) uint16_t img[];  // [SMP][Cin][RS][WP] bf16, WIDE: + stg[SMP][R*OW][SP] f32
+    constexpr int SP = 36;  // staging pitch of a pixel, words: 32 channels + 4 (lanes kg and kg + 1 of a ds_write_b32 group land 16 banks apart)
+    float *const stg = reinterpret_cast<float *>(img + SMP * Cin * RS * WP);
+    static_assert((SMP * Cin * RS * WP * 2) % 16 == 0, "staging tile must start 16-byte aligned");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = g.Cout;
     const int wsmp = NCT == 2 ? wave : (wave >> 1), ct0 = NCT == 2 ? 0 : (wave & 1);  // this wave's sample / first column tile
@@ -137,11 +172,24 @@ __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__res
         origin[t] = (wsmp * Cin * RS + ohl * S + kg) * WP + ow * S;  // kh = 4*(kb & 1) + kg
     }
     const float scl = g.inv_scale;
+#if SF_CONV1_TRACE
+    unsigned long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+    const unsigned long long tc0_ = tprev_, tw0_ = wall_clock64();
+#endif
     for (int unit = 0; unit < total_units; ++unit) {
         const int lq = unit / nstrips, st = unit - lq * nstrips;
         const int s0 = ((int)blockIdx.x + lq * (int)gridDim.x) * SMP;
+#if SF_CONV1_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SF_C1T(0);  // waiting for the prefetched bytes (and this unit's output stores)
+#endif
         store_strip();
+#if SF_CONV1_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SF_C1T(1);  // convert + LDS writes
+#endif
         __syncthreads();
+        SF_C1T(2);  // barrier 1
         if (unit + 1 < total_units) load_strip(unit + 1);  // lands during the MFMA phase
         f32x4 acc[TMF][NCT];
 #pragma unroll
@@ -175,6 +223,15 @@ __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__res
                             acc[t][ct], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if SF_CONV1_TRACE
+        {
+            float sink = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMF; ++t) sink += acc[t][0][0];
+            asm volatile("" ::"v"(sink));  // results landed
+        }
+        SF_C1T(3);  // load issue + MFMA phase
+#endif
         auto epilogue = [&](auto kc) {
             constexpr int KIND = decltype(kc)::value;
             const bool sok = s0 + wsmp < nsamples;
@@ -184,6 +241,17 @@ __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__res
             // (kg) x 16 channels (col); lane (kg, col 0) stores its pixel's half.
             uint16_t *mb = mask_out ? reinterpret_cast<uint16_t *>(mask_out) +
                                           ((int64_t)(s0 + wsmp) * OHOW + st * (R * OW)) * 2 + ct0 : nullptr;
+            if constexpr (WIDE) {  // stage: lane (col, kg), register r -> pixel t*16 + 4*kg + r, channel ct*16 + col of this wave's sample
+                float *sl = stg + (wsmp * (R * OW) + 4 * kg) * SP + ct0 * 16 + col;
+#pragma unroll
+                for (int t = 0; t < TMF; ++t)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            sl[(t * 16 + r) * SP + ct * 16] = act_fwd_c<KIND>(acc[t][ct][r] * scl + bv[ct], g.relu);
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < TMF; ++t)
 #pragma unroll
@@ -202,8 +270,41 @@ __device__ __forceinline__ void conv1_u8_bf16_body(ConvG g, const uint8_t *__res
         };
         if (g.relu == 1) epilogue(std::integral_constant<int, 1>{});
         else epilogue(std::integral_constant<int, -1>{});
+        SF_C1T(4);  // epilogue issue
         __syncthreads();  // everybody is done reading this strip before it is overwritten
+        SF_C1T(5);  // barrier 2
+        if constexpr (WIDE) {  // the staged tile, in output order: thread -> 16-byte word q of [SMP][80 pixels][8 words]
+            constexpr int QS = R * OW * 8;  // 16-byte words per sample and strip
+#pragma unroll
+            for (int k = 0; k < (SMP * QS + 255) / 256; ++k) {
+                const int q = tid + 256 * k, z = q >= QS ? 1 : 0, qq = q - z * QS, px = qq >> 3, ch = qq & 7;
+                if (SMP * QS % 256 != 0 && q >= SMP * QS) break;
+                const float4 v = *reinterpret_cast<const float4 *>(stg + (z * (R * OW) + px) * SP + ch * 4);
+                const bool sok = s0 + z < nsamples;
+                const int64_t pix0 = (int64_t)(s0 + z) * OHOW + st * (R * OW);
+                if (sok) *reinterpret_cast<float4 *>(out + pix0 * 32 + qq * 4) = v;
+                if (g.relu == 1 && mask_out) {  // (uniform) sign bits of the pixel: 4 per lane, OR over its 8 lanes
+                    int nib = (v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0);
+                    nib <<= 4 * ch;
+                    nib |= __builtin_amdgcn_update_dpp(0, nib, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+                    nib |= __builtin_amdgcn_update_dpp(0, nib, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+                    nib |= __builtin_amdgcn_update_dpp(0, nib, 0x141 /* row_half_mirror */, 0xF, 0xF, true);
+                    if (ch == 0 && sok) mask_out[pix0 + px] = (uint32_t)nib;
+                }
+            }
+            SF_C1T(6);  // staged tile -> global
+        }
     }
+#if SF_CONV1_TRACE
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(&sf_conv1_trace_acc[i], tacc_[i]);
+        atomicAdd(&sf_conv1_trace_acc[7], (unsigned long long)total_units);
+        atomicAdd(&sf_conv1_trace_acc[8], clock64() - tc0_);      // the strip loop in s_memtime ticks ...
+        atomicAdd(&sf_conv1_trace_acc[9], wall_clock64() - tw0_);  // ... and in 100 MHz ticks
+        atomicAdd(&sf_conv1_trace_acc[10], 1ull);
+    }
+#endif
 }
 
 template <bool SUB>
@@ -211,7 +312,14 @@ __global__ __launch_bounds__(256, 2)
 void k_conv1_u8_bf16(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride, const int32_t *__restrict__ index,
                      int64_t offset, const float *__restrict__ w, const float *__restrict__ bias,
                      float *__restrict__ out, uint32_t *__restrict__ mask_out, int nsamples) {
-    conv1_u8_bf16_body<SUB, 1>(g, in, in_stride, index, offset, w, bias, out, mask_out, nsamples);
+    conv1_u8_bf16_body<SUB, 1, false>(g, in, in_stride, index, offset, w, bias, out, mask_out, nsamples);
+}
+template <bool SUB>
+__global__ __launch_bounds__(256, 2)
+void k_conv1_u8_bf16_w(ConvG g, const uint8_t *__restrict__ in, int64_t in_stride, const int32_t *__restrict__ index,
+                       int64_t offset, const float *__restrict__ w, const float *__restrict__ bias,
+                       float *__restrict__ out, uint32_t *__restrict__ mask_out, int nsamples) {
+    conv1_u8_bf16_body<SUB, 1, true>(g, in, in_stride, index, offset, w, bias, out, mask_out, nsamples);
 }
 
 // ============================================================================================== WEIGHT GRADIENT, raw u8 frames

@@ -1,5 +1,5 @@
 """Every A/B switch of the network kernels (SF_CONV1_BF16, SF_CONV1_IMG, SF_DGRAD_PIX, SF_WGRAD_GLDS, SF_WGRAD_IMG, SF_RELU_MASK, SF_GLDS_CFG,
-SF_FWD_IMG, SF_GLDS_SPLITK, SF_GLDS_FC64, SF_GLDS_SMALL64, SF_GLDS_SPLIT64, SF_TAP_PERM, SF_XCD_ROWS, SF_GLDS_ZL, SF_XCD_RASTER, SF_DGRAD_LPT, SF_LINEAR_NARROW, SF_REDUCE_TREE; recurrent passes: SF_SEQ_BWD_REGW, SF_SEQ_FWD_X — read once per process) selects a different kernel for the same operation; each must pass
+SF_FWD_IMG, SF_GLDS_SPLITK, SF_GLDS_FC64, SF_GLDS_SMALL64, SF_GLDS_SPLIT64, SF_TAP_PERM, SF_XCD_ROWS, SF_GLDS_ZL, SF_CONV1_WIDE, SF_XCD_RASTER, SF_DGRAD_LPT, SF_LINEAR_NARROW, SF_REDUCE_TREE; recurrent passes: SF_SEQ_BWD_REGW, SF_SEQ_FWD_X — read once per process) selects a different kernel for the same operation; each must pass
 the same kernel-vs-torch tests as the default dispatch.  One pytest subprocess per group of independent (different
 operation) non-default settings; the two tests that assert which kernel / plan the DEFAULT dispatch picks are left out
 where the switch under test changes exactly that."""
@@ -21,7 +21,8 @@ GROUPS = [
     ("SF_CONV1_BF16=0 SF_DGRAD_PIX=2 SF_WGRAD_GLDS=2 SF_WGRAD_IMG=0 SF_GLDS_CFG=2 SF_GLDS_ZL=0 SF_DGRAD_ZL=2 SF_WGRAD_ZL=0", ""),
     ("SF_DGRAD_PIX=3 SF_WGRAD_GLDS=3 SF_WGRAD_IMG=1 SF_RELU_MASK=0 SF_GLDS_SPLITK=0", " and not splitk_small_grids and not relu_sign_bits"),
     # the tiled kernels for the narrow / small linear layers, the serial reduction of partials
-    ("SF_LINEAR_NARROW=0 SF_REDUCE_TREE=0", " and not narrow_linear"),
+    # ... conv1 forward with per-wave dword stores instead of the LDS-staged whole-line ones
+    ("SF_LINEAR_NARROW=0 SF_REDUCE_TREE=0 SF_CONV1_WIDE=0", " and not narrow_linear"),
     # round-4 dispatch changes switched off: fc forward of a rollout step back on 128x128 tiles x K slices, plain block
     # order instead of the XCD-aware one, conv3 data-gradient rows in index order instead of longest first
     # (+ round 5: small inference launches back on the register-staged kernels)
