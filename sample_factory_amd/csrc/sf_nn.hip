@@ -1642,6 +1642,11 @@ static int dgrad_lpt() {  // longest rows first (k_dgrad_pix block order, sf_nn_
     static const int on = getenv("SF_DGRAD_LPT") ? atoi(getenv("SF_DGRAD_LPT")) : 1;
     return on;
 }
+// k_dgrad_pix_z (SF_DGRAD_ZL bit 1): per-lane dY / W offsets of the SADDR-form DMA must fit 32 bits, channels in whole 64s
+static bool dgrad_pix_zl(const ConvG &g, int64_t n) {
+    static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 3;
+    return (dzl & 2) && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) && (int64_t)g.K * g.Cout < (1LL << 30);
+}
 // k_dgrad_quadrow_z addresses dY / W lanes as 32-bit element offsets and the input-gradient / activation elements as
 // 32-bit BYTE offsets from a uniform base: both tensors must stay below 2^30 elements
 static bool dgrad_quadrow_zl(const ConvG &g, int64_t n) {
@@ -1705,7 +1710,7 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
 #define DGRAD_PIX(BM, BN, WM, WN)                                                                          \
     do {                                                                                                   \
         const int ntiles = (int)((n + BM - 1) / BM), tiles8 = (ntiles + 7) / 8, ctiles = (g.Cin + BN - 1) / BN; \
-        if (dgrad_zl && (dzl & 2))                                                                         \
+        if (dgrad_zl)                                                                                      \
             k_dgrad_pix_z<BM, BN, WM, WN><<<dim3((unsigned)(tiles8 * 8 * g.H * ctiles)), dim3(256), 0, st>>>( \
                 g, dout, w, in_act, din, (int)n, ntiles, tiles8, dgrad_lpt());                              \
         else                                                                                               \
@@ -1717,9 +1722,7 @@ extern "C" int sf_conv_dgrad(const float *dout, const float *w, const float *in_
         // k_dgrad_pix_z with SADDR-form DMA only (conv3: 1308 / 1316 -> 1277 / 1297 us; the full form — pointer fragment reads,
         // two chunks per trip — costs hipcc 256 + 168 registers against 173 + 32 and the second wave per SIMD with them:
         // 1214 -> 1316 us, compile-time switch SF_DGRAD_PIX_ZL_LITE=0) — profiles/r05_k_dgrad_zl_ab.log, r05_n_dgrad_pix_lite_ab.log
-        static const int dzl = getenv("SF_DGRAD_ZL") ? atoi(getenv("SF_DGRAD_ZL")) : 3;
-        const bool dgrad_zl = dzl && g.Cout % 64 == 0 && n * (int64_t)g.OH * g.OW * g.Cout < (1LL << 30) &&
-                              (int64_t)g.K * g.Cout < (1LL << 30);
+        const bool dgrad_zl = dgrad_pix_zl(g, n);
         if (g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0 && pix_cfg != 3) {
             // strided conv, row-walking tiles of (sample, group-column) rows: contiguous activation / gradient rows
             const int Wg = g.W / g.S;
@@ -1807,7 +1810,7 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024 && g.S > 1 && g.KH % g.S == 0 && g.KW % g.S == 0 && g.W % g.S == 0)
             snprintf(out, cap, dgrad_quadrow_zl(g, n) ? "k_dgrad_quadrow_z<128, 128, 2, 2>" : "k_dgrad_quadrow<128, 128, 2, 2>");
         else if (g.vecB && g.Cout % 32 == 0 && n >= 1024)
-            snprintf(out, cap, g.Cin <= 32 ? "k_dgrad_pix<256, 32, 4, 1>" : "k_dgrad_pix<128, 64, 2, 2>");
+            snprintf(out, cap, "k_dgrad_pix%s<%s>", dgrad_pix_zl(g, n) ? "_z" : "", g.Cin <= 32 ? "256, 32, 4, 1" : "128, 64, 2, 2");
         else if (g.Cin <= 32) snprintf(out, cap, "k_conv_dgrad<128, 32, 4, 1, %s>", v);
         else if (Mc * ((g.Cin + 63) / 64) < 128LL * 1024) snprintf(out, cap, "k_conv_dgrad<64, 64, 2, 2, %s>", v);
         else snprintf(out, cap, "k_conv_dgrad<128, 64, 2, 2, %s>", v);
