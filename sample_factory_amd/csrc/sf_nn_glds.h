@@ -22,7 +22,8 @@
 
 // SF_GLDS_ABLATE (compile-time, tools/build_variant.sh; TIMING EXPERIMENTS ONLY — results are wrong with any bit set):
 // bit 0: k_fwd_glds issues no DMA inside its k-loop, bit 1: no wait / barrier per chunk, bit 2: no epilogue stores,
-// bit 3: one k-chunk per tile (prologue + epilogue only)
+// bit 3: one k-chunk per tile (prologue + epilogue only); k_dgrad_quadrow_z: bit 4 no DMA, bit 5 no output stores,
+// bit 6 no wait / barrier per chunk, bit 7 no MFMAs
 #ifndef SF_GLDS_ABLATE
 #define SF_GLDS_ABLATE 0
 #endif
@@ -182,6 +183,9 @@ __device__ __forceinline__ void mma_chunk_ptrs(const float *const (&ap)[4], cons
     }
 }
 
+#ifndef SF_QUADROW_PREP
+#define SF_QUADROW_PREP 1  // k_dgrad_quadrow_z: DMA addresses prepared one chunk ahead (0: computed between barrier and DMA)
+#endif
 #ifndef SF_DGRAD_PIX_ZL_LITE
 #define SF_DGRAD_PIX_ZL_LITE 1  // k_dgrad_pix_z: 1 = SADDR-form DMA only (fragment reads stay "runtime stage + VALU add")
 #endif
@@ -831,6 +835,8 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + boff, sb + (i * 4 + wave) * 256);
     };
+    // (preparing a chunk's DMA bases one chunk ahead as k_dgrad_quadrow_z does costs hipcc 256 registers + 550 bytes of
+    // scratch in this kernel: not used)
     Px cur = pixel(0);
     for (int z = 0; z < cur.iw; ++z) zero_pixel(z);
     if (cur.iw < g.W) issue(cur, 0, 0);
@@ -1470,7 +1476,7 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
                         if (FULL || (ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H)) {
                             float v = zero ? 0.f : acc[tm][tn][r];
                             if (!zero) v = act_bwd_mul<KIND>(v, actv[tm][tn][r], akind);
-                            st32(din, ro + cb[tn], v);
+                            if (!(ZL && (SF_GLDS_ABLATE & 32))) st32(din, ro + cb[tn], v);
                         }
                 }
         };
@@ -1486,6 +1492,11 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
     };
     // (the last group column of an image whose width is not a multiple of S has pixels past W: never the case for the
     // launcher's contract W % S == 0)
+    // (All work-groups of a launch have the same work and the resident ones start together; the ablation of
+    // profiles/r05_aa_quadrow_ablation.log — time without MFMAs 565 us + MFMA time 1219 us = the kernel's 1784 us — suggested
+    // they run in lock-step with nothing overlapping.  Walking the group rows rotated by one in half of the work-groups (the
+    // first and last group row have half the taps: half a step of phase shift for free) changed nothing, 1654 vs 1654 us:
+    // profiles/r05_ab_quadrow_rotation.log.)
     struct St { int ihc, a_lo, na, total; };
     auto step = [&](int ihc) {
         St p;
@@ -1520,6 +1531,7 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
         }
     }
     auto issue = [&](const St &p, int q, int stage) {
+        if (ZL && (SF_GLDS_ABLATE & 16)) return;
         const int blk = q / CC, cc = q - blk * CC;
         const int a = p.a_lo + blk / KWs, b = blk % KWs;
         const int64_t aoff = (int64_t)((p.ihc - a) * OW - b) * Cout + cc * 32;
@@ -1541,9 +1553,49 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + boff, sb + (i * 4 + wave) * 256);
     };
+    // ZL + SF_QUADROW_PREP: the addresses of a chunk's DMA are worked out ONE CHUNK AHEAD (scalar divisions of the chunk
+    // index, the per-row zero-page select and its 64-bit adds: ~40 scalar + ~30 vector instructions that otherwise sit
+    // between the barrier and the DMA with no MFMA of this wave in flight), so that after the barrier only the 8 DMA
+    // instructions are left; the work for the chunk after next is placed behind them, among the MFMAs.
+    struct It { St st; int q; };
+    auto advance = [&](It &it) {
+        if (it.q + 1 < it.st.total) ++it.q;
+        else { it.st = next_step(it.st.ihc + 1); it.q = 0; }
+    };
+    struct Prep { const float *bb; const float *as[AI]; bool valid; };
+    auto prep = [&](const It &it) {
+        Prep r;
+        r.valid = it.st.ihc < Hg;
+        const int q = r.valid ? it.q : 0;
+        const int blk = q / CC, cc = q - blk * CC;
+        const int a = it.st.a_lo + blk / KWs, b = blk % KWs;
+        const int64_t aoff = (int64_t)((it.st.ihc - a) * OW - b) * Cout + cc * 32;
+        r.bb = w + (int64_t)((S * a * g.KW + S * b) * Cin) * Cout + cc * 32;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int ow = aiwc[i] - b;
+            r.as[i] = (ow >= 0 && ow < OW) ? asrc[i] + aoff : sf_zero_page + zpos;
+        }
+        return r;
+    };
+    auto fire = [&](const Prep &r, int stage) {
+        if (!r.valid || (SF_GLDS_ABLATE & 16)) return;
+        float *sa = lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) GLDS16(r.as[i], sa + (i * 4 + wave) * 256);
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            glds16_s(r.bb, bvoff[i], lds0 + (uint32_t)((stage * STAGE + BM * 32 + (i * 4 + wave) * 256) * 4));
+    };
     St cur = next_step(0);
     for (int z = 0; z < cur.ihc && z < Hg; ++z) store_step(z, true);
-    if (cur.ihc < Hg) issue(cur, 0, 0);
+    It ahead{cur, 0};
+    Prep pend;
+    if constexpr (ZL && SF_QUADROW_PREP) {
+        fire(prep(ahead), 0);
+        advance(ahead);
+        pend = prep(ahead);
+    } else if (cur.ihc < Hg) issue(cur, 0, 0);
     int stage = 0;
     while (cur.ihc < Hg) {
         const St nx = next_step(cur.ihc + 1);
@@ -1559,11 +1611,29 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
             auto chunk = [&](int q, auto stc, auto firstc) {
                 constexpr int ST = decltype(stc)::value;
                 constexpr bool FIRST = decltype(firstc)::value;  // first chunk of the step: accumulation starts from the constant 0
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
-                else if (nx.ihc < Hg) issue(nx, 0, ST ^ 1);
+                if (!(SF_GLDS_ABLATE & 64)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+                if constexpr (SF_QUADROW_PREP) {
+                    fire(pend, ST ^ 1);  // the chunk after this one
+                    advance(ahead);
+                    pend = prep(ahead);  // ... and the addresses of the one after that
+                } else {
+                    if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
+                    else if (nx.ihc < Hg) issue(nx, 0, ST ^ 1);
+                }
                 if (FIRST) prefetch_act(cur.ihc);
+                if (SF_GLDS_ABLATE & 128) {
+                    if (FIRST) {
+#pragma unroll
+                        for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+                            for (int b_ = 0; b_ < TN; ++b_)
+#pragma unroll
+                                for (int r_ = 0; r_ < 16; ++r_) acc[a_][b_][r_] = 0.f;
+                    }
+                } else
                 mma_chunk_ptrs<TM, TN, ST * STAGE, FIRST>(apl, bpl, acc);
             };
             chunk(0, std::integral_constant<int, 0>{}, std::true_type{});
