@@ -1173,6 +1173,16 @@ static int tap_perm_on() {
     static const int on = getenv("SF_TAP_PERM") ? atoi(getenv("SF_TAP_PERM")) : 0;
     return on;
 }
+// SF_GLDS_TAILSPLIT (default 1): single-column unsplit 128 x 64 launches whose last round of work-groups is at most half
+// full run that round as 64-row tiles (k_fwd_glds_zt).  Returns the number of 128-row tiles in front of it, 0 = plain launch.
+static int fwd_tail_split(const ConvG &g, int64_t Mtot, int Z, bool zl_ok) {
+    static const int on = getenv("SF_GLDS_TAILSPLIT") ? atoi(getenv("SF_GLDS_TAILSPLIT")) : 1;
+    if (!on || !zl_ok || glds_zl_on() < 1 || Z != 1 || g.Cout > 64 || xcd_rows_on()) return 0;
+    static const int occ = occupancy_of(k_fwd_glds_zt<128, 64, 2, 2>, 256, (128 + 64) * 32 * 2 * sizeof(float));
+    const int64_t tiles = cdiv64(Mtot, 128), resident = (int64_t)num_cus() * occ, tail = tiles % resident;
+    if (tiles <= resident || tail == 0 || 2 * tail > resident) return 0;
+    return (int)(tiles - tail);
+}
 #define GLDS_FWD(BM, BN, WM, WN, NS)                                                                           \
     do {                                                                                                       \
         dim3 gq(cdiv64(Mtot, BM), cdiv64(g.Cout, BN), p.Z);                                                    \
@@ -1250,7 +1260,11 @@ extern "C" int sf_conv_fwd_t(const float *in, int64_t in_sample_stride, const fl
     } else
     if (p.sq64) GLDS_FWD(64, 64, 2, 2, 2);
     else if (p.wide) GLDS_FWD(128, 128, 2, 2, 2);
-    else GLDS_FWD(128, 64, 2, 2, 2);
+    else if (const int main_tiles = fwd_tail_split(g, Mtot, p.Z, zl_ok); main_tiles > 0) {
+        const int tail = (int)cdiv64(Mtot, 128) - main_tiles;
+        k_fwd_glds_zt<128, 64, 2, 2><<<dim3((unsigned)(main_tiles + 2 * tail)), dim3(256), (128 + 64) * 32 * 2 * sizeof(float), st>>>(
+            g, in, in_sample_stride, wt, bias, out, Mtot, p.k_per_split, main_tiles, tap_perm_on());
+    } else GLDS_FWD(128, 64, 2, 2, 2);
     if (partial) {
         const int64_t MN = Mtot * g.Cout;
         k_splitk_finish<<<dim3(cdiv64(MN, 256) < 4096 ? cdiv64(MN, 256) : 4096), dim3(256), 0, st>>>(
@@ -1781,7 +1795,9 @@ extern "C" int sf_conv_kernel_name(int op, int64_t n, const sf_conv_desc *h_desc
             const GldsFwdPlan q = plan_fwd_t(Mtot, g.Cout, g.K);
             const bool zl = glds_zl_on() && (!q.wide || glds_zl_on() >= 2) && (n - 1) * (int64_t)(g.H * g.W * g.Cin) + (int64_t)g.H * g.W * g.Cin < (1LL << 30) &&
                             (int64_t)g.Cout * g.K < (1LL << 30);  // (dense samples: the stride the model launches with)
-            if (zl) snprintf(out, cap, q.sq64 ? "k_fwd_glds_z<64, 64, 2, 2>" : q.wide ? "k_fwd_glds_z<128, 128, 2, 2>" : "k_fwd_glds_z<128, 64, 2, 2>");
+            const int qz = q.ok ? q.Z : 1;
+            if (zl && !q.sq64 && !q.wide && fwd_tail_split(g, Mtot, qz, true) > 0) snprintf(out, cap, "k_fwd_glds_zt<128, 64, 2, 2>");
+            else if (zl) snprintf(out, cap, q.sq64 ? "k_fwd_glds_z<64, 64, 2, 2>" : q.wide ? "k_fwd_glds_z<128, 128, 2, 2>" : "k_fwd_glds_z<128, 64, 2, 2>");
             else
             snprintf(out, cap, q.sq64 ? "k_fwd_glds<64, 64, 2, 2, 2>" : q.wide ? "k_fwd_glds<128, 128, 2, 2, 2>" : "k_fwd_glds<128, 64, 2, 2, 2>");
         }

@@ -206,17 +206,21 @@ __device__ __forceinline__ void mma_chunk_stage(const float *const (&ap)[4], con
 // constant.  The loop body is then MFMA + ds_read + DMA + scalar instructions only (the plain form spends 10 v_add_u32 and
 // 6 v_lshl_add_u64 per 32 MFMAs on addresses; vector ALU instructions do not overlap with MFMAs on a SIMD).  Needs
 // every per-lane operand offset < 4 GiB (the launcher checks).
-template <int BM, int BN, int WM, int WN, int NS, bool ZL, bool PERSIST = false>
+// DYNLDS: the pipeline stages live in the launch's dynamic LDS (k_fwd_glds_zt runs two instantiations in one kernel: two
+// static arrays would both be allocated); bx_shift: added to the row-tile index (the 64-row tail tiles of that kernel)
+template <int BM, int BN, int WM, int WN, int NS, bool ZL, bool PERSIST = false, bool DYNLDS = false>
 __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                               const float *__restrict__ wt, const float *__restrict__ bias,
                                               float *__restrict__ out, int64_t Mtot, int k_per_split,
                                               float *__restrict__ partial, const float *__restrict__ dmask,
-                                              int dmask_on, int rx, int ry, int rtot, int tap_perm) {
+                                              int dmask_on, int rx, int ry, int rtot, int tap_perm, int bx_shift = 0) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave and chunk (8 rows x 128 B each)
     constexpr int STAGE = (BM + BN) * 32;      // floats per pipeline stage
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && (NS == 2 || NS == 3), "4 waves per block");
-    __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];
+    __shared__ __attribute__((aligned(1024))) float lds_static[DYNLDS ? 1 : NS * STAGE];
+    extern __shared__ __attribute__((aligned(1024))) float lds_dynamic[];
+    float *const lds = DYNLDS ? lds_dynamic : lds_static;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware block order (rtot > 0: 1-D launch of 8 * ceil(rtot / 8) ids, see k_wgrad_glds): XCD c owns a contiguous
@@ -226,7 +230,7 @@ __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__
     // PERSIST (k_fwd_glds_zp, single-column unsplit launches): the work-group walks the row tiles b, b + grid, ...
     const int ptiles = PERSIST ? (int)((Mtot + BM - 1) / BM) : 1;
     for (int ptile = PERSIST ? (int)blockIdx.x : 0; ptile < ptiles; ptile += PERSIST ? (int)gridDim.x : 1) {
-    int bx = PERSIST ? ptile : (int)blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int bx = PERSIST ? ptile : (int)blockIdx.x + bx_shift, by = blockIdx.y, bz = blockIdx.z;
     if (rtot > 0) {
         const int per = (rtot + 7) >> 3, L = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
         if (L >= rtot) return;
@@ -487,6 +491,23 @@ __global__ __launch_bounds__(256, 2) void k_fwd_glds_zp(ConvG g, const float *__
                                                        const float *__restrict__ wt, const float *__restrict__ bias,
                                                        float *__restrict__ out, int64_t Mtot, int k_per_split) {
     fwd_glds_body<BM, BN, WM, WN, 2, true, true>(g, in, in_stride, wt, bias, out, Mtot, k_per_split, nullptr, nullptr, 0, 0, 0, 0, 0);
+}
+// TAIL SPLIT (single-column unsplit launches): every tile of such a launch costs the same, so a launch of T tiles on R
+// resident work-groups runs floor(T / R) full rounds and one more for the T mod R tiles left over — conv2 at a rollout
+// step: 2592 tiles on 512 = five rounds + 32 tiles that keep a sixteenth of the chip busy for a sixth round.  Here the
+// last `T mod R` 128-row tiles are run as twice as many 64-row tiles (blocks main_tiles .. of the same launch, the
+// <BM/2, BN> instantiation of the same body): the last round is half as long.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_fwd_glds_zt(ConvG g, const float *__restrict__ in, int64_t in_stride,
+                                                       const float *__restrict__ wt, const float *__restrict__ bias,
+                                                       float *__restrict__ out, int64_t Mtot, int k_per_split, int main_tiles,
+                                                       int tap_perm) {
+    if ((int)blockIdx.x < main_tiles)
+        fwd_glds_body<BM, BN, WM, WN, 2, true, false, true>(g, in, in_stride, wt, bias, out, Mtot, k_per_split, nullptr, nullptr, 0,
+                                                            0, 0, 0, tap_perm);
+    else
+        fwd_glds_body<BM / 2, BN, WM, WN, 2, true, false, true>(g, in, in_stride, wt, bias, out, Mtot, k_per_split, nullptr,
+                                                                nullptr, 0, 0, 0, 0, tap_perm, main_tiles);
 }
 // the same kernel with the zero-VALU k-loop (see fwd_glds_body, ZL)
 template <int BM, int BN, int WM, int WN>

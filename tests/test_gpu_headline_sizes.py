@@ -109,7 +109,7 @@ def test_dispatch_is_the_benchmarks(lib, st):
     d0.traj_T = T
     assert _name(lib, "fwd", N, d0) in ("k_conv1_u8_bf16_w<false>", "k_conv1_u8_bf16<false>")  # SF_CONV1_WIDE=0: the dword-store form
     assert _name(lib, "wgrad", N, d0) == "k_conv1_wgrad_bf16<false>"
-    assert _name(lib, "fwd_t", N, L[1].desc) in ("k_fwd_glds<128, 64, 2, 2, 2>", "k_fwd_glds_z<128, 64, 2, 2>")
+    assert _name(lib, "fwd_t", N, L[1].desc) in ("k_fwd_glds<128, 64, 2, 2, 2>", "k_fwd_glds_z<128, 64, 2, 2>", "k_fwd_glds_zt<128, 64, 2, 2>")
     assert _name(lib, "fwd_t", N, L[2].desc).startswith("k_fwd_img<64, 9, 9, 3, 1")
     assert _name(lib, "fwd_t", N, L[3].desc) in ("k_fwd_glds<128, 128, 2, 2, 2>", "k_fwd_glds_z<128, 128, 2, 2>")
     assert _name(lib, "wgrad", N, L[1].desc) == "k_wgrad_img<32, 20, 20, 4, 2, 2>"
