@@ -1173,14 +1173,15 @@ static int tap_perm_on() {
     static const int on = getenv("SF_TAP_PERM") ? atoi(getenv("SF_TAP_PERM")) : 0;
     return on;
 }
-// SF_GLDS_TAILSPLIT (default 1): single-column unsplit 128 x 64 launches whose last round of work-groups is at most half
-// full run that round as 64-row tiles (k_fwd_glds_zt).  Returns the number of 128-row tiles in front of it, 0 = plain launch.
+// SF_GLDS_TAILSPLIT (default 1): single-column unsplit 128 x 64 launches go through k_fwd_glds_zt, which runs a last round of
+// work-groups that is at most half full as 64-row tiles.  Returns the number of 128-row tiles in front of that round (all of
+// them when there is nothing to split), 0 = not such a launch (k_fwd_glds_z / k_fwd_glds).
 static int fwd_tail_split(const ConvG &g, int64_t Mtot, int Z, bool zl_ok) {
     static const int on = getenv("SF_GLDS_TAILSPLIT") ? atoi(getenv("SF_GLDS_TAILSPLIT")) : 1;
     if (!on || !zl_ok || glds_zl_on() < 1 || Z != 1 || g.Cout > 64 || xcd_rows_on()) return 0;
     static const int occ = occupancy_of(k_fwd_glds_zt<128, 64, 2, 2>, 256, (128 + 64) * 32 * 2 * sizeof(float));
     const int64_t tiles = cdiv64(Mtot, 128), resident = (int64_t)num_cus() * occ, tail = tiles % resident;
-    if (tiles <= resident || tail == 0 || 2 * tail > resident) return 0;
+    if (tiles <= resident || tail == 0 || 2 * tail > resident) return (int)tiles;
     return (int)(tiles - tail);
 }
 #define GLDS_FWD(BM, BN, WM, WN, NS)                                                                           \

@@ -496,7 +496,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd_glds_zp(ConvG g, const float *__
 // resident work-groups runs floor(T / R) full rounds and one more for the T mod R tiles left over — conv2 at a rollout
 // step: 2592 tiles on 512 = five rounds + 32 tiles that keep a sixteenth of the chip busy for a sixth round.  Here the
 // last `T mod R` 128-row tiles are run as twice as many 64-row tiles (blocks main_tiles .. of the same launch, the
-// <BM/2, BN> instantiation of the same body): the last round is half as long.
+// <BM/2, BN> instantiation of the same body): the last round is half as long (rollout-size launch of conv2 184 - 191 ->
+// 179 - 181 us, profiles/r05_ad_fwd_tail_split.log).  Every single-column unsplit launch takes this kernel; one whose tile
+// count leaves nothing to split (n = 32768: 27 full rounds) passes main_tiles = all of them.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void k_fwd_glds_zt(ConvG g, const float *__restrict__ in, int64_t in_stride,
                                                        const float *__restrict__ wt, const float *__restrict__ bias,
