@@ -183,6 +183,81 @@ __device__ __forceinline__ void mma_chunk_ptrs(const float *const (&ap)[4], cons
     }
 }
 
+// SF_FWD_FRAG_DB / SF_QUADROW_FRAG_DB (64 x 64 wave tiles of the zero-VALU kernels: fc forward / data gradient, conv2 data gradient): hipcc reads a
+// group's four fragments right in front of the group's 16 MFMAs and waits for them (lgkmcnt(0)) with only the previous
+// group's last MFMA still in the pipe: one bare LDS round trip per 16 MFMAs and wave.  1: the fragments of group c + 1
+// are read behind the first 4 MFMAs of group c into a second register set (12 MFMAs = 768 cycles to land); 2: also the
+// first group's fragments are read right behind the chunk's barrier, IN FRONT of the DMA instructions and the address
+// work for the next chunk (`pre`), which then run in the shadow of that LDS round trip.  Same MFMAs in the same order.
+#ifndef SF_FWD_FRAG_DB
+#define SF_FWD_FRAG_DB 0      // fc forward / data gradient (k_fwd_glds_z<128, 128>): 2 is +-0 on the forward launch and +1..2 % on the
+#endif                        // data gradient (its ReLU-mask prefetch already fills the register file): off
+#ifndef SF_QUADROW_FRAG_DB
+#define SF_QUADROW_FRAG_DB 2  // conv2 data gradient: -2.1 .. -2.8 % (profiles/r05_af_fragdb_rot.log, r05_ag_fragdb_spread.log)
+#endif
+template <int P> using HookPt = std::integral_constant<int, P>;
+// hook(HookPt<0>): right behind the first group's fragment reads; <1>, <2>: behind the first / second 4 MFMAs of group 0
+// (... = 3: half of the chunk's DMA instructions each -- a DMA instruction holds its wave's issue port while the
+// address unit takes it, in a burst in front of the MFMAs that is dead time of this wave, between MFMAs it is covered by
+// the 4 x 64 matrix-pipe cycles just issued); <3>: behind group 0, unfenced (address work for the chunk after next: hipcc
+// may spread it over group 1's MFMAs).  SINK: how many MFMAs at the END of the chunk hipcc may move behind the NEXT chunk's
+// barrier (they cover the fragment round trip there); the rest is fenced in front of it, so that the next chunk's DMA is
+// not issued late.
+#ifndef SF_FRAG_DB_SINK
+#define SF_FRAG_DB_SINK 16
+#endif
+template <int TM, int TN, int OFF, bool ZEROC = false, bool SPREAD = false, typename F>
+__device__ __forceinline__ void mma_chunk_ptrs_db(const float *const (&ap)[4], const float *const (&bp)[4],
+                                                  f32x16 (&acc)[TM][TN], F &&hook) {
+    float4 a[2][TM], b[2][TN];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[c & 1][i] = *reinterpret_cast<const float4 *>(ap[c] + OFF + i * 32 * 32);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) b[c & 1][i] = *reinterpret_cast<const float4 *>(bp[c] + OFF + i * 32 * 32);
+    };
+    auto mfmas = [&](int c, int j) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    j == 0 ? a[c & 1][tm].x : j == 1 ? a[c & 1][tm].y : j == 2 ? a[c & 1][tm].z : a[c & 1][tm].w,
+                    j == 0 ? b[c & 1][tn].x : j == 1 ? b[c & 1][tn].y : j == 2 ? b[c & 1][tn].z : b[c & 1][tn].w,
+                    (ZEROC && c == 0 && j == 0) ? zero : acc[tm][tn], 0, 0, 0);
+            }
+    };
+    constexpr int PER = TM * TN;  // MFMAs per k-step
+    fetch(0);
+    hook(HookPt<0>{});
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mfmas(c, 0);
+        if (c + 1 < 4 || c == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 0) hook(HookPt<1>{});
+            if (c + 1 < 4) fetch(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (SF_FRAG_DB_SINK == 3 * PER) __builtin_amdgcn_sched_barrier(0);
+        mfmas(c, 1);
+        if (c == 0 && SPREAD) {
+            __builtin_amdgcn_sched_barrier(0);
+            hook(HookPt<2>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c == 3 && SF_FRAG_DB_SINK == 2 * PER) __builtin_amdgcn_sched_barrier(0);
+        mfmas(c, 2);
+        if (c == 3 && SF_FRAG_DB_SINK == PER) __builtin_amdgcn_sched_barrier(0);
+        mfmas(c, 3);
+        if (c == 0) hook(HookPt<3>{});
+        if (c == 3 && SF_FRAG_DB_SINK == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+#ifndef SF_QUADROW_ROT
+#define SF_QUADROW_ROT 0  // k_dgrad_quadrow_z: co-resident work-groups walk the group rows in different rotations (see the kernel)
+#endif
 #ifndef SF_QUADROW_PREP
 #define SF_QUADROW_PREP 1  // k_dgrad_quadrow_z: DMA addresses prepared one chunk ahead (0: computed between barrier and DMA)
 #endif
@@ -372,11 +447,28 @@ __device__ __forceinline__ void fwd_glds_body(ConvG g, const float *__restrict__
                     }
                 });
             } else {  // 64 x 64 wave tiles: burst in front of the chunk (see the plain form below)
-                if (prefetch) {
+                auto burst = [&](int qlo, int qhi) {
+                    if (prefetch) {
 #pragma unroll
-                    for (int q = 0; q < AI + BI; ++q) dma(q, ab, bb, ST ^ 1);
+                        for (int q = 0; q < AI + BI; ++q)
+                            if (q >= qlo && q < qhi) dma(q, ab, bb, ST ^ 1);
+                    }
+                };
+                if constexpr (SF_FWD_FRAG_DB >= 2) {
+                    mma_chunk_ptrs_db<TM, TN, ST * STAGE, false, SF_FWD_FRAG_DB == 3>(apl, bpl, acc, [&](auto pt) {
+                        constexpr int P = decltype(pt)::value, HALF = (AI + BI) / 2;
+                        if constexpr (SF_FWD_FRAG_DB == 2) {
+                            if constexpr (P == 0) burst(0, AI + BI);
+                        } else {
+                            if constexpr (P == 1) burst(0, HALF);
+                            if constexpr (P == 2) burst(HALF, AI + BI);
+                        }
+                    });
+                } else {
+                    burst(0, AI + BI);
+                    if constexpr (SF_FWD_FRAG_DB == 1) mma_chunk_ptrs_db<TM, TN, ST * STAGE>(apl, bpl, acc, [](auto) {});
+                    else mma_chunk_ptrs<TM, TN, ST * STAGE>(apl, bpl, acc);
                 }
-                mma_chunk_ptrs<TM, TN, ST * STAGE>(apl, bpl, acc);
             }
             k0 += 32;
         };
@@ -1385,8 +1477,15 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per block");
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
     __shared__ uint32_t rowoff[BM];  // element offset of (sample, iwc) inside din / in_act, 0xFFFFFFFF = row past M
+    __shared__ int rot_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: LDS-DMA bases (M0) stay on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
+    // SF_QUADROW_ROT: the two work-groups that share a CU walk the group rows in different rotations (0, 1, .., Hg-1 and
+    // 1, .., Hg-1, 0): the first and the last row have half the taps, so the second one's output stores fall half a step
+    // behind the first one's for the whole tile, at the same total time.  The key is the hardware wave slot of wave 0
+    // (HW_ID.wave_id: with two waves per SIMD the co-resident work-groups sit in slots of different parity, and a
+    // work-group that replaces a finished one inherits its slot) -- a key from blockIdx cannot know who shares a CU.
+    if (ZL && SF_QUADROW_ROT && tid == 0) rot_s = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u);
     const int Cin = g.Cin, Cout = g.Cout, S = g.S, OH = g.OH, OW = g.OW, H = g.H, W = g.W;
     const int Hg = (H + S - 1) / S, Wg = (int)dWg.d, N = S * S * Cin;
     const int KHs = g.KH / S, KWs = g.KW / S, CC = Cout >> 5;
@@ -1499,7 +1598,7 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
                         if (FULL || (ro != 0xFFFFFFFFu && colok[tn] && ihc * S + phv[tn] < H)) {
                             float v = zero ? 0.f : acc[tm][tn][r];
                             if (!zero) v = act_bwd_mul<KIND>(v, actv[tm][tn][r], akind);
-                            if (!(ZL && (SF_GLDS_ABLATE & 32))) st32(din, ro + cb[tn], v);
+                            if (!(ZL && (SF_GLDS_ABLATE & 32)) || v == 1.2345e-30f) st32(din, ro + cb[tn], v);  // (ablation: the compare keeps the MFMAs alive)
                         }
                 }
         };
@@ -1520,9 +1619,13 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
     // they run in lock-step with nothing overlapping.  Walking the group rows rotated by one in half of the work-groups (the
     // first and last group row have half the taps: half a step of phase shift for free) changed nothing, 1654 vs 1654 us:
     // profiles/r05_ab_quadrow_rotation.log.)
-    struct St { int ihc, a_lo, na, total; };
-    auto step = [&](int ihc) {
+    // v = position in the walk, ihc = the group row visited there (v + rot, wrapping; v >= Hg: past the end)
+    const int rot = (ZL && SF_QUADROW_ROT && Hg > 1) ? __builtin_amdgcn_readfirstlane(rot_s) : 0;
+    struct St { int v, ihc, a_lo, na, total; };
+    auto step = [&](int v) {
         St p;
+        p.v = v;
+        const int ihc = v + rot < Hg ? v + rot : v + rot - Hg;
         p.ihc = ihc;
         p.a_lo = ihc - OH + 1 > 0 ? ihc - OH + 1 : 0;
         const int a_hi = ihc < KHs - 1 ? ihc : KHs - 1;
@@ -1531,11 +1634,12 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
         p.total = p.na * KWs * CC;
         return p;
     };
-    auto next_step = [&](int ihc) {  // first step >= ihc with work (Hg: none)
-        St p = step(ihc);
-        while (p.ihc < Hg && p.total == 0) p = step(p.ihc + 1);
+    auto next_step = [&](int v) {  // first position >= v with work (v = Hg: none)
+        St p = step(v);
+        while (p.v < Hg && p.total == 0) p = step(p.v + 1);
         return p;
     };
+    auto row_at = [&](int v) { return v + rot < Hg ? v + rot : v + rot - Hg; };
     // ZL (k_dgrad_quadrow_z): fragments through per-lane LDS pointers with the stage as an immediate, the weight operand's
     // DMA as uniform base + 32-bit lane offset.  (The dY operand keeps 64-bit lane addresses: a lane whose tap column is
     // outside dY reads the zero page, which no 32-bit offset from dY can name.)
@@ -1583,12 +1687,12 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
     struct It { St st; int q; };
     auto advance = [&](It &it) {
         if (it.q + 1 < it.st.total) ++it.q;
-        else { it.st = next_step(it.st.ihc + 1); it.q = 0; }
+        else { it.st = next_step(it.st.v + 1); it.q = 0; }
     };
     struct Prep { const float *bb; const float *as[AI]; bool valid; };
     auto prep = [&](const It &it) {
         Prep r;
-        r.valid = it.st.ihc < Hg;
+        r.valid = it.st.v < Hg;
         const int q = r.valid ? it.q : 0;
         const int blk = q / CC, cc = q - blk * CC;
         const int a = it.st.a_lo + blk / KWs, b = blk % KWs;
@@ -1601,27 +1705,31 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
         }
         return r;
     };
-    auto fire = [&](const Prep &r, int stage) {
+    auto fire = [&](const Prep &r, int stage, int part = 3) {  // part: 1 = the dY rows, 2 = the weight rows, 3 = both
         if (!r.valid || (SF_GLDS_ABLATE & 16)) return;
         float *sa = lds + stage * STAGE;
+        if (part & 1) {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) GLDS16(r.as[i], sa + (i * 4 + wave) * 256);
+            for (int i = 0; i < AI; ++i) GLDS16(r.as[i], sa + (i * 4 + wave) * 256);
+        }
+        if (part & 2) {
 #pragma unroll
-        for (int i = 0; i < BI; ++i)
-            glds16_s(r.bb, bvoff[i], lds0 + (uint32_t)((stage * STAGE + BM * 32 + (i * 4 + wave) * 256) * 4));
+            for (int i = 0; i < BI; ++i)
+                glds16_s(r.bb, bvoff[i], lds0 + (uint32_t)((stage * STAGE + BM * 32 + (i * 4 + wave) * 256) * 4));
+        }
     };
     St cur = next_step(0);
-    for (int z = 0; z < cur.ihc && z < Hg; ++z) store_step(z, true);
+    for (int z = 0; z < cur.v && z < Hg; ++z) store_step(row_at(z), true);
     It ahead{cur, 0};
     Prep pend;
     if constexpr (ZL && SF_QUADROW_PREP) {
         fire(prep(ahead), 0);
         advance(ahead);
         pend = prep(ahead);
-    } else if (cur.ihc < Hg) issue(cur, 0, 0);
+    } else if (cur.v < Hg) issue(cur, 0, 0);
     int stage = 0;
-    while (cur.ihc < Hg) {
-        const St nx = next_step(cur.ihc + 1);
+    while (cur.v < Hg) {
+        const St nx = next_step(cur.v + 1);
         if constexpr (!ZL) {
 #pragma unroll
             for (int a_ = 0; a_ < TM; ++a_)
@@ -1638,15 +1746,38 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                 }
-                if constexpr (SF_QUADROW_PREP) {
-                    fire(pend, ST ^ 1);  // the chunk after this one
-                    advance(ahead);
-                    pend = prep(ahead);  // ... and the addresses of the one after that
-                } else {
-                    if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
-                    else if (nx.ihc < Hg) issue(nx, 0, ST ^ 1);
+                auto refill = [&]() {
+                    if constexpr (SF_QUADROW_PREP) {
+                        fire(pend, ST ^ 1);  // the chunk after this one
+                        advance(ahead);
+                        pend = prep(ahead);  // ... and the addresses of the one after that
+                    } else {
+                        if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
+                        else if (nx.v < Hg) issue(nx, 0, ST ^ 1);
+                    }
+                    if (FIRST) prefetch_act(cur.ihc);
+                };
+                if constexpr (SF_QUADROW_FRAG_DB == 2 && !(SF_GLDS_ABLATE & 128)) {
+                    mma_chunk_ptrs_db<TM, TN, ST * STAGE, FIRST>(apl, bpl, acc, [&](auto pt) {
+                        if constexpr (decltype(pt)::value == 0) refill();
+                    });
+                    return;
                 }
-                if (FIRST) prefetch_act(cur.ihc);
+                if constexpr (SF_QUADROW_FRAG_DB == 3 && SF_QUADROW_PREP && !(SF_GLDS_ABLATE & 128)) {
+                    mma_chunk_ptrs_db<TM, TN, ST * STAGE, FIRST, true>(apl, bpl, acc, [&](auto pt) {
+                        constexpr int P = decltype(pt)::value;
+                        if constexpr (P == 0) { if (FIRST) prefetch_act(cur.ihc); }
+                        if constexpr (P == 1) fire(pend, ST ^ 1, 1);
+                        if constexpr (P == 2) fire(pend, ST ^ 1, 2);
+                        if constexpr (P == 3) { advance(ahead); pend = prep(ahead); }
+                    });
+                    return;
+                }
+                refill();
+                if constexpr (SF_QUADROW_FRAG_DB == 1 && !(SF_GLDS_ABLATE & 128)) {
+                    mma_chunk_ptrs_db<TM, TN, ST * STAGE, FIRST>(apl, bpl, acc, [](auto) {});
+                    return;
+                }
                 if (SF_GLDS_ABLATE & 128) {
                     if (FIRST) {
 #pragma unroll
@@ -1670,13 +1801,13 @@ __device__ __forceinline__ void dgrad_quadrow_body(ConvG g, const float *__restr
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (q + 1 < cur.total) issue(cur, q + 1, stage ^ 1);
-            else if (nx.ihc < Hg) issue(nx, 0, stage ^ 1);
+            else if (nx.v < Hg) issue(nx, 0, stage ^ 1);
             if (q == 0) prefetch_act(cur.ihc);
             const float *sa = lds + stage * STAGE;
             mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
         }
         store_step(cur.ihc, false);
-        for (int z = cur.ihc + 1; z < nx.ihc && z < Hg; ++z) store_step(z, true);
+        for (int z = cur.v + 1; z < nx.v && z < Hg; ++z) store_step(row_at(z), true);
         cur = nx;
     }
 }

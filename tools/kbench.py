@@ -20,8 +20,14 @@ def timeit(fn, reps):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps
 
+def digest(t):  # KBENCH_HASH=1: seeded inputs + a digest of every result (bit-identity of two builds of the library)
+    import hashlib
+    return hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()[:12]
+
 def main():
     which = sys.argv[1:] or ["fwd", "wgrad", "dgrad"]
+    HASH = os.environ.get("KBENCH_HASH") == "1"
+    if HASH: torch.manual_seed(0)
     ns = [int(v) for v in os.environ["KBENCH_NS"].split(",")] if os.environ.get("KBENCH_NS") else [4096, 32768]
     only = os.environ.get("KBENCH_LAYERS", "").split(",") if os.environ.get("KBENCH_LAYERS") else None
     for n in ns:
@@ -39,7 +45,7 @@ def main():
             res = []
             if "fwd" in which:
                 wsb = lib.conv_fwd_workspace(n, d); ws = torch.empty(max(wsb,16),dtype=torch.uint8,device="cuda") if wsb else None
-                t = timeit(lambda: lib.conv_fwd(x, stride, None, 0, w, b, out, n, d, ws), reps); res.append(f"fwd {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+                t = timeit(lambda: lib.conv_fwd(x, stride, None, 0, w, b, out, n, d, ws), reps); res.append(f"fwd {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF" + (f" #{digest(out)}" if HASH else ""))
             if "fwd" in which and lib.conv_fwd_t_supported(n, d):
                 wt = torch.empty((d.Cout, K), device="cuda"); lib.transpose(w, wt, K, d.Cout)
                 assert torch.equal(wt, w.t().contiguous())
@@ -48,17 +54,17 @@ def main():
                     nb = lib.conv_fwd_t_workspace(n, d); wst = torch.empty(nb,dtype=torch.uint8,device="cuda") if nb else None
                     t = timeit(lambda: lib.conv_fwd_t(x, stride, wt, b, out, n, d, wst), reps)
                     err = (out - ref).abs().max().item() / ref.abs().max().item()
-                    res.append(f"fwd_t {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF relerr {err:.1e}")
+                    res.append(f"fwd_t {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF relerr {err:.1e}" + (f" #{digest(out)}" if HASH else ""))
             if "wgrad" in which and n == 32768:
                 dw = torch.empty_like(w); db = torch.empty_like(b)
                 ws = torch.empty(lib.conv_wgrad_workspace(n, d),dtype=torch.uint8,device="cuda")
-                t = timeit(lambda: lib.conv_wgrad(x, stride, None, 0, dy, dw, db, n, d, ws), reps); res.append(f"wgrad {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+                t = timeit(lambda: lib.conv_wgrad(x, stride, None, 0, dy, dw, db, n, d, ws), reps); res.append(f"wgrad {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF" + (f" #{digest(dw)}" if HASH else ""))
             if "dgrad" in which and n == 32768 and not d.in_u8:
                 din = torch.empty((n,d.H,d.W,d.Cin),device="cuda")
-                t = timeit(lambda: lib.conv_dgrad(dy, w, x, din, n, d), reps); res.append(f"dgrad {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+                t = timeit(lambda: lib.conv_dgrad(dy, w, x, din, n, d), reps); res.append(f"dgrad {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF" + (f" #{digest(din)}" if HASH else ""))
             if "dgrad_noact" in which and n == 32768 and not d.in_u8:  # upper bound of what a mask-free epilogue could win
                 din = torch.empty((n,d.H,d.W,d.Cin),device="cuda")
-                t = timeit(lambda: lib.conv_dgrad(dy, w, None, din, n, d), reps); res.append(f"dgrad(no act read) {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF")
+                t = timeit(lambda: lib.conv_dgrad(dy, w, None, din, n, d), reps); res.append(f"dgrad(no act read) {t*1e3:8.1f}us {flops/t/1e9:6.1f}TF" + (f" #{digest(din)}" if HASH else ""))
             print(f"n={n:6d} {name:6s} " + " | ".join(res), flush=True)
 
 if __name__ == "__main__":
