@@ -255,6 +255,9 @@ __device__ __forceinline__ void mma_chunk_ptrs_db(const float *const (&ap)[4], c
     }
 }
 
+#ifndef SF_PIX_INCR
+#define SF_PIX_INCR 1  // k_dgrad_pix(_z): the next chunk's (filter row, filter column, channel chunk) stepped, not decoded from q
+#endif
 #ifndef SF_QUADROW_ROT
 #define SF_QUADROW_ROT 0  // k_dgrad_quadrow_z: co-resident work-groups walk the group rows in different rotations (see the kernel)
 #endif
@@ -929,9 +932,19 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
             bpl[c] = lds + BM * 32 + (wn * TN * 32 + r) * 32 + pos;
         }
     }
-    auto issue = [&](const Px &p, int q, int stage) {
-        const int tap = q / CC, cc = q - tap * CC;  // CC, nb: small wave-uniform divisors (scalar unit)
-        const int a = a_lo + tap / p.nb, b = p.b_lo + tap % p.nb;
+    // SF_PIX_INCR: the chunk to fetch next is carried as (filter-row index a, filter-column index b, channel chunk cc) and
+    // stepped (cc fastest, then b, then a = the order of q) instead of being decoded from q -- q / CC, tap / nb and tap % nb
+    // are divisions by run-time values, ~60 scalar instructions (and SGPRs spilled to VGPR lanes around them) between the
+    // chunk's barrier and its DMA instructions in a kernel whose chunk is only 32 MFMAs per wave.  Same addresses.
+    struct Cq { int a, b, cc; };
+    auto first_chunk = [&](const Px &p) { return Cq{a_lo, p.b_lo, 0}; };
+    auto next_chunk = [&](Cq &c, const Px &p) {
+        if (++c.cc == CC) {
+            c.cc = 0;
+            if (++c.b == p.b_lo + p.nb) { c.b = p.b_lo; ++c.a; }
+        }
+    };
+    auto issue_c = [&](const Px &p, int a, int b, int cc, int stage) {
         const int oh = ihc - a, ow = p.iwc - b, kh = ph + a * S, kw = p.pw + b * S;
         const int64_t aoff = (int64_t)(oh * OW + ow) * Cout + cc * 32;
         const int64_t boff = (int64_t)((kh * g.KW + kw) * Cin) * Cout + cc * 32;
@@ -950,14 +963,40 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16(bsrc[i] + boff, sb + (i * 4 + wave) * 256);
     };
+    auto issue = [&](const Px &p, int q, int stage) {
+        const int tap = q / CC, cc = q - tap * CC;  // CC, nb: small wave-uniform divisors (scalar unit)
+        issue_c(p, a_lo + tap / p.nb, p.b_lo + tap % p.nb, cc, stage);
+    };
     // (preparing a chunk's DMA bases one chunk ahead as k_dgrad_quadrow_z does costs hipcc 256 registers + 550 bytes of
     // scratch in this kernel: not used)
     Px cur = pixel(0);
     for (int z = 0; z < cur.iw; ++z) zero_pixel(z);
-    if (cur.iw < g.W) issue(cur, 0, 0);
+    Cq nq{0, 0, 0};  // SF_PIX_INCR: the chunk the next DMA round fetches
+    if (cur.iw < g.W) {
+        if constexpr (SF_PIX_INCR) {
+            nq = first_chunk(cur);
+            issue_c(cur, nq.a, nq.b, nq.cc, 0);
+            next_chunk(nq, cur);
+        } else issue(cur, 0, 0);
+    }
     int stage = 0, parked = -1;  // parked: pixel whose result waits in pend[]
     while (cur.iw < g.W) {
         const Px nx = pixel(cur.iw + 1);
+        auto issue_next = [&](int q, int stg) {  // chunk q + 1 of this pixel, or the first one of the next pixel
+            if constexpr (SF_PIX_INCR) {
+                if (q + 1 < cur.total) {
+                    issue_c(cur, nq.a, nq.b, nq.cc, stg);
+                    next_chunk(nq, cur);
+                } else if (nx.iw < g.W) {  // the DMA pipeline runs across the pixel boundary
+                    nq = first_chunk(nx);
+                    issue_c(nx, nq.a, nq.b, nq.cc, stg);
+                    next_chunk(nq, nx);
+                }
+            } else {
+                if (q + 1 < cur.total) issue(cur, q + 1, stg);
+                else if (nx.iw < g.W) issue(nx, 0, stg);
+            }
+        };
         zero_acc();
         if constexpr (ZL && !SF_DGRAD_PIX_ZL_LITE) {
             // every tap is CC chunks and CC is even (the launcher's contract for this form: Cout % 64 == 0), so a pixel
@@ -967,8 +1006,7 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (ST == 0 && q == 0 && parked >= 0) store_pixel(parked);
-                if (q + 1 < cur.total) issue(cur, q + 1, ST ^ 1);
-                else if (nx.iw < g.W) issue(nx, 0, ST ^ 1);
+                issue_next(q, ST ^ 1);
                 if (ST == 0 && q == 0) prefetch_act(cur.iw);
                 mma_chunk_ptrs<TM, TN, ST * STAGE>(apl, bpl, acc);
             };
@@ -983,8 +1021,7 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (q == 0 && parked >= 0) store_pixel(parked);
-            if (q + 1 < cur.total) issue(cur, q + 1, stage ^ 1);
-            else if (nx.iw < g.W) issue(nx, 0, stage ^ 1);  // the DMA pipeline runs across the pixel boundary
+            issue_next(q, stage ^ 1);
             if (q == 0) prefetch_act(cur.iw);
             const float *sa = lds + stage * STAGE;
             mma_chunk_rows<TM, TN>(sa, sa + BM * 32, wm * TM * 32, wn * TN * 32, lane, acc);
