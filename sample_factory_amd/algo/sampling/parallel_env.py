@@ -29,10 +29,11 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 
+from sample_factory_amd.envs.env_utils import RewardShapingInterface
 from sample_factory_amd.envs.spaces import action_head_sizes, is_box
 from sample_factory_amd.utils.attr_dict import AttrDict
 
-CMD_RESET, CMD_STEP, CMD_CLOSE, CMD_TRAINING_INFO = 0, 1, 2, 3
+CMD_RESET, CMD_STEP, CMD_CLOSE, CMD_TRAINING_INFO, CMD_REWARD_SHAPING = 0, 1, 2, 3, 4
 
 
 def _as_obs_dict(obs) -> Dict[str, Any]:
@@ -104,15 +105,26 @@ class _InstanceStepper:
     split, exactly what a rollout worker does per message (rollout_worker.py:201-259, make_env.py:97-128,147-237)"""
 
     def __init__(self, make_env_func, env_name, cfg, widx, instances, arrays, heads, continuous, render_mode=None):
-        from sample_factory_amd.envs.env_utils import find_training_info_interface
+        from sample_factory_amd.envs.env_utils import RewardShapingInterface, find_training_info_interface, find_wrapper_interface
         self.arrays, self.heads, self.continuous, self.envs = arrays, heads, continuous, []
-        self.training_info_ifaces = []
+        self.training_info_ifaces, self.reward_shaping_ifaces = [], []
         for split, vidx, env_id, row0, nrows in instances:
             env = make_env_func(env_name, cfg, AttrDict(worker_index=widx, vector_index=vidx, env_id=env_id), render_mode)
             self.envs.append((split, env, env_is_batched(env), row0, nrows, env_id))
             iface = find_training_info_interface(env)
             if iface is not None:
                 self.training_info_ifaces.append(iface)
+            iface = find_wrapper_interface(env, RewardShapingInterface)
+            if iface is not None:
+                self.reward_shaping_ifaces.append(iface)
+
+    def default_reward_shaping(self):
+        """the scheme of the first instance that has one (env_utils.py:96-103 asks ONE env; instances of an env agree)"""
+        return self.reward_shaping_ifaces[0].get_default_reward_shaping() if self.reward_shaping_ifaces else None
+
+    def set_reward_shaping(self, reward_shaping, agent_idx) -> None:
+        for iface in self.reward_shaping_ifaces:
+            iface.set_reward_shaping(reward_shaping, agent_idx)
 
     def set_training_info(self, training_info) -> None:
         """curricula (batched_sampling.py:352-355): every instance that implements TrainingInfoInterface gets the dict"""
@@ -175,13 +187,16 @@ def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: 
                 shms.append(s)
                 arrays[split][name] = s.array
         stepper = _InstanceStepper(make_env_func, env_name, cfg, widx, instances, arrays, heads, continuous)
-        conn.send(("ready", widx, len(stepper.training_info_ifaces)))
+        conn.send(("ready", widx, len(stepper.training_info_ifaces), stepper.default_reward_shaping()))
         while True:
             cmd, split = conn.recv()
             if cmd == CMD_CLOSE:
                 break
             if cmd == CMD_TRAINING_INFO:  # payload in place of the split index; no completion signal
                 stepper.set_training_info(split)
+                continue
+            if cmd == CMD_REWARD_SHAPING:  # payload = (scheme, agent_idx); no completion signal
+                stepper.set_reward_shaping(*split)
                 continue
             stepper.run(cmd, split)
             done_sems[split].release()
@@ -199,8 +214,10 @@ def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: 
             s.close()
 
 
-class ParallelVecEnvView:
-    """One split's agents over all workers, presented as ONE batched host env (reset / step / step_async / step_wait)."""
+class ParallelVecEnvView(RewardShapingInterface):
+    """One split's agents over all workers, presented as ONE batched host env (reset / step / step_async / step_wait).
+    It answers for its instances where the reference walks a wrapper chain: `get_default_reward_shaping(view)` /
+    `set_reward_shaping(view, ...)` (envs/env_utils.py:96-111) reach the env instances in their worker processes."""
 
     def __init__(self, parent: "ParallelHostEnvs", split: int, num_agents: int):
         self.parent, self.split, self.num_agents = parent, split, int(num_agents)
@@ -244,6 +261,14 @@ class ParallelVecEnvView:
         if self.split == 0:  # one message per worker and rollout covers all splits
             self.parent.set_training_info(training_info)
 
+    def get_default_reward_shaping(self):
+        """the instances' default reward shaping scheme (None when no instance implements RewardShapingInterface)"""
+        return self.parent.default_reward_shaping
+
+    def set_reward_shaping(self, reward_shaping, agent_idx) -> None:
+        if self.split == 0:  # one message per worker covers the instances of every split
+            self.parent.set_reward_shaping(reward_shaping, agent_idx)
+
     def close(self):
         self.parent.close()
 
@@ -270,6 +295,7 @@ class ParallelHostEnvs:
                 pass
         self.observation_space, self.action_space, self.agents_per_instance = probed
         self._training_info_instances = 0
+        self.default_reward_shaping = None
         spaces_ = obs_space_dict(self.observation_space)
         if not hasattr(self.observation_space, "spaces"):  # make_env.py:46-66: a bare space becomes Dict(obs=space)
             from sample_factory_amd.envs import spaces as _sp
@@ -318,6 +344,8 @@ class ParallelHostEnvs:
                                                        {s_: self.arrays[s_] for s_ in range(num_splits)}, self.heads,
                                                        self.continuous, render_mode))
                 self._training_info_instances += len(self._steppers[-1].training_info_ifaces)
+                if self.default_reward_shaping is None:
+                    self.default_reward_shaping = self._steppers[-1].default_reward_shaping()
             self.views = [ParallelVecEnvView(self, s_, n) for s_ in range(num_splits)]
             return
         # ---- workers
@@ -346,6 +374,8 @@ class ParallelHostEnvs:
                 self.close()
                 raise RuntimeError(f"env worker {w} failed to create its envs:\n{msg[1]}")
             self._training_info_instances += int(msg[2])
+            if self.default_reward_shaping is None:
+                self.default_reward_shaping = msg[3]
         self.views = [ParallelVecEnvView(self, s, n) for s in range(num_splits)]
 
     # ---- pinned pages: let the DMA engine read the workers' pages directly
@@ -383,6 +413,17 @@ class ParallelHostEnvs:
             return
         for c in self._conns:
             c.send((CMD_TRAINING_INFO, dict(training_info)))
+
+    def set_reward_shaping(self, reward_shaping, agent_idx) -> None:
+        """env_utils.py:106-111: a new reward shaping scheme for the env instances (where they live)"""
+        if self._closed or reward_shaping is None:
+            return
+        if self.inline:
+            for st in self._steppers:
+                st.set_reward_shaping(reward_shaping, agent_idx)
+            return
+        for c in self._conns:
+            c.send((CMD_REWARD_SHAPING, (dict(reward_shaping), agent_idx)))
 
     def _command(self, split: int, cmd: int) -> None:
         if self.inline:

@@ -22,6 +22,12 @@ def total_num_agents(cfg, env_info) -> int:
     return total_num_envs(cfg) * env_info.num_agents
 
 
+def samples_per_trajectory(trajectory) -> int:
+    """rl_utils.py:45-48: env steps in a [batch, rollout, ...] trajectory dict"""
+    batch, rollout = trajectory["rewards"].shape[:2]
+    return int(batch) * int(rollout)
+
+
 def gae_advantages(rewards, dones, values, valids, γ: float, λ: float):
     """rl_utils.py:78-94: rewards/dones [E,T], values/valids [E,T+1] -> advantages [E,T] (GPU tensors)."""
     adv = torch.empty_like(rewards)

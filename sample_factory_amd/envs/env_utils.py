@@ -7,6 +7,11 @@ from typing import Callable, Dict
 _ENV_REGISTRY: Dict[str, Callable] = {}
 
 
+class EnvCriticalError(Exception):
+    """an env integration raises it for a failure the env cannot recover from by resetting (envs/env_utils.py:34-35:
+    sf_examples/vizdoom/doom/doom_gym.py when the game process is gone); it propagates out of the rollout and stops the run"""
+
+
 def register_env(env_name: str, make_env_func: Callable) -> None:
     if env_name in _ENV_REGISTRY:
         print(f"[sample_factory_amd] env {env_name} already registered, overwriting")

@@ -42,6 +42,9 @@ class Dict:
     def __getitem__(self, k):
         return self.spaces[k]
 
+    def __repr__(self):
+        return "Dict(" + ", ".join(f"{k!r}: {v!r}" for k, v in self.spaces.items()) + ")"
+
 
 class Tuple:
     """gymnasium.spaces.Tuple stand-in (multi-head action spaces, e.g. VizDoom: move / turn / attack)"""

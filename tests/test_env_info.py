@@ -1,0 +1,157 @@
+"""EnvInfo the way the reference obtains it (sample_factory/algo/utils/env_info.py:42-145): extracted from a batched env,
+obtained from a spawned child process (the env is never built in the caller's process), cached per env name, checked against
+the env that is finally built — plus the small helper modules env integrations import next to it."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from sample_factory_amd.algo.utils import env_info as ei
+from sample_factory_amd.cfg.arguments import default_cfg
+from sample_factory_amd.envs import spaces
+from sample_factory_amd.envs.cartpole import make_cartpole_env
+from sample_factory_amd.envs.env_utils import RewardShapingInterface, register_env
+
+BUILT_HERE = []  # env ids constructed in THIS process
+
+
+class DoomLikeEnv(RewardShapingInterface):
+    """single-agent env with a Tuple action space and a reward-shaping scheme"""
+
+    def __init__(self):
+        BUILT_HERE.append(os.getpid())
+        self.observation_space = spaces.Box(0, 255, (3, 8, 8), np.uint8)
+        self.action_space = spaces.Tuple([spaces.Discrete(3), spaces.Discrete(2)])
+
+    def get_default_reward_shaping(self):
+        return {"kill": 1.0, "death": -0.5}
+
+    def set_reward_shaping(self, reward_shaping, agent_idx):
+        pass
+
+    def reset(self, **kw):
+        return np.zeros((3, 8, 8), np.uint8), {}
+
+    def step(self, action):
+        return np.zeros((3, 8, 8), np.uint8), 0.0, False, False, {}
+
+    def close(self):
+        pass
+
+
+def make_doomlike(full_env_name, cfg=None, env_config=None, render_mode=None):
+    return DoomLikeEnv()
+
+
+def _cfg(env, tmp_path, **kw):
+    return default_cfg(env=env, train_dir=str(tmp_path), experiment="x", **kw)
+
+
+def test_extract_env_info_fields():
+    cfg = default_cfg(env="doomlike", env_frameskip=4)
+    env = DoomLikeEnv()
+    env.num_agents = 1
+    env.action_space = spaces.Tuple([spaces.Discrete(3), spaces.Discrete(2), spaces.Box(-1, 1, (2,), np.float32)])
+    info = ei.extract_env_info(env, cfg)
+    assert info.num_agents == 1 and info.frameskip == 4
+    assert info.action_splits == [1, 1, 2] and info.all_discrete is False  # action components per Tuple member
+    assert info.reward_shaping_scheme == {"kill": 1.0, "death": -0.5}
+    assert info.env_info_protocol_version == ei.ENV_INFO_PROTOCOL_VERSION
+    assert info.gpu_actions == bool(cfg.env_gpu_actions) and info.gpu_observations == bool(cfg.env_gpu_observations)
+    plain = ei.extract_env_info(type("E", (), dict(observation_space=spaces.Box(-1, 1, (4,)), action_space=spaces.Discrete(2),
+                                                   num_agents=3))(), cfg)
+    assert plain.action_splits is None and plain.all_discrete is None and plain.reward_shaping_scheme is None
+
+
+def test_env_info_from_a_separate_process_and_cache(tmp_path, monkeypatch):
+    monkeypatch.setattr(ei, "env_info_cache_filename", lambda cfg: str(tmp_path / f"env_info_{cfg.env}"))
+    register_env("CartPole-probe", make_cartpole_env)
+    cfg = _cfg("CartPole-probe", tmp_path, use_env_info_cache=True)
+    info = ei.obtain_env_info_in_a_separate_process(cfg, timeout=120)
+    assert info.num_agents >= 1 and info.action_space.n == 2
+    assert tuple(info.obs_space["obs"].shape) == (4,)  # a bare Box becomes Dict(obs=Box), make_env.py:46-66
+    cache = tmp_path / "env_info_CartPole-probe"
+    assert cache.is_file()
+    # a cached entry of the current protocol version is returned without starting a process ...
+    marked = pickle.loads(cache.read_bytes())
+    marked.frameskip = 77
+    cache.write_bytes(pickle.dumps(marked))
+    assert ei.obtain_env_info_in_a_separate_process(cfg, timeout=120).frameskip == 77
+    # ... one of another version is ignored and replaced
+    marked.env_info_protocol_version = -1
+    cache.write_bytes(pickle.dumps(marked))
+    assert ei.obtain_env_info_in_a_separate_process(cfg, timeout=120).frameskip == int(cfg.env_frameskip)
+
+
+def test_env_is_not_built_in_the_calling_process(tmp_path, monkeypatch):
+    monkeypatch.setattr(ei, "env_info_cache_filename", lambda cfg: str(tmp_path / f"env_info_{cfg.env}"))
+    register_env("doomlike", make_doomlike)
+    BUILT_HERE.clear()
+    info = ei.obtain_env_info_in_a_separate_process(_cfg("doomlike", tmp_path), timeout=120)
+    assert BUILT_HERE == []  # the child built it, not this process
+    assert info.action_splits == [1, 1] and info.all_discrete is True
+    assert info.reward_shaping_scheme == {"kill": 1.0, "death": -0.5}  # found through the one-agent batched view's env chain
+    assert not (tmp_path / "env_info_doomlike").exists()  # use_env_info_cache defaults to False
+
+
+def _broken(full_env_name, cfg=None, env_config=None, render_mode=None):
+    raise OSError("no display")
+
+
+def test_probe_failure_is_raised_in_the_caller(tmp_path):
+    register_env("broken-env", _broken)
+    with pytest.raises(RuntimeError, match="no display"):
+        ei.obtain_env_info_in_a_separate_process(_cfg("broken-env", tmp_path), timeout=120)
+
+
+def test_check_env_info_detects_a_stale_cache(tmp_path, monkeypatch):
+    monkeypatch.setattr(ei, "env_info_cache_filename", lambda cfg: str(tmp_path / f"env_info_{cfg.env}"))
+    cfg = _cfg("doomlike", tmp_path)
+    env = DoomLikeEnv()
+    env.num_agents = 1
+    info = ei.extract_env_info(env, cfg)
+    ei.check_env_info(env, info, cfg)  # same env: fine
+    env2 = DoomLikeEnv()
+    env2.num_agents = 1
+    env2.observation_space = spaces.Dict({"obs": env2.observation_space, "measurements": spaces.Box(-1, 1, (5,))})
+    ei.check_env_info(env2, pickle.loads(pickle.dumps(ei.extract_env_info(env2, cfg))), cfg)  # equal after a round trip through the cache format
+    (tmp_path / "env_info_doomlike").write_bytes(b"stale")
+    env.action_space = spaces.Discrete(7)
+    with pytest.raises(ValueError, match="Env info mismatch"):
+        ei.check_env_info(env, info, cfg)
+    assert not (tmp_path / "env_info_doomlike").exists()  # the stale entry is gone
+
+
+def test_small_helper_modules():
+    import torch
+    import torch.nn as nn
+
+    from sample_factory.algo.utils.multiprocessing_utils import FakeLock, get_lock, get_mp_ctx, get_mp_lock
+    from sample_factory.algo.utils.rl_utils import samples_per_trajectory
+    from sample_factory.algo.utils.spaces.discretized import Discretized
+    from sample_factory.envs.env_utils import EnvCriticalError
+    from sample_factory.model.utils import he_normal_init, orthogonal_init
+    from sample_factory.utils.network import is_udp_port_available
+
+    assert get_mp_ctx(True) is None and get_mp_ctx(False) is get_mp_ctx(False) and get_mp_ctx(False).get_start_method() == "spawn"
+    assert isinstance(get_lock(serial=True), FakeLock)
+    with get_lock(serial=True), get_mp_lock(get_mp_ctx(False)), get_mp_lock():
+        pass
+    d = Discretized(11, -1.0, 1.0)  # discretized.py:11-14: n = 11 over [-1, 1] -> steps of 0.2
+    assert d.n == 11 and d.to_continuous(0) == -1.0 and d.to_continuous(10) == 1.0 and abs(d.to_continuous(6) - 0.2) < 1e-12
+    from sample_factory_amd.envs.spaces import calc_num_action_parameters, calc_num_actions, is_discrete
+    assert is_discrete(d) and calc_num_actions(d) == 1 and calc_num_action_parameters(d) == 11
+    assert samples_per_trajectory({"rewards": torch.zeros(5, 7)}) == 35
+    assert issubclass(EnvCriticalError, Exception)
+    net = nn.Sequential(nn.Linear(6, 6), nn.LayerNorm(6), nn.Conv2d(2, 2, 1))
+    for m in net:
+        if hasattr(m, "bias"):
+            m.bias.data.fill_(3.0)
+    net.apply(lambda m: orthogonal_init(m, gain=2.0))
+    w = net[0].weight.detach()
+    assert torch.allclose(w @ w.t(), 4.0 * torch.eye(6), atol=1e-4)  # orthogonal rows scaled by the gain
+    assert float(net[0].bias.detach().abs().sum()) == 0.0 and float(net[2].bias.detach().abs().sum()) == 0.0
+    assert float(net[1].bias[0]) == 3.0  # only Linear / Conv2d are touched
+    assert he_normal_init(net[0]) is net[0] and float(net[0].weight.std()) > 0
+    assert isinstance(is_udp_port_available(0), bool)

@@ -282,3 +282,62 @@ def test_env_deployment_plan_follows_serial_mode_and_env_kind(env, serial, mode,
     r = Runner(cfg)
     assert r._env_plan() == want
     assert (getattr(r, "_probe_env", None) is not None) == (want == "direct")  # the probe is reused only as instance 0
+
+
+class ShapedEnv:
+    """single-agent env whose reward is scheme["w"] and which also listens for training info: the optional env interfaces of
+    envs/env_utils.py:60-133 must reach instances that live in worker processes"""
+
+    def __init__(self):
+        from sample_factory_amd.envs.env_utils import RewardShapingInterface, TrainingInfoInterface
+
+        class _Impl(RewardShapingInterface, TrainingInfoInterface):
+            def __init__(s):
+                TrainingInfoInterface.__init__(s)
+                s.scheme = {"w": 1.0}
+
+            def get_default_reward_shaping(s):
+                return {"w": 1.0}
+
+            def set_reward_shaping(s, reward_shaping, agent_idx):
+                s.scheme = dict(reward_shaping)
+
+        self.env = _Impl()  # one layer down, as behind a gym wrapper
+        self.observation_space = spaces.Box(-1, 1, (2,), np.float32)
+        self.action_space = spaces.Discrete(2)
+
+    def reset(self, **kw):
+        return np.zeros(2, np.float32), {}
+
+    def step(self, action):
+        steps = float(self.env.training_info.get("approx_total_training_steps", 0))
+        return np.array([steps, 0], np.float32), float(self.env.scheme["w"]), False, False, {}
+
+    def close(self):
+        pass
+
+
+def make_shaped_env(full_env_name, cfg=None, env_config=None, render_mode=None):
+    return ShapedEnv()
+
+
+@pytest.mark.parametrize("inline", [True, False])
+def test_reward_shaping_and_training_info_reach_the_instances(inline):
+    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
+    from sample_factory_amd.envs.env_utils import get_default_reward_shaping, set_reward_shaping
+    cfg = default_cfg(env="shaped", seed=0)
+    host = ParallelHostEnvs(cfg, "shaped", make_shaped_env, 2, 2, num_splits=2, inline=inline)
+    try:
+        view = host.views[0]
+        assert get_default_reward_shaping(view) == {"w": 1.0}  # env_info.py:52 asks the batched env for it
+        for v in host.views:
+            v.reset()
+        _, rew, *_ = view.step(np.zeros(view.num_agents, np.int32))
+        assert np.all(rew == 1.0)
+        set_reward_shaping(view, {"w": 3.0}, slice(None))
+        view.set_training_info(dict(approx_total_training_steps=500))
+        for v in host.views:  # instances of BOTH splits got the messages
+            obs, rew, *_ = v.step(np.zeros(v.num_agents, np.int32))
+            assert np.all(rew == 3.0) and np.all(obs["obs"][:, 0] == 500.0)
+    finally:
+        host.close()
