@@ -5,9 +5,10 @@ import re
 import sys
 
 
-def main():
-    s = open(sys.argv[1]).read()
-    pat = sys.argv[2] if len(sys.argv) > 2 else ""
+def kernel_stats(s: str, pat: str = ""):
+    """[{name, vgpr, agpr, lds, scratch, mfma, glds, hot: {lines, mfma, glds, ds_read, waitcnt, barrier, valu, salu}}] for
+    every kernel of the listing `s` whose mangled name contains `pat`"""
+    out = []
     for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:', s, re.S | re.M):
         name, body = m.group(1), m.group(2)
         if pat not in name:
@@ -20,12 +21,25 @@ def main():
         blocks = re.split(r'^\.LBB\d+_\d+:', body, flags=re.M)
         hot = max(blocks, key=lambda b: len(re.findall('v_mfma', b)))
         h = lambda p: len(re.findall(p, hot))
-        valu, salu = h(r'\tv_(?!mfma)'), h(r'\ts_(?!waitcnt|barrier|nop)')
-        print(f"{name[:70]}\n   vgpr {get('num_vgpr')} agpr {get('num_agpr')} sgpr {get('num_sgpr')} lds {lds and lds.group(1)} "
-              f"scratch {cnt('scratch_')} | total: mfma {cnt('v_mfma')} glds {cnt('global_load_lds')} gload {cnt('global_load_dword')} "
-              f"bload {cnt('buffer_load')} | hot block: {len(hot.splitlines())} lines, mfma {h('v_mfma')} glds {h('global_load_lds')} "
-              f"gload {h('global_load_dword')} ds_read {h('ds_read')} ds_write {h('ds_write')} waitcnt {h('s_waitcnt')} "
-              f"barrier {h('s_barrier')} valu {valu} salu {salu}")
+        num = lambda v: int(v) if str(v).isdigit() else None
+        out.append(dict(name=name, vgpr=num(get('num_vgpr')), agpr=num(get('num_agpr')), lds=num(lds.group(1)) if lds else None,
+                        scratch=cnt('scratch_'), mfma=cnt('v_mfma'), glds=cnt('global_load_lds'), gload=cnt('global_load_dword'),
+                        bload=cnt('buffer_load'),
+                        hot=dict(lines=len(hot.splitlines()), mfma=h('v_mfma'), glds=h('global_load_lds'), gload=h('global_load_dword'),
+                                 ds_read=h('ds_read'), ds_write=h('ds_write'), waitcnt=h('s_waitcnt'), barrier=h('s_barrier'),
+                                 valu=h(r'\tv_(?!mfma)'), salu=h(r'\ts_(?!waitcnt|barrier|nop)'))))
+    return out
+
+
+def main():
+    s = open(sys.argv[1]).read()
+    for k in kernel_stats(s, sys.argv[2] if len(sys.argv) > 2 else ""):
+        h = k["hot"]
+        print(f"{k['name'][:70]}\n   vgpr {k['vgpr']} agpr {k['agpr']} sgpr ? lds {k['lds']} "
+              f"scratch {k['scratch']} | total: mfma {k['mfma']} glds {k['glds']} gload {k['gload']} "
+              f"bload {k['bload']} | hot block: {h['lines']} lines, mfma {h['mfma']} glds {h['glds']} "
+              f"gload {h['gload']} ds_read {h['ds_read']} ds_write {h['ds_write']} waitcnt {h['waitcnt']} "
+              f"barrier {h['barrier']} valu {h['valu']} salu {h['salu']}")
 
 
 if __name__ == "__main__":
