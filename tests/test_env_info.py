@@ -152,6 +152,6 @@ def test_small_helper_modules():
     w = net[0].weight.detach()
     assert torch.allclose(w @ w.t(), 4.0 * torch.eye(6), atol=1e-4)  # orthogonal rows scaled by the gain
     assert float(net[0].bias.detach().abs().sum()) == 0.0 and float(net[2].bias.detach().abs().sum()) == 0.0
-    assert float(net[1].bias[0]) == 3.0  # only Linear / Conv2d are touched
-    assert he_normal_init(net[0]) is net[0] and float(net[0].weight.std()) > 0
+    assert float(net[1].bias.detach()[0]) == 3.0  # only Linear / Conv2d are touched
+    assert he_normal_init(net[0]) is net[0] and float(net[0].weight.detach().std()) > 0
     assert isinstance(is_udp_port_available(0), bool)
