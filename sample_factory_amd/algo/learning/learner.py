@@ -39,6 +39,7 @@ from sample_factory_amd.envs.spaces import (action_head_sizes, calc_num_action_p
 from sample_factory_amd.model.actor_critic import ActorCritic
 from sample_factory_amd.model.model_factory import create_actor_critic
 from sample_factory_amd.utils.attr_dict import AttrDict
+from sample_factory_amd.utils.decay import LinearDecay
 
 LEARNER_ENV_STEPS, POLICY_ID_KEY, STATS_KEY, TRAIN_STATS = "learner_env_steps", "policy_id", "stats", "train"
 
@@ -682,15 +683,10 @@ class Learner:
         return stats
 
     _last_summary_time = 0.0
+    _summary_rate_decay = LinearDecay([(0, 2.0), (100000, 60.0), (1000000, 120.0)])  # seconds between summaries over train_step (learner.py:164)
 
     def _should_save_summaries(self) -> bool:
-        pts = [(0, 2.0), (100000, 60.0), (1000000, 120.0)]  # LinearDecay of learner.py:164 over train_step
-        s = float(self.train_step)
-        every = pts[-1][1]
-        for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
-            if s <= x1:
-                every = y0 + (y1 - y0) * max(0.0, s - x0) / (x1 - x0)
-                break
+        every = self._summary_rate_decay.at(float(self.train_step))
         return time.time() - self._last_summary_time >= every or getattr(self.cfg, "summaries_every_train", False)
 
     def _record_summaries(self, buff: AttrDict) -> Dict[str, float]:

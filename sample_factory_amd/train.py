@@ -26,6 +26,7 @@ from sample_factory_amd.cfg.arguments import cfg_dict, preprocess_cfg
 from sample_factory_amd.envs.env_utils import create_env, find_training_info_interface, set_training_info
 from sample_factory_amd.algo.sampling.parallel_env import ParallelVecEnvView
 from sample_factory_amd.utils.attr_dict import AttrDict
+from sample_factory_amd.utils.timing import Timing
 from sample_factory_amd.utils.utils import init_file_logger, log
 
 
@@ -69,6 +70,9 @@ class Runner:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.report_interval_sec = 5.0  # runner.py:117
+        # wall-clock profile of the loop (utils/timing.py; printed as a tree when run() ends, runner.py:731-735).  Around
+        # asynchronous launches this is host time spent ENQUEUEING — device times come from HIP events (bench.py) / rocprofv3
+        self.timing = Timing("Runner profile")
         self.training_iteration_since_resume = 0
         # key -> per-policy deque(maxlen=cfg.stats_avg), filled by the default episodic-stats handler
         self.policy_avg_stats: Dict[str, List[deque]] = dict()
@@ -470,10 +474,12 @@ class Runner:
         if self.cfg.async_rl:
             return self.iteration_async()
         while not self._ready:
-            self._rollout_all(float(self.learner.train_step))
+            with self.timing.add_time("rollout"):
+                self._rollout_all(float(self.learner.train_step))
         stats = None
         while self._ready:
-            stats = self._train_dataset(self._ready.pop(0)) or stats
+            with self.timing.add_time("train"):
+                stats = self._train_dataset(self._ready.pop(0)) or stats
         return stats
 
     def iteration_async(self):
@@ -682,6 +688,7 @@ class Runner:
         self._save_policy()        # runner.py:685-698 (_stop_training): final checkpoint + best check
         self._save_best_policy()
         if self.rank == 0:
+            log.info(str(self.timing))
             print(f"Collected {{0: {self.env_steps}}}, FPS: {self.fps:.1f}")
         return self.status
 
