@@ -138,12 +138,17 @@ def secondary_lines(args):
     timed steps bracketed by synchronize, whole-job env-steps/s, roofline of that run's dominant kernel."""
     import subprocess
     out = []
-    for wl, steps, warm in (("c5", 6, 2), ("c3", 4, 2), ("c2_normalize_input", 4, 2)):
+    # c2_atari_preset = SURVEY.md 8(d)'s second measurement point: the C2 workload at the learner settings of the reference's
+    # envpool-Atari preset (rollout=128, num_epochs=4, num_batches_per_epoch=4 per dataset of the preset -> here 16 minibatches
+    # of 32768 over the 4096 x 128 dataset; /root/reference/sf_examples/envpool/atari/envpool_atari_params.py:31-34)
+    extra = {"c2_normalize_input": ["--normalize_input"],
+             "c2_atari_preset": ["--rollout", "128", "--num_batches", "16", "--num_epochs", "4"]}
+    for wl, steps, warm in (("c5", 16, 3), ("c3", 12, 3), ("c2_normalize_input", 12, 2), ("c2_atari_preset", 3, 2)):
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl.split("_")[0], "--steps", str(steps), "--warmup",
-               str(warm), "--no_cpu_baseline", "--no_secondary"] + (["--normalize_input"] if wl.endswith("normalize_input") else [])
+               str(warm), "--no_cpu_baseline", "--no_secondary"] + extra.get(wl, [])
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=150)
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=200)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 out.append({"workload": wl, "error": f"rc {r.returncode}: {r.stderr[-200:]}"})
@@ -155,7 +160,7 @@ def secondary_lines(args):
                    "data": "synthetic", "config": d["config"]["workload"],
                    "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                        "traffic_source", "clock_ghz", "frac_at_measured_clock",
-                                                       "avg_launch_ms", "launches", "share_of_step_time")},
+                                                       "avg_launch_ms", "launches", "share_of_step_time", "scope")},
                    "wall_s": round(time.perf_counter() - t0, 1)}
             if "ingest" in d:
                 ent["ingest"] = {k: d["ingest"].get(k) for k in ("h2d_bytes_per_env_step", "obs_dma_gbs", "sampler_thread",
@@ -315,7 +320,10 @@ def workload_cfg(args, rank, world):
         desc = (f"BASELINE.json configs[2] stand-in: HOST vector env {B} envs/GPU ({how}; numpy u8 [4,84,84] frames as "
                 f"envpool returns them, int32 "
                 f"actions D2H), Discrete(6), Nature-CNN, APPO {mode}, rollout={T}, batch_size={cfg.batch_size} x "
-                f"{args.num_batches} minibatches x {args.num_epochs} epoch(s) (envpool-Atari preset)")
+                f"{args.num_batches} minibatches x {args.num_epochs} epoch(s); from the reference's envpool-Atari preset "
+                f"(envpool_atari_params.py:26-45): async_rl, num_epochs=4, num_batches_per_epoch=4, lr 2.5e-4, adam_eps 1e-5, "
+                f"max_grad_norm 0.5, no input / return normalisation; NOT from it: rollout {T} (preset 128) and batch_size "
+                f"{cfg.batch_size} (preset 256) - one dataset = one rollout of all {B} envs here")
         return cfg, "host_atari", make_host_frame_env, desc, \
             "env-steps/sec (whole node), 1024 host envs, 84x84x4 obs ingested over PCIe"
     raise SystemExit(f"unknown workload {args.workload}")
@@ -437,11 +445,17 @@ def main():
             ms = sorted(s_.elapsed_time(e_) for s_, e_ in evs)
             return ms[len(ms) // 2] * len(ms)
 
+        # c3 (host envs, async): the rollout side is hundreds of small per-split inference launches that share the chip with
+        # the training stream -- the roofline of that run is taken on the TRAINING-side launches (n = the minibatch size)
+        def in_scope(key):
+            return args.workload != "c3" or key[1] == cfg.batch_size
+
         by_name = {}
         for key, evs in warm_prof.items():
-            by_name[key[-1]] = by_name.get(key[-1], 0.0) + robust_total(evs)
+            if in_scope(key):
+                by_name[key[-1]] = by_name.get(key[-1], 0.0) + robust_total(evs)
         dominant = max(by_name, key=by_name.get)
-        lib.PROFILE, lib.PROFILE_ONLY = {}, {key for key in warm_prof if key[-1] == dominant}
+        lib.PROFILE, lib.PROFILE_ONLY = {}, {key for key in warm_prof if key[-1] == dominant and in_scope(key)}
         # optional subsampling of the event pairs (--event_stride k: every k-th launch of each shape; default 1 = all)
         lib.PROFILE_STRIDE, lib.PROFILE_SEEN = max(1, int(args.event_stride)), {}
     env_steps0, rounds0 = runner.learner.env_steps, runner.sampling_rounds
@@ -478,7 +492,8 @@ def main():
                   "obs_dma_gbs": round(dma_bytes / (dma_ms * 1e-3) / 1e9, 2) if dma_ms else None,
                   "obs_dma_ms_total": round(dma_ms, 1), "h2d_gbs_over_wall_clock": round(h2d / dt / 1e9, 2),
                   "host_s": {k: round(v, 3) for k, v in tot.items()}, "wall_s": round(dt, 3), "sampling_rounds": rounds,
-                  "sampler_thread": bool(runner.threaded), "env_worker_processes": int(getattr(cfg, "env_workers", 0) or 0),
+                  "sampler_thread": bool(runner.threaded),
+                  "env_worker_processes": int(args.env_workers) if cfg.env_workers_mode == "process" else 0,
                   "obs_dma_from_worker_pages_in_place": direct_dma,
                   "dma_share_of_wall_clock": round(dma_ms * 1e-3 / dt, 4)}
     prof, lib.PROFILE, lib.PROFILE_ONLY = lib.PROFILE, None, None
@@ -577,6 +592,9 @@ def main():
                 "timed_launches": timed, "event_stride": int(args.event_stride),
                 "gflop_per_launch": round(flops / launches / 1e9, 3),
                 "share_of_step_time": round(total_ms / (dt * 1e3), 4), "shapes": shapes}
+    if args.workload == "c3":
+        roofline["scope"] = (f"training-side launches only (n = {cfg.batch_size}); they run while the rollout side's small "
+                             f"inference launches share the chip (async_rl)")
     if clock is not None:  # peak is priced at the 2.4 GHz maximum clock; the timed region ran at clock["ghz"] (median sample)
         roofline["clock_ghz"] = clock["ghz"]
         roofline["clock"] = clock

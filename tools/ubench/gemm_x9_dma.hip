@@ -29,7 +29,13 @@ constexpr int BK = 32;  // reduction elements per chunk: 64-byte LDS rows, one 1
 // A-planes [3][M][K], W-planes [3][N][K] (bf16 bit patterns).  WGM x WGN waves, wave tile (BM/WGM) x (BN/WGN).
 template <int BM, int BN, int WGM, int WGN, int NPROD>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_x9(const uint16_t *__restrict__ Ap, const uint16_t *__restrict__ Wp,
-                                                            float *__restrict__ out, int M, int N, int K) {
+                                                            float *__restrict__ out, int M, int N, int K,
+                                                            unsigned long long *__restrict__ clk) {
+    // clock probe (round 6): the work-group in the middle of the grid records s_memtime ticks (shader cycles) and the
+    // 100 MHz wall clock over its own life time: ticks / (10 ns units) * 0.1 = the shader clock in GHz WHILE THIS KERNEL RUNS
+    const bool probe = clk && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0;
+    unsigned long long t0 = 0, w0 = 0;
+    if (probe) { t0 = __builtin_amdgcn_s_memtime(); w0 = wall_clock64(); }
     constexpr int NW = WGM * WGN, TM = BM / WGM / 16, TN = BN / WGN / 16;
     constexpr int FA = BM / 16, FB = BN / 16;               // 16-row fragments per plane
     constexpr int NFR = 3 * (FA + FB);                      // DMA instructions per chunk and work-group
@@ -112,6 +118,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_x9(const uint16_t *__re
                 const int64_t m = m0 + (wm * TM + ta) * 16 + 4 * kg + r;
                 if (m < M) out[m * N + n0 + (wn * TN + tb) * 16 + i16] = acc[ta][tb][r];
             }
+    if (probe) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = wall_clock64() - w0; }
 }
 
 // ---- operands generated and split on the device (the conv2 shape is 1.36 G elements)
@@ -158,7 +165,7 @@ static void run(const char *label, const uint16_t *dA, const uint16_t *dW, float
     int occ = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WGM * WGN, ldsb);
     dim3 grid((M + BM - 1) / BM, N / BN);
-    kern<<<grid, 64 * WGM * WGN, ldsb>>>(dA, dW, dO, M, N, K);
+    kern<<<grid, 64 * WGM * WGN, ldsb>>>(dA, dW, dO, M, N, K, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed: %s\n", label, hipGetErrorString(hipGetLastError())); return; }
     // float64 check on sampled entries of the LAST 64 rows and the first 64 rows
     double maxerr = 0, maxref = 0;
@@ -179,18 +186,27 @@ static void run(const char *label, const uint16_t *dA, const uint16_t *dW, float
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f, sum = 0;
     const int reps = 12;
+    unsigned long long *dclk, hclk[2];
+    hipMalloc(&dclk, 16);
+    double ghz_sum = 0;
     for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
-        kern<<<grid, 64 * WGM * WGN, ldsb>>>(dA, dW, dO, M, N, K);
+        kern<<<grid, 64 * WGM * WGN, ldsb>>>(dA, dW, dO, M, N, K, dclk);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         best = fminf(best, ms); sum += ms;
+        hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost);
+        ghz_sum += (double)hclk[0] / ((double)hclk[1] * 10.0);   // ticks per ns
     }
+    hipFree(dclk);
     const double mean = sum / reps, tf = 2.0 * M * N * K / (mean * 1e-3) / 1e12;
     printf("%-34s %d products tile %dx%d waves %dx%d occ %d: best %.3f ms mean %.3f ms = %.1f TFLOP/s f32-equivalent; "
-           "vs k_fwd_glds %.3f ms: %.2fx; err vs f64 %.2e relative to max|ref| %.3f\n",
-           label, NPROD, BM, BN, WGM, WGN, occ, best, mean, tf, ref_ms, ref_ms / mean, maxerr / maxref, maxref);
+           "vs k_fwd_glds %.3f ms: %.2fx; err vs f64 %.2e relative to max|ref| %.3f; shader clock inside the kernel %.2f GHz "
+           "-> bf16 pipe %.2f of its rate at that clock\n",
+           label, NPROD, BM, BN, WGM, WGN, occ, best, mean, tf, ref_ms, ref_ms / mean, maxerr / maxref, maxref, ghz_sum / reps,
+           // NPROD MFMAs of 16384 FLOP per 16x16x32 output block at 1024 FLOP per cycle and SIMD, 1024 SIMDs
+           (2.0 * M * N * K * NPROD / (mean * 1e-3)) / (1024.0 * 1024.0 * (ghz_sum / reps) * 1e9));
 }
 
 static void shape(const char *label, int M, int N, int K, double ref_ms) {
