@@ -99,26 +99,15 @@ def cpu_baseline_leg(args, T):
     err = None
     if ref_import_path.reference_available():
         try:
-            r = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", str(args.cpu_reference_envs), "5", "auto"],
-                               cwd=ROOT, capture_output=True, text=True, timeout=240)
+            # sample: 1024 of the 4096 trajectories (x4 to the full Tier-B iteration; the full 4096 x 32 dataset is ~30 s per
+            # Learner.train call and ~45 GB of the reference's f32 frame copies: --cpu_reference_envs 4096 runs it where the
+            # host allows), one untimed + three timed Learner.train calls, value from the median, spread in the line
+            r = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", str(args.cpu_reference_envs), "4", "auto",
+                                str(args.cpu_reference_repeats)],
+                               cwd=ROOT, capture_output=True, text=True, timeout=420)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode == 0 and line:
-                res = json.loads(line[-1])
-                # beside the single-process figure: P pinned copies at once (8 x 32 threads on the 256-core box) — the
-                # whole host rather than one process at its best pool size.  Reported under "processes"; `value` stays
-                # the single-process number the earlier rounds quoted.
-                try:
-                    host = int(res.get("host_cores") or len(os.sched_getaffinity(0)))
-                    P = max(2, min(8, host // 16))
-                    r2 = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_tier_b", "--procs", str(P),
-                                         str(max(64, args.cpu_reference_envs // 2)), "3", str(max(1, host // P))],
-                                        cwd=ROOT, capture_output=True, text=True, timeout=240)
-                    l2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
-                    res["processes"] = json.loads(l2[-1]) if (r2.returncode == 0 and l2) else \
-                        {"error": f"rc {r2.returncode}: {r2.stderr[-200:]}"}
-                except Exception as e:  # noqa: BLE001
-                    res["processes"] = {"error": repr(e)}
-                return res
+                return json.loads(line[-1])
             err = f"rc {r.returncode}: {r.stderr[-300:]}"
         except Exception as e:  # noqa: BLE001 - the baseline leg must never take the bench line down
             err = repr(e)
@@ -350,8 +339,11 @@ def main():
                     help="c2, one GPU: skip the secondary workload lines (c5, c3) measured after the timed region")
     ap.add_argument("--no_kernel_events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu_baseline_envs", type=int, default=256)
-    ap.add_argument("--cpu_reference_envs", type=int, default=256,
-                    help="trajectories of the sample the REFERENCE's CPU path is timed on (cpu_baseline kind 'reference')")
+    ap.add_argument("--cpu_reference_envs", type=int, default=1024,
+                    help="trajectories of the sample the REFERENCE's CPU path is timed on (cpu_baseline kind 'reference'; "
+                         "4096 = the full Tier-B workload, nothing extrapolated)")
+    ap.add_argument("--cpu_reference_repeats", type=int, default=3,
+                    help="timed Learner.train calls of the cpu_baseline leg (after one untimed call)")
     ap.add_argument("--event_stride", type=int, default=1,
                     help="timed region: every k-th launch of the dominant kernel carries a HIP-event pair (1 = all of them, the "
                          "default: a stride of 4 saved 0.2 ms per step but aliased with the 4 minibatches per step — every "
