@@ -216,6 +216,57 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _cpulist(text: str):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def numa_plan(local_rank: int, device_nodes, allowed, node_cpus):
+    """cores of `local_rank`: the cores of its GPU's NUMA node that this process may use, split evenly (in local-rank order)
+    among the ranks whose GPUs sit on the same node.  device_nodes[r] = NUMA node of rank r's GPU (-1 / None: unknown ->
+    no pinning for that rank), node_cpus[node] = cpu ids.  Pure function (tests/test_abi_and_host.py)."""
+    node = device_nodes[local_rank]
+    if node is None or node < 0 or node not in node_cpus:
+        return None
+    cpus = sorted(set(node_cpus[node]) & set(allowed))
+    peers = [r for r, nd in enumerate(device_nodes) if nd == node]
+    k, m = peers.index(local_rank), len(peers)
+    share = cpus[k * len(cpus) // m:(k + 1) * len(cpus) // m]
+    return share or None
+
+
+def pin_rank_to_gpu_numa(local_rank: int, local_world: int, sysfs: str = "/sys"):
+    """One process per GPU: keep the rank — and the env worker processes it starts later, which inherit the mask — on the
+    cores of the NUMA node its GPU hangs off (H2D of host-env frames and the launch path stay off the inter-socket link).
+    Returns {"numa_node", "cpus"} or a reason why nothing was pinned; never fails the run."""
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+        nodes = []
+        for r in range(local_world):
+            pr = torch.cuda.get_device_properties(r % ndev)
+            bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id"), getattr(pr, "pci_bus_id"), getattr(pr, "pci_device_id"))
+            try:
+                nodes.append(int(open(f"{sysfs}/bus/pci/devices/{bus}/numa_node").read()))
+            except OSError:
+                nodes.append(None)
+        node_cpus = {}
+        for nd in {n for n in nodes if n is not None and n >= 0}:
+            node_cpus[nd] = _cpulist(open(f"{sysfs}/devices/system/node/node{nd}/cpulist").read())
+        share = numa_plan(local_rank, nodes, os.sched_getaffinity(0), node_cpus)
+        if not share:
+            return {"numa_node": nodes[local_rank], "cpus": None, "note": "GPU's NUMA node unknown: affinity left as it was"}
+        os.sched_setaffinity(0, share)
+        return {"numa_node": nodes[local_rank], "cpus": len(share), "first_cpu": share[0]}
+    except Exception as e:  # noqa: BLE001 - placement is an optimisation
+        return {"numa_node": None, "cpus": None, "note": repr(e)}
+
+
 def init_replicas(world: int, rank: int, need_gpu: bool = True):
     """process group + a self-check of the collective path: all-reduce of a rank-stamped tensor must give
     sum(2^r) = 2^world - 1 (every rank contributed exactly once) and the ranks must sit on distinct devices.
@@ -379,8 +430,14 @@ def main():
     import torch
 
     rccl_ranks, rank_devices, backend = 1, [0], None
+    affinity = None
     if world > 1:
         rccl_ranks, rank_devices, backend = init_replicas(world, rank, need_gpu=not args.check_launch)
+        if torch.cuda.is_available() and os.environ.get("SF_NUMA_PIN", "1") != "0":
+            mine = pin_rank_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            allp = [None] * world
+            torch.distributed.all_gather_object(allp, mine)
+            affinity = allp
     if args.check_launch:
         if rank == 0:
             print(json.dumps({"launch_check": True, "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
@@ -619,6 +676,7 @@ def main():
                        "f32 weights / output gradients split exactly into 3 bf16 terms) - every product exact, no rounding of any "
                        "operand (csrc/sf_nn_u8.h)") if args.workload != "c5" else "f32 (f32 MFMA, f32 accumulation)",
         "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+        **({"rank_affinity": affinity} if affinity is not None else {}),
         "config": {"workload": workload_desc,
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
                    "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},

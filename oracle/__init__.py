@@ -170,7 +170,7 @@ def sample_masked(logits, mask, seed, step, row0=0):
 def sample_tuple(logits, head_sizes, seed, step, row0=0):
     logits = _f32(logits)
     N, H = logits.shape[0], len(head_sizes)
-    actions = np.zeros((N, H), np.float32)
+    actions = np.zeros((N, sum(1 if int(x) > 0 else -int(x) for x in head_sizes)), np.float32)  # x < 0: Box(-x) member
     logp = np.zeros(N, np.float32)
     lib().sfo_sample_tuple(_p(logits, C.c_float), C.c_long(N), (C.c_int * H)(*[int(x) for x in head_sizes]), H,
                            C.c_uint32(seed), C.c_uint32(step), C.c_uint32(row0), _p(actions, C.c_float),

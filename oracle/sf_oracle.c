@@ -204,13 +204,17 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
                           double clip_ratio, double clip_value, double value_loss_coeff, double exploration_coeff,
                           int exploration_kind, double kl_coeff, const double *ext_moments, float *out_scalars,
                           float *g_params, float *g_values, const int *head_n, int num_heads) {
-    /* head_n/num_heads: Tuple of Discrete spaces (action_distributions.py:197-287) = independent categorical heads
-     * whose log-prob / entropy / KL / symmetric-KL add up; actions then holds num_heads floats per sample.
+    /* head_n/num_heads: Tuple space (action_distributions.py:197-287) = independent heads whose log-prob / entropy / KL /
+     * symmetric-KL add up.  head_n[h] > 0: Discrete(head_n[h]) — head_n[h] logits, one action column; head_n[h] < 0:
+     * Box(D = -head_n[h]) — 2 D parameters [means | log_std], D action columns (TupleActionDistribution builds every member
+     * with get_action_distribution, :222-225, so any mix is legal there).  actions holds sum(columns) floats per sample.
      * NULL / <= 1: one Discrete(A). */
     int one_head[1];
     one_head[0] = A;
     if (!head_n || num_heads <= 1) { head_n = one_head; num_heads = 1; }
     const int H = num_heads;
+    int NA = 0;
+    for (int hd = 0; hd < H; ++hd) NA += head_n[hd] > 0 ? 1 : -head_n[hd];
     float ent_h[8], kl_h[8], klpu_h[8];
     int acts[8];
     const float clip_hi = (float)(1.0 + clip_ratio);
@@ -252,10 +256,27 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
             if (action_kind == 0) {
                 const float *zo = old_params + i * A;
                 logp_a = 0.f;
-                int off = 0;
+                int off = 0, aoff = 0;
                 for (int hd = 0; hd < H; ++hd) {
                     const int nh = head_n[hd];
                     const float *zh = z + off, *zoh = zo + off;
+                    if (nh < 0) { /* Box member: the Continuous formulas of the action_kind 1 branch below */
+                        const int Dh = -nh;
+                        float e = 0.f, kk = 0.f;
+                        for (int k = 0; k < Dh; ++k) {
+                            const float mu = zh[k], sd = clampf(expf(zh[Dh + k]), 1e-4f, 1e4f);
+                            const float a = actions[i * NA + aoff + k];
+                            logp_a += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+                            e += 0.5f + 0.91893853320467274178f + logf(sd);
+                            const float muo = zoh[k], sdo = clampf(expf(zoh[Dh + k]), 1e-4f, 1e4f);
+                            const float vr = (sd / sdo) * (sd / sdo);
+                            const float t1 = ((mu - muo) / sdo) * ((mu - muo) / sdo);
+                            kk += 0.5f * (vr + t1 - 1.f - logf(vr));
+                        }
+                        ent_h[hd] = e; kl_h[hd] = kk; klpu_h[hd] = 0.f; ent += e; kl += kk;
+                        off += 2 * Dh; aoff += Dh;
+                        continue;
+                    }
                     float mx = zh[0]; for (int k = 1; k < nh; ++k) mx = zh[k] > mx ? zh[k] : mx;
                     float se = 0.f; for (int k = 0; k < nh; ++k) se += expf(zh[k] - mx);
                     const float lse = logf(se);
@@ -264,7 +285,7 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
                     float seo = 0.f; for (int k = 0; k < nh; ++k) seo += expf(zoh[k] - mxo);
                     const float lseo = logf(seo);
                     for (int k = 0; k < nh; ++k) q[off + k] = (zoh[k] - mxo) - lseo;
-                    acts[hd] = (int)actions[i * H + hd];
+                    acts[hd] = (int)actions[i * NA + aoff];
                     logp_a += lp[off + acts[hd]];
                     float e = 0.f, kk = 0.f;
                     for (int k = 0; k < nh; ++k) { e -= p[off + k] * lp[off + k]; kk += p[off + k] * (lp[off + k] - q[off + k]); }
@@ -274,7 +295,7 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
                     for (int k = 0; k < nh; ++k) { a1 += p[off + k] * (lp[off + k] - lu); a2 += u * (lu - lp[off + k]); }
                     klpu_h[hd] = a1;
                     if (exploration_kind == 2) symkl += 0.5f * (a1 + a2);
-                    off += nh;
+                    off += nh; aoff += 1;
                 }
             } else {
                 /* Normal(mu, clamp(exp(log_std), 1e-4, 1e4)); Independent sums over D */
@@ -322,9 +343,33 @@ SFO_API void sfo_ppo_loss(const float *params, const float *values, const float 
             const int in_hard = raw_ratio >= 0.05f && raw_ratio <= 20.0f;
             const float dL_dlogp = in_hard ? (-inv_n) * dpl_dr * raw_ratio : 0.f;
             if (action_kind == 0) {
-                int off = 0;
+                int off = 0, aoff = 0;
                 for (int hd = 0; hd < H; ++hd) {
                     const int nh = head_n[hd];
+                    if (nh < 0) { /* Box member */
+                        const int Dh = -nh;
+                        const float *zh = z + off, *zoh = old_params + i * A + off;
+                        for (int k = 0; k < Dh; ++k) {
+                            const float mu = zh[k], e = expf(zh[Dh + k]);
+                            const float sd = clampf(e, 1e-4f, 1e4f);
+                            const float dsd_dls = (e >= 1e-4f && e <= 1e4f) ? e : 0.f;
+                            const float a = actions[i * NA + aoff + k];
+                            const float var = sd * sd;
+                            float gmu = dL_dlogp * ((a - mu) / var);
+                            float gsd = dL_dlogp * (((a - mu) * (a - mu)) / (var * sd) - 1.f / sd);
+                            if (exploration_kind == 1) gsd += -(float)exploration_coeff * inv_n * (1.f / sd);
+                            if (kl_coeff != 0.0) {
+                                const float muo = zoh[k], sdo = clampf(expf(zoh[Dh + k]), 1e-4f, 1e4f);
+                                gmu += (float)kl_coeff * inv_n * ((mu - muo) / (sdo * sdo));
+                                gsd += (float)kl_coeff * inv_n * (sd / (sdo * sdo) - 1.f / sd);
+                            }
+                            gz[off + k] = gmu;
+                            gz[off + Dh + k] = gsd * dsd_dls;
+                        }
+                        off += 2 * Dh; aoff += Dh;
+                        continue;
+                    }
+                    aoff += 1;
                     const float u = 1.0f / (float)nh, lu = logf(u);
                     for (int k = off; k < off + nh; ++k) {
                         float gk = dL_dlogp * ((k - off == acts[hd] ? 1.f : 0.f) - p[k]);
@@ -578,18 +623,39 @@ SFO_API void sfo_sample_masked(const float *logits, const uint8_t *mask, long N,
     }
 }
 
-/* Tuple of Discrete heads as sampled by sf_sample_write_step_tuple: head h draws from Philox counter (step, h, 2, 0);
- * actions [N, H], logp = sum of the heads' log-probs (TupleActionDistribution._calc_log_probs). */
+/* Tuple heads as sampled by sf_sample_write_step_tuple: a Discrete head h draws from Philox counter (step, h, 2, 0); a Box(D)
+ * head (head_n[h] = -D, parameters [means | log_std]) draws the normals of its dims 2j, 2j+1 from counter (step, j, 3, h) by
+ * Box-Muller as sfo_sample_normal does; actions [N, sum(columns)], logp = sum of the heads' log-probs
+ * (TupleActionDistribution._calc_log_probs). */
 SFO_API void sfo_sample_tuple(const float *logits, long N, const int *head_n, int H, uint32_t seed, uint32_t step,
                               uint32_t row0, float *actions, float *logp) {
-    int A = 0;
-    for (int h = 0; h < H; ++h) A += head_n[h];
+    int A = 0, NA = 0;
+    for (int h = 0; h < H; ++h) { A += head_n[h] > 0 ? head_n[h] : -2 * head_n[h]; NA += head_n[h] > 0 ? 1 : -head_n[h]; }
     for (long i = 0; i < N; ++i) {
         const float *z = logits + i * A;
         float lps = 0.f;
-        int off = 0;
+        int off = 0, aoff = 0;
         for (int h = 0; h < H; ++h) {
             const int nh = head_n[h];
+            if (nh < 0) {
+                const int D = -nh;
+                for (int k = 0; k < D; ++k) {
+                    uint32_t w[4];
+                    philox4x32_10(step, (uint32_t)(k >> 1), 3u, (uint32_t)h, seed, row0 + (uint32_t)i, w);
+                    const uint32_t w1 = (k & 1) ? w[2] : w[0], w2 = (k & 1) ? w[3] : w[1];
+                    const float u1 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                    const float u2 = (float)(w2 >> 8) * (1.0f / 16777216.0f);
+                    const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+                    const float mu = z[off + k];
+                    float sd = expf(z[off + D + k]);
+                    sd = sd < 1e-4f ? 1e-4f : (sd > 1e4f ? 1e4f : sd);
+                    const float a = mu + sd * eps;
+                    actions[i * NA + aoff + k] = a;
+                    lps += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+                }
+                off += 2 * D; aoff += D;
+                continue;
+            }
             float mx = z[off]; for (int k = 1; k < nh; ++k) mx = z[off + k] > mx ? z[off + k] : mx;
             float se = 0.f; for (int k = 0; k < nh; ++k) se += expf(z[off + k] - mx);
             const float lse = logf(se);
@@ -598,9 +664,9 @@ SFO_API void sfo_sample_tuple(const float *logits, long N, const int *head_n, in
             const float u = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
             float acc = 0.f; int a = nh - 1;
             for (int k = 0; k < nh; ++k) { acc += expf((z[off + k] - mx) - lse); if (u < acc) { a = k; break; } }
-            actions[i * H + h] = (float)a;
+            actions[i * NA + aoff] = (float)a;
             lps += (z[off + a] - mx) - lse;
-            off += nh;
+            off += nh; aoff += 1;
         }
         logp[i] = lps;
     }

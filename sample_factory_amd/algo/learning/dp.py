@@ -37,6 +37,8 @@ class _EventHandle:
         self.event, self.group = event, group
 
     def wait(self) -> None:
+        if self.group is not None:
+            self.group._mark("grad_async_wait")
         with _Exposed(self.group):
             torch.cuda.current_stream().wait_event(self.event)
 
@@ -48,6 +50,7 @@ class _TimedWork:
         self.work, self.group = work, group
 
     def wait(self) -> None:
+        self.group._mark("grad_async_wait")
         with _Exposed(self.group):
             self.work.wait()
 
@@ -90,8 +93,17 @@ class ReplicaGroup:
         self._comm = self._xstream = None
         # optional measurement (bench.py --gpus N): {"exposed": [(e0, e1)], "xchg": [(e0, e1)], "count": n}
         self.timing = None
+        # optional order trace (tests/test_gpu_dp.py): [(tag, HIP event recorded on the CURRENT stream at that point)] —
+        # where the gradient buckets are enqueued / waited for relative to the backward pass's launches
+        self.trace = None
         if native_rccl and self.on:
             self._init_native()
+
+    def _mark(self, tag: str) -> None:
+        if self.trace is not None and torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace.append((tag, ev))
 
     def enable_timing(self) -> None:
         """bracket every collective with HIP events: `exposed` = pairs on the compute stream around each point where it
@@ -146,12 +158,16 @@ class ReplicaGroup:
 
     def all_reduce_grads(self, t: torch.Tensor) -> torch.Tensor:
         """SUM of a slice of the flat fp32 gradient over the replicas; the current stream continues behind the result"""
+        self._mark("grad_sync")
         if self.native:
-            self._native_reduce(t).wait()
+            h = self._native_reduce(t)
+            with _Exposed(self):
+                torch.cuda.current_stream().wait_event(h.event)
             return t
         return self.all_reduce_sum(t)
 
     def all_reduce_grads_async(self, t: torch.Tensor):
+        self._mark("grad_async_enqueue")
         if self.native:
             return self._native_reduce(t)
         return self.all_reduce_sum_async(t)

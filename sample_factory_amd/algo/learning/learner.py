@@ -497,7 +497,8 @@ class Learner:
                              kl_old_mean=sc[4].clone(), ratio=self._ratio[:n], values=heads[:n, 0], g_heads=g_heads)
         return dist, sc[0].clone(), sc[1].clone(), kl_old, sc[2].clone(), sc[3].clone(), summaries
 
-    def _losses_native(self, buff: AttrDict, mb, num_invalids: int, scalars_out: Optional[torch.Tensor] = None):
+    def _losses_native(self, buff: AttrDict, mb, num_invalids: int, scalars_out: Optional[torch.Tensor] = None,
+                       moments: Optional[torch.Tensor] = None):
         """learner.py:537-669 for one minibatch mb=(index, offset, n): forward, (v-trace), advantage moments,
         fused loss forward+backward.  Returns (acts, g_heads, scalars[16] device tensor) — scalars follow
         sf_loss_scalars: policy, exploration, kl, value losses, kl mean/max, adv mean/std, n_valid, entropy."""
@@ -525,21 +526,44 @@ class Learner:
                        cfg.vtrace_c, vs, adv, head_sizes=self._head_sizes)
             lib.moments(adv, buff.valids, index, n, self._moments, offset=offset, dense_x=True)
             adv_arr, tgt_arr = adv, vs
-        else:
+        elif moments is None:
             lib.moments(buff.advantages, buff.valids, index, n, self._moments, offset=offset)
             adv_arr, tgt_arr = buff.advantages, buff.returns
-        self._all_reduce(self._moments)  # global per-minibatch advantage statistics under DP
+        else:
+            adv_arr, tgt_arr = buff.advantages, buff.returns
+        if moments is None:
+            moments = self._moments
+            self._all_reduce(moments)  # global per-minibatch advantage statistics under DP
+        # else: `moments` is this minibatch's row of the per-epoch table (_epoch_moments): GAE advantages do not depend on
+        # the weights, so every minibatch's {sum, sumsq, n} was computed and exchanged ONCE, before the epoch's first
+        # forward pass -- no collective sits between this forward pass and its loss
         self._ratio = ac._buf(("loss", "ratio"), (n,))
         self.loss_cfg.old_values_T = buff.T  # buff["values"] is the slab's [E, T+1] array
         lib.ppo_loss(params, ld, values, ld, buff.actions, buff.log_prob_actions, buff.action_logits, buff["values"],
-                     adv_arr, tgt_arr, buff.valids, index, offset, n, A, self.loss_cfg, self._moments, self._sums,
+                     adv_arr, tgt_arr, buff.valids, index, offset, n, A, self.loss_cfg, moments, self._sums,
                      g_heads[:, 1:], g_heads[:, 0], ratio_out=self._ratio)
         self._last_mb = (index, offset, n, values, adv_arr)  # for _record_summaries
         if self.dp and self._dp_reduce_each_mb:  # only the per-minibatch KL-adaptive LR needs global values NOW
             self.group.loss_sums(self._sums)
         out = scalars_out if scalars_out is not None else torch.zeros(16, dtype=torch.float32, device=self.device)
-        lib.loss_scalars(self._sums, self._moments, self.loss_cfg, out)
+        lib.loss_scalars(self._sums, moments, self.loss_cfg, out)
         return acts, g_heads, out
+
+    def _epoch_moments(self, buff: AttrDict, minibatches) -> Optional[torch.Tensor]:
+        """Data-parallel replicas, GAE advantages (no V-trace): {sum(adv), sum(adv^2), n_valid} of EVERY minibatch of the
+        epoch in one [num_minibatches, 3] f64 table and ONE all-reduce of it, issued before the epoch's first forward
+        pass (the advantages are inputs of the epoch — `_prepare_batch` wrote them — and the index sets are known as
+        soon as `_get_minibatches` returns).  Replaces one 24-byte collective per SGD step that sat on the critical
+        path between the forward pass and the loss (learner.py:646-647 needs the GLOBAL minibatch statistics).  Same
+        kernel, same per-minibatch sums, same reduction over the ranks: the values are those of the per-step exchange.
+        V-trace advantages depend on the current weights (learner.py:571-640) and keep the per-step exchange."""
+        if not self.dp or self.cfg.with_vtrace or not getattr(self.cfg, "dp_epoch_moments", True):
+            return None
+        tab = self.actor_critic._buf(("loss", "epoch_moments"), (len(minibatches), 3), dtype=torch.float64)
+        for i, (index, offset, n) in enumerate(minibatches):
+            lib.moments(buff.advantages, buff.valids, index, n, tab[i], offset=offset)
+        self._all_reduce(tab)
+        return tab
 
     # ------------------------------------------------------------------------------------------ SGD
     def _train(self, buff: AttrDict, batch_size: int, experience_size: int, num_invalids: int) -> Optional[AttrDict]:
@@ -570,9 +594,11 @@ class Learner:
             ac.rnn_abort_clear()
         for epoch in range(cfg.num_epochs):
             minibatches = self._get_minibatches(batch_size, experience_size)
+            mom_tab = self._epoch_moments(buff, minibatches)
             for batch_num, mb in enumerate(minibatches):
                 row = self._scalars[epoch * n_mb + batch_num]
-                acts, g_heads, _ = self._losses_native(buff, mb, num_invalids, row)
+                acts, g_heads, _ = self._losses_native(buff, mb, num_invalids, row,
+                                                       moments=None if mom_tab is None else mom_tab[batch_num])
                 index, offset, n = mb
                 # C1: every replica's gradient already carries the GLOBAL 1/n_valid -> SUM over replicas
                 if self._dp_split is not None:

@@ -68,6 +68,7 @@ FLAGS = [
 ENGINE_FLAGS = [
     ("data_parallel", _bool, False),         # learner replicas over torch.distributed (set automatically when WORLD_SIZE > 1)
     ("dp_overlap", _bool, True),             # all-reduce the fc/heads gradient bucket while the conv layers back-propagate
+    ("dp_epoch_moments", _bool, True),       # GAE: every minibatch's advantage moments exchanged once per epoch (False: one 24-byte all-reduce per SGD step)
     ("dp_native_rccl", _bool, False),        # gradient buckets through the C-ABI (sf_allreduce_grads) instead of torch.distributed
     ("dp_force_collectives", _bool, False),  # issue the collectives in a group of one rank (tests)
     ("device_shuffle", _bool, False),        # shuffle_minibatches with the stateless on-device permutation

@@ -318,18 +318,34 @@ __device__ __forceinline__ float action_logp(const float *__restrict__ z, int A,
 struct HeadsDev {
     int num_heads, head_n[8];
 };
-// log-prob of a Tuple-of-Discrete action: sum over the heads of log_softmax(z_h)[a_h]
+// action columns of a Tuple space: one per Discrete member (head_n > 0), D per Box(D) member (head_n = -D)
+__device__ __host__ __forceinline__ int heads_action_cols(const int *head_n, int num_heads) {
+    int c = 0;
+    for (int h = 0; h < num_heads; ++h) c += head_n[h] > 0 ? 1 : -head_n[h];
+    return c;
+}
+// log-prob of a Tuple action: sum over the members of log_softmax(z_h)[a_h] (Discrete) / Normal log-density (Box, head_n = -D)
 __device__ __forceinline__ float tuple_logp(const float *__restrict__ z, const float *__restrict__ act, const HeadsDev &hd) {
     float lp = 0.f;
-    int off = 0;
+    int off = 0, aoff = 0;
     for (int h = 0; h < hd.num_heads; ++h) {
         const int nh = hd.head_n[h];
+        if (nh < 0) {
+            const int D = -nh;
+            for (int k = 0; k < D; ++k) {
+                const float mu = z[off + k], sd = clampf(expf(z[off + D + k]), 1e-4f, 1e4f);
+                const float a = act[aoff + k];
+                lp += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+            }
+            off += 2 * D; aoff += D;
+            continue;
+        }
         float mx = -INFINITY;
         for (int k = 0; k < nh; ++k) mx = fmaxf(mx, z[off + k]);
         float se = 0.f;
         for (int k = 0; k < nh; ++k) se += expf(z[off + k] - mx);
-        lp += (z[off + (int)act[h]] - mx) - logf(se);
-        off += nh;
+        lp += (z[off + (int)act[aoff]] - mx) - logf(se);
+        off += nh; aoff += 1;
     }
     return lp;
 }
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(256) void k_vtrace_ratio(const float *__restrict__ 
                                                       int action_kind, float *__restrict__ ratio_out, HeadsDev hd) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const int nact = hd.num_heads > 1 ? hd.num_heads : (action_kind == 0 ? 1 : A / 2);
+    const int nact = hd.num_heads > 1 ? heads_action_cols(hd.head_n, hd.num_heads) : (action_kind == 0 ? 1 : A / 2);
     const int64_t d = index ? (int64_t)index[k] : offset + k;
     const float lp = hd.num_heads > 1 ? tuple_logp(params + k * ldp, actions + d * nact, hd)
                                       : action_logp<MAXA>(params + k * ldp, A, action_kind, actions + d * nact);
@@ -391,10 +407,14 @@ extern "C" int sf_vtrace(const float *params, int ld_params, const float *values
     SF_REQUIRE(ld_params >= A && ld_values >= 1, "sf_vtrace: bad strides");
     HeadsDev hd = {};
     if (head_n && num_heads > 1) {
-        SF_REQUIRE(num_heads <= 8 && action_kind == 0, "sf_vtrace: at most 8 Discrete heads");
+        SF_REQUIRE(num_heads <= 8 && action_kind == 0, "sf_vtrace: at most 8 heads (action_kind 0 with a head list)");
         int tot = 0;
         hd.num_heads = num_heads;
-        for (int i = 0; i < num_heads; ++i) { hd.head_n[i] = head_n[i]; tot += head_n[i]; }
+        for (int i = 0; i < num_heads; ++i) {  // head_n > 0: Discrete(n), n logits; < 0: Box(-n), 2 * (-n) parameters
+            SF_REQUIRE(head_n[i] != 0, "sf_vtrace: empty action head");
+            hd.head_n[i] = head_n[i];
+            tot += head_n[i] > 0 ? head_n[i] : -2 * head_n[i];
+        }
         SF_REQUIRE(tot == A, "sf_vtrace: head sizes sum to %d, A = %d", tot, A);
     }
     SF_REQUIRE(params && values && actions && old_logp && rewards && dones && vs && adv, "sf_vtrace: null pointer");
@@ -656,15 +676,34 @@ __global__ __launch_bounds__(256) void k_ppo_loss_md(const float *__restrict__ p
         float *gz = g_params + i * ldp;
         float logp_a = 0.f, ent = 0.f, kl = 0.f, symkl = 0.f;
         float mx[8], lse[8], mxo[8], lseo[8], ent_h[8], kl_h[8], klpu_h[8];
-        int off = 0;
+        int off = 0, aoff = 0;
+        const int NA = heads_action_cols(h.head_n, H);
         for (int hd = 0; hd < H; ++hd) {
             const int nh = h.head_n[hd];
+            if (nh < 0) {  // Box(D) member: [means | log_std], the formulas of k_ppo_loss's continuous branch
+                const int Dh = -nh;
+                float e = 0.f, kk = 0.f;
+                for (int k = 0; k < Dh; ++k) {
+                    const float mu = z[off + k], sd = clampf(expf(z[off + Dh + k]), 1e-4f, 1e4f);
+                    const float a = actions[d * NA + aoff + k];
+                    logp_a += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+                    e += 0.5f + 0.91893853320467274178f + logf(sd);
+                    const float muo = zo[off + k], sdo = clampf(expf(zo[off + Dh + k]), 1e-4f, 1e4f);
+                    const float vr = (sd / sdo) * (sd / sdo);
+                    const float t1 = ((mu - muo) / sdo) * ((mu - muo) / sdo);
+                    kk += 0.5f * (vr + t1 - 1.f - logf(vr));
+                }
+                ent_h[hd] = e; kl_h[hd] = kk; klpu_h[hd] = 0.f;
+                ent += e; kl += kk;
+                off += 2 * Dh; aoff += Dh;
+                continue;
+            }
             float m1 = -INFINITY, m2 = -INFINITY;
             for (int k = 0; k < nh; ++k) { m1 = fmaxf(m1, z[off + k]); m2 = fmaxf(m2, zo[off + k]); }
             float s1 = 0.f, s2 = 0.f;
             for (int k = 0; k < nh; ++k) { s1 += expf(z[off + k] - m1); s2 += expf(zo[off + k] - m2); }
             mx[hd] = m1; lse[hd] = logf(s1); mxo[hd] = m2; lseo[hd] = logf(s2);
-            const int act = (int)actions[d * H + hd];
+            const int act = (int)actions[d * NA + aoff];
             const float u = 1.0f / (float)nh, lu = logf(u);
             float e = 0.f, kk = 0.f, a1 = 0.f, a2 = 0.f;
             for (int k = 0; k < nh; ++k) {
@@ -677,7 +716,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_md(const float *__restrict__ p
             }
             ent_h[hd] = e; kl_h[hd] = kk; klpu_h[hd] = a1;
             ent += e; kl += kk; symkl += 0.5f * (a1 + a2);
-            off += nh;
+            off += nh; aoff += 1;
         }
         if (sym_pass) {
             if (valid) acc[0] = symkl;
@@ -708,9 +747,33 @@ __global__ __launch_bounds__(256) void k_ppo_loss_md(const float *__restrict__ p
                 const bool in_hard = raw_ratio >= 0.05f && raw_ratio <= 20.0f;
                 const float dL_dlogp = in_hard ? (-inv_n) * dpl_dr * raw_ratio : 0.f;
                 off = 0;
+                aoff = 0;
                 for (int hd = 0; hd < H; ++hd) {
                     const int nh = h.head_n[hd];
-                    const int act = (int)actions[d * H + hd];
+                    if (nh < 0) {  // Box(D) member
+                        const int Dh = -nh;
+                        for (int k = 0; k < Dh; ++k) {
+                            const float mu = z[off + k], e = expf(z[off + Dh + k]);
+                            const float sd = clampf(e, 1e-4f, 1e4f);
+                            const float dsd = (e >= 1e-4f && e <= 1e4f) ? e : 0.f;
+                            const float a = actions[d * NA + aoff + k];
+                            const float var = sd * sd;
+                            float gmu = dL_dlogp * ((a - mu) / var);
+                            float gsd = dL_dlogp * (((a - mu) * (a - mu)) / (var * sd) - 1.f / sd);
+                            if (h.expl_kind == 1) gsd += -h.expl_coeff * inv_n * (1.f / sd);
+                            if (h.kl_coeff != 0.f) {
+                                const float muo = zo[off + k], sdo = clampf(expf(zo[off + Dh + k]), 1e-4f, 1e4f);
+                                gmu += h.kl_coeff * inv_n * ((mu - muo) / (sdo * sdo));
+                                gsd += h.kl_coeff * inv_n * (sd / (sdo * sdo) - 1.f / sd);
+                            }
+                            gz[off + k] = gmu;
+                            gz[off + Dh + k] = gsd * dsd;
+                        }
+                        off += 2 * Dh; aoff += Dh;
+                        continue;
+                    }
+                    const int act = (int)actions[d * NA + aoff];
+                    aoff += 1;
                     const float u = 1.0f / (float)nh, lu = logf(u);
                     for (int k = 0; k < nh; ++k) {
                         const float lp = (z[off + k] - mx[hd]) - lse[hd], p = expf(lp);
@@ -833,8 +896,16 @@ extern "C" int sf_ppo_loss(const float *params, int ld_params, const float *valu
     if (h.action_kind == 0 && h.num_heads > 1) {
         int tot = 0;
         SF_REQUIRE(h.num_heads <= 8, "sf_ppo_loss: at most 8 action heads");
-        for (int i = 0; i < h.num_heads; ++i) { SF_REQUIRE(h.head_n[i] > 0, "sf_ppo_loss: empty action head"); tot += h.head_n[i]; }
+        bool any_box = false;  // head_n > 0: Discrete(n); head_n < 0: Box(-n) member with 2 * (-n) parameters
+        for (int i = 0; i < h.num_heads; ++i) {
+            SF_REQUIRE(h.head_n[i] != 0, "sf_ppo_loss: empty action head");
+            tot += h.head_n[i] > 0 ? h.head_n[i] : -2 * h.head_n[i];
+            any_box = any_box || h.head_n[i] < 0;
+        }
         SF_REQUIRE(tot == A, "sf_ppo_loss: head sizes sum to %d, A = %d", tot, A);
+        SF_REQUIRE(!(any_box && h.expl_kind == 2),
+                   "sf_ppo_loss: symmetric_kl exploration loss needs categorical heads only (the reference's "
+                   "ContinuousActionDistribution has no symmetric_kl_with_uniform_prior)");
         if (h.expl_kind == 2) {
             k_ppo_loss_md<<<grid, block, 0, STREAM(stream)>>>(params, ld_params, values, ld_values, actions, old_logp, old_params,
                                                               old_values, adv, targets, valids, index, offset, n, A, h, moments,
@@ -1583,10 +1654,29 @@ __global__ __launch_bounds__(256) void k_sample_write_tuple(const float *__restr
     const float *z = logits + (int64_t)b * ldl;
     const int64_t it = (int64_t)b * T + t;
     const int H = hd.num_heads;
+    const int NA = heads_action_cols(hd.head_n, H);
     float lp_sum = 0.f;
-    int off = 0;
+    int off = 0, aoff = 0;
     for (int h = 0; h < H; ++h) {
         const int nh = hd.head_n[h];
+        if (nh < 0) {  // Box(D) member: a = mu + sd * eps, eps from Box-Muller on Philox counter (step, k / 2, 3, h)
+            const int D = -nh;
+            for (int k = 0; k < D; ++k) {
+                uint32_t w[4];
+                sf_philox4x32_10(step, (uint32_t)(k >> 1), 3u, (uint32_t)h, seed, row0 + (uint32_t)b, w);
+                const uint32_t w1 = (k & 1) ? w[2] : w[0], w2 = (k & 1) ? w[3] : w[1];
+                const float u1 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                const float u2 = (float)(w2 >> 8) * (1.0f / 16777216.0f);
+                const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+                const float mu = z[off + k];
+                const float sd = clampf(expf(z[off + D + k]), 1e-4f, 1e4f);
+                const float a = deterministic ? mu : mu + sd * eps;
+                t_actions[it * NA + aoff + k] = a;
+                lp_sum += -((a - mu) * (a - mu)) / (2.f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;
+            }
+            off += 2 * D; aoff += D;
+            continue;
+        }
         float mx = -INFINITY;
         for (int k = 0; k < nh; ++k) mx = fmaxf(mx, z[off + k]);
         float se = 0.f;
@@ -1606,9 +1696,9 @@ __global__ __launch_bounds__(256) void k_sample_write_tuple(const float *__restr
             }
         }
         lp_sum += (z[off + a] - mx) - lse;
-        t_actions[it * H + h] = (float)a;
-        if (env_actions) env_actions[(int64_t)b * H + h] = a;
-        off += nh;
+        t_actions[it * NA + aoff] = (float)a;
+        if (env_actions) env_actions[(int64_t)b * H + h] = a;  // all-Discrete tuples only (the launcher checks)
+        off += nh; aoff += 1;
     }
     for (int k = 0; k < A; ++k) t_logits[it * A + k] = z[k];
     t_logp[it] = lp_sum;
@@ -1628,10 +1718,13 @@ extern "C" int sf_sample_write_step_tuple(const float *logits, int ld_logits, co
     LossDev hd = {};
     hd.num_heads = num_heads;
     int A = 0;
-    for (int i = 0; i < num_heads; ++i) {
-        SF_REQUIRE(head_n[i] > 0, "sf_sample_write_step_tuple: empty action head");
+    for (int i = 0; i < num_heads; ++i) {  // head_n > 0: Discrete(n); head_n < 0: Box(-n) member, 2 * (-n) parameters
+        SF_REQUIRE(head_n[i] != 0, "sf_sample_write_step_tuple: empty action head");
+        SF_REQUIRE(head_n[i] > 0 || !env_actions,
+                   "sf_sample_write_step_tuple: a tuple with a Box member has no int32 env_actions (the env reads the "
+                   "trajectory's f32 action row)");
         hd.head_n[i] = head_n[i];
-        A += head_n[i];
+        A += head_n[i] > 0 ? head_n[i] : -2 * head_n[i];
     }
     SF_REQUIRE(ld_logits >= A && ld_values >= 1, "sf_sample_write_step_tuple: bad strides");
     k_sample_write_tuple<<<dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM(stream)>>>(

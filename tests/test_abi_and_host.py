@@ -490,3 +490,17 @@ def test_row_ledger_conserves_rows_under_random_traffic():
             assert all(set(range(a, b)) <= held for a, b, _ in runs)
 
     run()
+
+
+def test_bench_numa_plan_splits_a_node_between_the_ranks_on_it():
+    """bench.py pins every rank (and the env worker processes it starts) to its GPU's NUMA node; ranks whose GPUs share a
+    node split its cores in local-rank order; an unknown node leaves the rank unpinned"""
+    import bench
+    node_cpus = {0: list(range(0, 32)) + list(range(64, 96)), 1: list(range(32, 64)) + list(range(96, 128))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    shares = [bench.numa_plan(r, nodes, range(128), node_cpus) for r in range(8)]
+    assert all(len(s) == 16 for s in shares)
+    assert sorted(sum(shares[:4], [])) == sorted(node_cpus[0]) and sorted(sum(shares[4:], [])) == sorted(node_cpus[1])
+    assert bench.numa_plan(0, [0, 1], [0, 1, 2, 3, 40], node_cpus) == [0, 1, 2, 3]      # the process's own mask is respected
+    assert bench.numa_plan(1, [0, None], range(128), node_cpus) is None and bench.numa_plan(0, [-1], range(8), {}) is None
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

@@ -291,3 +291,132 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     assert len(c["exposed_ms_per_step"]) == 2 and all(x > 0 for x in c["exposed_ms_per_step"])
     assert all(x >= 10 for x in c["collectives_per_step"])      # 4 minibatches x (moments + gradient buckets) + per-dataset
     assert c["allreduce_ms_per_step"] == [None, None]           # only the native path has an exchange stream to bracket
+
+
+# ------------------------------------------------------------------------------------------ overlap ORDER of the buckets
+_ORDER_CODE = r'''
+import json, os, sys, torch
+sys.path.insert(0, %r)
+from sample_factory_amd import lib
+from sample_factory_amd.cfg.arguments import default_cfg
+from sample_factory_amd.envs.env_utils import register_env
+from sample_factory_amd.envs.synthetic import make_synthetic_env
+from sample_factory_amd.train import make_runner
+native = os.environ["FORCE"] == "2"
+torch.cuda.set_device(0)
+torch.distributed.init_process_group("nccl")
+register_env("synthetic_atari", make_synthetic_env)
+cfg = default_cfg(env="synthetic_atari", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                  encoder_conv_architecture="convnet_atari", rollout=8, batch_size=2048, num_batches_per_epoch=1,
+                  num_epochs=1, num_workers=1, num_envs_per_worker=1, worker_num_splits=1, async_rl=False, seed=1,
+                  serial_mode=True, synthetic_num_agents=256, train_dir=%r, experiment="order" + os.environ["FORCE"],
+                  data_parallel=True, dp_force_collectives=True, dp_native_rccl=native)
+cfg, runner = make_runner(cfg)
+runner.init()
+lr, grp = runner.learner, runner.learner.group
+assert lr.dp and lr._dp_split is not None and grp.native == native
+runner.iteration()                       # warm-up (allocations, lazy code objects)
+torch.cuda.synchronize()
+# ONE SGD step with every network launch bracketed by HIP events (lib.PROFILE) and the bucket calls marked (grp.trace):
+# all on the learner's compute stream, so elapsed_time(a, b) >= 0 <=> b was enqueued behind a
+lib.PROFILE, grp.trace = {}, []
+grp.enable_timing()
+runner.iteration()
+torch.cuda.synchronize()
+prof, lib.PROFILE = lib.PROFILE, None
+tr = grp.trace
+tags = [t for t, _ in tr]
+def ev(tag):
+    hits = [e for t, e in tr if t == tag]
+    assert len(hits) == 1, (tag, tags)
+    return hits[0]
+def launches(op, cin):
+    out = []
+    for key, evs in prof.items():
+        if key[0] == op and key[2] == cin and key[1] == 2048:
+            out += evs
+    assert out, (op, cin, list(prof))
+    return out
+after = lambda a, b: a.elapsed_time(b)   # ms from a to b on the device time line
+enq, wait, sync = ev("grad_async_enqueue"), ev("grad_async_wait"), ev("grad_sync")
+fc_w = launches("wgrad", 3136)[-1]        # fc weight gradient: the last launch the tail bucket (fc + heads) depends on
+c3_d = launches("dgrad", 64)[0]           # conv3 data gradient = first conv-backward launch
+c1_w = launches("wgrad", 4)[-1]           # conv1 weight gradient = last launch of the backward pass
+res = dict(
+    tags=tags,
+    fc_wgrad_end_to_enqueue=after(fc_w[1], enq), enqueue_to_conv3_dgrad_start=after(enq, c3_d[0]),
+    conv1_wgrad_end_to_head_bucket=after(c1_w[1], sync), head_bucket_to_tail_wait=after(sync, wait),
+    enqueue_to_wait=after(enq, wait), conv_backward_ms=after(c3_d[0], c1_w[1]),
+    exposed_ms=grp.timing_summary()[0], exchange_ms=grp.timing_summary()[1])
+print("RESULT " + json.dumps(res))
+if native:
+    grp.close()
+torch.distributed.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("force", ["1", "2"])
+def test_tail_bucket_is_enqueued_before_the_conv_backward_and_waited_for_after_it(tmp_path, force):
+    """DESIGN.md §6 prices the data-parallel step on the fc + heads bucket (95 % of the gradient bytes) being exchanged WHILE
+    conv3 / conv2 / conv1 back-propagate.  That is a statement about enqueue order, checked here with HIP events on the
+    learner's stream for both exchange paths (1: torch.distributed / RCCL, 2: sf_allreduce_grads on the exchange stream), one
+    rank with forced collectives: the tail bucket's all-reduce is handed over right behind the fc layer's weight gradient
+    and BEFORE the first conv-backward launch (conv3's data gradient); the compute stream first blocks on a bucket only
+    behind conv1's weight gradient (the head bucket's exchange, then the tail bucket's wait)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("SF_DP_BACKEND",)}
+    env.update(FORCE=force, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", _ORDER_CODE % (ROOT, str(tmp_path))], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2500:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    # program order of the bucket calls of one SGD step
+    assert res["tags"] == ["grad_async_enqueue", "grad_sync", "grad_async_wait"], res["tags"]
+    assert res["fc_wgrad_end_to_enqueue"] >= 0.0           # the bucket is complete when it is handed over ...
+    assert res["enqueue_to_conv3_dgrad_start"] >= 0.0      # ... and handed over before any conv-backward launch
+    assert res["conv1_wgrad_end_to_head_bucket"] >= 0.0    # nothing blocks the compute stream before conv1's weight gradient
+    assert res["head_bucket_to_tail_wait"] >= 0.0
+    # the whole conv backward lies between the hand-over and the wait
+    assert res["enqueue_to_wait"] >= res["conv_backward_ms"] > 0.0, res
+    print("bucket order:", json.dumps(res))
+
+
+# ------------------------------------------------------------------------------------------ per-epoch moment exchange
+def _worker_mom(rank, world, port, out_dir, epoch_moments):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", SF_DP_BACKEND="gloo")
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_atari", make_synthetic_env)
+    cfg = _cfg(32, dp_epoch_moments=bool(epoch_moments))
+    cfg.batch_size, cfg.num_batches_per_epoch, cfg.num_epochs, cfg.shuffle_minibatches = 64, 4, 2, True
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    grp = runner.learner.group
+    runner.iteration()
+    grp.enable_timing()
+    runner.iteration()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"mom{int(epoch_moments)}_rank{rank}.npz"),
+             params=runner.learner.actor_critic.flat_params.cpu().numpy(), collectives=grp.timing["count"])
+    torch.distributed.destroy_process_group()
+
+
+def test_epoch_moment_exchange_equals_the_per_step_one(tmp_path):
+    """cfg.dp_epoch_moments (default): the advantage moments of every minibatch of an epoch travel in ONE all-reduce before
+    the epoch's first forward pass instead of one 24-byte all-reduce in front of every loss.  Two replicas sharing the GPU,
+    4 shuffled minibatches x 2 epochs: the weights are bit-identical to the per-step exchange's, and the iteration issues
+    3 collectives fewer per epoch."""
+    out = {}
+    for em in (1, 0):
+        mp.spawn(_worker_mom, args=(2, _free_port(), str(tmp_path), em), nprocs=2, join=True)
+        out[em] = [np.load(tmp_path / f"mom{em}_rank{r}.npz") for r in range(2)]
+    for k in ("WORLD_SIZE", "RANK"):
+        os.environ.pop(k, None)
+    np.testing.assert_array_equal(out[1][0]["params"], out[1][1]["params"])   # replicas in lock-step
+    np.testing.assert_array_equal(out[1][0]["params"], out[0][0]["params"])   # same numbers either way
+    assert int(out[0][0]["collectives"]) - int(out[1][0]["collectives"]) == 2 * (4 - 1), \
+        (int(out[0][0]["collectives"]), int(out[1][0]["collectives"]))
