@@ -113,7 +113,7 @@ int sf_rows_add_scale(const float *a, const float *b, const float *keep, int64_t
 int sf_vtrace(const float *params, int ld_params, const float *values, int ld_values, const float *actions,
               const float *old_logp, const float *rewards, const uint8_t *dones, const int32_t *index, int64_t offset,
               int64_t n, int A, int action_kind, int recurrence, float gamma, float rho_hat, float c_hat, float *vs,
-              float *adv, const int32_t *head_n /* host; Tuple of Discrete heads, or NULL */, int num_heads,
+              float *adv, const int32_t *head_n /* host; Tuple members as in sf_loss_cfg.head_n, or NULL */, int num_heads,
               void *stream);
 
 /* ---- K16: PPO loss head, forward + backward ----------------------------------------------------------------
@@ -137,9 +137,12 @@ typedef struct {
     int32_t exploration_kind;
     int32_t action_kind;
     int32_t dense_adv;
-    /* Tuple of Discrete spaces (action_distributions.py:197-287: independent heads; log-prob, entropy, KL and
-     * symmetric-KL are sums over the heads): num_heads > 1 and head_n[h] = size of head h, sum = A; `actions` then
-     * holds num_heads floats per sample.  num_heads <= 1: one Discrete(A). */
+    /* Tuple spaces (action_distributions.py:197-287: independent members built by get_action_distribution, :222-225;
+     * log-prob, entropy, KL and symmetric-KL are sums over the members): num_heads > 1 and, per member h,
+     * head_n[h] = n > 0 for Discrete(n) (n logits, one action column) or head_n[h] = -D < 0 for Box(D) (2 D parameters
+     * [means | log_std], D action columns; symmetric-KL exploration is refused for it, as the reference's
+     * ContinuousActionDistribution has no symmetric_kl_with_uniform_prior).  Parameters sum to A; `actions` holds the
+     * members' columns side by side per sample.  num_heads <= 1: one Discrete(A). */
     int32_t num_heads;
     int32_t head_n[8];
     /* > 0: `old_values` is the trajectory slab's values array [E, old_values_T + 1] read IN PLACE — dataset row
@@ -246,10 +249,12 @@ int sf_sample_write_step_masked(const float *logits, int ld_logits, const float 
                                 float *traj_actions, float *traj_logits, float *traj_logp, float *traj_values,
                                 float *traj_policy_version, int32_t *env_actions, void *stream);
 
-/* Tuple-of-Discrete variant of sf_sample_write_step (TupleActionDistribution.sample_actions_log_probs,
- * action_distributions.py:241-245): head h (size head_n[h], host array of num_heads <= 8 entries) is sampled by inverse
- * CDF from its own Philox uniform (counter (step, h, 2, 0)); traj_actions gets num_heads floats per step, traj_logp the
- * SUM of the heads' log-probs, env_actions [B, num_heads] int32. */
+/* Tuple variant of sf_sample_write_step (TupleActionDistribution.sample_actions_log_probs,
+ * action_distributions.py:241-245): member h (head_n[h] as in sf_loss_cfg, host array of num_heads <= 8 entries) is
+ * sampled by inverse CDF from its own Philox uniform (counter (step, h, 2, 0)) if Discrete, as mu + sd * eps with
+ * Box-Muller normals from counter (step, dim / 2, 3, h) if Box(D) (deterministic: arg-max / the mean); traj_actions
+ * gets the members' columns side by side, traj_logp the SUM of the members' log-probs.  env_actions [B, num_heads]
+ * int32 for an all-Discrete tuple; NULL (required) when a member is a Box — the env then reads traj_actions[:, t]. */
 int sf_sample_write_step_tuple(const float *logits, int ld_logits, const float *values, int ld_values, int B,
                                int num_heads, const int32_t *head_n, int T, int t, uint32_t seed, uint32_t step,
                                uint32_t row0, float policy_version, int deterministic, float *traj_actions,

@@ -240,7 +240,7 @@ def capture_heads(learner):
     return cap, (h1, h2)
 
 
-def gen_prepare_and_losses():
+def gen_prepare_and_losses(only=None):
     variants = [
         dict(name="ff_default", args=[], E=16, T=8, A=6, fill={}),
         dict(name="ff_invalids", args=["--max_policy_lag=5", "--kl_loss_coeff=0.2"], E=16, T=8, A=6,
@@ -256,13 +256,20 @@ def gen_prepare_and_losses():
              heads=(3, 5, 2), fill={}),
         dict(name="ff_tuple_symkl", args=["--exploration_loss=symmetric_kl", "--exploration_loss_coeff=0.02"], E=10,
              T=8, A=9, heads=(6, 3), fill=dict(p_other_policy=0.1)),
+        # Tuple(Discrete(3), Box(2), Discrete(4)): TupleActionDistribution builds every member with get_action_distribution
+        # (action_distributions.py:222-225); a negative entry -D of `heads` is a Box(D) member (2 D parameters, D action columns)
+        dict(name="ff_tuple_mixed", args=["--kl_loss_coeff=0.1", "--exploration_loss_coeff=0.01"], E=12, T=8, A=11,
+             heads=(3, -2, 4), fill=dict(p_other_policy=0.1)),
     ]
     for vi, var in enumerate(variants):
+        if only and var["name"] not in only:
+            continue
         E, T = var["E"], var["T"]
         continuous = var.get("A") is None
         action_space = gym.spaces.Box(-1, 1, (var["D"],), np.float32) if continuous else gym.spaces.Discrete(var["A"])
         if "heads" in var:
-            action_space = gym.spaces.Tuple([gym.spaces.Discrete(n) for n in var["heads"]])
+            action_space = gym.spaces.Tuple([gym.spaces.Discrete(n) if n > 0 else gym.spaces.Box(-1, 1, (-n,), np.float32)
+                                             for n in var["heads"]])
         nb = 2
         cfg = make_cfg(MLP_ARGS + [f"--rollout={T}", f"--batch_size={E * T // nb}", f"--num_batches_per_epoch={nb}",
                                    "--num_epochs=1"] + var["args"])
@@ -277,8 +284,9 @@ def gen_prepare_and_losses():
         g = torch.Generator().manual_seed(1000 + vi)
         b = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cpu", False)
         fill_batch(b, g, var.get("A"), continuous=continuous, **var["fill"])
-        if "heads" in var:  # one action per head, each within its own head's range
-            b["actions"].copy_(torch.cat([torch.randint(0, n, (E, T, 1), generator=g) for n in var["heads"]], dim=2).float())
+        if "heads" in var:  # one action per Discrete head, within its own range; D normal columns per Box(D) member
+            b["actions"].copy_(torch.cat([torch.randint(0, n, (E, T, 1), generator=g).float() if n > 0 else
+                                          torch.randn((E, T, -n), generator=g) for n in var["heads"]], dim=2))
         arrays = {"ref": "sample_factory/algo/learning/learner.py:943-1034 Learner._prepare_batch; "
                          ":537-669 Learner._calculate_losses", "argv": " ".join(var["args"]),
                   "param_seed": 7, "train_step": learner.train_step}
@@ -1017,6 +1025,9 @@ def main():
         gen_action_dist()
     if "learner" in which:
         gen_prepare_and_losses()
+    for w in which:  # learner:<case>[,<case>] = only those cases of the learner fixtures
+        if w.startswith("learner:"):
+            gen_prepare_and_losses(only=w.split(":", 1)[1].split(","))
     if "mb" in which:
         gen_minibatch_indices()
     if "ckpt" in which:

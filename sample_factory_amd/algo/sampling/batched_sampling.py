@@ -20,7 +20,7 @@ import torch
 
 from sample_factory_amd import lib
 from sample_factory_amd.algo.utils.tensor_dict import TensorDict
-from sample_factory_amd.envs.spaces import action_head_sizes, is_box
+from sample_factory_amd.envs.spaces import action_head_sizes, heads_mixed, is_box, split_tuple_actions
 
 
 class BatchedVectorEnvRunner:
@@ -36,7 +36,8 @@ class BatchedVectorEnvRunner:
         dev = actor_critic.device
         self.device = dev
         assert traj["rewards"].shape == (self.B, self.T), "one slab row per agent (sync mode: one rollout per dataset)"
-        self.heads = action_head_sizes(env_info.action_space)  # [n] | [n1, n2, ...] (Tuple of Discrete) | [] (Box)
+        self.heads = action_head_sizes(env_info.action_space)  # [n] | [n1, -D2, ...] (Tuple; -D = a Box(D) member) | [] (Box)
+        self.mixed = heads_mixed(self.heads)  # Tuple with a Box member: the env reads the slab's f32 action row, split per member
         self.env_actions = torch.zeros((self.B, len(self.heads)) if len(self.heads) > 1 else self.B, dtype=torch.int32,
                                        device=dev)
         self.ep_return = torch.zeros(self.B, dtype=torch.float32, device=dev)
@@ -188,17 +189,18 @@ class BatchedVectorEnvRunner:
                                          self.sample_seed, self.global_step, self.row0, ver, deterministic,
                                          tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
                                          tr["policy_version"], self.env_actions)
-        elif len(self.heads) > 1:  # Tuple of Discrete spaces: one categorical per head, actions [B, H]
+        elif len(self.heads) > 1:  # Tuple space: one categorical per Discrete member, a diagonal normal per Box member
             lib.sample_write_step_tuple(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, self.heads, T, t,
                                         self.sample_seed, self.global_step, self.row0, ver, deterministic,
                                         tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
-                                        tr["policy_version"], self.env_actions)
+                                        tr["policy_version"], None if self.mixed else self.env_actions)
         else:
             lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
                                   self.global_step, self.row0, ver, deterministic, tr["actions"],
                                   tr["action_logits"], tr["log_prob_actions"], tr["values"], tr["policy_version"],
                                   None if self.continuous else self.env_actions, action_kind=int(self.continuous))
-        env_actions = tr["actions"][:, t] if self.continuous else self.env_actions  # Box: f32 [B, D] view
+        # Box: f32 [B, D] view of the slab; Tuple with a Box member: f32 [B, columns] view, split per member for the env
+        env_actions = tr["actions"][:, t] if (self.continuous or self.mixed) else self.env_actions
         if self.async_env:  # worker processes step the envs from here on (parallel_env.py); rollout_step_finish collects
             self.env.step_async(self._actions_to_host(env_actions))
             return
@@ -214,6 +216,8 @@ class BatchedVectorEnvRunner:
     def _env_step_and_record(self, t: int, env_actions) -> None:
         tr, T, cfg = self.traj, self.T, self.cfg
         if self.zero_copy:
+            if self.mixed:  # batched_sampling.py:51-59: a list with one (device) array per Tuple member
+                env_actions = split_tuple_actions(env_actions, self.heads)
             rew, term, trunc = self.env.step_into(env_actions, self.obs[:, t + 1])
         else:
             if self.host_env is None:  # decided by what reset() returned
@@ -223,6 +227,8 @@ class BatchedVectorEnvRunner:
                 o, rew, term, trunc, _ = self.env.step_wait()
             else:
                 acts_in = self._actions_to_host(env_actions) if self.host_env else env_actions
+                if self.mixed:  # batched_sampling.py:51-59: a list with one array per Tuple member
+                    acts_in = split_tuple_actions(acts_in, self.heads)
                 o, rew, term, trunc, _ = self.env.step(acts_in)
             if self.ingest_prof is not None:
                 self.ingest_prof["env_step_s"] = self.ingest_prof.get("env_step_s", 0.0) + time.perf_counter() - t0

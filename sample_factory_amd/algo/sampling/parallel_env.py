@@ -30,7 +30,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 import numpy as np
 
 from sample_factory_amd.envs.env_utils import RewardShapingInterface
-from sample_factory_amd.envs.spaces import action_head_sizes, is_box
+from sample_factory_amd.envs.spaces import action_head_sizes, heads_action_cols, heads_mixed, is_box, split_tuple_actions
 from sample_factory_amd.utils.attr_dict import AttrDict
 
 CMD_RESET, CMD_STEP, CMD_CLOSE, CMD_TRAINING_INFO, CMD_REWARD_SHAPING = 0, 1, 2, 3, 4
@@ -93,6 +93,8 @@ def _format_actions(act_rows: np.ndarray, heads: List[int], continuous: bool, ba
     if continuous:
         a = act_rows.astype(np.float32, copy=False)
         return a if batched else a[0]
+    if heads_mixed(heads):  # Tuple with a Box member: one array per member (batched_sampling.py:51-59)
+        return split_tuple_actions(act_rows, heads, batched)
     if len(heads) > 1:
         a = act_rows.reshape(act_rows.shape[0], len(heads))
         return a if batched else a[0]
@@ -328,6 +330,8 @@ class ParallelHostEnvs:
             add("trunc", (n,), np.bool_)
             if self.continuous:
                 add("act", (n, int(self.action_space.shape[0])), np.float32)
+            elif heads_mixed(self.heads):  # Tuple with a Box member: the slab's f32 action rows
+                add("act", (n, heads_action_cols(self.heads)), np.float32)
             else:
                 add("act", (n, len(self.heads)) if len(self.heads) > 1 else (n,), np.int32)
             self.arrays.append(arr)

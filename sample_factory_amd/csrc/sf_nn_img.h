@@ -21,13 +21,27 @@
 // R = output rows per UNIT: a unit is a horizontal strip of one sample (R = OH: the whole image).  Units are numbered
 // sample-major, so output row m = unit * (R*OW) + pixel-in-strip — the same flat row space as without strips; a strip
 // needs HU = (R-1)*S + KS input rows (consecutive strips overlap by KS - S rows, loaded twice).
+// SF_IMG_FLIP (round 6): the image rows are stored BOTTOM-UP in LDS and every channel-chunk plane is padded to a multiple of
+// 16 chunks.  ds_read_b128 is served in groups of 16 lanes, one LDS cycle per group when their 16-byte chunks fall into 16
+// different residues mod 16 (64 banks x 4 B); a group holds every fragment row exactly once, half of them from plane kg and
+// half from plane kg + 1.  Top-down rows at pitch WQ = 9 put output pixel j = oh*7 + ow at chunk 9*oh + ow = j + 2*(j/7): the
+// +2 at every row wrap makes rows of one fragment collide (and PLANE = 81 shifts the odd plane by one more) — 2-3 LDS cycles
+// per group, SQ_LDS_BANK_CONFLICT 6 x the active cycles (profiles/r04_f_stall_counters.txt).  Bottom-up, the same pixel sits
+// at 9*(6 - oh) + ow = 54 - 9*oh + ow, and because 9 = -7 (mod 16) that is 54 + 7*oh + ow = 54 + j (mod 16): LINEAR in the
+// output pixel index, so any 16 consecutive pixels of a sample hit 16 different residues; with PLANE = 0 (mod 16) both planes
+// of a group see the same residues.  Only fragments that straddle two samples keep one 2-way pair.  The filter tap stays an
+// immediate ((KS-1-kh)*WQ + kw), products and summation order are unchanged: bit-identical results.
+#ifndef SF_IMG_FLIP
+#define SF_IMG_FLIP 1
+#endif
 template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS, int R>
 struct ImgFwdGeom {
     static constexpr int OH = (H - KS) / ST + 1, OW = (W - KS) / ST + 1, OHW = R * OW;  // rows per unit
     static constexpr int U = OH / R, HU = (R - 1) * ST + KS;  // units per sample, input rows per unit
     static constexpr int K = KS * KS * CIN, KG = K / 16;  // 16-deep reduction groups (one f32x4 of weights per lane)
     static constexpr int C4 = CIN / 4, WQ = W / ST;       // 16-byte chunks per pixel, columns per w-parity class
-    static constexpr int PLANE = ST * HU * WQ;            // chunks per channel chunk
+    static constexpr int PLANE_USED = ST * HU * WQ;       // image chunks per channel chunk
+    static constexpr int PLANE = SF_IMG_FLIP ? (PLANE_USED + 15) / 16 * 16 : PLANE_USED;  // plane pitch in chunks
     static constexpr int IMG_CH = C4 * PLANE;             // chunks per image
     static constexpr int IMG_B = (IMG_CH * 16 + 1023) / 1024 * 1024;  // slot size: whole 1-KiB DMA instructions
     // samples touched by two consecutive row blocks (the one being multiplied + the one being fetched)
@@ -70,8 +84,12 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
     for (int j = 0; j < NI; ++j) {
         int q = (wave + NW * j) * 64 + lane;  // chunk index inside the slot: (c, pw, ih, iwq)
         q = q < G::IMG_CH ? q : 0;           // slot padding: any valid address
-        const int c = q / PLANE, r0 = q - c * PLANE, pw = r0 / (HU * WQ), r1 = r0 - pw * (HU * WQ);
-        const int ih = r1 / WQ, iwq = r1 - ih * WQ;
+        const int c = q / PLANE;
+        int r0 = q - c * PLANE;
+        r0 = r0 < G::PLANE_USED ? r0 : 0;    // plane padding (SF_IMG_FLIP): any valid address
+        const int pw = r0 / (HU * WQ), r1 = r0 - pw * (HU * WQ);
+        const int ihl = r1 / WQ, iwq = r1 - ihl * WQ;
+        const int ih = SF_IMG_FLIP ? HU - 1 - ihl : ihl;  // LDS row ihl holds image row ih
         srcoff[j] = (ih * W + iwq * ST + pw) * CIN + c * 4;
     }
     auto load_image = [&](int s) {  // s: unit index
@@ -124,7 +142,10 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
             uint32_t m = (uint32_t)(nf > 0 ? fb + (f < nf ? f : 0) : fb0) * 16u + (uint32_t)col;
             m = m < M32 ? m : M32 - 1u;
             const uint32_t s = m / (uint32_t)OHW, p = m - s * (uint32_t)OHW, oh = p / (uint32_t)OW, ow = p - oh * (uint32_t)OW;
-            base[f] = (int)((s % (uint32_t)RING) * (uint32_t)IMG_B + ((uint32_t)kg * PLANE + (oh * ST) * WQ + ow) * 16u);
+            // row of the patch origin in LDS: top-down oh*ST, or bottom-up (R-1-oh)*ST with the tap's (KS-1-kh) added by the
+            // immediate: (R-1-oh)*ST + (KS-1-kh) = HU-1 - (oh*ST + kh)
+            const uint32_t prow = SF_IMG_FLIP ? ((uint32_t)(R - 1) - oh) * ST : oh * ST;
+            base[f] = (int)((s % (uint32_t)RING) * (uint32_t)IMG_B + ((uint32_t)kg * PLANE + prow * WQ + ow) * 16u);
         }
         f32x4 acc[TMF];
 #pragma unroll
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
         f32x4 a[2][2][TMF];
         auto fetch = [&](int g, int slot) {  // g is a compile-time constant after unrolling: the offset is an immediate
             const int tap = (16 * g) / CIN, cb = ((16 * g) % CIN) / 4, kh = tap / KS, kw = tap % KS;
-            const int imm = (cb * PLANE + ((kw % ST) * HU + kh) * WQ + kw / ST) * 16;
+            const int imm = (cb * PLANE + ((kw % ST) * HU + (SF_IMG_FLIP ? KS - 1 - kh : kh)) * WQ + kw / ST) * 16;
 #pragma unroll
             for (int f = 0; f < TMF; ++f)
                 a[slot][g & 1][f] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(ring + base[f] + imm, 16));

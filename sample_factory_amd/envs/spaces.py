@@ -74,17 +74,59 @@ def is_tuple(space) -> bool:
 
 
 def action_head_sizes(action_space):
-    """sizes of the categorical heads: [n] for Discrete(n), [n1, n2, ...] for a Tuple of Discrete spaces (the only
-    Tuple the native loss / sampler kernels take; a Tuple containing a Box is rejected)"""
+    """members of the action distribution as the native loss / sampler kernels take them: [n] for Discrete(n); one entry
+    per member of a Tuple — n for Discrete(n), -D for Box(D) (2 D parameters [means | log_std], D action columns;
+    action_distributions.py:197-287 composes any members) — at most 8; [] for a bare Box"""
     if is_discrete(action_space):
         return [int(action_space.n)]
     if is_tuple(action_space):
-        if not all(is_discrete(sp) for sp in action_space.spaces):
-            raise NotImplementedError("Tuple action spaces are supported for Discrete members only")
         if len(action_space.spaces) > 8:
             raise NotImplementedError("at most 8 action heads")
-        return [int(sp.n) for sp in action_space.spaces]
+        out = []
+        for sp in action_space.spaces:
+            if is_discrete(sp):
+                out.append(int(sp.n))
+            elif is_box(sp):
+                if len(sp.shape) != 1:
+                    raise Exception("Non-trivial shape Box action spaces not currently supported. Try to flatten the space.")
+                out.append(-int(sp.shape[0]))
+            else:
+                raise NotImplementedError(f"Tuple member {sp!r}: only Discrete and Box members are supported")
+        return out
     return []
+
+
+def heads_action_cols(heads) -> int:
+    """action columns of a head list: one per Discrete member, D per Box(D) member (entry -D)"""
+    return sum(1 if h > 0 else -h for h in heads)
+
+
+def heads_mixed(heads) -> bool:
+    """a Tuple with at least one Box member: its actions travel as f32 rows and are split per member for the env"""
+    return any(h < 0 for h in heads)
+
+
+def split_tuple_actions(rows, heads, batched: bool = True):
+    """what `preprocess_actions` hands the env for a Tuple with a Box member (batched_sampling.py:51-59): one array per
+    member — int32 with the action axis squeezed for a Discrete member, f32 [agents, D] for a Box(D) member.  `rows`:
+    [agents, heads_action_cols] f32 (numpy or torch)."""
+    out, c = [], 0
+    is_torch = hasattr(rows, "dim")
+    for h in heads:
+        if h > 0:
+            col = rows[:, c]
+            if is_torch:
+                import torch
+                col = col.to(torch.int32)
+            else:
+                col = col.astype(np.int32)
+            out.append(col if batched else int(col[0]))
+            c += 1
+        else:
+            blk = rows[:, c:c - h]
+            out.append(blk if batched else blk[0])
+            c -= h
+    return out
 
 
 def is_box(space) -> bool:

@@ -153,19 +153,28 @@ def make_host_frame_env(full_env_name, cfg=None, env_config=None, render_mode=No
 
 class SyntheticTupleEnv(SyntheticVecEnv):
     """Multi-head variant (Tuple(Discrete(n0), Discrete(n1), ...), the VizDoom-style action space of
-    action_distributions.py:197-287): same frames; the reward rule looks at head 0, the other heads are free."""
+    action_distributions.py:197-287): same frames; the reward rule looks at head 0, the other heads are free.
+    A negative entry -D of `head_sizes` is a Box(-1, 1, (D,)) member (a mixed Tuple: the env then receives the list of
+    per-member arrays `preprocess_actions` builds, batched_sampling.py:51-59)."""
 
     def __init__(self, head_sizes=(6, 3), **kw):
+        assert int(head_sizes[0]) > 0, "member 0 carries the reward rule: Discrete"
         super().__init__(num_actions=int(head_sizes[0]), **kw)
-        self.action_space = spaces.Tuple([spaces.Discrete(int(n)) for n in head_sizes])
+        self.action_space = spaces.Tuple([spaces.Discrete(int(n)) if int(n) > 0 else
+                                          spaces.Box(-1.0, 1.0, (-int(n),), np.float32) for n in head_sizes])
+        self.last_actions = None  # what the sampler handed over at the last step (tests look at the format)
 
-    def step_into(self, actions: torch.Tensor, obs_out: torch.Tensor):
-        a = actions.reshape(self.num_agents, -1)[:, 0].contiguous()
-        return super().step_into(a, obs_out)
+    def _head0(self, actions):
+        self.last_actions = actions
+        if isinstance(actions, (list, tuple)):  # mixed Tuple: one array per member
+            return torch.as_tensor(actions[0], device=self.device).to(torch.int32).reshape(self.num_agents).contiguous()
+        return torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(self.num_agents, -1)[:, 0].contiguous()
+
+    def step_into(self, actions, obs_out: torch.Tensor):
+        return super().step_into(self._head0(actions), obs_out)
 
     def step(self, actions):
-        a = torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(self.num_agents, -1)[:, 0]
-        return super().step(a)
+        return super().step(self._head0(actions))
 
 
 class MaskedBanditEnv:

@@ -856,7 +856,7 @@ def _kv(argv):
 
 
 @pytest.mark.parametrize("case", ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous", "ff_vtrace",
-                                  "ff_tuple", "ff_tuple_symkl"])
+                                  "ff_tuple", "ff_tuple_symkl", "ff_tuple_mixed"])
 def test_learner_prepare_batch_and_losses_match_reference(lib, golden, tmp_path, case):
     """The native Learner's _prepare_batch + _calculate_losses (network forward included) replayed on the reference's
     golden batches: discrete / invalid+stale samples + KL loss / value bootstrap + symmetric-KL / Box actions / V-trace."""
@@ -872,7 +872,8 @@ def test_learner_prepare_batch_and_losses_match_reference(lib, golden, tmp_path,
     A = g["in_action_logits"].shape[-1]
     action_space = spaces.Box(-1, 1, (A // 2,), np.float32) if continuous else spaces.Discrete(A)
     if "head_sizes" in g:
-        action_space = spaces.Tuple([spaces.Discrete(int(nh)) for nh in g["head_sizes"]])
+        action_space = spaces.Tuple([spaces.Discrete(int(nh)) if int(nh) > 0 else spaces.Box(-1, 1, (-int(nh),), np.float32)
+                                     for nh in g["head_sizes"]])  # -D: a Box(D) member (mixed Tuple)
     over = dict(exploration_loss=kv.get("exploration_loss", "entropy"),
                 exploration_loss_coeff=float(kv.get("exploration_loss_coeff", 0.003)),
                 kl_loss_coeff=float(kv.get("kl_loss_coeff", 0.0)), max_policy_lag=int(kv.get("max_policy_lag", 1000)),
@@ -986,6 +987,50 @@ def test_tuple_action_space_end_to_end(lib):
     lp = (torch.log_softmax(lg[..., :6], -1).gather(-1, a[..., :1].long()) +
           torch.log_softmax(lg[..., 6:], -1).gather(-1, a[..., 1:].long())).squeeze(-1)
     assert (lp - runner.traj["log_prob_actions"]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("vtrace", [False, True])
+def test_mixed_tuple_action_space_end_to_end(lib, vtrace):
+    """Tuple(Discrete(6), Box(2), Discrete(3)) — a Tuple with a Box member, which the reference's TupleActionDistribution
+    composes like any other (action_distributions.py:197-287): sampled by sf_sample_write_step_tuple (categorical heads +
+    a diagonal normal), trained through sf_ppo_loss (and sf_vtrace); the env receives the reference's per-member list
+    (batched_sampling.py:51-59: int32 [agents] for a Discrete member, f32 [agents, D] for the Box member)"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_tuple_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_tuple", make_synthetic_tuple_env)
+    cfg = default_cfg(env="synthetic_tuple", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
+                      encoder_conv_architecture="convnet_atari", rollout=8, recurrence=8 if vtrace else 1, batch_size=256,
+                      num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=False, seed=2,
+                      serial_mode=True, synthetic_num_agents=64, kl_loss_coeff=0.05, synthetic_head_sizes=(6, -2, 3),
+                      with_vtrace=vtrace, normalize_returns=not vtrace, shuffle_minibatches=not vtrace)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    ac = runner.learner.actor_critic
+    assert ac.num_action_params == 6 + 4 + 3 and runner.traj["actions"].shape == (64, 8, 4)
+    p0 = ac.flat_params.clone()
+    for _ in range(3):
+        stats = runner.iteration()
+    torch.cuda.synchronize()
+    a = runner.traj["actions"]
+    assert ((a[..., 0] >= 0) & (a[..., 0] < 6) & (a[..., 0] == a[..., 0].round())).all()
+    assert ((a[..., 3] >= 0) & (a[..., 3] < 3) & (a[..., 3] == a[..., 3].round())).all()
+    assert a[..., 1:3].std() > 0.1 and torch.isfinite(a).all()                     # the Box member's two dims: real-valued
+    assert np.isfinite(stats["train"]["loss"]) and torch.isfinite(ac.flat_params).all() and not torch.equal(p0, ac.flat_params)
+    # recorded log-prob = categorical(6) + Normal over 2 dims + categorical(3) at the recorded actions
+    lg = runner.traj["action_logits"]
+    mu, sd = lg[..., 6:8], lg[..., 8:10].exp().clamp(1e-4, 1e4)
+    lp = (torch.log_softmax(lg[..., :6], -1).gather(-1, a[..., :1].long()).squeeze(-1) +
+          torch.distributions.Normal(mu, sd).log_prob(a[..., 1:3]).sum(-1) +
+          torch.log_softmax(lg[..., 10:], -1).gather(-1, a[..., 3:].long()).squeeze(-1))
+    assert (lp - runner.traj["log_prob_actions"]).abs().max() < 2e-5
+    # what the env was handed at the last step: the reference's per-member list
+    last = runner.samplers[0].env.last_actions
+    assert isinstance(last, list) and len(last) == 3
+    assert last[0].dtype == torch.int32 and tuple(last[0].shape) == (64,) and tuple(last[1].shape) == (64, 2) \
+        and last[1].dtype == torch.float32 and last[2].dtype == torch.int32
+    assert torch.equal(last[0].float(), a[:, -1, 0]) and torch.equal(last[1], a[:, -1, 1:3])
 
 
 def test_continuous_env_rollout_and_vtrace_training(lib):

@@ -169,7 +169,7 @@ def run_loss(lib, cfg, params, values, actions, old_logp, old_params, old_values
 
 
 @pytest.mark.parametrize("case", ["ff_default", "ff_invalids", "ff_bootstrap_nonorm", "ff_continuous", "ff_vtrace",
-                                  "ff_tuple", "ff_tuple_symkl"])
+                                  "ff_tuple", "ff_tuple_symkl", "ff_tuple_mixed"])
 @pytest.mark.parametrize("fused_heads", [False, True])
 def test_ppo_loss_golden(lib, golden, case, fused_heads):
     g = golden("learner_" + case)
@@ -177,7 +177,7 @@ def test_ppo_loss_golden(lib, golden, case, fused_heads):
     n = int(g["mb_size"])
     continuous = case == "ff_continuous"
     cfg = _loss_cfg(lib, kv, continuous, dense_adv=case == "ff_vtrace")
-    if "head_sizes" in g:  # Tuple of Discrete spaces
+    if "head_sizes" in g:  # Tuple space: n > 0 = Discrete(n) member, -D = Box(D) member
         cfg.num_heads = len(g["head_sizes"])
         for i, nh in enumerate(g["head_sizes"]):
             cfg.head_n[i] = int(nh)
@@ -526,6 +526,74 @@ def test_sample_tuple_vs_oracle(lib):
     am = np.stack([logits[:, off[i]:off[i + 1]].argmax(1) for i in range(H)], 1)
     np.testing.assert_array_equal(env_a.cpu().numpy(), am.astype(np.int32))
 
+
+
+def test_sample_mixed_tuple_vs_oracle(lib):
+    """Tuple with a Box member — hs = [6, -2, 4] = (Discrete(6), Box(2), Discrete(4)): the Discrete members as above, the Box
+    member a = mu + clamp(exp(log_std)) * eps with eps from Box-Muller on Philox counter (step, dim / 2, 3, member index);
+    actions [B, 1 + 2 + 1] f32, no int32 env_actions; log-prob = sum over the members; deterministic: arg-max / the mean"""
+    rng = np.random.default_rng(23)
+    B, hs, T, t = 3000, [6, -2, 4], 4, 1
+    A, NA = 6 + 4 + 4, 4
+    logits = (rng.standard_normal((B, A)) * 1.2).astype(np.float32)
+    values = rng.standard_normal(B).astype(np.float32)
+    heads = dev(np.concatenate([values[:, None], logits, np.zeros((B, 1), np.float32)], 1))
+    ld = heads.shape[1]
+    z = lambda *s: torch.full(s, -7.0, device="cuda")
+    ta, tl, tp, tv, tver = z(B, T, NA), z(B, T, A), z(B, T), z(B, T + 1), z(B, T)
+    lib.sample_write_step_tuple(heads[:, 1:], ld, heads[:, 0], ld, B, hs, T, t, 11, 77, 5, 9.0, False, ta, tl, tp, tv,
+                                tver, None)
+    a_ref, lp_ref = oracle.sample_tuple(logits, hs, 11, 77, row0=5)
+    got = ta[:, t].cpu().numpy()
+    np.testing.assert_array_equal(got[:, [0, 3]], a_ref[:, [0, 3]])                      # integer members: exact
+    np.testing.assert_allclose(got[:, 1:3], a_ref[:, 1:3], atol=2e-5, rtol=1e-5)         # libm vs device exp / log / cos
+    np.testing.assert_allclose(tp[:, t].cpu().numpy(), lp_ref, atol=3e-5)
+    np.testing.assert_array_equal(tl[:, t].cpu().numpy(), logits)
+    assert torch.all(ta[:, t + 1] == -7.0) and torch.all(tver[:, t] == 9.0)
+    # the Box member is a standard normal in (a - mu) / sd
+    sd = np.clip(np.exp(logits[:, 8:10]), 1e-4, 1e4)
+    zs = (got[:, 1:3] - logits[:, 6:8]) / sd
+    assert abs(zs.mean()) < 0.05 and abs(zs.std() - 1.0) < 0.05
+    # a tuple with a Box member has no int32 action buffer
+    with pytest.raises(lib.SfHipError):
+        lib.sample_write_step_tuple(heads[:, 1:], ld, heads[:, 0], ld, B, hs, T, t, 11, 77, 5, 9.0, False, ta, tl, tp, tv,
+                                    tver, torch.zeros((B, 3), dtype=torch.int32, device="cuda"))
+    lib.sample_write_step_tuple(heads[:, 1:], ld, heads[:, 0], ld, B, hs, T, t, 11, 77, 5, 9.0, True, ta, tl, tp, tv,
+                                tver, None)
+    got = ta[:, t].cpu().numpy()
+    np.testing.assert_array_equal(got[:, 0], logits[:, :6].argmax(1))
+    np.testing.assert_array_equal(got[:, 1:3], logits[:, 6:8])
+    np.testing.assert_array_equal(got[:, 3], logits[:, 10:].argmax(1))
+
+
+def test_vtrace_mixed_tuple_vs_oracle(lib):
+    """V-trace importance ratios of a Tuple(Discrete(3), Box(2), Discrete(4)) policy: exp(sum of the members' log-probs -
+    old log-prob), against the oracle's loss head evaluated on the same parameters (its ratio is the same expression)"""
+    rng = np.random.default_rng(29)
+    hs, rec, ntraj = [3, -2, 4], 8, 64
+    n, A, NA = rec * ntraj, 3 + 4 + 4, 4
+    params = (rng.standard_normal((n, A)) * 0.7).astype(np.float32)
+    values = rng.standard_normal(n).astype(np.float32)
+    actions = np.concatenate([rng.integers(0, 3, (n, 1)), rng.standard_normal((n, 2)), rng.integers(0, 4, (n, 1))], 1).astype(np.float32)
+    # reference log-prob in float64 from the definition
+    def logp(p):
+        lp = np.log(np.exp(p[:, :3] - p[:, :3].max(1, keepdims=True)) / np.exp(p[:, :3] - p[:, :3].max(1, keepdims=True)).sum(1, keepdims=True))
+        out = lp[np.arange(n), actions[:, 0].astype(int)].astype(np.float64)
+        mu, sd = p[:, 3:5].astype(np.float64), np.clip(np.exp(p[:, 5:7].astype(np.float64)), 1e-4, 1e4)
+        out += (-((actions[:, 1:3] - mu) ** 2) / (2 * sd * sd) - np.log(sd) - 0.5 * np.log(2 * np.pi)).sum(1)
+        l2 = p[:, 7:] - p[:, 7:].max(1, keepdims=True)
+        l2 = l2 - np.log(np.exp(l2).sum(1, keepdims=True))
+        return out + l2[np.arange(n), actions[:, 3].astype(int)]
+    old_logp = (logp(params) + rng.standard_normal(n) * 0.2).astype(np.float32)
+    rewards = rng.standard_normal(n).astype(np.float32)
+    dones = rng.random(n) < 0.1
+    ratio = np.clip(np.exp(logp(params) - old_logp), 0.05, 20.0).astype(np.float32)
+    vs_ref, adv_ref = oracle.vtrace(ratio, values, rewards, dones.astype(np.float32), rec, 0.99, 0.9, 0.8)
+    vs, adv = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    lib.vtrace(dev(params), A, dev(values), 1, dev(actions), dev(old_logp), dev(rewards), dev(dones, torch.bool), None, 0, n, A,
+               0, rec, 0.99, 0.9, 0.8, vs, adv, head_sizes=hs)
+    np.testing.assert_allclose(vs.cpu().numpy(), vs_ref, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(adv.cpu().numpy(), adv_ref, atol=2e-5, rtol=1e-5)
 
 def test_sample_continuous_vs_oracle(lib):
     rng = np.random.default_rng(3)

@@ -94,7 +94,7 @@ def _loss_kwargs(kv, continuous):
                 exploration_coeff=coeff, exploration_kind=kind, kl_coeff=float(kv.get("kl_loss_coeff", 0.0)))
 
 
-@pytest.mark.parametrize("case", LEARNER_CASES + ["ff_vtrace", "ff_tuple", "ff_tuple_symkl"])
+@pytest.mark.parametrize("case", LEARNER_CASES + ["ff_vtrace", "ff_tuple", "ff_tuple_symkl", "ff_tuple_mixed"])
 def test_ppo_loss_matches_reference(golden, case):
     g = golden("learner_" + case)
     kv = _cfg_from_argv(g["argv"])
