@@ -85,6 +85,25 @@ class _Shm:
             pass
 
 
+def local_agent_index(agent_idx, row0: int, nrows: int):
+    """view-level agent index (int | slice | None) -> the index an instance owning rows [row0, row0 + nrows) understands, or
+    None when none of its agents is meant.  A slice is cut to the instance's rows (step 1 only; the whole view = slice(None))."""
+    if agent_idx is None:
+        return slice(None)
+    if isinstance(agent_idx, slice):
+        if agent_idx.step not in (None, 1):
+            raise ValueError(f"set_reward_shaping: strided agent slices are not supported ({agent_idx})")
+        if agent_idx.start is None and agent_idx.stop is None:
+            return slice(None)
+        lo = max(agent_idx.start or 0, row0)
+        hi = row0 + nrows if agent_idx.stop is None else min(agent_idx.stop, row0 + nrows)
+        if lo >= hi:
+            return None
+        return slice(None) if (lo == row0 and hi == row0 + nrows) else slice(lo - row0, hi - row0)
+    i = int(agent_idx)
+    return i - row0 if row0 <= i < row0 + nrows else None
+
+
 def _format_actions(act_rows: np.ndarray, heads: List[int], continuous: bool, batched: bool):
     """what `preprocess_actions` hands the env (batched_sampling.py:30-82): int32, the action axis squeezed for ONE Discrete
     head; an all-Discrete Tuple space gets the [agents, heads] int32 array (the `all_discrete` branch — pinned by
@@ -110,6 +129,7 @@ class _InstanceStepper:
         from sample_factory_amd.envs.env_utils import RewardShapingInterface, find_training_info_interface, find_wrapper_interface
         self.arrays, self.heads, self.continuous, self.envs = arrays, heads, continuous, []
         self.training_info_ifaces, self.reward_shaping_ifaces = [], []
+        self._shaping_rows = []  # (split, first row, rows, interface) of every instance that can be re-shaped
         for split, vidx, env_id, row0, nrows in instances:
             env = make_env_func(env_name, cfg, AttrDict(worker_index=widx, vector_index=vidx, env_id=env_id), render_mode)
             self.envs.append((split, env, env_is_batched(env), row0, nrows, env_id))
@@ -119,14 +139,22 @@ class _InstanceStepper:
             iface = find_wrapper_interface(env, RewardShapingInterface)
             if iface is not None:
                 self.reward_shaping_ifaces.append(iface)
+                self._shaping_rows.append((split, row0, nrows, iface))
 
     def default_reward_shaping(self):
         """the scheme of the first instance that has one (env_utils.py:96-103 asks ONE env; instances of an env agree)"""
         return self.reward_shaping_ifaces[0].get_default_reward_shaping() if self.reward_shaping_ifaces else None
 
-    def set_reward_shaping(self, reward_shaping, agent_idx) -> None:
-        for iface in self.reward_shaping_ifaces:
-            iface.set_reward_shaping(reward_shaping, agent_idx)
+    def set_reward_shaping(self, reward_shaping, agent_idx, split=None) -> None:
+        """`agent_idx` indexes the batched agent axis of ONE view (env_utils.py:106-111: an int, or a slice in batched mode):
+        it is translated to the instance that owns those rows and handed over as that instance's LOCAL index — a per-agent
+        (PBT-style) update reaches one agent, not every instance.  split=None / a slice over the whole view: everybody."""
+        for sp_, row0, nrows, iface in self._shaping_rows:
+            if split is not None and sp_ != split:
+                continue
+            local = local_agent_index(agent_idx, row0, nrows)
+            if local is not None:
+                iface.set_reward_shaping(reward_shaping, local)
 
     def set_training_info(self, training_info) -> None:
         """curricula (batched_sampling.py:352-355): every instance that implements TrainingInfoInterface gets the dict"""
@@ -197,8 +225,9 @@ def _worker_main(widx: int, conn, done_sems, make_env_func: Callable, env_name: 
             if cmd == CMD_TRAINING_INFO:  # payload in place of the split index; no completion signal
                 stepper.set_training_info(split)
                 continue
-            if cmd == CMD_REWARD_SHAPING:  # payload = (scheme, agent_idx); no completion signal
-                stepper.set_reward_shaping(*split)
+            if cmd == CMD_REWARD_SHAPING:  # payload = (scheme, agent index | slice fields, is_slice, split); no completion signal
+                scheme, idx, is_slice, sp_ = split
+                stepper.set_reward_shaping(scheme, slice(*idx) if is_slice else idx, sp_)
                 continue
             stepper.run(cmd, split)
             done_sems[split].release()
@@ -268,8 +297,12 @@ class ParallelVecEnvView(RewardShapingInterface):
         return self.parent.default_reward_shaping
 
     def set_reward_shaping(self, reward_shaping, agent_idx) -> None:
-        if self.split == 0:  # one message per worker covers the instances of every split
-            self.parent.set_reward_shaping(reward_shaping, agent_idx)
+        whole = agent_idx is None or (isinstance(agent_idx, slice) and agent_idx.start is None and agent_idx.stop is None)
+        if whole:
+            if self.split == 0:  # one message per worker covers the instances of every split
+                self.parent.set_reward_shaping(reward_shaping, agent_idx)
+        else:                    # rows of THIS view: only the instance that owns them is re-shaped
+            self.parent.set_reward_shaping(reward_shaping, agent_idx, split=self.split)
 
     def close(self):
         self.parent.close()
@@ -418,16 +451,18 @@ class ParallelHostEnvs:
         for c in self._conns:
             c.send((CMD_TRAINING_INFO, dict(training_info)))
 
-    def set_reward_shaping(self, reward_shaping, agent_idx) -> None:
-        """env_utils.py:106-111: a new reward shaping scheme for the env instances (where they live)"""
+    def set_reward_shaping(self, reward_shaping, agent_idx, split=None) -> None:
+        """env_utils.py:106-111: a new reward shaping scheme for the env instances (where they live); `agent_idx` is a row
+        of the view of `split` (None: every instance of every split)"""
         if self._closed or reward_shaping is None:
             return
         if self.inline:
             for st in self._steppers:
-                st.set_reward_shaping(reward_shaping, agent_idx)
+                st.set_reward_shaping(reward_shaping, agent_idx, split)
             return
+        idx = (agent_idx.start, agent_idx.stop, agent_idx.step) if isinstance(agent_idx, slice) else agent_idx
         for c in self._conns:
-            c.send((CMD_REWARD_SHAPING, (dict(reward_shaping), agent_idx)))
+            c.send((CMD_REWARD_SHAPING, (dict(reward_shaping), idx, isinstance(agent_idx, slice), split)))
 
     def _command(self, split: int, cmd: int) -> None:
         if self.inline:

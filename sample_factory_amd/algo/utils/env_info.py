@@ -103,7 +103,7 @@ def obtain_env_info_in_a_separate_process(cfg, timeout: float = 600.0) -> EnvInf
 
     cache = env_info_cache_filename(cfg)
     use_cache = bool(getattr(cfg, "use_env_info_cache", False))
-    if use_cache and os.path.isfile(cache):
+    if use_cache and os.path.isfile(cache) and _cache_entry_is_ours(cache):
         try:
             with open(cache, "rb") as f:
                 info = pickle.load(f)
@@ -116,12 +116,23 @@ def obtain_env_info_in_a_separate_process(cfg, timeout: float = 600.0) -> EnvInf
     q = ctx.Queue()
     p = ctx.Process(target=_probe_env, args=(cfg.env, registered_env_factory(cfg.env), cfg, q), daemon=True)
     p.start()
+    import time
+    info, deadline = None, time.monotonic() + timeout
     try:
-        info = q.get(timeout=timeout)
-    except _queue.Empty:
-        p.kill()
-        raise RuntimeError(f"no env info for {cfg.env!r} after {timeout:.0f} s (the probe process "
-                           f"{'died with exit code ' + str(p.exitcode) if p.exitcode is not None else 'is still running'})")
+        while info is None:
+            try:
+                info = q.get(timeout=1.0)
+            except _queue.Empty:
+                if not p.is_alive():  # a probe that died without a word (segfault in a simulator, OOM kill): fail NOW
+                    try:
+                        info = q.get(timeout=0.5)  # ... unless its answer was still in flight
+                    except _queue.Empty:
+                        raise RuntimeError(f"the env probe process for {cfg.env!r} died with exit code {p.exitcode} "
+                                           f"without reporting env info") from None
+                elif time.monotonic() > deadline:
+                    p.kill()
+                    raise RuntimeError(f"no env info for {cfg.env!r} after {timeout:.0f} s (the probe process is still "
+                                       f"running; killed)") from None
     finally:
         p.join(timeout=10)
     if isinstance(info, Exception):
@@ -130,3 +141,21 @@ def obtain_env_info_in_a_separate_process(cfg, timeout: float = 600.0) -> EnvInf
         with open(cache, "wb") as f:
             pickle.dump(info, f)
     return info
+
+
+def _cache_entry_is_ours(path: str) -> bool:
+    """an env-info cache entry is unpickled only when the file and its directory belong to this user and nobody else can
+    write there (the path under the shared temporary directory is predictable)"""
+    import os
+    import stat
+
+    from sample_factory_amd.utils.utils import log
+    try:
+        for p_ in (os.path.dirname(path), path):
+            st = os.stat(p_)
+            if st.st_uid != os.getuid() or (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH)):
+                log.warning(f"ignoring env info cache entry {path}: {p_} is not exclusively owned by this user")
+                return False
+        return True
+    except OSError:
+        return False

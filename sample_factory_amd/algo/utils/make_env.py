@@ -31,7 +31,8 @@ def make_env_func_batched(cfg, env_config, render_mode: Optional[str] = None):
     env = create_env(cfg.env, cfg=cfg, env_config=env_config, render_mode=render_mode)
     if hasattr(env, "step_into") or is_multiagent_env(env):
         return env
+    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs, probe_info
+    probed = probe_info(env)  # spaces / agents of the instance just built: ParallelHostEnvs does not build another probe
     env.close()
-    from sample_factory_amd.algo.sampling.parallel_env import ParallelHostEnvs
     return ParallelHostEnvs(cfg, cfg.env, registered_env_factory(cfg.env), 1, 1, num_splits=1, inline=True,
-                            render_mode=render_mode).views[0]
+                            render_mode=render_mode, probed=probed).views[0]

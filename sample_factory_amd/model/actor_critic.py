@@ -410,6 +410,18 @@ class ActorCritic:
             self._bufs[key] = t
         return t
 
+    def _aligned_frames(self, tag, x, stride, idx, off, tT, n):
+        """the n frames a launch would read — dataset row d = idx[i] | off + i, slab row d + d // traj_T (sf_common.h
+        sample_base) — gathered into a dense, allocator-aligned u8 [n, obs_elems] buffer"""
+        d = idx.long() if idx is not None else torch.arange(off, off + n, device=x.device)
+        pos = d + torch.div(d, int(tT), rounding_mode="floor") if tT else d
+        avail = (x.untyped_storage().nbytes() - x.storage_offset() * x.element_size()) // x.element_size()
+        rows = (avail - self.obs_elems) // int(stride) + 1
+        flat = x.as_strided((rows, self.obs_elems), (int(stride), 1))
+        out = self._buf((tag, "frames_aligned"), (n, self.obs_elems), dtype=x.dtype)
+        torch.index_select(flat, 0, pos, out=out)
+        return out, self.obs_elems, None, 0, 0
+
     def _zbuf(self, key, shape):
         """like _buf but zero-filled on creation (buffers with never-written padding columns)"""
         t = self._bufs.get(key)
@@ -537,6 +549,10 @@ class ActorCritic:
                 # image frames: (x - mu) * rstd, clamped, happens in conv1's loader (sf_conv_fwd_norm) — the frames stay
                 # u8 in the slab and no normalised f32 copy is written or read
                 norm_tabs = tabs if tabs is not None else (on.mu_tab, on.rstd_tab)
+                if x.data_ptr() % 4 or stride % 4:
+                    # the loader fetches the bytes as 32-bit words: a frame view at an odd address (a custom slab offset)
+                    # degrades to one aligned u8 copy of the batch's frames instead of failing the launch
+                    x, stride, idx, off, tT = self._aligned_frames(tag, x, stride, idx, off, tT, n)
             else:  # any other shape: materialise the normalised f32 batch (NHWC), as the reference does
                 xn = self._buf((tag, "obsn"), (n, self.obs_elems))
                 on.apply(obs, sample_stride, n, xn, index=index, offset=offset, traj_T=traj_T, tabs=tabs)

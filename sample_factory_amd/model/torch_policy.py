@@ -337,12 +337,14 @@ class TorchPolicyAdapter:
         the flat parameters (+ the module's buffers and the observation normaliser's moments); forwards tagged "inf*"
         run the module of slot `snap_read`."""
         import copy
-        self._snap, self._snap_modules, self._snap_norms = [], [], []
+        self._snap, self._snap_modules, self._snap_norms, self._snap_frozen = [], [], [], []
+        self._frozen = [p for p in self.module.parameters() if not p.requires_grad]  # not in flat_params: copied on publish
         for _ in range(2):
             buf = self.flat_params.clone()
             m = copy.deepcopy(self.module)
             mine = [p for p in m.parameters() if p.requires_grad]
-            assert len(mine) == len(self._params)
+            self._snap_frozen.append([p for p in m.parameters() if not p.requires_grad])
+            assert len(mine) == len(self._params) and len(self._snap_frozen[-1]) == len(self._frozen)
             for p, o in zip(mine, self._offs):
                 p.grad = None
                 p.requires_grad_(False)
@@ -358,6 +360,8 @@ class TorchPolicyAdapter:
         with torch.no_grad():
             for dst, src in zip(self._snap_modules[slot].buffers(), self.module.buffers()):
                 dst.copy_(src)
+            for dst, src in zip(self._snap_frozen[slot], self._frozen):  # frozen (requires_grad=False) parameters a user
+                dst.copy_(src)                                           # callback may still have changed
         # TorchObsNormalizer.update REBINDS mean / var to new tensors, so holding the current ones is a snapshot
         self._snap_norms[slot] = {k: (nm.mean, nm.var) for k, nm in self._norms.items()}
 
@@ -406,6 +410,20 @@ class TorchPolicyAdapter:
             main = self._norm.key
             xd = {"obs": self._norm(self._gather(obs, n, index, offset, traj_T), nstats.get(main))}
         train = tag == "train"
+        # rollout forwards ("inf*") run in eval mode on BOTH paths, as the reference's inference worker does with its own
+        # copy (inference_worker.py: actor_critic.eval()): the snapshot modules are eval() copies; in sync mode the learner's
+        # module (kept in train mode, learner.py:228) is switched for the duration of the forward, so Dropout / BatchNorm
+        # layers of a user encoder behave the same with async_rl on and off
+        flip = tag.startswith("inf") and module is self.module and module.training
+        if flip:
+            module.eval()
+        try:
+            return self._forward_heads(module, xd, n, tag, rnn, train)
+        finally:
+            if flip:
+                module.train()
+
+    def _forward_heads(self, module, xd, n, tag, rnn, train) -> List[torch.Tensor]:
         with torch.set_grad_enabled(train):
             if rnn is None:
                 res = module(xd, None, values_only=False)

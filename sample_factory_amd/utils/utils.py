@@ -170,7 +170,16 @@ def get_username() -> str:
 
 
 def project_tmp_dir(mkdir: bool = True) -> str:
-    return maybe_ensure_dir_exists(join(tempfile.gettempdir(), f"sf2_{get_username()}"), mkdir)
+    """per-user scratch directory under the shared temporary directory; created (and kept) private: mode 0700"""
+    path = join(tempfile.gettempdir(), f"sf2_{get_username()}")
+    if mkdir:
+        os.makedirs(path, mode=0o700, exist_ok=True)
+        try:
+            if os.stat(path).st_uid == os.getuid():
+                os.chmod(path, 0o700)
+        except OSError:
+            pass
+    return path
 
 
 def experiments_dir(cfg, mkdir=True) -> str:

@@ -105,6 +105,33 @@ def test_probe_failure_is_raised_in_the_caller(tmp_path):
         ei.obtain_env_info_in_a_separate_process(_cfg("broken-env", tmp_path), timeout=120)
 
 
+def _dies_silently(full_env_name, cfg=None, env_config=None, render_mode=None):
+    os._exit(7)  # a simulator that takes its process down (segfault, OOM kill): nothing is posted to the queue
+
+
+def test_a_probe_process_that_dies_without_a_word_fails_fast(tmp_path):
+    import time
+    register_env("dying-env", _dies_silently)
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError, match="died with exit code 7"):
+        ei.obtain_env_info_in_a_separate_process(_cfg("dying-env", tmp_path), timeout=600)
+    assert time.monotonic() - t0 < 60  # not the 10-minute queue timeout
+
+
+def test_env_info_cache_entry_of_another_owner_or_mode_is_not_unpickled(tmp_path):
+    d = tmp_path / "cache"
+    d.mkdir(mode=0o700)
+    f = d / "env_info_x"
+    f.write_bytes(b"x")
+    os.chmod(f, 0o600)
+    assert ei._cache_entry_is_ours(str(f))
+    os.chmod(d, 0o777)  # anybody could have replaced the entry
+    assert not ei._cache_entry_is_ours(str(f))
+    os.chmod(d, 0o700)
+    os.chmod(f, 0o666)
+    assert not ei._cache_entry_is_ours(str(f))
+
+
 def test_check_env_info_detects_a_stale_cache(tmp_path, monkeypatch):
     monkeypatch.setattr(ei, "env_info_cache_filename", lambda cfg: str(tmp_path / f"env_info_{cfg.env}"))
     cfg = _cfg("doomlike", tmp_path)

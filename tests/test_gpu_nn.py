@@ -1179,6 +1179,63 @@ def test_async_rl_two_streams_equal_same_schedule_on_one_stream(lib, variant):
     assert (ra.slabs[1]["policy_version"] == 8.0).all() and ra.learner.train_step == 10
 
 
+def test_user_torch_model_inference_runs_in_eval_mode_and_frozen_parameters_are_published(lib, tmp_path):
+    """A user encoder with Dropout and a frozen (requires_grad=False) parameter: rollout forwards ("inf") run in eval mode
+    whether they use the learner's module (sync) or a published snapshot (async_rl, the reference's default) — the
+    reference's inference worker holds an eval() copy — while the training forward keeps train mode; publish_weights also
+    copies frozen parameters, which are not part of the flat trainable buffer"""
+    from torch import nn
+    from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
+    from sample_factory_amd.algo.utils.env_info import EnvInfo
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.model_factory import global_model_factory
+    from sample_factory_amd.model.torch_policy import TorchPolicyAdapter
+
+    class DropEncoder(nn.Module):
+        def __init__(self, cfg, obs_space):
+            super().__init__()
+            self.net = nn.Sequential(nn.Linear(8, 32), nn.Tanh(), nn.Dropout(0.5))
+            self.gain = nn.Parameter(torch.ones(32), requires_grad=False)
+
+        def forward(self, obs_dict):
+            return self.net(obs_dict["obs"]) * self.gain
+
+        def get_out_size(self):
+            return 32
+
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    env_info = EnvInfo(obs_space, spaces.Discrete(4), 16)
+    pv = torch.zeros(1, dtype=torch.int32)
+    global_model_factory().register_encoder_factory(lambda cfg, obs_space: DropEncoder(cfg, obs_space))
+    try:
+        lr = Learner(default_cfg(train_dir=str(tmp_path), use_rnn=False, normalize_input=False, rollout=8, batch_size=64,
+                                 num_batches_per_epoch=2, serial_mode=True, experiment="t"), env_info, pv, 0,
+                     ParameterServer(0, pv))
+        lr.init()
+    finally:
+        global_model_factory().reset()
+    ac = lr.actor_critic
+    assert isinstance(ac, TorchPolicyAdapter) and ac.module.training
+    x = torch.randn(64, 8, device="cuda")
+    a = ac.forward_heads(x, 64, sample_stride=8, tag="inf")[-1].clone()
+    b = ac.forward_heads(x, 64, sample_stride=8, tag="inf")[-1].clone()
+    assert torch.equal(a, b) and ac.module.training            # no dropout noise in rollouts; train mode restored
+    t1 = ac.forward_heads(x, 64, sample_stride=8, tag="train")[-1].clone()
+    t2 = ac.forward_heads(x, 64, sample_stride=8, tag="train")[-1].clone()
+    assert not torch.equal(t1, t2)                              # the learner's forward does see Dropout
+    ac.enable_weight_snapshots()
+    ac.publish_weights(0)
+    ac.snap_read = 0
+    s0 = ac.forward_heads(x, 64, sample_stride=8, tag="inf")[-1].clone()
+    assert torch.equal(s0, a)                                   # snapshot (eval copy) == sync-mode inference
+    with torch.no_grad():
+        ac.module.encoder.gain.mul_(2.0)                        # a frozen parameter changed by a user callback
+    ac.publish_weights(0)
+    s1 = ac.forward_heads(x, 64, sample_stride=8, tag="inf")[-1].clone()
+    assert not torch.equal(s1, s0)                              # ... reaches the published copy
+
+
 def test_user_registered_torch_model_trains_through_the_native_path(lib, tmp_path):
     """Model plugin surface (model/model_factory.py:16-60): a custom encoder registered with
     global_model_factory().register_encoder_factory keeps working — the network runs through torch autograd, everything
@@ -1735,6 +1792,35 @@ def test_normalize_input_keys_subset_on_the_native_model(lib):
         ac = ActorCritic(cfg, obs_space, spaces.Discrete(4), "cuda")
         assert (ac.obs_normalizer is not None) == expect, keys
         assert ("obs_normalizer.running_mean_std.running_mean_std.obs.running_mean" in ac.state_dict()) == expect
+
+
+def test_fused_input_normalisation_on_a_frame_view_at_an_odd_address(lib):
+    """normalize_input=True on 84x84 frames runs inside conv1's loader, which fetches the bytes as 32-bit words.  A frame view
+    whose base is not 4-byte aligned (a custom slab offset) used to fail the launch; it now goes through one aligned u8 copy of
+    the batch's frames — same numbers as the aligned view, with and without an index gather"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import ActorCritic
+    obs_space = spaces.Dict({"obs": spaces.Box(0, 255, (4, 84, 84), np.uint8)})
+    cfg = default_cfg(use_rnn=False, nonlinearity="relu", normalize_input=True, obs_scale=255.0,
+                      encoder_conv_architecture="convnet_atari", encoder_conv_mlp_layers=[512])
+    ac = ActorCritic(cfg, obs_space, spaces.Discrete(6), "cuda")
+    assert ac._fused_norm
+    n, E = 96, 28224
+    g = torch.Generator(device="cuda").manual_seed(3)
+    frames = torch.randint(0, 256, (n, E), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+    ac.obs_normalizer.update(frames, E, n)
+    ref = ac.forward_heads(frames, n, sample_stride=E, tag="inf")[-1].clone()
+    raw = torch.empty(n * E + 1, dtype=torch.uint8, device="cuda")
+    odd = raw[1:].view(n, E)
+    odd.copy_(frames)
+    assert odd.data_ptr() % 4 == 1
+    got = ac.forward_heads(odd, n, sample_stride=E, tag="inf")[-1]
+    assert torch.equal(got, ref)
+    idx = torch.randperm(n, device="cuda", generator=g)[:64].to(torch.int32)
+    ref_i = ac.forward_heads(frames, 64, sample_stride=E, index=idx, tag="inf")[-1].clone()
+    got_i = ac.forward_heads(odd, 64, sample_stride=E, index=idx, tag="inf")[-1]
+    assert torch.equal(got_i, ref_i)
 
 
 @pytest.mark.parametrize("rnn_type", ["lstm", "gru"])

@@ -339,5 +339,20 @@ def test_reward_shaping_and_training_info_reach_the_instances(inline):
         for v in host.views:  # instances of BOTH splits got the messages
             obs, rew, *_ = v.step(np.zeros(v.num_agents, np.int32))
             assert np.all(rew == 3.0) and np.all(obs["obs"][:, 0] == 500.0)
+        # a per-agent update (an int index into ONE view's agent axis, env_utils.py:106-111) reaches the instance that owns
+        # that row — and only it — with the instance's local index (2 workers x 1 instance per split: rows 0 and 1 of a view)
+        set_reward_shaping(host.views[1], {"w": 7.0}, 1)
+        _, rew0, *_ = host.views[0].step(np.zeros(2, np.int32))
+        _, rew1, *_ = host.views[1].step(np.zeros(2, np.int32))
+        assert np.all(rew0 == 3.0) and rew1.tolist() == [3.0, 7.0]
     finally:
         host.close()
+
+
+def test_local_agent_index():
+    from sample_factory_amd.algo.sampling.parallel_env import local_agent_index as f
+    assert f(None, 4, 2) == slice(None) and f(slice(None), 4, 2) == slice(None)
+    assert f(5, 4, 2) == 1 and f(3, 4, 2) is None and f(6, 4, 2) is None
+    assert f(slice(4, 6), 4, 2) == slice(None) and f(slice(0, 5), 4, 2) == slice(0, 1) and f(slice(6, 9), 4, 2) is None
+    with pytest.raises(ValueError):
+        f(slice(0, 8, 2), 4, 2)
