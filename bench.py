@@ -309,7 +309,9 @@ def workload_cfg(args, rank, world):
                   synthetic_num_agents=B // args.env_instances, data_parallel=world > 1,
                   # SF_DP_NATIVE=1: gradient buckets through the C-ABI (sf_allreduce_grads, one RCCL communicator per rank)
                   # instead of torch.distributed — both exchange paths can be measured by the same --gpus N run
-                  dp_native_rccl=os.environ.get("SF_DP_NATIVE", "0") not in ("", "0"))
+                  dp_native_rccl=os.environ.get("SF_DP_NATIVE", "0") not in ("", "0"),
+                  # SF_DP_ONESHOT=<bytes> (1 = 1 MiB): small SUM buckets through the one-shot mailbox exchange (sf_dp_oneshot_*)
+                  dp_oneshot_bytes=(lambda v: (1 << 20) if v == 1 else v)(int(os.environ.get("SF_DP_ONESHOT", "0") or 0)))
     mode = "async (rollout k+1 || train k)" if args.async_rl else "sync"
     if args.workload == "c2":
         cfg = default_cfg(
@@ -563,6 +565,8 @@ def main():
             collectives = {
                 "gradient_exchange": "sf_allreduce_grads (C-ABI, own RCCL communicator + exchange stream)"
                 if grp.native else "torch.distributed all_reduce (RCCL), async tail bucket",
+                "small_buckets": (f"one-shot mailbox exchange (sf_dp_oneshot_*, buckets <= {grp._os_cap} bytes)"
+                                  if getattr(grp, "_os", None) is not None else "torch.distributed all_reduce (RCCL)"),
                 "exposed_ms_per_step": [round(float(a[0]) / args.steps, 3) for a in allr],
                 "allreduce_ms_per_step": [None if float(a[1]) < 0 else round(float(a[1]) / args.steps, 3) for a in allr],
                 "collectives_per_step": [round(float(a[2]) / args.steps, 1) for a in allr],
@@ -700,6 +704,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        if grp is not None:
+            grp.close()  # native communicator / one-shot mailboxes (collective: every rank gets here)
         torch.distributed.destroy_process_group()
 
 

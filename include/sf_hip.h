@@ -477,6 +477,25 @@ int sf_allreduce_grads(void *comm, float *grads, int64_t n, void *stream);
 int sf_dp_allreduce_f64(void *comm, double *buf, int64_t n, int op, void *stream);
 int sf_dp_broadcast(void *comm, void *buf, int64_t nbytes, int root, void *stream);
 
+/* ---- one-shot ("direct") exchange for small buckets (<= 8 MB never goes round a ring) -----------------
+ * Every rank owns a mailbox in its HBM which every peer maps (hipIpc) and reads over xGMI: ONE kernel per rank and call
+ * publishes the bucket, waits for the peers' flags and adds the peers' copies in rank order (bit-identical results on all
+ * ranks; one hop instead of 2 (W-1)).  Meant for the 0.31 MB conv bucket of the gradient, which completes last in the
+ * backward pass, and the 24 ... 400-byte moment / loss-scalar buckets; larger buckets stay on sf_allreduce_grads.
+ * sf_dp_oneshot_create: allocates the mailbox for buckets of up to max_bytes and writes its SF_DP_IPC_HANDLE_BYTES handle
+ * to handle_out; the host ships every rank's handle to every rank (rank order, any channel) and calls
+ * sf_dp_oneshot_connect.  The all-reduce calls are collective, in place, enqueued on `stream`, and must be issued in the
+ * same order on every rank (they carry a sequence number).  A peer that does not arrive within 5 s sets the context's error
+ * word (sf_dp_oneshot_status) instead of hanging the queue.  No reference counterpart (one learner per policy:
+ * sample_factory/algo/utils/shared_buffers.py:26-32). */
+#define SF_DP_IPC_HANDLE_BYTES 64
+int sf_dp_oneshot_create(int nranks, int rank, int64_t max_bytes, void **ctx_out, void *handle_out);
+int sf_dp_oneshot_connect(void *ctx, const void *all_handles /* nranks x SF_DP_IPC_HANDLE_BYTES, rank order */);
+int sf_dp_oneshot_allreduce_f32(void *ctx, float *buf, int64_t n, void *stream);            /* SUM */
+int sf_dp_oneshot_allreduce_f64(void *ctx, double *buf, int64_t n, int op, void *stream);   /* op 0 = SUM, 1 = MAX */
+int sf_dp_oneshot_status(void *ctx);
+int sf_dp_oneshot_destroy(void *ctx);
+
 /* action means squashed to [-scale, scale] (continuous_tanh_scale > 0, model/action_parameterization.py:62-66), in
  * place on columns [col0, col0+ncols) of a row-major [n, ld] matrix: y = tanh(x/scale)*scale; backward: g *= 1-(y/scale)^2
  * with y the squashed output. */

@@ -78,7 +78,8 @@ class _Exposed:
 
 
 class ReplicaGroup:
-    def __init__(self, process_group=None, force_collectives: bool = False, native_rccl: bool = False):
+    def __init__(self, process_group=None, force_collectives: bool = False, native_rccl: bool = False,
+                 oneshot_bytes: int = 0):
         self.pg = process_group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.active else 1
@@ -98,6 +99,27 @@ class ReplicaGroup:
         self.trace = None
         if native_rccl and self.on:
             self._init_native()
+        # cfg.dp_oneshot_bytes > 0 (opt-in): small SUM buckets through the one-shot mailbox exchange of csrc/sf_dp.hip
+        self._os = None
+        self._os_cap = 0
+        if oneshot_bytes > 0 and self.on and torch.cuda.is_available():
+            self._init_oneshot(int(oneshot_bytes))
+
+    def _init_oneshot(self, cap: int) -> None:
+        """every rank allocates its mailbox, the hipIpc handles travel over the torch process group (64 bytes per rank), every
+        rank maps every peer's mailbox.  One context per group; buckets of at most `cap` bytes qualify."""
+        from sample_factory_amd import lib
+        ctx, handle = lib.dp_oneshot_create(self.world, self.rank, cap)
+        dev = torch.device("cpu") if self._stage else torch.device("cuda", torch.cuda.current_device())
+        mine = torch.frombuffer(bytearray(handle), dtype=torch.uint8).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.pg)
+        lib.dp_oneshot_connect(ctx, b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts))
+        self._os, self._os_cap, self._oslib = ctx, cap, lib
+
+    def _oneshot_ok(self, t: torch.Tensor) -> bool:
+        return (self._os is not None and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+                and 0 < t.numel() * t.element_size() <= self._os_cap)
 
     def _mark(self, tag: str) -> None:
         if self.trace is not None and torch.cuda.is_available():
@@ -159,6 +181,8 @@ class ReplicaGroup:
     def all_reduce_grads(self, t: torch.Tensor) -> torch.Tensor:
         """SUM of a slice of the flat fp32 gradient over the replicas; the current stream continues behind the result"""
         self._mark("grad_sync")
+        if self._oneshot_ok(t):  # the small head bucket (conv layers): one hop, nothing left to hide a ring behind
+            return self.all_reduce_sum(t)
         if self.native:
             h = self._native_reduce(t)
             with _Exposed(self):
@@ -177,6 +201,13 @@ class ReplicaGroup:
             torch.cuda.synchronize()
             self._lib.dp_comm_destroy(self._comm)
             self._comm = None
+        if self._os is not None:
+            torch.cuda.synchronize()
+            if self.active:
+                dist.barrier(group=self.pg)  # nobody unmaps a mailbox a peer's kernel may still read
+            self._oslib.dp_oneshot_status(self._os)
+            self._oslib.dp_oneshot_destroy(self._os)
+            self._os = None
 
     def _collective(self, fn, t: torch.Tensor) -> torch.Tensor:
         if self.on:
@@ -192,6 +223,12 @@ class ReplicaGroup:
         return t
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.on and self._oneshot_ok(t):
+            if self.timing is not None:
+                self.timing["count"] += 1
+            with _Exposed(self):
+                self._oslib.dp_oneshot_allreduce(self._os, t, "sum")
+            return t
         return self._collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.pg), t)
 
     def all_reduce_sum_async(self, t: torch.Tensor):

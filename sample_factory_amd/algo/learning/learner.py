@@ -158,7 +158,8 @@ class Learner:
         self.pg = process_group
         dp_on = process_group is not None or (getattr(cfg, "data_parallel", False) and torch.distributed.is_initialized())
         self.group = ReplicaGroup(process_group, bool(getattr(cfg, "dp_force_collectives", False)),
-                                  bool(getattr(cfg, "dp_native_rccl", False))) if dp_on else None
+                                  bool(getattr(cfg, "dp_native_rccl", False)),
+                                  oneshot_bytes=int(getattr(cfg, "dp_oneshot_bytes", 0) or 0)) if dp_on else None
         self.world = self.group.world if self.group is not None else 1
         self.dp = self.group is not None and self.group.on  # collectives are issued (world > 1, or forced for tests)
         self._grad_norms: List[float] = []

@@ -69,6 +69,7 @@ ENGINE_FLAGS = [
     ("data_parallel", _bool, False),         # learner replicas over torch.distributed (set automatically when WORLD_SIZE > 1)
     ("dp_overlap", _bool, True),             # all-reduce the fc/heads gradient bucket while the conv layers back-propagate
     ("dp_epoch_moments", _bool, True),       # GAE: every minibatch's advantage moments exchanged once per epoch (False: one 24-byte all-reduce per SGD step)
+    ("dp_oneshot_bytes", int, 0),            # > 0: f32 / f64 SUM buckets up to this size (the 0.31 MB conv bucket, the moment / invalid-count scalars) go through the one-shot mailbox exchange (sf_dp_oneshot_*) instead of a ring all-reduce
     ("dp_native_rccl", _bool, False),        # gradient buckets through the C-ABI (sf_allreduce_grads) instead of torch.distributed
     ("dp_force_collectives", _bool, False),  # issue the collectives in a group of one rank (tests)
     ("device_shuffle", _bool, False),        # shuffle_minibatches with the stateless on-device permutation

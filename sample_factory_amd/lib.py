@@ -47,7 +47,8 @@ SYMBOLS = [
     "sf_tanh_scale_fwd", "sf_tanh_scale_bwd",
     "sf_linear_fwd", "sf_linear_wgrad_workspace", "sf_linear_wgrad", "sf_linear_dgrad", "sf_relu_mask",
     "sf_dp_unique_id", "sf_dp_comm_create", "sf_dp_comm_destroy", "sf_dp_comm_info", "sf_allreduce_grads",
-    "sf_dp_allreduce_f64", "sf_dp_broadcast",
+    "sf_dp_allreduce_f64", "sf_dp_broadcast", "sf_dp_oneshot_create", "sf_dp_oneshot_connect", "sf_dp_oneshot_allreduce_f32",
+    "sf_dp_oneshot_allreduce_f64", "sf_dp_oneshot_status", "sf_dp_oneshot_destroy",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -839,3 +840,39 @@ def dp_broadcast(comm, buf: torch.Tensor, root: int = 0, stream_=None) -> None:
         raise SfHipError("dp_broadcast: a contiguous device tensor is required")
     _check(load().sf_dp_broadcast(comm, C.c_void_p(buf.data_ptr()), i64(buf.numel() * buf.element_size()), int(root),
                                   _cur_or(stream_)), "sf_dp_broadcast")
+
+
+# ---- one-shot small-bucket exchange (csrc/sf_dp.hip, include/sf_hip.h: mailboxes mapped over hipIpc, one kernel per call)
+DP_IPC_HANDLE_BYTES = 64
+
+
+def dp_oneshot_create(nranks: int, rank: int, max_bytes: int):
+    """-> (context, this rank's mailbox handle: DP_IPC_HANDLE_BYTES bytes to ship to every rank)"""
+    ctx, h = C.c_void_p(), C.create_string_buffer(DP_IPC_HANDLE_BYTES)
+    _check(load().sf_dp_oneshot_create(int(nranks), int(rank), i64(max_bytes), C.byref(ctx), h), "sf_dp_oneshot_create")
+    return ctx, bytes(h.raw)
+
+
+def dp_oneshot_connect(ctx, all_handles: bytes) -> None:
+    """all_handles: the handles of ALL ranks, rank order, concatenated"""
+    _check(load().sf_dp_oneshot_connect(ctx, C.c_char_p(all_handles)), "sf_dp_oneshot_connect")
+
+
+def dp_oneshot_allreduce(ctx, buf: torch.Tensor, op: str = "sum", stream_=None) -> None:
+    """in-place all-reduce of a contiguous f32 (sum) or f64 (sum / max) device tensor that fits the mailbox"""
+    if buf.dtype == torch.float32:
+        if op != "sum":
+            raise SfHipError("dp_oneshot_allreduce: f32 buckets are summed")
+        _check(load().sf_dp_oneshot_allreduce_f32(ctx, ptr(buf, "f32", "buf"), i64(buf.numel()), _cur_or(stream_)),
+               "sf_dp_oneshot_allreduce_f32")
+    else:
+        _check(load().sf_dp_oneshot_allreduce_f64(ctx, ptr(buf, "f64", "buf"), i64(buf.numel()), {"sum": 0, "max": 1}[op],
+                                                  _cur_or(stream_)), "sf_dp_oneshot_allreduce_f64")
+
+
+def dp_oneshot_status(ctx) -> None:
+    _check(load().sf_dp_oneshot_status(ctx), "sf_dp_oneshot_status")
+
+
+def dp_oneshot_destroy(ctx) -> None:
+    _check(load().sf_dp_oneshot_destroy(ctx), "sf_dp_oneshot_destroy")

@@ -420,3 +420,94 @@ def test_epoch_moment_exchange_equals_the_per_step_one(tmp_path):
     np.testing.assert_array_equal(out[1][0]["params"], out[0][0]["params"])   # same numbers either way
     assert int(out[0][0]["collectives"]) - int(out[1][0]["collectives"]) == 2 * (4 - 1), \
         (int(out[0][0]["collectives"]), int(out[1][0]["collectives"]))
+
+
+# ------------------------------------------------------------------------------------------ one-shot small-bucket exchange
+def _worker_oneshot(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from sample_factory_amd.algo.learning.dp import ReplicaGroup
+    grp = ReplicaGroup(oneshot_bytes=1 << 20)
+    assert grp._os is not None and grp.world == world
+    bad = []
+    for it in range(30):  # both slots, many reuses; sizes: scalars, one block, the 0.31 MB conv bucket (20 blocks)
+        for n in (3, 1000, 77_777):
+            base = (torch.arange(n, device="cuda") % 97 + 1).float()
+            t = base * float((rank + 1) * (it + 1))
+            grp.all_reduce_sum(t)
+            want = base * float(sum(r + 1 for r in range(world)) * (it + 1))  # small integers: exact in f32
+            if not torch.equal(t, want):
+                bad.append(("f32", it, n, float((t - want).abs().max())))
+        d = torch.tensor([1.5 * (rank + 1), -2.0 * it, 7.0], dtype=torch.float64, device="cuda")
+        grp.all_reduce_sum(d)
+        wd = torch.tensor([1.5 * sum(r + 1 for r in range(world)), -2.0 * it * world, 7.0 * world], dtype=torch.float64)
+        if not torch.equal(d.cpu(), wd):
+            bad.append(("f64", it, d.tolist()))
+        g = torch.full((50_000,), float(rank + 1), device="cuda")  # a slice of a larger buffer, as the head bucket is
+        grp.all_reduce_grads(g[100:40_100])
+        if not (bool((g[100:40_100] == float(sum(r + 1 for r in range(world)))).all()) and float(g[0]) == rank + 1
+                and float(g[-1]) == rank + 1):
+            bad.append(("slice", it))
+    big = torch.ones(1 << 19, device="cuda")  # 2 MiB: above the mailbox size -> the ordinary (staged gloo) path
+    grp.all_reduce_sum(big)
+    torch.cuda.synchronize()
+    ok_big = bool((big == float(world)).all())
+    from sample_factory_amd import lib
+    lib.dp_oneshot_status(grp._os)
+    grp.close()
+    np.savez(os.path.join(out_dir, f"oneshot_rank{rank}.npz"), bad=len(bad), first=str(bad[:3]), ok_big=ok_big)
+    dist.destroy_process_group()
+
+
+def test_one_shot_exchange_between_two_ranks_on_one_device(tmp_path):
+    """csrc/sf_dp.hip one-shot exchange: mailboxes mapped across PROCESSES with hipIpc, one kernel per rank and
+    call.  Two ranks sharing the box's GPU: f32 sums of 3 ... 77 777 elements (the conv bucket's size), f64 scalars, a slice of
+    a larger buffer, 30 rounds over both slots — exact results on both ranks; a bucket above the mailbox size takes the
+    ordinary path; no wait timed out"""
+    mp.spawn(_worker_oneshot, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for k in ("WORLD_SIZE", "RANK"):
+        os.environ.pop(k, None)
+    for r in range(2):
+        z = np.load(tmp_path / f"oneshot_rank{r}.npz")
+        assert int(z["bad"]) == 0 and bool(z["ok_big"]), (r, str(z["first"]))
+
+
+def _worker_learner_oneshot(rank, world, port, out_dir, oneshot):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", SF_DP_BACKEND="gloo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_atari", make_synthetic_env)
+    cfg = _cfg(32, dp_oneshot_bytes=(1 << 20) if oneshot else 0)
+    cfg.batch_size, cfg.num_batches_per_epoch, cfg.num_epochs = 128, 2, 2
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    grp = runner.learner.group
+    assert (grp._os is not None) == bool(oneshot)
+    for _ in range(2):
+        runner.iteration()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"los{int(oneshot)}_rank{rank}.npz"), params=runner.learner.actor_critic.flat_params.cpu().numpy())
+    grp.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_learner_with_the_one_shot_exchange_equals_the_ring_path(tmp_path):
+    """cfg.dp_oneshot_bytes: the learner's small SUM buckets (advantage / return moments, invalid counts, the conv bucket of
+    the gradient) through the mailbox exchange.  With two ranks a sum has one order, so the weights after two datasets are
+    bit-identical to the run on torch.distributed's all-reduce, and the replicas stay in lock-step"""
+    out = {}
+    for os_ in (1, 0):
+        mp.spawn(_worker_learner_oneshot, args=(2, _free_port(), str(tmp_path), os_), nprocs=2, join=True)
+        out[os_] = [np.load(tmp_path / f"los{os_}_rank{r}.npz")["params"] for r in range(2)]
+    for k in ("WORLD_SIZE", "RANK"):
+        os.environ.pop(k, None)
+    np.testing.assert_array_equal(out[1][0], out[1][1])
+    np.testing.assert_array_equal(out[1][0], out[0][0])
