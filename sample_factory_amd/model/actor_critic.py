@@ -30,10 +30,8 @@ from sample_factory_amd import lib
 from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
 from sample_factory_amd.envs.spaces import is_box, calc_num_action_parameters, is_discrete
 
-import contextlib
 import os
 
-_BWD_STREAMS = os.environ.get("SF_BWD_STREAMS", "0") != "0"  # experiment: weight gradients on a side stream (see backward)
 _LSTM_SEQ = os.environ.get("SF_LSTM_SEQ", "1") != "0"  # A/B switch: 0 = per-step launches instead of the fused passes
 _CONV1_NORM = os.environ.get("SF_CONV1_NORM", "1") != "0"  # A/B switch: 0 = normalised f32 copy of the frames + f32 conv1
 _MLP2 = os.environ.get("SF_MLP2", "1") != "0"          # A/B switch: 0 = layer-by-layer encoder in the rollout as well
@@ -805,34 +803,6 @@ class ActorCritic:
             lib.tanh_scale_bwd(g_heads, ctx["acts"][-1], self.heads_ld, n, 1, self.num_action_params // 2, self.tanh_scale)
         chain = [li for li, L in enumerate(self.layers) if L.role != "rnn_hh"]
         mask0 = ctx.get("relu_mask0")  # sign bits recorded by THIS train forward (None: conv2's dgrad reads the activation)
-        # SF_BWD_STREAMS=1 (experiment, round 6): a layer's weight gradient and its data gradient both only read g — the weight
-        # gradients run on a side stream, one behind the other (they share the partial-sum workspace), beside the data-gradient
-        # chain on the launch stream; the two streams meet again at the end of the pass
-        side = _BWD_STREAMS and self.rnn_kind is None and on_layer_done is None
-        if side:
-            if getattr(self, "_bwd_stream", None) is None:
-                self._bwd_stream = torch.cuda.Stream()
-            main_s = torch.cuda.current_stream()
-
-        def wgrad_ws(nbytes):  # the side stream's own scratch (allocated under that stream; grown only when it is idle)
-            if not side:
-                return self._workspace(nbytes)
-            ws_ = self._wss.get("learner_wgrad_side")
-            if ws_ is None or ws_.numel() < nbytes:
-                self._bwd_stream.synchronize()
-                with torch.cuda.stream(self._bwd_stream):
-                    ws_ = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-                self._wss["learner_wgrad_side"] = ws_
-            return ws_
-
-        def wgrad_ctx():
-            if not side:
-                return contextlib.nullcontext()
-            ev = torch.cuda.Event()
-            ev.record(main_s)              # g of this layer is complete on the launch stream
-            self._bwd_stream.wait_event(ev)
-            return torch.cuda.stream(self._bwd_stream)
-
         for pos in range(len(chain) - 1, -1, -1):
             li = chain[pos]
             L = self.layers[li]
@@ -842,20 +812,18 @@ class ActorCritic:
             if pos == 0:
                 d0 = lib.sf_conv_desc.from_buffer_copy(d)
                 d0.traj_T = int(tT0)
-                ws = wgrad_ws(lib.conv_wgrad_workspace(n, d0))
-                with wgrad_ctx():
-                    if ctx.get("norm_tabs") is not None:  # the forward normalised in conv1's loader: so does the gradient
-                        mu_, rstd_ = ctx["norm_tabs"]
-                        lib.conv_wgrad_norm(x0, stride0, idx0, off0, mu_, rstd_, g, L.gw, L.gb, n, d0, ws)
-                    elif mask0 is not None:  # g is the gradient wrt conv1's ReLU output, unmasked: the kernel applies the bits
-                        lib.conv_wgrad_relu_mask(x0, stride0, idx0, off0, g, mask0, L.gw, L.gb, n, d0, ws)
-                    else:
-                        lib.conv_wgrad_raw(x0, stride0, idx0, off0, g, L.gw, L.gb, n, d0, ws)
+                ws = self._workspace(lib.conv_wgrad_workspace(n, d0))
+                if ctx.get("norm_tabs") is not None:  # the forward normalised in conv1's loader: so does the gradient
+                    mu_, rstd_ = ctx["norm_tabs"]
+                    lib.conv_wgrad_norm(x0, stride0, idx0, off0, mu_, rstd_, g, L.gw, L.gb, n, d0, ws)
+                elif mask0 is not None:  # g is the gradient wrt conv1's ReLU output, unmasked: the kernel applies the bits
+                    lib.conv_wgrad_relu_mask(x0, stride0, idx0, off0, g, mask0, L.gw, L.gb, n, d0, ws)
+                else:
+                    lib.conv_wgrad_raw(x0, stride0, idx0, off0, g, L.gw, L.gb, n, d0, ws)
             else:
                 x = inputs[li]
-                ws = wgrad_ws(lib.conv_wgrad_workspace(n, d))
-                with wgrad_ctx():
-                    lib.conv_wgrad_raw(x, d.H * d.W * d.Cin, None, 0, g, L.gw, L.gb, n, d, ws)
+                ws = self._workspace(lib.conv_wgrad_workspace(n, d))
+                lib.conv_wgrad_raw(x, d.H * d.W * d.Cin, None, 0, g, L.gw, L.gb, n, d, ws)
                 gin = self._buf(("g", li - 1), tuple(x.shape))
                 dd = lib.sf_conv_desc.from_buffer_copy(d)
                 dd.relu = L.in_act_kind  # derivative of the activation that produced x, fused into the epilogue
@@ -875,7 +843,3 @@ class ActorCritic:
                 L.gw[:, 1 + A // 2:1 + A].zero_()
             if on_layer_done is not None:
                 on_layer_done(li)
-        if side:
-            ev = torch.cuda.Event()
-            ev.record(self._bwd_stream)
-            main_s.wait_event(ev)
