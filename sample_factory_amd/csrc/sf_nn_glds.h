@@ -118,6 +118,22 @@ __device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint3
                  :: "s"(lds_byte_addr), "v"(voff), "s"(ubase) : "memory", "m0");
 }
 
+// ... with the LDS destination as (SGPR base + compile-time immediate): hipcc otherwise keeps one loop-invariant destination per
+// DMA instruction and, short of SGPRs, parks them in VGPR lanes (k_dgrad_pix_z: 6 v_readlane + 6 s_add per chunk between the
+// barrier and the DMA burst)
+template <int I, int N, typename F>
+__device__ __forceinline__ void sf_static_for(F &&f) {  // f(integral_constant<int, I>) for I = I .. N-1, unrolled at compile time
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sf_static_for<I + 1, N>(f);
+    }
+}
+template <int IMM>
+__device__ __forceinline__ void glds16_si(const void *ubase, uint32_t voff, uint32_t lds_base) {
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_base), "v"(voff), "s"(ubase), "n"(IMM) : "memory", "m0", "scc");
+}
+
 // mma_chunk_rows_mid with the fragment addresses as per-lane LDS POINTERS computed once per kernel (ap[c], bp[c]: group c of
 // stage 0) and the stage as a compile-time float offset: every ds_read_b128 is "VGPR + immediate", no address VALU at all.
 template <int TM, int TN, int OFF, typename F>
@@ -257,6 +273,9 @@ __device__ __forceinline__ void mma_chunk_ptrs_db(const float *const (&ap)[4], c
 
 #ifndef SF_PIX_INCR
 #define SF_PIX_INCR 1  // k_dgrad_pix(_z): the next chunk's (filter row, filter column, channel chunk) stepped, not decoded from q
+#endif
+#ifndef SF_PIX_LDSIMM
+#define SF_PIX_LDSIMM 1  // k_dgrad_pix_z: LDS destinations of the DMA instructions as SGPR base + immediate (see glds16_si)
 #endif
 #ifndef SF_QUADROW_ROT
 #define SF_QUADROW_ROT 0  // k_dgrad_quadrow_z: co-resident work-groups walk the group rows in different rotations (see the kernel)
@@ -919,6 +938,7 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
     uint32_t avoff[AI], bvoff[BI];
     const float *apl[4], *bpl[4];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+    const uint32_t ldsw = lds0 + (uint32_t)wave * 1024u;  // (SF_PIX_LDSIMM) this wave's 8 rows of every 32-row DMA group
     if constexpr (ZL) {
 #pragma unroll
         for (int i = 0; i < AI; ++i) avoff[i] = (uint32_t)((asrc[i] - dy) * (int64_t)sizeof(float));
@@ -950,6 +970,19 @@ __device__ __forceinline__ void dgrad_pix_body(ConvG g, const float *__restrict_
         const int64_t boff = (int64_t)((kh * g.KW + kw) * Cin) * Cout + cc * 32;
         if constexpr (ZL) {
             const float *ab = dy + aoff, *bb = w + boff;
+            if constexpr (SF_PIX_LDSIMM) {
+                // destination = (lds0 + wave * 1 KiB + stage * STAGE) [one scalar add per chunk] + an immediate per instruction
+                const uint32_t sb = ldsw + (uint32_t)stage * (uint32_t)(STAGE * 4);
+                sf_static_for<0, AI>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    glds16_si<I * 4096>(ab, avoff[I], sb);
+                });
+                sf_static_for<0, BI>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    glds16_si<BM * 128 + I * 4096>(bb, bvoff[I], sb);
+                });
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < AI; ++i) glds16_s(ab, avoff[i], lds0 + (uint32_t)((stage * STAGE + (i * 4 + wave) * 256) * 4));
 #pragma unroll

@@ -34,6 +34,12 @@
 #ifndef SF_IMG_FLIP
 #define SF_IMG_FLIP 1
 #endif
+#ifndef SF_IMG_PRIO
+#define SF_IMG_PRIO 0
+#endif
+#ifndef SF_IMG_HALFSTEP
+#define SF_IMG_HALFSTEP 1  // a last step with one live fragment runs the one-fragment k-loop (see the kernel)
+#endif
 template <int CIN, int H, int W, int KS, int ST, int TMF, int WSETS, int R>
 struct ImgFwdGeom {
     static constexpr int OH = (H - KS) / ST + 1, OW = (W - KS) / ST + 1, OHW = R * OW;  // rows per unit
@@ -62,6 +68,11 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
     __shared__ __attribute__((aligned(1024))) char ring[RING * IMG_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, kg = lane >> 4, n = (wave & 3) * 16 + col, wset = wave >> 2;
+#if SF_IMG_PRIO
+    // experiment: the two co-resident work-groups of a CU (hardware wave slots of different parity) get different static
+    // priorities, so that they do not run their per-step overhead (barrier, address set-up, DMA, stores) in phase
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u) __builtin_amdgcn_s_setprio(SF_IMG_PRIO);
+#endif
     const int nunits = nsamples * U;
     const int64_t Mtot = (int64_t)nunits * OHW;
     // ---- this work-group's rows: a contiguous run of 16-row fragments
@@ -147,27 +158,33 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
             const uint32_t prow = SF_IMG_FLIP ? ((uint32_t)(R - 1) - oh) * ST : oh * ST;
             base[f] = (int)((s % (uint32_t)RING) * (uint32_t)IMG_B + ((uint32_t)kg * PLANE + prow * WQ + ow) * 16u);
         }
-        f32x4 acc[TMF];
+        // The k-loop for NF live fragments (compile time).  SF_IMG_HALFSTEP: a work-group's LAST step may hold fewer fragments
+        // than TMF (conv3 at a rollout step: 12544 fragments on 512 work-groups = 24.5 each, 13 steps of 2) — it then runs the
+        // NF = 1 instantiation instead of multiplying a duplicate of fragment 0: the rollout-size launch is 12.5 step times
+        // long instead of 13.  Same MFMAs in the same order for the live fragments: bit-identical.
+        auto compute = [&](auto nfc) {
+        constexpr int NF = decltype(nfc)::value;
+        f32x4 acc[NF];
 #pragma unroll
-        for (int f = 0; f < TMF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
         // k-groups are processed in PAIRS: the fragment reads of the next pair sit between the two groups of the
         // current pair.  hipcc waits with lgkmcnt(0), i.e. for the youngest read, so what matters is the distance
         // from the LAST read to the wait: one whole group of 4*TMF MFMAs here (first version: reads right in front of
         // the wait, 18 exposed LDS latencies per block step = 25 % of the step with one wave per SIMD).
         static_assert(KG % 2 == 0, "k-groups come in pairs");
-        f32x4 a[2][2][TMF];
+        f32x4 a[2][2][NF];
         auto fetch = [&](int g, int slot) {  // g is a compile-time constant after unrolling: the offset is an immediate
             const int tap = (16 * g) / CIN, cb = ((16 * g) % CIN) / 4, kh = tap / KS, kw = tap % KS;
             const int imm = (cb * PLANE + ((kw % ST) * HU + (SF_IMG_FLIP ? KS - 1 - kh : kh)) * WQ + kw / ST) * 16;
 #pragma unroll
-            for (int f = 0; f < TMF; ++f)
+            for (int f = 0; f < NF; ++f)
                 a[slot][g & 1][f] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(ring + base[f] + imm, 16));
         };
         auto mfmas = [&](int g, int slot) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int f = 0; f < TMF; ++f)
+                for (int f = 0; f < NF; ++f)
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[slot][g & 1][f][j], breg[g][j], acc[f], 0, 0, 0);
         };
         fetch(0, 0);
@@ -188,12 +205,15 @@ __global__ __launch_bounds__(256 * WSETS, 1) void k_fwd_img(const float *__restr
         auto park = [&](auto kc) {
             constexpr int KIND = decltype(kc)::value;
 #pragma unroll
-            for (int f = 0; f < TMF; ++f)
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pend[f][r] = act_fwd_c<KIND>(acc[f][r] + bv, act);
         };
         if (act == 1) park(std::integral_constant<int, 1>{});
         else park(std::integral_constant<int, -1>{});
+        };
+        if (SF_IMG_HALFSTEP && TMF == 2 && nf == 1) compute(std::integral_constant<int, 1>{});
+        else compute(std::integral_constant<int, TMF>{});
         pend_fb = fb;
         pend_nf = nf;
     }
