@@ -24,7 +24,7 @@ BUDGET = {
     "k_wgrad_glds_zILi128ELi128ELi2ELi2E": (256, 0, 65536, 1, 2),       # fc weight gradient
     "k_wgrad_imgILi32ELi20ELi20ELi4ELi2ELi2E": (256, 0, 145408, 28, 1),  # conv2 weight gradient (persistent, one work-group per CU)
     "k_wgrad_imgILi64ELi9ELi9ELi3ELi1ELi1E": (256, 0, 69632, 0, 2),     # conv3 weight gradient
-    "k_fwd_imgILi64ELi9ELi9ELi3ELi1ELi2ELi1ELi7E": (256, 0, 81920, 76, 2),  # conv3 forward (SF_IMG_FLIP: planes padded to 16 chunks, 3 x 24 KiB; two work-groups per CU)
+    "k_fwd_imgILi64ELi9ELi9ELi3ELi1ELi2ELi1ELi7E": (256, 0, 81920, 80, 2),  # conv3 forward (SF_IMG_FLIP: planes padded to 16 chunks, 3 x 24 KiB; two work-groups per CU)
     "k_conv1_u8_bf16_wILb0E": (256, 0, 0, 57, 2),                       # conv1 forward on u8 frames (dynamic LDS)
     "k_conv1_wgrad_bf16ILb0E": (256, 0, 0, 40, 2),                      # conv1 weight gradient
 }
