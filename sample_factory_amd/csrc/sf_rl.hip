@@ -10,7 +10,7 @@
 thread_local char sf_err_buf[512] = "";
 
 extern "C" const char *sf_last_error(void) { return sf_err_buf; }
-extern "C" int sf_abi_version(void) { return 18; }
+extern "C" int sf_abi_version(void) { return 19; }
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 

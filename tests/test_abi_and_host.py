@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(lib.SYMBOLS) == syms, "sample_factory_amd.lib.SYMBOLS out of date with include/sf_hip.h"
     for s in syms:
         assert hasattr(L, s), f"libsf_hip.so does not export {s}"
-    assert L.sf_abi_version() == 18
+    assert L.sf_abi_version() == 19
     assert L.sf_selftest_host() == 0          # exact integer division used by every im2col address
     assert isinstance(L.sf_last_error(), bytes)
 
