@@ -249,8 +249,10 @@ class BatchedVectorEnvRunner:
             # the state THIS runner's forward produced (keyed by its tag: the learner thread may have run its bootstrap
             # forward through the same model object since)
             parts = self.ac.new_rnn_parts_of(self.tag)
-            if parts is not None:  # native model: mask + store [h | c] in one launch
-                lib.rnn_store_state(parts[0], parts[1], tr["dones"][:, t], tr["rnn_states"][:, t + 1])
+            if parts is not None:  # native model: mask + store [h | c] in one launch per recurrent layer
+                dst, SL = tr["rnn_states"][:, t + 1], tr["rnn_states"].shape[-1] // len(parts)
+                for l, (h_, c_) in enumerate(parts):  # stacked layers: layer l owns columns [l * SL, (l + 1) * SL) (core.py:54-58)
+                    lib.rnn_store_state(h_, c_, tr["dones"][:, t], dst[:, l * SL:(l + 1) * SL])
             else:                  # torch model path
                 keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
                 torch.mul(self.ac.new_rnn_states_of(self.tag), keep, out=tr["rnn_states"][:, t + 1])

@@ -69,6 +69,7 @@ class _Layer:
         self.bname = bname or name + ".bias"
         self.role = role          # "chain" | "rnn_ih" (x projection, followed by the cell) | "rnn_hh" (side branch)
         self.in_act_kind = 0      # activation kind of the tensor feeding this layer (fused into its dgrad epilogue)
+        self.rnn_l = 0            # index of the stacked recurrent layer a "rnn_ih" / "rnn_hh" projection belongs to
         self.desc = desc
         self.kind = kind          # "conv_u8" | "conv" | "linear" | "linear_after_conv" | "heads"
         self.ref_w_shape = ref_w_shape
@@ -119,8 +120,8 @@ class ActorCritic:
         self.action_space = action_space
         self.device = torch.device(device)
         self.training = True
-        if cfg.use_rnn and (cfg.rnn_num_layers != 1 or cfg.rnn_type not in ("gru", "lstm")):
-            raise NotImplementedError("native recurrent core: one-layer GRU or LSTM only")
+        if cfg.use_rnn and (cfg.rnn_num_layers < 1 or cfg.rnn_type not in ("gru", "lstm")):
+            raise NotImplementedError("native recurrent core: GRU or LSTM, rnn_num_layers >= 1")
         if not cfg.actor_critic_share_weights:
             raise NotImplementedError("separate actor/critic weights are outside the hot-path scope (SURVEY.md §2.1)")
         if cfg.nonlinearity not in ACT_KIND:
@@ -191,17 +192,24 @@ class ActorCritic:
         else:
             raise NotImplementedError(f"Unsupported observation shape {self.obs_shape}")
         self.rnn_kind, self.rnn_H, self.rnn_S = None, 0, get_rnn_size(cfg)
+        self.rnn_L = int(cfg.rnn_num_layers) if cfg.use_rnn else 0
+        self.rnn_SL = self.rnn_S // max(1, self.rnn_L)  # state columns of ONE recurrent layer: H (GRU) or 2 H (LSTM: [h | c])
         if cfg.use_rnn and not self.layers:
             raise NotImplementedError("a recurrent core needs at least one encoder layer in front of it")
         if cfg.use_rnn:  # model/core.py:19-64: nn.GRU / nn.LSTM(input=feat, hidden=rnn_size), torch gate order
             Hs = cfg.rnn_size
             G = 3 if cfg.rnn_type == "gru" else 4
             self.rnn_kind, self.rnn_H = (0 if cfg.rnn_type == "gru" else 1), Hs
-            self.layers.append(_Layer("core.core.ih", _linear_desc(feat, G * Hs, 0), (G * Hs, feat), "linear",
-                                      wname="core.core.weight_ih_l0", bname="core.core.bias_ih_l0", role="rnn_ih"))
-            self.layers.append(_Layer("core.core.hh", _linear_desc(Hs, G * Hs, 0), (G * Hs, Hs), "linear",
-                                      wname="core.core.weight_hh_l0", bname="core.core.bias_hh_l0", role="rnn_hh"))
-            feat = Hs
+            # cfg.rnn_num_layers stacked layers (nn.GRU / nn.LSTM(input, hidden, num_layers), model/core.py:27-30): layer l > 0
+            # reads layer l - 1's output; every layer is one (input projection, recurrent projection) pair on the same
+            # cell / sequence kernels; its state is columns [l * SL, (l + 1) * SL) of a sample's state row (core.py:42-58)
+            for l in range(int(cfg.rnn_num_layers)):
+                for nm, role, kin in (("ih", "rnn_ih", feat), ("hh", "rnn_hh", Hs)):
+                    Lr = _Layer(f"core.core.{nm}{l}", _linear_desc(kin, G * Hs, 0), (G * Hs, kin), "linear",
+                                wname=f"core.core.weight_{nm}_l{l}", bname=f"core.core.bias_{nm}_l{l}", role=role)
+                    Lr.rnn_l = l
+                    self.layers.append(Lr)
+                feat = Hs
         for j, size in enumerate(cfg.decoder_mlp_layers):
             self.layers.append(_Layer(f"decoder.mlp.{2 * j}", _linear_desc(feat, size, act), (size, feat), "linear"))
             feat = size
@@ -262,7 +270,8 @@ class ActorCritic:
         # per-tag results of the last forward: a sampler thread ("inf*" tags) and the learner thread ("boot", "train")
         # call forward_heads concurrently, so nothing a forward leaves behind may live in an untagged attribute
         self._ctx: Dict = {}
-        self._rnn_out: Dict = {}   # tag -> (h_out, c_out | None) of the last ONE-STEP recurrent forward under that tag
+        self._rnn_out: Dict = {}   # tag -> [(h_out, c_out | None) per recurrent layer] of the last ONE-STEP forward under that tag
+        self._rnn_saved_l: Dict = {}  # layer index -> what the last training pass of that recurrent layer left for its BPTT
         self.initialize_weights()
 
     # ------------------------------------------------------------------------------------------ reference surface
@@ -564,7 +573,7 @@ class ActorCritic:
                 continue
             if L.role == "rnn_ih" and seq:  # BPTT pass: the recurrent block works time-major ([R, C, .])
                 R, Cn = rnn["R"], n // rnn["R"]
-                xt = self._buf((tag, "x_tm"), (n, L.K))
+                xt = self._buf((tag, "x_tm", li), (n, L.K))
                 xt.view(R, Cn, L.K).copy_(x.view(Cn, R, L.K).transpose(0, 1))
                 x = xt
             inputs[li] = x
@@ -627,13 +636,14 @@ class ActorCritic:
     def _rnn_step(self, li, gx, n, rnn, tag, x_in=None, x_stride=0):
         """one inference step: (gx, h W_hh^T + b_hh) -> cell -> new state (model/core.py:37-64)"""
         Lh, H, S, kind = self.layers[li + 1], self.rnn_H, self.rnn_S, self.rnn_kind
-        st = rnn["states"]
-        assert st.shape == (n, S) and st.stride(1) == 1
-        gh = self._buf((tag, "gh"), (n, Lh.N))
+        l, SL = self.layers[li].rnn_l, self.rnn_SL
+        assert rnn["states"].shape == (n, S) and rnn["states"].stride(1) == 1
+        st = rnn["states"][:, l * SL:(l + 1) * SL]  # this layer's [h | c] columns of the state rows (strided view)
+        gh = self._buf((tag, "gh", l), (n, Lh.N))
         w_hh, b_hh, wt_hh = self._wb(li + 1, tag)
         if x_in is not None:  # both projections and both biases in one launch; the cell reads the [n, 4H] pre-activations
             _, b_ih, wt_ih = self._wb(li, tag)
-            gpre = self._buf((tag, "gpre"), (n, 4 * H))
+            gpre = self._buf((tag, "gpre", l), (n, 4 * H))
             lib.linear_fwd_dual(x_in, x_stride, wt_ih, b_ih, st, st.stride(0), wt_hh, b_hh, gpre, n, gru_H=H if kind == 0 else 0)
             gx, gh = gpre, None
         elif wt_hh is not None and lib.conv_fwd_t_supported(n, Lh.desc):  # LDS-DMA GEMM (2048 envs x 512 x 2048 fills the chip)
@@ -641,13 +651,15 @@ class ActorCritic:
             lib.conv_fwd_t(st, st.stride(0), wt_hh, b_hh, gh, n, Lh.desc, self._workspace(wsb) if wsb else None)
         else:
             lib.conv_fwd_raw(st, st.stride(0), None, 0, w_hh, b_hh, gh, n, Lh.desc)
-        h_out = self._buf((tag, "h_out"), (n, H))
-        c_out = self._buf((tag, "c_out"), (n, H)) if kind == 1 else None
+        h_out = self._buf((tag, "h_out", l), (n, H))
+        c_out = self._buf((tag, "c_out", l), (n, H)) if kind == 1 else None
         lib.rnn_cell_fwd(kind, gx, gh, st, st.stride(0), st[:, H:] if kind == 1 else None, st.stride(0), None, n, H,
                          None, h_out, c_out, None, None)
         # keyed by tag: the rollout runner masks + stores ITS OWN step's state in one launch (sf_rnn_store_state) even
         # while the learner thread runs the bootstrap forward (tag "boot") through the same model object
-        self._rnn_out[tag] = (h_out, c_out)
+        if l == 0:
+            self._rnn_out[tag] = []
+        self._rnn_out[tag].append((h_out, c_out))
         return h_out
 
     def _rnn_sequence_fwd(self, li, GX, n, rnn, tag, x_tm=None):
@@ -655,16 +667,17 @@ class ActorCritic:
         the loop form of rnn_utils.py:114-158, see tests/algo/test_rnn.py in the reference)"""
         Lh, H, kind = self.layers[li + 1], self.rnn_H, self.rnn_kind
         R, Cn = rnn["R"], n // rnn["R"]
-        h0, keep = rnn["h0"], rnn["keep_tm"]
+        l, SL = self.layers[li].rnn_l, self.rnn_SL
+        h0, keep = rnn["h0"][:, l * SL:(l + 1) * SL], rnn["keep_tm"]  # this layer's columns of the chunk-start states
         GH = Lh.N
-        gates = self._buf((tag, "gates"), (R, Cn, 4 * H))
-        Hprev = self._buf((tag, "Hprev"), (R + 1, Cn, H))
-        Cprev = self._buf((tag, "Cprev"), (R + 1, Cn, H)) if kind == 1 else None
-        Cout = self._buf((tag, "Cout"), (R, Cn, H)) if kind == 1 else None
+        gates = self._buf((tag, "gates", li), (R, Cn, 4 * H))
+        Hprev = self._buf((tag, "Hprev", li), (R + 1, Cn, H))
+        Cprev = self._buf((tag, "Cprev", li), (R + 1, Cn, H)) if kind == 1 else None
+        Cout = self._buf((tag, "Cout", li), (R, Cn, H)) if kind == 1 else None
         lib.copy_rows(Hprev[0], h0[:, :H])  # (the library's own row-copy kernel: [h | c] columns of the chunk-start states)
         if kind == 1:
             lib.copy_rows(Cprev[0], h0[:, H:])
-        out = self._buf((tag, "core_out"), (n, H))
+        out = self._buf((tag, "core_out", li), (n, H))
         fused = _LSTM_SEQ and lib.lstm_seq_supported(Cn, H)
         if fused:  # ONE persistent launch for the whole time loop (csrc/sf_rnn.hip): W_hh slices resident in LDS; the
             # core output is written in the minibatch's own row order (chunk-major), no transpose copy
@@ -678,10 +691,10 @@ class ActorCritic:
                 lib.lstm_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, Cprev, Cout, sync, R, Cn, H, env_major=True)
             else:
                 lib.gru_seq_fwd(GX, Lh.w, Lh.b, keep, gates, Hprev, out, sync, R, Cn, H, env_major=True)
-            self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=True)
+            self._rnn_saved_l[li] = self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=True)
             return out
-        Hout = self._buf((tag, "Hout"), (R, Cn, H))
-        gh = self._buf((tag, "gh_seq"), (Cn, GH))
+        Hout = self._buf((tag, "Hout", li), (R, Cn, H))
+        gh = self._buf((tag, "gh_seq", li), (Cn, GH))
         GXv = GX.view(R, Cn, GH)
         for t in range(R):
             lib.conv_fwd_raw(Hprev[t], H, None, 0, Lh.w, Lh.b, gh, Cn, Lh.desc)
@@ -689,16 +702,16 @@ class ActorCritic:
                              gates[t], Hout[t], Cout[t] if kind == 1 else None, Hprev[t + 1],
                              Cprev[t + 1] if kind == 1 else None)
         out.view(Cn, R, H).copy_(Hout.transpose(0, 1))
-        self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=False)
+        self._rnn_saved_l[li] = self._rnn_saved = dict(gates=gates, Hprev=Hprev, Cprev=Cprev, Cout=Cout, keep=keep, R=R, Cn=Cn, fused=False)
         return out
 
     def _rnn_sequence_bwd(self, li, d_core, n):
         """BPTT: returns dL/d(gx) time-major [R*C, G*H]; accumulates the W_hh / b_hh gradients"""
         Lh, H, kind = self.layers[li + 1], self.rnn_H, self.rnn_kind
-        sv = self._rnn_saved
+        sv = self._rnn_saved_l[li]
         R, Cn, keep = sv["R"], sv["Cn"], sv["keep"]
         GH = Lh.N
-        dGX = self._buf(("g", "dGX"), (R, Cn, GH))
+        dGX = self._buf(("g", "dGX", li), (R, Cn, GH))
         if sv.get("fused"):  # the whole backward time loop in one persistent launch (cell backward + W_hh^T product + carries)
             sync = self._seq_sync_buf()
             dGH = dGX
@@ -706,20 +719,20 @@ class ActorCritic:
             if kind == 1:
                 lib.lstm_seq_bwd(dOut, sv["gates"], sv["Cprev"], sv["Cout"], keep, Lh.w, dGX, sync, R, Cn, H, env_major=True)
             else:  # GRU: the candidate gate's recurrent part is scaled by r -> W_hh sees its own gate gradients
-                dGH = self._buf(("g", "dGH"), (R, Cn, GH))
+                dGH = self._buf(("g", "dGH", li), (R, Cn, GH))
                 lib.gru_seq_bwd(dOut, sv["gates"], sv["Hprev"], keep, Lh.w, dGX, dGH, sync, R, Cn, H, env_major=True)
             ws = self._workspace(lib.conv_wgrad_workspace(n, Lh.desc))
             lib.conv_wgrad_raw(sv["Hprev"][:R].reshape(n, H), H, None, 0, dGH.view(n, GH), Lh.gw, Lh.gb, n, Lh.desc, ws)
             return dGX.view(n, GH)
-        dOut = self._buf(("g", "dOut_tm"), (R, Cn, H))
+        dOut = self._buf(("g", "dOut_tm", li), (R, Cn, H))
         dOut.copy_(d_core.view(Cn, R, H).transpose(0, 1))
-        dGH = self._buf(("g", "dGH"), (R, Cn, GH)) if kind == 0 else dGX
-        dh = self._buf(("g", "dh"), (Cn, H))
-        dh_direct = self._buf(("g", "dh_direct"), (Cn, H)) if kind == 0 else None
-        dhW = self._buf(("g", "dhW"), (Cn, H))
-        carry_h = self._buf(("g", "carry_h"), (Cn, H))
-        carry_c = self._buf(("g", "carry_c"), (Cn, H)) if kind == 1 else None
-        dc_prev = self._buf(("g", "dc_prev"), (Cn, H)) if kind == 1 else None
+        dGH = self._buf(("g", "dGH", li), (R, Cn, GH)) if kind == 0 else dGX
+        dh = self._buf(("g", "dh", li), (Cn, H))
+        dh_direct = self._buf(("g", "dh_direct", li), (Cn, H)) if kind == 0 else None
+        dhW = self._buf(("g", "dhW", li), (Cn, H))
+        carry_h = self._buf(("g", "carry_h", li), (Cn, H))
+        carry_c = self._buf(("g", "carry_c", li), (Cn, H)) if kind == 1 else None
+        dc_prev = self._buf(("g", "dc_prev", li), (Cn, H)) if kind == 1 else None
         for t in range(R - 1, -1, -1):
             last = t == R - 1
             lib.rows_add_scale(dOut[t], None if last else carry_h, None, Cn, H, dh)
@@ -736,13 +749,14 @@ class ActorCritic:
         return dGX.view(n, GH)
 
     def new_rnn_parts_of(self, tag: str = "inf"):
-        """(h, c | None) produced by the last one-step forward issued under `tag` (None if there was none)"""
+        """[(h, c | None) per recurrent layer] produced by the last one-step forward issued under `tag` (None if there was
+        none); layer l's parts belong into columns [l * rnn_SL, (l + 1) * rnn_SL) of a state row"""
         return self._rnn_out.get(tag)
 
     def new_rnn_states_of(self, tag: str = "inf") -> torch.Tensor:
-        """[B, S] state after the last one-step forward under `tag` (reference output key `new_rnn_states`)"""
-        h, c = self._rnn_out[tag]
-        return h if c is None else torch.cat([h, c], dim=1)
+        """[B, S] state after the last one-step forward under `tag` (reference output key `new_rnn_states`; stacked layers:
+        [h0 | c0 | h1 | c1 ...], model/core.py:54-58)"""
+        return torch.cat([t for h, c in self._rnn_out[tag] for t in ((h,) if c is None else (h, c))], dim=1)
 
     @property
     def new_rnn_states(self) -> torch.Tensor:
@@ -835,7 +849,7 @@ class ActorCritic:
                 g = gin
                 if L.role == "rnn_ih":  # back to sample-major for the encoder
                     R, Cn = self._rnn_saved["R"], self._rnn_saved["Cn"]
-                    gs = self._buf(("g", "x_sm"), (n, L.K))
+                    gs = self._buf(("g", "x_sm", li), (n, L.K))
                     gs.view(Cn, R, L.K).copy_(g.view(R, Cn, L.K).transpose(0, 1))
                     g = gs
             if self.nonadaptive_std and li == len(self.layers) - 1:

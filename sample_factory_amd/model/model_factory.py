@@ -56,15 +56,16 @@ def create_actor_critic(cfg, obs_space, action_space, device, all_reduce=None):
     """model/actor_critic.py:337-342 create_actor_critic: the native model unless the user registered something"""
     f = global_model_factory()
     from sample_factory_amd.model.torch_policy import TorchPolicyAdapter, build_torch_actor_critic, obs_keys_of
-    stacked_rnn = bool(cfg.use_rnn) and int(cfg.rnn_num_layers) > 1
     separate = not bool(cfg.actor_critic_share_weights)
+    # (stacked recurrent layers, cfg.rnn_num_layers > 1, run on the native model since round 6: SF_NATIVE_STACKED_RNN=0 sends
+    # them back to the torch path)
+    import os
+    stacked_rnn = bool(cfg.use_rnn) and int(cfg.rnn_num_layers) > 1 and os.environ.get("SF_NATIVE_STACKED_RNN", "1") == "0"
     if f.is_default() and len(obs_keys_of(obs_space)) <= 1 and not stacked_rnn and not separate:
         from sample_factory_amd.model.actor_critic import ActorCritic
         return ActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
     # cfg.actor_critic_share_weights=False (ActorCriticSeparateWeights, model/actor_critic.py:198-334: an encoder / core /
     # decoder each for the actor and the critic) and
-    # stacked recurrent layers (cfg.rnn_num_layers > 1, model/core.py:19-64): the default architecture on the torch path
-    # (the native core is one layer: fused sequence passes for H in {256, 512}, per-step cell kernels otherwise)
     # observation dicts of several keys (model/encoder.py:33-69, MultiInputEncoder: one encoder per key, concatenated)
     # run the default architecture in torch: same fallback as a user-registered model, everything around the network
     # stays native

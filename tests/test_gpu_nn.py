@@ -785,10 +785,13 @@ def test_rnn_cells_match_torch(lib, rnn_type):
         np.testing.assert_allclose(dc_prev.cpu().numpy(), c0r.grad.numpy(), atol=3e-6)
 
 
-@pytest.mark.parametrize("name", ["gru", "lstm_inv"])
+@pytest.mark.parametrize("name", ["gru", "lstm_inv", "gru2", "lstm2"])
 def test_learner_train_matches_reference_rnn(lib, golden, tmp_path, name):
     """Recurrent policies: the reference's PackedSequence BPTT (rnn_utils.py) vs the native masked time loop —
-    full Learner.train (stored chunk-start states, resets on dones / invalid rows, 2 minibatches [x 2 epochs])."""
+    full Learner.train (stored chunk-start states, resets on dones / invalid rows, 2 minibatches [x 2 epochs]).
+    gru2 / lstm2: cfg.rnn_num_layers = 2 (nn.GRU / nn.LSTM with two stacked layers, model/core.py:27-30,42-58) on the NATIVE
+    model since round 6: one (input projection, recurrent projection) pair per layer on the same cell kernels, layer l's state
+    in columns [l * SL, (l + 1) * SL) of the state rows."""
     from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
     from sample_factory_amd.algo.utils.env_info import EnvInfo
     from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
@@ -810,6 +813,8 @@ def test_learner_train_matches_reference_rnn(lib, golden, tmp_path, name):
     learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
     learner.init()
     ac = learner.actor_critic
+    from sample_factory_amd.model.actor_critic import ActorCritic
+    assert isinstance(ac, ActorCritic) and ac.rnn_L == layers
     assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
     load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
     batch = alloc_trajectory_tensors(env_info, E, T, get_rnn_size(cfg), "cuda")
@@ -825,6 +830,7 @@ def test_learner_train_matches_reference_rnn(lib, golden, tmp_path, name):
     compare_post_train(learner, g, before, name, **TIGHT)
     after = ac.state_dict()
     assert "core.core.weight_hh_l0" in after and after["core.core.weight_ih_l0"].shape == ((3 if rnn_type == "gru" else 4) * 32, 32)
+    assert (f"core.core.weight_hh_l{layers - 1}" in after) and (f"core.core.weight_ih_l{layers}" not in after)
 
 
 def test_recurrent_policy_rollout_and_training(lib):
@@ -1701,7 +1707,7 @@ def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden
     architecture itself; also what observation dicts with several keys use): default one-layer GRU / LSTM core with
     the reference's parameter names, BPTT as a masked time loop under autograd, everything around the network native —
     against the reference's Learner.train (PackedSequence BPTT).  gru2 / lstm2: TWO stacked recurrent layers
-    (cfg.rnn_num_layers = 2, model/core.py:19-64) — create_actor_critic routes them to this path by itself."""
+    (cfg.rnn_num_layers = 2, model/core.py:19-64) on this path too (the native model takes them since round 6)."""
     from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
     from sample_factory_amd.algo.utils.env_info import EnvInfo
     from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
@@ -1723,8 +1729,7 @@ def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden
     obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
     env_info = EnvInfo(obs_space, spaces.Discrete(A), E)
     pv = torch.zeros(1, dtype=torch.int32)
-    if layers == 1:  # (stacked layers take the torch path without anything registered)
-        global_model_factory().register_encoder_factory(lambda c, o: _TorchMultiInputEncoder(c, o))
+    global_model_factory().register_encoder_factory(lambda c, o: _TorchMultiInputEncoder(c, o))  # -> the torch model path
     try:
         learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
         learner.init()
@@ -1821,6 +1826,77 @@ def test_fused_input_normalisation_on_a_frame_view_at_an_odd_address(lib):
     ref_i = ac.forward_heads(frames, 64, sample_stride=E, index=idx, tag="inf")[-1].clone()
     got_i = ac.forward_heads(odd, 64, sample_stride=E, index=idx, tag="inf")[-1]
     assert torch.equal(got_i, ref_i)
+
+
+@pytest.mark.parametrize("rnn_type", ["lstm", "gru"])
+def test_stacked_recurrent_layers_native_rollout_and_fused_passes(lib, rnn_type, monkeypatch):
+    """cfg.rnn_num_layers = 2 at rnn_size = 256 on the native model, end to end: the rollout carries [h0 | c0 | h1 | c1] rows
+    through the slab (zeroed after a done), both layers take the fused persistent BPTT passes, and the run on the per-step cell
+    kernels gives the same weights; the one-step forward equals torch's two-layer nn.LSTM / nn.GRU on the same weights"""
+    import sample_factory_amd.model.actor_critic as acm
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+    S = 256 * 2 * (2 if rnn_type == "lstm" else 1)
+
+    def run(fused):
+        monkeypatch.setattr(acm, "_LSTM_SEQ", fused)
+        cfg = default_cfg(env="synthetic_ant", use_rnn=True, rnn_type=rnn_type, rnn_size=256, rnn_num_layers=2, nonlinearity="tanh",
+                          normalize_input=True, encoder_mlp_layers=[64, 64], rollout=8, recurrence=8, batch_size=1024,
+                          num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=False,
+                          seed=3, serial_mode=True, synthetic_num_agents=256, with_vtrace=True, normalize_returns=False,
+                          kl_loss_coeff=0.1)
+        cfg, runner = make_runner(cfg)
+        runner.init()
+        ac = runner.learner.actor_critic
+        assert isinstance(ac, acm.ActorCritic) and ac.rnn_L == 2 and ac.rnn_S == S
+        lib.PROFILE = {}
+        try:
+            for _ in range(2):
+                runner.iteration()
+            torch.cuda.synchronize()
+            names = [k[-1] for k in lib.PROFILE for _ in lib.PROFILE[k]]
+        finally:
+            lib.PROFILE = None
+        return runner, names
+
+    runner, names = run(True)
+    ac = runner.learner.actor_critic
+    assert sum(f"k_{rnn_type}_seq_fwd" in n for n in names) >= 2 * 2 and any(f"k_{rnn_type}_seq_bwd" in n for n in names), set(names)
+    tr = runner.traj
+    assert tr["rnn_states"].shape == (256, 9, S) and torch.isfinite(tr["rnn_states"]).all()
+    assert tr["rnn_states"][:, 1:].abs().sum(-1).gt(0).any()
+    assert (tr["rnn_states"][:, 1:-1][tr["dones"][:, :-1]].abs().sum() == 0)      # every layer's state zeroed after a done step
+    # one inference step against torch's stacked core on the same weights (model/core.py:37-64)
+    sd = ac.state_dict()
+    core = (torch.nn.LSTM if rnn_type == "lstm" else torch.nn.GRU)(64, 256, 2).cuda().double()
+    core.load_state_dict({k[len("core.core."):]: v.double() for k, v in sd.items() if k.startswith("core.core.")})
+    n = 64
+    feats = torch.randn(n, 64, device="cuda")
+    st = torch.randn(n, S, device="cuda") * 0.5
+    per = st.double().reshape(n, 2, -1).transpose(0, 1).contiguous()
+    if rnn_type == "lstm":
+        out_ref, (h, c) = core(feats.double().unsqueeze(0), (per[..., :256].contiguous(), per[..., 256:].contiguous()))
+        new_ref = torch.cat((h, c), 2)
+    else:
+        out_ref, new_ref = core(feats.double().unsqueeze(0), per)
+    new_ref = new_ref.transpose(0, 1).reshape(n, -1)
+    li0 = [i for i, L in enumerate(ac.layers) if L.role == "rnn_ih"]
+    x = feats
+    for li in li0:  # the model's own one-step path, layer by layer
+        gx = torch.empty((n, ac.layers[li].N), device="cuda")
+        ac._gemm(li, x, x.shape[1], None, 0, 0, gx, n, "boot")
+        x = ac._rnn_step(li, gx, n, dict(states=st), "boot")
+    assert (x.double() - out_ref.squeeze(0)).abs().max() < 2e-5
+    assert (ac.new_rnn_states_of("boot").double() - new_ref).abs().max() < 2e-5
+    p_fused = ac.flat_params.clone()
+    runner2, names2 = run(False)
+    assert not any("_seq_" in n for n in names2)
+    p_step = runner2.learner.actor_critic.flat_params
+    scale = float(p_step.abs().max())
+    assert torch.isfinite(p_fused).all() and (p_fused - p_step).abs().max().item() < 1e-4 * scale
 
 
 @pytest.mark.parametrize("rnn_type", ["lstm", "gru"])

@@ -106,7 +106,8 @@ class ScriptedPolicy:
         if not self.native_state:
             return None
         n, H = self._new, self.H
-        return (n[:, :H].contiguous(), n[:, H:].contiguous() if self.rnn_kind == "lstm" else None)
+        # one (h, c | None) pair per recurrent layer, as the native model hands them to sf_rnn_store_state
+        return [(n[:, :H].contiguous(), n[:, H:].contiguous() if self.rnn_kind == "lstm" else None)]
 
     def new_rnn_states_of(self, tag):
         return self._new
