@@ -240,20 +240,9 @@ class ActorCritic:
             self._segs.append((off, off + _pad(L.K * L.N)))
             off = self._segs[-1][1] + _pad(L.N)
         self.num_flat = off
-        self.flat_params = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.flat_grads = torch.zeros_like(self.flat_params)
-        for L, (o, ob) in zip(self.layers, self._segs):
-            L.w = self.flat_params[o:o + L.K * L.N].view(L.K, L.N)
-            L.b = self.flat_params[ob:ob + L.N]
-            L.gw = self.flat_grads[o:o + L.K * L.N].view(L.K, L.N)
-            L.gb = self.flat_grads[ob:ob + L.N]
-        # Cout-major copies [N, K] of the weights of the layers the gfx950 LDS-DMA forward can take (sf_conv_fwd_t);
-        # refreshed by params_changed() after every parameter update
-        self.flat_params_t = torch.zeros_like(self.flat_params)
-        for L, (o, ob) in zip(self.layers, self._segs):
-            # (incl. the recurrent projections W_ih / W_hh; the narrow heads matrix takes sf_conv_fwd_t's one-wave-per-16-rows kernel)
-            ok = not L.desc.in_u8 and ((L.desc.Cin % 32 == 0 and L.N >= 32) or (L.kind == "heads" and L.K % 16 == 0))
-            L.wt = self.flat_params_t[o:o + L.K * L.N].view(L.N, L.K) if ok else None
+        self.seat_flat(torch.zeros(off, dtype=torch.float32, device=self.device),
+                       torch.zeros(off, dtype=torch.float32, device=self.device),
+                       torch.zeros(off, dtype=torch.float32, device=self.device))
         self.obs_normalizer = None
         if norm_input:
             from sample_factory_amd.utils.normalize import ObservationNormalizer
@@ -273,6 +262,26 @@ class ActorCritic:
         self._rnn_out: Dict = {}   # tag -> [(h_out, c_out | None) per recurrent layer] of the last ONE-STEP forward under that tag
         self._rnn_saved_l: Dict = {}  # layer index -> what the last training pass of that recurrent layer left for its BPTT
         self.initialize_weights()
+
+    def seat_flat(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, flat_params_t: torch.Tensor) -> None:
+        """(re)build every layer's views on the given flat buffers [num_flat] — parameters, gradients and the Cout-major
+        copies [N, K] of the weights of the layers the gfx950 LDS-DMA forward can take (sf_conv_fwd_t; refreshed by
+        params_changed() after every parameter update).  A model composed of several of these (separate actor / critic
+        weights) seats its towers on slices of ONE buffer, so that the optimiser, the gradient exchange and the snapshots
+        see a single flat parameter vector.  Current values are carried over."""
+        old = getattr(self, "flat_params", None)
+        if old is not None:
+            flat_params.copy_(old)
+            flat_params_t.copy_(self.flat_params_t)
+        self.flat_params, self.flat_grads, self.flat_params_t = flat_params, flat_grads, flat_params_t
+        for L, (o, ob) in zip(self.layers, self._segs):
+            L.w = flat_params[o:o + L.K * L.N].view(L.K, L.N)
+            L.b = flat_params[ob:ob + L.N]
+            L.gw = flat_grads[o:o + L.K * L.N].view(L.K, L.N)
+            L.gb = flat_grads[ob:ob + L.N]
+            # (incl. the recurrent projections W_ih / W_hh; the narrow heads matrix takes sf_conv_fwd_t's one-wave-per-16-rows kernel)
+            ok = not L.desc.in_u8 and ((L.desc.Cin % 32 == 0 and L.N >= 32) or (L.kind == "heads" and L.K % 16 == 0))
+            L.wt = flat_params_t[o:o + L.K * L.N].view(L.N, L.K) if ok else None
 
     # ------------------------------------------------------------------------------------------ reference surface
     def num_params(self) -> int:

@@ -64,6 +64,13 @@ def create_actor_critic(cfg, obs_space, action_space, device, all_reduce=None):
     if f.is_default() and len(obs_keys_of(obs_space)) <= 1 and not stacked_rnn and not separate:
         from sample_factory_amd.model.actor_critic import ActorCritic
         return ActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
+    import torch
+    if (f.is_default() and len(obs_keys_of(obs_space)) <= 1 and not stacked_rnn and separate
+            and torch.device(device).type == "cuda" and os.environ.get("SF_NATIVE_SEPARATE_WEIGHTS", "1") != "0"):
+        # cfg.actor_critic_share_weights=False (ActorCriticSeparateWeights, model/actor_critic.py:198-334) on the native
+        # kernels since round 6: two towers on one flat parameter buffer (model/actor_critic_separate.py)
+        from sample_factory_amd.model.actor_critic_separate import SeparateActorCritic
+        return SeparateActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
     # cfg.actor_critic_share_weights=False (ActorCriticSeparateWeights, model/actor_critic.py:198-334: an encoder / core /
     # decoder each for the actor and the critic) and
     # observation dicts of several keys (model/encoder.py:33-69, MultiInputEncoder: one encoder per key, concatenated)

@@ -1660,11 +1660,82 @@ def test_multi_input_model_forward_matches_reference(lib, golden):
     np.testing.assert_allclose(res["values"].cpu().numpy(), g["values"], atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["ff", "gru", "lstm"])
+def test_native_separate_weights_forward_matches_reference(lib, tag):
+    """cfg.actor_critic_share_weights=False on the native towers (model/actor_critic_separate.py): the reference's parameter
+    names / shapes, and — with the same seeded weights — its logits, values and new recurrent state [actor | critic]
+    (tests/golden/model_fwd_separate_*.npz, generated by running ActorCriticSeparateWeights)"""
+    import os
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.actor_critic import get_rnn_size
+    from sample_factory_amd.model.actor_critic_separate import SeparateActorCritic
+    from sample_factory_amd.model.model_factory import create_actor_critic
+    from oracle.weights import seeded_state
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"model_fwd_separate_{tag}.npz"), allow_pickle=True)
+    kw = dict(ff=dict(use_rnn=False), gru=dict(use_rnn=True, rnn_type="gru", rnn_size=12, recurrence=4),
+              lstm=dict(use_rnn=True, rnn_type="lstm", rnn_size=10, recurrence=4, decoder_mlp_layers=[14]))[tag]
+    cfg = default_cfg(actor_critic_share_weights=False, encoder_mlp_layers=[16, 12], nonlinearity="tanh",
+                      normalize_input=False, normalize_returns=False, **kw)
+    cfg.dp_world = 1
+    obs_space = spaces.Dict({"obs": spaces.Box(-10, 10, (8,), np.float32)})
+    ac = create_actor_critic(cfg, obs_space, spaces.Discrete(5), torch.device("cuda"))
+    assert isinstance(ac, SeparateActorCritic)
+    assert [(n, tuple(s)) for n, s in ac.ref_param_shapes()] == \
+        [(str(n), tuple(eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])]
+    st = seeded_state([(str(n), eval(str(s))) for n, s in zip(g["param_names"], g["param_shapes"])], int(g["param_seed"]))
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    sd = ac.state_dict()
+    for k, v in st.items():
+        np.testing.assert_array_equal(sd[k].numpy(), v)  # round trip under the reference's names
+    ac.eval()
+    rnn = torch.from_numpy(g["rnn_states"]).cuda()
+    assert rnn.shape[1] == get_rnn_size(cfg) == ac.rnn_S
+    res = ac.forward({"obs": torch.from_numpy(g["obs"]).cuda()}, rnn)
+    np.testing.assert_allclose(res["action_logits"].cpu().numpy(), g["action_logits"], atol=3e-6, rtol=2e-5)
+    np.testing.assert_allclose(res["values"].cpu().numpy(), g["values"], atol=3e-6, rtol=2e-5)
+    if tag != "ff":
+        np.testing.assert_allclose(res["new_rnn_states"].cpu().numpy(), g["new_rnn_states"], atol=3e-6, rtol=2e-5)
+
+
+def test_native_separate_weights_async_rollout_and_training(lib):
+    """separate actor / critic weights end to end on the native towers in the reference's default mode (async_rl): published
+    weight snapshots of both towers, recurrent state [actor | critic] carried through the slab, one flat buffer under Adam"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_synthetic_continuous_env
+    from sample_factory_amd.model.actor_critic_separate import SeparateActorCritic
+    from sample_factory_amd.train import make_runner
+    register_env("synthetic_ant", make_synthetic_continuous_env)
+    cfg = default_cfg(env="synthetic_ant", actor_critic_share_weights=False, use_rnn=True, rnn_type="lstm", rnn_size=64,
+                      nonlinearity="tanh", normalize_input=True, encoder_mlp_layers=[64, 64], rollout=8, recurrence=8,
+                      batch_size=512, num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=True,
+                      seed=4, serial_mode=False, synthetic_num_agents=128, kl_loss_coeff=0.1)
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    ac = runner.learner.actor_critic
+    assert isinstance(ac, SeparateActorCritic) and ac.rnn_S == 4 * 64 and runner.traj["rnn_states"].shape[-1] == 256
+    p0 = ac.flat_params.clone()
+    for _ in range(4):
+        stats = runner.iteration()
+    torch.cuda.synchronize()
+    runner.stop_sampler_thread()
+    assert np.isfinite(stats["train"]["loss"]) and torch.isfinite(ac.flat_params).all() and not torch.equal(p0, ac.flat_params)
+    na = ac.actor.num_flat
+    assert not torch.equal(p0[:na], ac.flat_params[:na]) and not torch.equal(p0[na:], ac.flat_params[na:])  # both towers train
+    st = runner.traj["rnn_states"]
+    assert torch.isfinite(st).all() and st[:, 1:, :128].abs().sum() > 0 and st[:, 1:, 128:].abs().sum() > 0
+    assert float(ac.actor.layers[-1].w[:, 0].abs().max()) == 0.0 and float(ac.critic.layers[-1].w[:, 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native_towers", "torch_path"])
 @pytest.mark.parametrize("name", ["sep_gru", "sep_mlp"])
-def test_learner_train_matches_reference_separate_actor_critic_weights(lib, golden, tmp_path, name):
+def test_learner_train_matches_reference_separate_actor_critic_weights(lib, golden, tmp_path, name, native, monkeypatch):
     """cfg.actor_critic_share_weights=False (ActorCriticSeparateWeights, model/actor_critic.py:198-334): the reference's
-    Learner.train replayed on the torch model path create_actor_critic picks for it — two encoders / cores, recurrent
-    state [actor | critic] carried and chunk-started through the native slab kernels, loss / clip / Adam native."""
+    Learner.train replayed — two encoders / cores, recurrent state [actor | critic] carried and chunk-started through the
+    native slab kernels, loss / clip / Adam native.  native_towers (the default since round 6): two native towers on one flat
+    parameter buffer (model/actor_critic_separate.py); torch_path (SF_NATIVE_SEPARATE_WEIGHTS=0): the torch module."""
+    monkeypatch.setenv("SF_NATIVE_SEPARATE_WEIGHTS", "1" if native else "0")
     from sample_factory_amd.algo.learning.learner import Learner, ParameterServer
     from sample_factory_amd.algo.utils.env_info import EnvInfo
     from sample_factory_amd.algo.utils.shared_buffers import alloc_trajectory_tensors
@@ -1685,7 +1756,8 @@ def test_learner_train_matches_reference_separate_actor_critic_weights(lib, gold
     learner = Learner(cfg, env_info, pv, 0, ParameterServer(0, pv))
     learner.init()
     ac = learner.actor_critic
-    assert isinstance(ac, TorchPolicyAdapter)
+    from sample_factory_amd.model.actor_critic_separate import SeparateActorCritic
+    assert isinstance(ac, SeparateActorCritic if native else TorchPolicyAdapter)
     assert get_rnn_size(cfg) == (64 if rnn else 2) == int(g["in_rnn_states"].shape[-1])
     assert [n for n, _ in ac.ref_param_shapes()] == list(g["param_names"])
     load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
@@ -1698,7 +1770,9 @@ def test_learner_train_matches_reference_separate_actor_critic_weights(lib, gold
     stats = learner.train(batch)
     assert stats["learner_env_steps"] == int(g["env_steps"]) and learner.train_step == int(g["train_step"])
     np.testing.assert_allclose(learner._grad_norms, g["grad_norms"], rtol=5e-4)
-    compare_post_train(learner, g, before, name, **TIGHT)
+    compare_post_train(learner, g, before, name + ("" if native else "_torch_path"), **TIGHT)
+    if native:  # the heads columns a tower does not own never move
+        assert float(ac.actor.layers[-1].w[:, 0].abs().max()) == 0.0 and float(ac.critic.layers[-1].w[:, 1:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("name", ["gru", "lstm_inv", "gru2", "lstm2"])
