@@ -453,7 +453,8 @@ def test_host_env_async_sampler_thread_with_recurrent_core(rnn_type):
     assert trained == 8 and runner._thread_error is None
     ac = runner.learner.actor_critic
     assert set(ac._rnn_out) >= {"inf", "inf1", "boot"}          # sampler tags and the learner's tag kept apart
-    assert ac._rnn_out["inf"][0].shape[0] == 64 and ac._rnn_out["boot"][0].shape[0] == 128
+    # (one (h, c | None) pair per recurrent layer)
+    assert ac._rnn_out["inf"][0][0].shape[0] == 64 and ac._rnn_out["boot"][0][0].shape[0] == 128
     assert torch.isfinite(ac.flat_params).all()
     H = 64
     for e in range(2):
