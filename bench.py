@@ -226,18 +226,20 @@ def _cpulist(text: str):
     return out
 
 
-def numa_plan(local_rank: int, device_nodes, allowed, node_cpus):
+def numa_plan(local_rank: int, device_nodes, allowed, node_cpus, core_of=None):
     """cores of `local_rank`: the cores of its GPU's NUMA node that this process may use, split evenly (in local-rank order)
     among the ranks whose GPUs sit on the same node.  device_nodes[r] = NUMA node of rank r's GPU (-1 / None: unknown ->
-    no pinning for that rank), node_cpus[node] = cpu ids.  Pure function (tests/test_abi_and_host.py)."""
+    no pinning for that rank), node_cpus[node] = cpu ids, core_of[cpu] = physical core of a logical cpu (SMT siblings stay
+    with one rank: a node lists them as "0-63,128-191", and a split of the plain order would hand one rank the first threads
+    and its neighbour the second threads of the SAME cores).  Pure function (tests/test_abi_and_host.py)."""
     node = device_nodes[local_rank]
     if node is None or node < 0 or node not in node_cpus:
         return None
-    cpus = sorted(set(node_cpus[node]) & set(allowed))
+    cpus = sorted(set(node_cpus[node]) & set(allowed), key=(lambda c: (core_of.get(c, c), c)) if core_of else None)
     peers = [r for r, nd in enumerate(device_nodes) if nd == node]
     k, m = peers.index(local_rank), len(peers)
     share = cpus[k * len(cpus) // m:(k + 1) * len(cpus) // m]
-    return share or None
+    return sorted(share) or None
 
 
 def pin_rank_to_gpu_numa(local_rank: int, local_world: int, sysfs: str = "/sys"):
@@ -258,7 +260,15 @@ def pin_rank_to_gpu_numa(local_rank: int, local_world: int, sysfs: str = "/sys")
         node_cpus = {}
         for nd in {n for n in nodes if n is not None and n >= 0}:
             node_cpus[nd] = _cpulist(open(f"{sysfs}/devices/system/node/node{nd}/cpulist").read())
-        share = numa_plan(local_rank, nodes, os.sched_getaffinity(0), node_cpus)
+        core_of = {}
+        for cpus_ in node_cpus.values():
+            for c_ in cpus_:
+                try:
+                    t_ = f"{sysfs}/devices/system/cpu/cpu{c_}/topology/"
+                    core_of[c_] = (int(open(t_ + "physical_package_id").read()), int(open(t_ + "core_id").read()))
+                except (OSError, ValueError):
+                    pass
+        share = numa_plan(local_rank, nodes, os.sched_getaffinity(0), node_cpus, core_of or None)
         if not share:
             return {"numa_node": nodes[local_rank], "cpus": None, "note": "GPU's NUMA node unknown: affinity left as it was"}
         os.sched_setaffinity(0, share)

@@ -504,3 +504,7 @@ def test_bench_numa_plan_splits_a_node_between_the_ranks_on_it():
     assert bench.numa_plan(0, [0, 1], [0, 1, 2, 3, 40], node_cpus) == [0, 1, 2, 3]      # the process's own mask is respected
     assert bench.numa_plan(1, [0, None], range(128), node_cpus) is None and bench.numa_plan(0, [-1], range(8), {}) is None
     assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # SMT siblings (cpu c and c + 64 share a core on this host's numbering) stay with one rank
+    core_of = {c: (0, c % 32) for c in node_cpus[0]}
+    a, b = (bench.numa_plan(r, [0, 0], range(128), node_cpus, core_of) for r in range(2))
+    assert a == list(range(0, 16)) + list(range(64, 80)) and b == list(range(16, 32)) + list(range(80, 96))
