@@ -866,6 +866,10 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
     if action_kind == "tuple":
         action_space = gym.spaces.Tuple([gym.spaces.Discrete(int(n_)) for n_ in A])
         heads, A = [int(n_) for n_ in A], int(sum(A))
+    elif action_kind == "tuple_mixed":  # a negative entry -D is a Box(D) member (2 D action parameters, D action columns)
+        action_space = gym.spaces.Tuple([gym.spaces.Discrete(int(n_)) if n_ > 0 else
+                                         gym.spaces.Box(-1.0, 1.0, (-int(n_),), np.float32) for n_ in A])
+        heads, A = [int(n_) for n_ in A], int(sum(n_ if n_ > 0 else -2 * n_ for n_ in A))
     elif action_kind == "box":
         action_space = gym.spaces.Box(-1.0, 1.0, (int(A),), np.float32)
         heads, A = [], 2 * int(A)
@@ -910,6 +914,8 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
     dist = get_action_distribution(action_space, tl.reshape(-1, A))
     if action_kind == "tuple":  # per-head arg-max (TupleActionDistribution.argmax is written for ONE sample: enjoy.py)
         acts = torch.stack([argmax_actions(d_) for d_ in dist.distributions], dim=1)
+    elif action_kind == "tuple_mixed":  # arg-max of a Discrete member, the means of a Box member, column-wise
+        acts = torch.cat([argmax_actions(d_).reshape(steps * B, -1).float() for d_ in dist.distributions], dim=1)
     else:
         acts = argmax_actions(dist)                  # deterministic actions (action_distributions.py:73-81)
     acts = acts.reshape(steps * B, -1)               # [N, num_actions] as the actor-critic stores them
@@ -967,9 +973,13 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
                   action_kind=action_kind, head_sizes=np.asarray(heads, np.int64),
                   # what env.step received (preprocess_actions): one array for Discrete / Box, a LIST of per-head arrays for
                   # a Tuple space -> stacked here as [steps, heads, B]
-                  env_seen_actions=np.stack([np.stack(a) if len(a) > 1 else a[0] for a in env_box["env"].seen_actions]),
+                  # (a Tuple with a Box member: the members differ in shape and dtype -> env_seen_member<i>, [steps, B(, D)])
+                  env_seen_actions=(np.zeros(0) if action_kind == "tuple_mixed" else
+                                    np.stack([np.stack(a) if len(a) > 1 else a[0] for a in env_box["env"].seen_actions])),
                   env_seen_is_list=bool(len(env_box["env"].seen_actions[0]) > 1),
                   env_seen_actions_dtype=str(env_box["env"].seen_actions[0][0].dtype),
+                  **({f"env_seen_member{i}": np.stack([a[i] for a in env_box["env"].seen_actions])
+                      for i in range(len(heads))} if action_kind == "tuple_mixed" else {}),
                   final_ep_reward=runner.curr_episode_reward.numpy(), final_ep_len=runner.curr_episode_len.numpy(),
                   final_last_rnn=runner.last_rnn_state.numpy())
     for key, v in script["obs"].items():
@@ -995,6 +1005,13 @@ def gen_rollout_case(name, B, T, n_rollouts, obs_spec, A, rnn, reward_scale, rew
     save("rollout_" + name, **arrays)
 
 
+def gen_rollout_tuple_mixed():
+    """Tuple(Discrete(3), Box(2), Discrete(4)) through the reference's runner: slab layout of the action columns and the
+    per-member list preprocess_actions hands the env (batched_sampling.py:51-59)"""
+    gen_rollout_case("tuple_mixed", B=12, T=6, n_rollouts=2, obs_spec={"obs": ((11,), np.float32)}, A=(3, -2, 4), rnn=None,
+                     reward_scale=1.0, reward_clip=1000.0, async_rl=False, seed=508, action_kind="tuple_mixed")
+
+
 def gen_rollout():
     vec = {"obs": ((11,), np.float32)}
     gen_rollout_case("ff_sync", B=24, T=8, n_rollouts=3, obs_spec=vec, A=6, rnn=None, reward_scale=1.0, reward_clip=1000.0,
@@ -1009,6 +1026,7 @@ def gen_rollout():
                      reward_clip=1000.0, async_rl=False, seed=506, action_kind="tuple")
     gen_rollout_case("box_actions", B=12, T=6, n_rollouts=2, obs_spec=vec, A=3, rnn=("gru", 8), reward_scale=1.0,
                      reward_clip=1000.0, async_rl=False, seed=507, action_kind="box", gpu_actions=True)
+    gen_rollout_tuple_mixed()
     gen_rollout_case("multikey_policy1", B=8, T=5, n_rollouts=2,
                      obs_spec={"obs": ((7,), np.float32), "aux": ((2, 3, 3), np.uint8)}, A=3, rnn=("gru", 8),
                      reward_scale=1.0, reward_clip=1.0, async_rl=False, seed=505, num_policies=2, worker_idx=1)
@@ -1023,6 +1041,8 @@ def main():
         gen_rms()
     if "dist" in which:
         gen_action_dist()
+    if "rollout_tuple_mixed" in which:
+        gen_rollout_tuple_mixed()
     if "learner" in which:
         gen_prepare_and_losses()
     for w in which:  # learner:<case>[,<case>] = only those cases of the learner fixtures

@@ -26,7 +26,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1", "tuple_heads", "box_actions"]
+CASES = ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1", "tuple_heads", "box_actions",
+         "tuple_mixed"]
 
 
 def _spaces(g):
@@ -39,6 +40,9 @@ def _spaces(g):
     kind = str(g["action_kind"]) if "action_kind" in g.files else "discrete"
     if kind == "tuple":
         act = spaces.Tuple([spaces.Discrete(int(n)) for n in g["head_sizes"]])
+    elif kind == "tuple_mixed":  # a negative head size -D is a Box(D) member
+        act = spaces.Tuple([spaces.Discrete(int(n)) if n > 0 else spaces.Box(-1.0, 1.0, (-int(n),), np.float32)
+                            for n in g["head_sizes"]])
     elif kind == "box":
         act = spaces.Box(-1.0, 1.0, (int(g["A"]) // 2,), np.float32)
     else:
@@ -67,7 +71,10 @@ class ScriptedEnv:
         return self._obs(), {}
 
     def step(self, actions):
-        self.seen_actions.append(actions.copy() if isinstance(actions, np.ndarray) else actions.cpu().numpy())
+        if isinstance(actions, (list, tuple)):   # Tuple with a Box member: one array per member
+            self.seen_actions.append([a.copy() if isinstance(a, np.ndarray) else a.cpu().numpy() for a in actions])
+        else:
+            self.seen_actions.append(actions.copy() if isinstance(actions, np.ndarray) else actions.cpu().numpy())
         k = self.k
         self.k += 1
         return self._obs(), self._out(self.g["in_rew"][k]), self._out(self.g["in_term"][k]), \
@@ -175,7 +182,7 @@ def test_rollout_slab_equals_the_reference(golden, case, host_env, native_state)
                 continue
             if name == "log_prob_actions":  # log-softmax / Normal log-density: expf / logf vs torch's, summed over the heads
                 kind_ = str(g["action_kind"]) if "action_kind" in g.files else "discrete"
-                tol = dict(discrete=1e-6, tuple=2e-6, box=5e-6)[kind_]
+                tol = dict(discrete=1e-6, tuple=2e-6, box=5e-6, tuple_mixed=6e-6)[kind_]
                 np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=f"{case} rollout {r} {name}")
             else:
                 assert got.dtype == want.dtype or name.startswith("obs_"), (name, got.dtype, want.dtype)
@@ -191,10 +198,20 @@ def test_rollout_slab_equals_the_reference(golden, case, host_env, native_state)
                                           err_msg=f"policy input rnn state step {kk}")
     # ---- the env was stepped with what the reference's preprocess_actions handed ITS env (batched_sampling.py:30-82):
     # int32 [B] for one Discrete head, int32 [B, heads] for an all-Discrete Tuple, f32 [B, D] for a Box
-    seen = np.stack(env.seen_actions)
-    assert str(seen.dtype) == str(g["env_seen_actions_dtype"]) and seen.shape == g["env_seen_actions"].shape
     kind = str(g["action_kind"]) if "action_kind" in g.files else "discrete"
-    if kind == "box":  # deterministic: the means, bit for bit
+    if kind == "tuple_mixed":  # a list with one array per member: int32 [B] / f32 [B, D] / int32 [B]
+        assert bool(g["env_seen_is_list"]) and all(isinstance(a, list) for a in env.seen_actions)
+        for i in range(len(g["head_sizes"])):
+            seen, want = np.stack([a[i] for a in env.seen_actions]), g[f"env_seen_member{i}"]
+            assert seen.dtype == want.dtype and seen.shape == want.shape, (i, seen.dtype, seen.shape, want.dtype, want.shape)
+            np.testing.assert_array_equal(seen, want, err_msg=f"member {i} handed to the env")
+        seen = None
+    else:
+        seen = np.stack(env.seen_actions)
+        assert str(seen.dtype) == str(g["env_seen_actions_dtype"]) and seen.shape == g["env_seen_actions"].shape
+    if seen is None:
+        pass
+    elif kind == "box":  # deterministic: the means, bit for bit
         np.testing.assert_array_equal(seen, g["env_seen_actions"])
         np.testing.assert_array_equal(seen, g["in_logits"][..., :seen.shape[-1]])
     else:

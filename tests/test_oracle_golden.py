@@ -234,7 +234,7 @@ def test_float64_anchor_of_the_train_replays(golden, name, ref_bound):
 
 
 @pytest.mark.parametrize("case", ["ff_sync", "gru_scale_clip", "lstm_async", "u8_image", "multikey_policy1", "tuple_heads",
-                                  "box_actions"])
+                                  "box_actions", "tuple_mixed"])
 def test_rollout_restatement_equals_the_reference_runner(golden, case):
     """oracle.rollout_replay (numpy) against slab rows written by the reference's BatchedVectorEnvRunner
     (tests/golden/rollout_*.npz, oracle/gen_golden.py gen_rollout_case): bit-equal"""
@@ -271,6 +271,31 @@ def test_rollout_restatement_equals_the_reference_runner(golden, case):
         np.testing.assert_allclose(la.reshape(g["ref_logp"].shape), g["ref_logp"], atol=2e-6)
         # what the env was handed: the [B, heads] int32 array itself (preprocess_actions' all_discrete branch)
         assert not bool(g["env_seen_is_list"]) and g["env_seen_actions"].shape[1:] == g["ref_actions"].shape[1:]
+    elif kind == "tuple_mixed":  # Tuple(Discrete, Box, Discrete): members add up, the env gets ONE ARRAY PER MEMBER
+        heads = [int(v) for v in g["head_sizes"]]
+        la, o, c = 0.0, 0, 0
+        assert bool(g["env_seen_is_list"]) and g["ref_actions"].shape[-1] == sum(1 if n > 0 else -n for n in heads)
+        for h, n in enumerate(heads):
+            seen = g[f"env_seen_member{h}"]
+            if n > 0:
+                col = g["ref_actions"][..., c]
+                la = la + oracle.categorical(g["in_logits"][..., o:o + n].reshape(-1, n), col.reshape(-1))[1]
+                assert seen.dtype == np.int32 and seen.shape == col.shape   # batched_sampling.py:56-57
+                np.testing.assert_array_equal(seen, col.astype(np.int32))
+                o, c = o + n, c + 1
+            else:
+                D = -n
+                mu, ls = g["in_logits"][..., o:o + D], g["in_logits"][..., o + D:o + 2 * D]
+                np.testing.assert_array_equal(g["ref_actions"][..., c:c + D], mu)   # deterministic action = the mean
+                sd = np.clip(np.exp(ls.astype(np.float64)), 1e-4, 1e4)
+                la = la + (-np.log(sd) - 0.5 * np.log(2 * np.pi)).sum(-1).reshape(-1)
+                assert seen.dtype == np.float32                                # Box member: f32 [B, D], not clipped here
+                np.testing.assert_array_equal(seen, mu)
+                o, c = o + 2 * D, c + D
+        np.testing.assert_allclose(np.asarray(la).reshape(g["ref_logp"].shape), g["ref_logp"], atol=1e-5)
+        # oracle.sample_tuple's column layout is the slab's: [discrete | D box columns | discrete]
+        acts, _ = oracle.sample_tuple(g["in_logits"].reshape(-1, int(g["A"])), heads, seed=1, step=0)[:2]
+        assert acts.shape[1] == g["ref_actions"].shape[-1]
     else:  # Box: deterministic action = the mean, log-density of a diagonal normal at its mean
         D = int(g["A"]) // 2
         np.testing.assert_array_equal(g["ref_actions"], g["in_logits"][..., :D])

@@ -245,6 +245,27 @@ def test_action_format_handed_to_the_env_equals_the_reference(case):
         assert isinstance(one, int) and one == int(seen[0][0])
 
 
+def test_mixed_tuple_members_handed_to_the_env_equal_the_reference():
+    """Tuple(Discrete(3), Box(2), Discrete(4)): `_format_actions` hands the env one array per member, the same arrays (dtype,
+    shape, values) the reference's `preprocess_actions` (batched_sampling.py:51-59) handed the scripted env when
+    tests/golden/rollout_tuple_mixed.npz was recorded."""
+    import os
+    from sample_factory_amd.algo.sampling.parallel_env import _format_actions
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "rollout_tuple_mixed.npz"), allow_pickle=True)
+    heads, ref = [int(v) for v in d["head_sizes"]], d["ref_actions"]       # [steps, agents, action columns] f32
+    assert bool(d["env_seen_is_list"]) and heads == [3, -2, 4]
+    for t in range(ref.shape[0]):
+        got = _format_actions(ref[t], heads, continuous=False, batched=True)
+        assert isinstance(got, list) and len(got) == len(heads)
+        for i, a in enumerate(got):
+            want = d[f"env_seen_member{i}"][t]
+            assert a.dtype == want.dtype and a.shape == want.shape, (i, a.dtype, a.shape, want.dtype, want.shape)
+            assert np.array_equal(a, want)
+    one = _format_actions(ref[0][:1], heads, continuous=False, batched=False)  # single-agent env: no agent axis
+    assert isinstance(one[0], int) and one[0] == int(d["env_seen_member0"][0, 0])
+    assert one[1].shape == (2,) and np.array_equal(one[1], d["env_seen_member1"][0, 0])
+
+
 class _HostVecEnv:
     """batched HOST env (num_agents attribute, numpy observations): the reference steps such an env as it is"""
     num_agents = 4
