@@ -12,6 +12,7 @@ CPU every step: batched_sampling.py:216,323,390-392; torch_utils.py:58-66).
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
 from typing import Dict, Optional
 
@@ -70,6 +71,14 @@ class BatchedVectorEnvRunner:
         self._term = torch.zeros(self.B, dtype=torch.bool, device=dev)
         self._trunc = torch.zeros(self.B, dtype=torch.bool, device=dev)
         # obs["action_mask"] (inference_worker.py:324-331): kept in the slab like every other obs key, used by the sampler
+        # launch programs (lib.LaunchProgram): the library calls of step t — policy forward + sampler, and the trajectory
+        # write + state store behind the env step — recorded once per (t, slab, stream, model layout) and replayed with
+        # one foreign call per launch.  The two values that change between replays live in ctypes cells.
+        self._c_step, self._c_ver = C.c_uint32(0), C.c_float(0.0)
+        self._progs: Dict = {}
+        self._progs_layout = None
+        self.program_replays = 0
+        self._launch_key = getattr(actor_critic, "launch_key", None) if lib.LAUNCH_PROGRAMS else None
         self.masked = "action_mask" in traj["obs"]
         if self.masked and (self.continuous or len(self.heads) != 1):
             raise NotImplementedError("action masks are supported for a single Discrete action space")
@@ -176,35 +185,72 @@ class BatchedVectorEnvRunner:
         self.rollout_step_begin(t)
         self.rollout_step_finish(t)
 
+    def _program(self, half: str, t: int, extra=()):
+        """(program to replay | None, key to record under | None) for one half of step t.  A key is run plainly the first
+        time it is seen (buffers are allocated lazily), recorded the second time, replayed from the third on; anything
+        that moves an address the calls hold changes the key (the model's launch_key, the slab rows, the stream)."""
+        if self._launch_key is None:
+            return None, None
+        layout, weights = self._launch_key(self.tag)
+        if layout != self._progs_layout:  # a buffer was (re)allocated: drop every program (and the memory they hold)
+            self._progs.clear()
+            self._progs_layout = layout
+        key = (half, t, self.traj["rewards"].data_ptr(), self._deterministic, torch.cuda.current_stream().cuda_stream,
+               weights, extra)
+        slot = self._progs.get(key)
+        if slot is None:                       # first sight: run plainly
+            if len(self._progs) > 64 * self.T:
+                self._progs.clear()
+            self._progs[key] = False
+            return None, None
+        if slot is False:                      # second sight: record
+            return None, key
+        return (slot, None) if slot.unsafe is None else (None, None)
+
     def rollout_step_begin(self, t: int) -> None:
         """policy forward + sampling of step t and, for in-process envs, the env step itself"""
-        tr, T, B, A = self.traj, self.T, self.B, self.A
-        ver, deterministic, cfg = self._ver, self._deterministic, self.cfg
-        rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
-        x = {k: tr["obs"][k][:, t] for k in self.obs_keys} if self.multi_key else self.obs[:, t]
-        heads = self.ac.forward_heads(x, B, sample_stride=self.obs.stride(0), tag=self.tag, rnn=rnn)[-1]
-        if self.masked:
-            mk = tr["obs"]["action_mask"][:, t]
-            lib.sample_write_step_masked(heads[:, 1:], self.ld, heads[:, 0], self.ld, mk, mk.stride(0), B, A, T, t,
-                                         self.sample_seed, self.global_step, self.row0, ver, deterministic,
-                                         tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
-                                         tr["policy_version"], self.env_actions)
-        elif len(self.heads) > 1:  # Tuple space: one categorical per Discrete member, a diagonal normal per Box member
-            lib.sample_write_step_tuple(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, self.heads, T, t,
-                                        self.sample_seed, self.global_step, self.row0, ver, deterministic,
-                                        tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
-                                        tr["policy_version"], None if self.mixed else self.env_actions)
+        self._c_step.value, self._c_ver.value = self.global_step & 0xFFFFFFFF, self._ver
+        prog, rec_key = self._program("policy", t)
+        if prog is not None:
+            prog.replay()
+            self.program_replays += 1
+        elif rec_key is not None:
+            with lib.record_launches() as prog:
+                self._policy_and_sample(t)
+            self._progs[rec_key] = prog
         else:
-            lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
-                                  self.global_step, self.row0, ver, deterministic, tr["actions"],
-                                  tr["action_logits"], tr["log_prob_actions"], tr["values"], tr["policy_version"],
-                                  None if self.continuous else self.env_actions, action_kind=int(self.continuous))
+            self._policy_and_sample(t)
+        tr = self.traj
         # Box: f32 [B, D] view of the slab; Tuple with a Box member: f32 [B, columns] view, split per member for the env
         env_actions = tr["actions"][:, t] if (self.continuous or self.mixed) else self.env_actions
         if self.async_env:  # worker processes step the envs from here on (parallel_env.py); rollout_step_finish collects
             self.env.step_async(self._actions_to_host(env_actions))
             return
         self._env_step_and_record(t, env_actions)
+
+    def _policy_and_sample(self, t: int) -> None:
+        tr, T, B, A = self.traj, self.T, self.B, self.A
+        # (ctypes cells, not numbers: a recorded program reads their CURRENT value at every replay)
+        ver, deterministic, cfg, step = self._c_ver, self._deterministic, self.cfg, self._c_step
+        rnn = dict(states=tr["rnn_states"][:, t]) if self.rnn else None  # the state INPUT of step t (parity trap 13)
+        x = {k: tr["obs"][k][:, t] for k in self.obs_keys} if self.multi_key else self.obs[:, t]
+        heads = self.ac.forward_heads(x, B, sample_stride=self.obs.stride(0), tag=self.tag, rnn=rnn)[-1]
+        if self.masked:
+            mk = tr["obs"]["action_mask"][:, t]
+            lib.sample_write_step_masked(heads[:, 1:], self.ld, heads[:, 0], self.ld, mk, mk.stride(0), B, A, T, t,
+                                         self.sample_seed, step, self.row0, ver, deterministic,
+                                         tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
+                                         tr["policy_version"], self.env_actions)
+        elif len(self.heads) > 1:  # Tuple space: one categorical per Discrete member, a diagonal normal per Box member
+            lib.sample_write_step_tuple(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, self.heads, T, t,
+                                        self.sample_seed, step, self.row0, ver, deterministic,
+                                        tr["actions"], tr["action_logits"], tr["log_prob_actions"], tr["values"],
+                                        tr["policy_version"], None if self.mixed else self.env_actions)
+        else:
+            lib.sample_write_step(heads[:, 1:], self.ld, heads[:, 0], self.ld, B, A, T, t, self.sample_seed,
+                                  step, self.row0, ver, deterministic, tr["actions"],
+                                  tr["action_logits"], tr["log_prob_actions"], tr["values"], tr["policy_version"],
+                                  None if self.continuous else self.env_actions, action_kind=int(self.continuous))
 
     def rollout_step_finish(self, t: int) -> None:
         """second half of a step for envs that are stepped asynchronously by worker processes (`step_async` / `step_wait`):
@@ -242,6 +288,24 @@ class BatchedVectorEnvRunner:
                 rew = torch.as_tensor(rew, dtype=torch.float32, device=self.device).contiguous()
                 term = torch.as_tensor(term, dtype=torch.bool, device=self.device).contiguous()
                 trunc = torch.as_tensor(trunc, dtype=torch.bool, device=self.device).contiguous()
+        parts = self.ac.new_rnn_parts_of(self.tag) if self.rnn else None
+        if (self.rnn and parts is None) or not (self.zero_copy or self.host_env):
+            prog = rec_key = None  # torch model path (the state store is a torch op) / env outputs in fresh tensors every step
+        else:
+            prog, rec_key = self._program("record", t, (rew.data_ptr(), term.data_ptr(), trunc.data_ptr()))
+        if prog is not None:
+            prog.replay()
+        elif rec_key is not None:
+            with lib.record_launches() as prog:
+                self._record_step(t, rew, term, trunc)
+            self._progs[rec_key] = prog
+        else:
+            self._record_step(t, rew, term, trunc)
+        self.global_step += 1
+
+    def _record_step(self, t: int, rew, term, trunc) -> None:
+        """env outputs of step t -> slab (rewards shaped, dones, episode statistics), next-step recurrent state"""
+        tr, T, cfg = self.traj, self.T, self.cfg
         lib.traj_write_env_step(rew, term, trunc, T, t, cfg.reward_scale, cfg.reward_clip, self.policy_id,
                                 tr["rewards"], tr["dones"], tr["time_outs"], tr["policy_id"], self.ep_return,
                                 self.ep_len, self.ep_stats)
@@ -256,7 +320,6 @@ class BatchedVectorEnvRunner:
             else:                  # torch model path
                 keep = (~tr["dones"][:, t]).to(torch.float32).unsqueeze(1)
                 torch.mul(self.ac.new_rnn_states_of(self.tag), keep, out=tr["rnn_states"][:, t + 1])
-        self.global_step += 1
 
     def set_slab(self, traj: TensorDict, carry_from: Optional[TensorDict] = None) -> None:
         """async mode: switch to another slab; its step 0 continues from the last step of `carry_from`"""

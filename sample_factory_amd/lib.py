@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -53,6 +54,97 @@ SYMBOLS = [
 
 _lib: Optional[C.CDLL] = None
 
+# ---- launch programs.  A rollout step of a small network is eight kernels of 5-50 us; issued through the wrappers below
+# (argument checks, pointer conversions, the model's layer loop) the host needs ~20 us per launch and the GPU idles a third
+# of the step (profiles/r06_p_c5_gaps.txt).  A LaunchProgram is the list of foreign calls one such step made, with their
+# CONVERTED arguments: replaying it costs one ctypes call per launch.  What varies between replays (the sampler's Philox
+# step, the policy version) is passed as a ctypes cell (c_uint32 / c_float) whose value the caller updates; everything
+# else — pointers, strides, sizes, the stream — is constant under the key the caller files the program under.
+_REC = threading.local()  # .rec: the _Recorder of the program this THREAD is recording (the learner thread is not affected)
+_QUERIES = ("_supported", "_workspace", "_kernel_name", "sf_last_error", "sf_abi_version")  # no launch: never recorded
+_HOST_STATE = ("sf_h2d_rows", "sf_dp_", "sf_allreduce_grads", "sf_clock_probe")  # read host memory / communicators: not replayable
+LAUNCH_PROGRAMS = os.environ.get("SF_LAUNCH_PROGRAMS", "1") != "0"
+
+
+class LaunchProgram:
+    __slots__ = ("calls", "keep", "unsafe")
+
+    def __init__(self):
+        self.calls = []     # (foreign function, converted arguments, name, profiling key | None)
+        self.keep = []      # every tensor whose address a call holds: its memory stays allocated as long as the program
+        self.unsafe = None  # reason this recording must not be replayed (work outside the library was part of the step)
+
+    def replay(self) -> None:
+        if PROFILE is None:
+            for fn, args, what, _ in self.calls:
+                rc = fn(*args)
+                if rc:
+                    _check(rc, what)
+        else:  # bench.py's per-launch HIP events see replayed launches like any other
+            for fn, args, what, key in self.calls:
+                with _timed(key):
+                    _check(fn(*args), what)
+
+
+class _Recorder:
+    """stands where the CDLL stands while a program is recorded: every launch goes through AND is logged"""
+
+    def __init__(self, real, prog: LaunchProgram):
+        self._real, self.prog, self.key = real, prog, None
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if name.endswith(_QUERIES):
+            return fn
+        if name.startswith(_HOST_STATE):
+            self.prog.unsafe = self.prog.unsafe or name
+            return fn
+
+        def call(*args):
+            self.prog.calls.append((fn, args, name, self.key))
+            return fn(*args)
+        return call
+
+
+class record_launches:
+    """with record_launches() as prog: ... — every library launch the block issues on this thread runs and is logged"""
+
+    def __enter__(self) -> LaunchProgram:
+        if getattr(_REC, "rec", None) is not None:
+            raise SfHipError("record_launches: already recording on this thread")
+        prog = LaunchProgram()
+        real = load()
+        _REC.rec = _Recorder(real, prog)
+        return prog
+
+    def __exit__(self, *a):
+        _REC.rec = None
+        return False
+
+
+def recording_unsafe(reason: str) -> None:
+    """called by code that is about to do work OUTSIDE the library (a torch op, a host copy) as part of a step: a program
+    being recorded around it would silently drop that work on replay, so it is marked and never replayed"""
+    rec = getattr(_REC, "rec", None)
+    if rec is not None:
+        rec.prog.unsafe = rec.prog.unsafe or reason
+
+
+def _keep(t):
+    rec = getattr(_REC, "rec", None)
+    if rec is not None:
+        rec.prog.keep.append(t)
+
+
+def _vp(t: torch.Tensor) -> C.c_void_p:
+    """address of a device view whose layout the caller has checked"""
+    _keep(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def _keys_wanted() -> bool:
+    return PROFILE is not None or getattr(_REC, "rec", None) is not None
+
 # Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).  Events are recorded on
 # torch's CURRENT stream, which is the stream every call below launches on.  PROFILE maps key -> [(start, end), ...].
 PROFILE: Optional[dict] = None
@@ -69,6 +161,9 @@ PROFILE_SEEN: dict = {}  # key -> launches seen so far (timed or not)
 
 class _timed:
     def __init__(self, key):
+        self.rec = getattr(_REC, "rec", None)
+        if self.rec is not None:
+            self.rec.key = key  # the launches inside this block replay under the same key
         self.key = key if PROFILE is not None and key is not None and \
             (PROFILE_ONLY is None or key in PROFILE_ONLY) else None
         if self.key is not None and PROFILE_STRIDE > 1:
@@ -90,6 +185,8 @@ class _timed:
         if self.key is not None:
             self.e.record()
             PROFILE.setdefault(self.key, []).append((self.s, self.e))
+        if self.rec is not None:
+            self.rec.key = None
         return False
 
 
@@ -99,7 +196,7 @@ _names: dict = {}
 
 def _dkey(op, n, d):
     """profiling key of a network launch: (op, n, geometry..., kernel instantiation name as rocprofv3 prints it)"""
-    if PROFILE is None:
+    if not _keys_wanted():
         return None
     k = (op, int(n), d.Cin, d.H, d.W, d.Cout, d.KH, d.stride, d.OH, d.OW, d.in_u8)
     name = _names.get(k)
@@ -117,6 +214,9 @@ def conv_kernel_name(op: int, n: int, desc) -> str:
 def load() -> C.CDLL:
     """Load the HIP library or fail loudly (no CPU path exists)."""
     global _lib
+    rec = getattr(_REC, "rec", None)
+    if rec is not None:
+        return rec
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise SfHipError(
@@ -152,7 +252,7 @@ def ptr(t: Optional[torch.Tensor], kind: str, name: str = "tensor") -> C.c_void_
         raise SfHipError(f"{name}: tensor lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
     if not t.is_contiguous():
         raise SfHipError(f"{name}: tensor must be contiguous (shape {tuple(t.shape)}, strides {t.stride()})")
-    return C.c_void_p(t.data_ptr())
+    return _vp(t)
 
 
 def _raw(t: torch.Tensor, kind: str, name: str) -> C.c_void_p:
@@ -162,7 +262,7 @@ def _raw(t: torch.Tensor, kind: str, name: str) -> C.c_void_p:
         raise SfHipError(f"{name}: expected dtype {kind}, got {t.dtype}")
     if not t.is_cuda:
         raise SfHipError(f"{name}: tensor lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
-    return C.c_void_p(t.data_ptr())
+    return _vp(t)
 
 
 def stream() -> C.c_void_p:
@@ -170,7 +270,7 @@ def stream() -> C.c_void_p:
 
 
 def f(x) -> C.c_float:
-    return C.c_float(float(x))
+    return x if isinstance(x, C.c_float) else C.c_float(float(x))  # (a c_float cell: a launch program's variable)
 
 
 def i64(x) -> C.c_int64:
@@ -178,7 +278,7 @@ def i64(x) -> C.c_int64:
 
 
 def u32(x) -> C.c_uint32:
-    return C.c_uint32(int(x) & 0xFFFFFFFF)
+    return x if isinstance(x, C.c_uint32) else C.c_uint32(int(x) & 0xFFFFFFFF)
 
 
 # ------------------------------------------------------------------------------------------------ thin wrappers
@@ -228,7 +328,7 @@ def _raw_any(t: torch.Tensor, u8: bool, name: str) -> C.c_void_p:
         raise SfHipError(f"{name}: expected {want}, got {t.dtype}")
     if not t.is_cuda:
         raise SfHipError(f"{name} lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
-    return C.c_void_p(t.data_ptr())
+    return _vp(t)
 
 
 def obsnorm_moments(inp, u8, stride, index, offset, traj_T, n, D, sub_mean, inv_scale, s, ss) -> None:
@@ -288,7 +388,7 @@ def rnn_store_state(h, c, dones_col, out) -> None:
         raise SfHipError(f"rnn_store_state: dones must be a device bool/u8 [B] column, got {dones_col.dtype} {tuple(dones_col.shape)}")
     if out.shape != (B, H if c is None else 2 * H) or out.stride(1) != 1:
         raise SfHipError(f"rnn_store_state: out must be [B, {H if c is None else 2 * H}] with unit column stride")
-    _check(load().sf_rnn_store_state(ptr(h, "f32", "h"), ptr(c, "f32", "c"), C.c_void_p(dones_col.data_ptr()),
+    _check(load().sf_rnn_store_state(ptr(h, "f32", "h"), ptr(c, "f32", "c"), _vp(dones_col),
                                      i64(dones_col.stride(0)), _raw(out, "f32", "out"), i64(out.stride(0)), i64(B), int(H),
                                      stream()), "sf_rnn_store_state")
 
@@ -315,7 +415,7 @@ def lstm_seq_supported(Cn: int, H: int) -> bool:
 def _seq_key(op, R, Cn, H, steps, G=4, x_cols=0):
     """profiling key of a fused LSTM pass in bench.py's layout: 2 * (steps*Cn) * 4H * H algorithmic FLOPs of the
     recurrent products (forward: R steps; backward: R-1, the first step has no state in front of it)"""
-    if PROFILE is None:
+    if not _keys_wanted():
         return None
     kind, direction = op.split("_")
     name = None
@@ -370,7 +470,7 @@ def linear_fwd_dual(a1, lda1, w1t, bias1, a2, lda2, w2t, bias2, out, n, gru_H=0)
     (w_it [3H, K_i], out [n, 4H], see sf_hip.h)"""
     N, K1, K2 = int(out.shape[1]), int(w1t.shape[1]), int(w2t.shape[1])
     # (GRU layout: 3H columns' worth of products spread over 4H output columns)
-    key = None if PROFILE is None else ("fwd_dual", int(n), K1 + K2, 1, 1, 3 * int(gru_H) if gru_H else N, 1, 1, 1, 1, "k_fwd_glds2<128, 64, 2, 2>")
+    key = None if not _keys_wanted() else ("fwd_dual", int(n), K1 + K2, 1, 1, 3 * int(gru_H) if gru_H else N, 1, 1, 1, 1, "k_fwd_glds2<128, 64, 2, 2>")
     with _timed(key):
         _check(load().sf_linear_fwd_dual(_raw(a1, "f32", "a1"), i64(lda1), ptr(w1t, "f32", "w1t"), ptr(bias1, "f32", "bias1"), K1,
                                          _raw(a2, "f32", "a2"), i64(lda2), ptr(w2t, "f32", "w2t"), ptr(bias2, "f32", "bias2"), K2,
@@ -537,7 +637,7 @@ def sample_write_step_masked(logits, ld_logits, values, ld_values, mask, ld_mask
         raise SfHipError(f"action_mask: expected a u8/bool CUDA tensor, got {mask.dtype} on {mask.device}")
     _check(load().sf_sample_write_step_masked(_raw(logits, "f32", "logits"), int(ld_logits),
                                               _raw(values, "f32", "values"), int(ld_values),
-                                              C.c_void_p(mask.data_ptr()), i64(ld_mask), int(B), int(A), int(T), int(t),
+                                              _vp(mask), i64(ld_mask), int(B), int(A), int(T), int(t),
                                               u32(seed), u32(step), u32(row0), f(policy_version),
                                               int(bool(deterministic)), ptr(traj_actions, "f32"),
                                               ptr(traj_logits, "f32"), ptr(traj_logp, "f32"), ptr(traj_values, "f32"),
@@ -623,7 +723,7 @@ def copy_rows(dst: torch.Tensor, src: torch.Tensor) -> None:
             rd, bd, pd = rs, bs, bs
         elif rs == 1 and rd > 1:
             rs, bs, ps = rd, bd, bd
-    _check(load().sf_copy_rows(C.c_void_p(dst.data_ptr()), i64(pd), C.c_void_p(src.data_ptr()), i64(ps), i64(bd),
+    _check(load().sf_copy_rows(_vp(dst), i64(pd), _vp(src), i64(ps), i64(bd),
                                i64(rd), stream()), "sf_copy_rows")
 
 
@@ -645,7 +745,7 @@ def _raw_in(t: torch.Tensor, desc: sf_conv_desc) -> C.c_void_p:
         raise SfHipError(f"conv input: expected {want}, got {t.dtype}")
     if not t.is_cuda:
         raise SfHipError(f"conv input lives on {t.device}; the hot path only runs on the GPU (no CPU fallback)")
-    return C.c_void_p(t.data_ptr())
+    return _vp(t)
 
 
 def conv_fwd_workspace(n, desc: sf_conv_desc) -> int:

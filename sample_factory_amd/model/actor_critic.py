@@ -253,6 +253,7 @@ class ActorCritic:
         if cfg.normalize_returns:
             self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
         self._bufs: Dict = {}
+        self._layout_gen = 0  # bumped whenever a buffer, workspace or parameter view is (re)allocated: launch_key()
         self._wss: Dict = {}
         self._tls = threading.local()  # per-thread "which scratch am I using": a sampler thread may run beside the learner
         self._snap = None
@@ -274,6 +275,7 @@ class ActorCritic:
             flat_params.copy_(old)
             flat_params_t.copy_(self.flat_params_t)
         self.flat_params, self.flat_grads, self.flat_params_t = flat_params, flat_grads, flat_params_t
+        self._layout_gen = getattr(self, "_layout_gen", 0) + 1
         for L, (o, ob) in zip(self.layers, self._segs):
             L.w = flat_params[o:o + L.K * L.N].view(L.K, L.N)
             L.b = flat_params[ob:ob + L.N]
@@ -426,7 +428,14 @@ class ActorCritic:
         if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self._bufs[key] = t
+            self._layout_gen += 1
         return t
+
+    def launch_key(self, tag: str = "inf"):
+        """identity of every address a one-step forward under `tag` hands the library (weights or the published snapshot
+        it reads, activation buffers, workspaces): a recorded launch program (lib.LaunchProgram) of that forward is valid
+        exactly as long as this value does not change"""
+        return (self._layout_gen, self.snap_read if self._snap is not None else -1)
 
     def _aligned_frames(self, tag, x, stride, idx, off, tT, n):
         """the n frames a launch would read — dataset row d = idx[i] | off + i, slab row d + d // traj_T (sf_common.h
@@ -437,6 +446,7 @@ class ActorCritic:
         rows = (avail - self.obs_elems) // int(stride) + 1
         flat = x.as_strided((rows, self.obs_elems), (int(stride), 1))
         out = self._buf((tag, "frames_aligned"), (n, self.obs_elems), dtype=x.dtype)
+        lib.recording_unsafe("frames gathered by a torch op")
         torch.index_select(flat, 0, pos, out=out)
         return out, self.obs_elems, None, 0, 0
 
@@ -446,6 +456,7 @@ class ActorCritic:
         if t is None or t.shape != torch.Size(shape):
             t = torch.zeros(shape, dtype=torch.float32, device=self.device)
             self._bufs[key] = t
+            self._layout_gen += 1
         return t
 
     def tensor_segment_ids(self):
@@ -485,6 +496,7 @@ class ActorCritic:
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
             self._wss[key] = ws
+            self._layout_gen += 1
         return ws
 
     # ---- async mode (cfg.async_rl): inference reads a published SNAPSHOT of the weights (K20).  The reference copies
@@ -499,6 +511,7 @@ class ActorCritic:
                                       buft[o:o + L.K * L.N].view(L.N, L.K) if L.wt is not None else None)
                                      for L, (o, ob) in zip(self.layers, self._segs)])
         self.snap_read = 0
+        self._layout_gen += 1
         on = self.obs_normalizer
         self._snap_tabs = [(on.mu_tab.clone(), on.rstd_tab.clone()) for _ in range(2)] if on is not None else None
 

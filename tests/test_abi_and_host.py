@@ -508,3 +508,48 @@ def test_bench_numa_plan_splits_a_node_between_the_ranks_on_it():
     core_of = {c: (0, c % 32) for c in node_cpus[0]}
     a, b = (bench.numa_plan(r, [0, 0], range(128), node_cpus, core_of) for r in range(2))
     assert a == list(range(0, 16)) + list(range(64, 80)) and b == list(range(16, 32)) + list(range(80, 96))
+
+
+def test_launch_program_recorder_on_a_stand_in_library(monkeypatch):
+    """lib.record_launches / LaunchProgram without a GPU: a stand-in for the CDLL shows that launches are logged with the
+    arguments they were called with AND executed, queries pass through unlogged, a ctypes cell is read again at every
+    replay, calls that read host state mark the program, and a failing replayed call raises like the wrapper would."""
+    import ctypes as C
+    from sample_factory_amd import lib
+
+    class Fake:
+        def __init__(self):
+            self.log, self.fail = [], False
+
+        def sf_thing(self, *a):
+            self.log.append(("thing",) + tuple(x.value if hasattr(x, "value") else x for x in a))
+            return 7 if self.fail else 0
+
+        def sf_thing_supported(self, *a):
+            self.log.append(("query",))
+            return 1
+
+        def sf_h2d_rows(self, *a):
+            return 0
+
+        def sf_last_error(self):
+            return b"stand-in failure"
+
+    fake = Fake()
+    monkeypatch.setattr(lib, "_lib", fake)
+    cell = C.c_uint32(4)
+    assert lib.u32(cell) is cell and lib.f(C.c_float(2.0)).value == 2.0 and lib.u32(2 ** 32 + 3).value == 3
+    with lib.record_launches() as p:
+        assert lib.load().sf_thing_supported(1) == 1
+        assert lib.load().sf_thing(lib.u32(cell), 9) == 0
+    assert lib.load() is fake
+    assert fake.log == [("query",), ("thing", 4, 9)] and [c[2] for c in p.calls] == ["sf_thing"] and p.unsafe is None
+    cell.value = 5
+    p.replay()
+    assert fake.log[-1] == ("thing", 5, 9) and len(fake.log) == 3
+    fake.fail = True
+    with pytest.raises(lib.SfHipError, match="sf_thing failed \\(7\\): stand-in failure"):
+        p.replay()
+    with lib.record_launches() as q:
+        lib.load().sf_h2d_rows(0)
+    assert q.unsafe == "sf_h2d_rows" and q.calls == []
