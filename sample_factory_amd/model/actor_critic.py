@@ -114,12 +114,21 @@ def _linear_desc(K, N, relu) -> lib.sf_conv_desc:
 class ActorCritic:
     """Shared-weights feed-forward actor-critic (reference: ActorCriticSharedWeights)."""
 
-    def __init__(self, cfg, obs_space, action_space, device="cuda", all_reduce=None):
+    def __init__(self, cfg, obs_space, action_space, device="cuda", all_reduce=None, obs_key: str = "obs", part: str = "full"):
+        """part: "full" = the whole shared-weights model on the single key "obs"; "encoder" = only the encoder of observation
+        key `obs_key` (no core / decoder / heads: forward_heads ends at the encoder output, backward starts from the gradient
+        wrt its last layer's pre-activation); "trunk" = core + decoder + heads on a dense f32 feature batch (obs_space["obs"] =
+        Box(F): the concatenated encoder outputs, already activated), whose backward also produces d(loss)/d(features)
+        (`g_input`).  The two partial forms are the towers of model/actor_critic_multikey.py."""
+        assert part in ("full", "encoder", "trunk")
         self.cfg = cfg
         self.obs_space = obs_space
         self.action_space = action_space
         self.device = torch.device(device)
         self.training = True
+        self.part, self.obs_key = part, obs_key
+        self.headless, self.features_in = part == "encoder", part == "trunk"
+        self.g_input = None
         if cfg.use_rnn and (cfg.rnn_num_layers < 1 or cfg.rnn_type not in ("gru", "lstm")):
             raise NotImplementedError("native recurrent core: GRU or LSTM, rnn_num_layers >= 1")
         if not cfg.actor_critic_share_weights:
@@ -130,19 +139,19 @@ class ActorCritic:
         # running input statistics exist for the keys in cfg.normalize_input_keys (None / []: all keys,
         # running_mean_std.py:113-131); this model has the single key "obs"
         keys_ = getattr(cfg, "normalize_input_keys", None)
-        norm_input = bool(cfg.normalize_input) and (not keys_ or "obs" in keys_)
+        norm_input = bool(cfg.normalize_input) and (not keys_ or obs_key in keys_) and not self.features_in
         # ActionParameterizationContinuousNonAdaptiveStddev (action_parameterization.py:42-78): the network outputs the
         # means only, log-stddev is one learned vector.  In the fused heads GEMM the log-stddev columns keep ZERO weights
         # (their weight gradient is discarded) and their BIAS is the learned vector, so params = [means | log_std] comes
         # out of the same launch and the bias gradient (column sums) is exactly d loss / d learned_stddev.
-        self.nonadaptive_std = is_box(action_space) and not cfg.adaptive_stddev
+        self.nonadaptive_std = is_box(action_space) and not cfg.adaptive_stddev and not self.headless
         # continuous_tanh_scale > 0 (non-adaptive case only, as in the reference): means = tanh(x / s) * s, applied in
         # place to the mean columns of the heads matrix (sf_tanh_scale_fwd / _bwd)
         self.tanh_scale = float(cfg.continuous_tanh_scale) if self.nonadaptive_std else 0.0
         keys = sorted(k for k in obs_space.spaces.keys() if k != "action_mask")  # obs_space_without_action_mask
-        if keys != ["obs"]:
+        if part != "encoder" and keys != ["obs"]:
             raise NotImplementedError(f"single 'obs' key (+ optional 'action_mask') only, got {keys}")
-        space = obs_space["obs"]
+        space = obs_space[obs_key]
         self.obs_shape = tuple(space.shape)
         self.obs_u8 = np.dtype(space.dtype) == np.uint8
         self.num_action_params = calc_num_action_parameters(action_space)
@@ -151,13 +160,15 @@ class ActorCritic:
         inv_scale = float(np.float32(1.0 / cfg.obs_scale)) if abs(cfg.obs_scale - 1.0) > 1e-5 else 1.0
         if abs(sub_mean) <= 1e-5:
             sub_mean = 0.0
+        if obs_key != "obs" or self.features_in:  # normalize.py:38-47: mean shift / scale belong to the key named "obs" only
+            sub_mean, inv_scale = 0.0, 1.0
 
         self._fused_norm = False
         if len(self.obs_shape) == 3:
             C, H, W = self.obs_shape
             if not self.obs_u8:
                 raise NotImplementedError("image observations must be uint8 CHW (pixel_format=CHW)")
-            pfx = "encoder.encoders.obs.enc."
+            pfx = f"encoder.encoders.{obs_key}.enc."
             cin, h, w = C, H, W
             for i, (cout, k, s) in enumerate(CONV_ARCHS[cfg.encoder_conv_architecture]):
                 oh, ow = (h - k) // s + 1, (w - k) // s + 1
@@ -185,18 +196,22 @@ class ActorCritic:
                 raise NotImplementedError("vector observations must be f32; obs_scale/obs_subtract_mean on vectors "
                                           "need normalize_input=True")
             feat = self.obs_shape[0]
-            for j, size in enumerate(cfg.encoder_mlp_layers):
-                self.layers.append(_Layer(f"encoder.encoders.obs.mlp_head.{2 * j}", _linear_desc(feat, size, act),
+            for j, size in enumerate([] if self.features_in else cfg.encoder_mlp_layers):
+                self.layers.append(_Layer(f"encoder.encoders.{obs_key}.mlp_head.{2 * j}", _linear_desc(feat, size, act),
                                           (size, feat), "linear"))
                 feat = size
         else:
             raise NotImplementedError(f"Unsupported observation shape {self.obs_shape}")
         self.rnn_kind, self.rnn_H, self.rnn_S = None, 0, get_rnn_size(cfg)
-        self.rnn_L = int(cfg.rnn_num_layers) if cfg.use_rnn else 0
+        use_rnn = bool(cfg.use_rnn) and not self.headless
+        self.rnn_L = int(cfg.rnn_num_layers) if use_rnn else 0
         self.rnn_SL = self.rnn_S // max(1, self.rnn_L)  # state columns of ONE recurrent layer: H (GRU) or 2 H (LSTM: [h | c])
-        if cfg.use_rnn and not self.layers:
+        if use_rnn and not self.layers and not self.features_in:
             raise NotImplementedError("a recurrent core needs at least one encoder layer in front of it")
-        if cfg.use_rnn:  # model/core.py:19-64: nn.GRU / nn.LSTM(input=feat, hidden=rnn_size), torch gate order
+        if self.headless and (not self.layers or self.layers[-1].kind not in ("linear", "linear_after_conv")):
+            # (an image encoder without mlp layers hands the reference's core CHW-flattened features; ours are NHWC)
+            raise NotImplementedError(f"encoder of key '{obs_key}': at least one fully connected layer needed")
+        if use_rnn:  # model/core.py:19-64: nn.GRU / nn.LSTM(input=feat, hidden=rnn_size), torch gate order
             Hs = cfg.rnn_size
             G = 3 if cfg.rnn_type == "gru" else 4
             self.rnn_kind, self.rnn_H = (0 if cfg.rnn_type == "gru" else 1), Hs
@@ -210,7 +225,7 @@ class ActorCritic:
                     Lr.rnn_l = l
                     self.layers.append(Lr)
                 feat = Hs
-        for j, size in enumerate(cfg.decoder_mlp_layers):
+        for j, size in enumerate([] if self.headless else cfg.decoder_mlp_layers):
             self.layers.append(_Layer(f"decoder.mlp.{2 * j}", _linear_desc(feat, size, act), (size, feat), "linear"))
             feat = size
         self.feat = feat
@@ -218,9 +233,12 @@ class ActorCritic:
         # fused heads [F, 1+A] padded to a multiple of 4 columns (zero weights, zero gradients) so that every operand
         # of every layer takes the 16-byte vector loaders; column 0 = value, columns 1..A = action parameters
         self.heads_ld = (1 + A + 3) // 4 * 4
-        self.layers.append(_Layer("heads", _linear_desc(feat, self.heads_ld, 0), (self.heads_ld, feat), "heads"))
+        if not self.headless:
+            self.layers.append(_Layer("heads", _linear_desc(feat, self.heads_ld, 0), (self.heads_ld, feat), "heads"))
         self.act_kind = act
-        prev_kind = 0  # what produced the input of each chain layer: obs (0), an activated layer (act), the RNN cell (0)
+        # what produced the input of each chain layer: obs (0), an activated layer (act), the RNN cell (0); a trunk's input
+        # is the encoders' activated output
+        prev_kind = act if self.features_in else 0
         for L in self.layers:
             if L.role == "rnn_hh":
                 continue
@@ -228,7 +246,7 @@ class ActorCritic:
             prev_kind = 0 if L.role == "rnn_ih" else L.desc.relu
         self.obs_elems = int(np.prod(self.obs_shape))
         # vector observations through a two-layer MLP encoder: the rollout can take the fused inference kernel
-        self._mlp2_ok = (len(self.obs_shape) == 1 and len(self.layers) >= 3 and
+        self._mlp2_ok = (len(self.obs_shape) == 1 and len(self.layers) >= (2 if self.headless else 3) and not self.features_in and
                          all(L.kind == "linear" and L.role == "chain" and L.desc.relu == act for L in self.layers[:2]) and
                          len(cfg.encoder_mlp_layers) == 2 and
                          lib.mlp2_supported(self.obs_shape[0], self.layers[0].N, self.layers[1].N))
@@ -248,9 +266,12 @@ class ActorCritic:
             from sample_factory_amd.utils.normalize import ObservationNormalizer
             self.obs_normalizer = ObservationNormalizer(cfg, self.obs_shape, self.obs_u8, self.device,
                                                         all_reduce=all_reduce, world=getattr(cfg, "dp_world", 1))
+            if obs_key != "obs":  # mean shift / scale: the key named "obs" only (normalize.py:38-47)
+                self.obs_normalizer.sub_mean, self.obs_normalizer.inv_scale = 0.0, 1.0
+        self._norm_prefix = f"obs_normalizer.running_mean_std.running_mean_std.{obs_key}."
         self._xn: Dict = {}
         self.returns_normalizer: Optional[RunningMeanStdInPlace] = None
-        if cfg.normalize_returns:
+        if cfg.normalize_returns and not self.headless:
             self.returns_normalizer = RunningMeanStdInPlace((1,), self.device, all_reduce=all_reduce)
         self._bufs: Dict = {}
         self._layout_gen = 0  # bumped whenever a buffer, workspace or parameter view is (re)allocated: launch_key()
@@ -287,8 +308,12 @@ class ActorCritic:
 
     # ------------------------------------------------------------------------------------------ reference surface
     def num_params(self) -> int:
-        n = sum(L.K * L.N + L.N for L in self.layers[:-1])
-        return n + (self.feat + 1) * (1 + self.num_action_params)
+        n = sum(L.K * L.N + L.N for L in self._body())
+        return n if self.headless else n + (self.feat + 1) * (1 + self.num_action_params)
+
+    def _body(self):
+        """every layer but the fused heads (an encoder tower has none)"""
+        return self.layers if self.headless else self.layers[:-1]
 
     def train(self, mode=True):
         self.training = mode
@@ -337,7 +362,7 @@ class ActorCritic:
     def ref_param_shapes(self):
         """(name, shape) of every trainable parameter under the reference's names, in the reference's order."""
         out = []
-        for L in self.layers[:-1]:
+        for L in self._body():
             if L.role == "rnn_hh":
                 continue
             if L.role == "rnn_ih":  # torch order: weight_ih, weight_hh, bias_ih, bias_hh
@@ -347,6 +372,8 @@ class ActorCritic:
                 continue
             out.append((L.wname, tuple(L.ref_w_shape)))
             out.append((L.bname, (L.N,)))
+        if self.headless:
+            return out
         A, F = self.num_action_params, self.feat
         out += [("critic_linear.weight", (1, F)), ("critic_linear.bias", (1,))]
         if self.nonadaptive_std:  # torch lists a module's own parameters before its children's
@@ -361,12 +388,14 @@ class ActorCritic:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         sd = {}
         if self.obs_normalizer is not None:
-            sd.update(self.obs_normalizer.state_dict())
+            sd.update(self.obs_normalizer.state_dict(self._norm_prefix))
         if self.returns_normalizer is not None:
             sd.update(self.returns_normalizer.state_dict("returns_normalizer."))
-        for L in self.layers[:-1]:
+        for L in self._body():
             sd[L.wname] = L.w_to_ref(L.w.detach()).cpu()
             sd[L.bname] = L.b.detach().cpu().clone()
+        if self.headless:
+            return sd
         H, A = self.layers[-1], self.num_action_params
         w = H.w.detach().cpu()
         sd["critic_linear.weight"] = w[:, 0:1].t().contiguous()
@@ -380,9 +409,14 @@ class ActorCritic:
 
     def load_state_dict(self, sd, strict=True):
         with torch.no_grad():
-            for L in self.layers[:-1]:
+            for L in self._body():
                 L.w.copy_(L.w_from_ref(torch.as_tensor(sd[L.wname], dtype=torch.float32)))
                 L.b.copy_(torch.as_tensor(sd[L.bname], dtype=torch.float32))
+            if self.headless:
+                self.params_changed()
+                if self.obs_normalizer is not None and self._norm_prefix + "count" in sd:
+                    self.obs_normalizer.load_state_dict(sd, self._norm_prefix)
+                return
             H, A = self.layers[-1], self.num_action_params
             cw = torch.as_tensor(sd["critic_linear.weight"], dtype=torch.float32)
             aw = torch.as_tensor(sd["action_parameterization.distribution_linear.weight"], dtype=torch.float32)
@@ -396,8 +430,8 @@ class ActorCritic:
             H.b.copy_(torch.cat([torch.as_tensor(sd["critic_linear.bias"], dtype=torch.float32).reshape(1), ab,
                                  torch.zeros(pad)]))
             self.params_changed()
-            if self.obs_normalizer is not None and "obs_normalizer.running_mean_std.running_mean_std.obs.count" in sd:
-                self.obs_normalizer.load_state_dict(sd)
+            if self.obs_normalizer is not None and self._norm_prefix + "count" in sd:
+                self.obs_normalizer.load_state_dict(sd, self._norm_prefix)
             if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
                 self.returns_normalizer.load_state_dict(sd, "returns_normalizer.")
             elif strict and self.returns_normalizer is not None:
@@ -407,9 +441,11 @@ class ActorCritic:
     def flat_to_ref(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Interpret a flat buffer (params, grads or Adam moments) under the reference's names/layouts."""
         out = {}
-        for L, (o, ob) in zip(self.layers[:-1], self._segs[:-1]):
+        for L, (o, ob) in zip(self._body(), self._segs):
             out[L.wname] = L.w_to_ref(flat[o:o + L.K * L.N].view(L.K, L.N)).cpu()
             out[L.bname] = flat[ob:ob + L.N].cpu().clone()
+        if self.headless:
+            return out
         H, (o, ob), A = self.layers[-1], self._segs[-1], self.num_action_params
         w = flat[o:o + H.K * H.N].view(H.K, H.N).cpu()
         b = flat[ob:ob + H.N].cpu()
@@ -465,10 +501,12 @@ class ActorCritic:
         holds two reference tensors column-wise: critic_linear (column 0) and distribution_linear (columns 1..A)."""
         seg = torch.full((self.num_flat,), 255, dtype=torch.uint8)
         nseg = 0
-        for L, (o, ob) in zip(self.layers[:-1], self._segs[:-1]):
+        for L, (o, ob) in zip(self._body(), self._segs):
             seg[o:o + L.K * L.N] = nseg
             seg[ob:ob + L.N] = nseg + 1
             nseg += 2
+        if self.headless:
+            return seg.to(self.device), nseg
         H, (o, ob), A = self.layers[-1], self._segs[-1], self.num_action_params
         hw = torch.full((H.K, H.N), 255, dtype=torch.uint8)
         hw[:, 0] = nseg          # critic_linear.weight
@@ -845,7 +883,7 @@ class ActorCritic:
             d = L.desc
             if L.role == "rnn_ih":
                 g = self._rnn_sequence_bwd(li, g, n)  # dL/d(core_out) [n,H] -> dL/d(gx) time-major
-            if pos == 0:
+            if pos == 0 and not self.features_in:
                 d0 = lib.sf_conv_desc.from_buffer_copy(d)
                 d0.traj_T = int(tT0)
                 ws = self._workspace(lib.conv_wgrad_workspace(n, d0))
@@ -874,6 +912,8 @@ class ActorCritic:
                     gs = self._buf(("g", "x_sm", li), (n, L.K))
                     gs.view(Cn, R, L.K).copy_(g.view(R, Cn, L.K).transpose(0, 1))
                     g = gs
+                if pos == 0:  # a trunk: d(loss) / d(pre-activation of the encoders' last layers), [n, F]
+                    self.g_input = g
             if self.nonadaptive_std and li == len(self.layers) - 1:
                 A = self.num_action_params  # the log-stddev columns have no weights in the reference: keep them at zero
                 L.gw[:, 1 + A // 2:1 + A].zero_()

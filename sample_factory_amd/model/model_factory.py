@@ -71,10 +71,20 @@ def create_actor_critic(cfg, obs_space, action_space, device, all_reduce=None):
         # kernels since round 6: two towers on one flat parameter buffer (model/actor_critic_separate.py)
         from sample_factory_amd.model.actor_critic_separate import SeparateActorCritic
         return SeparateActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
-    # cfg.actor_critic_share_weights=False (ActorCriticSeparateWeights, model/actor_critic.py:198-334: an encoder / core /
-    # decoder each for the actor and the critic) and
-    # observation dicts of several keys (model/encoder.py:33-69, MultiInputEncoder: one encoder per key, concatenated)
-    # run the default architecture in torch: same fallback as a user-registered model, everything around the network
+    if (f.is_default() and len(obs_keys_of(obs_space)) > 1 and not stacked_rnn and not separate
+            and torch.device(device).type == "cuda" and os.environ.get("SF_NATIVE_MULTIKEY", "1") != "0"):
+        # observation dicts of several keys (model/encoder.py:33-69, MultiInputEncoder: one encoder per key, concatenated) on
+        # the native kernels since round 6: one encoder tower per key + a trunk on one flat parameter buffer
+        # (model/actor_critic_multikey.py).  Shapes the towers do not take (an image encoder without a fully connected
+        # layer, a concatenated width that is not a multiple of 4) keep the torch path below.
+        from sample_factory_amd.model.actor_critic_multikey import MultiKeyActorCritic
+        try:
+            return MultiKeyActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
+        except NotImplementedError as e:
+            from sample_factory_amd.utils.utils import log
+            log.warning("multi-key observations: torch path (%s)", e)
+    # cfg.actor_critic_share_weights=False with several keys, CPU devices, user-registered parts:
+    # the default architecture in torch: same fallback as a user-registered model, everything around the network
     # stays native
     if f.make_actor_critic_func is not None:
         module = f.make_actor_critic_func(cfg, obs_space, action_space)

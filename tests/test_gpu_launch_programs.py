@@ -16,6 +16,7 @@ def _cfg(kind, **over):
     register_env("synthetic_atari", synthetic.make_synthetic_env)
     register_env("synthetic_ant", synthetic.make_synthetic_continuous_env)
     register_env("synthetic_tuple", synthetic.make_synthetic_tuple_env)
+    register_env("dict_bandit", synthetic.make_dict_obs_bandit_env)
     common = dict(rollout=8, num_epochs=1, num_workers=1, num_envs_per_worker=1, worker_num_splits=1, async_rl=False, seed=3,
                   serial_mode=True, num_batches_per_epoch=2)
     if kind == "conv_discrete":        # BASELINE configs[1] in miniature
@@ -33,6 +34,11 @@ def _cfg(kind, **over):
         base = dict(env="synthetic_tuple", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
                     encoder_conv_architecture="convnet_atari", synthetic_num_agents=64, batch_size=256,
                     synthetic_head_sizes=(6, -2, 3))
+    elif kind == "dict_multikey_gru":  # image + vector keys on the native towers, a torch-stepped device env (no step_into)
+        base = dict(env="dict_bandit", use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=8, nonlinearity="relu",
+                    normalize_input=True, normalize_input_keys=["measurements"], obs_scale=255.0,
+                    encoder_conv_architecture="convnet_impala", encoder_conv_mlp_layers=[32], encoder_mlp_layers=[32],
+                    synthetic_num_agents=64, batch_size=256, normalize_returns=False)
     else:
         raise KeyError(kind)
     base.update(common)
@@ -82,7 +88,7 @@ def _same_run(a, b):
 
 
 @pytest.mark.parametrize("kind", ["conv_discrete", "conv_normalized", "mlp_lstm_box", "mlp_gru_box", "mlp_lstm2_box",
-                                  "conv_tuple_mixed"])
+                                  "conv_tuple_mixed", "dict_multikey_gru"])
 def test_replayed_rollouts_equal_the_wrapper_path(kind):
     """5 iterations (rollout + train each): first sight, recording, then replays — against the same run with programs off.
     The sampler's Philox step and the policy version travel through ctypes cells: a stale value would repeat actions /
@@ -96,8 +102,9 @@ def test_replayed_rollouts_equal_the_wrapper_path(kind):
     for s in prog["samplers"]:
         T = s.T
         progs = [p for p in s._progs.values() if isinstance(p, lib.LaunchProgram)]
-        # a policy and a record program per step (and slab slice)
-        assert len(progs) >= 2 * T and len(progs) % (2 * T) == 0, (len(progs), sorted(k[:2] for k in s._progs))
+        # a policy and a record program per step (and slab slice); env outputs in fresh tensors: the policy program only
+        per_step = 2 if (s.zero_copy or s.host_env) else 1
+        assert len(progs) >= per_step * T and len(progs) % (per_step * T) == 0, (len(progs), sorted(k[:2] for k in s._progs))
         assert all(p.unsafe is None for p in progs)
         assert s.program_replays >= T, s.program_replays  # (the layout settles after the first training pass)
         pol = [p for k, p in s._progs.items() if k[0] == "policy"]

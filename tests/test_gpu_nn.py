@@ -1589,16 +1589,21 @@ def test_lds_image_forward_conv3_vs_torch(lib, n, act):
     assert (got2 - ref2).abs().max().item() < 3e-5 * max(1.0, ref2.abs().max().item())
 
 
-def test_multi_key_observation_dict_end_to_end(lib, tmp_path):
+@pytest.mark.parametrize("native", [True, False], ids=["native_towers", "torch_path"])
+def test_multi_key_observation_dict_end_to_end(lib, tmp_path, monkeypatch, native):
     """Observation dicts with several keys (image + vector: the reference's MultiInputEncoder, model/encoder.py:33-69):
-    every key lives in the slab, the default architecture (one encoder per sorted key, concatenated) runs on the torch
-    fallback with the reference's parameter names, everything around the network stays native; the policy learns a
-    bandit whose context is only in the VECTOR key; per-key input normalisation and checkpoints round-trip."""
+    every key lives in the slab, the default architecture (one encoder per sorted key, concatenated) runs on the native
+    towers of model/actor_critic_multikey.py (SF_NATIVE_MULTIKEY=0: the torch path) with the reference's parameter names;
+    the policy learns a bandit whose context is only in the VECTOR key; per-key input normalisation and checkpoints
+    round-trip."""
     from sample_factory_amd.cfg.arguments import default_cfg
     from sample_factory_amd.envs.env_utils import register_env
     from sample_factory_amd.envs.synthetic import make_dict_obs_bandit_env
+    from sample_factory_amd.model.actor_critic_multikey import MultiKeyActorCritic
     from sample_factory_amd.model.torch_policy import TorchPolicyAdapter
     from sample_factory_amd.train import make_runner
+    monkeypatch.setenv("SF_NATIVE_MULTIKEY", "1" if native else "0")
+    TorchPolicyAdapter = MultiKeyActorCritic if native else TorchPolicyAdapter  # noqa: F811 (the class this run must build)
     register_env("dict_bandit", make_dict_obs_bandit_env)
     cfg = default_cfg(env="dict_bandit", use_rnn=False, nonlinearity="relu", normalize_input=True,
                       normalize_input_keys=["measurements"], obs_scale=255.0, encoder_conv_architecture="convnet_impala",
@@ -1636,13 +1641,15 @@ def test_multi_key_observation_dict_end_to_end(lib, tmp_path):
     assert torch.equal(ac2.flat_params, ac.flat_params), "resume loads the multi-key checkpoint"
 
 
-def test_multi_input_model_forward_matches_reference(lib, golden):
+@pytest.mark.parametrize("native", [True, False], ids=["native_towers", "torch_path"])
+def test_multi_input_model_forward_matches_reference(lib, golden, monkeypatch, native):
     """the default architecture for an image + vector observation dict vs the REFERENCE model (model_fwd_multi.npz,
     MultiInputEncoder inside ActorCriticSharedWeights): identical parameter names and shapes, same logits / values
-    from the same seeded weights (obs_scale only on the "obs" key)."""
+    from the same seeded weights (obs_scale only on the "obs" key) — on the native towers and on the torch path."""
     from sample_factory_amd.cfg.arguments import default_cfg
     from sample_factory_amd.envs import spaces
     from sample_factory_amd.model.model_factory import create_actor_critic
+    monkeypatch.setenv("SF_NATIVE_MULTIKEY", "1" if native else "0")
     g = golden("model_fwd_multi")
     cfg = default_cfg(encoder_conv_architecture="convnet_impala", nonlinearity="relu", obs_scale=255.0,
                       normalize_input=False, encoder_conv_mlp_layers=[32], encoder_mlp_layers=[16, 16], use_rnn=False)
@@ -1650,6 +1657,7 @@ def test_multi_input_model_forward_matches_reference(lib, golden):
     obs_space = spaces.Dict({"obs": spaces.Box(0, 255, (4, 36, 36), np.uint8),
                              "measurements": spaces.Box(-1, 1, (5,), np.float32)})
     ac = create_actor_critic(cfg, obs_space, spaces.Discrete(6), torch.device("cuda"))
+    assert type(ac).__name__ == ("MultiKeyActorCritic" if native else "TorchPolicyAdapter")
     assert [(n, str(tuple(s))) for n, s in ac.ref_param_shapes()] == \
         [(str(n), str(tuple(eval(str(s))))) for n, s in zip(g["param_names"], g["param_shapes"])]
     load_seeded(ac, g["param_names"], g["param_shapes"], int(g["param_seed"]))
@@ -1826,13 +1834,16 @@ def test_learner_train_matches_reference_rnn_on_the_torch_model_path(lib, golden
     compare_post_train(learner, g, before, name + "_torch_path", **TIGHT)
 
 
-def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tmp_path):
+@pytest.mark.parametrize("native", [True, False], ids=["native_towers", "torch_path"])
+def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tmp_path, monkeypatch, native):
     """the reference's DEFAULT configuration for a dict observation: MultiInputEncoder + GRU core (use_rnn=True) — state
-    carried through the slab by the native rollout runner, BPTT on the torch model path"""
+    carried through the slab by the native rollout runner, BPTT through the trunk tower's sequence passes (torch path: the
+    masked time loop of model/torch_policy.py)"""
     from sample_factory_amd.cfg.arguments import default_cfg
     from sample_factory_amd.envs.env_utils import register_env
     from sample_factory_amd.envs.synthetic import make_dict_obs_bandit_env
     from sample_factory_amd.train import make_runner
+    monkeypatch.setenv("SF_NATIVE_MULTIKEY", "1" if native else "0")
     register_env("dict_bandit_rnn", make_dict_obs_bandit_env)
     cfg = default_cfg(env="dict_bandit_rnn", use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=8, nonlinearity="relu",
                       normalize_input=False, obs_scale=255.0, encoder_conv_architecture="convnet_impala",
@@ -1843,6 +1854,7 @@ def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tm
     cfg, runner = make_runner(cfg)
     runner.init()
     ac = runner.learner.actor_critic
+    assert type(ac).__name__ == ("MultiKeyActorCritic" if native else "TorchPolicyAdapter")
     assert ac.rnn_kind == 0 and "core.core.weight_hh_l0" in [n for n, _ in ac.ref_param_shapes()]
     p0 = ac.flat_params.clone()
     first = None
@@ -1856,6 +1868,121 @@ def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tm
     assert (tr["rnn_states"][:, 1:] == 0).all() and ac.new_rnn_states.abs().max() > 0
     assert torch.isfinite(ac.flat_params).all() and not torch.equal(p0, ac.flat_params)
     assert np.isfinite(stats["train"]["loss"]) and r > first + 0.3 and r > 0.75, (first, r)
+
+
+@pytest.mark.parametrize("core", ["ff", "gru", "lstm_decoder"])
+def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
+    """model/actor_critic_multikey.py against the torch construction of the same architecture (model/torch_policy.py builds
+    the reference's modules: MultiInputEncoder -> core -> decoder -> heads, model/encoder.py:33-69) on the same seeded
+    weights and the same slab leaves: heads of a training pass (dataset-row addressing into [E, T + 1, ...] leaves, an
+    index gather), of a one-step pass on a slab column, and EVERY parameter gradient under the reference's names; per-key
+    normalisation (running statistics on the vector key only, mean shift / scale on "obs" only) included."""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs import spaces
+    from sample_factory_amd.model.model_factory import create_actor_critic
+    kw = dict(ff=dict(use_rnn=False), gru=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4),
+              lstm_decoder=dict(use_rnn=True, rnn_type="lstm", rnn_size=32, recurrence=4, decoder_mlp_layers=[24]))[core]
+    cfg = default_cfg(encoder_conv_architecture="convnet_impala", nonlinearity="relu", obs_scale=255.0, obs_subtract_mean=3.0,
+                      normalize_input=True, normalize_input_keys=["measurements"], encoder_conv_mlp_layers=[32],
+                      encoder_mlp_layers=[16, 16], normalize_returns=False, **kw)
+    cfg.dp_world = 1
+    obs_space = spaces.Dict({"obs": spaces.Box(0, 255, (4, 36, 36), np.uint8),
+                             "measurements": spaces.Box(-1, 1, (5,), np.float32)})
+    models = {}
+    for native in (True, False):
+        monkeypatch.setenv("SF_NATIVE_MULTIKEY", "1" if native else "0")
+        models[native] = create_actor_critic(cfg, obs_space, spaces.Discrete(6), torch.device("cuda"))
+    nat, ref = models[True], models[False]
+    assert type(nat).__name__ == "MultiKeyActorCritic" and type(ref).__name__ == "TorchPolicyAdapter"
+    shapes = ref.ref_param_shapes()
+    assert [(n, tuple(s)) for n, s in nat.ref_param_shapes()] == [(n, tuple(s)) for n, s in shapes]
+    st = seeded_state([(n, tuple(s)) for n, s in shapes], 21)
+    for m in (nat, ref):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=False)
+    E, T = 16, 4
+    g = torch.Generator().manual_seed(5)
+    obs = {"obs": torch.randint(0, 256, (E, T + 1, 4, 36, 36), generator=g, dtype=torch.int32).to(torch.uint8).cuda(),
+           "measurements": (torch.rand((E, T + 1, 5), generator=g) * 2 - 1).cuda()}
+    for m in (nat, ref):   # one statistics update of the normalised key, as the Learner does per dataset
+        m.obs_normalizer.update(obs, m.obs_elems, E * (T + 1))
+    sd_n, sd_r = nat.state_dict(), ref.state_dict()
+    k_ = "obs_normalizer.running_mean_std.running_mean_std.measurements.running_mean"
+    np.testing.assert_allclose(sd_n[k_].numpy(), sd_r[k_].numpy(), rtol=1e-6, atol=1e-7)
+    assert "obs_normalizer.running_mean_std.running_mean_std.obs.running_mean" not in sd_n
+    n = E * T
+    S = nat.rnn_S if nat.rnn_kind is not None else 1
+    rnn = None
+    if nat.rnn_kind is not None:
+        R, Cn = 4, n // 4
+        keep = (torch.rand((R, Cn), generator=g) > 0.2).float().cuda()
+        h0 = (torch.randn((Cn, S), generator=g) * 0.3).cuda()
+        rnn = dict(R=R, h0=h0, keep_tm=keep)
+    g_heads = torch.zeros((n, nat.heads_ld), device="cuda")
+    g_heads[:, :1 + nat.num_action_params] = torch.randn((n, 1 + nat.num_action_params), generator=g).cuda() / n
+    outs = {}
+    for name, m in (("native", nat), ("torch", ref)):
+        m.train()
+        m.flat_grads.zero_()
+        acts = m.forward_heads(obs, n, sample_stride=m.obs_elems, index=None, offset=0, traj_T=T, tag="train",
+                               rnn=None if rnn is None else dict(rnn))
+        heads = acts[-1].clone()
+        m.backward(acts, g_heads.clone(), obs, n, sample_stride=m.obs_elems, index=None, offset=0, traj_T=T)
+        torch.cuda.synchronize()
+        grads = m.flat_to_ref(m.flat_grads)
+        # one inference step on slab column 2 (strided views), recurrent state included
+        col = {k: v[:, 2] for k, v in obs.items()}
+        st_in = (torch.randn((E, S), generator=torch.Generator().manual_seed(8)) * 0.3).cuda()
+        h1 = m.forward_heads(col, E, sample_stride=0, tag="inf", rnn=dict(states=st_in) if nat.rnn_kind is not None else None)[-1]
+        new_state = m.new_rnn_states_of("inf").clone() if nat.rnn_kind is not None else None
+        outs[name] = (heads, grads, h1.clone(), new_state)
+    A1 = 1 + nat.num_action_params
+    np.testing.assert_allclose(outs["native"][0][:, :A1].cpu().numpy(), outs["torch"][0][:, :A1].cpu().numpy(), atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(outs["native"][2][:, :A1].cpu().numpy(), outs["torch"][2][:, :A1].cpu().numpy(), atol=3e-5, rtol=1e-4)
+    if nat.rnn_kind is not None:
+        np.testing.assert_allclose(outs["native"][3].cpu().numpy(), outs["torch"][3].cpu().numpy(), atol=2e-5, rtol=1e-4)
+    for name, _ in shapes:
+        a, b = outs["native"][1][name].numpy(), outs["torch"][1][name].numpy()
+        assert a.shape == b.shape, name
+        scale = max(1e-6, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-4 * scale + 1e-7, (name, float(np.abs(a - b).max()), scale)
+        assert np.abs(b).max() > 0, f"{name}: the torch path's gradient is zero — the check would be vacuous"
+
+
+def test_native_multi_key_towers_in_async_mode(lib, tmp_path):
+    """async_rl with several observation keys on the native towers: inference reads the PUBLISHED snapshot of every tower
+    (weights and the per-key normalisation tables), the learner trains the live buffers; the bandit is still learned and a
+    checkpoint written mid-run loads into a fresh model bit for bit"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_dict_obs_bandit_env
+    from sample_factory_amd.train import make_runner
+    register_env("dict_bandit_async", make_dict_obs_bandit_env)
+    cfg = default_cfg(env="dict_bandit_async", use_rnn=False, nonlinearity="relu", normalize_input=True,
+                      normalize_input_keys=["measurements"], obs_scale=255.0, encoder_conv_architecture="convnet_impala",
+                      encoder_conv_mlp_layers=[32], encoder_mlp_layers=[32], rollout=8, batch_size=256,
+                      num_batches_per_epoch=2, num_epochs=1, num_workers=1, num_envs_per_worker=1, async_rl=True,
+                      serial_mode=False, seed=4, synthetic_num_agents=64, learning_rate=3e-3, gamma=0.0,
+                      normalize_returns=False, train_dir=str(tmp_path), experiment="dict_async")
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    ac = runner.learner.actor_critic
+    assert type(ac).__name__ == "MultiKeyActorCritic" and ac._snap is not None
+    assert all(t._snap is not None for t in ac.towers)
+    first = None
+    for _ in range(40):
+        runner.iteration()
+        r = float(runner.traj["rewards"].mean())
+        first = r if first is None else first
+    torch.cuda.synchronize()
+    assert r > first + 0.3 and r > 0.7, (first, r)
+    # the snapshot the sampler reads is a copy of the live parameters as of the last publish, tower by tower
+    slot = ac.snap_read
+    for t in ac.towers:
+        assert t._snap[slot].shape == t.flat_params.shape and torch.isfinite(t._snap[slot]).all()
+    runner.learner.save()
+    cfg2, runner2 = make_runner(cfg)
+    runner2.init()
+    assert torch.equal(runner2.learner.actor_critic.flat_params, ac.flat_params)
 
 
 def test_normalize_input_keys_subset_on_the_native_model(lib):
