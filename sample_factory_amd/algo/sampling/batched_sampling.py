@@ -292,7 +292,9 @@ class BatchedVectorEnvRunner:
         if (self.rnn and parts is None) or not (self.zero_copy or self.host_env):
             prog = rec_key = None  # torch model path (the state store is a torch op) / env outputs in fresh tensors every step
         else:
-            prog, rec_key = self._program("record", t, (rew.data_ptr(), term.data_ptr(), trunc.data_ptr()))
+            # (the shaping constants are launch arguments: a cfg update between rollouts must not replay the old ones)
+            prog, rec_key = self._program("record", t, (rew.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                                                        float(cfg.reward_scale), float(cfg.reward_clip)))
         if prog is not None:
             prog.replay()
         elif rec_key is not None:
