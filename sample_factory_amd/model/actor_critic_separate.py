@@ -18,6 +18,7 @@ from typing import Dict, List, Optional
 
 import torch
 
+from sample_factory_amd import lib
 from sample_factory_amd.model.actor_critic import ActorCritic, get_rnn_size
 
 _PARTS = ("encoder.", "core.", "decoder.")
@@ -183,6 +184,10 @@ class SeparateActorCritic:
     def _zbuf(self, key, shape):
         return self.actor._zbuf(("sep",) + tuple(key), shape)
 
+    def launch_key(self, tag: str = "inf"):
+        ka, kc = self.actor.launch_key(tag), self.critic.launch_key(tag)
+        return (ka[0], kc[0]), ka[1]
+
     @property
     def snap_read(self):
         return self.actor.snap_read
@@ -236,8 +241,8 @@ class SeparateActorCritic:
         hc = self.critic.forward_heads(obs, n, sample_stride=sample_stride, index=index, offset=offset, traj_T=traj_T, tag=tag,
                                        rnn=self._rnn_of(rnn if self.rnn_kind is not None else None, 1))[-1]
         out = self._buf((tag, "heads"), (n, self.heads_ld))
-        out.copy_(ha)
-        out[:, 0].copy_(hc[:, 0])
+        lib.copy_rows(out, ha)                    # (library launches, not torch ops: a rollout step of this model is
+        lib.copy_rows(out[:, 0:1], hc[:, 0:1])    #  recordable as a launch program, lib.LaunchProgram)
         return [out]
 
     def backward(self, acts, g_heads: torch.Tensor, obs, n: int, *, sample_stride: int, index=None, offset: int = 0,

@@ -452,6 +452,15 @@ def _worker_oneshot(rank, world, port, out_dir):
         if not (bool((g[100:40_100] == float(sum(r + 1 for r in range(world)))).all()) and float(g[0]) == rank + 1
                 and float(g[-1]) == rank + 1):
             bad.append(("slice", it))
+    # the peers' copies are added IN RANK ORDER on every rank: values whose f32 sum depends on the order
+    vals = [1e8, 1.0, -1e8, 0.5, 3.0, -0.25, 2e7, 1.0][:world]
+    o = torch.full((257,), vals[rank], device="cuda")
+    grp.all_reduce_sum(o)
+    acc = np.float32(0.0)
+    for v in vals:
+        acc = np.float32(acc + np.float32(v))
+    if not bool((o == float(acc)).all()):
+        bad.append(("order", float(o[0]), float(acc)))
     big = torch.ones(1 << 19, device="cuda")  # 2 MiB: above the mailbox size -> the ordinary (staged gloo) path
     grp.all_reduce_sum(big)
     torch.cuda.synchronize()
@@ -463,15 +472,17 @@ def _worker_oneshot(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_one_shot_exchange_between_two_ranks_on_one_device(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_shot_exchange_between_two_ranks_on_one_device(tmp_path, world):
     """csrc/sf_dp.hip one-shot exchange: mailboxes mapped across PROCESSES with hipIpc, one kernel per rank and
-    call.  Two ranks sharing the box's GPU: f32 sums of 3 ... 77 777 elements (the conv bucket's size), f64 scalars, a slice of
-    a larger buffer, 30 rounds over both slots — exact results on both ranks; a bucket above the mailbox size takes the
-    ordinary path; no wait timed out"""
-    mp.spawn(_worker_oneshot, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    call.  Two (four) ranks sharing the box's GPU: f32 sums of 3 ... 77 777 elements (the conv bucket's size), f64 scalars, a
+    slice of a larger buffer, 30 rounds over both slots — exact results on every rank; a sum whose f32 value depends on the
+    order comes out as the RANK-ORDER sum everywhere; a bucket above the mailbox size takes the ordinary path; no wait timed
+    out"""
+    mp.spawn(_worker_oneshot, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for k in ("WORLD_SIZE", "RANK"):
         os.environ.pop(k, None)
-    for r in range(2):
+    for r in range(world):
         z = np.load(tmp_path / f"oneshot_rank{r}.npz")
         assert int(z["bad"]) == 0 and bool(z["ok_big"]), (r, str(z["first"]))
 

@@ -34,6 +34,10 @@ def _cfg(kind, **over):
         base = dict(env="synthetic_tuple", use_rnn=False, nonlinearity="relu", normalize_input=False, obs_scale=255.0,
                     encoder_conv_architecture="convnet_atari", synthetic_num_agents=64, batch_size=256,
                     synthetic_head_sizes=(6, -2, 3))
+    elif kind == "separate_gru_box":   # actor / critic towers on one flat buffer; state rows [actor | critic]
+        base = dict(env="synthetic_ant", use_rnn=True, rnn_type="gru", rnn_size=64, nonlinearity="tanh", normalize_input=True,
+                    encoder_mlp_layers=[64, 64], recurrence=8, synthetic_num_agents=128, batch_size=512,
+                    actor_critic_share_weights=False, normalize_returns=True, adaptive_stddev=False)
     elif kind == "dict_multikey_gru":  # image + vector keys on the native towers, a torch-stepped device env (no step_into)
         base = dict(env="dict_bandit", use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=8, nonlinearity="relu",
                     normalize_input=True, normalize_input_keys=["measurements"], obs_scale=255.0,
@@ -88,7 +92,7 @@ def _same_run(a, b):
 
 
 @pytest.mark.parametrize("kind", ["conv_discrete", "conv_normalized", "mlp_lstm_box", "mlp_gru_box", "mlp_lstm2_box",
-                                  "conv_tuple_mixed", "dict_multikey_gru"])
+                                  "conv_tuple_mixed", "dict_multikey_gru", "separate_gru_box"])
 def test_replayed_rollouts_equal_the_wrapper_path(kind):
     """5 iterations (rollout + train each): first sight, recording, then replays — against the same run with programs off.
     The sampler's Philox step and the policy version travel through ctypes cells: a stale value would repeat actions /
