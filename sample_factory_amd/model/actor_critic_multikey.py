@@ -58,8 +58,6 @@ class MultiKeyActorCritic:
             self.col0[k] = F
             F += self.feat_of[k]
         self.F = F
-        if F % 4:
-            raise NotImplementedError(f"concatenated encoder width {F}: a multiple of 4 needed (16-byte rows)")
         tspace = spaces.Dict({"obs": spaces.Box(-np.inf, np.inf, (F,), np.float32)})
         self.trunk = ActorCritic(cfg, tspace, action_space, device, all_reduce=all_reduce, part="trunk")
         t = self.trunk

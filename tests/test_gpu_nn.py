@@ -1870,7 +1870,7 @@ def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tm
     assert np.isfinite(stats["train"]["loss"]) and r > first + 0.3 and r > 0.75, (first, r)
 
 
-@pytest.mark.parametrize("core", ["ff", "gru", "lstm_decoder"])
+@pytest.mark.parametrize("core", ["ff", "gru", "lstm_decoder", "ff_odd_widths", "gru_odd_widths"])
 def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
     """model/actor_critic_multikey.py against the torch construction of the same architecture (model/torch_policy.py builds
     the reference's modules: MultiInputEncoder -> core -> decoder -> heads, model/encoder.py:33-69) on the same seeded
@@ -1881,10 +1881,15 @@ def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
     from sample_factory_amd.envs import spaces
     from sample_factory_amd.model.model_factory import create_actor_critic
     kw = dict(ff=dict(use_rnn=False), gru=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4),
-              lstm_decoder=dict(use_rnn=True, rnn_type="lstm", rnn_size=32, recurrence=4, decoder_mlp_layers=[24]))[core]
+              lstm_decoder=dict(use_rnn=True, rnn_type="lstm", rnn_size=32, recurrence=4, decoder_mlp_layers=[24]),
+              # encoder widths 15 + 32 = 47 columns: no 16-byte alignment anywhere in the feature batch
+              ff_odd_widths=dict(use_rnn=False, encoder_mlp_layers=[16, 15]),
+              gru_odd_widths=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4, encoder_mlp_layers=[16, 15],
+                                  encoder_conv_mlp_layers=[33]))[core]
+    base = dict(encoder_conv_mlp_layers=[32], encoder_mlp_layers=[16, 16])
+    base.update(kw)
     cfg = default_cfg(encoder_conv_architecture="convnet_impala", nonlinearity="relu", obs_scale=255.0, obs_subtract_mean=3.0,
-                      normalize_input=True, normalize_input_keys=["measurements"], encoder_conv_mlp_layers=[32],
-                      encoder_mlp_layers=[16, 16], normalize_returns=False, **kw)
+                      normalize_input=True, normalize_input_keys=["measurements"], normalize_returns=False, **base)
     cfg.dp_world = 1
     obs_space = spaces.Dict({"obs": spaces.Box(0, 255, (4, 36, 36), np.uint8),
                              "measurements": spaces.Box(-1, 1, (5,), np.float32)})
