@@ -28,7 +28,7 @@ import torch
 
 from sample_factory_amd import lib
 from sample_factory_amd.algo.utils.running_mean_std import RunningMeanStdInPlace
-from sample_factory_amd.envs.spaces import is_box, calc_num_action_parameters, is_discrete
+from sample_factory_amd.envs.spaces import is_box, calc_num_action_parameters
 
 import os
 

@@ -16,7 +16,6 @@ action_parameterization.*); per-key normalisation rules are normalize.py:24-70's
 running statistics for the keys in cfg.normalize_input_keys)."""
 from __future__ import annotations
 
-import copy
 from typing import Dict, List
 
 import numpy as np

@@ -2,7 +2,6 @@
 recorded once and replayed with one foreign call per launch.  A replayed run must be the SAME run: every slab leaf, the
 parameters and the episode statistics bit for bit equal to a run that goes through the wrappers every step — for the data
 path of sample_factory/algo/sampling/batched_sampling.py:298-388 nothing but the host time may change."""
-import numpy as np
 import pytest
 import torch
 
