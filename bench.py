@@ -147,6 +147,7 @@ def secondary_lines(args):
             ent = {"workload": wl, "metric": d["metric"], "value": d["value"], "unit": d["unit"],
                    "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
                    "data": "synthetic", "config": d["config"]["workload"],
+                   "rollout_launch_programs": d.get("rollout_launch_programs"),
                    "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                        "traffic_source", "clock_ghz", "frac_at_measured_clock",
                                                        "avg_launch_ms", "launches", "share_of_step_time", "scope")},
@@ -695,6 +696,10 @@ def main():
                    "envs_per_gpu": B, "rollout": T, "batch_size": cfg.batch_size, "num_batches_per_epoch": args.num_batches,
                    "num_epochs": args.num_epochs, "parallelism": f"dp{world}"},
         "roofline": roofline,
+        # host side of the rollout step: the step's library calls recorded once and replayed with one foreign call per
+        # launch (lib.LaunchProgram) -- same launches, same arguments, same stream; SF_LAUNCH_PROGRAMS=0 = off
+        "rollout_launch_programs": {"enabled": bool(lib.LAUNCH_PROGRAMS),
+                                    "replayed_steps": int(sum(getattr(sm, "program_replays", 0) for sm in runner.samplers))},
         **({"collectives": collectives} if collectives else {}),
         **({"ingest": ingest} if ingest is not None else {}),
         "network_kernels": {"source": "instrumented warm-up step (every launch timed in isolation; not the timed region)",
