@@ -208,9 +208,12 @@ class ActorCritic:
         self.rnn_SL = self.rnn_S // max(1, self.rnn_L)  # state columns of ONE recurrent layer: H (GRU) or 2 H (LSTM: [h | c])
         if use_rnn and not self.layers and not self.features_in:
             raise NotImplementedError("a recurrent core needs at least one encoder layer in front of it")
-        if self.headless and (not self.layers or self.layers[-1].kind not in ("linear", "linear_after_conv")):
-            # (an image encoder without mlp layers hands the reference's core CHW-flattened features; ours are NHWC)
-            raise NotImplementedError(f"encoder of key '{obs_key}': at least one fully connected layer needed")
+        if self.headless and not self.layers:
+            raise NotImplementedError(f"encoder of key '{obs_key}': at least one layer needed")
+        # an image encoder WITHOUT fully connected layers ends in a conv layer: its output rows are [pixel][channel] (NHWC)
+        # while the reference flattens [channel][pixel] (encoder.py:117: view(-1, conv_head_out_size) of an NCHW tensor) —
+        # the composite re-orders the features when it concatenates them (out_chw = (C, OH, OW))
+        self.out_chw = chw if (self.headless and len(self.obs_shape) == 3 and self.layers[-1].kind in ("conv", "conv_u8")) else None
         if use_rnn:  # model/core.py:19-64: nn.GRU / nn.LSTM(input=feat, hidden=rnn_size), torch gate order
             Hs = cfg.rnn_size
             G = 3 if cfg.rnn_type == "gru" else 4

@@ -198,7 +198,12 @@ class MultiKeyActorCritic:
             out = e.forward_heads(v, n, sample_stride=self._stride_of(k, v, traj_T), index=index, offset=offset,
                                   traj_T=traj_T, tag=tag)[-1]
             c = self.col0[k]
-            lib.copy_rows(cat[:, c:c + e.feat], out.view(n, e.feat))
+            if e.out_chw is None:
+                lib.copy_rows(cat[:, c:c + e.feat], out.view(n, e.feat))
+            else:  # conv output [n][pixel][channel] -> the reference's [channel][pixel] feature order (a torch copy kernel)
+                C, HW = e.out_chw[0], e.out_chw[1] * e.out_chw[2]
+                lib.recording_unsafe("feature re-ordering of a conv-last encoder is a torch op")
+                cat[:, c:c + e.feat].unflatten(1, (C, HW)).copy_(out.view(n, HW, C).transpose(1, 2))
         return self.trunk.forward_heads(cat, n, sample_stride=self.F, tag=tag, rnn=rnn)
 
     def backward(self, acts, g_heads: torch.Tensor, obs, n: int, *, sample_stride: int = 0, index=None, offset: int = 0,
@@ -209,7 +214,11 @@ class MultiKeyActorCritic:
         for k in self.obs_keys:
             e, v, c = self.encoders[k], obs[k], self.col0[k]
             g = e._buf(("g", "out"), (n, e.feat))
-            lib.copy_rows(g, gin[:, c:c + e.feat])
+            if e.out_chw is None:
+                lib.copy_rows(g, gin[:, c:c + e.feat])
+            else:
+                C, HW = e.out_chw[0], e.out_chw[1] * e.out_chw[2]
+                g.view(n, HW, C).copy_(gin[:, c:c + e.feat].unflatten(1, (C, HW)).transpose(1, 2))
             e.backward(None, g, v, n, sample_stride=self._stride_of(k, v, traj_T), index=index, offset=offset, traj_T=traj_T)
 
     def new_rnn_parts_of(self, tag: str = "inf"):

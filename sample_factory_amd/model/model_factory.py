@@ -75,8 +75,7 @@ def create_actor_critic(cfg, obs_space, action_space, device, all_reduce=None):
             and torch.device(device).type == "cuda" and os.environ.get("SF_NATIVE_MULTIKEY", "1") != "0"):
         # observation dicts of several keys (model/encoder.py:33-69, MultiInputEncoder: one encoder per key, concatenated) on
         # the native kernels since round 6: one encoder tower per key + a trunk on one flat parameter buffer
-        # (model/actor_critic_multikey.py).  A shape the towers do not take (an image encoder without a fully connected
-        # layer) keeps the torch path below.
+        # (model/actor_critic_multikey.py).  A shape the towers refuse keeps the torch path below.
         from sample_factory_amd.model.actor_critic_multikey import MultiKeyActorCritic
         try:
             return MultiKeyActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)

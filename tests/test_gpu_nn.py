@@ -1870,7 +1870,7 @@ def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tm
     assert np.isfinite(stats["train"]["loss"]) and r > first + 0.3 and r > 0.75, (first, r)
 
 
-@pytest.mark.parametrize("core", ["ff", "gru", "lstm_decoder", "ff_odd_widths", "gru_odd_widths"])
+@pytest.mark.parametrize("core", ["ff", "gru", "lstm_decoder", "ff_odd_widths", "gru_odd_widths", "ff_conv_last", "gru_conv_last"])
 def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
     """model/actor_critic_multikey.py against the torch construction of the same architecture (model/torch_policy.py builds
     the reference's modules: MultiInputEncoder -> core -> decoder -> heads, model/encoder.py:33-69) on the same seeded
@@ -1885,9 +1885,12 @@ def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
               # encoder widths 15 + 32 = 47 columns: no 16-byte alignment anywhere in the feature batch
               ff_odd_widths=dict(use_rnn=False, encoder_mlp_layers=[16, 15]),
               gru_odd_widths=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4, encoder_mlp_layers=[16, 15],
-                                  encoder_conv_mlp_layers=[33]))[core]
+                                  encoder_conv_mlp_layers=[33])).get(core)
+    # an image encoder WITHOUT fully connected layers: the 32 x 3 x 3 conv output is concatenated in the reference's CHW order
+    kw_more = dict(ff_conv_last=dict(use_rnn=False, encoder_conv_mlp_layers=[]),
+                   gru_conv_last=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4, encoder_conv_mlp_layers=[]))
     base = dict(encoder_conv_mlp_layers=[32], encoder_mlp_layers=[16, 16])
-    base.update(kw)
+    base.update(kw if kw is not None else kw_more[core])
     cfg = default_cfg(encoder_conv_architecture="convnet_impala", nonlinearity="relu", obs_scale=255.0, obs_subtract_mean=3.0,
                       normalize_input=True, normalize_input_keys=["measurements"], normalize_returns=False, **base)
     cfg.dp_world = 1
