@@ -318,6 +318,29 @@ class ActorCritic:
         """every layer but the fused heads (an encoder tower has none)"""
         return self.layers if self.headless else self.layers[:-1]
 
+    # ---- what a composite (model/actor_critic_separate.py) needs from a tower, whatever the tower is made of
+    @property
+    def heads_layer(self):
+        return self.layers[-1]
+
+    def share_normalizers_from(self, other) -> None:
+        """input / return normalisers belong to the MODEL (actor_critic.py:44-61): a second tower uses the first one's"""
+        self.obs_normalizer = other.obs_normalizer
+        self.returns_normalizer = None
+
+    def share_seq_sync_from(self, other) -> None:
+        self._bufs[("rnn", "seq_sync")] = other._seq_sync_buf()
+
+    def share_snapshot_tables_from(self, other) -> None:
+        self._snap_tabs = other._snap_tabs
+
+    def normalizer_state(self) -> Dict[str, torch.Tensor]:
+        return self.obs_normalizer.state_dict(self._norm_prefix) if self.obs_normalizer is not None else {}
+
+    def load_normalizer_state(self, sd) -> None:
+        if self.obs_normalizer is not None and self._norm_prefix + "count" in sd:
+            self.obs_normalizer.load_state_dict(sd, self._norm_prefix)
+
     def train(self, mode=True):
         self.training = mode
         if self.returns_normalizer is not None:

@@ -141,6 +141,39 @@ class MultiKeyActorCritic:
             raise NotImplementedError("Lamb with more than 64 parameter tensors")
         return torch.cat(segs), base
 
+    # ---- the tower protocol of model/actor_critic_separate.py (this model as the actor's / the critic's tower)
+    def seat_flat(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, flat_params_t: torch.Tensor) -> None:
+        for tw, o in zip(self.towers, self._base):  # (every tower carries its current values over)
+            tw.seat_flat(flat_params[o:o + tw.num_flat], flat_grads[o:o + tw.num_flat], flat_params_t[o:o + tw.num_flat])
+        self.flat_params, self.flat_grads, self.flat_params_t = flat_params, flat_grads, flat_params_t
+
+    @property
+    def heads_layer(self):
+        return self.trunk.layers[-1]
+
+    def share_normalizers_from(self, other) -> None:
+        for k, e in self.encoders.items():
+            e.obs_normalizer = other.encoders[k].obs_normalizer
+        self.obs_normalizer = other.obs_normalizer
+        self.trunk.returns_normalizer = self.returns_normalizer = None
+
+    def share_seq_sync_from(self, other) -> None:
+        self.trunk.share_seq_sync_from(other.trunk)
+
+    def _seq_sync_buf(self):
+        return self.trunk._seq_sync_buf()
+
+    def share_snapshot_tables_from(self, other) -> None:
+        for k, e in self.encoders.items():
+            e._snap_tabs = other.encoders[k]._snap_tabs
+
+    def normalizer_state(self) -> Dict[str, torch.Tensor]:
+        return {k: v for e in self.encoders.values() for k, v in e.normalizer_state().items()}
+
+    def load_normalizer_state(self, sd) -> None:
+        for e in self.encoders.values():
+            e.load_normalizer_state(sd)
+
     # ------------------------------------------------------------------------------------------ compute plumbing
     def params_changed(self) -> None:
         for tw in self.towers:

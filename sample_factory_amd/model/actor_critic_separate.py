@@ -29,10 +29,16 @@ class SeparateActorCritic:
         self.cfg = cfg
         tcfg = copy.copy(cfg)
         tcfg.actor_critic_share_weights = True  # a tower is the shared-weights architecture
-        self.actor = ActorCritic(tcfg, obs_space, action_space, device, all_reduce=all_reduce)
-        self.critic = ActorCritic(tcfg, obs_space, action_space, device, all_reduce=all_reduce)
+        keys = [k for k in obs_space.spaces.keys() if k != "action_mask"]
+        if len(keys) > 1:  # observation dicts with several keys: each tower is the multi-key composite (encoder towers + trunk)
+            from sample_factory_amd.model.actor_critic_multikey import MultiKeyActorCritic as Tower
+        else:
+            Tower = ActorCritic
+        self.actor = Tower(tcfg, obs_space, action_space, device, all_reduce=all_reduce)
+        self.critic = Tower(tcfg, obs_space, action_space, device, all_reduce=all_reduce)
         self.towers = (self.actor, self.critic)
         a, c = self.towers
+        self.multi_key, self.obs_keys = bool(getattr(a, "multi_key", False)), list(getattr(a, "obs_keys", ["obs"]))
         self.device, self.obs_space, self.action_space = a.device, obs_space, action_space
         self.obs_shape, self.obs_elems, self.obs_u8 = a.obs_shape, a.obs_elems, a.obs_u8
         self.num_action_params, self.heads_ld = a.num_action_params, a.heads_ld
@@ -50,11 +56,10 @@ class SeparateActorCritic:
         c.seat_flat(self.flat_params[na:], self.flat_grads[na:], self.flat_params_t[na:])
         # ---- shared: input / return normalisers (actor_critic.py:44-61: they belong to the model, not to a tower), the
         # fused sequence passes' sync words (one sticky abort word for the optimiser's skip flag)
-        c.obs_normalizer = a.obs_normalizer
-        c.returns_normalizer = None
+        c.share_normalizers_from(a)
         self.obs_normalizer, self.returns_normalizer = a.obs_normalizer, a.returns_normalizer
         if self.rnn_kind is not None:
-            c._bufs[("rnn", "seq_sync")] = a._seq_sync_buf()
+            c.share_seq_sync_from(a)
         self._snap = None
         self._zero_foreign_columns()
 
@@ -62,7 +67,7 @@ class SeparateActorCritic:
     def _zero_foreign_columns(self) -> None:
         """the value column of the actor's heads and the action columns of the critic's: not parameters of the model"""
         with torch.no_grad():
-            Ha, Hc = self.actor.layers[-1], self.critic.layers[-1]
+            Ha, Hc = self.actor.heads_layer, self.critic.heads_layer
             Ha.w[:, 0].zero_()
             Ha.b[0].zero_()
             Hc.w[:, 1:].zero_()
@@ -121,9 +126,7 @@ class SeparateActorCritic:
         return out
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
-        sd = {}
-        if self.obs_normalizer is not None:
-            sd.update(self.obs_normalizer.state_dict())
+        sd = dict(self.actor.normalizer_state())
         if self.returns_normalizer is not None:
             sd.update(self.returns_normalizer.state_dict("returns_normalizer."))
         parts = {who: self._split_sd(t.state_dict(), who) for who, t in (("actor", self.actor), ("critic", self.critic))}
@@ -145,8 +148,7 @@ class SeparateActorCritic:
                 del own[k]
             t.load_state_dict(own, strict=False)
         self._zero_foreign_columns()
-        if self.obs_normalizer is not None and "obs_normalizer.running_mean_std.running_mean_std.obs.count" in sd:
-            self.obs_normalizer.load_state_dict(sd)
+        self.actor.load_normalizer_state(sd)
         if self.returns_normalizer is not None and "returns_normalizer.running_mean" in sd:
             self.returns_normalizer.load_state_dict(sd, "returns_normalizer.")
         elif strict and self.returns_normalizer is not None:
@@ -200,14 +202,13 @@ class SeparateActorCritic:
     def enable_weight_snapshots(self) -> None:
         for t in self.towers:
             t.enable_weight_snapshots()
-        self.critic._snap_tabs = self.actor._snap_tabs  # one normaliser, one pair of published tables
+        self.critic.share_snapshot_tables_from(self.actor)  # one normaliser (per key), one pair of published tables
         self._snap = True
 
     def publish_weights(self, slot: int) -> None:
+        # (the shared normalisation tables are copied by both calls: the same few KB twice, stream-ordered)
         self.actor.publish_weights(slot)
-        tabs, self.critic._snap_tabs = self.critic._snap_tabs, None  # (already copied by the actor's call)
         self.critic.publish_weights(slot)
-        self.critic._snap_tabs = tabs
 
     def rnn_abort_word(self):
         return self.actor.rnn_abort_word()
@@ -268,10 +269,14 @@ class SeparateActorCritic:
         return self.new_rnn_states_of("inf")
 
     def forward(self, normalized_obs_dict, rnn_states=None, values_only: bool = False, action_mask=None):
-        obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
-        B = obs.shape[0]
+        if self.multi_key:
+            obs = {k: normalized_obs_dict[k].contiguous() for k in self.obs_keys}
+            B, stride = obs[self.obs_keys[0]].shape[0], 0
+        else:
+            obs = normalized_obs_dict["obs"] if isinstance(normalized_obs_dict, dict) else normalized_obs_dict
+            B, stride = obs.shape[0], (self.obs_elems if obs.is_contiguous() else obs.stride(0))
         rnn = dict(states=rnn_states) if self.rnn_kind is not None else None
-        heads = self.forward_heads(obs, B, sample_stride=self.obs_elems if obs.is_contiguous() else obs.stride(0), rnn=rnn)[-1]
+        heads = self.forward_heads(obs, B, sample_stride=stride, rnn=rnn)[-1]
         res = dict(values=heads[:, 0])
         if not values_only:
             res["action_logits"] = heads[:, 1:1 + self.num_action_params]

@@ -65,8 +65,10 @@ def create_actor_critic(cfg, obs_space, action_space, device, all_reduce=None):
         from sample_factory_amd.model.actor_critic import ActorCritic
         return ActorCritic(cfg, obs_space, action_space, device, all_reduce=all_reduce)
     import torch
-    if (f.is_default() and len(obs_keys_of(obs_space)) <= 1 and not stacked_rnn and separate
-            and torch.device(device).type == "cuda" and os.environ.get("SF_NATIVE_SEPARATE_WEIGHTS", "1") != "0"):
+    multi = len(obs_keys_of(obs_space)) > 1
+    if (f.is_default() and not stacked_rnn and separate and torch.device(device).type == "cuda"
+            and os.environ.get("SF_NATIVE_SEPARATE_WEIGHTS", "1") != "0"
+            and (not multi or os.environ.get("SF_NATIVE_MULTIKEY", "1") != "0")):
         # cfg.actor_critic_share_weights=False (ActorCriticSeparateWeights, model/actor_critic.py:198-334) on the native
         # kernels since round 6: two towers on one flat parameter buffer (model/actor_critic_separate.py)
         from sample_factory_amd.model.actor_critic_separate import SeparateActorCritic

@@ -42,6 +42,11 @@ def _cfg(kind, **over):
                     normalize_input=True, normalize_input_keys=["measurements"], obs_scale=255.0,
                     encoder_conv_architecture="convnet_impala", encoder_conv_mlp_layers=[32], encoder_mlp_layers=[32],
                     synthetic_num_agents=64, batch_size=256, normalize_returns=False)
+    elif kind == "dict_multikey_separate":  # separate actor / critic weights x several keys: towers of towers
+        base = dict(env="dict_bandit", use_rnn=True, rnn_type="lstm", rnn_size=32, recurrence=8, nonlinearity="relu",
+                    normalize_input=True, normalize_input_keys=["measurements"], obs_scale=255.0,
+                    encoder_conv_architecture="convnet_impala", encoder_conv_mlp_layers=[32], encoder_mlp_layers=[32],
+                    synthetic_num_agents=64, batch_size=256, normalize_returns=True, actor_critic_share_weights=False)
     else:
         raise KeyError(kind)
     base.update(common)
@@ -91,7 +96,8 @@ def _same_run(a, b):
 
 
 @pytest.mark.parametrize("kind", ["conv_discrete", "conv_normalized", "mlp_lstm_box", "mlp_gru_box", "mlp_lstm2_box",
-                                  "conv_tuple_mixed", "dict_multikey_gru", "separate_gru_box"])
+                                  "conv_tuple_mixed", "dict_multikey_gru", "separate_gru_box",
+                                  "dict_multikey_separate"])
 def test_replayed_rollouts_equal_the_wrapper_path(kind):
     """5 iterations (rollout + train each): first sight, recording, then replays — against the same run with programs off.
     The sampler's Philox step and the policy version travel through ctypes cells: a stale value would repeat actions /

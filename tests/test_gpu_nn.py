@@ -1870,7 +1870,8 @@ def test_multi_key_observations_with_recurrent_core_rollout_and_training(lib, tm
     assert np.isfinite(stats["train"]["loss"]) and r > first + 0.3 and r > 0.75, (first, r)
 
 
-@pytest.mark.parametrize("core", ["ff", "gru", "lstm_decoder", "ff_odd_widths", "gru_odd_widths", "ff_conv_last", "gru_conv_last"])
+@pytest.mark.parametrize("core", ["ff", "gru", "lstm_decoder", "ff_odd_widths", "gru_odd_widths", "ff_conv_last", "gru_conv_last",
+                                  "separate_ff", "separate_gru"])
 def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
     """model/actor_critic_multikey.py against the torch construction of the same architecture (model/torch_policy.py builds
     the reference's modules: MultiInputEncoder -> core -> decoder -> heads, model/encoder.py:33-69) on the same seeded
@@ -1888,7 +1889,11 @@ def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
                                   encoder_conv_mlp_layers=[33])).get(core)
     # an image encoder WITHOUT fully connected layers: the 32 x 3 x 3 conv output is concatenated in the reference's CHW order
     kw_more = dict(ff_conv_last=dict(use_rnn=False, encoder_conv_mlp_layers=[]),
-                   gru_conv_last=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4, encoder_conv_mlp_layers=[]))
+                   gru_conv_last=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4, encoder_conv_mlp_layers=[]),
+                   # separate actor / critic weights x several keys: each tower of model/actor_critic_separate.py is the multi-key
+                   # composite (actor_encoder.encoders.<key>.*, critic_encoder.encoders.<key>.*, ...)
+                   separate_ff=dict(use_rnn=False, actor_critic_share_weights=False),
+                   separate_gru=dict(use_rnn=True, rnn_type="gru", rnn_size=32, recurrence=4, actor_critic_share_weights=False))
     base = dict(encoder_conv_mlp_layers=[32], encoder_mlp_layers=[16, 16])
     base.update(kw if kw is not None else kw_more[core])
     cfg = default_cfg(encoder_conv_architecture="convnet_impala", nonlinearity="relu", obs_scale=255.0, obs_subtract_mean=3.0,
@@ -1901,7 +1906,8 @@ def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
         monkeypatch.setenv("SF_NATIVE_MULTIKEY", "1" if native else "0")
         models[native] = create_actor_critic(cfg, obs_space, spaces.Discrete(6), torch.device("cuda"))
     nat, ref = models[True], models[False]
-    assert type(nat).__name__ == "MultiKeyActorCritic" and type(ref).__name__ == "TorchPolicyAdapter"
+    assert type(nat).__name__ == ("SeparateActorCritic" if core.startswith("separate") else "MultiKeyActorCritic")
+    assert type(ref).__name__ == "TorchPolicyAdapter" and nat.multi_key and nat.obs_keys == ["measurements", "obs"]
     shapes = ref.ref_param_shapes()
     assert [(n, tuple(s)) for n, s in nat.ref_param_shapes()] == [(n, tuple(s)) for n, s in shapes]
     st = seeded_state([(n, tuple(s)) for n, s in shapes], 21)
@@ -1954,6 +1960,48 @@ def test_native_multi_key_towers_against_the_torch_path(lib, monkeypatch, core):
         scale = max(1e-6, float(np.abs(b).max()))
         assert np.abs(a - b).max() <= 2e-4 * scale + 1e-7, (name, float(np.abs(a - b).max()), scale)
         assert np.abs(b).max() > 0, f"{name}: the torch path's gradient is zero — the check would be vacuous"
+
+
+def test_separate_weights_with_several_keys_end_to_end(lib, tmp_path):
+    """cfg.actor_critic_share_weights=False on an image + vector observation dict: SeparateActorCritic whose two towers are
+    multi-key composites (reference: ActorCriticSeparateWeights with a MultiInputEncoder per tower, model/actor_critic.py:198-334
+    + model/encoder.py:33-69) — learns the vector-key bandit, names are the reference's, the checkpoint round-trips"""
+    from sample_factory_amd.cfg.arguments import default_cfg
+    from sample_factory_amd.envs.env_utils import register_env
+    from sample_factory_amd.envs.synthetic import make_dict_obs_bandit_env
+    from sample_factory_amd.train import make_runner
+    register_env("dict_bandit_sep", make_dict_obs_bandit_env)
+    cfg = default_cfg(env="dict_bandit_sep", use_rnn=False, nonlinearity="relu", normalize_input=True,
+                      normalize_input_keys=["measurements"], obs_scale=255.0, encoder_conv_architecture="convnet_impala",
+                      encoder_conv_mlp_layers=[32], encoder_mlp_layers=[32], rollout=8, batch_size=256,
+                      num_batches_per_epoch=2, num_epochs=2, num_workers=1, num_envs_per_worker=1, async_rl=False, seed=4,
+                      serial_mode=True, synthetic_num_agents=64, learning_rate=3e-3, gamma=0.0, normalize_returns=False,
+                      actor_critic_share_weights=False, train_dir=str(tmp_path), experiment="dict_sep")
+    cfg, runner = make_runner(cfg)
+    runner.init()
+    ac = runner.learner.actor_critic
+    assert type(ac).__name__ == "SeparateActorCritic" and type(ac.actor).__name__ == "MultiKeyActorCritic" and ac.multi_key
+    names = [n for n, _ in ac.ref_param_shapes()]
+    for n in ("actor_encoder.encoders.measurements.mlp_head.0.weight", "critic_encoder.encoders.obs.enc.conv_head.0.weight",
+              "critic_encoder.encoders.obs.enc.mlp_layers.0.bias", "critic_linear.weight",
+              "action_parameterization.distribution_linear.weight"):
+        assert n in names, n
+    first = None
+    for _ in range(30):
+        runner.iteration()
+        r = float(runner.traj["rewards"].mean())
+        first = r if first is None else first
+    assert r > first + 0.3 and r > 0.75, (first, r)
+    sd = ac.state_dict()
+    assert "obs_normalizer.running_mean_std.running_mean_std.measurements.running_mean" in sd
+    assert "obs_normalizer.running_mean_std.running_mean_std.obs.running_mean" not in sd
+    runner.learner.save()
+    cfg2, runner2 = make_runner(cfg)
+    runner2.init()
+    assert torch.equal(runner2.learner.actor_critic.flat_params, ac.flat_params)
+    ns2 = runner2.learner.actor_critic.state_dict()
+    k_ = "obs_normalizer.running_mean_std.running_mean_std.measurements.count"
+    assert float(ns2[k_]) == float(sd[k_]) > 64 * 9
 
 
 def test_native_multi_key_towers_in_async_mode(lib, tmp_path):
